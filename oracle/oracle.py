@@ -1,0 +1,237 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY (numpy/ctypes face of oracle/nnest_oracle.c).
+
+Importable by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only; the product
+package nnest_amd/ never imports it.  Parity status: PINNED (tests/test_oracle_golden.py checks
+every function below against fixtures produced by running the reference, tests/golden/).
+Each method names the reference function it restates (paths under /root/reference).
+"""
+import os
+import ctypes
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, '_build', 'libnnest_oracle.so')
+
+LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'mixture': 1, 'gaussianmix': 1, 'himmelblau': 2}
+
+
+def build(force=False):
+    """Compile the C restatement (gcc; seconds)."""
+    src = [os.path.join(_HERE, f) for f in ('nnest_oracle.c', 'nnest_oracle_impl.h', 'Makefile')]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(['make', '-C', _HERE, '--no-print-directory'], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+_fp = ctypes.POINTER(ctypes.c_float)
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        L.orc_num_params.restype = ctypes.c_int
+        for name in ('orc_loglike_f32', 'orc_loglike_f64', 'orc_train_step', 'orc_loss_grad_f64',
+                     'orc_valid_loss', 'orc_training_jitter', 'orc32_nvp_loss_grad', 'orc64_nvp_loss_grad'):
+            getattr(L, name).restype = ctypes.c_double
+        L.orc_mcmc_sample.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def num_params(D, H, B, L):
+    return lib().orc_num_params(D, H, B, L)
+
+
+class NVP(object):
+    """RealNVP coupling stack with packed (state_dict-order) fp32 weights.
+
+    Restates SingleSpeedNVP / NormalizingFlowModel (nnest/networks.py:17-84, :248-347)."""
+
+    def __init__(self, D, H=16, B=3, L=1, weights=None):
+        self.D, self.H, self.B, self.L = int(D), int(H), int(B), int(L)
+        self.n = num_params(D, H, B, L)
+        self.w = np.zeros(self.n, np.float32) if weights is None else _f32(weights).copy()
+        assert self.w.size == self.n, (self.w.size, self.n)
+        self.m = np.zeros(self.n, np.float32)  # Adam exp_avg
+        self.v = np.zeros(self.n, np.float32)  # Adam exp_avg_sq
+        self.t = 0                             # Adam step count
+
+    def _cfg(self):
+        return (_p(self.w, _fp), self.D, self.H, self.B, self.L)
+
+    def _run(self, fn32, fn64, x, f64, two_out=True):
+        x = np.atleast_2d(x)
+        N = x.shape[0]
+        if f64:
+            xi = _f64(x); o = np.empty((N, self.D)); ld = np.empty(N); t = _dp
+            fn = fn64
+        else:
+            xi = _f32(x); o = np.empty((N, self.D), np.float32); ld = np.empty(N, np.float32); t = _fp
+            fn = fn32
+        fn(*self._cfg(), _p(xi, t), N, _p(o, t), _p(ld, t))
+        return o, ld
+
+    def forward(self, x, f64=False):
+        """NormalizingFlow.forward (networks.py:24-32) -> (z, logdet)"""
+        return self._run(lib().orc32_nvp_forward, lib().orc64_nvp_forward, x, f64)
+
+    def inverse(self, z, f64=False):
+        """NormalizingFlow.inverse (networks.py:34-42) -> (x, logdet)"""
+        return self._run(lib().orc32_nvp_inverse, lib().orc64_nvp_inverse, z, f64)
+
+    def log_probs(self, x, f64=False):
+        """NormalizingFlowModel.log_probs (networks.py:71-76)"""
+        x = np.atleast_2d(x)
+        N = x.shape[0]
+        if f64:
+            xi = _f64(x); o = np.empty(N)
+            lib().orc64_nvp_log_probs(*self._cfg(), _p(xi, _dp), N, _p(o, _dp))
+        else:
+            xi = _f32(x); o = np.empty(N, np.float32)
+            lib().orc32_nvp_log_probs(*self._cfg(), _p(xi, _fp), N, _p(o, _fp))
+        return o
+
+    def loss_grad(self, X, f64=False):
+        """loss = -mean(log_probs(X)) and its gradient wrt the packed weights (trainer.py:394, :400)"""
+        X = _f32(X)
+        M = X.shape[0]
+        if f64:
+            g = np.empty(self.n)
+            loss = lib().orc_loss_grad_f64(*self._cfg(), _p(X, _fp), M, _p(g, _dp))
+        else:
+            g = np.empty(self.n, np.float32)
+            loss = lib().orc32_nvp_loss_grad(*self._cfg(), _p(X, _fp), M, _p(g, _fp))
+        return loss, g
+
+    def train_step(self, X, idx, noise, jitter, lr=1e-3, wd=1e-6):
+        """One minibatch of Trainer._train (trainer.py:390-401) + Adam (trainer.py:121-122)."""
+        X = _f32(X)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        M = idx.size
+        nz = None if noise is None else _f32(noise)
+        g = np.empty(self.n, np.float32)
+        self.t += 1
+        loss = lib().orc_train_step(_p(self.w, _fp), _p(self.m, _fp), _p(self.v, _fp), self.D, self.H, self.B,
+                                    self.L, _p(X, _fp), _p(idx, _ip), None if nz is None else _p(nz, _fp), M,
+                                    ctypes.c_float(jitter), self.t, ctypes.c_float(lr), ctypes.c_float(wd),
+                                    _p(g, _fp))
+        return loss, g
+
+    def valid_loss(self, X):
+        """Trainer._validate's batch loss before the /len(dataset) (trainer.py:405-418)"""
+        X = _f32(X)
+        return lib().orc_valid_loss(*self._cfg(), _p(X, _fp), X.shape[0])
+
+    def train_epoch(self, X, perm, noise, jitter, batch=100, lr=1e-3, wd=1e-6):
+        """Trainer._train (trainer.py:384-403): returns sum(batch means)/len(dataset) like the reference."""
+        n = X.shape[0]
+        tot = 0.0
+        for b in range(0, n, batch):
+            idx = perm[b:b + batch]
+            nz = None if noise is None else noise[b:b + batch]
+            loss, _ = self.train_step(X, idx, nz, jitter, lr, wd)
+            tot += loss
+        return tot / n
+
+    def train(self, samples, perm_split, perms, noises, jitter, max_iters, patience=50, batch=100, lr=1e-3,
+              wd=1e-6, validation_fraction=0.1):
+        """Trainer.train (trainer.py:134-245) with the split / shuffles / jitter noise supplied."""
+        N = samples.shape[0]
+        n_valid = int(np.ceil(validation_fraction * N))
+        n_train = N - n_valid
+        Xv = _f32(samples[perm_split[:n_valid]])
+        Xt = _f32(samples[perm_split[n_valid:n_valid + n_train]])
+        best, best_epoch, best_w, counter = float('inf'), 0, self.w.copy(), 0
+        tl, vl = [], []
+        for epoch in range(1, max_iters + 1):
+            tl.append(self.train_epoch(Xt, perms[epoch - 1], None if noises is None else noises[epoch - 1],
+                                       jitter, batch, lr, wd))
+            v = self.valid_loss(Xv) / n_valid
+            vl.append(v)
+            if v < best:
+                best, best_epoch, best_w, counter = v, epoch, self.w.copy(), 0
+            counter += 1
+            if counter > patience:
+                break
+        self.w = best_w
+        return dict(train_losses=np.array(tl), valid_losses=np.array(vl), best_validation_loss=best,
+                    best_validation_epoch=best_epoch, epochs_run=len(tl))
+
+
+def loglike(name, x_unit, scale):
+    """safe_loglike(x) = loglike(transform(x)) (nnest/sampler.py:110-133; nnest/likelihoods.py).
+    float32 input follows the reference's float32 arithmetic, float64 input its float64 arithmetic."""
+    lid = LIKE_IDS[name.lower()]
+    x = np.atleast_2d(x_unit)
+    N, D = x.shape
+    out = np.empty(N)
+    if x.dtype == np.float32:
+        xi = _f32(x)
+        lib().orc_loglike_batch_f32(lid, _p(xi, _fp), N, D, ctypes.c_float(scale), _p(out, _dp))
+    else:
+        xi = _f64(x)
+        lib().orc_loglike_batch_f64(lid, _p(xi, _dp), N, D, ctypes.c_double(scale), _p(out, _dp))
+    return out
+
+
+def prior_inbox(x):
+    """UniformPrior(D,-1,1) via safe_prior (nnest/priors.py:39-43, nnest/sampler.py:152-161): 0 / -inf"""
+    x = np.atleast_2d(x)
+    if x.dtype == np.float32:
+        xi = _f32(x)
+        flag = [lib().orc_prior_inbox_f32(_p(xi[i], _fp), x.shape[1]) for i in range(x.shape[0])]
+    else:
+        xi = _f64(x)
+        flag = [lib().orc_prior_inbox_f64(_p(xi[i], _dp), x.shape[1]) for i in range(x.shape[0])]
+    return np.where(np.array(flag) == 1, 0.0, -np.inf)
+
+
+def mcmc_sample(nvp, like, like_scale, init, init_logl, loglstar, step, dynamic, dz, u):
+    """Sampler._mcmc_sample hard-constraint branch (nnest/sampler.py:229-463) with recorded noise.
+    Returns the reference's tuple pieces: samples, latent, loglikes, scale, ncall, (acc, rej)."""
+    S, C, D = dz.shape
+    init = _f64(init); init_logl = _f64(init_logl); dz = _f32(dz); u = _f32(u)
+    samples = np.empty((C, S + 1, D), np.float32)
+    latent = np.empty((C, S + 1, D), np.float32)
+    loglikes = np.empty((C, S + 1))
+    scale = ctypes.c_double(step)
+    acc = ctypes.c_long(0); rej = ctypes.c_long(0)
+    ncall = lib().orc_mcmc_sample(_p(nvp.w, _fp), nvp.D, nvp.H, nvp.B, nvp.L, LIKE_IDS[like.lower()],
+                                  ctypes.c_float(like_scale), _p(init, _dp), _p(init_logl, _dp), C, S,
+                                  ctypes.c_double(loglstar), ctypes.byref(scale), int(bool(dynamic)), _p(dz, _fp),
+                                  _p(u, _fp), _p(samples, _fp), _p(latent, _fp), _p(loglikes, _dp),
+                                  ctypes.byref(acc), ctypes.byref(rej))
+    return samples, latent, loglikes, scale.value, ncall, (acc.value, rej.value)
+
+
+def training_jitter(samples):
+    """trainer.py:168-171 with jitter < 0: 0.2 * mean(cKDTree(samples).query(samples, 2) distances)"""
+    X = _f64(samples)
+    return lib().orc_training_jitter(_p(X, _dp), X.shape[0], X.shape[1])
+
+
+def philox4x32_10(ctr, key):
+    c = (ctypes.c_uint32 * 4)(*[int(v) & 0xffffffff for v in ctr])
+    k = (ctypes.c_uint32 * 2)(*[int(v) & 0xffffffff for v in key])
+    o = (ctypes.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return [int(v) for v in o]

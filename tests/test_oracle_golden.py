@@ -1,0 +1,179 @@
+"""Pin the oracle (oracle/nnest_oracle.c) against fixtures produced by RUNNING the reference
+(oracle/gen_golden.py).  CPU only.  Tolerances are stated per check; the reference's own bound for
+this path is 1e-5 on round trips of O(1) values (tests/test_flows.py:8, :27-30)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+FLOW_FILES = sorted(glob.glob(os.path.join(G, 'flow_*.npz')))
+
+
+def rel(a, b):
+    return np.max(np.abs(a - b) / (1.0 + np.abs(b)))
+
+
+@pytest.mark.parametrize('path', FLOW_FILES, ids=[os.path.basename(p)[5:-4] for p in FLOW_FILES])
+def test_flow_forward_inverse_logprob(path):
+    g = np.load(path)
+    D, H, B, L = int(g['D']), int(g['H']), int(g['B']), int(g['L'])
+    x = g['x']
+    for tag in ('init', 'trained'):
+        nvp = orc.NVP(D, H, B, L, g['w_' + tag])
+        z, ldf = nvp.forward(x)
+        # fp32 vs torch's fp32 (different summation order inside nn.Linear): 1e-5 relative-to-(1+|v|)
+        assert rel(z, g['z_' + tag]) < 1e-5
+        assert rel(ldf, g['ldf_' + tag]) < 1e-5
+        xb, ldi = nvp.inverse(g['z_' + tag])
+        assert rel(xb, g['xb_' + tag]) < 1e-5
+        assert rel(ldi, g['ldi_' + tag]) < 1e-5
+        lp = nvp.log_probs(x)
+        assert rel(lp, g['lp_' + tag]) < 2e-5
+        # fp64 yardstick agrees too, and round-trips like tests/test_flows.py:27-30
+        z64, ld64 = nvp.forward(x, f64=True)
+        assert rel(z64, g['z_' + tag]) < 1e-5
+        xb64, ldi64 = nvp.inverse(z64, f64=True)
+        assert np.max(np.abs(xb64 - x)) < 1e-10
+        assert np.max(np.abs(ld64 + ldi64)) < 1e-10
+        xb32, ldi32 = nvp.inverse(z)
+        assert np.abs(np.max(xb32 - x.astype(np.float32))) <= 1e-5
+        assert np.abs(np.max(ldi32 + ldf)) <= 1e-5
+
+
+def test_likelihoods():
+    g = np.load(os.path.join(G, 'like.npz'))
+    keys = sorted(set(k[:-4] for k in g.files if k.endswith('_x64')))
+    assert len(keys) == 7
+    for key in keys:
+        name = key.split('_d')[0]
+        x64 = g[key + '_x64']
+        scale = float(g[key + '_scale'])
+        l64 = orc.loglike(name, x64, scale)
+        np.testing.assert_allclose(l64, g[key + '_l64'], rtol=1e-13, atol=1e-12)
+        l32 = orc.loglike(name, x64.astype(np.float32), scale)
+        if name == 'gaussmix':
+            # float32 sum of squares then float64 tail (numpy 2 promotion): exact order restated
+            np.testing.assert_allclose(l32, g[key + '_l32'], rtol=1e-13, atol=1e-12)
+        else:
+            # float32 elementwise ops + sequential float32 Python sum(): bit-exact
+            assert np.array_equal(l32.astype(np.float32), g[key + '_l32'].astype(np.float32)), key
+
+
+def test_prior_box():
+    g = np.load(os.path.join(G, 'prior.npz'))
+    assert np.array_equal(orc.prior_inbox(g['x']), g['flag64'])
+    assert np.array_equal(orc.prior_inbox(g['x'].astype(np.float32)), g['flag32'])
+
+
+TRAIN_FILES = sorted(glob.glob(os.path.join(G, 'train_*.npz')))
+
+
+@pytest.mark.parametrize('path', TRAIN_FILES, ids=[os.path.basename(p)[6:-4] for p in TRAIN_FILES])
+def test_train_steps(path):
+    g = np.load(path)
+    D, H, B, L = int(g['D']), int(g['H']), int(g['B']), int(g['L'])
+    nvp = orc.NVP(D, H, B, L, g['w0'])
+    X, batch, jitter = g['X'], int(g['batch']), float(g['jitter'])
+    n = X.shape[0]
+    k = 0
+    for e in range(g['perms'].shape[0]):
+        for b in range(0, n, batch):
+            idx = g['perms'][e][b:b + batch]
+            # pin the step to the reference trajectory: start every step from the reference's state
+            if k > 0:
+                nvp.w[:] = g['ws'][k - 1]; nvp.m[:] = g['ms'][k - 1]; nvp.v[:] = g['vs'][k - 1]
+            loss, grad = nvp.train_step(X, idx, g['noises'][e][b:b + batch], jitter, float(g['lr']),
+                                        float(g['weight_decay']))
+            assert abs(loss - g['losses'][k]) < 2e-5 * (1 + abs(g['losses'][k]))
+            gref = g['grads'][k]
+            # gradients: fp32 accumulation-order noise, relative to the gradient's scale
+            assert np.max(np.abs(grad - gref)) < 2e-5 * (1e-3 + np.max(np.abs(gref)))
+            # Adam moments
+            assert np.max(np.abs(nvp.m - g['ms'][k])) < 2e-6 * (1e-3 + np.max(np.abs(g['ms'][k])))
+            assert np.max(np.abs(nvp.v - g["vs"][k])) < 5e-5 * (1e-6 + np.max(np.abs(g["vs"][k])))  # v ~ g^2: twice the gradient tolerance
+            # post-Adam weights: lr = 1e-3 and |update| <= ~lr, so agreement is relative to the update
+            dref = g['ws'][k] - (g['w0'] if k == 0 else g['ws'][k - 1])
+            dour = nvp.w - (g['w0'] if k == 0 else g['ws'][k - 1])
+            # elements whose gradient is pure rounding noise can flip sign under Adam's normalisation,
+            # so compare where the reference gradient is above the noise floor, and bound the rest by lr
+            big = np.abs(gref) > 1e-4 * np.max(np.abs(gref))
+            assert np.max(np.abs(dour - dref)[big]) < 2e-2 * float(g['lr'])
+            assert np.max(np.abs(dour - dref)) <= 2.1 * float(g['lr'])
+            k += 1
+    # fp64 gradient vs reference fp32 gradient at w0, as a noise yardstick
+    nvp = orc.NVP(D, H, B, L, g['w0'])
+    data = X[g['perms'][0][:batch]] + np.float32(jitter) * g['noises'][0][:batch]
+    loss64, g64 = nvp.loss_grad(data, f64=True)
+    assert np.max(np.abs(g64 - g['grads'][0])) < 2e-5 * (1e-3 + np.max(np.abs(g['grads'][0])))
+    # validation loss (trainer.py:405-418)
+    nvp.w[:] = g['ws'][-1]
+    assert abs(nvp.valid_loss(X) / n - float(g['valid_loss'])) < 1e-5 * (1 + abs(float(g['valid_loss'])))
+
+
+RUN_FILES = sorted(glob.glob(os.path.join(G, 'trainrun_*.npz')))
+
+
+@pytest.mark.parametrize('path', RUN_FILES, ids=[os.path.basename(p)[9:-4] for p in RUN_FILES])
+def test_train_run(path):
+    g = np.load(path)
+    nvp = orc.NVP(int(g['D']), int(g['H']), int(g['B']), int(g['L']), g['w0'])
+    res = nvp.train(g['live'], g['perm_split'], g['perms'], g['noises'], float(g['jitter']), int(g['max_iters']),
+                    patience=int(g['patience']), batch=int(g['batch']), lr=float(g['lr']), wd=float(g['weight_decay']))
+    assert res['epochs_run'] == int(g['epochs_run'])
+    assert res['best_validation_epoch'] == int(g['best_validation_epoch'])
+    # logged losses are printed with 4 decimals (trainer.py:212-213); fp32 rounding noise grows with the
+    # number of Adam steps because Adam normalises noise-level gradients to +-lr moves
+    tol = 2e-4 if res['epochs_run'] <= 10 else 2e-3
+    np.testing.assert_allclose(res['train_losses'], g['train_losses_logged'], atol=tol)
+    np.testing.assert_allclose(res['valid_losses'], g['valid_losses_logged'], atol=tol)
+    assert abs(res['best_validation_loss'] - float(g['best_validation_loss'])) < tol
+    # weights: drift is small against the distance training moved them
+    moved = np.sqrt(np.mean((g['w_final'] - g['w0']) ** 2))
+    assert np.sqrt(np.mean((nvp.w - g['w_final']) ** 2)) < 0.25 * moved
+
+
+MCMC_FILES = sorted(glob.glob(os.path.join(G, 'mcmc_*.npz')))
+
+
+@pytest.mark.parametrize('path', MCMC_FILES, ids=[os.path.basename(p)[5:-4] for p in MCMC_FILES])
+def test_mcmc_sample_trace(path):
+    g = np.load(path)
+    nvp = orc.NVP(int(g['D']), int(g['H']), int(g['B']), int(g['L']), g['w'])
+    like = {'Rosenbrock': 'rosenbrock', 'GaussianMix': 'gaussmix', 'Himmelblau': 'himmelblau'}[str(g['like'])]
+    samples, latent, loglikes, scale, ncall, (acc, rej) = orc.mcmc_sample(
+        nvp, like, float(g['scale']), g['init'], g['init_logl'], float(g['loglstar']), float(g['step']),
+        bool(g['dynamic']), g['dz'], g['u'])
+    # every accept/reject decision identical => identical call and acceptance counters
+    assert ncall == int(g['ncall'])
+    assert acc == int(g['total_accepted']) and rej == int(g['total_rejected'])
+    assert abs(scale - float(g['scale_out'])) < 1e-12 * max(1.0, abs(scale))
+    assert rel(latent, g['latent']) < 2e-5
+    assert rel(samples, g['samples']) < 2e-5
+    assert rel(loglikes, g['loglikes']) < 2e-5
+
+
+def test_nested_cfg1_fixture_matches_survey_probe():
+    with open(os.path.join(G, 'nested_cfg1.json')) as f:
+        r = json.load(f)
+    assert r['logz'] == -6.0258095377983825 and int(r['ncall']) == 4814 and int(r['niter']) == 691
+
+
+def test_training_jitter_matches_ckdtree():
+    scipy_spatial = pytest.importorskip('scipy.spatial')
+    rng = np.random.RandomState(0)
+    X = rng.uniform(-1, 1, size=(300, 7))
+    dists, _ = scipy_spatial.cKDTree(X).query(X, 2)
+    assert abs(orc.training_jitter(X) - 0.2 * np.mean(dists)) < 1e-12
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert orc.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
