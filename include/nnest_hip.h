@@ -1,0 +1,160 @@
+/*
+ * nnest_hip.h -- C ABI of libnnest_hip.so: the MI355X (gfx950) implementation of the nnest
+ * flow-transform + batched-proposal + likelihood + flow-training hot path.
+ *
+ * The reference (adammoss/nnest v0.4.2) is pure Python and has no FFI; the seam it offers is
+ * constructor injection of a Trainer-shaped object (nnest/sampler.py:50, :196-212;
+ * nnest/nested.py:44, :83).  Each entry point below names the reference function it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - all pointers named *_dev are DEVICE pointers (e.g. torch tensor .data_ptr()); the caller owns
+ *     every buffer; rows are row-major [N, D] float32 unless stated
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is asynchronous
+ *     on that stream unless documented otherwise; nothing here calls hipDeviceSynchronize
+ *   - return value: 0 = ok, non-zero = error (NNEST_E_*); message via nnest_hip_last_error();
+ *     nothing throws across the ABI
+ *   - packed weights are float32 in torch state_dict order: per block,
+ *     scale_net {W[H,D] b[H] (W[H,H] b[H])xL W[D,H] b[D]} then translate_net (same shapes)
+ */
+#ifndef NNEST_HIP_H
+#define NNEST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNEST_HIP_ABI_VERSION 1
+
+enum {
+    NNEST_OK = 0,
+    NNEST_E_ARG = 1,         /* bad argument / unsupported configuration */
+    NNEST_E_HIP = 2,         /* HIP runtime error */
+    NNEST_E_UNSUPPORTED = 3, /* shape outside what the kernels are instantiated for */
+};
+
+/* likelihood ids for the fused kernels (nnest/likelihoods.py) */
+enum {
+    NNEST_LIKE_ROSENBROCK = 0, /* Rosenbrock.loglike   likelihoods.py:51 */
+    NNEST_LIKE_GAUSSMIX = 1,   /* GaussianMix.loglike  likelihoods.py:165-189 (sep 4, sigma 1, w .4 .3 .2 .1) */
+    NNEST_LIKE_HIMMELBLAU = 2, /* Himmelblau.loglike   likelihoods.py:70 (D>2: sum over consecutive pairs) */
+};
+
+/* flags for nnest_mh_constrained_steps */
+enum {
+    NNEST_MH_DYNAMIC_STEP = 1, /* sampler.py:422-431 step-size adaptation (see DESIGN.md for the group rule) */
+};
+
+typedef struct nnest_nvp nnest_nvp_t; /* opaque: RealNVP coupling stack + Adam state on one device */
+
+int nnest_hip_version(void);
+const char *nnest_hip_last_error(void);
+/* number of compute units / device name of the current device (diagnostics for bench.py) */
+int nnest_hip_device_info(int *num_cu, int *clock_khz, char *name, int name_len);
+
+/* SingleSpeedNVP(num_inputs=D, num_hidden=H, num_blocks=B, num_layers=L) -- networks.py:328-347.
+ * Allocates device storage for the packed weights, Adam moments and the MFMA-fragment image. */
+int nnest_nvp_create(int D, int H, int B, int L, nnest_nvp_t **out);
+int nnest_nvp_destroy(nnest_nvp_t *nvp);
+int nnest_nvp_num_params(const nnest_nvp_t *nvp);
+/* netG.load_state_dict / state_dict (trainer.py:102-106, :241): host<->device copy of the packed
+ * weights.  These two synchronise `stream` before returning. */
+int nnest_nvp_load_weights(nnest_nvp_t *nvp, const float *packed_host, void *stream);
+int nnest_nvp_store_weights(nnest_nvp_t *nvp, float *packed_host, void *stream);
+/* device pointer of the packed weights / Adam exp_avg / exp_avg_sq (read-only views for tests) */
+int nnest_nvp_device_ptrs(nnest_nvp_t *nvp, float **w_dev, float **m_dev, float **v_dev);
+/* host copies of Adam's exp_avg / exp_avg_sq (torch.optim.Adam state, trainer.py:121-122); synchronises `stream` */
+int nnest_nvp_store_adam(nnest_nvp_t *nvp, float *exp_avg_host, float *exp_avg_sq_host, void *stream);
+int nnest_nvp_load_adam(nnest_nvp_t *nvp, const float *exp_avg_host, const float *exp_avg_sq_host, void *stream);
+/* Adam step counter and optimiser reset (torch.optim.Adam state, trainer.py:121-122) */
+int nnest_nvp_adam_state(nnest_nvp_t *nvp, int *step_count, int set_step, int reset_moments, void *stream);
+
+/* NormalizingFlow.forward (networks.py:24-32) via Trainer.forward (trainer.py:247-257): x -> z, logdet */
+int nnest_nvp_forward(nnest_nvp_t *nvp, const float *x_dev, float *z_dev, float *logdet_dev, int N, void *stream);
+/* NormalizingFlow.inverse (networks.py:34-42) via Trainer.inverse (trainer.py:259-269): z -> x, logdet */
+int nnest_nvp_inverse(nnest_nvp_t *nvp, const float *z_dev, float *x_dev, float *logdet_dev, int N, void *stream);
+/* NormalizingFlowModel.log_probs (networks.py:71-76), N(0,I) base (networks.py:51-57) */
+int nnest_nvp_log_probs(nnest_nvp_t *nvp, const float *x_dev, float *logp_dev, int N, void *stream);
+
+/* Fused "one eval": x = f^-1(z), logdet; box prior UniformPrior(-1,1) (priors.py:39-43);
+ * logl = loglike(like_scale * x) as safe_loglike (sampler.py:110-133) incl. non-finite -> -1e100.
+ * logl_dev is float64 [N]; inbox_dev int32 [N] (1 = inside the box).  x_dev/logdet_dev may be NULL. */
+int nnest_nvp_inverse_loglike(nnest_nvp_t *nvp, int like_id, float like_scale, const float *z_dev, float *x_dev,
+                              float *logdet_dev, double *logl_dev, int *inbox_dev, int N, void *stream);
+
+/* Likelihood.__call__ over rows (likelihoods.py:14-22) through safe_loglike: logl[n] = loglike(scale*x[n]).
+ * x_unit_dev float32 [N,D]; logl_dev float64 [N]. */
+int nnest_loglike(int like_id, const float *x_unit_dev, float like_scale, double *logl_dev, int N, int D,
+                  void *stream);
+
+/* Sampler._mcmc_sample, hard-constraint branch (sampler.py:229-463), `steps` Metropolis steps for C
+ * walkers inside ONE launch.
+ *   z_dev [C,D]        in: latent start (= forward(init_samples), sampler.py:264); out: final latent
+ *   x_dev [C,D]        out: final x = f^-1(z) (sampler.py:266, :439)
+ *   logl_dev [C] f64   in: init_loglikes; out: final log-likelihoods
+ *   loglstar           hard constraint logl > loglstar (sampler.py:361)
+ *   step_size          initial proposal scale (sampler.py:255)
+ *   noise_dz_dev       NULL -> in-kernel Philox4x32-10 + Box-Muller keyed by (seed, walker_offset + walker, step, dim);
+ *                      else recorded noise [steps, C, D] (torch.randn_like(z), sampler.py:310)
+ *   noise_u_dev        recorded uniforms [steps, C] (torch.rand, sampler.py:334); required iff noise_dz_dev
+ *   hist_x_dev         optional [C, steps+1, D] history of x (reference return layout, sampler.py:455);
+ *   hist_logl_dev      optional [C, steps+1] f64
+ *   n_accept_dev [C]   out int32: accepted moves per walker  (sampler.py:418-420)
+ *   n_call_dev [C]     out int32: likelihood calls per walker (rows that passed the prior/Jacobian test,
+ *                      sampler.py:358-363)
+ *   scale_out_dev      optional float32 [ngroups]: final scale per adaptation group (sampler.py:422-431)
+ */
+int nnest_mh_constrained_steps(nnest_nvp_t *nvp, int like_id, float like_scale, float *z_dev, float *x_dev,
+                               double *logl_dev, double loglstar, float step_size, int steps, int C, int flags,
+                               const float *noise_dz_dev, const float *noise_u_dev, uint64_t seed,
+                               uint64_t walker_offset, float *hist_x_dev, double *hist_logl_dev, int *n_accept_dev,
+                               int *n_call_dev, float *scale_out_dev, void *stream);
+/* number of adaptation groups nnest_mh_constrained_steps uses for C walkers (size of scale_out_dev) */
+int nnest_mh_num_groups(const nnest_nvp_t *nvp, int C);
+
+/* The in-kernel proposal noise as arrays, for tests: dz[steps,C,D] ~ N(0,1), u[steps,C] ~ U[0,1),
+ * bit-identical to what nnest_mh_constrained_steps draws for (seed, walker_offset). */
+int nnest_mh_fill_noise(float *dz_dev, float *u_dev, int steps, int C, int D, uint64_t seed, uint64_t walker_offset,
+                        void *stream);
+
+/* Trainer.train's epoch loop (trainer.py:198-232) inside one launch: for each epoch, Trainer._train
+ * (trainer.py:384-403: minibatches of `batch` rows in the order perm_dev[epoch], data + jitter*noise,
+ * loss = -mean(log_probs), backward, Adam with coupled weight decay) then Trainer._validate
+ * (trainer.py:405-418), early stopping with `patience` and best-model restore (trainer.py:205-209, :241).
+ *   xtrain_dev [n_train,D], xvalid_dev [n_valid,D] float32
+ *   perm_dev [max_epochs, n_train] int32 (DataLoader shuffle order per epoch, trainer.py:185)
+ *   noise_dev  NULL -> in-kernel Philox normals keyed by (seed, epoch, row, dim); else [max_epochs, n_train, D]
+ *              in perm order (torch.randn_like(data), trainer.py:392)
+ *   losses_dev optional float32 [max_epochs, 2]: (train, validation) loss per epoch, normalised as the
+ *              reference logs them (/len(dataset), trainer.py:403, :418)
+ *   result_dev int32 [4] + float [..]: see nnest_train_result_t
+ * Adam moments and step count persist in the handle across calls (optimizer is created once,
+ * trainer.py:121-122).  On return (stream order) the handle's weights are the best-validation weights.
+ */
+typedef struct {
+    int epochs_run;
+    int best_epoch;
+    float best_validation_loss;
+    float last_train_loss;
+} nnest_train_result_t;
+
+int nnest_nvp_train(nnest_nvp_t *nvp, const float *xtrain_dev, int n_train, const float *xvalid_dev, int n_valid,
+                    const int *perm_dev, const float *noise_dev, uint64_t seed, float jitter, int batch,
+                    int max_epochs, int patience, float lr, float weight_decay, float *losses_dev,
+                    nnest_train_result_t *result_dev, void *stream);
+
+/* One minibatch: loss and dloss/dw (before weight decay) into grad_dev [num_params], no update.
+ * For tests (reference: loss.backward(), trainer.py:400). x_dev [M,D]. loss_dev float32[1]. */
+int nnest_nvp_loss_grad(nnest_nvp_t *nvp, const float *x_dev, int M, float *grad_dev, float *loss_dev, void *stream);
+
+/* training jitter when jitter < 0 (trainer.py:168-171): 0.2 * mean of the 2-nearest-neighbour distance
+ * table (self distance 0 included) of samples_dev [N,D] float64; result to out_dev float64[1]. */
+int nnest_training_jitter(const double *samples_dev, int N, int D, double *out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNEST_HIP_H */

@@ -1,0 +1,104 @@
+"""ctypes binding of libnnest_hip.so (include/nnest_hip.h).
+
+The shared library is the product: there is no CPU or PyTorch fallback.  Importing this module
+without the built library raises; calling into it without a GPU returns the library's own error.
+`import torch` happens first so that the library's libamdhip64.so.7 dependency resolves to the HIP
+runtime PyTorch-ROCm has already loaded (one runtime per process; device pointers and streams are
+shared with torch tensors).
+"""
+import os
+import ctypes
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnnest_hip.so')
+
+NNEST_OK = 0
+LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'himmelblau': 2}
+MH_DYNAMIC_STEP = 1
+
+
+class NnestHipError(RuntimeError):
+    pass
+
+
+class TrainResult(ctypes.Structure):
+    _fields_ = [('epochs_run', ctypes.c_int), ('best_epoch', ctypes.c_int),
+                ('best_validation_loss', ctypes.c_float), ('last_train_loss', ctypes.c_float)]
+
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_d = ctypes.c_double
+_u64 = ctypes.c_uint64
+
+# name -> argtypes; every entry point include/nnest_hip.h declares (checked by tests/test_abi.py)
+SIGNATURES = {
+    'nnest_hip_version': [],
+    'nnest_hip_last_error': [],
+    'nnest_hip_device_info': [ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _i],
+    'nnest_nvp_create': [_i, _i, _i, _i, ctypes.POINTER(_vp)],
+    'nnest_nvp_destroy': [_vp],
+    'nnest_nvp_num_params': [_vp],
+    'nnest_nvp_load_weights': [_vp, _vp, _vp],
+    'nnest_nvp_store_weights': [_vp, _vp, _vp],
+    'nnest_nvp_device_ptrs': [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)],
+    'nnest_nvp_store_adam': [_vp, _vp, _vp, _vp],
+    'nnest_nvp_load_adam': [_vp, _vp, _vp, _vp],
+    'nnest_nvp_adam_state': [_vp, ctypes.POINTER(_i), _i, _i, _vp],
+    'nnest_nvp_forward': [_vp, _vp, _vp, _vp, _i, _vp],
+    'nnest_nvp_inverse': [_vp, _vp, _vp, _vp, _i, _vp],
+    'nnest_nvp_log_probs': [_vp, _vp, _vp, _i, _vp],
+    'nnest_nvp_inverse_loglike': [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    'nnest_loglike': [_i, _vp, _f, _vp, _i, _i, _vp],
+    'nnest_mh_constrained_steps': [_vp, _i, _f, _vp, _vp, _vp, _d, _f, _i, _i, _i, _vp, _vp, _u64, _u64,
+                                   _vp, _vp, _vp, _vp, _vp, _vp],
+    'nnest_mh_num_groups': [_vp, _i],
+    'nnest_mh_fill_noise': [_vp, _vp, _i, _i, _i, _u64, _u64, _vp],
+    'nnest_nvp_train': [_vp, _vp, _i, _vp, _i, _vp, _vp, _u64, _f, _i, _i, _i, _f, _f, _vp, _vp, _vp],
+    'nnest_nvp_loss_grad': [_vp, _vp, _i, _vp, _vp, _vp],
+    'nnest_training_jitter': [_vp, _i, _i, _vp, _vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load libnnest_hip.so (built by __graft_entry__.build() / make -C nnest_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NnestHipError('%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                                '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_char_p if name == 'nnest_hip_last_error' else ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != NNEST_OK:
+        msg = load().nnest_hip_last_error()
+        raise NnestHipError('libnnest_hip error %d: %s' % (rc, msg.decode() if msg else '?'))
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def device_info():
+    n = ctypes.c_int(0)
+    clk = ctypes.c_int(0)
+    buf = ctypes.create_string_buffer(256)
+    check(load().nnest_hip_device_info(ctypes.byref(n), ctypes.byref(clk), buf, 256))
+    return {'num_cu': n.value, 'clock_khz': clk.value, 'name': buf.value.decode()}

@@ -1,0 +1,294 @@
+// nnest_abi.hip -- the extern "C" surface of libnnest_hip.so (include/nnest_hip.h): handle management,
+// argument checks, error reporting.  No torch types, no exceptions across the boundary.
+#include <stdio.h>
+#include <string.h>
+#include <stdarg.h>
+
+#include "nnest_internal.h"
+
+using namespace nnest;
+
+struct nnest_nvp {
+    FlowShape s;
+    int device;
+    int num_cu;
+    int num_params;
+    float *w;        // packed weights (state_dict order)
+    float *adam_m;   // exp_avg
+    float *adam_v;   // exp_avg_sq
+    float *best_w;   // best-validation snapshot (Trainer.train's deepcopy, trainer.py:194, :208)
+    float *img;      // MFMA fragment image of w
+    int *adam_step;  // device int: torch.optim.Adam state['step']
+    float *train_ws; // training workspace
+    size_t train_ws_floats;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) return fail(NNEST_E_HIP, "%s: %s", #expr, hipGetErrorString(e__));       \
+    } while (0)
+
+extern "C" {
+
+int nnest_hip_version(void) { return NNEST_HIP_ABI_VERSION; }
+
+const char *nnest_hip_last_error(void) { return g_err; }
+
+int nnest_hip_device_info(int *num_cu, int *clock_khz, char *name, int name_len) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, dev));
+    if (num_cu) *num_cu = p.multiProcessorCount;
+    if (clock_khz) *clock_khz = p.clockRate;
+    if (name && name_len > 0) {
+        snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    return NNEST_OK;
+}
+
+int nnest_nvp_create(int D, int H, int B, int L, nnest_nvp_t **out) {
+    if (!out) return fail(NNEST_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (D < 1 || H < 1 || B < 1 || L < 0) return fail(NNEST_E_ARG, "bad shape D=%d H=%d B=%d L=%d", D, H, B, L);
+    if (H % 16 != 0)
+        return fail(NNEST_E_UNSUPPORTED, "hidden_dim=%d: the gfx950 kernels tile the hidden layer by 16 (MFMA 16x16x4)", H);
+    FlowShape s;
+    s.D = D; s.H = H; s.B = B; s.L = L;
+    s.NT = ((D + 1) / 2 + 15) / 16;
+    s.NH = H / 16;
+    s.net_floats = frag_net_floats(s.NT, s.NH, L);
+    s.image_floats = B * 2 * s.net_floats;
+    s.net_params = H * D + H + L * (H * H + H) + D * H + D;
+    if (!shape_supported(s))
+        return fail(NNEST_E_UNSUPPORTED, "x_dim=%d hidden_dim=%d not instantiated (x_dim<=128 at H=16, <=64 at H=32, <=32 at H=64)", D, H);
+    nnest_nvp *h = new nnest_nvp();
+    memset(h, 0, sizeof(*h));
+    h->s = s;
+    h->num_params = B * 2 * s.net_params;
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(NNEST_E_HIP, "hipGetDevice failed (no GPU?)"); }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, h->device) != hipSuccess) { delete h; return fail(NNEST_E_HIP, "hipGetDeviceProperties failed"); }
+    h->num_cu = p.multiProcessorCount;
+    size_t nb = (size_t)h->num_params * sizeof(float);
+    h->train_ws_floats = train_workspace_floats(s, 128);
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc((void **)&h->w, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->adam_m, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->adam_v, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->best_w, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->img, (size_t)s.image_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->adam_step, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->train_ws, h->train_ws_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->w, 0, nb);
+    if (e == hipSuccess) e = hipMemset(h->adam_m, 0, nb);
+    if (e == hipSuccess) e = hipMemset(h->adam_v, 0, nb);
+    if (e == hipSuccess) e = hipMemset(h->adam_step, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->img, 0, (size_t)s.image_floats * sizeof(float));
+    if (e != hipSuccess) {
+        nnest_nvp_destroy(h);
+        return fail(NNEST_E_HIP, "device allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return NNEST_OK;
+}
+
+int nnest_nvp_destroy(nnest_nvp_t *h) {
+    if (!h) return NNEST_OK;
+    (void)hipFree(h->w); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->best_w); (void)hipFree(h->img);
+    (void)hipFree(h->adam_step); (void)hipFree(h->train_ws);
+    delete h;
+    return NNEST_OK;
+}
+
+int nnest_nvp_num_params(const nnest_nvp_t *h) { return h ? h->num_params : -1; }
+
+int nnest_nvp_load_weights(nnest_nvp_t *h, const float *packed_host, void *stream) {
+    if (!h || !packed_host) return fail(NNEST_E_ARG, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(h->w, packed_host, (size_t)h->num_params * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_repack(h->w, h->img, h->s, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NNEST_OK;
+}
+
+int nnest_nvp_store_weights(nnest_nvp_t *h, float *packed_host, void *stream) {
+    if (!h || !packed_host) return fail(NNEST_E_ARG, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(packed_host, h->w, (size_t)h->num_params * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NNEST_OK;
+}
+
+int nnest_nvp_device_ptrs(nnest_nvp_t *h, float **w_dev, float **m_dev, float **v_dev) {
+    if (!h) return fail(NNEST_E_ARG, "NULL handle");
+    if (w_dev) *w_dev = h->w;
+    if (m_dev) *m_dev = h->adam_m;
+    if (v_dev) *v_dev = h->adam_v;
+    return NNEST_OK;
+}
+
+int nnest_nvp_store_adam(nnest_nvp_t *h, float *exp_avg_host, float *exp_avg_sq_host, void *stream) {
+    if (!h || !exp_avg_host || !exp_avg_sq_host) return fail(NNEST_E_ARG, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    size_t nb = (size_t)h->num_params * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(exp_avg_host, h->adam_m, nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(exp_avg_sq_host, h->adam_v, nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NNEST_OK;
+}
+
+int nnest_nvp_load_adam(nnest_nvp_t *h, const float *exp_avg_host, const float *exp_avg_sq_host, void *stream) {
+    if (!h || !exp_avg_host || !exp_avg_sq_host) return fail(NNEST_E_ARG, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    size_t nb = (size_t)h->num_params * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(h->adam_m, exp_avg_host, nb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->adam_v, exp_avg_sq_host, nb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NNEST_OK;
+}
+
+int nnest_nvp_adam_state(nnest_nvp_t *h, int *step_count, int set_step, int reset_moments, void *stream) {
+    if (!h) return fail(NNEST_E_ARG, "NULL handle");
+    hipStream_t st = (hipStream_t)stream;
+    if (reset_moments) {
+        HIP_TRY(hipMemsetAsync(h->adam_m, 0, (size_t)h->num_params * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(h->adam_v, 0, (size_t)h->num_params * sizeof(float), st));
+    }
+    if (set_step >= 0) HIP_TRY(hipMemcpyAsync(h->adam_step, &set_step, sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (step_count) {
+        HIP_TRY(hipMemcpyAsync(step_count, h->adam_step, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return NNEST_OK;
+}
+
+static int check_rows(const nnest_nvp_t *h, const void *a, const void *b, int N) {
+    if (!h) return fail(NNEST_E_ARG, "NULL handle");
+    if (N < 0) return fail(NNEST_E_ARG, "N=%d < 0", N);
+    if (N > 0 && (!a || !b)) return fail(NNEST_E_ARG, "NULL device buffer");
+    return NNEST_OK;
+}
+
+int nnest_nvp_forward(nnest_nvp_t *h, const float *x_dev, float *z_dev, float *logdet_dev, int N, void *stream) {
+    int rc = check_rows(h, x_dev, z_dev, N);
+    if (rc) return rc;
+    HIP_TRY(launch_pass(h->img, h->s, PASS_FORWARD, x_dev, z_dev, logdet_dev, nullptr, nullptr, N, 0, 1.f, h->num_cu,
+                        (hipStream_t)stream));
+    return NNEST_OK;
+}
+
+int nnest_nvp_inverse(nnest_nvp_t *h, const float *z_dev, float *x_dev, float *logdet_dev, int N, void *stream) {
+    int rc = check_rows(h, z_dev, x_dev, N);
+    if (rc) return rc;
+    HIP_TRY(launch_pass(h->img, h->s, PASS_INVERSE, z_dev, x_dev, logdet_dev, nullptr, nullptr, N, 0, 1.f, h->num_cu,
+                        (hipStream_t)stream));
+    return NNEST_OK;
+}
+
+int nnest_nvp_log_probs(nnest_nvp_t *h, const float *x_dev, float *logp_dev, int N, void *stream) {
+    int rc = check_rows(h, x_dev, logp_dev, N);
+    if (rc) return rc;
+    HIP_TRY(launch_pass(h->img, h->s, PASS_LOGPROB, x_dev, logp_dev, nullptr, nullptr, nullptr, N, 0, 1.f, h->num_cu,
+                        (hipStream_t)stream));
+    return NNEST_OK;
+}
+
+static int check_like(int like_id) {
+    if (like_id < NNEST_LIKE_ROSENBROCK || like_id > NNEST_LIKE_HIMMELBLAU) return fail(NNEST_E_ARG, "unknown like_id %d", like_id);
+    return NNEST_OK;
+}
+
+int nnest_nvp_inverse_loglike(nnest_nvp_t *h, int like_id, float like_scale, const float *z_dev, float *x_dev,
+                              float *logdet_dev, double *logl_dev, int *inbox_dev, int N, void *stream) {
+    int rc = check_rows(h, z_dev, logl_dev, N);
+    if (rc) return rc;
+    if ((rc = check_like(like_id))) return rc;
+    HIP_TRY(launch_pass(h->img, h->s, PASS_INVERSE_LOGLIKE, z_dev, x_dev, logdet_dev, logl_dev, inbox_dev, N, like_id,
+                        like_scale, h->num_cu, (hipStream_t)stream));
+    return NNEST_OK;
+}
+
+int nnest_loglike(int like_id, const float *x_unit_dev, float like_scale, double *logl_dev, int N, int D, void *stream) {
+    int rc = check_like(like_id);
+    if (rc) return rc;
+    if (N < 0 || D < 1) return fail(NNEST_E_ARG, "bad N=%d D=%d", N, D);
+    if (D > 128) return fail(NNEST_E_UNSUPPORTED, "x_dim=%d > 128", D);
+    if (N > 0 && (!x_unit_dev || !logl_dev)) return fail(NNEST_E_ARG, "NULL device buffer");
+    int dev = 0, num_cu = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    HIP_TRY(launch_loglike(like_id, x_unit_dev, like_scale, logl_dev, N, D, num_cu, (hipStream_t)stream));
+    return NNEST_OK;
+}
+
+int nnest_mh_constrained_steps(nnest_nvp_t *h, int like_id, float like_scale, float *z_dev, float *x_dev,
+                               double *logl_dev, double loglstar, float step_size, int steps, int C, int flags,
+                               const float *noise_dz_dev, const float *noise_u_dev, uint64_t seed,
+                               uint64_t walker_offset, float *hist_x_dev, double *hist_logl_dev, int *n_accept_dev,
+                               int *n_call_dev, float *scale_out_dev, void *stream) {
+    int rc = check_rows(h, z_dev, logl_dev, C);
+    if (rc) return rc;
+    if ((rc = check_like(like_id))) return rc;
+    if (steps < 0) return fail(NNEST_E_ARG, "steps=%d < 0", steps);
+    if ((noise_dz_dev == nullptr) != (noise_u_dev == nullptr))
+        return fail(NNEST_E_ARG, "noise_dz_dev and noise_u_dev must both be given or both be NULL");
+    HIP_TRY(launch_mh(h->img, h->s, like_id, like_scale, z_dev, x_dev, logl_dev, loglstar, step_size, steps, C, flags,
+                      noise_dz_dev, noise_u_dev, seed, walker_offset, hist_x_dev, hist_logl_dev, n_accept_dev, n_call_dev,
+                      scale_out_dev, h->num_cu, (hipStream_t)stream));
+    return NNEST_OK;
+}
+
+int nnest_mh_num_groups(const nnest_nvp_t *h, int C) {
+    (void)h;
+    return mh_num_groups(C);
+}
+
+int nnest_mh_fill_noise(float *dz_dev, float *u_dev, int steps, int C, int D, uint64_t seed, uint64_t walker_offset,
+                        void *stream) {
+    if (!dz_dev) return fail(NNEST_E_ARG, "NULL dz_dev");
+    HIP_TRY(launch_fill_noise(dz_dev, u_dev, steps, C, D, seed, walker_offset, (hipStream_t)stream));
+    return NNEST_OK;
+}
+
+int nnest_nvp_train(nnest_nvp_t *h, const float *xtrain_dev, int n_train, const float *xvalid_dev, int n_valid,
+                    const int *perm_dev, const float *noise_dev, uint64_t seed, float jitter, int batch,
+                    int max_epochs, int patience, float lr, float weight_decay, float *losses_dev,
+                    nnest_train_result_t *result_dev, void *stream) {
+    if (!h) return fail(NNEST_E_ARG, "NULL handle");
+    if (!xtrain_dev || !xvalid_dev || !perm_dev || !result_dev) return fail(NNEST_E_ARG, "NULL device buffer");
+    if (n_train < 1 || n_valid < 1 || batch < 1 || max_epochs < 0)
+        return fail(NNEST_E_ARG, "bad sizes n_train=%d n_valid=%d batch=%d max_epochs=%d", n_train, n_valid, batch, max_epochs);
+    if (batch > 128) return fail(NNEST_E_UNSUPPORTED, "batch_size=%d > 128 (one workgroup holds a minibatch)", batch);
+    HIP_TRY(launch_train(h->w, h->adam_m, h->adam_v, h->best_w, h->img, h->adam_step, h->s, xtrain_dev, n_train, xvalid_dev,
+                         n_valid, perm_dev, noise_dev, seed, jitter, batch, max_epochs, patience, lr, weight_decay,
+                         losses_dev, result_dev, h->train_ws, (hipStream_t)stream));
+    return NNEST_OK;
+}
+
+int nnest_nvp_loss_grad(nnest_nvp_t *h, const float *x_dev, int M, float *grad_dev, float *loss_dev, void *stream) {
+    if (!h || !x_dev || !grad_dev || !loss_dev) return fail(NNEST_E_ARG, "NULL argument");
+    if (M < 1 || M > 128) return fail(NNEST_E_UNSUPPORTED, "M=%d outside [1,128]", M);
+    HIP_TRY(launch_loss_grad(h->w, h->s, x_dev, M, grad_dev, loss_dev, h->train_ws, (hipStream_t)stream));
+    return NNEST_OK;
+}
+
+int nnest_training_jitter(const double *samples_dev, int N, int D, double *out_dev, void *stream) {
+    if (!samples_dev || !out_dev || N < 2 || D < 1) return fail(NNEST_E_ARG, "bad arguments");
+    HIP_TRY(launch_training_jitter(samples_dev, N, D, out_dev, (hipStream_t)stream));
+    return NNEST_OK;
+}
+
+}  // extern "C"

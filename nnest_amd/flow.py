@@ -1,0 +1,246 @@
+"""HipNVP: the RealNVP coupling stack resident on one MI355X, driven through the C ABI.
+
+Mirrors SingleSpeedNVP / NormalizingFlowModel (reference nnest/networks.py:17-84, :328-347):
+forward, inverse, log_probs, sample -- all on torch CUDA (ROCm) float32 tensors, computed by the HIP
+kernels in libnnest_hip.so.  No PyTorch arithmetic is used for the flow itself.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _as_dev_f32(x, device):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if not torch.is_tensor(x):
+        x = torch.as_tensor(x)
+    x = x.to(device=device, dtype=torch.float32)
+    if x.dim() == 1:
+        x = x[None, :]
+    return x.contiguous()
+
+
+class HipNVP(object):
+    """num_inputs=D, num_hidden=H, num_blocks=B, num_layers=L as SingleSpeedNVP (networks.py:330-331)."""
+
+    def __init__(self, num_inputs, num_hidden=16, num_blocks=3, num_layers=1, device=None, seed=None):
+        if not torch.cuda.is_available():
+            raise _lib.NnestHipError('HipNVP needs an MI355X visible to PyTorch-ROCm (torch.cuda.is_available() is False); '
+                                     'there is no CPU fallback')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.D, self.H, self.B, self.L = int(num_inputs), int(num_hidden), int(num_blocks), int(num_layers)
+        self.num_inputs = self.D
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_nvp_create(self.D, self.H, self.B, self.L, ctypes.byref(self._h)))
+        self.num_params = self._lib.nnest_nvp_num_params(self._h)
+        self.prior = torch.distributions.MultivariateNormal(torch.zeros(self.D, device=self.device),
+                                                            torch.eye(self.D, device=self.device))
+        self.load_packed(self.default_init(seed))
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None) is not None and self._h.value:
+                self._lib.nnest_nvp_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def layer_shapes(self):
+        """[(name, shape)] in torch state_dict order"""
+        out = []
+        D, H, L = self.D, self.H, self.L
+        for b in range(self.B):
+            for net in ('scale_net', 'translate_net'):
+                dims = [(H, D)] + [(H, H)] * L + [(D, H)]
+                for i, (o, k) in enumerate(dims):
+                    out.append(('flow.flows.%d.%s.%d.weight' % (b, net, 2 * i), (o, k)))
+                    out.append(('flow.flows.%d.%s.%d.bias' % (b, net, 2 * i), (o,)))
+        return out
+
+    def default_init(self, seed=None):
+        """nn.Linear's default init (kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for both
+        weight and bias), which is what the reference ends up with: its orthogonal init closure is never
+        applied (networks.py:284-287)."""
+        g = torch.Generator()
+        if seed is None:
+            g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+        else:
+            g.manual_seed(int(seed))
+        parts = []
+        for name, shape in self.layer_shapes():
+            fan_in = shape[1] if len(shape) == 2 else None
+            if fan_in is None:
+                fan_in = last_fan_in
+            else:
+                last_fan_in = fan_in
+            bound = 1.0 / math.sqrt(fan_in)
+            parts.append((torch.rand(int(np.prod(shape)), generator=g) * 2 - 1) * bound)
+        return torch.cat(parts).numpy().astype(np.float32)
+
+    def load_packed(self, packed):
+        packed = np.ascontiguousarray(packed, dtype=np.float32)
+        if packed.size != self.num_params:
+            raise ValueError('expected %d packed weights, got %d' % (self.num_params, packed.size))
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_nvp_load_weights(self._h, packed.ctypes.data_as(ctypes.c_void_p),
+                                                        _lib.current_stream(self.device)))
+
+    def store_packed(self):
+        out = np.empty(self.num_params, np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_nvp_store_weights(self._h, out.ctypes.data_as(ctypes.c_void_p),
+                                                         _lib.current_stream(self.device)))
+        return out
+
+    def state_dict(self):
+        packed = self.store_packed()
+        sd, off = {}, 0
+        for name, shape in self.layer_shapes():
+            n = int(np.prod(shape))
+            sd[name] = torch.from_numpy(packed[off:off + n].reshape(shape).copy())
+            off += n
+        return sd
+
+    def load_state_dict(self, sd):
+        self.load_packed(np.concatenate([np.asarray(sd[name].detach().cpu().numpy() if torch.is_tensor(sd[name])
+                                                    else sd[name], dtype=np.float32).ravel()
+                                         for name, _ in self.layer_shapes()]))
+
+    def adam_step_count(self):
+        n = ctypes.c_int(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_nvp_adam_state(self._h, ctypes.byref(n), -1, 0, _lib.current_stream(self.device)))
+        return n.value
+
+    def adam_moments(self):
+        """host copies of Adam's (exp_avg, exp_avg_sq)"""
+        m = np.empty(self.num_params, np.float32)
+        v = np.empty(self.num_params, np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_nvp_store_adam(self._h, m.ctypes.data_as(ctypes.c_void_p),
+                                                      v.ctypes.data_as(ctypes.c_void_p), _lib.current_stream(self.device)))
+        return m, v
+
+    def set_adam(self, m, v, step):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_nvp_load_adam(self._h, m.ctypes.data_as(ctypes.c_void_p),
+                                                     v.ctypes.data_as(ctypes.c_void_p), _lib.current_stream(self.device)))
+            _lib.check(self._lib.nnest_nvp_adam_state(self._h, None, int(step), 0, _lib.current_stream(self.device)))
+
+    # nn.Module look-alikes the reference's Sampler calls (sampler.py:246, :553, :611, :647)
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def parameters(self):
+        return list(self.state_dict().values())
+
+    # ---- flow passes -----------------------------------------------------------------------------
+    def _pass(self, fn, x, want_logdet=True):
+        x = _as_dev_f32(x, self.device)
+        N = x.shape[0]
+        if x.shape[1] != self.D:
+            raise ValueError('expected [N, %d], got %s' % (self.D, tuple(x.shape)))
+        out = torch.empty_like(x)
+        ld = torch.empty(N, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(fn(self._h, _lib.ptr(x), _lib.ptr(out), _lib.ptr(ld), N, _lib.current_stream(self.device)))
+        return out, ld
+
+    def forward(self, x):
+        """NormalizingFlow.forward (networks.py:24-32): (z, log_det)"""
+        return self._pass(self._lib.nnest_nvp_forward, x)
+
+    def inverse(self, z):
+        """NormalizingFlow.inverse (networks.py:34-42): (x, log_det)"""
+        return self._pass(self._lib.nnest_nvp_inverse, z)
+
+    def log_probs(self, x):
+        """NormalizingFlowModel.log_probs (networks.py:71-76)"""
+        x = _as_dev_f32(x, self.device)
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_nvp_log_probs(self._h, _lib.ptr(x), _lib.ptr(out), x.shape[0],
+                                                     _lib.current_stream(self.device)))
+        return out
+
+    def sample(self, num_samples=None, noise=None):
+        """NormalizingFlowModel.sample (networks.py:78-84)"""
+        if noise is None:
+            noise = torch.randn(num_samples, self.D, device=self.device)
+        x, _ = self.inverse(noise)
+        return x
+
+    def inverse_loglike(self, like_id, like_scale, z, want_x=True):
+        """K3: x = f^-1(z), logdet, box-prior flag, logl = loglike(like_scale * x) in one launch."""
+        z = _as_dev_f32(z, self.device)
+        N = z.shape[0]
+        x = torch.empty_like(z) if want_x else None
+        ld = torch.empty(N, dtype=torch.float32, device=self.device)
+        logl = torch.empty(N, dtype=torch.float64, device=self.device)
+        inbox = torch.empty(N, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_nvp_inverse_loglike(self._h, int(like_id), float(like_scale), _lib.ptr(z),
+                                                           _lib.ptr(x), _lib.ptr(ld), _lib.ptr(logl), _lib.ptr(inbox), N,
+                                                           _lib.current_stream(self.device)))
+        return x, ld, logl, inbox
+
+    def mh_steps(self, like_id, like_scale, z, logl, loglstar, step_size, steps, dynamic=False, noise=None, seed=0,
+                 walker_offset=0, history=False):
+        """K4: `steps` constrained Metropolis steps for all walkers in one launch (Sampler._mcmc_sample,
+        sampler.py:229-463).  z [C,D] float32 and logl [C] float64 are updated in place.
+        noise = (dz [steps,C,D], u [steps,C]) replays recorded draws; None = in-kernel Philox."""
+        assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()
+        assert logl.is_cuda and logl.dtype == torch.float64 and logl.is_contiguous()
+        C = z.shape[0]
+        dev = self.device
+        x = torch.empty_like(z)
+        n_acc = torch.zeros(C, dtype=torch.int32, device=dev)
+        n_call = torch.zeros(C, dtype=torch.int32, device=dev)
+        ngroups = self._lib.nnest_mh_num_groups(self._h, C)
+        scale_out = torch.empty(max(ngroups, 1), dtype=torch.float32, device=dev)
+        hx = torch.empty(C, steps + 1, self.D, dtype=torch.float32, device=dev) if history else None
+        hl = torch.empty(C, steps + 1, dtype=torch.float64, device=dev) if history else None
+        dz = u = None
+        if noise is not None:
+            dz = _as_dev_f32(noise[0].reshape(-1, self.D), dev)
+            u = noise[1].to(device=dev, dtype=torch.float32).contiguous()
+            assert dz.shape[0] == steps * C and u.numel() == steps * C
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.nnest_mh_constrained_steps(
+                self._h, int(like_id), float(like_scale), _lib.ptr(z), _lib.ptr(x), _lib.ptr(logl), float(loglstar),
+                float(step_size), int(steps), C, _lib.MH_DYNAMIC_STEP if dynamic else 0, _lib.ptr(dz), _lib.ptr(u),
+                int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), _lib.ptr(hx), _lib.ptr(hl), _lib.ptr(n_acc),
+                _lib.ptr(n_call), _lib.ptr(scale_out), _lib.current_stream(dev)))
+        return dict(x=x, n_accept=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl)
+
+    def fill_noise(self, steps, C, seed=0, walker_offset=0):
+        dz = torch.empty(steps, C, self.D, dtype=torch.float32, device=self.device)
+        u = torch.empty(steps, C, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_mh_fill_noise(_lib.ptr(dz), _lib.ptr(u), steps, C, self.D,
+                                                     int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset),
+                                                     _lib.current_stream(self.device)))
+        return dz, u
+
+
+def loglike(like_id, x_unit, like_scale, device=None):
+    """K6: batched analytic likelihood through safe_loglike (sampler.py:110-133): float64 [N]."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    x = _as_dev_f32(x_unit, device)
+    out = torch.empty(x.shape[0], dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().nnest_loglike(int(like_id), _lib.ptr(x), float(like_scale), _lib.ptr(out), x.shape[0],
+                                             x.shape[1], _lib.current_stream(device)))
+    return out

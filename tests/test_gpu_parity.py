@@ -1,0 +1,209 @@
+"""GPU parity tests: the HIP path (through the C ABI, libnnest_hip.so) against
+  (a) the golden fixtures produced by running the reference (tests/golden/), and
+  (b) the oracle (oracle/, CPU restatement) on the same seeded inputs.
+Run on an MI355X with  pytest -m gpu.  Tolerances are stated next to each check; the reference's own
+bound for this path is 1e-5 on round trips (reference tests/test_flows.py:8, :27-30)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+from oracle import oracle as orc  # noqa: E402  (checker only)
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+FLOW_FILES = sorted(glob.glob(os.path.join(G, 'flow_*.npz')))
+MCMC_FILES = sorted(glob.glob(os.path.join(G, 'mcmc_*.npz')))
+LIKE_NAME = {'Rosenbrock': 'rosenbrock', 'GaussianMix': 'gaussmix', 'Himmelblau': 'himmelblau'}
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b))))
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from nnest_amd import flow
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: the -m gpu tests must run on an MI355X')
+    return flow
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize('path', FLOW_FILES, ids=[os.path.basename(p)[5:-4] for p in FLOW_FILES])
+def test_flow_vs_golden(hip, path):
+    g = np.load(path)
+    D, H, B, L = int(g['D']), int(g['H']), int(g['B']), int(g['L'])
+    nvp = hip.HipNVP(D, H, B, L)
+    x = g['x']
+    for tag in ('init', 'trained'):
+        nvp.load_packed(g['w_' + tag])
+        assert np.array_equal(nvp.store_packed(), g['w_' + tag])
+        z, ldf = nvp.forward(x)
+        # float32 MFMA chains + fast tanh/exp vs torch CPU float32: 2e-5 relative to (1+|v|)
+        assert rel(cpu(z), g['z_' + tag]) < 2e-5
+        assert rel(cpu(ldf), g['ldf_' + tag]) < 2e-5
+        xb, ldi = nvp.inverse(g['z_' + tag])
+        assert rel(cpu(xb), g['xb_' + tag]) < 2e-5
+        assert rel(cpu(ldi), g['ldi_' + tag]) < 2e-5
+        lp = nvp.log_probs(x)
+        assert rel(cpu(lp), g['lp_' + tag]) < 3e-5
+        # the reference's own test (tests/test_flows.py:27-30): signed max of the round trip <= 1e-5
+        xr, ldr = nvp.inverse(z)
+        assert abs(float(torch.max(xr - torch.from_numpy(x).float().cuda()))) <= 1e-5
+        assert abs(float(torch.max(ldr + ldf))) <= 1e-5
+        # conditioning dims of the last block pass through bit-exactly (what makes the inverse exact)
+        z1, _ = nvp.forward(x)
+        assert torch.equal(z, z1)
+
+
+@pytest.mark.parametrize('N', [0, 1, 15, 16, 17, 1000, 4099])
+def test_flow_ragged_sizes_vs_oracle(hip, N):
+    g = np.load(os.path.join(G, 'flow_d50.npz'))
+    nvp = hip.HipNVP(50, 16, 3, 1)
+    nvp.load_packed(g['w_trained'])
+    o = orc.NVP(50, 16, 3, 1, g['w_trained'])
+    rng = np.random.RandomState(N)
+    x = rng.uniform(-1, 1, size=(N, 50)).astype(np.float32)
+    z, ld = nvp.forward(x)
+    assert z.shape == (N, 50) and ld.shape == (N,)
+    if N == 0:
+        return
+    zo, ldo = o.forward(x)
+    assert rel(cpu(z), zo) < 2e-5 and rel(cpu(ld), ldo) < 2e-5
+    xi, ldi = nvp.inverse(zo)
+    xo, ldio = o.inverse(zo)
+    assert rel(cpu(xi), xo) < 2e-5 and rel(cpu(ldi), ldio) < 2e-5
+    assert rel(cpu(nvp.log_probs(x)), o.log_probs(x)) < 3e-5
+
+
+def test_likelihoods_vs_golden(hip):
+    g = np.load(os.path.join(G, 'like.npz'))
+    keys = sorted(set(k[:-4] for k in g.files if k.endswith('_x64')))
+    for key in keys:
+        name = key.split('_d')[0]
+        x32 = g[key + '_x64'].astype(np.float32)
+        scale = float(g[key + '_scale'])
+        got = cpu(hip.loglike(hip._lib.LIKE_IDS[name], x32, scale))
+        ref = g[key + '_l32']  # the reference's value on float32 inputs (what _mcmc_sample computes)
+        # terms are float32 like the reference; the sum is float64 here and float32 there, so agreement is
+        # float32 rounding of a sum of same-sign terms: 2e-6 relative
+        np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-5)
+        # and against the float64 evaluation of the same float32 inputs (oracle, exact arithmetic)
+        exact = orc.loglike(name, x32.astype(np.float64), scale)
+        np.testing.assert_allclose(got, exact, rtol=1e-6, atol=1e-5)
+
+
+def test_fused_inverse_prior_loglike_vs_oracle(hip):
+    g = np.load(os.path.join(G, 'mcmc_rosen_d50.npz'))
+    nvp = hip.HipNVP(50, 16, 3, 1)
+    nvp.load_packed(g['w'])
+    o = orc.NVP(50, 16, 3, 1, g['w'])
+    rng = np.random.RandomState(3)
+    z = (rng.normal(size=(777, 50)) * 0.8).astype(np.float32)
+    x, ld, logl, inbox = nvp.inverse_loglike(0, 5.0, z)
+    xo, ldo = o.inverse(z)
+    assert rel(cpu(x), xo) < 2e-5 and rel(cpu(ld), ldo) < 2e-5
+    # prior flag: compare on the GPU's own x (a coordinate within 1e-6 of the box edge may differ otherwise)
+    flag = orc.prior_inbox(cpu(x))
+    assert np.array_equal(cpu(inbox) == 1, flag == 0)
+    assert 0 < int(cpu(inbox).sum()) < 777
+    lo = orc.loglike('rosenbrock', cpu(x), 5.0)
+    np.testing.assert_allclose(cpu(logl), lo, rtol=2e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize('path', MCMC_FILES, ids=[os.path.basename(p)[5:-4] for p in MCMC_FILES])
+def test_mh_trace_vs_golden_recorded_noise(hip, path):
+    """Sampler._mcmc_sample with the reference's own recorded torch noise: every accept/reject decision
+    and every intermediate state must match the reference trace."""
+    g = np.load(path)
+    D = int(g['D'])
+    nvp = hip.HipNVP(D, int(g['H']), int(g['B']), int(g['L']))
+    nvp.load_packed(g['w'])
+    like = LIKE_NAME[str(g['like'])]
+    S, C, _ = g['dz'].shape
+    z, _ = nvp.forward(g['init'])           # sampler.py:264
+    logl = torch.from_numpy(g['init_logl']).cuda().contiguous()
+    res = nvp.mh_steps(hip._lib.LIKE_IDS[like], float(g['scale']), z, logl, float(g['loglstar']), float(g['step']), S,
+                       dynamic=bool(g['dynamic']), noise=(torch.from_numpy(g['dz']), torch.from_numpy(g['u'])),
+                       history=True)
+    assert int(res['n_call'].sum()) == int(g['ncall'])
+    assert int(res['n_accept'].sum()) == int(g['total_accepted'])
+    assert rel(cpu(res['hist_x']), g['samples']) < 3e-5
+    assert rel(cpu(res['hist_logl']), g['loglikes']) < 3e-5
+    assert rel(cpu(res['x']), g['samples'][:, -1]) < 3e-5
+    assert rel(cpu(z), g['latent'][:, -1]) < 3e-5
+    assert rel(cpu(logl), g['loglikes'][:, -1]) < 3e-5
+    # C <= 16 walkers = one adaptation group = the reference's global rule (sampler.py:422-431)
+    assert abs(float(res['scale'][0]) - float(g['scale_out'])) < 1e-6 * max(1.0, float(g['scale_out']))
+
+
+@pytest.mark.parametrize('C,S,dyn', [(1000, 40, False), (37, 25, True), (16, 60, True)])
+def test_mh_inkernel_noise_vs_oracle(hip, C, S, dyn):
+    """In-kernel Philox noise: export the same draws with nnest_mh_fill_noise, replay them through the
+    oracle, compare the whole chain.  Per-group step adaptation = the oracle run per 16-walker group."""
+    g = np.load(os.path.join(G, 'mcmc_rosen_d50.npz'))
+    D = 50
+    nvp = hip.HipNVP(D, 16, 3, 1)
+    nvp.load_packed(g['w'])
+    o = orc.NVP(D, 16, 3, 1, g['w'])
+    rng = np.random.RandomState(C)
+    init = g['init'][rng.randint(0, g['init'].shape[0], size=C)]
+    init_logl = orc.loglike('rosenbrock', init, 5.0)
+    loglstar = float(np.min(init_logl)) - 1e3
+    step = 0.05
+    seed, off = 1234567, 1000
+    dz, u = nvp.fill_noise(S, C, seed=seed, walker_offset=off)
+    dzc, uc = cpu(dz), cpu(u)
+    # noise sanity: N(0,1) and U[0,1)
+    assert abs(dzc.mean()) < 0.02 and abs(dzc.std() - 1) < 0.02 and 0 <= uc.min() and uc.max() < 1
+    z, _ = nvp.forward(init)
+    logl = torch.from_numpy(init_logl).cuda()
+    res = nvp.mh_steps(0, 5.0, z, logl, loglstar, step, S, dynamic=dyn, seed=seed, walker_offset=off, history=True)
+    hx, hl = cpu(res['hist_x']), cpu(res['hist_logl'])
+    n_bad = 0
+    for g0 in range(0, C, 16):
+        sl = slice(g0, min(g0 + 16, C))
+        so, _, lo, sc, ncall, (acc, rej) = orc.mcmc_sample(o, 'rosenbrock', 5.0, init[sl], init_logl[sl], loglstar, step,
+                                                           dyn, dzc[:, sl], uc[:, sl])
+        same = (int(res['n_call'][sl].sum()) == ncall) and (int(res['n_accept'][sl].sum()) == acc)
+        if same:
+            assert rel(hx[sl], so) < 5e-5
+            assert rel(hl[sl], lo) < 5e-5
+            assert abs(float(res['scale'][g0 // 16]) - sc) < 1e-5 * max(1.0, sc)
+        else:
+            n_bad += 1  # a borderline u<ratio / logl>loglstar decision flipped by float32 rounding
+    assert n_bad <= max(1, (C // 16) // 20)
+    assert int(res['n_accept'].sum()) > 0
+
+
+def test_mh_in_kernel_noise_reproducible_and_sharded(hip):
+    """Same (seed, walker_offset) -> identical chains; a shard [a,b) run with walker_offset=a equals
+    the slice of the full run (what makes multi-GPU sharding replica-free)."""
+    g = np.load(os.path.join(G, 'mcmc_rosen_d50.npz'))
+    nvp = hip.HipNVP(50, 16, 3, 1)
+    nvp.load_packed(g['w'])
+    C = 96
+    init = g['init'][np.arange(C) % g['init'].shape[0]]
+    init_logl = orc.loglike('rosenbrock', init, 5.0)
+
+    def run(lo, hi, off):
+        z, _ = nvp.forward(init[lo:hi])
+        logl = torch.from_numpy(init_logl[lo:hi]).cuda()
+        nvp.mh_steps(0, 5.0, z, logl, -1e9, 0.03, 30, seed=99, walker_offset=off)
+        return cpu(z), cpu(logl)
+
+    za, la = run(0, C, 0)
+    zb, lb = run(0, C, 0)
+    assert np.array_equal(za, zb) and np.array_equal(la, lb)
+    zc, lc = run(32, 64, 32)
+    assert np.array_equal(zc, za[32:64]) and np.array_equal(lc, la[32:64])
+    assert not np.array_equal(za, cpu(nvp.forward(init)[0]))
