@@ -130,21 +130,31 @@ int nnest_mh_fill_noise(float *dz_dev, float *u_dev, int steps, int C, int D, ui
  *              in perm order (torch.randn_like(data), trainer.py:392)
  *   losses_dev optional float32 [max_epochs, 2]: (train, validation) loss per epoch, normalised as the
  *              reference logs them (/len(dataset), trainer.py:403, :418)
- *   result_dev int32 [4] + float [..]: see nnest_train_result_t
+ *   result_dev see nnest_train_result_t (device memory; in/out when NNEST_TRAIN_RESUME is set)
+ *   epoch_offset, flags: a long train() may be issued as several launches ("chunks") so that the shuffle
+ *              table stays small: chunk k passes epoch_offset = epochs already run and NNEST_TRAIN_RESUME,
+ *              which continues the early-stopping state held in result_dev and the best-weights snapshot;
+ *              NNEST_TRAIN_FINALIZE (last chunk) restores the best-validation weights (trainer.py:241); that
+ *              restore also happens whenever patience runs out.  A single-launch train() passes
+ *              epoch_offset 0 and flags = NNEST_TRAIN_FINALIZE.
  * Adam moments and step count persist in the handle across calls (optimizer is created once,
- * trainer.py:121-122).  On return (stream order) the handle's weights are the best-validation weights.
+ * trainer.py:121-122).
  */
 typedef struct {
-    int epochs_run;
-    int best_epoch;
+    int epochs_run;             /* total epochs run so far (including previous chunks) */
+    int best_epoch;             /* 1-based epoch of the best validation loss (trainer.py:206) */
     float best_validation_loss;
     float last_train_loss;
+    int counter;                /* epochs since the last improvement (trainer.py:209, :223) */
+    int stopped;                /* 1 when counter > patience ended the run (trainer.py:225) */
 } nnest_train_result_t;
+
+enum { NNEST_TRAIN_RESUME = 1, NNEST_TRAIN_FINALIZE = 2 };
 
 int nnest_nvp_train(nnest_nvp_t *nvp, const float *xtrain_dev, int n_train, const float *xvalid_dev, int n_valid,
                     const int *perm_dev, const float *noise_dev, uint64_t seed, float jitter, int batch,
-                    int max_epochs, int patience, float lr, float weight_decay, float *losses_dev,
-                    nnest_train_result_t *result_dev, void *stream);
+                    int max_epochs, int patience, float lr, float weight_decay, int epoch_offset, int flags,
+                    float *losses_dev, nnest_train_result_t *result_dev, void *stream);
 
 /* One minibatch: loss and dloss/dw (before weight decay) into grad_dev [num_params], no update.
  * For tests (reference: loss.backward(), trainer.py:400). x_dev [M,D]. loss_dev float32[1]. */

@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_HERE, 'libnnest_hip.so')
 NNEST_OK = 0
 LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'himmelblau': 2}
 MH_DYNAMIC_STEP = 1
+TRAIN_RESUME = 1
+TRAIN_FINALIZE = 2
 
 
 class NnestHipError(RuntimeError):
@@ -25,7 +27,8 @@ class NnestHipError(RuntimeError):
 
 class TrainResult(ctypes.Structure):
     _fields_ = [('epochs_run', ctypes.c_int), ('best_epoch', ctypes.c_int),
-                ('best_validation_loss', ctypes.c_float), ('last_train_loss', ctypes.c_float)]
+                ('best_validation_loss', ctypes.c_float), ('last_train_loss', ctypes.c_float),
+                ('counter', ctypes.c_int), ('stopped', ctypes.c_int)]
 
 
 _vp = ctypes.c_void_p
@@ -57,7 +60,7 @@ SIGNATURES = {
                                    _vp, _vp, _vp, _vp, _vp, _vp],
     'nnest_mh_num_groups': [_vp, _i],
     'nnest_mh_fill_noise': [_vp, _vp, _i, _i, _i, _u64, _u64, _vp],
-    'nnest_nvp_train': [_vp, _vp, _i, _vp, _i, _vp, _vp, _u64, _f, _i, _i, _i, _f, _f, _vp, _vp, _vp],
+    'nnest_nvp_train': [_vp, _vp, _i, _vp, _i, _vp, _vp, _u64, _f, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp],
     'nnest_nvp_loss_grad': [_vp, _vp, _i, _vp, _vp, _vp],
     'nnest_training_jitter': [_vp, _i, _i, _vp, _vp],
 }

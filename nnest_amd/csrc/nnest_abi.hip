@@ -265,8 +265,8 @@ int nnest_mh_fill_noise(float *dz_dev, float *u_dev, int steps, int C, int D, ui
 
 int nnest_nvp_train(nnest_nvp_t *h, const float *xtrain_dev, int n_train, const float *xvalid_dev, int n_valid,
                     const int *perm_dev, const float *noise_dev, uint64_t seed, float jitter, int batch,
-                    int max_epochs, int patience, float lr, float weight_decay, float *losses_dev,
-                    nnest_train_result_t *result_dev, void *stream) {
+                    int max_epochs, int patience, float lr, float weight_decay, int epoch_offset, int flags,
+                    float *losses_dev, nnest_train_result_t *result_dev, void *stream) {
     if (!h) return fail(NNEST_E_ARG, "NULL handle");
     if (!xtrain_dev || !xvalid_dev || !perm_dev || !result_dev) return fail(NNEST_E_ARG, "NULL device buffer");
     if (n_train < 1 || n_valid < 1 || batch < 1 || max_epochs < 0)
@@ -274,14 +274,14 @@ int nnest_nvp_train(nnest_nvp_t *h, const float *xtrain_dev, int n_train, const 
     if (batch > 128) return fail(NNEST_E_UNSUPPORTED, "batch_size=%d > 128 (one workgroup holds a minibatch)", batch);
     HIP_TRY(launch_train(h->w, h->adam_m, h->adam_v, h->best_w, h->img, h->adam_step, h->s, xtrain_dev, n_train, xvalid_dev,
                          n_valid, perm_dev, noise_dev, seed, jitter, batch, max_epochs, patience, lr, weight_decay,
-                         losses_dev, result_dev, h->train_ws, (hipStream_t)stream));
+                         epoch_offset, flags, losses_dev, result_dev, h->train_ws, (hipStream_t)stream));
     return NNEST_OK;
 }
 
 int nnest_nvp_loss_grad(nnest_nvp_t *h, const float *x_dev, int M, float *grad_dev, float *loss_dev, void *stream) {
     if (!h || !x_dev || !grad_dev || !loss_dev) return fail(NNEST_E_ARG, "NULL argument");
     if (M < 1 || M > 128) return fail(NNEST_E_UNSUPPORTED, "M=%d outside [1,128]", M);
-    HIP_TRY(launch_loss_grad(h->w, h->s, x_dev, M, grad_dev, loss_dev, h->train_ws, (hipStream_t)stream));
+    HIP_TRY(launch_loss_grad(h->w, h->s, x_dev, M, grad_dev, loss_dev, h->train_ws, h->img, (hipStream_t)stream));
     return NNEST_OK;
 }
 

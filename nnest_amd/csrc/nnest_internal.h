@@ -25,12 +25,13 @@ int mh_num_groups(int C);
 // training (nnest_train.hip)
 struct TrainArgs;
 hipError_t launch_loss_grad(const float *packed, const FlowShape &s, const float *x, int M, float *grad, float *loss,
-                            float *workspace, hipStream_t st);
+                            float *workspace, float *img_fwd, hipStream_t st);
 size_t train_workspace_floats(const FlowShape &s, int batch);
 hipError_t launch_train(float *packed, float *adam_m, float *adam_v, float *best_w, float *img, int *adam_step_dev,
                         const FlowShape &s, const float *xtrain, int n_train, const float *xvalid, int n_valid,
                         const int *perm, const float *noise, uint64_t seed, float jitter, int batch, int max_epochs,
-                        int patience, float lr, float wd, float *losses, nnest_train_result_t *result, float *workspace,
+                        int patience, float lr, float wd, int epoch_offset, int flags, float *losses, nnest_train_result_t *result,
+                        float *workspace,
                         hipStream_t st);
 hipError_t launch_training_jitter(const double *samples, int N, int D, double *out, hipStream_t st);
 

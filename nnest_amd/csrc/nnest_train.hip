@@ -1,9 +1,644 @@
-// nnest_train.hip -- training-side kernels (placeholder while the inference path is brought up)
+// nnest_train.hip -- K5: Trainer.train's epoch loop (reference nnest/trainer.py:134-245, :384-418) as ONE
+// persistent single-workgroup kernel on gfx950: forward, hand-written backward, Adam, validation, early
+// stopping and best-model restore all on device; the host only launches and reads the result struct.
+//
+// Why one workgroup: a minibatch is 100 rows x ~12.7 kFLOP x 3 (fwd + recompute + bwd) = 4 MFLOP, and the
+// Adam steps are strictly sequential (9 per epoch at 1000 live points), so the loop is latency-bound; a
+// grid barrier (>= 4 us, MI355X_MICROARCH.md "barrier-xcd") per phase would cost more than the phase.
+//
+// Per minibatch (M <= 128 rows = up to 8 row tiles of 16, one wave each):
+//   A  row-tile waves: forward (same MFMA tile code as inference) -> per-row log_prob, loss;
+//      backward block by block WITHOUT stored activations: a coupling block is invertible, so its input
+//      is recovered from its output ((y - t) e^{-ls}) after recomputing the two MLPs from the untouched
+//      conditioning half; delta-propagation uses transposed weight fragments (the "backward image").
+//      For each (block, net) the per-row gradients G and activations are staged in LDS as [row][16].
+//   B  tile-owner waves: dW[out,in] = sum_rows G[row,out] * Act[row,in] as MFMA 16x16x4 over all rows
+//      (A and B operands are both plain [row][16] LDS reads; biases use B = 1), scattered into the
+//      packed gradient vector.  No atomics: every gradient element has exactly one producer, so training
+//      is bitwise reproducible (which is what lets every rank of a multi-GPU run train an identical
+//      replica with no weight broadcast).
+//   C  all threads: Adam with coupled weight decay over the packed vector (torch.optim.Adam,
+//      trainer.py:121-122), then rebuild the forward + backward fragment images.
+#include <string.h>
 #include "nnest_internal.h"
 
 namespace nnest {
 
-// training jitter (trainer.py:168-171): 0.2 * mean over both columns of cKDTree(samples).query(samples, 2)
+enum { TRAIN_MODE_EPOCHS = 0, TRAIN_MODE_GRAD_ONLY = 1 };
+static const int TRAIN_THREADS = 512;  // 8 waves
+static const int TRAIN_WAVES = 8;
+static const int TRAIN_MAX_ROWS = 128;
+
+struct TrainArgs {
+    float *w, *m, *v, *best_w, *img_fwd, *img_bwd, *grad;
+    int *adam_step;
+    FlowShape s;
+    const float *xtrain;
+    int n_train;
+    const float *xvalid;
+    int n_valid;
+    const int *perm;
+    const float *noise;
+    uint64_t seed;
+    float jitter;
+    int batch, max_epochs, patience;
+    float lr, wd;
+    float *losses;
+    nnest_train_result_t *result;
+    float *loss_out;
+    int mode;
+    int epoch_offset, flags;
+};
+
+// ---- fragment images -----------------------------------------------------------------------------------
+// forward image element (same definition as repack_fragments_kernel in nnest_kernels.hip)
+__device__ __forceinline__ float fwd_image_elem(const float *__restrict__ packed, const FlowShape &s, int idx) {
+    const int NT = s.NT, NH = s.NH, L = s.L, D = s.D, H = s.H;
+    int bn = idx / s.net_floats, o = idx - bn * s.net_floats;
+    int b = bn >> 1, net = bn & 1;
+    const float *p = packed + ((size_t)b * 2 + net) * s.net_params;
+    const int pc = (b + 1) & 1, pt = b & 1;
+    const int pb0 = H * D, phid = H * D + H, pWo = H * D + H + L * (H * H + H), pbo = pWo + D * H;
+    if (o < frag_off_L2(NT, NH)) {
+        int lane = o & 63, q = o >> 6, r = q & 3, tau = (q >> 2) % NT, ht = (q >> 2) / NT;
+        int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + 4 * g + r) + pc;
+        return d < D ? p[(16 * ht + i) * D + d] : 0.f;
+    } else if (o < frag_off_L3(NT, NH, L)) {
+        int oo = o - frag_off_L2(NT, NH);
+        int lane = oo & 63, q = oo >> 6, r = q & 3, hti = (q >> 2) % NH, hto = ((q >> 2) / NH) % NH, l = (q >> 2) / (NH * NH);
+        int g = lane >> 4, i = lane & 15;
+        return p[phid + l * (H * H + H) + (16 * hto + i) * H + 16 * hti + 4 * g + r];
+    } else if (o < frag_off_b1(NT, NH, L)) {
+        int oo = o - frag_off_L3(NT, NH, L);
+        int lane = oo & 63, q = oo >> 6, r = q & 3, ht = (q >> 2) % NH, tau = (q >> 2) / NH;
+        int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + i) + pt;
+        return d < D ? p[pWo + d * H + 16 * ht + 4 * g + r] : 0.f;
+    } else if (o < frag_off_b2(NT, NH, L)) {
+        return p[pb0 + (o - frag_off_b1(NT, NH, L))];
+    } else if (o < frag_off_b3(NT, NH, L)) {
+        int oo = o - frag_off_b2(NT, NH, L), l = oo / (16 * NH), j = oo % (16 * NH);
+        return p[phid + l * (H * H + H) + H * H + j];
+    } else {
+        int sl = o - frag_off_b3(NT, NH, L), d = 2 * sl + pt;
+        return d < D ? p[pbo + d] : 0.f;
+    }
+}
+
+// backward image: transposed A-fragments, same region sizes as the forward image (no biases used)
+//   region L1-sized  B3 [ht][tau][r][lane]   g_h[ht]   += Wout^T : lane(g,i) = Wout[dim(16tau+4g+r)][16ht+i]
+//   region L2-sized  B2 [l][hti][hto][r][lane] g_h[hti] += W_l^T : lane(g,i) = W_l[16hto+4g+r][16hti+i]
+//   region L3-sized  B1 [tau][ht][r][lane]   g_m[tau]  += W0^T   : lane(g,i) = W0[16ht+4g+r][dim(16tau+i)]
+__device__ __forceinline__ float bwd_image_elem(const float *__restrict__ packed, const FlowShape &s, int idx) {
+    const int NT = s.NT, NH = s.NH, L = s.L, D = s.D, H = s.H;
+    int bn = idx / s.net_floats, o = idx - bn * s.net_floats;
+    int b = bn >> 1, net = bn & 1;
+    const float *p = packed + ((size_t)b * 2 + net) * s.net_params;
+    const int pc = (b + 1) & 1, pt = b & 1;
+    const int phid = H * D + H, pWo = H * D + H + L * (H * H + H);
+    if (o < frag_off_L2(NT, NH)) {
+        int lane = o & 63, q = o >> 6, r = q & 3, tau = (q >> 2) % NT, ht = (q >> 2) / NT;
+        int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + 4 * g + r) + pt;
+        return d < D ? p[pWo + d * H + 16 * ht + i] : 0.f;
+    } else if (o < frag_off_L3(NT, NH, L)) {
+        int oo = o - frag_off_L2(NT, NH);
+        int lane = oo & 63, q = oo >> 6, r = q & 3, hto = (q >> 2) % NH, hti = ((q >> 2) / NH) % NH, l = (q >> 2) / (NH * NH);
+        int g = lane >> 4, i = lane & 15;
+        return p[phid + l * (H * H + H) + (16 * hto + 4 * g + r) * H + 16 * hti + i];
+    } else if (o < frag_off_b1(NT, NH, L)) {
+        int oo = o - frag_off_L3(NT, NH, L);
+        int lane = oo & 63, q = oo >> 6, r = q & 3, ht = (q >> 2) % NH, tau = (q >> 2) / NH;
+        int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + i) + pc;
+        return d < D ? p[(16 * ht + 4 * g + r) * D + d] : 0.f;
+    }
+    return 0.f;
+}
+
+__device__ __forceinline__ void rebuild_images(const TrainArgs &a) {
+    for (int i = threadIdx.x; i < a.s.image_floats; i += blockDim.x) {
+        a.img_fwd[i] = fwd_image_elem(a.w, a.s, i);
+        a.img_bwd[i] = bwd_image_elem(a.w, a.s, i);
+    }
+}
+
+// ---- MLP forward keeping the hidden activations (for the backward pass) ---------------------------------
+template <int NT, int NH, int L, int ACT>
+__device__ __forceinline__ void mlp_fwd_keep(const float *__restrict__ wn, int lane, const f32x4 (&in)[NT],
+                                             f32x4 (&acts)[L + 1][NH], f32x4 (&out)[NT]) {
+    const int g4 = (lane >> 4) * 4;
+    const float *fL1 = wn + frag_off_L1() + lane;
+    const float *fL2 = wn + frag_off_L2(NT, NH) + lane;
+    const float *fL3 = wn + frag_off_L3(NT, NH, L) + lane;
+    const float *b1 = wn + frag_off_b1(NT, NH, L) + g4;
+    const float *b2 = wn + frag_off_b2(NT, NH, L) + g4;
+    const float *b3 = wn + frag_off_b3(NT, NH, L) + g4;
+#pragma unroll
+    for (int ht = 0; ht < NH; ++ht) {
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(b1 + 16 * ht);
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            const float *f = fL1 + ((ht * NT + tau) * 4) * 64;
+            acc = mfma4(f[0], in[tau].x, acc);
+            acc = mfma4(f[64], in[tau].y, acc);
+            acc = mfma4(f[128], in[tau].z, acc);
+            acc = mfma4(f[192], in[tau].w, acc);
+        }
+        acts[0][ht] = activate<ACT>(acc);
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+        for (int hto = 0; hto < NH; ++hto) {
+            f32x4 acc = *reinterpret_cast<const f32x4 *>(b2 + (l * NH + hto) * 16);
+#pragma unroll
+            for (int hti = 0; hti < NH; ++hti) {
+                const float *f = fL2 + (((l * NH + hto) * NH + hti) * 4) * 64;
+                acc = mfma4(f[0], acts[l][hti].x, acc);
+                acc = mfma4(f[64], acts[l][hti].y, acc);
+                acc = mfma4(f[128], acts[l][hti].z, acc);
+                acc = mfma4(f[192], acts[l][hti].w, acc);
+            }
+            acts[l + 1][hto] = activate<ACT>(acc);
+        }
+    }
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(b3 + 16 * tau);
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) {
+            const float *f = fL3 + ((tau * NH + ht) * 4) * 64;
+            acc = mfma4(f[0], acts[L][ht].x, acc);
+            acc = mfma4(f[64], acts[L][ht].y, acc);
+            acc = mfma4(f[128], acts[L][ht].z, acc);
+            acc = mfma4(f[192], acts[L][ht].w, acc);
+        }
+        out[tau] = acc;
+    }
+}
+
+template <int ACT>
+__device__ __forceinline__ f32x4 act_grad(f32x4 g, f32x4 a) {  // g * act'(pre), written with the post-activation a
+    f32x4 o;
+    if (ACT == 0) {  // tanh' = 1 - a^2
+        o.x = g.x * (1.f - a.x * a.x); o.y = g.y * (1.f - a.y * a.y);
+        o.z = g.z * (1.f - a.z * a.z); o.w = g.w * (1.f - a.w * a.w);
+    } else {  // relu' = [a > 0]
+        o.x = a.x > 0.f ? g.x : 0.f; o.y = a.y > 0.f ? g.y : 0.f;
+        o.z = a.z > 0.f ? g.z : 0.f; o.w = a.w > 0.f ? g.w : 0.f;
+    }
+    return o;
+}
+
+// staging: column tile ct of the (block, net) being processed = [rows][16] floats
+__device__ __forceinline__ void stage_tile(float *stg, int rows_pad, int ct, int row, int lane, f32x4 v) {
+    // lane (g,w) holds features 4g..4g+3 of row w -> 16 contiguous bytes of that row
+    *reinterpret_cast<f32x4 *>(stg + ((size_t)ct * rows_pad + row) * 16 + (lane >> 4) * 4) = v;
+}
+
+// column-tile map of the staging area for one net
+template <int NT, int NH, int L> struct StageMap {
+    static constexpr int gout(int tau) { return tau; }
+    static constexpr int gpre(int l, int ht) { return NT + l * NH + ht; }
+    static constexpr int act(int l, int ht) { return NT + (L + 1) * NH + l * NH + ht; }
+    static constexpr int m(int tau) { return NT + 2 * (L + 1) * NH + tau; }
+    static constexpr int count = 2 * NT + 2 * (L + 1) * NH;
+};
+
+// backward through one MLP; stages G tiles and activations; returns g_m (gradient wrt the conditioning inputs)
+template <int NT, int NH, int L, int ACT>
+__device__ __forceinline__ void mlp_bwd(const float *__restrict__ bn, int lane, float *stg, int rows_pad, int row,
+                                        const f32x4 (&g_out)[NT], const f32x4 (&acts)[L + 1][NH], f32x4 (&g_m)[NT]) {
+    typedef StageMap<NT, NH, L> SM;
+    const float *B3 = bn + frag_off_L1() + lane;
+    const float *B2 = bn + frag_off_L2(NT, NH) + lane;
+    const float *B1 = bn + frag_off_L3(NT, NH, L) + lane;
+    f32x4 gh[NH];
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) stage_tile(stg, rows_pad, SM::gout(tau), row, lane, g_out[tau]);
+#pragma unroll
+    for (int ht = 0; ht < NH; ++ht) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            const float *f = B3 + ((ht * NT + tau) * 4) * 64;
+            acc = mfma4(f[0], g_out[tau].x, acc);
+            acc = mfma4(f[64], g_out[tau].y, acc);
+            acc = mfma4(f[128], g_out[tau].z, acc);
+            acc = mfma4(f[192], g_out[tau].w, acc);
+        }
+        gh[ht] = acc;
+    }
+#pragma unroll
+    for (int l = L; l >= 1; --l) {
+        f32x4 gpre[NH];
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) {
+            gpre[ht] = act_grad<ACT>(gh[ht], acts[l][ht]);
+            stage_tile(stg, rows_pad, SM::gpre(l, ht), row, lane, gpre[ht]);
+            stage_tile(stg, rows_pad, SM::act(l, ht), row, lane, acts[l][ht]);
+        }
+#pragma unroll
+        for (int hti = 0; hti < NH; ++hti) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hto = 0; hto < NH; ++hto) {
+                const float *f = B2 + ((((l - 1) * NH + hti) * NH + hto) * 4) * 64;
+                acc = mfma4(f[0], gpre[hto].x, acc);
+                acc = mfma4(f[64], gpre[hto].y, acc);
+                acc = mfma4(f[128], gpre[hto].z, acc);
+                acc = mfma4(f[192], gpre[hto].w, acc);
+            }
+            gh[hti] = acc;
+        }
+    }
+    f32x4 gpre0[NH];
+#pragma unroll
+    for (int ht = 0; ht < NH; ++ht) {
+        gpre0[ht] = act_grad<ACT>(gh[ht], acts[0][ht]);
+        stage_tile(stg, rows_pad, SM::gpre(0, ht), row, lane, gpre0[ht]);
+        stage_tile(stg, rows_pad, SM::act(0, ht), row, lane, acts[0][ht]);
+    }
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) {
+            const float *f = B1 + ((tau * NH + ht) * 4) * 64;
+            acc = mfma4(f[0], gpre0[ht].x, acc);
+            acc = mfma4(f[64], gpre0[ht].y, acc);
+            acc = mfma4(f[128], gpre0[ht].z, acc);
+            acc = mfma4(f[192], gpre0[ht].w, acc);
+        }
+        g_m[tau] = acc;
+    }
+}
+
+// ---- phase B: one dW tile = sum over rows of G[row][16] (x) Act[row][16] ----------------------------------
+__device__ __forceinline__ f32x4 contract_rows(const float *stg, int rows_pad, int ct_g, int ct_a, int lane) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float *G = stg + (size_t)ct_g * rows_pad * 16 + (lane >> 4) * 16 + (lane & 15);
+    if (ct_a >= 0) {
+        const float *A = stg + (size_t)ct_a * rows_pad * 16 + (lane >> 4) * 16 + (lane & 15);
+        for (int r4 = 0; r4 < rows_pad; r4 += 4) acc = mfma4(G[r4 * 16], A[r4 * 16], acc);
+    } else {
+        for (int r4 = 0; r4 < rows_pad; r4 += 4) acc = mfma4(G[r4 * 16], 1.0f, acc);  // bias: Act = 1
+    }
+    return acc;  // lane (gq, j) reg r  <->  (out feature 4*gq + r, in feature j)
+}
+
+template <int NT, int NH, int L>
+__device__ __forceinline__ void weight_grad_jobs(const TrainArgs &a, const float *stg, int rows_pad, int b, int net,
+                                                 int wave, int lane) {
+    typedef StageMap<NT, NH, L> SM;
+    const int D = a.s.D, H = a.s.H;
+    const int pc = (b + 1) & 1, pt = b & 1;
+    const int pb0 = H * D, phid = H * D + H, pWo = H * D + H + L * (H * H + H), pbo = pWo + D * H;
+    float *gp = a.grad + ((size_t)b * 2 + net) * a.s.net_params;
+    const int gq = lane >> 4, j = lane & 15;
+    constexpr int J_W3 = NT * NH, J_B3 = NT, J_W2 = L * NH * NH, J_B2 = L * NH, J_W1 = NH * NT, J_B1 = NH;
+    constexpr int NJOBS = J_W3 + J_B3 + J_W2 + J_B2 + J_W1 + J_B1;
+    for (int job = wave; job < NJOBS; job += TRAIN_WAVES) {
+        int q = job;
+        if (q < J_W3) {  // dWout[slot][hidden]
+            int tau = q / NH, ht = q % NH;
+            f32x4 t = contract_rows(stg, rows_pad, SM::gout(tau), SM::act(L, ht), lane);
+            float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int d = 2 * (16 * tau + 4 * gq + r) + pt;
+                if (d < D) gp[pWo + d * H + 16 * ht + j] = v[r];
+            }
+            continue;
+        }
+        q -= J_W3;
+        if (q < J_B3) {
+            int tau = q;
+            f32x4 t = contract_rows(stg, rows_pad, SM::gout(tau), -1, lane);
+            float v[4] = {t.x, t.y, t.z, t.w};
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int d = 2 * (16 * tau + 4 * gq + r) + pt;
+                    if (d < D) gp[pbo + d] = v[r];
+                }
+            }
+            continue;
+        }
+        q -= J_B3;
+        if (q < J_W2) {  // hidden layer l = 1..L : dW_l[out][in]
+            int l = q / (NH * NH) + 1, hto = (q / NH) % NH, hti = q % NH;
+            f32x4 t = contract_rows(stg, rows_pad, SM::gpre(l, hto), SM::act(l - 1, hti), lane);
+            float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gp[phid + (l - 1) * (H * H + H) + (16 * hto + 4 * gq + r) * H + 16 * hti + j] = v[r];
+            continue;
+        }
+        q -= J_W2;
+        if (q < J_B2) {
+            int l = q / NH + 1, hto = q % NH;
+            f32x4 t = contract_rows(stg, rows_pad, SM::gpre(l, hto), -1, lane);
+            float v[4] = {t.x, t.y, t.z, t.w};
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gp[phid + (l - 1) * (H * H + H) + H * H + 16 * hto + 4 * gq + r] = v[r];
+            }
+            continue;
+        }
+        q -= J_B2;
+        if (q < J_W1) {  // dW0[hidden][dim]
+            int ht = q / NT, tau = q % NT;
+            f32x4 t = contract_rows(stg, rows_pad, SM::gpre(0, ht), SM::m(tau), lane);
+            float v[4] = {t.x, t.y, t.z, t.w};
+            int d = 2 * (16 * tau + j) + pc;
+            if (d < D) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gp[(16 * ht + 4 * gq + r) * D + d] = v[r];
+            }
+            continue;
+        }
+        q -= J_W1;
+        {
+            int ht = q;
+            f32x4 t = contract_rows(stg, rows_pad, SM::gpre(0, ht), -1, lane);
+            float v[4] = {t.x, t.y, t.z, t.w};
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gp[pb0 + 16 * ht + 4 * gq + r] = v[r];
+            }
+        }
+    }
+}
+
+// ---- one coupling block of the backward pass (on a row tile) -----------------------------------------------
+// On entry: cond / ytrans = the block's OUTPUT halves, gcond / gtrans = dLoss/d(output halves), gld = dLoss/dlogdet.
+// On exit : ytrans = the block's input (recovered through the inverse), gcond / gtrans = dLoss/d(input halves).
+// Staging + weight-gradient jobs for both nets happen inside (4 workgroup barriers).
+template <int NT, int NH, int L>
+__device__ __forceinline__ void block_backward(const TrainArgs &a, float *stg, int rows_pad, int b, int wave, int lane,
+                                               bool tile_active, int row, bool row_ok, const f32x4 (&cond)[NT],
+                                               f32x4 (&ytrans)[NT], f32x4 (&gcond)[NT], f32x4 (&gtrans)[NT], float gld) {
+    typedef StageMap<NT, NH, L> SM;
+    const int pt = b & 1;
+    const float *wf = a.img_fwd + (size_t)b * 2 * a.s.net_floats;
+    const float *wb = a.img_bwd + (size_t)b * 2 * a.s.net_floats;
+    f32x4 as[L + 1][NH], at[L + 1][NH], ls[NT], t[NT], g_ls[NT], g_t[NT], gm_s[NT], gm_t[NT];
+    const int g = lane >> 4;
+    if (tile_active) {
+        mlp_fwd_keep<NT, NH, L, 0>(wf, lane, cond, as, ls);
+        mlp_fwd_keep<NT, NH, L, 1>(wf + a.s.net_floats, lane, cond, at, t);
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            float lsv[4] = {ls[tau].x, ls[tau].y, ls[tau].z, ls[tau].w};
+            float tv[4] = {t[tau].x, t[tau].y, t[tau].z, t[tau].w};
+            float yv[4] = {ytrans[tau].x, ytrans[tau].y, ytrans[tau].z, ytrans[tau].w};
+            float gv[4] = {gtrans[tau].x, gtrans[tau].y, gtrans[tau].z, gtrans[tau].w};
+            float o_gls[4], o_gt[4], o_x[4], o_gx[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 2 * (16 * tau + 4 * g + r) + pt;
+                const bool valid = row_ok && d < a.s.D;
+                float ymt = yv[r] - tv[r];                 // = x_in * e^{ls}
+                o_gls[r] = valid ? gv[r] * ymt + gld : 0.f;  // y = x e^{ls} + t ; logdet += ls
+                o_gt[r] = valid ? gv[r] : 0.f;
+                o_x[r] = ymt * __expf(-lsv[r]);            // block input (networks.py:307-309)
+                o_gx[r] = gv[r] * __expf(lsv[r]);          // direct path dy/dx
+            }
+            g_ls[tau] = (f32x4){o_gls[0], o_gls[1], o_gls[2], o_gls[3]};
+            g_t[tau] = (f32x4){o_gt[0], o_gt[1], o_gt[2], o_gt[3]};
+            ytrans[tau] = (f32x4){o_x[0], o_x[1], o_x[2], o_x[3]};
+            gtrans[tau] = (f32x4){o_gx[0], o_gx[1], o_gx[2], o_gx[3]};
+        }
+        // scale net: stage G, activations and the shared conditioning input m
+        mlp_bwd<NT, NH, L, 0>(wb, lane, stg, rows_pad, row, g_ls, as, gm_s);
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            f32x4 mv = cond[tau];
+            if (!row_ok) mv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            stage_tile(stg, rows_pad, SM::m(tau), row, lane, mv);
+        }
+    }
+    __syncthreads();
+    weight_grad_jobs<NT, NH, L>(a, stg, rows_pad, b, 0, wave, lane);
+    __syncthreads();
+    if (tile_active) mlp_bwd<NT, NH, L, 1>(wb + a.s.net_floats, lane, stg, rows_pad, row, g_t, at, gm_t);
+    __syncthreads();
+    weight_grad_jobs<NT, NH, L>(a, stg, rows_pad, b, 1, wave, lane);
+    __syncthreads();
+    if (tile_active) {
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) gcond[tau] = gcond[tau] + gm_s[tau] + gm_t[tau];  // masked_inputs = inputs * mask
+    }
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------------
+template <int NT, int NH, int L>
+__global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float stg[];
+    __shared__ float red[TRAIN_WAVES];
+    __shared__ int ctl[4];      // [0] stop flag, [1] counter, [2] best epoch
+    __shared__ float ctlf[2];   // [0] best validation loss
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = lane & 15, g = lane >> 4;
+    const int D = a.s.D, B = a.s.B;
+    const int np = B * 2 * a.s.net_params;
+    const float half_log_2pi = 0.91893853320467274f;
+
+    rebuild_images(a);
+    if (a.mode == TRAIN_MODE_GRAD_ONLY)
+        for (int i = threadIdx.x; i < np; i += blockDim.x) a.grad[i] = 0.f;
+    const bool resume = a.mode == TRAIN_MODE_EPOCHS && (a.flags & NNEST_TRAIN_RESUME);
+    if (threadIdx.x == 0) {
+        ctl[0] = 0;
+        ctl[1] = resume ? a.result->counter : 0;
+        ctl[2] = resume ? a.result->best_epoch : 0;
+        ctlf[0] = resume ? a.result->best_validation_loss : INFINITY;
+    }
+    if (a.mode == TRAIN_MODE_EPOCHS)
+        for (int i = threadIdx.x; i < np; i += blockDim.x) {
+            if (!resume) a.best_w[i] = a.w[i];  // best_model = deepcopy(netG)  trainer.py:194
+            a.grad[i] = 0.f;
+        }
+    __syncthreads();
+
+    const int n_mb = a.mode == TRAIN_MODE_GRAD_ONLY ? 1 : (a.n_train + a.batch - 1) / a.batch;
+    const int n_epochs = a.mode == TRAIN_MODE_GRAD_ONLY ? 1 : a.max_epochs;
+    int adam_t = a.adam_step ? *a.adam_step : 0;
+    int epochs_run = 0;
+    float last_train_loss = 0.f;
+
+    for (int epoch = 0; epoch < n_epochs; ++epoch) {
+        float epoch_loss = 0.f;  // sum of minibatch means (trainer.py:398)
+        for (int mb = 0; mb < n_mb; ++mb) {
+            const int M = a.mode == TRAIN_MODE_GRAD_ONLY ? a.n_train : min(a.batch, a.n_train - mb * a.batch);
+            const int ntile = (M + 15) >> 4;
+            const int rows_pad = ntile * 16;
+            const bool tile_active = wave < ntile;
+            const int row = wave * 16 + w;  // row inside the minibatch
+            const bool row_ok = tile_active && row < M;
+            f32x4 xs[2][NT], gs[2][NT];
+            float ld = 0.f;
+            if (tile_active) {
+                // data = X[perm] + jitter * randn  (trainer.py:392)
+                long src = 0;
+                if (row_ok) src = a.mode == TRAIN_MODE_GRAD_ONLY ? row : a.perm[(size_t)epoch * a.n_train + mb * a.batch + row];
+                load_tile<NT>(a.xtrain, src, row_ok, D, lane, xs);
+                if (a.mode == TRAIN_MODE_EPOCHS && a.jitter != 0.f) {
+                    const long p = (long)mb * a.batch + row;
+                    if (a.noise) {
+                        f32x4 nz[2][NT];
+                        load_tile<NT>(a.noise + (size_t)epoch * a.n_train * D, p, row_ok, D, lane, nz);
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) xs[c][t] = xs[c][t] + nz[c][t] * a.jitter;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            f32x4 n0 = noise_normal4(a.seed, (uint64_t)p, (uint32_t)(a.epoch_offset + epoch), (uint32_t)(8 * t + 2 * g), NOISE_STREAM_JITTER);
+                            f32x4 n1 = noise_normal4(a.seed, (uint64_t)p, (uint32_t)(a.epoch_offset + epoch), (uint32_t)(8 * t + 2 * g + 1), NOISE_STREAM_JITTER);
+                            const int d0 = 32 * t + 8 * g;
+                            if (row_ok) {
+                                if (d0 + 0 < D) xs[0][t].x += n0.x * a.jitter; if (d0 + 1 < D) xs[1][t].x += n0.y * a.jitter;
+                                if (d0 + 2 < D) xs[0][t].y += n0.z * a.jitter; if (d0 + 3 < D) xs[1][t].y += n0.w * a.jitter;
+                                if (d0 + 4 < D) xs[0][t].z += n1.x * a.jitter; if (d0 + 5 < D) xs[1][t].z += n1.y * a.jitter;
+                                if (d0 + 6 < D) xs[0][t].w += n1.z * a.jitter; if (d0 + 7 < D) xs[1][t].w += n1.w * a.jitter;
+                            }
+                        }
+                    }
+                }
+                ld = group_sum(flow_forward_tile<NT, NH>(a.img_fwd, a.s.net_floats, B, L, lane, xs));
+            }
+            // loss = -mean(log_probs)  (trainer.py:394; networks.py:71-76)
+            float lp = 0.f;
+            if (tile_active) {
+                float ss = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        f32x4 v = xs[c][t];
+                        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    }
+                ss = group_sum(ss);
+                lp = (row_ok && g == 0) ? (-0.5f * ss - half_log_2pi * (float)D + ld) : 0.f;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) lp += __shfl_xor(lp, o);
+            }
+            if (lane == 0) red[wave] = tile_active ? lp : 0.f;
+            __syncthreads();
+            float loss = 0.f;
+            for (int k = 0; k < TRAIN_WAVES; ++k) loss += red[k];
+            loss = -loss / (float)M;
+            epoch_loss += loss;
+            // d(loss)/du = u/M ; d(loss)/d(logdet) = -1/M
+            const float invM = 1.0f / (float)M, gld = -invM;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) gs[c][t] = row_ok ? xs[c][t] * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int b = B - 1; b >= 0; --b) {
+                if (b & 1) block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[0], xs[1], gs[0], gs[1], gld);
+                else       block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[1], xs[0], gs[1], gs[0], gld);
+            }
+            if (a.mode == TRAIN_MODE_GRAD_ONLY) {
+                if (threadIdx.x == 0) *a.loss_out = loss;
+                __syncthreads();
+                return;
+            }
+            // Adam with coupled weight decay (torch/optim/adam.py _single_tensor_adam; trainer.py:121-122)
+            adam_t += 1;
+            {
+                const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+                const double bc1 = 1.0 - pow((double)b1, (double)adam_t), bc2 = 1.0 - pow((double)b2, (double)adam_t);
+                const float step_size = (float)((double)a.lr / bc1), bc2s = (float)sqrt(bc2);
+                for (int i = threadIdx.x; i < np; i += blockDim.x) {
+                    float wi = a.w[i];
+                    float gi = a.grad[i] + a.wd * wi;
+                    float mi = a.m[i], vi = a.v[i];
+                    mi = mi + (gi - mi) * (1.0f - b1);
+                    vi = vi * b2 + (1.0f - b2) * gi * gi;
+                    float denom = sqrtf(vi) / bc2s + eps;
+                    a.w[i] = wi - step_size * (mi / denom);
+                    a.m[i] = mi;
+                    a.v[i] = vi;
+                }
+            }
+            __syncthreads();
+            rebuild_images(a);
+            __syncthreads();
+        }
+        // ---- Trainer._validate (trainer.py:405-418): one full batch, loss / len(valid) -----------------------
+        float vsum = 0.f;
+        {
+            const int vtiles = (a.n_valid + 15) >> 4;
+            for (int tile = wave; tile < vtiles; tile += TRAIN_WAVES) {
+                const int r = tile * 16 + w;
+                const bool ok = r < a.n_valid;
+                f32x4 xv[2][NT];
+                load_tile<NT>(a.xvalid, r, ok, D, lane, xv);
+                float ldv = group_sum(flow_forward_tile<NT, NH>(a.img_fwd, a.s.net_floats, B, L, lane, xv));
+                float ss = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        f32x4 v = xv[c][t];
+                        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    }
+                ss = group_sum(ss);
+                float lpv = (ok && g == 0) ? (-0.5f * ss - half_log_2pi * (float)D + ldv) : 0.f;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) lpv += __shfl_xor(lpv, o);
+                vsum += lpv;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) red[wave] = vsum;
+        __syncthreads();
+        float vtot = 0.f;
+        for (int k = 0; k < TRAIN_WAVES; ++k) vtot += red[k];
+        const float valid_loss = (-vtot / (float)a.n_valid) / (float)a.n_valid;  // mean, then / len(dataset)  :418
+        const float train_loss = epoch_loss / (float)a.n_train;                   // trainer.py:403
+        last_train_loss = train_loss;
+        epochs_run = epoch + 1;
+        if (a.losses && threadIdx.x == 0) {
+            a.losses[2 * epoch] = train_loss;
+            a.losses[2 * epoch + 1] = valid_loss;
+        }
+        // early stopping bookkeeping (trainer.py:205-209, :223-232); every thread evaluates the same values
+        const bool improved = valid_loss < ctlf[0];
+        __syncthreads();
+        if (improved) {
+            for (int i = threadIdx.x; i < np; i += blockDim.x) a.best_w[i] = a.w[i];
+            if (threadIdx.x == 0) { ctlf[0] = valid_loss; ctl[2] = a.epoch_offset + epoch + 1; ctl[1] = 0; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ctl[1] += 1;
+            if (ctl[1] > a.patience) ctl[0] = 1;
+        }
+        __syncthreads();
+        if (ctl[0]) break;
+    }
+    // netG.load_state_dict(best_model)  (trainer.py:241): at the end of train() or when patience ran out
+    __syncthreads();
+    const bool stopped = ctl[0] != 0;
+    if (stopped || (a.flags & NNEST_TRAIN_FINALIZE)) {
+        for (int i = threadIdx.x; i < np; i += blockDim.x) a.w[i] = a.best_w[i];
+        __syncthreads();
+        rebuild_images(a);
+    }
+    if (threadIdx.x == 0) {
+        if (a.adam_step) *a.adam_step = adam_t;
+        a.result->epochs_run = a.epoch_offset + epochs_run;
+        a.result->best_epoch = ctl[2];
+        a.result->best_validation_loss = ctlf[0];
+        a.result->last_train_loss = last_train_loss;
+        a.result->counter = ctl[1];
+        a.result->stopped = stopped ? 1 : 0;
+    }
+}
+
+// ---- training jitter (trainer.py:168-171): 0.2 * mean over both columns of cKDTree(samples).query(samples, 2)
 // = 0.2 * sum_i nn_dist(i) / (2N).  Brute force in float64: N is the live-point count (<= ~1e4).
 __global__ void __launch_bounds__(256) nn_distance_kernel(const double *__restrict__ X, int N, int D, double *__restrict__ out) {
     __shared__ double red[256];
@@ -40,16 +675,74 @@ hipError_t launch_training_jitter(const double *samples, int N, int D, double *o
     return hipGetLastError();
 }
 
-size_t train_workspace_floats(const FlowShape &s, int batch) { (void)s; (void)batch; return 1024; }
-
-hipError_t launch_loss_grad(const float *, const FlowShape &, const float *, int, float *, float *, float *, hipStream_t) {
-    return hipErrorNotSupported;
+// ---- launchers --------------------------------------------------------------------------------------------
+// workspace layout (floats): [img_bwd: image_floats][grad: num_params]
+size_t train_workspace_floats(const FlowShape &s, int batch) {
+    (void)batch;
+    return (size_t)s.image_floats + (size_t)s.B * 2 * s.net_params + 64;
 }
 
-hipError_t launch_train(float *, float *, float *, float *, float *, int *, const FlowShape &, const float *, int,
-                        const float *, int, const int *, const float *, uint64_t, float, int, int, int, float, float,
-                        float *, nnest_train_result_t *, float *, hipStream_t) {
-    return hipErrorNotSupported;
+template <int NT, int NH, int L>
+static hipError_t launch_train_t(const TrainArgs &a, hipStream_t st) {
+    typedef StageMap<NT, NH, L> SM;
+    const size_t lds = (size_t)SM::count * TRAIN_MAX_ROWS * 16 * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(train_kernel<NT, NH, L>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((train_kernel<NT, NH, L>), dim3(1), dim3(TRAIN_THREADS), lds, st, a);
+    return hipGetLastError();
+}
+
+static hipError_t dispatch_train(const TrainArgs &a, hipStream_t st) {
+    const FlowShape &s = a.s;
+#define TRY_SHAPE(nt, nh, l) if (s.NT == nt && s.NH == nh && s.L == l) return launch_train_t<nt, nh, l>(a, st)
+    TRY_SHAPE(1, 1, 0); TRY_SHAPE(2, 1, 0); TRY_SHAPE(3, 1, 0); TRY_SHAPE(4, 1, 0);
+    TRY_SHAPE(1, 1, 1); TRY_SHAPE(2, 1, 1); TRY_SHAPE(3, 1, 1); TRY_SHAPE(4, 1, 1);
+    TRY_SHAPE(1, 1, 2); TRY_SHAPE(2, 1, 2); TRY_SHAPE(3, 1, 2); TRY_SHAPE(4, 1, 2);
+    TRY_SHAPE(1, 2, 1); TRY_SHAPE(2, 2, 1); TRY_SHAPE(1, 2, 2); TRY_SHAPE(2, 2, 2);
+    TRY_SHAPE(1, 4, 1);
+#undef TRY_SHAPE
+    return hipErrorInvalidConfiguration;
+}
+
+hipError_t launch_loss_grad(const float *packed, const FlowShape &s, const float *x, int M, float *grad, float *loss,
+                            float *workspace, float *img_fwd, hipStream_t st) {
+    TrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = const_cast<float *>(packed);
+    a.img_fwd = img_fwd;
+    a.img_bwd = workspace;
+    a.grad = grad;
+    a.s = s;
+    a.xtrain = x;
+    a.n_train = M;
+    a.batch = M;
+    a.loss_out = loss;
+    a.mode = TRAIN_MODE_GRAD_ONLY;
+    return dispatch_train(a, st);
+}
+
+hipError_t launch_train(float *packed, float *adam_m, float *adam_v, float *best_w, float *img, int *adam_step_dev,
+                        const FlowShape &s, const float *xtrain, int n_train, const float *xvalid, int n_valid,
+                        const int *perm, const float *noise, uint64_t seed, float jitter, int batch, int max_epochs,
+                        int patience, float lr, float wd, int epoch_offset, int flags, float *losses,
+                        nnest_train_result_t *result, float *workspace, hipStream_t st) {
+    TrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = packed; a.m = adam_m; a.v = adam_v; a.best_w = best_w; a.img_fwd = img;
+    a.img_bwd = workspace;
+    a.grad = workspace + s.image_floats;
+    a.adam_step = adam_step_dev;
+    a.s = s;
+    a.xtrain = xtrain; a.n_train = n_train; a.xvalid = xvalid; a.n_valid = n_valid;
+    a.perm = perm; a.noise = noise; a.seed = seed; a.jitter = jitter; a.batch = batch;
+    a.max_epochs = max_epochs; a.patience = patience; a.lr = lr; a.wd = wd;
+    a.losses = losses; a.result = result;
+    a.epoch_offset = epoch_offset; a.flags = flags;
+    a.mode = TRAIN_MODE_EPOCHS;
+    return dispatch_train(a, st);
 }
 
 }  // namespace nnest

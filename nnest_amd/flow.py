@@ -225,6 +225,50 @@ class HipNVP(object):
                 _lib.ptr(n_call), _lib.ptr(scale_out), _lib.current_stream(dev)))
         return dict(x=x, n_accept=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl)
 
+    def loss_grad(self, x):
+        """loss = -mean(log_probs(x)) and dloss/dw (packed order) for one minibatch of <= 128 rows
+        (loss.backward(), trainer.py:394-400), no weight update."""
+        x = _as_dev_f32(x, self.device)
+        grad = torch.empty(self.num_params, dtype=torch.float32, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_nvp_loss_grad(self._h, _lib.ptr(x), x.shape[0], _lib.ptr(grad), _lib.ptr(loss),
+                                                     _lib.current_stream(self.device)))
+        return loss, grad
+
+    def train_epochs(self, xtrain, xvalid, perm, noise=None, seed=0, jitter=0.0, batch=100, max_epochs=1, patience=50,
+                     lr=1e-3, weight_decay=1e-6, epoch_offset=0, resume=False, finalize=True, result=None):
+        """K5: Trainer.train's epoch loop (trainer.py:198-241) in one launch.  perm int32 [max_epochs, n_train];
+        noise None (in-kernel Philox) or float32 [max_epochs, n_train, D] in loader order.
+        A long train() can be split into chunks: pass the previous chunk's `result` tensor with resume=True,
+        epoch_offset = epochs already run, finalize=True only for the last chunk (see include/nnest_hip.h).
+        Returns dict(losses [epochs,2] tensor, epochs_run, best_epoch, best_validation_loss, last_train_loss,
+        counter, stopped, result)."""
+        dev = self.device
+        xtrain = _as_dev_f32(xtrain, dev)
+        xvalid = _as_dev_f32(xvalid, dev)
+        perm = perm.to(device=dev, dtype=torch.int32).contiguous()
+        n_train, n_valid = xtrain.shape[0], xvalid.shape[0]
+        assert perm.numel() == max_epochs * n_train
+        if noise is not None:
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+            assert noise.numel() == max_epochs * n_train * self.D
+        losses = torch.zeros(max(max_epochs, 1), 2, dtype=torch.float32, device=dev)
+        if result is None:
+            assert not resume
+            result = torch.zeros(6, dtype=torch.int32, device=dev)  # nnest_train_result_t
+        flags = (_lib.TRAIN_RESUME if resume else 0) | (_lib.TRAIN_FINALIZE if finalize else 0)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.nnest_nvp_train(self._h, _lib.ptr(xtrain), n_train, _lib.ptr(xvalid), n_valid,
+                                                 _lib.ptr(perm), _lib.ptr(noise), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                 float(jitter), int(batch), int(max_epochs), int(patience), float(lr),
+                                                 float(weight_decay), int(epoch_offset), flags, _lib.ptr(losses),
+                                                 _lib.ptr(result), _lib.current_stream(dev)))
+        r = result.cpu()
+        fl = r[2:4].view(torch.float32)
+        return dict(losses=losses, epochs_run=int(r[0]), best_epoch=int(r[1]), best_validation_loss=float(fl[0]),
+                    last_train_loss=float(fl[1]), counter=int(r[4]), stopped=bool(int(r[5])), result=result)
+
     def fill_noise(self, steps, C, seed=0, walker_offset=0):
         dz = torch.empty(steps, C, self.D, dtype=torch.float32, device=self.device)
         u = torch.empty(steps, C, dtype=torch.float32, device=self.device)

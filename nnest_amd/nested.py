@@ -1,0 +1,379 @@
+"""NestedSampler: the reference's nested-sampling outer loop (nnest/nested.py:24-510) kept on the host in
+float64, driving the HIP hot path: flow retrain (Trainer.train -> nnest_nvp_train) and batched constrained
+Metropolis proposals (Sampler._mcmc_sample -> nnest_mh_constrained_steps).
+
+Same constructor and run() keywords, same result attributes (logz, samples, weights, loglikes) and the same
+on-disk products (results/results.csv, results/final.csv, checkpoint/*.npy + checkpoint_<it>.txt,
+chains/chain.txt) as the reference.  Strategies: 'rejection_prior' and 'mcmc' (the reference default pair,
+nested.py:136-137); 'rejection_flow' / 'density_flow' are low-dimensional conveniences outside this build's
+scope and raise.
+
+Multi-GPU (torch.distributed, one process per GPU): the live set and the evidence state are replicated on
+every rank; rank 0 draws all host-side randomness and broadcasts it; each MCMC batch is sharded over ranks
+and its endpoints are all-gathered; rank 0 retrains the flow and broadcasts the <= 86 KB of weights.
+"""
+import csv
+import glob
+import json
+import logging
+import os
+
+import numpy as np
+
+from .priors import UniformPrior
+from .sampler import Sampler
+
+
+class NestedSampler(Sampler):
+
+    def __init__(self,
+                 x_dim,
+                 loglike,
+                 transform=None,
+                 append_run_num=True,
+                 hidden_dim=16,
+                 num_slow=0,
+                 num_derived=0,
+                 batch_size=100,
+                 flow='nvp',
+                 num_blocks=3,
+                 num_layers=1,
+                 learning_rate=0.001,
+                 log_dir='logs/test',
+                 resume=True,
+                 base_dist=None,
+                 scale='',
+                 use_gpu=True,
+                 trainer=None,
+                 oversample_rate=-1,
+                 log_level=logging.INFO,
+                 param_names=None,
+                 num_live_points=1000,
+                 fused=True,
+                 mcmc_history=False):
+        prior = UniformPrior(x_dim, -1, 1)  # nested.py:76
+        super(NestedSampler, self).__init__(x_dim, loglike, transform=transform, append_run_num=append_run_num,
+                                            hidden_dim=hidden_dim, num_slow=num_slow, num_derived=num_derived,
+                                            batch_size=batch_size, flow=flow, num_blocks=num_blocks,
+                                            num_layers=num_layers, learning_rate=learning_rate, log_dir=log_dir,
+                                            resume=resume, use_gpu=use_gpu, base_dist=base_dist, scale=scale,
+                                            trainer=trainer, prior=prior, transform_prior=False, log_level=log_level,
+                                            param_names=param_names, oversample_rate=oversample_rate, fused=fused,
+                                            mcmc_history=mcmc_history)
+        self.num_live_points = num_live_points
+        self.sampler = 'nested'
+        if self.single_or_primary_process:
+            self.logger.info('Num live points [%d]' % self.num_live_points)
+            with open(os.path.join(self.logs['results'], 'results.csv'), 'w') as f:
+                csv.writer(f).writerow(['step', 'acceptance', 'min_ess', 'max_ess', 'jump_distance', 'scale', 'loglstar',
+                                        'logz', 'fraction_remain', 'ncall'])
+
+    # ---- helpers ---------------------------------------------------------------------------------------------
+    def _initial_loglikes(self, active_u):
+        """nested.py:210-228: likelihood of the initial live points through the host protocol (float64),
+        sharded over ranks and all-gathered when distributed."""
+        if not self.use_mpi:
+            return self.loglike(active_u)
+        N = active_u.shape[0]
+        per = -(-N // self.mpi_size)
+        rows = np.arange(self.mpi_rank * per, (self.mpi_rank + 1) * per) % N
+        logl, derived = self.loglike(active_u[rows])
+        logl = self._all_gather_rows(logl)[:N] if per * self.mpi_size == N else self._gather_padded(logl, N, per)
+        derived = np.empty((N, self.num_derived)) if self.num_derived == 0 else self._gather_padded(derived, N, per)
+        return logl, derived
+
+    def _gather_padded(self, arr, N, per):
+        full = self._all_gather_rows(arr)
+        out = np.empty((N,) + arr.shape[1:], dtype=arr.dtype)
+        for r in range(self.mpi_size):
+            rows = np.arange(r * per, (r + 1) * per) % N
+            out[rows] = full[r * per:(r + 1) * per]
+        return out
+
+    def _train(self, active_u, train_iters, jitter):
+        """nested.py:311-314.  Distributed: rank 0 trains, the packed weights are broadcast (C3)."""
+        if not self.use_mpi:
+            self.trainer.train(active_u, max_iters=train_iters, jitter=jitter)
+            return
+        if self.mpi_rank == 0:
+            self.trainer.train(active_u, max_iters=train_iters, jitter=jitter)
+        w = self.trainer.netG.store_packed()
+        w = self._broadcast(w, src=0)
+        if self.mpi_rank != 0:
+            self.trainer.netG.load_packed(w)
+
+    def _checkpoint(self, it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt, state):
+        cp = self.logs['checkpoint']
+        np.save(os.path.join(cp, 'active_u_%s.npy' % it), active_u)
+        np.save(os.path.join(cp, 'active_v_%s.npy' % it), active_v)
+        np.save(os.path.join(cp, 'active_logl_%s.npy' % it), active_logl)
+        np.save(os.path.join(cp, 'active_derived_%s.npy' % it), active_derived)
+        np.save(os.path.join(cp, 'saved_v.npy'), np.array(saved_v))
+        np.save(os.path.join(cp, 'saved_logl.npy'), np.array(saved_logl))
+        np.save(os.path.join(cp, 'saved_logwt.npy'), np.array(saved_logwt))
+        with open(os.path.join(cp, 'checkpoint_%s.txt' % it), 'w') as f:
+            json.dump(state, f)
+
+    # ---- the run ----------------------------------------------------------------------------------------------
+    def run(self,
+            strategy=None,
+            mcmc_steps=0,
+            mcmc_num_chains=10,
+            mcmc_dynamic_step_size=True,
+            max_iters=1000000,
+            update_interval=None,
+            log_interval=None,
+            dlogz=0.5,
+            train_iters=500,
+            volume_switch=-1.0,
+            step_size=0.0,
+            jitter=-1.0,
+            rejection_cache_interval=10,
+            rejection_enlargement_factor=1.1,
+            rejection_trials=None):
+        if strategy is None or len(strategy) == 0:
+            strategy = ['rejection_prior', 'mcmc']
+        for s in strategy:
+            if s not in ('rejection_prior', 'mcmc'):
+                raise NotImplementedError("strategy %r: this build implements 'rejection_prior' and 'mcmc'" % s)
+        expired_strategies = []
+        current_method = ''
+        N = self.num_live_points
+        update_interval = max(1, round(0.5 * N)) if update_interval is None else round(update_interval)
+        if update_interval < 1:
+            raise ValueError('update_interval must be >= 1')
+        log_interval = max(1, round(0.2 * N)) if log_interval is None else round(log_interval)
+        if log_interval < 1:
+            raise ValueError('log_interval must be >= 1')
+        if mcmc_steps <= 0:
+            mcmc_steps = 5 * self.x_dim                      # nested.py:155-156
+        if step_size <= 0.0:
+            step_size = 1 / self.x_dim ** 0.5                # nested.py:158-159
+        primary = self.single_or_primary_process
+        if primary:
+            self.logger.info('MCMC steps [%d]' % mcmc_steps)
+            self.logger.info('Initial scale [%5.4f]' % step_size)
+            self.logger.info('Volume switch [%5.4f]' % volume_switch)
+
+        it = -1
+        if self.resume and self.logs is not None and not self.logs['created']:
+            for f in glob.glob(os.path.join(self.logs['checkpoint'], 'checkpoint_*.txt')):
+                it = max(it, int(f.split('/checkpoint_')[1].split('.txt')[0]))
+        if self.use_mpi:
+            it = int(self._broadcast(np.array([it], dtype=np.int64))[0])
+        total_calls = 0
+        if it >= 0:
+            if primary:
+                self.logger.info('Using checkpoint [%d]' % it)
+                cp = self.logs['checkpoint']
+                with open(os.path.join(cp, 'checkpoint_%s.txt' % it), 'r') as f:
+                    data = json.load(f)
+                active_u = np.load(os.path.join(cp, 'active_u_%s.npy' % it))
+                active_logl = np.load(os.path.join(cp, 'active_logl_%s.npy' % it))
+                active_derived = np.load(os.path.join(cp, 'active_derived_%s.npy' % it))
+                saved_v = list(np.load(os.path.join(cp, 'saved_v.npy')))
+                saved_logl = np.load(os.path.join(cp, 'saved_logl.npy')).tolist()
+                saved_logwt = np.load(os.path.join(cp, 'saved_logwt.npy')).tolist()
+                assert it == len(saved_logl)
+            if self.use_mpi:
+                raise NotImplementedError('resume from checkpoint with more than one rank')
+            logz, h, logvol = data['logz'], data['h'], data['logvol']
+            self.total_calls = int(data['ncall'] / self.mpi_size)
+            total_calls = data['ncall']
+            fraction_remain = data['fraction_remain']
+            strategy, expired_strategies = data['strategy'], data['expired_strategies']
+            active_v = self.transform(active_u)
+        else:
+            active_u = self.sample_prior(N) if primary else np.empty((N, self.x_dim))   # nested.py:199-207
+            active_u = self._broadcast(active_u)
+            active_v = self.transform(active_u)
+            active_logl, active_derived = self._initial_loglikes(active_u)
+            total_calls = int(self._all_sum(self.total_calls))
+            if primary:
+                self.logger.info('Step [0] max logl [%5.4e] vol [1.0] ncalls [%d]' % (np.max(active_logl), total_calls))
+            saved_v, saved_logl, saved_logwt = [], [], []
+            h = 0.0
+            logz = -1e300
+            logvol = np.log(1.0 - np.exp(-1.0 / N))          # nested.py:244
+            fraction_remain = 1.0
+            it = 0
+            if primary:
+                self._checkpoint(it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt,
+                                 {'logz': logz, 'h': h, 'logvol': logvol, 'ncall': total_calls,
+                                  'fraction_remain': fraction_remain, 'strategy': strategy,
+                                  'expired_strategies': expired_strategies})
+
+        first_time = True
+        get_samples = True
+        nb = 0
+        ncs = []
+        accept_point = True
+        samples = loglikes = None
+        scale = step_size
+        mean_calls = 0
+        self.num_retrains = 0
+        self.num_batches = 0
+
+        while fraction_remain > dlogz and it <= max_iters:
+            worst = int(np.argmin(active_logl))              # nested.py:272
+            logwt = logvol + active_logl[worst]
+            loglstar = active_logl[worst]
+            expected_vol = np.exp(-it / N)
+            if accept_point:                                 # nested.py:280-293
+                logz_new = np.logaddexp(logz, logwt)
+                h = (np.exp(logwt - logz_new) * active_logl[worst] + np.exp(logz - logz_new) * (h + logz) - logz_new)
+                logz = logz_new
+                if self.num_derived > 0:
+                    saved_v.append(np.concatenate((active_v[worst], active_derived[worst])))
+                else:
+                    saved_v.append(np.array(active_v[worst], copy=True))
+                saved_logwt.append(logwt)
+                saved_logl.append(active_logl[worst])
+                accept_point = False
+
+            old_method = current_method
+            for method in strategy:
+                if method not in expired_strategies:
+                    current_method = method
+                    break
+            if current_method != old_method:
+                get_samples = True
+
+            if current_method != 'rejection_prior' and (first_time or it % update_interval == 0):
+                self._train(active_u, train_iters, jitter)   # nested.py:311-314
+                self.num_retrains += 1
+                first_time = False
+
+            if current_method == 'rejection_prior':          # nested.py:322-334, :375-396
+                if get_samples:
+                    nb = 0
+                    if primary:
+                        s_x, s_l, s_d, nc = self._rejection_prior_sample(loglstar, num_trials=rejection_trials)
+                        pack = np.concatenate([np.ravel(s_x), np.ravel(s_l), [float(nc), float(len(np.ravel(s_l)))]])
+                    else:
+                        pack = None
+                    if self.use_mpi:
+                        n_rows = rejection_trials if rejection_trials else 1
+                        if not primary:
+                            pack = np.empty(n_rows * (self.x_dim + 1) + 2)
+                        pack = self._broadcast(pack)
+                        n_rows = int(pack[-1])
+                        s_x = pack[:n_rows * self.x_dim].reshape(n_rows, self.x_dim)
+                        s_l = pack[n_rows * self.x_dim:n_rows * (self.x_dim + 1)]
+                        s_d = np.empty((n_rows, 0))
+                        nc = pack[-2]
+                    samples, loglikes, derived_samples = np.atleast_2d(s_x), np.ravel(s_l), s_d
+                    ncs.append(nc)
+                    mean_calls = np.mean(ncs[-20:]) if len(ncs) > 20 else 0
+                    if expected_vol < volume_switch >= 0 or \
+                            (volume_switch < 0 and mean_calls > mcmc_steps and 'mcmc' in strategy
+                             and 'mcmc' not in expired_strategies):
+                        if primary:
+                            self.logger.info('Rejection prior no longer efficient, switching sampling method')
+                        expired_strategies.append('rejection_prior')
+                        ncs = []
+                for ib in range(nb, samples.shape[0]):
+                    nb += 1
+                    get_samples = nb == samples.shape[0]
+                    if loglikes[ib] > loglstar:
+                        active_u[worst] = samples[nb - 1, :]
+                        active_v[worst] = self.transform(active_u[worst])
+                        active_logl[worst] = loglikes[nb - 1]
+                        accept_point = True
+                        break
+                total_calls = int(self._all_sum(self.total_calls))
+                if accept_point and it > 0 and (it + 1) % log_interval == 0 and primary:
+                    self.logger.info('Step [%d] loglstar [%5.4e] max logl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
+                                     'mean calls [%5.4f]' % (it + 1, loglstar, np.max(active_logl), logz, expected_vol,
+                                                             total_calls, mean_calls))
+
+            elif current_method == 'mcmc':                   # nested.py:398-456
+                if get_samples:
+                    nb = 0
+                    C = mcmc_num_chains
+                    per = -(-C // self.mpi_size)
+                    ctl = np.zeros(per * self.mpi_size + 1, dtype=np.int64)
+                    if primary:
+                        idx = np.random.randint(low=0, high=N, size=C)      # nested.py:405
+                        ctl[:-1] = np.resize(idx, per * self.mpi_size)
+                        ctl[-1] = self._next_seed() & 0x7FFFFFFFFFFFFFFF
+                    ctl = self._broadcast(ctl)
+                    lo = self.mpi_rank * per
+                    my = ctl[lo:lo + per]
+                    init_derived = active_derived[my, :] if self.num_derived > 0 else np.empty((per, 0))
+                    s_x, _lat, s_d, s_l, scale, nc = self._mcmc_sample(
+                        mcmc_steps, init_samples=active_u[my, :], init_loglikes=active_logl[my], init_derived=init_derived,
+                        loglstar=loglstar, step_size=step_size, dynamic_step_size=mcmc_dynamic_step_size,
+                        walker_offset=lo, seed=int(ctl[-1]))
+                    # only step 0, the last step and its logL are consumed (nested.py:432-437): gather those (C2)
+                    ends = np.concatenate([s_x[:, 0, :], s_x[:, -1, :], s_l[:, -1:]], axis=1).astype(np.float64)
+                    ends = self._all_gather_rows(ends)[:C]
+                    samples = np.stack([ends[:, :self.x_dim], ends[:, self.x_dim:2 * self.x_dim]], axis=1)
+                    loglikes = np.stack([ends[:, -1], ends[:, -1]], axis=1)
+                    derived_samples = s_d
+                    self.num_batches += 1
+                for ib in range(nb, samples.shape[0]):
+                    nb += 1
+                    get_samples = nb == samples.shape[0]
+                    if np.all(samples[ib, 0, :] != samples[ib, -1, :]) and loglikes[ib, -1] > loglstar:
+                        active_u[worst] = samples[ib, -1, :]
+                        active_v[worst] = self.transform(active_u[worst])
+                        active_logl[worst] = loglikes[ib, -1]
+                        if self.num_derived > 0 and not self.use_mpi:
+                            active_derived[worst] = derived_samples[ib, -1, :]
+                        accept_point = True
+                        break
+                total_calls = int(self._all_sum(self.total_calls))
+                if accept_point and it > 0 and it % log_interval == 0 and primary:
+                    acc = self.total_accepted / max(1, self.total_accepted + self.total_rejected)
+                    self.logger.info('Step [%d] loglstar [%5.4e] maxlogl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
+                                     'scale [%5.4f]' % (it, loglstar, np.max(active_logl), logz, expected_vol, total_calls, scale))
+                    with open(os.path.join(self.logs['results'], 'results.csv'), 'a') as f:
+                        csv.writer(f).writerow([it, acc, float('nan'), float('nan'), float('nan'), scale, loglstar, logz,
+                                                fraction_remain, total_calls])
+
+            if accept_point:                                 # nested.py:458-485
+                logvol -= 1.0 / N
+                logz_remain = np.max(active_logl) - it / N
+                fraction_remain = np.logaddexp(logz, logz_remain) - logz
+                it += 1
+                if primary:
+                    self.trainer.writer.add_scalar('logz', logz, it)
+                if it > 0 and it % log_interval == 0 and primary:
+                    self.samples = np.array(saved_v)
+                    self.weights = np.exp(np.array(saved_logwt) - logz)
+                    self.loglikes = np.array(saved_logl)
+                    self._checkpoint(it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt,
+                                     {'logz': logz, 'h': h, 'logvol': logvol, 'ncall': total_calls,
+                                      'fraction_remain': fraction_remain, 'strategy': strategy,
+                                      'expired_strategies': expired_strategies})
+                    self._save_samples(self.samples, self.loglikes, weights=self.weights)
+
+        # final live points (nested.py:487-495)
+        logvol = -len(saved_v) / N - np.log(N)
+        for i in range(N):
+            logwt = logvol + active_logl[i]
+            logz_new = np.logaddexp(logz, logwt)
+            h = (np.exp(logwt - logz_new) * active_logl[i] + np.exp(logz - logz_new) * (h + logz) - logz_new)
+            logz = logz_new
+            saved_v.append(np.array(active_v[i]))
+            saved_logwt.append(logwt)
+            saved_logl.append(active_logl[i])
+
+        self.logz = logz
+        self.h = h
+        self.logzerr = np.sqrt(h / N)
+        self.niter = it + 1
+        self.ncall = total_calls
+        self.samples = np.array(saved_v)
+        self.weights = np.exp(np.array(saved_logwt) - logz)
+        self.loglikes = np.array(saved_logl)
+        if primary:
+            with open(os.path.join(self.logs['results'], 'final.csv'), 'w') as f:
+                wr = csv.writer(f)
+                wr.writerow(['niter', 'ncall', 'logz', 'logzerr', 'h'])
+                wr.writerow([it + 1, total_calls, logz, np.sqrt(h / N), h])
+            self._save_samples(self.samples, self.loglikes, weights=self.weights)
+            self.trainer.writer.flush() if hasattr(self.trainer.writer, 'flush') else None
+            self.logger.info('niter: {:d}\n ncall: {:d}\n nsamples: {:d}\n logz: {:6.3f} +/- {:6.3f}\n h: {:6.3f}'
+                             .format(it + 1, total_calls, len(saved_v), logz, np.sqrt(h / N), h))

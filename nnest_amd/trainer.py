@@ -1,0 +1,186 @@
+"""Trainer: drop-in for the reference's nnest.trainer.Trainer on the path flow='nvp', num_slow=0, N(0,I) base.
+
+Same constructor keywords, attributes and method contracts as the reference (nnest/trainer.py:28-301), so
+that `NestedSampler(..., trainer=Trainer(...))` -- the reference's own injection point (nnest/sampler.py:50,
+:196-212) -- works unchanged.  All arithmetic runs in libnnest_hip.so on the GPU; there is no CPU fallback.
+"""
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .flow import HipNVP, _as_dev_f32
+from .utils import create_logger, ScalarWriter
+
+EPOCH_CHUNK = 128  # epochs per training launch (bounds the device shuffle table; see include/nnest_hip.h)
+
+
+class Trainer(object):
+    best_validation_epoch = None
+    best_validation_loss = None
+
+    def __init__(self,
+                 x_dim,
+                 hidden_dim=16,
+                 num_slow=0,
+                 batch_size=100,
+                 flow='nvp',
+                 scale='',
+                 num_blocks=3,
+                 num_layers=1,
+                 base_dist=None,
+                 load_model='',
+                 log_dir='logs/test',
+                 use_gpu=True,
+                 log=True,
+                 learning_rate=0.0001,
+                 weight_decay=1e-6,
+                 log_level=logging.INFO,
+                 device=None,
+                 seed=None):
+        if not torch.cuda.is_available():
+            raise _lib.NnestHipError('nnest_amd.Trainer needs an MI355X (torch.cuda.is_available() is False); '
+                                     'there is no CPU fallback')
+        if flow.lower() != 'nvp':
+            raise NotImplementedError("flow=%r: this build implements the RealNVP path (flow='nvp'); the spline and "
+                                      "Choleksy flows of the reference are outside its scope (DESIGN.md)" % flow)
+        if num_slow != 0:
+            raise NotImplementedError('num_slow > 0 (fast/slow hierarchy) is outside the scope of this build')
+        if scale not in ('', None):
+            raise NotImplementedError("scale=%r: only the full affine coupling (scale='') is implemented" % scale)
+        if base_dist is not None:
+            raise NotImplementedError('only the N(0, I) base distribution is implemented')
+        if batch_size > 128:
+            raise NotImplementedError('batch_size > 128: one workgroup holds a minibatch (nnest_train.hip)')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.x_dim = x_dim
+        self.z_dim = x_dim
+        self.batch_size = batch_size
+        self.total_iters = 0
+        self.num_slow = 0
+        self.learning_rate = learning_rate
+        self.weight_decay = weight_decay
+        self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.device, seed=seed)
+        if load_model:
+            self.path = os.path.join(log_dir, load_model)
+            self.netG.load_state_dict(torch.load(os.path.join(self.path, 'models', 'netG.pt')))
+        elif log_dir is not None:
+            self.path = log_dir
+            for sub in ('models', 'data', 'chains', 'plots'):
+                os.makedirs(os.path.join(self.path, sub), exist_ok=True)
+        else:
+            self.path = None
+        self.logger = create_logger(__name__, level=log_level)
+        self.log = log
+        self.writer = ScalarWriter(self.path)
+        self.logger.info('Number of network params: [%s]' % self.netG.num_params)
+        self.logger.info('Device [%s]' % self.device)
+
+    # ------------------------------------------------------------------------------------------------
+    def training_jitter(self, samples):
+        """trainer.py:168-171 (jitter < 0): 0.2 * mean(cKDTree(samples).query(samples, 2) distances)"""
+        x = torch.as_tensor(np.ascontiguousarray(samples, dtype=np.float64)).to(self.device)
+        out = torch.zeros(1, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().nnest_training_jitter(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(out),
+                                                         _lib.current_stream(self.device)))
+        return float(out.item())
+
+    def train(self, samples, max_iters=10000, log_interval=100, save_interval=100, jitter=0.0,
+              validation_fraction=0.1, patience=50, l2_norm=0.0, split=None, perms=None, noises=None):
+        """Trainer.train (trainer.py:134-245).  `split`, `perms`, `noises` optionally replay recorded
+        randomness (tests); by default the split comes from numpy's global RNG exactly as sklearn's
+        train_test_split consumes it, the per-epoch shuffles from torch's CUDA generator and the jitter
+        noise from the in-kernel Philox stream seeded from torch's CPU generator."""
+        if l2_norm != 0.0:
+            raise NotImplementedError('l2_norm != 0 (the reference default is 0; nested.py:313 never sets it)')
+        start_time = time.time()
+        samples = np.asarray(samples)
+        if self.path:
+            np.save(os.path.join(self.path, 'data', 'originals.npy'), samples)
+        training_jitter = self.training_jitter(samples) if jitter < 0 else jitter
+        if self.log:
+            self.logger.info('Number of training samples [%d]' % samples.shape[0])
+            self.logger.info('Training jitter [%5.4f]' % training_jitter)
+        # train_test_split(samples, test_size=validation_fraction): ShuffleSplit draws rng.permutation(N) from
+        # numpy's global state; test = first n_test, train = next n_train (sklearn/model_selection/_split.py)
+        N = samples.shape[0]
+        n_valid = int(np.ceil(validation_fraction * N))
+        n_train = N - n_valid
+        if n_train < 1 or n_valid < 1:
+            raise ValueError('need at least one training and one validation sample (N=%d)' % N)
+        perm_split = np.random.permutation(N) if split is None else np.asarray(split)
+        x_valid = _as_dev_f32(samples[perm_split[:n_valid]], self.device)
+        x_train = _as_dev_f32(samples[perm_split[n_valid:n_valid + n_train]], self.device)
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        result, res, done, all_losses = None, None, 0, []
+        while done < max_iters:
+            chunk = min(EPOCH_CHUNK, max_iters - done)
+            if perms is not None:
+                perm = torch.as_tensor(perms[done:done + chunk])
+            else:  # DataLoader(shuffle=True): a fresh permutation per epoch (trainer.py:185)
+                perm = torch.rand(chunk, n_train, device=self.device).argsort(dim=1).int()
+            nz = None if noises is None else torch.as_tensor(noises[done:done + chunk])
+            res = self.netG.train_epochs(x_train, x_valid, perm, nz, seed=seed, jitter=training_jitter,
+                                         batch=self.batch_size, max_epochs=chunk, patience=patience,
+                                         lr=self.learning_rate, weight_decay=self.weight_decay, epoch_offset=done,
+                                         resume=result is not None, finalize=(done + chunk >= max_iters), result=result)
+            result = res['result']
+            ran = res['epochs_run'] - done
+            losses = res['losses'][:ran].cpu().numpy()
+            all_losses.append(losses)
+            for k in range(ran):
+                epoch = done + k + 1
+                if self.log and (epoch == 1 or epoch % log_interval == 0):
+                    self.logger.info('Epoch [%i] train loss [%5.4f] validation loss [%5.4f]' % (epoch, losses[k, 0], losses[k, 1]))
+                self.writer.add_scalar('loss', losses[k, 1], self.total_iters + epoch)
+            done = res['epochs_run']
+            if res['stopped']:
+                self.logger.info('Epoch [%i] ran out of patience' % done)
+                break
+        self.total_iters += done
+        self.losses = np.concatenate(all_losses, 0) if all_losses else np.zeros((0, 2), np.float32)
+        self.best_validation_epoch = res['best_epoch'] if res else 0
+        self.best_validation_loss = res['best_validation_loss'] if res else float('inf')
+        if self.path:
+            torch.save(self.netG.state_dict(), os.path.join(self.path, 'models', 'netG.pt'))
+        self.logger.info('Best epoch [%i] validation loss [%5.4f] train time (s) [%5.4f]]'
+                         % (self.best_validation_epoch, self.best_validation_loss, time.time() - start_time))
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, x, to_numpy=False):
+        """trainer.py:247-257"""
+        z, log_det_J = self.netG.forward(x)
+        if to_numpy:
+            return z.cpu().numpy(), log_det_J.cpu().numpy()
+        return z, log_det_J
+
+    def inverse(self, z, to_numpy=False):
+        """trainer.py:259-269"""
+        x, log_det_J = self.netG.inverse(z)
+        if to_numpy:
+            return x.cpu().numpy(), log_det_J.cpu().numpy()
+        return x, log_det_J
+
+    def get_prior_samples(self, num_samples, to_numpy=False):
+        z = torch.randn(num_samples, self.x_dim, device=self.device)
+        return z.cpu().numpy() if to_numpy else z
+
+    def get_latent_samples(self, x, to_numpy=False):
+        z, _ = self.forward(x, to_numpy=to_numpy)
+        return z
+
+    def get_samples(self, z, to_numpy=False):
+        x, _ = self.inverse(z, to_numpy=to_numpy)
+        return x
+
+    def get_synthetic_samples(self, num_samples, to_numpy=False):
+        x = self.netG.sample(num_samples)
+        return x.cpu().numpy() if to_numpy else x
+
+    def log_probs(self, x, to_numpy=False):
+        lp = self.netG.log_probs(x)
+        return lp.cpu().numpy() if to_numpy else lp
