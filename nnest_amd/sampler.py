@@ -196,7 +196,7 @@ class Sampler(object):
         # verify the kernel's likelihood against the host callable on a few points before trusting it
         from . import flow
         x = np.random.RandomState(4321).uniform(-1, 1, size=(32, self.x_dim)).astype(np.float32)
-        dev = flow.loglike(like_id, x, self._linear_scale, device=self.trainer.device).cpu().numpy()
+        dev = flow.loglike(like_id, x, self._linear_scale, device=netG.device).cpu().numpy()
         host = np.asarray(like(self._linear_scale * x.astype(np.float64)), dtype=np.float64)
         if not np.allclose(dev, host, rtol=1e-5, atol=1e-4):
             self.logger.warning('fused likelihood id %d disagrees with the host callable; using the host protocol' % like_id)
@@ -241,13 +241,13 @@ class Sampler(object):
     def _mcmc_sample_fused(self, mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar, walker_offset,
                            seed):
         netG = self.trainer.netG
-        dev = self.trainer.device
+        dev = netG.device
         C = init_samples.shape[0]
-        z, _ = self.trainer.forward(init_samples)                       # sampler.py:264
+        z, _ = netG.forward(init_samples)                               # sampler.py:264
         logl = torch.as_tensor(np.ascontiguousarray(init_loglikes, dtype=np.float64)).to(dev)
         x0 = None
         if not self.mcmc_history:
-            x0 = self.trainer.get_samples(z)                           # sampler.py:266
+            x0, _ = netG.inverse(z)                                    # sampler.py:266
         z0 = z.clone()
         res = netG.mh_steps(self._fused_like_id, self._linear_scale, z, logl, float(loglstar), float(step_size),
                             int(mcmc_steps), dynamic=dynamic, seed=self._next_seed() if seed is None else seed,

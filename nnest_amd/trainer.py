@@ -40,7 +40,8 @@ class Trainer(object):
                  weight_decay=1e-6,
                  log_level=logging.INFO,
                  device=None,
-                 seed=None):
+                 seed=None,
+                 host_tensors=False):
         if not torch.cuda.is_available():
             raise _lib.NnestHipError('nnest_amd.Trainer needs an MI355X (torch.cuda.is_available() is False); '
                                      'there is no CPU fallback')
@@ -55,7 +56,12 @@ class Trainer(object):
             raise NotImplementedError('only the N(0, I) base distribution is implemented')
         if batch_size > 128:
             raise NotImplementedError('batch_size > 128: one workgroup holds a minibatch (nnest_train.hip)')
-        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        # host_tensors=True: forward/inverse/... return CPU tensors and `.device` reads 'cpu' while the arithmetic
+        # still runs on the GPU.  Needed only under the UNMODIFIED reference sampler, whose _mcmc_sample mixes CPU
+        # tensors into the loop (nnest/sampler.py:305, :344) and therefore cannot consume CUDA tensors.
+        self.gpu = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.host_tensors = bool(host_tensors)
+        self.device = torch.device('cpu') if self.host_tensors else self.gpu
         self.x_dim = x_dim
         self.z_dim = x_dim
         self.batch_size = batch_size
@@ -63,7 +69,7 @@ class Trainer(object):
         self.num_slow = 0
         self.learning_rate = learning_rate
         self.weight_decay = weight_decay
-        self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.device, seed=seed)
+        self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed)
         if load_model:
             self.path = os.path.join(log_dir, load_model)
             self.netG.load_state_dict(torch.load(os.path.join(self.path, 'models', 'netG.pt')))
@@ -82,11 +88,11 @@ class Trainer(object):
     # ------------------------------------------------------------------------------------------------
     def training_jitter(self, samples):
         """trainer.py:168-171 (jitter < 0): 0.2 * mean(cKDTree(samples).query(samples, 2) distances)"""
-        x = torch.as_tensor(np.ascontiguousarray(samples, dtype=np.float64)).to(self.device)
-        out = torch.zeros(1, dtype=torch.float64, device=self.device)
-        with torch.cuda.device(self.device):
+        x = torch.as_tensor(np.ascontiguousarray(samples, dtype=np.float64)).to(self.gpu)
+        out = torch.zeros(1, dtype=torch.float64, device=self.gpu)
+        with torch.cuda.device(self.gpu):
             _lib.check(_lib.load().nnest_training_jitter(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(out),
-                                                         _lib.current_stream(self.device)))
+                                                         _lib.current_stream(self.gpu)))
         return float(out.item())
 
     def train(self, samples, max_iters=10000, log_interval=100, save_interval=100, jitter=0.0,
@@ -113,8 +119,8 @@ class Trainer(object):
         if n_train < 1 or n_valid < 1:
             raise ValueError('need at least one training and one validation sample (N=%d)' % N)
         perm_split = np.random.permutation(N) if split is None else np.asarray(split)
-        x_valid = _as_dev_f32(samples[perm_split[:n_valid]], self.device)
-        x_train = _as_dev_f32(samples[perm_split[n_valid:n_valid + n_train]], self.device)
+        x_valid = _as_dev_f32(samples[perm_split[:n_valid]], self.gpu)
+        x_train = _as_dev_f32(samples[perm_split[n_valid:n_valid + n_train]], self.gpu)
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
         result, res, done, all_losses = None, None, 0, []
         while done < max_iters:
@@ -122,7 +128,7 @@ class Trainer(object):
             if perms is not None:
                 perm = torch.as_tensor(perms[done:done + chunk])
             else:  # DataLoader(shuffle=True): a fresh permutation per epoch (trainer.py:185)
-                perm = torch.rand(chunk, n_train, device=self.device).argsort(dim=1).int()
+                perm = torch.rand(chunk, n_train, device=self.gpu).argsort(dim=1).int()
             nz = None if noises is None else torch.as_tensor(noises[done:done + chunk])
             res = self.netG.train_epochs(x_train, x_valid, perm, nz, seed=seed, jitter=training_jitter,
                                          batch=self.batch_size, max_epochs=chunk, patience=patience,
@@ -156,18 +162,21 @@ class Trainer(object):
         z, log_det_J = self.netG.forward(x)
         if to_numpy:
             return z.cpu().numpy(), log_det_J.cpu().numpy()
-        return z, log_det_J
+        return self._out(z), self._out(log_det_J)
 
     def inverse(self, z, to_numpy=False):
         """trainer.py:259-269"""
         x, log_det_J = self.netG.inverse(z)
         if to_numpy:
             return x.cpu().numpy(), log_det_J.cpu().numpy()
-        return x, log_det_J
+        return self._out(x), self._out(log_det_J)
 
     def get_prior_samples(self, num_samples, to_numpy=False):
         z = torch.randn(num_samples, self.x_dim, device=self.device)
         return z.cpu().numpy() if to_numpy else z
+
+    def _out(self, t):
+        return t.cpu() if self.host_tensors else t
 
     def get_latent_samples(self, x, to_numpy=False):
         z, _ = self.forward(x, to_numpy=to_numpy)
@@ -179,8 +188,8 @@ class Trainer(object):
 
     def get_synthetic_samples(self, num_samples, to_numpy=False):
         x = self.netG.sample(num_samples)
-        return x.cpu().numpy() if to_numpy else x
+        return x.cpu().numpy() if to_numpy else self._out(x)
 
     def log_probs(self, x, to_numpy=False):
         lp = self.netG.log_probs(x)
-        return lp.cpu().numpy() if to_numpy else lp
+        return lp.cpu().numpy() if to_numpy else self._out(lp)
