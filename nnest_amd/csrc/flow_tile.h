@@ -156,6 +156,212 @@ __device__ __forceinline__ float coupling_tile(const float *__restrict__ wblk, i
     return ld;
 }
 
+// The same coupling block with the layer structure fixed at compile time (L = number of hidden HxH layers) and
+// written for instruction-level parallelism: a lone wave issues a dependent v_mfma_f32_16x16x4_f32 only every
+// ~40 cycles (MI355X_MICROARCH.md), and the straightforward net-after-net order above measured 75 cycles per
+// MFMA (tools/ablate_mh.hip).  Here the scale and translate nets advance layer by layer together and every
+// K-accumulation is split over two accumulators, so four independent chains are in flight per layer.
+// Fragment accessors: fragment number idx within one (block, net) -- L1 [o][tau][r], then L2 [l][o][i][r],
+// then L3 [tau][i][r] -- read either from the image (LDS or global; pointer already offset by the lane) or from
+// a per-lane register array filled once per kernel.
+struct ImageFrags {
+    const float *p;
+    __device__ __forceinline__ float operator()(int idx) const { return p[idx * 64]; }
+};
+template <int N> struct RegFrags {
+    float v[N];
+    __device__ __forceinline__ float operator()(int idx) const { return v[idx]; }
+};
+template <int NT, int NH, int L> struct FragCount {
+    static constexpr int F1 = NH * NT * 4, F2 = L * NH * NH * 4, F3 = NT * NH * 4, N = F1 + F2 + F3;
+};
+
+template <int NT, int NH, int L, bool INVERSE, class FS, class FT>
+__device__ __forceinline__ float coupling_core(const FS &fs, const FT &ft, const float *__restrict__ bias_s,
+                                               const float *__restrict__ bias_t, int lane, const f32x4 (&cond)[NT],
+                                               f32x4 (&trans)[NT]) {
+    // bias_s / bias_t -> [b1: 16*NH][b2: L*16*NH][b3: 16*NT] of the scale / translate net
+    typedef FragCount<NT, NH, L> FC;
+    const int g4 = (lane >> 4) * 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 hs[NH], ht[NH];
+    {  // Linear(D,H) + activation, both nets
+        const float *bs = bias_s + g4, *bt = bias_t + g4;
+#pragma unroll
+        for (int o = 0; o < NH; ++o) {
+            f32x4 s0 = *reinterpret_cast<const f32x4 *>(bs + 16 * o), s1 = zero4;
+            f32x4 t0 = *reinterpret_cast<const f32x4 *>(bt + 16 * o), t1 = zero4;
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) {
+                const int f = (o * NT + tau) * 4;
+                s0 = mfma4(fs(f), cond[tau].x, s0);
+                t0 = mfma4(ft(f), cond[tau].x, t0);
+                s1 = mfma4(fs(f + 1), cond[tau].y, s1);
+                t1 = mfma4(ft(f + 1), cond[tau].y, t1);
+                s0 = mfma4(fs(f + 2), cond[tau].z, s0);
+                t0 = mfma4(ft(f + 2), cond[tau].z, t0);
+                s1 = mfma4(fs(f + 3), cond[tau].w, s1);
+                t1 = mfma4(ft(f + 3), cond[tau].w, t1);
+            }
+            hs[o] = activate<0>(s0 + s1);
+            ht[o] = activate<1>(t0 + t1);
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {  // hidden Linear(H,H) + activation, both nets
+        const float *bs = bias_s + 16 * NH + g4, *bt = bias_t + 16 * NH + g4;
+        f32x4 hs2[NH], ht2[NH];
+#pragma unroll
+        for (int o = 0; o < NH; ++o) {
+            f32x4 s0 = *reinterpret_cast<const f32x4 *>(bs + (l * NH + o) * 16), s1 = zero4;
+            f32x4 t0 = *reinterpret_cast<const f32x4 *>(bt + (l * NH + o) * 16), t1 = zero4;
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                const int f = FC::F1 + ((l * NH + o) * NH + i) * 4;
+                s0 = mfma4(fs(f), hs[i].x, s0);
+                t0 = mfma4(ft(f), ht[i].x, t0);
+                s1 = mfma4(fs(f + 1), hs[i].y, s1);
+                t1 = mfma4(ft(f + 1), ht[i].y, t1);
+                s0 = mfma4(fs(f + 2), hs[i].z, s0);
+                t0 = mfma4(ft(f + 2), ht[i].z, t0);
+                s1 = mfma4(fs(f + 3), hs[i].w, s1);
+                t1 = mfma4(ft(f + 3), ht[i].w, t1);
+            }
+            hs2[o] = activate<0>(s0 + s1);
+            ht2[o] = activate<1>(t0 + t1);
+        }
+#pragma unroll
+        for (int o = 0; o < NH; ++o) { hs[o] = hs2[o]; ht[o] = ht2[o]; }
+    }
+    float ld = 0.f;
+    {  // Linear(H,D) restricted to the transformed class, both nets, then the affine update
+        const float *bs = bias_s + 16 * NH * (1 + L) + g4, *bt = bias_t + 16 * NH * (1 + L) + g4;
+        f32x4 ls[NT], t[NT];
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            ls[tau] = *reinterpret_cast<const f32x4 *>(bs + 16 * tau);
+            t[tau] = *reinterpret_cast<const f32x4 *>(bt + 16 * tau);
+        }
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bsv = r == 0 ? hs[i].x : r == 1 ? hs[i].y : r == 2 ? hs[i].z : hs[i].w;
+                const float btv = r == 0 ? ht[i].x : r == 1 ? ht[i].y : r == 2 ? ht[i].z : ht[i].w;
+#pragma unroll
+                for (int tau = 0; tau < NT; ++tau) {  // 2*NT independent chains, round robin
+                    const int f = FC::F1 + FC::F2 + (tau * NH + i) * 4 + r;
+                    ls[tau] = mfma4(fs(f), bsv, ls[tau]);
+                    t[tau] = mfma4(ft(f), btv, t[tau]);
+                }
+            }
+        }
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            if (!INVERSE) {  // inputs * exp(log_s) + t ; +sum(log_s)      networks.py:296-298
+                trans[tau].x = trans[tau].x * __expf(ls[tau].x) + t[tau].x;
+                trans[tau].y = trans[tau].y * __expf(ls[tau].y) + t[tau].y;
+                trans[tau].z = trans[tau].z * __expf(ls[tau].z) + t[tau].z;
+                trans[tau].w = trans[tau].w * __expf(ls[tau].w) + t[tau].w;
+                ld += (ls[tau].x + ls[tau].y) + (ls[tau].z + ls[tau].w);
+            } else {  // (inputs - t) * exp(-log_s) ; -sum(log_s)             networks.py:307-309
+                trans[tau].x = (trans[tau].x - t[tau].x) * __expf(-ls[tau].x);
+                trans[tau].y = (trans[tau].y - t[tau].y) * __expf(-ls[tau].y);
+                trans[tau].z = (trans[tau].z - t[tau].z) * __expf(-ls[tau].z);
+                trans[tau].w = (trans[tau].w - t[tau].w) * __expf(-ls[tau].w);
+                ld -= (ls[tau].x + ls[tau].y) + (ls[tau].z + ls[tau].w);
+            }
+        }
+    }
+    return ld;
+}
+
+// ONE net of a coupling block (used by the multi-wave "team" kernel where the scale and translate nets run on
+// different waves).  Same k-step -> accumulator assignment as coupling_core, so the values are bit-identical.
+template <int NT, int NH, int L, int ACT, class F>
+__device__ __forceinline__ void mlp_core(const F &fr, const float *__restrict__ bias, int lane, const f32x4 (&cond)[NT],
+                                         f32x4 (&out)[NT]) {
+    typedef FragCount<NT, NH, L> FC;
+    const int g4 = (lane >> 4) * 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 h[NH];
+#pragma unroll
+    for (int o = 0; o < NH; ++o) {
+        f32x4 s0 = *reinterpret_cast<const f32x4 *>(bias + g4 + 16 * o), s1 = zero4;
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            const int f = (o * NT + tau) * 4;
+            s0 = mfma4(fr(f), cond[tau].x, s0);
+            s1 = mfma4(fr(f + 1), cond[tau].y, s1);
+            s0 = mfma4(fr(f + 2), cond[tau].z, s0);
+            s1 = mfma4(fr(f + 3), cond[tau].w, s1);
+        }
+        h[o] = activate<ACT>(s0 + s1);
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        f32x4 h2[NH];
+#pragma unroll
+        for (int o = 0; o < NH; ++o) {
+            f32x4 s0 = *reinterpret_cast<const f32x4 *>(bias + 16 * NH + g4 + (l * NH + o) * 16), s1 = zero4;
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                const int f = FC::F1 + ((l * NH + o) * NH + i) * 4;
+                s0 = mfma4(fr(f), h[i].x, s0);
+                s1 = mfma4(fr(f + 1), h[i].y, s1);
+                s0 = mfma4(fr(f + 2), h[i].z, s0);
+                s1 = mfma4(fr(f + 3), h[i].w, s1);
+            }
+            h2[o] = activate<ACT>(s0 + s1);
+        }
+#pragma unroll
+        for (int o = 0; o < NH; ++o) h[o] = h2[o];
+    }
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) out[tau] = *reinterpret_cast<const f32x4 *>(bias + 16 * NH * (1 + L) + g4 + 16 * tau);
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float bv = r == 0 ? h[i].x : r == 1 ? h[i].y : r == 2 ? h[i].z : h[i].w;
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) out[tau] = mfma4(fr(FC::F1 + FC::F2 + (tau * NH + i) * 4 + r), bv, out[tau]);
+        }
+    }
+}
+
+// the affine update of a coupling block given both nets' outputs; returns the lane's log-det partial
+template <int NT, bool INVERSE>
+__device__ __forceinline__ float affine_update(const f32x4 (&ls)[NT], const f32x4 (&t)[NT], f32x4 (&trans)[NT]) {
+    float ld = 0.f;
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        if (!INVERSE) {
+            trans[tau].x = trans[tau].x * __expf(ls[tau].x) + t[tau].x;
+            trans[tau].y = trans[tau].y * __expf(ls[tau].y) + t[tau].y;
+            trans[tau].z = trans[tau].z * __expf(ls[tau].z) + t[tau].z;
+            trans[tau].w = trans[tau].w * __expf(ls[tau].w) + t[tau].w;
+            ld += (ls[tau].x + ls[tau].y) + (ls[tau].z + ls[tau].w);
+        } else {
+            trans[tau].x = (trans[tau].x - t[tau].x) * __expf(-ls[tau].x);
+            trans[tau].y = (trans[tau].y - t[tau].y) * __expf(-ls[tau].y);
+            trans[tau].z = (trans[tau].z - t[tau].z) * __expf(-ls[tau].z);
+            trans[tau].w = (trans[tau].w - t[tau].w) * __expf(-ls[tau].w);
+            ld -= (ls[tau].x + ls[tau].y) + (ls[tau].z + ls[tau].w);
+        }
+    }
+    return ld;
+}
+
+// image-backed form (fragments read from LDS/global at each use)
+template <int NT, int NH, int L, bool INVERSE>
+__device__ __forceinline__ float coupling_tile_il(const float *__restrict__ wblk, int net_floats, int lane,
+                                                  const f32x4 (&cond)[NT], f32x4 (&trans)[NT]) {
+    ImageFrags fs = {wblk + lane}, ft = {wblk + net_floats + lane};
+    const int ob = frag_off_b1(NT, NH, L);
+    return coupling_core<NT, NH, L, INVERSE>(fs, ft, wblk + ob, wblk + net_floats + ob, lane, cond, trans);
+}
+
 // sum a per-lane partial over the 4 lane groups of a walker (lanes w, w+16, w+32, w+48); every lane
 // ends with the walker total.
 __device__ __forceinline__ float group_sum(float v) {
@@ -174,29 +380,38 @@ __device__ __forceinline__ int group_and(int v) {
     return v;
 }
 
+// one coupling block in either direction; LT >= 0 selects the compile-time-L interleaved form, LT = -1 the
+// generic runtime-L form
+template <int NT, int NH, int LT, bool INVERSE>
+__device__ __forceinline__ float coupling_any(const float *__restrict__ wblk, int net_floats, int L, int lane,
+                                              const f32x4 (&cond)[NT], f32x4 (&trans)[NT]) {
+    if constexpr (LT >= 0) return coupling_tile_il<NT, NH, LT, INVERSE>(wblk, net_floats, lane, cond, trans);
+    else return coupling_tile<NT, NH, INVERSE>(wblk, net_floats, L, lane, cond, trans);
+}
+
 // NormalizingFlow.forward (networks.py:24-32): blocks 0..B-1.  xs[c][tau] = class c tiles.
 // Block b conditions on class (b+1)&1 and transforms class b&1 (mask = arange(D)%2 flipped per block).
-template <int NT, int NH>
+template <int NT, int NH, int LT = -1>
 __device__ __forceinline__ float flow_forward_tile(const float *__restrict__ img, int net_floats, int B, int L,
                                                    int lane, f32x4 (&xs)[2][NT]) {
     float ld = 0.f;
     for (int b = 0; b < B; ++b) {
         const float *wblk = img + (size_t)b * 2 * net_floats;
-        if (b & 1) ld += coupling_tile<NT, NH, false>(wblk, net_floats, L, lane, xs[0], xs[1]);
-        else       ld += coupling_tile<NT, NH, false>(wblk, net_floats, L, lane, xs[1], xs[0]);
+        if (b & 1) ld += coupling_any<NT, NH, LT, false>(wblk, net_floats, L, lane, xs[0], xs[1]);
+        else       ld += coupling_any<NT, NH, LT, false>(wblk, net_floats, L, lane, xs[1], xs[0]);
     }
     return ld;
 }
 
 // NormalizingFlow.inverse (networks.py:34-42): blocks reversed.
-template <int NT, int NH>
+template <int NT, int NH, int LT = -1>
 __device__ __forceinline__ float flow_inverse_tile(const float *__restrict__ img, int net_floats, int B, int L,
                                                    int lane, f32x4 (&xs)[2][NT]) {
     float ld = 0.f;
     for (int b = B - 1; b >= 0; --b) {
         const float *wblk = img + (size_t)b * 2 * net_floats;
-        if (b & 1) ld += coupling_tile<NT, NH, true>(wblk, net_floats, L, lane, xs[0], xs[1]);
-        else       ld += coupling_tile<NT, NH, true>(wblk, net_floats, L, lane, xs[1], xs[0]);
+        if (b & 1) ld += coupling_any<NT, NH, LT, true>(wblk, net_floats, L, lane, xs[0], xs[1]);
+        else       ld += coupling_any<NT, NH, LT, true>(wblk, net_floats, L, lane, xs[1], xs[0]);
     }
     return ld;
 }
@@ -260,13 +475,15 @@ __device__ __forceinline__ int inbox_tile(const f32x4 (&xs)[2][NT]) {
 
 // ---- likelihoods (nnest/likelihoods.py) through safe_loglike (nnest/sampler.py:110-133) --------------
 // theta = like_scale * x in float32 (transform = lambda x: s*x on a float32 array, examples/nested/run.py:25-42);
-// per-term arithmetic in float32 with the reference's operation order and no FMA contraction; the sum
-// over terms is accumulated in float64 (the reference sums in float32; DESIGN.md "Precision").
+// per-term arithmetic in float32 with the reference's operation order and no FMA contraction; each lane sums
+// its own <= 8*NT terms in float32 (branch-free), the four lane partials of a walker are combined in float64
+// (the reference sums all terms sequentially in float32; DESIGN.md "Precision").
 #pragma clang fp contract(off)
 template <int NT>
 __device__ __forceinline__ double loglike_tile(int like_id, float scale, int D, int lane, const f32x4 (&xs)[2][NT]) {
     const int g = lane >> 4;
     double acc = 0.0;
+    float facc = 0.f;
     if (like_id == 0) {
         // Rosenbrock (likelihoods.py:51): -sum_i 100*(x[i+1]-x[i]^2)^2 + (1-x[i])^2, i = 0..D-2
 #pragma unroll
@@ -291,13 +508,12 @@ __device__ __forceinline__ double loglike_tile(int like_id, float scale, int D, 
                 float f = 1.0f - th[j];
                 float q = f * f;
                 float term = e + q;
-                if (i + 1 < D) acc += (double)term;
+                facc = facc + ((i + 1 < D) ? term : 0.f);
             }
         }
-        acc = -group_sum(acc);
+        acc = -group_sum((double)facc);
     } else if (like_id == 1) {
         // GaussianMix (likelihoods.py:165-189): logsumexp_k[ log w_k - |theta - mu_k|^2/2 - (D/2) log 2pi ]
-        double base = 0.0;
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
             float th[8];
@@ -309,10 +525,10 @@ __device__ __forceinline__ double loglike_tile(int like_id, float scale, int D, 
             for (int j = 0; j < 8; ++j) {
                 int d = 32 * tau + 8 * g + j;
                 float sq = th[j] * th[j];
-                if (d >= 2 && d < D) base += (double)sq;
+                facc = facc + ((d >= 2 && d < D) ? sq : 0.f);
             }
         }
-        base = group_sum(base);
+        const double base = group_sum((double)facc);
         const int w = lane & 15;
         float t0 = __shfl(scale * xs[0][0].x, w);  // theta[0], theta[1] live in lane group 0
         float t1 = __shfl(scale * xs[1][0].x, w);
@@ -343,10 +559,10 @@ __device__ __forceinline__ double loglike_tile(int like_id, float scale, int D, 
                 float a = x0 * x0 + x1 - 11.f;
                 float b = x0 + x1 * x1 - 7.f;
                 float v = -(a * a) - b * b;
-                if (d1 < D) acc += (double)v;
+                facc = facc + ((d1 < D) ? v : 0.f);
             }
         }
-        acc = group_sum(acc);
+        acc = group_sum((double)facc);
     }
     if (!(fabs(acc) <= 1.79769313486231570e308)) acc = -1e100;  // logl[~isfinite] = -1e100   sampler.py:128
     return acc;
@@ -404,5 +620,59 @@ __device__ __forceinline__ float noise_uniform(uint64_t seed, uint64_t walker, u
     u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     return (float)(r.x >> 8) * 5.9604644775390625e-08f;
 }
+
+// ---- proposal stream of the persistent MH kernel -------------------------------------------------------
+// Philox costs two 32x32->64 multiplies per round (quarter rate on CDNA) -- measured as the largest single
+// VALU cost of the MH step when used per draw -- so inside the step loop each lane advances a
+// xoshiro128++ state (Blackman & Vigna 2019: add / xor / shift / rotate only, full-rate VALU) that is SEEDED
+// by one Philox4x32-10 block keyed by (seed; walker, lane group, stream).  A walker's stream still depends
+// only on (seed, global walker index), so sharded runs reproduce the unsharded run bit for bit.
+struct Xoshiro128 { uint32_t a, b, c, d; };
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int k) { return __builtin_amdgcn_alignbit(x, x, 32 - k); }
+
+__device__ __forceinline__ uint32_t xoshiro_next(Xoshiro128 &s) {  // xoshiro128++
+    uint32_t r = rotl32(s.a + s.d, 7) + s.a;
+    uint32_t t = s.b << 9;
+    s.c ^= s.a;
+    s.d ^= s.b;
+    s.b ^= s.c;
+    s.a ^= s.d;
+    s.c ^= t;
+    s.d = rotl32(s.d, 11);
+    return r;
+}
+
+__device__ __forceinline__ Xoshiro128 xoshiro_seed(uint64_t seed, uint64_t walker, uint32_t sub, uint32_t stream) {
+    u32x4 c;
+    c.x = sub;
+    c.y = (uint32_t)walker;
+    c.z = 0x58f1c3a5u;  // distinguishes the seeding blocks from the per-draw blocks above
+    c.w = ((uint32_t)(walker >> 32) & 0x0fffffffu) | (stream << 28);
+    u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    Xoshiro128 s = {r.x, r.y, r.z, r.w | 1u};  // never the all-zero state
+    return s;
+}
+
+// Box-Muller pair from two 32-bit draws (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32 in revolutions)
+__device__ __forceinline__ void box_muller(uint32_t r0, uint32_t r1, float &n0, float &n1) {
+    const float two_m32 = 2.3283064365386963e-10f, two_m33 = 1.1641532182693481e-10f;
+    float u1 = fmaf((float)r0, two_m32, two_m33), ang = (float)r1 * two_m32;
+    // v_log_f32 is log2: -2 ln(u) = (-2 ln 2) log2(u); raw v_sqrt_f32 (1 ulp) -- no refinement sequence needed for noise
+    float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    n0 = rad * __builtin_amdgcn_cosf(ang);
+    n1 = rad * __builtin_amdgcn_sinf(ang);
+}
+
+// eight N(0,1) draws = the 8 consecutive dims a lane owns in one tile
+__device__ __forceinline__ void xoshiro_normal8(Xoshiro128 &s, float (&n)[8]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        uint32_t r0 = xoshiro_next(s), r1 = xoshiro_next(s);
+        box_muller(r0, r1, n[2 * p], n[2 * p + 1]);
+    }
+}
+
+__device__ __forceinline__ float xoshiro_uniform(Xoshiro128 &s) { return (float)(xoshiro_next(s) >> 8) * 5.9604644775390625e-08f; }
 
 }  // namespace nnest

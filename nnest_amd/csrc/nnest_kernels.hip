@@ -78,7 +78,7 @@ struct PassArgs {
     float like_scale;
 };
 
-template <int NT, int NH, bool WLDS>
+template <int NT, int NH, int LT, bool WLDS>
 __global__ void __launch_bounds__(256) flow_pass_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_img[];
     const float *img = a.img;
@@ -96,9 +96,9 @@ __global__ void __launch_bounds__(256) flow_pass_kernel(PassArgs a) {
         load_tile<NT>(a.in, row, ok, a.s.D, lane, xs);
         float ld;
         if (a.mode == PASS_FORWARD || a.mode == PASS_LOGPROB)
-            ld = flow_forward_tile<NT, NH>(img, a.s.net_floats, a.s.B, a.s.L, lane, xs);
+            ld = flow_forward_tile<NT, NH, LT>(img, a.s.net_floats, a.s.B, a.s.L, lane, xs);
         else
-            ld = flow_inverse_tile<NT, NH>(img, a.s.net_floats, a.s.B, a.s.L, lane, xs);
+            ld = flow_inverse_tile<NT, NH, LT>(img, a.s.net_floats, a.s.B, a.s.L, lane, xs);
         ld = group_sum(ld);
         if (a.mode == PASS_LOGPROB) {
             // MVN(0,I).log_prob(u) + logdet  (networks.py:51-57, :71-76)
@@ -172,24 +172,49 @@ struct MhArgs {
     float *scale_out;
 };
 
-template <int NT, int NH, bool WLDS>
-__global__ void __launch_bounds__(256) mh_kernel(MhArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds_img[];
-    const float *img = a.img;
-    if (WLDS) {
-        stage_image(lds_img, a.img, a.s.image_floats);
-        img = lds_img;
+// The step loop, shared by the two kernel forms below; `inv(xs)` inverts the coupling stack on a tile and
+// returns the lane's log-det partial.  DBG = true adds the test/diagnostic I/O (recorded noise replay, per-step
+// history); the production instantiation carries none of those pointers through the step loop.
+// in-wave proposal streams: normals per (walker, lane group); the accept uniform per walker (identical in its 4
+// lanes).  Padded dims get exactly 0 (their weight fragments are 0, but 0 * inf would poison the accumulators).
+template <int NT>
+struct XoshiroNoise {
+    Xoshiro128 rn, ru;
+    unsigned valid_mask;
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t walker, int g, int D) {
+        rn = xoshiro_seed(seed, walker, (uint32_t)g, NOISE_STREAM_DZ);
+        ru = xoshiro_seed(seed, walker, 0xffffffffu, NOISE_STREAM_U);
+        valid_mask = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (32 * t + 8 * g + j < D) valid_mask |= 1u << (8 * t + j);
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const int tile = blockIdx.x * wpb + wave;
-    const int ntiles = (a.C + 15) >> 4;
-    if (tile >= ntiles) return;
+    __device__ __forceinline__ void next(float (&nz)[NT][8], float &u) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            xoshiro_normal8(rn, nz[t]);  // dims 32t + 8g + [0,8) = (c0r0, c1r0, c0r1, c1r1, c0r2, c1r2, c0r3, c1r3)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (!((valid_mask >> (8 * t + j)) & 1u)) nz[t][j] = 0.f;
+        }
+        u = xoshiro_uniform(ru);
+    }
+};
+
+template <int NT, bool DBG, class Inv, class Noise>
+__device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, const Inv &inv, Noise &noise, bool writer) {
     const int w = lane & 15, g = lane >> 4;
     const int row = tile * 16 + w;
     const bool ok = row < a.C;
     const int D = a.s.D, S = a.steps;
     const uint64_t walker = a.walker_offset + (uint64_t)row;
     const int nvalid = min(16, a.C - tile * 16);  // walkers in this adaptation group
+    const int like_id = a.like_id;
+    const float like_scale = a.like_scale;
+    const double loglstar = a.loglstar;
+    const bool dynamic = (a.flags & NNEST_MH_DYNAMIC_STEP) != 0;
 
     f32x4 z[2][NT], x[2][NT];
     load_tile<NT>(a.z, row, ok, D, lane, z);
@@ -199,20 +224,28 @@ __global__ void __launch_bounds__(256) mh_kernel(MhArgs a) {
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int t = 0; t < NT; ++t) x[c][t] = z[c][t];
-    float ld = group_sum(flow_inverse_tile<NT, NH>(img, a.s.net_floats, a.s.B, a.s.L, lane, x));
+    float ld = group_sum(inv(x));
     double logl = ok ? a.logl[row] : 0.0;
     double scale = (double)a.step_size;  // python float in the reference (sampler.py:255, :428-431)
     int accept = 0, reject = 0, n_acc = 0, n_call = 0;
 
-    if (a.hist_x) store_tile<NT>(a.hist_x, (long)row * (S + 1), ok, D, lane, x);
-    if (a.hist_logl && ok && g == 0) a.hist_logl[(size_t)row * (S + 1)] = logl;
+    if (DBG && writer) {
+        if (a.hist_x) store_tile<NT>(a.hist_x, (long)row * (S + 1), ok, D, lane, x);
+        if (a.hist_logl && ok && g == 0) a.hist_logl[(size_t)row * (S + 1)] = logl;
+    }
+
+    // the draws for step it+1 are requested before step it's coupling stack (they do not depend on it)
+    float nz[NT][8];
+    float u_next = 0.f;
+    const bool recorded = DBG && a.noise_dz;
+    if (!recorded) noise.next(nz, u_next);
 
     for (int it = 1; it <= S; ++it) {
         // proposal z' = z + randn * scale  (sampler.py:310, :316); float32 like torch
         const float fs = (float)scale;
         f32x4 zp[2][NT], xp[2][NT];
         float u;
-        if (a.noise_dz) {
+        if (recorded) {
             f32x4 dz[2][NT];
             load_tile<NT>(a.noise_dz + (size_t)(it - 1) * a.C * D, row, ok, D, lane, dz);
 #pragma unroll
@@ -223,30 +256,19 @@ __global__ void __launch_bounds__(256) mh_kernel(MhArgs a) {
         } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                // dims 32t+8g+[0,4) and +[4,8): (c0r0,c1r0,c0r1,c1r1) and (c0r2,c1r2,c0r3,c1r3)
-                f32x4 n0 = noise_normal4(a.seed, walker, (uint32_t)it, (uint32_t)(8 * t + 2 * g), NOISE_STREAM_DZ);
-                f32x4 n1 = noise_normal4(a.seed, walker, (uint32_t)it, (uint32_t)(8 * t + 2 * g + 1), NOISE_STREAM_DZ);
-                zp[0][t].x = z[0][t].x + n0.x * fs; zp[1][t].x = z[1][t].x + n0.y * fs;
-                zp[0][t].y = z[0][t].y + n0.z * fs; zp[1][t].y = z[1][t].y + n0.w * fs;
-                zp[0][t].z = z[0][t].z + n1.x * fs; zp[1][t].z = z[1][t].z + n1.y * fs;
-                zp[0][t].w = z[0][t].w + n1.z * fs; zp[1][t].w = z[1][t].w + n1.w * fs;
+                zp[0][t].x = z[0][t].x + nz[t][0] * fs; zp[1][t].x = z[1][t].x + nz[t][1] * fs;
+                zp[0][t].y = z[0][t].y + nz[t][2] * fs; zp[1][t].y = z[1][t].y + nz[t][3] * fs;
+                zp[0][t].z = z[0][t].z + nz[t][4] * fs; zp[1][t].z = z[1][t].z + nz[t][5] * fs;
+                zp[0][t].w = z[0][t].w + nz[t][6] * fs; zp[1][t].w = z[1][t].w + nz[t][7] * fs;
             }
-            // padded dims must stay exactly 0 (their weight fragments are 0, but 0*inf would poison)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int d0 = 32 * t + 8 * g;
-                if (d0 + 0 >= D) zp[0][t].x = 0.f; if (d0 + 1 >= D) zp[1][t].x = 0.f;
-                if (d0 + 2 >= D) zp[0][t].y = 0.f; if (d0 + 3 >= D) zp[1][t].y = 0.f;
-                if (d0 + 4 >= D) zp[0][t].z = 0.f; if (d0 + 5 >= D) zp[1][t].z = 0.f;
-                if (d0 + 6 >= D) zp[0][t].w = 0.f; if (d0 + 7 >= D) zp[1][t].w = 0.f;
-            }
-            u = noise_uniform(a.seed, walker, (uint32_t)it);
+            u = u_next;
+            noise.next(nz, u_next);
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int t = 0; t < NT; ++t) xp[c][t] = zp[c][t];
-        float ldp = group_sum(flow_inverse_tile<NT, NH>(img, a.s.net_floats, a.s.B, a.s.L, lane, xp));  // :321
+        float ldp = group_sum(inv(xp));  // sampler.py:321
 
         // log_ratio = log_det_J' - log_det_J, -inf outside the prior box  (sampler.py:326-331)
         const int inb = inbox_tile<NT>(xp);
@@ -257,28 +279,34 @@ __global__ void __launch_bounds__(256) mh_kernel(MhArgs a) {
 
         // likelihood of the proposal (the reference evaluates it only for `pre` rows, :358-360; here it is
         // evaluated for every row -- the lanes run in lock step anyway -- and only counted for `pre` rows)
-        double lp = loglike_tile<NT>(a.like_id, a.like_scale, D, lane, xp);
-        const bool acc = pre && (lp > a.loglstar);  // finite is guaranteed by the -1e100 clamp  :361
+        double lp = loglike_tile<NT>(like_id, like_scale, D, lane, xp);
+        const bool acc = pre && (lp > loglstar);  // finite is guaranteed by the -1e100 clamp  :361
         n_call += pre ? 1 : 0;
         n_acc += acc ? 1 : 0;
-        if (acc) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { z[c][t] = zp[c][t]; x[c][t] = xp[c][t]; }
-            ld = ldp;
-            logl = lp;
-        }
-        if (a.flags & NNEST_MH_DYNAMIC_STEP) {  // sampler.py:422-431, per adaptation group
+            for (int t = 0; t < NT; ++t) {
+                z[c][t].x = acc ? zp[c][t].x : z[c][t].x; z[c][t].y = acc ? zp[c][t].y : z[c][t].y;
+                z[c][t].z = acc ? zp[c][t].z : z[c][t].z; z[c][t].w = acc ? zp[c][t].w : z[c][t].w;
+                x[c][t].x = acc ? xp[c][t].x : x[c][t].x; x[c][t].y = acc ? xp[c][t].y : x[c][t].y;
+                x[c][t].z = acc ? xp[c][t].z : x[c][t].z; x[c][t].w = acc ? xp[c][t].w : x[c][t].w;
+            }
+        ld = acc ? ldp : ld;
+        logl = acc ? lp : logl;
+        if (dynamic) {  // sampler.py:422-431, per adaptation group
             unsigned long long bal = __ballot(acc && g == 0);
             int num_accepted = __popcll(bal);
             if (2 * num_accepted > nvalid) accept += 1; else reject += 1;
             if (accept > reject) scale *= exp(1.0 / (1 + accept));
             if (accept < reject) scale /= exp(1.0 / (1 + reject));
         }
-        if (a.hist_x) store_tile<NT>(a.hist_x, (long)row * (S + 1) + it, ok, D, lane, x);
-        if (a.hist_logl && ok && g == 0) a.hist_logl[(size_t)row * (S + 1) + it] = logl;
+        if (DBG && writer) {
+            if (a.hist_x) store_tile<NT>(a.hist_x, (long)row * (S + 1) + it, ok, D, lane, x);
+            if (a.hist_logl && ok && g == 0) a.hist_logl[(size_t)row * (S + 1) + it] = logl;
+        }
     }
+    if (!writer) return;
     store_tile<NT>(a.z, row, ok, D, lane, z);
     if (a.x) store_tile<NT>(a.x, row, ok, D, lane, x);
     if (ok && g == 0) {
@@ -289,21 +317,211 @@ __global__ void __launch_bounds__(256) mh_kernel(MhArgs a) {
     if (a.scale_out && lane == 0) a.scale_out[tile] = (float)scale;
 }
 
+// Form 1 (any shape): weight fragments read from the image (LDS copy, or global when it does not fit) at each use.
+template <int NT, int NH, int LT>
+struct ImageInverse {
+    const float *img;
+    int net_floats, B, L, lane;
+    __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
+        return flow_inverse_tile<NT, NH, LT>(img, net_floats, B, L, lane, xs);
+    }
+};
+
+template <int NT, int NH, int LT, bool WLDS, bool DBG>
+__global__ void __launch_bounds__(256) mh_kernel(MhArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_img[];
+    const float *img = a.img;
+    if (WLDS) {
+        stage_image(lds_img, a.img, a.s.image_floats);
+        img = lds_img;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int tile = blockIdx.x * wpb + wave;
+    if (tile >= ((a.C + 15) >> 4)) return;
+    ImageInverse<NT, NH, LT> inv = {img, a.s.net_floats, a.s.B, a.s.L, lane};
+    XoshiroNoise<NT> noise;
+    noise.init(a.seed, a.walker_offset + (uint64_t)(tile * 16 + (lane & 15)), lane >> 4, a.s.D);
+    mh_body<NT, DBG>(a, tile, lane, inv, noise, true);
+}
+
+// Form 2 (the reference's default flow: num_blocks = B, num_layers = L fixed at compile time): every weight
+// fragment of the stack is loaded ONCE into this lane's registers (one float per MFMA, 40 per block at
+// x_dim 50) and stays there for all steps; only the biases sit in LDS.  The image-backed form measured ~75
+// cycles per MFMA because each fragment read exposes LDS latency in front of its MFMA (tools/ablate_mh.hip);
+// here the MFMA A operands are plain registers.  One wave per workgroup.
+template <int NT, int NH, int L, int B>
+struct RegInverse {
+    typedef FragCount<NT, NH, L> FC;
+    RegFrags<FC::N> w[B][2];
+    const float *bias;  // LDS: [b][net][16*NH*(1+L) + 16*NT]
+    int lane;
+    static constexpr int NBIAS = 16 * NH * (1 + L) + 16 * NT;
+    __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
+        float ld = 0.f;
+#pragma unroll
+        for (int b = B - 1; b >= 0; --b) {
+            const float *bs = bias + (b * 2) * NBIAS, *bt = bs + NBIAS;
+            if (b & 1) ld += coupling_core<NT, NH, L, true>(w[b][0], w[b][1], bs, bt, lane, xs[0], xs[1]);
+            else       ld += coupling_core<NT, NH, L, true>(w[b][0], w[b][1], bs, bt, lane, xs[1], xs[0]);
+        }
+        return ld;
+    }
+};
+
+template <int NT, int NH, int L, int B, bool DBG>
+__global__ void __launch_bounds__(64) mh_kernel_reg(MhArgs a) {
+    typedef RegInverse<NT, NH, L, B> RI;
+    __shared__ __attribute__((aligned(16))) float bias_lds[B * 2 * RI::NBIAS];
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int net_floats = a.s.net_floats;
+    RI inv;
+    inv.bias = bias_lds;
+    inv.lane = lane;
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float *src = a.img + (size_t)(b * 2 + n) * net_floats;
+#pragma unroll
+            for (int i = 0; i < RI::FC::N; ++i) inv.w[b][n].v[i] = src[i * 64 + lane];
+            for (int i = lane; i < RI::NBIAS; i += 64) bias_lds[(b * 2 + n) * RI::NBIAS + i] = src[frag_off_b1(NT, NH, L) + i];
+        }
+    __syncthreads();
+    XoshiroNoise<NT> noise;
+    noise.init(a.seed, a.walker_offset + (uint64_t)(tile * 16 + (lane & 15)), lane >> 4, a.s.D);
+    mh_body<NT, DBG>(a, tile, lane, inv, noise, true);
+}
+
+// Form 3 (small populations, default flow): a TEAM of three waves on one CU per 16-walker tile.
+//   wave 0  scale net       wave 1  translate net       wave 2  proposal noise for the NEXT step
+// A lone wave spends a step in a strictly serial chain (noise -> 3 x [Linear, act, Linear, act, Linear, affine] ->
+// likelihood -> accept, ~10k cycles with both nets' MFMAs in one issue stream); with fewer tiles than CUs the
+// other three SIMDs of the CU idle.  Here the two nets of a block run concurrently on two SIMDs and meet once per
+// block through LDS (each wave publishes its ls / t tiles, one barrier, each reads the other's and applies the
+// same affine update, so both hold bit-identical state), and the noise leaves the critical path.  Waves 0 and 1
+// evaluate prior / likelihood / accept redundantly on identical values; wave 0 writes the results.
+template <int NT, int L, int B>
+struct TeamInverse {
+    typedef FragCount<NT, 1, L> FC;
+    static constexpr int NBIAS = 16 * (1 + L) + 16 * NT;
+    RegFrags<FC::N> w[B];  // this wave's net only
+    const float *bias;     // LDS [b][net][NBIAS]
+    f32x4 *xch;            // LDS [parity][net][NT][64 lanes]
+    int lane, role;
+    __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
+        float ld = 0.f;
+#pragma unroll
+        for (int b = B - 1; b >= 0; --b) {
+            f32x4 mine[NT], other[NT];
+            if (b & 1) {
+                if (role == 0) mlp_core<NT, 1, L, 0>(w[b], bias + (b * 2 + 0) * NBIAS, lane, xs[0], mine);
+                else           mlp_core<NT, 1, L, 1>(w[b], bias + (b * 2 + 1) * NBIAS, lane, xs[0], mine);
+            } else {
+                if (role == 0) mlp_core<NT, 1, L, 0>(w[b], bias + (b * 2 + 0) * NBIAS, lane, xs[1], mine);
+                else           mlp_core<NT, 1, L, 1>(w[b], bias + (b * 2 + 1) * NBIAS, lane, xs[1], mine);
+            }
+            f32x4 *slot = xch + (size_t)((b & 1) * 2) * NT * 64;  // double-buffered by block parity
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) slot[(role * NT + tau) * 64 + lane] = mine[tau];
+            __syncthreads();
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) other[tau] = slot[((1 - role) * NT + tau) * 64 + lane];
+            if (b & 1) ld += role == 0 ? affine_update<NT, true>(mine, other, xs[1]) : affine_update<NT, true>(other, mine, xs[1]);
+            else       ld += role == 0 ? affine_update<NT, true>(mine, other, xs[0]) : affine_update<NT, true>(other, mine, xs[0]);
+        }
+        return ld;
+    }
+};
+
+template <int NT>
+struct LdsNoise {
+    const float *nbuf;  // [2][NT*8][64]
+    const float *ubuf;  // [2][64]
+    int lane, k;
+    __device__ __forceinline__ void next(float (&nz)[NT][8], float &u) {
+        __syncthreads();  // the noise wave has published buffer k&1
+        const float *p = nbuf + (size_t)(k & 1) * NT * 8 * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) nz[t][j] = p[(t * 8 + j) * 64];
+        u = ubuf[(k & 1) * 64 + lane];
+        ++k;
+    }
+};
+
+template <int NT, int L, int B, bool DBG>
+__global__ void __launch_bounds__(192) mh_kernel_team(MhArgs a) {
+    typedef TeamInverse<NT, L, B> TI;
+    __shared__ __attribute__((aligned(16))) float bias_lds[B * 2 * TI::NBIAS];
+    __shared__ __attribute__((aligned(16))) f32x4 xch[2 * 2 * NT * 64];
+    __shared__ float nbuf[2 * NT * 8 * 64];
+    __shared__ float ubuf[2 * 64];
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const int tile = blockIdx.x;
+    const int net_floats = a.s.net_floats, S = a.steps;
+    for (int i = threadIdx.x; i < B * 2 * TI::NBIAS; i += blockDim.x) {
+        int bn = i / TI::NBIAS, o = i - bn * TI::NBIAS;
+        bias_lds[i] = a.img[(size_t)bn * net_floats + frag_off_b1(NT, 1, L) + o];
+    }
+    __syncthreads();
+    if (role == 2) {  // noise producer: S+1 buffers, each published by the barrier the consumers wait on
+        XoshiroNoise<NT> gen;
+        gen.init(a.seed, a.walker_offset + (uint64_t)(tile * 16 + (lane & 15)), lane >> 4, a.s.D);
+        for (int k = 0; k <= S; ++k) {
+            float nz[NT][8], u;
+            gen.next(nz, u);
+            float *p = nbuf + (size_t)(k & 1) * NT * 8 * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p[(t * 8 + j) * 64] = nz[t][j];
+            ubuf[(k & 1) * 64 + lane] = u;
+            if (k == 0)
+                for (int b = 0; b < B; ++b) __syncthreads();  // the consumers' initial inverse
+            __syncthreads();                                   // publish buffer k
+            if (k >= 1)
+                for (int b = 0; b < B; ++b) __syncthreads();  // step k's inverse
+        }
+        return;
+    }
+    TI inv;
+    inv.bias = bias_lds;
+    inv.xch = xch;
+    inv.lane = lane;
+    inv.role = role;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const float *src = a.img + (size_t)(b * 2 + role) * net_floats;
+#pragma unroll
+        for (int i = 0; i < TI::FC::N; ++i) inv.w[b].v[i] = src[i * 64 + lane];
+    }
+    LdsNoise<NT> noise = {nbuf, ubuf, lane, 0};
+    mh_body<NT, DBG>(a, tile, lane, inv, noise, role == 0);
+}
+
+// The proposal noise of mh_kernel as arrays: one thread per (walker, lane group) replays the same streams.
 __global__ void fill_noise_kernel(float *__restrict__ dz, float *__restrict__ u, int steps, int C, int D, uint64_t seed,
                                   uint64_t walker_offset) {
-    const int nq = (D + 3) / 4;
-    const long total = (long)steps * C * nq;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int q = (int)(i % nq);
-        long sc = i / nq;
-        int c = (int)(sc % C), s = (int)(sc / C);
-        f32x4 n = noise_normal4(seed, walker_offset + (uint64_t)c, (uint32_t)(s + 1), (uint32_t)q, NOISE_STREAM_DZ);
-        float *o = dz + ((size_t)s * C + c) * D + 4 * q;
-        if (4 * q + 0 < D) o[0] = n.x;
-        if (4 * q + 1 < D) o[1] = n.y;
-        if (4 * q + 2 < D) o[2] = n.z;
-        if (4 * q + 3 < D) o[3] = n.w;
-        if (q == 0 && u) u[(size_t)s * C + c] = noise_uniform(seed, walker_offset + (uint64_t)c, (uint32_t)(s + 1));
+    const int NT = ((D + 1) / 2 + 15) / 16;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 4) return;
+    const int c = i >> 2, g = i & 3;
+    const uint64_t walker = walker_offset + (uint64_t)c;
+    Xoshiro128 rng_n = xoshiro_seed(seed, walker, (uint32_t)g, NOISE_STREAM_DZ);
+    Xoshiro128 rng_u = xoshiro_seed(seed, walker, 0xffffffffu, NOISE_STREAM_U);
+    for (int s = 0; s < steps; ++s) {
+        for (int t = 0; t < NT; ++t) {
+            float n[8];
+            xoshiro_normal8(rng_n, n);
+            for (int j = 0; j < 8; ++j) {
+                int d = 32 * t + 8 * g + j;
+                if (d < D) dz[((size_t)s * C + c) * D + d] = n[j];
+            }
+        }
+        float uu = xoshiro_uniform(rng_u);
+        if (g == 0 && u) u[(size_t)s * C + c] = uu;
     }
 }
 
@@ -329,7 +547,7 @@ static void pick_geometry(int ntiles, int num_cu, int *block, int *grid) {
     *grid = g;
 }
 
-template <int NT, int NH>
+template <int NT, int NH, int LT>
 static hipError_t launch_pass_t(const PassArgs &a, int num_cu, hipStream_t st) {
     const int ntiles = (a.N + 15) / 16;
     int block, grid;
@@ -338,51 +556,83 @@ static hipError_t launch_pass_t(const PassArgs &a, int num_cu, hipStream_t st) {
     // grid-stride over tiles once there are more than ~8 workgroups per CU (amortises the LDS staging)
     if (grid > 8 * num_cu) grid = 8 * num_cu;
     if (img_bytes <= (size_t)LDS_IMAGE_LIMIT) {
-        hipError_t e = allow_lds(flow_pass_kernel<NT, NH, true>, img_bytes);
+        hipError_t e = allow_lds(flow_pass_kernel<NT, NH, LT, true>, img_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((flow_pass_kernel<NT, NH, true>), dim3(grid), dim3(block), img_bytes, st, a);
+        hipLaunchKernelGGL((flow_pass_kernel<NT, NH, LT, true>), dim3(grid), dim3(block), img_bytes, st, a);
     } else {
-        hipLaunchKernelGGL((flow_pass_kernel<NT, NH, false>), dim3(grid), dim3(block), 0, st, a);
+        hipLaunchKernelGGL((flow_pass_kernel<NT, NH, LT, false>), dim3(grid), dim3(block), 0, st, a);
     }
     return hipGetLastError();
 }
 
-template <int NT, int NH>
+template <int NT, int NH, int LT>
 static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
     const int ntiles = (a.C + 15) / 16;
+    if constexpr (LT == 1 && NH == 1 && NT <= 2) {  // NT >= 3 would spill: those shapes stay on the image form
+        if (a.s.B == 3 && ntiles <= num_cu && !a.noise_dz) {  // fewer tiles than CUs: three waves per tile (team form)
+            if (a.hist_x || a.hist_logl)
+                hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, true>), dim3(ntiles), dim3(192), 0, st, a);
+            else
+                hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, false>), dim3(ntiles), dim3(192), 0, st, a);
+            return hipGetLastError();
+        }
+        if (a.s.B == 3 && ntiles <= 4 * num_cu) {  // one wave per SIMD available; SingleSpeedNVP defaults: hidden_dim 16, num_blocks 3, num_layers 1 (nnest/sampler.py:37-43)
+            if (a.noise_dz || a.hist_x || a.hist_logl)
+                hipLaunchKernelGGL((mh_kernel_reg<NT, 1, 1, 3, true>), dim3(ntiles), dim3(64), 0, st, a);
+            else
+                hipLaunchKernelGGL((mh_kernel_reg<NT, 1, 1, 3, false>), dim3(ntiles), dim3(64), 0, st, a);
+            return hipGetLastError();
+        }
+    }
     int block, grid;
     pick_geometry(ntiles, num_cu, &block, &grid);
     const size_t img_bytes = (size_t)a.s.image_floats * 4;
+    const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
     if (img_bytes <= (size_t)LDS_IMAGE_LIMIT) {
-        hipError_t e = allow_lds(mh_kernel<NT, NH, true>, img_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((mh_kernel<NT, NH, true>), dim3(grid), dim3(block), img_bytes, st, a);
+        if (dbg) {
+            hipError_t e = allow_lds(mh_kernel<NT, NH, LT, true, true>, img_bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((mh_kernel<NT, NH, LT, true, true>), dim3(grid), dim3(block), img_bytes, st, a);
+        } else {
+            hipError_t e = allow_lds(mh_kernel<NT, NH, LT, true, false>, img_bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((mh_kernel<NT, NH, LT, true, false>), dim3(grid), dim3(block), img_bytes, st, a);
+        }
     } else {
-        hipLaunchKernelGGL((mh_kernel<NT, NH, false>), dim3(grid), dim3(block), 0, st, a);
+        if (dbg) hipLaunchKernelGGL((mh_kernel<NT, NH, LT, false, true>), dim3(grid), dim3(block), 0, st, a);
+        else hipLaunchKernelGGL((mh_kernel<NT, NH, LT, false, false>), dim3(grid), dim3(block), 0, st, a);
     }
     return hipGetLastError();
 }
 
-#define DISPATCH_SHAPE(FN, s, ...)                                   \
+// L = 1 (the reference default, nnest/sampler.py:43) gets the compile-time interleaved form; other depths run
+// the generic runtime-L form (LT = -1)
+#define DISPATCH_NTNH(FN, s, LT, ...)                                \
     do {                                                             \
         if ((s).NH == 1) {                                           \
             switch ((s).NT) {                                        \
-                case 1: return FN<1, 1>(__VA_ARGS__);                \
-                case 2: return FN<2, 1>(__VA_ARGS__);                \
-                case 3: return FN<3, 1>(__VA_ARGS__);                \
-                case 4: return FN<4, 1>(__VA_ARGS__);                \
+                case 1: return FN<1, 1, LT>(__VA_ARGS__);            \
+                case 2: return FN<2, 1, LT>(__VA_ARGS__);            \
+                case 3: return FN<3, 1, LT>(__VA_ARGS__);            \
+                case 4: return FN<4, 1, LT>(__VA_ARGS__);            \
             }                                                        \
         } else if ((s).NH == 2) {                                    \
             switch ((s).NT) {                                        \
-                case 1: return FN<1, 2>(__VA_ARGS__);                \
-                case 2: return FN<2, 2>(__VA_ARGS__);                \
+                case 1: return FN<1, 2, LT>(__VA_ARGS__);            \
+                case 2: return FN<2, 2, LT>(__VA_ARGS__);            \
             }                                                        \
         } else if ((s).NH == 4) {                                    \
             switch ((s).NT) {                                        \
-                case 1: return FN<1, 4>(__VA_ARGS__);                \
+                case 1: return FN<1, 4, LT>(__VA_ARGS__);            \
             }                                                        \
         }                                                            \
         return hipErrorInvalidConfiguration;                         \
+    } while (0)
+
+#define DISPATCH_SHAPE(FN, s, ...)                                   \
+    do {                                                             \
+        if ((s).L == 1) DISPATCH_NTNH(FN, s, 1, __VA_ARGS__);        \
+        DISPATCH_NTNH(FN, s, -1, __VA_ARGS__);                       \
     } while (0)
 
 bool shape_supported(const FlowShape &s) {
@@ -439,12 +689,10 @@ hipError_t launch_loglike(int like_id, const float *x, float scale, double *logl
 
 hipError_t launch_fill_noise(float *dz, float *u, int steps, int C, int D, uint64_t seed, uint64_t walker_offset,
                              hipStream_t st) {
-    long total = (long)steps * C * ((D + 3) / 4);
-    if (total <= 0) return hipSuccess;
+    if (steps <= 0 || C <= 0) return hipSuccess;
     int block = 256;
-    long grid = (total + block - 1) / block;
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(fill_noise_kernel, dim3((int)grid), dim3(block), 0, st, dz, u, steps, C, D, seed, walker_offset);
+    int grid = (C * 4 + block - 1) / block;
+    hipLaunchKernelGGL(fill_noise_kernel, dim3(grid), dim3(block), 0, st, dz, u, steps, C, D, seed, walker_offset);
     return hipGetLastError();
 }
 

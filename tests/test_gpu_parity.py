@@ -146,7 +146,8 @@ def test_mh_trace_vs_golden_recorded_noise(hip, path):
     assert abs(float(res['scale'][0]) - float(g['scale_out'])) < 1e-6 * max(1.0, float(g['scale_out']))
 
 
-@pytest.mark.parametrize('C,S,dyn', [(1000, 40, False), (37, 25, True), (16, 60, True)])
+# C = 1000 / 37 / 16 -> team form (tiles <= CUs); 4800 -> register form (tiles <= SIMDs); 20000 -> image form
+@pytest.mark.parametrize('C,S,dyn', [(1000, 40, False), (37, 25, True), (16, 60, True), (4800, 6, False), (20000, 3, True)])
 def test_mh_inkernel_noise_vs_oracle(hip, C, S, dyn):
     """In-kernel Philox noise: export the same draws with nnest_mh_fill_noise, replay them through the
     oracle, compare the whole chain.  Per-group step adaptation = the oracle run per 16-walker group."""
