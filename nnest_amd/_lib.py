@@ -12,7 +12,7 @@ import ctypes
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnnest_hip.so')
+LIB_PATH = os.environ.get('NNEST_HIP_LIB', os.path.join(_HERE, 'libnnest_hip.so'))  # override: developer A/B builds only
 
 NNEST_OK = 0
 LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'himmelblau': 2}

@@ -48,7 +48,7 @@ __host__ __device__ inline int frag_net_floats(int NT, int NH, int L) { return f
 // tanh(x) = 1 - 2/(e^{2x}+1): v_exp_f32 + v_rcp_f32; abs error ~1e-7 (inputs to a linear layer, so
 // absolute accuracy is what matters).  Saturates correctly for |x| large; NaN propagates.
 __device__ __forceinline__ float fast_tanh(float x) {
-    float e = __expf(2.0f * x);
+    float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // e^{2x} = 2^{x * 2 log2(e)}: one multiply + v_exp_f32
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
@@ -276,58 +276,85 @@ __device__ __forceinline__ float coupling_core(const FS &fs, const FT &ft, const
     return ld;
 }
 
-// ONE net of a coupling block (used by the multi-wave "team" kernel where the scale and translate nets run on
-// different waves).  Same k-step -> accumulator assignment as coupling_core, so the values are bit-identical.
+// ONE net of a coupling block for the multi-wave "team" kernel (scale and translate nets on different waves),
+// written for the shortest dependent path of a lone wave: the biases arrive in registers (prefetched by the
+// caller while the previous block's exchange is in flight) and every K-accumulation is spread over enough
+// accumulators that no v_mfma waits on the previous one (dependent issue 40 cycles vs 32 back to back), the
+// partial accumulators being summed on the VALU afterwards.
+template <int NT, int NH, int L> struct NetBias {
+    f32x4 b1[NH];
+    f32x4 b2[L > 0 ? L : 1][NH];
+    f32x4 b3[NT];
+    __device__ __forceinline__ void load(const float *__restrict__ bias, int lane) {
+        const int g4 = (lane >> 4) * 4;
+#pragma unroll
+        for (int o = 0; o < NH; ++o) b1[o] = *reinterpret_cast<const f32x4 *>(bias + g4 + 16 * o);
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int o = 0; o < NH; ++o) b2[l][o] = *reinterpret_cast<const f32x4 *>(bias + 16 * NH + g4 + (l * NH + o) * 16);
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) b3[tau] = *reinterpret_cast<const f32x4 *>(bias + 16 * NH * (1 + L) + g4 + 16 * tau);
+    }
+};
+
 template <int NT, int NH, int L, int ACT, class F>
-__device__ __forceinline__ void mlp_core(const F &fr, const float *__restrict__ bias, int lane, const f32x4 (&cond)[NT],
-                                         f32x4 (&out)[NT]) {
+__device__ __forceinline__ void mlp_core(const F &fr, const NetBias<NT, NH, L> &nb, const f32x4 (&cond)[NT], f32x4 (&out)[NT]) {
     typedef FragCount<NT, NH, L> FC;
-    const int g4 = (lane >> 4) * 4;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 h[NH];
 #pragma unroll
-    for (int o = 0; o < NH; ++o) {
-        f32x4 s0 = *reinterpret_cast<const f32x4 *>(bias + g4 + 16 * o), s1 = zero4;
+    for (int o = 0; o < NH; ++o) {  // four accumulators (one per k-step r), NT deep
+        f32x4 a0 = nb.b1[o], a1 = zero4, a2 = zero4, a3 = zero4;
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
             const int f = (o * NT + tau) * 4;
-            s0 = mfma4(fr(f), cond[tau].x, s0);
-            s1 = mfma4(fr(f + 1), cond[tau].y, s1);
-            s0 = mfma4(fr(f + 2), cond[tau].z, s0);
-            s1 = mfma4(fr(f + 3), cond[tau].w, s1);
+            a0 = mfma4(fr(f), cond[tau].x, a0);
+            a1 = mfma4(fr(f + 1), cond[tau].y, a1);
+            a2 = mfma4(fr(f + 2), cond[tau].z, a2);
+            a3 = mfma4(fr(f + 3), cond[tau].w, a3);
         }
-        h[o] = activate<ACT>(s0 + s1);
+        h[o] = activate<ACT>((a0 + a1) + (a2 + a3));
     }
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         f32x4 h2[NH];
 #pragma unroll
         for (int o = 0; o < NH; ++o) {
-            f32x4 s0 = *reinterpret_cast<const f32x4 *>(bias + 16 * NH + g4 + (l * NH + o) * 16), s1 = zero4;
+            f32x4 a0 = nb.b2[l][o], a1 = zero4, a2 = zero4, a3 = zero4;
 #pragma unroll
             for (int i = 0; i < NH; ++i) {
                 const int f = FC::F1 + ((l * NH + o) * NH + i) * 4;
-                s0 = mfma4(fr(f), h[i].x, s0);
-                s1 = mfma4(fr(f + 1), h[i].y, s1);
-                s0 = mfma4(fr(f + 2), h[i].z, s0);
-                s1 = mfma4(fr(f + 3), h[i].w, s1);
+                a0 = mfma4(fr(f), h[i].x, a0);
+                a1 = mfma4(fr(f + 1), h[i].y, a1);
+                a2 = mfma4(fr(f + 2), h[i].z, a2);
+                a3 = mfma4(fr(f + 3), h[i].w, a3);
             }
-            h2[o] = activate<ACT>(s0 + s1);
+            h2[o] = activate<ACT>((a0 + a1) + (a2 + a3));
         }
 #pragma unroll
         for (int o = 0; o < NH; ++o) h[o] = h2[o];
     }
+    f32x4 p0[NT], p1[NT];  // two accumulators per output tile
 #pragma unroll
-    for (int tau = 0; tau < NT; ++tau) out[tau] = *reinterpret_cast<const f32x4 *>(bias + 16 * NH * (1 + L) + g4 + 16 * tau);
+    for (int tau = 0; tau < NT; ++tau) { p0[tau] = nb.b3[tau]; p1[tau] = zero4; }
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float bv = r == 0 ? h[i].x : r == 1 ? h[i].y : r == 2 ? h[i].z : h[i].w;
+        for (int tau = 0; tau < NT; ++tau) {
+            const int f = FC::F1 + FC::F2 + (tau * NH + i) * 4;
+            p0[tau] = mfma4(fr(f), h[i].x, p0[tau]);
+            p1[tau] = mfma4(fr(f + 1), h[i].y, p1[tau]);
+        }
 #pragma unroll
-            for (int tau = 0; tau < NT; ++tau) out[tau] = mfma4(fr(FC::F1 + FC::F2 + (tau * NH + i) * 4 + r), bv, out[tau]);
+        for (int tau = 0; tau < NT; ++tau) {
+            const int f = FC::F1 + FC::F2 + (tau * NH + i) * 4;
+            p0[tau] = mfma4(fr(f + 2), h[i].z, p0[tau]);
+            p1[tau] = mfma4(fr(f + 3), h[i].w, p1[tau]);
         }
     }
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) out[tau] = p0[tau] + p1[tau];
 }
 
 // the affine update of a coupling block given both nets' outputs; returns the lane's log-det partial
@@ -362,22 +389,27 @@ __device__ __forceinline__ float coupling_tile_il(const float *__restrict__ wblk
     return coupling_core<NT, NH, L, INVERSE>(fs, ft, wblk + ob, wblk + net_floats + ob, lane, cond, trans);
 }
 
-// sum a per-lane partial over the 4 lane groups of a walker (lanes w, w+16, w+32, w+48); every lane
-// ends with the walker total.
+// Sum a per-lane partial over the 4 lane groups of a walker (lanes w, w+16, w+32, w+48); every lane ends with
+// the walker total.  ONE round trip through the LDS crossbar (three independent ds_bpermute) instead of a
+// two-round butterfly: measured, the serialized cross-lane rounds were ~45 % of the post-inverse part of an MH
+// step.  The association (own pair) + (other pair) is the same set of additions in all four lanes (addition
+// commutes), so the four lanes of a walker hold bit-identical totals -- they must, they take the same
+// accept/reject decision.
 __device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    float t1 = __shfl_xor(v, 16), t2 = __shfl_xor(v, 32), t3 = __shfl_xor(v, 48);
+    return (v + t1) + (t2 + t3);
 }
-__device__ __forceinline__ double group_sum(double v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+// float partials, float64 total
+__device__ __forceinline__ double group_sum_wide(float v) {
+    float t1 = __shfl_xor(v, 16), t2 = __shfl_xor(v, 32), t3 = __shfl_xor(v, 48);
+    return ((double)v + (double)t1) + ((double)t2 + (double)t3);
 }
-__device__ __forceinline__ int group_and(int v) {
-    v &= __shfl_xor(v, 16);
-    v &= __shfl_xor(v, 32);
-    return v;
+// all four lanes of a walker true?  No LDS: one ballot, scalar shifts.
+__device__ __forceinline__ int group_all(bool ok_lane, int lane) {
+    unsigned long long m = __ballot(ok_lane);
+    m &= m >> 32;
+    m &= m >> 16;
+    return (int)((m >> (lane & 15)) & 1ull);
 }
 
 // one coupling block in either direction; LT >= 0 selects the compile-time-L interleaved form, LT = -1 the
@@ -460,7 +492,7 @@ __device__ __forceinline__ void store_tile(float *__restrict__ rows, long row, b
 // UniformPrior(D,-1,1).__call__ (nnest/priors.py:39-43): out of box iff any(x < -1) or any(x > 1);
 // NaN compares false, i.e. counts as inside, exactly like the reference.  Padded dims hold 0.
 template <int NT>
-__device__ __forceinline__ int inbox_tile(const f32x4 (&xs)[2][NT]) {
+__device__ __forceinline__ int inbox_tile(const f32x4 (&xs)[2][NT], int lane) {
     int ok = 1;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -470,7 +502,7 @@ __device__ __forceinline__ int inbox_tile(const f32x4 (&xs)[2][NT]) {
             ok &= !(v.x < -1.f || v.x > 1.f) & !(v.y < -1.f || v.y > 1.f) & !(v.z < -1.f || v.z > 1.f) &
                   !(v.w < -1.f || v.w > 1.f);
         }
-    return group_and(ok);
+    return group_all(ok != 0, lane);
 }
 
 // ---- likelihoods (nnest/likelihoods.py) through safe_loglike (nnest/sampler.py:110-133) --------------
@@ -511,7 +543,7 @@ __device__ __forceinline__ double loglike_tile(int like_id, float scale, int D, 
                 facc = facc + ((i + 1 < D) ? term : 0.f);
             }
         }
-        acc = -group_sum((double)facc);
+        acc = -group_sum_wide(facc);
     } else if (like_id == 1) {
         // GaussianMix (likelihoods.py:165-189): logsumexp_k[ log w_k - |theta - mu_k|^2/2 - (D/2) log 2pi ]
 #pragma unroll
@@ -528,7 +560,7 @@ __device__ __forceinline__ double loglike_tile(int like_id, float scale, int D, 
                 facc = facc + ((d >= 2 && d < D) ? sq : 0.f);
             }
         }
-        const double base = group_sum((double)facc);
+        const double base = group_sum_wide(facc);
         const int w = lane & 15;
         float t0 = __shfl(scale * xs[0][0].x, w);  // theta[0], theta[1] live in lane group 0
         float t1 = __shfl(scale * xs[1][0].x, w);
@@ -562,7 +594,7 @@ __device__ __forceinline__ double loglike_tile(int like_id, float scale, int D, 
                 facc = facc + ((d1 < D) ? v : 0.f);
             }
         }
-        acc = group_sum((double)facc);
+        acc = group_sum_wide(facc);
     }
     if (!(fabs(acc) <= 1.79769313486231570e308)) acc = -1e100;  // logl[~isfinite] = -1e100   sampler.py:128
     return acc;

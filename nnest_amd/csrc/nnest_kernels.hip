@@ -10,6 +10,13 @@
 
 namespace nnest {
 
+// NNEST_STAMP: diagnostic build only (tools/stamp_run.py): s_memtime stamps around the segments of the MH step
+#ifdef NNEST_STAMP
+#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(v) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // repack: one thread per float of the fragment image
 // ------------------------------------------------------------------------------------------------
@@ -117,7 +124,7 @@ __global__ void __launch_bounds__(256) flow_pass_kernel(PassArgs a) {
         if (a.out) store_tile<NT>(a.out, row, ok, a.s.D, lane, xs);
         if (a.logdet && ok && g == 0) a.logdet[row] = ld;
         if (a.mode == PASS_INVERSE_LOGLIKE) {
-            int inb = inbox_tile<NT>(xs);
+            int inb = inbox_tile<NT>(xs, lane);
             double ll = loglike_tile<NT>(a.like_id, a.like_scale, a.s.D, lane, xs);
             if (ok && g == 0) {
                 a.logl[row] = ll;
@@ -240,7 +247,10 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
     const bool recorded = DBG && a.noise_dz;
     if (!recorded) noise.next(nz, u_next);
 
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, a_noise = 0, a_inv = 0, a_post = 0, a_tot = 0;
+    (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)a_noise; (void)a_inv; (void)a_post; (void)a_tot;
     for (int it = 1; it <= S; ++it) {
+        STAMP(st4);
         // proposal z' = z + randn * scale  (sampler.py:310, :316); float32 like torch
         const float fs = (float)scale;
         f32x4 zp[2][NT], xp[2][NT];
@@ -262,16 +272,24 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
                 zp[0][t].w = z[0][t].w + nz[t][6] * fs; zp[1][t].w = z[1][t].w + nz[t][7] * fs;
             }
             u = u_next;
+            STAMP(st0);
             noise.next(nz, u_next);
+            STAMP(st1);
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int t = 0; t < NT; ++t) xp[c][t] = zp[c][t];
+        STAMP(st2);
         float ldp = group_sum(inv(xp));  // sampler.py:321
+        STAMP(st3);
 
         // log_ratio = log_det_J' - log_det_J, -inf outside the prior box  (sampler.py:326-331)
-        const int inb = inbox_tile<NT>(xp);
+#ifdef NNEST_ABL_NOPRIOR
+        const int inb = 1;
+#else
+        const int inb = inbox_tile<NT>(xp, lane);
+#endif
         float log_ratio = inb ? (ldp - ld) : -INFINITY;
         float ratio = fminf(__expf(log_ratio), 1.0f);  // exp().clamp(max=1)  :335
         if (log_ratio != log_ratio) ratio = log_ratio;  // NaN stays NaN (u < NaN is false, as in torch)
@@ -279,7 +297,11 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
 
         // likelihood of the proposal (the reference evaluates it only for `pre` rows, :358-360; here it is
         // evaluated for every row -- the lanes run in lock step anyway -- and only counted for `pre` rows)
+#ifdef NNEST_ABL_NOLIKE
+        double lp = (double)xp[0][0].x;
+#else
         double lp = loglike_tile<NT>(like_id, like_scale, D, lane, xp);
+#endif
         const bool acc = pre && (lp > loglstar);  // finite is guaranteed by the -1e100 clamp  :361
         n_call += pre ? 1 : 0;
         n_acc += acc ? 1 : 0;
@@ -301,12 +323,24 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
             if (accept > reject) scale *= exp(1.0 / (1 + accept));
             if (accept < reject) scale /= exp(1.0 / (1 + reject));
         }
+#ifdef NNEST_STAMP
+        { unsigned long long e; STAMP(e); a_noise += st1 - st0; a_inv += st3 - st2; a_post += e - st3; a_tot += e - st4; }
+#endif
         if (DBG && writer) {
             if (a.hist_x) store_tile<NT>(a.hist_x, (long)row * (S + 1) + it, ok, D, lane, x);
             if (a.hist_logl && ok && g == 0) a.hist_logl[(size_t)row * (S + 1) + it] = logl;
         }
     }
+#ifdef NNEST_STAMP
+    if (a.scale_out && lane == 0 && tile == 0) {  // diagnostic build only: cycles per segment, summed over steps
+        float *o = a.scale_out + (writer ? 0 : 8);
+        o[0] = (float)a_tot; o[1] = (float)a_noise; o[2] = (float)a_inv; o[3] = (float)a_post;
+        o[4] = (float)inv.t_mlp; o[5] = (float)inv.t_xch; o[6] = (float)inv.t_upd;
+    }
     if (!writer) return;
+#else
+    if (!writer) return;
+#endif
     store_tile<NT>(a.z, row, ok, D, lane, z);
     if (a.x) store_tile<NT>(a.x, row, ok, D, lane, x);
     if (ok && g == 0) {
@@ -314,7 +348,9 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
         if (a.n_accept) a.n_accept[row] = n_acc;
         if (a.n_call) a.n_call[row] = n_call;
     }
+#ifndef NNEST_STAMP
     if (a.scale_out && lane == 0) a.scale_out[tile] = (float)scale;
+#endif
 }
 
 // Form 1 (any shape): weight fragments read from the image (LDS copy, or global when it does not fit) at each use.
@@ -322,6 +358,9 @@ template <int NT, int NH, int LT>
 struct ImageInverse {
     const float *img;
     int net_floats, B, L, lane;
+#ifdef NNEST_STAMP
+    unsigned long long t_mlp = 0, t_xch = 0, t_upd = 0;
+#endif
     __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
         return flow_inverse_tile<NT, NH, LT>(img, net_floats, B, L, lane, xs);
     }
@@ -355,6 +394,9 @@ struct RegInverse {
     RegFrags<FC::N> w[B][2];
     const float *bias;  // LDS: [b][net][16*NH*(1+L) + 16*NT]
     int lane;
+#ifdef NNEST_STAMP
+    unsigned long long t_mlp = 0, t_xch = 0, t_upd = 0;
+#endif
     static constexpr int NBIAS = 16 * NH * (1 + L) + 16 * NT;
     __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
         float ld = 0.f;
@@ -409,26 +451,41 @@ struct TeamInverse {
     const float *bias;     // LDS [b][net][NBIAS]
     f32x4 *xch;            // LDS [parity][net][NT][64 lanes]
     int lane, role;
+#ifdef NNEST_STAMP
+    mutable unsigned long long t_mlp, t_xch, t_upd;
+#endif
     __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
         float ld = 0.f;
+        NetBias<NT, 1, L> nb;
+        nb.load(bias + ((B - 1) * 2 + role) * NBIAS, lane);
 #pragma unroll
         for (int b = B - 1; b >= 0; --b) {
             f32x4 mine[NT], other[NT];
+            unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            (void)s0; (void)s1; (void)s2; (void)s3;
+            STAMP(s0);
             if (b & 1) {
-                if (role == 0) mlp_core<NT, 1, L, 0>(w[b], bias + (b * 2 + 0) * NBIAS, lane, xs[0], mine);
-                else           mlp_core<NT, 1, L, 1>(w[b], bias + (b * 2 + 1) * NBIAS, lane, xs[0], mine);
+                if (role == 0) mlp_core<NT, 1, L, 0>(w[b], nb, xs[0], mine);
+                else           mlp_core<NT, 1, L, 1>(w[b], nb, xs[0], mine);
             } else {
-                if (role == 0) mlp_core<NT, 1, L, 0>(w[b], bias + (b * 2 + 0) * NBIAS, lane, xs[1], mine);
-                else           mlp_core<NT, 1, L, 1>(w[b], bias + (b * 2 + 1) * NBIAS, lane, xs[1], mine);
+                if (role == 0) mlp_core<NT, 1, L, 0>(w[b], nb, xs[1], mine);
+                else           mlp_core<NT, 1, L, 1>(w[b], nb, xs[1], mine);
             }
             f32x4 *slot = xch + (size_t)((b & 1) * 2) * NT * 64;  // double-buffered by block parity
+            STAMP(s1);
 #pragma unroll
             for (int tau = 0; tau < NT; ++tau) slot[(role * NT + tau) * 64 + lane] = mine[tau];
+            if (b > 0) nb.load(bias + ((b - 1) * 2 + role) * NBIAS, lane);  // next block's biases ride under the barrier
             __syncthreads();
 #pragma unroll
             for (int tau = 0; tau < NT; ++tau) other[tau] = slot[((1 - role) * NT + tau) * 64 + lane];
+            STAMP(s2);
             if (b & 1) ld += role == 0 ? affine_update<NT, true>(mine, other, xs[1]) : affine_update<NT, true>(other, mine, xs[1]);
             else       ld += role == 0 ? affine_update<NT, true>(mine, other, xs[0]) : affine_update<NT, true>(other, mine, xs[0]);
+            STAMP(s3);
+#ifdef NNEST_STAMP
+            t_mlp += s1 - s0; t_xch += s2 - s1; t_upd += s3 - s2;
+#endif
         }
         return ld;
     }
@@ -452,13 +509,13 @@ struct LdsNoise {
 };
 
 template <int NT, int L, int B, bool DBG>
-__global__ void __launch_bounds__(192) mh_kernel_team(MhArgs a) {
+__global__ void __launch_bounds__(192, 2) mh_kernel_team(MhArgs a) {  // min 2 waves/SIMD: <= 256 VGPRs, MFMA results stay in VGPRs
     typedef TeamInverse<NT, L, B> TI;
     __shared__ __attribute__((aligned(16))) float bias_lds[B * 2 * TI::NBIAS];
     __shared__ __attribute__((aligned(16))) f32x4 xch[2 * 2 * NT * 64];
     __shared__ float nbuf[2 * NT * 8 * 64];
     __shared__ float ubuf[2 * 64];
-    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform
     const int tile = blockIdx.x;
     const int net_floats = a.s.net_floats, S = a.steps;
     for (int i = threadIdx.x; i < B * 2 * TI::NBIAS; i += blockDim.x) {
@@ -491,6 +548,9 @@ __global__ void __launch_bounds__(192) mh_kernel_team(MhArgs a) {
     inv.xch = xch;
     inv.lane = lane;
     inv.role = role;
+#ifdef NNEST_STAMP
+    inv.t_mlp = inv.t_xch = inv.t_upd = 0;
+#endif
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         const float *src = a.img + (size_t)(b * 2 + role) * net_floats;

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) step_kernel(const float *gimg, FlowShape 
         for (int c = 0; c < 2; ++c) for (int t = 0; t < NT; ++t) xp[c][t] = zp[c][t];
         float ldp = 0.f;
         if (FLOW) ldp = group_sum(flow_inverse_tile<NT, NH, LTV>(img, s.net_floats, s.B, s.L, lane, xp));
-        const int inb = inbox_tile<NT>(xp);
+        const int inb = inbox_tile<NT>(xp, lane);
         float ratio = fminf(__expf(inb ? ldp - ld : -INFINITY), 1.f);
         bool pre = ok && u < ratio;
         double lp = 0;
