@@ -55,7 +55,7 @@ def cpu_baseline(D, H, B, L, w, walkers, target_seconds=12.0):
     orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, float(init_logl.min()), 1 / np.sqrt(D), False, dz, u)
     dt = time.perf_counter() - t0
     per_step = dt / steps
-    steps = int(max(2, min(250, target_seconds / max(per_step, 1e-9))))
+    steps = int(max(2, min(5000, target_seconds / max(per_step, 1e-9))))
     dz = rng.normal(size=(steps, walkers, D)).astype(np.float32)
     u = rng.uniform(size=(steps, walkers)).astype(np.float32)
     t0 = time.perf_counter()
@@ -166,11 +166,11 @@ def main():
         }
         if not args.no_saturation and world == 1:
             # the same kernel at a population that fills the chip (not the headline: BASELINE's config is 1000)
-            Cs = 16 * 4 * info['num_cu'] * 2
+            Cs = 16 * 4 * info['num_cu'] * 8  # 8 walker tiles per SIMD
             us = np.random.RandomState(5).uniform(-1, 1, size=(Cs, D))
             zz, _ = nvp.forward(us)
             ll = flow.loglike(0, us, 5.0, device=dev)
-            Ss = 50
+            Ss = 25
             nvp.mh_steps(0, 5.0, zz, ll, float(ll.min()), step_size, Ss, seed=1)
             torch.cuda.synchronize(dev)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

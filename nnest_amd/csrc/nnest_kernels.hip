@@ -367,7 +367,7 @@ struct ImageInverse {
 };
 
 template <int NT, int NH, int LT, bool WLDS, bool DBG>
-__global__ void __launch_bounds__(256) mh_kernel(MhArgs a) {
+__global__ void __launch_bounds__(512, 3) mh_kernel(MhArgs a) {  // >= 3 waves/SIMD: the chains of one wave hide behind the others
     extern __shared__ __attribute__((aligned(16))) float lds_img[];
     const float *img = a.img;
     if (WLDS) {
@@ -598,10 +598,12 @@ static hipError_t allow_lds(K kernel, size_t bytes) {
 }
 
 // pick workgroup width: few tiles -> one wave per workgroup so the tiles spread over CUs
-static void pick_geometry(int ntiles, int num_cu, int *block, int *grid) {
+static void pick_geometry(int ntiles, int num_cu, int max_wpb, int *block, int *grid) {
     int wpb = 1;
     if (ntiles > 2 * num_cu) wpb = 2;
-    if (ntiles > 8 * num_cu) wpb = 4;
+    if (ntiles > 4 * num_cu) wpb = 4;
+    if (ntiles > 8 * num_cu) wpb = 8;  // eight waves share one LDS copy of the weight image
+    if (wpb > max_wpb) wpb = max_wpb;
     *block = 64 * wpb;
     int g = (ntiles + wpb - 1) / wpb;
     *grid = g;
@@ -611,7 +613,7 @@ template <int NT, int NH, int LT>
 static hipError_t launch_pass_t(const PassArgs &a, int num_cu, hipStream_t st) {
     const int ntiles = (a.N + 15) / 16;
     int block, grid;
-    pick_geometry(ntiles, num_cu, &block, &grid);
+    pick_geometry(ntiles, num_cu, 4, &block, &grid);  // flow_pass_kernel: __launch_bounds__(256)
     const size_t img_bytes = (size_t)a.s.image_floats * 4;
     // grid-stride over tiles once there are more than ~8 workgroups per CU (amortises the LDS staging)
     if (grid > 8 * num_cu) grid = 8 * num_cu;
@@ -645,7 +647,7 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
         }
     }
     int block, grid;
-    pick_geometry(ntiles, num_cu, &block, &grid);
+    pick_geometry(ntiles, num_cu, 8, &block, &grid);  // mh_kernel: __launch_bounds__(512, 3)
     const size_t img_bytes = (size_t)a.s.image_floats * 4;
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
     if (img_bytes <= (size_t)LDS_IMAGE_LIMIT) {

@@ -65,7 +65,7 @@ def test_flow_vs_golden(hip, path):
         assert torch.equal(z, z1)
 
 
-@pytest.mark.parametrize('N', [0, 1, 15, 16, 17, 1000, 4099])
+@pytest.mark.parametrize('N', [0, 1, 15, 16, 17, 1000, 4099, 70001])
 def test_flow_ragged_sizes_vs_oracle(hip, N):
     g = np.load(os.path.join(G, 'flow_d50.npz'))
     nvp = hip.HipNVP(50, 16, 3, 1)
@@ -77,6 +77,9 @@ def test_flow_ragged_sizes_vs_oracle(hip, N):
     assert z.shape == (N, 50) and ld.shape == (N,)
     if N == 0:
         return
+    if N > 20000:  # large launch geometry: check a slice against the oracle
+        x = x[-3000:]
+        z, ld = z[-3000:], ld[-3000:]
     zo, ldo = o.forward(x)
     assert rel(cpu(z), zo) < 2e-5 and rel(cpu(ld), ldo) < 2e-5
     xi, ldi = nvp.inverse(zo)
