@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 1
+#define NNEST_HIP_ABI_VERSION 2
 
 enum {
     NNEST_OK = 0,
@@ -41,7 +41,21 @@ enum {
     NNEST_LIKE_ROSENBROCK = 0, /* Rosenbrock.loglike   likelihoods.py:51 */
     NNEST_LIKE_GAUSSMIX = 1,   /* GaussianMix.loglike  likelihoods.py:165-189 (sep 4, sigma 1, w .4 .3 .2 .1) */
     NNEST_LIKE_HIMMELBLAU = 2, /* Himmelblau.loglike   likelihoods.py:70 (D>2: sum over consecutive pairs) */
+    NNEST_LIKE_GAUSSIAN = 3,   /* Gaussian.loglike     likelihoods.py:77-94  params[0] = corr (equicorrelated covariance) */
+    NNEST_LIKE_EGGBOX = 4,     /* Eggbox.loglike       likelihoods.py:97-110 (x_dim = 2) */
+    NNEST_LIKE_SHELL = 5,      /* GaussianShell        likelihoods.py:113-132 params = sigma, rshell, center */
+    NNEST_LIKE_DOUBLE_SHELL = 6, /* DoubleGaussianShell likelihoods.py:135-150 params = sigma1, rshell1, center1,
+                                    sigma2, rshell2, center2 (weights 1, 1) */
+    NNEST_LIKE_COUNT = 7
 };
+
+/* which analytic likelihood the fused kernels evaluate, and on what: logl = loglike(scale * x)
+ * (the reference's transform = lambda x: scale * x, examples/nested/run.py:25-42).  Host struct. */
+typedef struct {
+    int id;          /* NNEST_LIKE_* */
+    float scale;
+    float params[6]; /* per-likelihood parameters, see the enum; unused entries ignored */
+} nnest_like_t;
 
 /* flags for nnest_mh_constrained_steps */
 enum {
@@ -80,14 +94,14 @@ int nnest_nvp_inverse(nnest_nvp_t *nvp, const float *z_dev, float *x_dev, float 
 int nnest_nvp_log_probs(nnest_nvp_t *nvp, const float *x_dev, float *logp_dev, int N, void *stream);
 
 /* Fused "one eval": x = f^-1(z), logdet; box prior UniformPrior(-1,1) (priors.py:39-43);
- * logl = loglike(like_scale * x) as safe_loglike (sampler.py:110-133) incl. non-finite -> -1e100.
+ * logl = loglike(like->scale * x) as safe_loglike (sampler.py:110-133) incl. non-finite -> -1e100.
  * logl_dev is float64 [N]; inbox_dev int32 [N] (1 = inside the box).  x_dev/logdet_dev may be NULL. */
-int nnest_nvp_inverse_loglike(nnest_nvp_t *nvp, int like_id, float like_scale, const float *z_dev, float *x_dev,
+int nnest_nvp_inverse_loglike(nnest_nvp_t *nvp, const nnest_like_t *like, const float *z_dev, float *x_dev,
                               float *logdet_dev, double *logl_dev, int *inbox_dev, int N, void *stream);
 
-/* Likelihood.__call__ over rows (likelihoods.py:14-22) through safe_loglike: logl[n] = loglike(scale*x[n]).
+/* Likelihood.__call__ over rows (likelihoods.py:14-22) through safe_loglike: logl[n] = loglike(like->scale*x[n]).
  * x_unit_dev float32 [N,D]; logl_dev float64 [N]. */
-int nnest_loglike(int like_id, const float *x_unit_dev, float like_scale, double *logl_dev, int N, int D,
+int nnest_loglike(const nnest_like_t *like, const float *x_unit_dev, double *logl_dev, int N, int D,
                   void *stream);
 
 /* Sampler._mcmc_sample, hard-constraint branch (sampler.py:229-463), `steps` Metropolis steps for C
@@ -107,7 +121,7 @@ int nnest_loglike(int like_id, const float *x_unit_dev, float like_scale, double
  *                      sampler.py:358-363)
  *   scale_out_dev      optional float32 [ngroups]: final scale per adaptation group (sampler.py:422-431)
  */
-int nnest_mh_constrained_steps(nnest_nvp_t *nvp, int like_id, float like_scale, float *z_dev, float *x_dev,
+int nnest_mh_constrained_steps(nnest_nvp_t *nvp, const nnest_like_t *like, float *z_dev, float *x_dev,
                                double *logl_dev, double loglstar, float step_size, int steps, int C, int flags,
                                const float *noise_dz_dev, const float *noise_u_dev, uint64_t seed,
                                uint64_t walker_offset, float *hist_x_dev, double *hist_logl_dev, int *n_accept_dev,

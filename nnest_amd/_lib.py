@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NNEST_HIP_LIB', os.path.join(_HERE, 'libnnest_hip.so'))  # override: developer A/B builds only
 
 NNEST_OK = 0
-LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'himmelblau': 2}
+LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'himmelblau': 2, 'gaussian': 3, 'eggbox': 4, 'shell': 5, 'double_shell': 6}
 MH_DYNAMIC_STEP = 1
 TRAIN_RESUME = 1
 TRAIN_FINALIZE = 2
@@ -23,6 +23,20 @@ TRAIN_FINALIZE = 2
 
 class NnestHipError(RuntimeError):
     pass
+
+
+class LikeSpec(ctypes.Structure):
+    """nnest_like_t (include/nnest_hip.h): likelihood id, transform scale, parameters"""
+    _fields_ = [('id', ctypes.c_int), ('scale', ctypes.c_float), ('params', ctypes.c_float * 6)]
+
+
+def like_spec(like_id, scale, params=None):
+    lk = LikeSpec()
+    lk.id = int(like_id)
+    lk.scale = float(scale)
+    for i, v in enumerate(params or ()):
+        lk.params[i] = float(v)
+    return lk
 
 
 class TrainResult(ctypes.Structure):
@@ -54,9 +68,9 @@ SIGNATURES = {
     'nnest_nvp_forward': [_vp, _vp, _vp, _vp, _i, _vp],
     'nnest_nvp_inverse': [_vp, _vp, _vp, _vp, _i, _vp],
     'nnest_nvp_log_probs': [_vp, _vp, _vp, _i, _vp],
-    'nnest_nvp_inverse_loglike': [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
-    'nnest_loglike': [_i, _vp, _f, _vp, _i, _i, _vp],
-    'nnest_mh_constrained_steps': [_vp, _i, _f, _vp, _vp, _vp, _d, _f, _i, _i, _i, _vp, _vp, _u64, _u64,
+    'nnest_nvp_inverse_loglike': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    'nnest_loglike': [_vp, _vp, _vp, _i, _i, _vp],
+    'nnest_mh_constrained_steps': [_vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i, _i, _vp, _vp, _u64, _u64,
                                    _vp, _vp, _vp, _vp, _vp, _vp],
     'nnest_mh_num_groups': [_vp, _i],
     'nnest_mh_fill_noise': [_vp, _vp, _i, _i, _i, _u64, _u64, _vp],

@@ -510,9 +510,24 @@ __device__ __forceinline__ int inbox_tile(const f32x4 (&xs)[2][NT], int lane) {
 // per-term arithmetic in float32 with the reference's operation order and no FMA contraction; each lane sums
 // its own <= 8*NT terms in float32 (branch-free), the four lane partials of a walker are combined in float64
 // (the reference sums all terms sequentially in float32; DESIGN.md "Precision").
+// which likelihood, on scale * x, with its parameters (mirror of nnest_like_t, include/nnest_hip.h)
+struct LikeSpec {
+    int id = 0;
+    float scale = 1.f;
+    float p[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+};
+
+// float64 sum of a per-lane float64 partial over a walker's 4 lane groups (one round trip, consistent in all 4 lanes)
+__device__ __forceinline__ double group_sum(double v) {
+    double t1 = __shfl_xor(v, 16), t2 = __shfl_xor(v, 32), t3 = __shfl_xor(v, 48);
+    return (v + t1) + (t2 + t3);
+}
+
 #pragma clang fp contract(off)
 template <int NT>
-__device__ __forceinline__ double loglike_tile(int like_id, float scale, int D, int lane, const f32x4 (&xs)[2][NT]) {
+__device__ __forceinline__ double loglike_tile(const LikeSpec &lk, int D, int lane, const f32x4 (&xs)[2][NT]) {
+    const int like_id = lk.id;
+    const float scale = lk.scale;
     const int g = lane >> 4;
     double acc = 0.0;
     float facc = 0.f;
@@ -578,7 +593,7 @@ __device__ __forceinline__ double loglike_tile(int like_id, float scale, int D, 
 #pragma unroll
         for (int k = 0; k < 4; ++k) se += __expf((float)(l[k] - mx));
         acc = mx + (double)__logf(se);
-    } else {
+    } else if (like_id == 2) {
         // Himmelblau (likelihoods.py:70) summed over consecutive pairs (x[2i], x[2i+1]) (= reference at D=2)
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
@@ -595,6 +610,60 @@ __device__ __forceinline__ double loglike_tile(int like_id, float scale, int D, 
             }
         }
         acc = group_sum_wide(facc);
+    } else if (like_id == 4) {
+        // Eggbox (likelihoods.py:104-106), x_dim = 2: (2 + cos(x0/2) cos(x1/2))^5 in float32 like the reference
+        const int w = lane & 15;
+        float t0 = __shfl(scale * xs[0][0].x, w), t1 = __shfl(scale * xs[1][0].x, w);
+        float chi = cosf(t0 / 2.f) * cosf(t1 / 2.f);
+        float b = 2.f + chi;
+        float b2 = b * b;
+        acc = (double)(b2 * b2 * b);
+    } else {
+        // likelihoods whose reference arithmetic is float64 on the float32-rounded inputs (scipy logpdf / int64
+        // centre arrays promote): moments of theta in float64
+        double s1 = 0.0, s2 = 0.0;  // sum theta, sum theta^2
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            float th[8];
+            th[0] = scale * xs[0][tau].x; th[1] = scale * xs[1][tau].x;
+            th[2] = scale * xs[0][tau].y; th[3] = scale * xs[1][tau].y;
+            th[4] = scale * xs[0][tau].z; th[5] = scale * xs[1][tau].z;
+            th[6] = scale * xs[0][tau].w; th[7] = scale * xs[1][tau].w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool valid = 32 * tau + 8 * g + j < D;
+                const double t = valid ? (double)th[j] : 0.0;
+                s1 += t;
+                s2 += t * t;
+            }
+        }
+        s1 = group_sum(s1);
+        s2 = group_sum(s2);
+        const double Dd = (double)D;
+        if (like_id == 3) {
+            // Gaussian (likelihoods.py:77-94): N(0, Sigma), Sigma = (1-c) I + c 11^T  (equicorrelated):
+            // x^T Sigma^-1 x = (s2 - c s1^2 / (1 + (D-1) c)) / (1 - c),  log det = (D-1) log(1-c) + log(1 + (D-1) c)
+            const double c = (double)lk.p[0];
+            const double quad = (s2 - c * s1 * s1 / (1.0 + (Dd - 1.0) * c)) / (1.0 - c);
+            const double logdet = (Dd - 1.0) * log(1.0 - c) + log(1.0 + (Dd - 1.0) * c);
+            acc = -0.5 * quad - 0.5 * logdet - 0.9189385332046727 * Dd;
+        } else {
+            // GaussianShell (likelihoods.py:113-132): -(|theta - centre| - r)^2 / (2 sigma^2); |theta - c 1|^2 = s2 - 2 c s1 + D c^2
+            // DoubleGaussianShell (likelihoods.py:135-150): logaddexp of two shells (weights 1, 1)
+            double sh[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double sig = (double)lk.p[3 * k], rs = (double)lk.p[3 * k + 1], cen = (double)lk.p[3 * k + 2];
+                double r2 = s2 - 2.0 * cen * s1 + Dd * cen * cen;
+                double rad = sqrt(r2 > 0.0 ? r2 : 0.0);
+                sh[k] = -((rad - rs) * (rad - rs)) / (2.0 * sig * sig);
+            }
+            if (like_id == 5) acc = sh[0];
+            else {
+                const double mx = sh[0] > sh[1] ? sh[0] : sh[1], mn = sh[0] > sh[1] ? sh[1] : sh[0];
+                acc = mx + log1p(exp(mn - mx));
+            }
+        }
     }
     if (!(fabs(acc) <= 1.79769313486231570e308)) acc = -1e100;  // logl[~isfinite] = -1e100   sampler.py:128
     return acc;

@@ -20,6 +20,8 @@ struct nnest_nvp {
     float *img;      // MFMA fragment image of w
     int *adam_step;  // device int: torch.optim.Adam state['step']
     float *train_ws; // training workspace
+    int *fwd_pos;    // packed parameter -> element of the forward fragment image (-1: absent)
+    int *bwd_pos;    // packed parameter -> element of the backward fragment image
     size_t train_ws_floats;
 };
 
@@ -91,6 +93,10 @@ int nnest_nvp_create(int D, int H, int B, int L, nnest_nvp_t **out) {
     if (e == hipSuccess) e = hipMalloc((void **)&h->img, (size_t)s.image_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->adam_step, sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->train_ws, h->train_ws_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->fwd_pos, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->bwd_pos, nb);
+    if (e == hipSuccess) e = launch_build_pos(h->fwd_pos, h->bwd_pos, s, 0);
+    if (e == hipSuccess) e = hipStreamSynchronize(0);
     if (e == hipSuccess) e = hipMemset(h->w, 0, nb);
     if (e == hipSuccess) e = hipMemset(h->adam_m, 0, nb);
     if (e == hipSuccess) e = hipMemset(h->adam_v, 0, nb);
@@ -107,7 +113,7 @@ int nnest_nvp_create(int D, int H, int B, int L, nnest_nvp_t **out) {
 int nnest_nvp_destroy(nnest_nvp_t *h) {
     if (!h) return NNEST_OK;
     (void)hipFree(h->w); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->best_w); (void)hipFree(h->img);
-    (void)hipFree(h->adam_step); (void)hipFree(h->train_ws);
+    (void)hipFree(h->adam_step); (void)hipFree(h->train_ws); (void)hipFree(h->fwd_pos); (void)hipFree(h->bwd_pos);
     delete h;
     return NNEST_OK;
 }
@@ -185,7 +191,7 @@ static int check_rows(const nnest_nvp_t *h, const void *a, const void *b, int N)
 int nnest_nvp_forward(nnest_nvp_t *h, const float *x_dev, float *z_dev, float *logdet_dev, int N, void *stream) {
     int rc = check_rows(h, x_dev, z_dev, N);
     if (rc) return rc;
-    HIP_TRY(launch_pass(h->img, h->s, PASS_FORWARD, x_dev, z_dev, logdet_dev, nullptr, nullptr, N, 0, 1.f, h->num_cu,
+    HIP_TRY(launch_pass(h->img, h->s, PASS_FORWARD, x_dev, z_dev, logdet_dev, nullptr, nullptr, N, LikeSpec(), h->num_cu,
                         (hipStream_t)stream));
     return NNEST_OK;
 }
@@ -193,7 +199,7 @@ int nnest_nvp_forward(nnest_nvp_t *h, const float *x_dev, float *z_dev, float *l
 int nnest_nvp_inverse(nnest_nvp_t *h, const float *z_dev, float *x_dev, float *logdet_dev, int N, void *stream) {
     int rc = check_rows(h, z_dev, x_dev, N);
     if (rc) return rc;
-    HIP_TRY(launch_pass(h->img, h->s, PASS_INVERSE, z_dev, x_dev, logdet_dev, nullptr, nullptr, N, 0, 1.f, h->num_cu,
+    HIP_TRY(launch_pass(h->img, h->s, PASS_INVERSE, z_dev, x_dev, logdet_dev, nullptr, nullptr, N, LikeSpec(), h->num_cu,
                         (hipStream_t)stream));
     return NNEST_OK;
 }
@@ -201,51 +207,60 @@ int nnest_nvp_inverse(nnest_nvp_t *h, const float *z_dev, float *x_dev, float *l
 int nnest_nvp_log_probs(nnest_nvp_t *h, const float *x_dev, float *logp_dev, int N, void *stream) {
     int rc = check_rows(h, x_dev, logp_dev, N);
     if (rc) return rc;
-    HIP_TRY(launch_pass(h->img, h->s, PASS_LOGPROB, x_dev, logp_dev, nullptr, nullptr, nullptr, N, 0, 1.f, h->num_cu,
+    HIP_TRY(launch_pass(h->img, h->s, PASS_LOGPROB, x_dev, logp_dev, nullptr, nullptr, nullptr, N, LikeSpec(), h->num_cu,
                         (hipStream_t)stream));
     return NNEST_OK;
 }
 
-static int check_like(int like_id) {
-    if (like_id < NNEST_LIKE_ROSENBROCK || like_id > NNEST_LIKE_HIMMELBLAU) return fail(NNEST_E_ARG, "unknown like_id %d", like_id);
+static int check_like(const nnest_like_t *like, int D, LikeSpec *out) {
+    if (!like) return fail(NNEST_E_ARG, "like is NULL");
+    if (like->id < 0 || like->id >= NNEST_LIKE_COUNT) return fail(NNEST_E_ARG, "unknown likelihood id %d", like->id);
+    if (like->id == NNEST_LIKE_EGGBOX && D != 2) return fail(NNEST_E_ARG, "Eggbox is defined for x_dim = 2 (likelihoods.py:97-102)");
+    if (like->id == NNEST_LIKE_GAUSSMIX && D < 2) return fail(NNEST_E_ARG, "GaussianMix needs x_dim >= 2");
+    out->id = like->id;
+    out->scale = like->scale;
+    for (int i = 0; i < 6; ++i) out->p[i] = like->params[i];
     return NNEST_OK;
 }
 
-int nnest_nvp_inverse_loglike(nnest_nvp_t *h, int like_id, float like_scale, const float *z_dev, float *x_dev,
+int nnest_nvp_inverse_loglike(nnest_nvp_t *h, const nnest_like_t *like, const float *z_dev, float *x_dev,
                               float *logdet_dev, double *logl_dev, int *inbox_dev, int N, void *stream) {
     int rc = check_rows(h, z_dev, logl_dev, N);
     if (rc) return rc;
-    if ((rc = check_like(like_id))) return rc;
-    HIP_TRY(launch_pass(h->img, h->s, PASS_INVERSE_LOGLIKE, z_dev, x_dev, logdet_dev, logl_dev, inbox_dev, N, like_id,
-                        like_scale, h->num_cu, (hipStream_t)stream));
+    LikeSpec lk;
+    if ((rc = check_like(like, h->s.D, &lk))) return rc;
+    HIP_TRY(launch_pass(h->img, h->s, PASS_INVERSE_LOGLIKE, z_dev, x_dev, logdet_dev, logl_dev, inbox_dev, N, lk,
+                        h->num_cu, (hipStream_t)stream));
     return NNEST_OK;
 }
 
-int nnest_loglike(int like_id, const float *x_unit_dev, float like_scale, double *logl_dev, int N, int D, void *stream) {
-    int rc = check_like(like_id);
-    if (rc) return rc;
+int nnest_loglike(const nnest_like_t *like, const float *x_unit_dev, double *logl_dev, int N, int D, void *stream) {
     if (N < 0 || D < 1) return fail(NNEST_E_ARG, "bad N=%d D=%d", N, D);
+    LikeSpec lk;
+    int rc = check_like(like, D, &lk);
+    if (rc) return rc;
     if (D > 128) return fail(NNEST_E_UNSUPPORTED, "x_dim=%d > 128", D);
     if (N > 0 && (!x_unit_dev || !logl_dev)) return fail(NNEST_E_ARG, "NULL device buffer");
     int dev = 0, num_cu = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    HIP_TRY(launch_loglike(like_id, x_unit_dev, like_scale, logl_dev, N, D, num_cu, (hipStream_t)stream));
+    HIP_TRY(launch_loglike(lk, x_unit_dev, logl_dev, N, D, num_cu, (hipStream_t)stream));
     return NNEST_OK;
 }
 
-int nnest_mh_constrained_steps(nnest_nvp_t *h, int like_id, float like_scale, float *z_dev, float *x_dev,
+int nnest_mh_constrained_steps(nnest_nvp_t *h, const nnest_like_t *like, float *z_dev, float *x_dev,
                                double *logl_dev, double loglstar, float step_size, int steps, int C, int flags,
                                const float *noise_dz_dev, const float *noise_u_dev, uint64_t seed,
                                uint64_t walker_offset, float *hist_x_dev, double *hist_logl_dev, int *n_accept_dev,
                                int *n_call_dev, float *scale_out_dev, void *stream) {
     int rc = check_rows(h, z_dev, logl_dev, C);
     if (rc) return rc;
-    if ((rc = check_like(like_id))) return rc;
+    LikeSpec lk;
+    if ((rc = check_like(like, h->s.D, &lk))) return rc;
     if (steps < 0) return fail(NNEST_E_ARG, "steps=%d < 0", steps);
     if ((noise_dz_dev == nullptr) != (noise_u_dev == nullptr))
         return fail(NNEST_E_ARG, "noise_dz_dev and noise_u_dev must both be given or both be NULL");
-    HIP_TRY(launch_mh(h->img, h->s, like_id, like_scale, z_dev, x_dev, logl_dev, loglstar, step_size, steps, C, flags,
+    HIP_TRY(launch_mh(h->img, h->s, lk, z_dev, x_dev, logl_dev, loglstar, step_size, steps, C, flags,
                       noise_dz_dev, noise_u_dev, seed, walker_offset, hist_x_dev, hist_logl_dev, n_accept_dev, n_call_dev,
                       scale_out_dev, h->num_cu, (hipStream_t)stream));
     return NNEST_OK;
@@ -274,14 +289,15 @@ int nnest_nvp_train(nnest_nvp_t *h, const float *xtrain_dev, int n_train, const 
     if (batch > 128) return fail(NNEST_E_UNSUPPORTED, "batch_size=%d > 128 (one workgroup holds a minibatch)", batch);
     HIP_TRY(launch_train(h->w, h->adam_m, h->adam_v, h->best_w, h->img, h->adam_step, h->s, xtrain_dev, n_train, xvalid_dev,
                          n_valid, perm_dev, noise_dev, seed, jitter, batch, max_epochs, patience, lr, weight_decay,
-                         epoch_offset, flags, losses_dev, result_dev, h->train_ws, (hipStream_t)stream));
+                         epoch_offset, flags, losses_dev, result_dev, h->train_ws, h->fwd_pos, h->bwd_pos, (hipStream_t)stream));
     return NNEST_OK;
 }
 
 int nnest_nvp_loss_grad(nnest_nvp_t *h, const float *x_dev, int M, float *grad_dev, float *loss_dev, void *stream) {
     if (!h || !x_dev || !grad_dev || !loss_dev) return fail(NNEST_E_ARG, "NULL argument");
     if (M < 1 || M > 128) return fail(NNEST_E_UNSUPPORTED, "M=%d outside [1,128]", M);
-    HIP_TRY(launch_loss_grad(h->w, h->s, x_dev, M, grad_dev, loss_dev, h->train_ws, h->img, (hipStream_t)stream));
+    HIP_TRY(launch_loss_grad(h->w, h->s, x_dev, M, grad_dev, loss_dev, h->train_ws, h->img, h->fwd_pos, h->bwd_pos,
+                             (hipStream_t)stream));
     return NNEST_OK;
 }
 

@@ -12,12 +12,12 @@ enum { PASS_FORWARD = 0, PASS_INVERSE = 1, PASS_LOGPROB = 2, PASS_INVERSE_LOGLIK
 bool shape_supported(const FlowShape &s);
 hipError_t launch_repack(const float *packed, float *img, const FlowShape &s, hipStream_t st);
 hipError_t launch_pass(const float *img, const FlowShape &s, int mode, const float *in, float *out, float *logdet,
-                       double *logl, int *inbox, int N, int like_id, float like_scale, int num_cu, hipStream_t st);
-hipError_t launch_mh(const float *img, const FlowShape &s, int like_id, float like_scale, float *z, float *x, double *logl,
+                       double *logl, int *inbox, int N, const LikeSpec &like, int num_cu, hipStream_t st);
+hipError_t launch_mh(const float *img, const FlowShape &s, const LikeSpec &like, float *z, float *x, double *logl,
                      double loglstar, float step_size, int steps, int C, int flags, const float *noise_dz,
                      const float *noise_u, uint64_t seed, uint64_t walker_offset, float *hist_x, double *hist_logl,
                      int *n_accept, int *n_call, float *scale_out, int num_cu, hipStream_t st);
-hipError_t launch_loglike(int like_id, const float *x, float scale, double *logl, int N, int D, int num_cu, hipStream_t st);
+hipError_t launch_loglike(const LikeSpec &like, const float *x, double *logl, int N, int D, int num_cu, hipStream_t st);
 hipError_t launch_fill_noise(float *dz, float *u, int steps, int C, int D, uint64_t seed, uint64_t walker_offset,
                              hipStream_t st);
 int mh_num_groups(int C);
@@ -25,14 +25,15 @@ int mh_num_groups(int C);
 // training (nnest_train.hip)
 struct TrainArgs;
 hipError_t launch_loss_grad(const float *packed, const FlowShape &s, const float *x, int M, float *grad, float *loss,
-                            float *workspace, float *img_fwd, hipStream_t st);
+                            float *workspace, float *img_fwd, const int *fwd_pos, const int *bwd_pos, hipStream_t st);
 size_t train_workspace_floats(const FlowShape &s, int batch);
 hipError_t launch_train(float *packed, float *adam_m, float *adam_v, float *best_w, float *img, int *adam_step_dev,
                         const FlowShape &s, const float *xtrain, int n_train, const float *xvalid, int n_valid,
                         const int *perm, const float *noise, uint64_t seed, float jitter, int batch, int max_epochs,
                         int patience, float lr, float wd, int epoch_offset, int flags, float *losses, nnest_train_result_t *result,
-                        float *workspace,
+                        float *workspace, const int *fwd_pos, const int *bwd_pos,
                         hipStream_t st);
+hipError_t launch_build_pos(int *fwd_pos, int *bwd_pos, const FlowShape &s, hipStream_t st);
 hipError_t launch_training_jitter(const double *samples, int N, int D, double *out, hipStream_t st);
 
 }  // namespace nnest

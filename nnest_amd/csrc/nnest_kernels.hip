@@ -81,8 +81,7 @@ struct PassArgs {
     double *logl;
     int *inbox;
     int N;
-    int like_id;
-    float like_scale;
+    LikeSpec like;
 };
 
 template <int NT, int NH, int LT, bool WLDS>
@@ -125,7 +124,7 @@ __global__ void __launch_bounds__(256) flow_pass_kernel(PassArgs a) {
         if (a.logdet && ok && g == 0) a.logdet[row] = ld;
         if (a.mode == PASS_INVERSE_LOGLIKE) {
             int inb = inbox_tile<NT>(xs, lane);
-            double ll = loglike_tile<NT>(a.like_id, a.like_scale, a.s.D, lane, xs);
+            double ll = loglike_tile<NT>(a.like, a.s.D, lane, xs);
             if (ok && g == 0) {
                 a.logl[row] = ll;
                 if (a.inbox) a.inbox[row] = inb;
@@ -137,7 +136,7 @@ __global__ void __launch_bounds__(256) flow_pass_kernel(PassArgs a) {
 // K6: likelihood only (no flow): reuses the tile layout so the arithmetic is the same code as the fused path
 template <int NT>
 __global__ void __launch_bounds__(256) loglike_kernel(const float *__restrict__ x, double *__restrict__ logl, int N, int D,
-                                                      int like_id, float scale) {
+                                                      LikeSpec like) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int ntiles = (N + 15) >> 4;
     for (int tile = blockIdx.x * wpb + wave; tile < ntiles; tile += gridDim.x * wpb) {
@@ -145,7 +144,7 @@ __global__ void __launch_bounds__(256) loglike_kernel(const float *__restrict__ 
         const bool ok = row < N;
         f32x4 xs[2][NT];
         load_tile<NT>(x, row, ok, D, lane, xs);
-        double ll = loglike_tile<NT>(like_id, scale, D, lane, xs);
+        double ll = loglike_tile<NT>(like, D, lane, xs);
         if (ok && (lane >> 4) == 0) logl[row] = ll;
     }
 }
@@ -166,8 +165,7 @@ struct MhArgs {
     int steps;
     int C;
     int flags;
-    int like_id;
-    float like_scale;
+    LikeSpec like;
     const float *noise_dz;
     const float *noise_u;
     uint64_t seed;
@@ -218,8 +216,7 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
     const int D = a.s.D, S = a.steps;
     const uint64_t walker = a.walker_offset + (uint64_t)row;
     const int nvalid = min(16, a.C - tile * 16);  // walkers in this adaptation group
-    const int like_id = a.like_id;
-    const float like_scale = a.like_scale;
+    const LikeSpec like = a.like;
     const double loglstar = a.loglstar;
     const bool dynamic = (a.flags & NNEST_MH_DYNAMIC_STEP) != 0;
 
@@ -300,7 +297,7 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
 #ifdef NNEST_ABL_NOLIKE
         double lp = (double)xp[0][0].x;
 #else
-        double lp = loglike_tile<NT>(like_id, like_scale, D, lane, xp);
+        double lp = loglike_tile<NT>(like, D, lane, xp);
 #endif
         const bool acc = pre && (lp > loglstar);  // finite is guaranteed by the -1e100 clamp  :361
         n_call += pre ? 1 : 0;
@@ -712,38 +709,38 @@ hipError_t launch_repack(const float *packed, float *img, const FlowShape &s, hi
 }
 
 hipError_t launch_pass(const float *img, const FlowShape &s, int mode, const float *in, float *out, float *logdet,
-                       double *logl, int *inbox, int N, int like_id, float like_scale, int num_cu, hipStream_t st) {
+                       double *logl, int *inbox, int N, const LikeSpec &like, int num_cu, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     PassArgs a;
     a.img = img; a.s = s; a.mode = mode; a.in = in; a.out = out; a.logdet = logdet; a.logl = logl; a.inbox = inbox;
-    a.N = N; a.like_id = like_id; a.like_scale = like_scale;
+    a.N = N; a.like = like;
     DISPATCH_SHAPE(launch_pass_t, s, a, num_cu, st);
 }
 
-hipError_t launch_mh(const float *img, const FlowShape &s, int like_id, float like_scale, float *z, float *x, double *logl,
+hipError_t launch_mh(const float *img, const FlowShape &s, const LikeSpec &like, float *z, float *x, double *logl,
                      double loglstar, float step_size, int steps, int C, int flags, const float *noise_dz,
                      const float *noise_u, uint64_t seed, uint64_t walker_offset, float *hist_x, double *hist_logl,
                      int *n_accept, int *n_call, float *scale_out, int num_cu, hipStream_t st) {
     if (C <= 0) return hipSuccess;
     MhArgs a;
     a.img = img; a.s = s; a.z = z; a.x = x; a.logl = logl; a.loglstar = loglstar; a.step_size = step_size;
-    a.steps = steps; a.C = C; a.flags = flags; a.like_id = like_id; a.like_scale = like_scale;
+    a.steps = steps; a.C = C; a.flags = flags; a.like = like;
     a.noise_dz = noise_dz; a.noise_u = noise_u; a.seed = seed; a.walker_offset = walker_offset;
     a.hist_x = hist_x; a.hist_logl = hist_logl; a.n_accept = n_accept; a.n_call = n_call; a.scale_out = scale_out;
     DISPATCH_SHAPE(launch_mh_t, s, a, num_cu, st);
 }
 
-hipError_t launch_loglike(int like_id, const float *x, float scale, double *logl, int N, int D, int num_cu, hipStream_t st) {
+hipError_t launch_loglike(const LikeSpec &like, const float *x, double *logl, int N, int D, int num_cu, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     const int NT = ((D + 1) / 2 + 15) / 16;
     const int ntiles = (N + 15) / 16;
     int block = 256, grid = (ntiles + 3) / 4;
     if (grid > 8 * num_cu) grid = 8 * num_cu;
     switch (NT) {
-        case 1: hipLaunchKernelGGL((loglike_kernel<1>), dim3(grid), dim3(block), 0, st, x, logl, N, D, like_id, scale); break;
-        case 2: hipLaunchKernelGGL((loglike_kernel<2>), dim3(grid), dim3(block), 0, st, x, logl, N, D, like_id, scale); break;
-        case 3: hipLaunchKernelGGL((loglike_kernel<3>), dim3(grid), dim3(block), 0, st, x, logl, N, D, like_id, scale); break;
-        case 4: hipLaunchKernelGGL((loglike_kernel<4>), dim3(grid), dim3(block), 0, st, x, logl, N, D, like_id, scale); break;
+        case 1: hipLaunchKernelGGL((loglike_kernel<1>), dim3(grid), dim3(block), 0, st, x, logl, N, D, like); break;
+        case 2: hipLaunchKernelGGL((loglike_kernel<2>), dim3(grid), dim3(block), 0, st, x, logl, N, D, like); break;
+        case 3: hipLaunchKernelGGL((loglike_kernel<3>), dim3(grid), dim3(block), 0, st, x, logl, N, D, like); break;
+        case 4: hipLaunchKernelGGL((loglike_kernel<4>), dim3(grid), dim3(block), 0, st, x, logl, N, D, like); break;
         default: return hipErrorInvalidConfiguration;
     }
     return hipGetLastError();

@@ -24,6 +24,15 @@
 
 namespace nnest {
 
+// NNEST_STAMP: diagnostic build only (tools/time_train.py --stamps): cycles per phase of a minibatch
+#ifdef NNEST_STAMP
+#define TSTAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TACC(acc, t1, t0) acc += (t1) - (t0)
+#else
+#define TSTAMP(v) do { } while (0)
+#define TACC(acc, t1, t0) do { } while (0)
+#endif
+
 enum { TRAIN_MODE_EPOCHS = 0, TRAIN_MODE_GRAD_ONLY = 1 };
 static const int TRAIN_THREADS = 512;  // 8 waves
 static const int TRAIN_WAVES = 8;
@@ -31,6 +40,7 @@ static const int TRAIN_MAX_ROWS = 128;
 
 struct TrainArgs {
     float *w, *m, *v, *best_w, *img_fwd, *img_bwd, *grad;
+    const int *fwd_pos, *bwd_pos;
     int *adam_step;
     FlowShape s;
     const float *xtrain;
@@ -51,36 +61,37 @@ struct TrainArgs {
 };
 
 // ---- fragment images -----------------------------------------------------------------------------------
-// forward image element (same definition as repack_fragments_kernel in nnest_kernels.hip)
-__device__ __forceinline__ float fwd_image_elem(const float *__restrict__ packed, const FlowShape &s, int idx) {
+// Which packed parameter (index into the state_dict-order vector) sits at element idx of the forward image
+// (same layout as repack_fragments_kernel in nnest_kernels.hip); -1 = structural zero (padding / pruned).
+__host__ __device__ inline int fwd_image_src(const FlowShape &s, int idx) {
     const int NT = s.NT, NH = s.NH, L = s.L, D = s.D, H = s.H;
     int bn = idx / s.net_floats, o = idx - bn * s.net_floats;
-    int b = bn >> 1, net = bn & 1;
-    const float *p = packed + ((size_t)b * 2 + net) * s.net_params;
+    int b = bn >> 1;
+    const int base = bn * s.net_params;
     const int pc = (b + 1) & 1, pt = b & 1;
     const int pb0 = H * D, phid = H * D + H, pWo = H * D + H + L * (H * H + H), pbo = pWo + D * H;
     if (o < frag_off_L2(NT, NH)) {
         int lane = o & 63, q = o >> 6, r = q & 3, tau = (q >> 2) % NT, ht = (q >> 2) / NT;
         int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + 4 * g + r) + pc;
-        return d < D ? p[(16 * ht + i) * D + d] : 0.f;
+        return d < D ? base + (16 * ht + i) * D + d : -1;
     } else if (o < frag_off_L3(NT, NH, L)) {
         int oo = o - frag_off_L2(NT, NH);
         int lane = oo & 63, q = oo >> 6, r = q & 3, hti = (q >> 2) % NH, hto = ((q >> 2) / NH) % NH, l = (q >> 2) / (NH * NH);
         int g = lane >> 4, i = lane & 15;
-        return p[phid + l * (H * H + H) + (16 * hto + i) * H + 16 * hti + 4 * g + r];
+        return base + phid + l * (H * H + H) + (16 * hto + i) * H + 16 * hti + 4 * g + r;
     } else if (o < frag_off_b1(NT, NH, L)) {
         int oo = o - frag_off_L3(NT, NH, L);
         int lane = oo & 63, q = oo >> 6, r = q & 3, ht = (q >> 2) % NH, tau = (q >> 2) / NH;
         int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + i) + pt;
-        return d < D ? p[pWo + d * H + 16 * ht + 4 * g + r] : 0.f;
+        return d < D ? base + pWo + d * H + 16 * ht + 4 * g + r : -1;
     } else if (o < frag_off_b2(NT, NH, L)) {
-        return p[pb0 + (o - frag_off_b1(NT, NH, L))];
+        return base + pb0 + (o - frag_off_b1(NT, NH, L));
     } else if (o < frag_off_b3(NT, NH, L)) {
         int oo = o - frag_off_b2(NT, NH, L), l = oo / (16 * NH), j = oo % (16 * NH);
-        return p[phid + l * (H * H + H) + H * H + j];
+        return base + phid + l * (H * H + H) + H * H + j;
     } else {
         int sl = o - frag_off_b3(NT, NH, L), d = 2 * sl + pt;
-        return d < D ? p[pbo + d] : 0.f;
+        return d < D ? base + pbo + d : -1;
     }
 }
 
@@ -88,37 +99,61 @@ __device__ __forceinline__ float fwd_image_elem(const float *__restrict__ packed
 //   region L1-sized  B3 [ht][tau][r][lane]   g_h[ht]   += Wout^T : lane(g,i) = Wout[dim(16tau+4g+r)][16ht+i]
 //   region L2-sized  B2 [l][hti][hto][r][lane] g_h[hti] += W_l^T : lane(g,i) = W_l[16hto+4g+r][16hti+i]
 //   region L3-sized  B1 [tau][ht][r][lane]   g_m[tau]  += W0^T   : lane(g,i) = W0[16ht+4g+r][dim(16tau+i)]
-__device__ __forceinline__ float bwd_image_elem(const float *__restrict__ packed, const FlowShape &s, int idx) {
+__host__ __device__ inline int bwd_image_src(const FlowShape &s, int idx) {
     const int NT = s.NT, NH = s.NH, L = s.L, D = s.D, H = s.H;
     int bn = idx / s.net_floats, o = idx - bn * s.net_floats;
-    int b = bn >> 1, net = bn & 1;
-    const float *p = packed + ((size_t)b * 2 + net) * s.net_params;
+    int b = bn >> 1;
+    const int base = bn * s.net_params;
     const int pc = (b + 1) & 1, pt = b & 1;
     const int phid = H * D + H, pWo = H * D + H + L * (H * H + H);
     if (o < frag_off_L2(NT, NH)) {
         int lane = o & 63, q = o >> 6, r = q & 3, tau = (q >> 2) % NT, ht = (q >> 2) / NT;
         int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + 4 * g + r) + pt;
-        return d < D ? p[pWo + d * H + 16 * ht + i] : 0.f;
+        return d < D ? base + pWo + d * H + 16 * ht + i : -1;
     } else if (o < frag_off_L3(NT, NH, L)) {
         int oo = o - frag_off_L2(NT, NH);
         int lane = oo & 63, q = oo >> 6, r = q & 3, hto = (q >> 2) % NH, hti = ((q >> 2) / NH) % NH, l = (q >> 2) / (NH * NH);
         int g = lane >> 4, i = lane & 15;
-        return p[phid + l * (H * H + H) + (16 * hto + 4 * g + r) * H + 16 * hti + i];
+        return base + phid + l * (H * H + H) + (16 * hto + 4 * g + r) * H + 16 * hti + i;
     } else if (o < frag_off_b1(NT, NH, L)) {
         int oo = o - frag_off_L3(NT, NH, L);
         int lane = oo & 63, q = oo >> 6, r = q & 3, ht = (q >> 2) % NH, tau = (q >> 2) / NH;
         int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + i) + pc;
-        return d < D ? p[(16 * ht + 4 * g + r) * D + d] : 0.f;
+        return d < D ? base + (16 * ht + 4 * g + r) * D + d : -1;
     }
-    return 0.f;
+    return -1;
 }
 
-__device__ __forceinline__ void rebuild_images(const TrainArgs &a) {
-    for (int i = threadIdx.x; i < a.s.image_floats; i += blockDim.x) {
-        a.img_fwd[i] = fwd_image_elem(a.w, a.s, i);
-        a.img_bwd[i] = bwd_image_elem(a.w, a.s, i);
+// inverse maps packed parameter -> image element (each parameter occurs at most once per image; -1 = absent:
+// exactly the parameters the alternating mask never reaches, whose gradient is identically zero)
+__global__ void build_pos_kernel(int *__restrict__ fwd_pos, int *__restrict__ bwd_pos, FlowShape s) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < s.image_floats; i += gridDim.x * blockDim.x) {
+        int f = fwd_image_src(s, i), b = bwd_image_src(s, i);
+        if (f >= 0) fwd_pos[f] = i;
+        if (b >= 0) bwd_pos[b] = i;
     }
 }
+
+hipError_t launch_build_pos(int *fwd_pos, int *bwd_pos, const FlowShape &s, hipStream_t st) {
+    const size_t nb = (size_t)s.B * 2 * s.net_params * sizeof(int);
+    hipError_t e = hipMemsetAsync(fwd_pos, 0xFF, nb, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(bwd_pos, 0xFF, nb, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(build_pos_kernel, dim3(64), dim3(256), 0, st, fwd_pos, bwd_pos, s);
+    return hipGetLastError();
+}
+
+// (re)build images from the packed weights: into global memory, and into the LDS copies when given
+__device__ __forceinline__ void rebuild_images_to(const TrainArgs &a, float *imgf, float *imgb) {
+    for (int i = threadIdx.x; i < a.s.image_floats; i += blockDim.x) {
+        int f = fwd_image_src(a.s, i), b = bwd_image_src(a.s, i);
+        imgf[i] = f >= 0 ? a.w[f] : 0.f;
+        imgb[i] = b >= 0 ? a.w[b] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void rebuild_images(const TrainArgs &a) { rebuild_images_to(a, a.img_fwd, a.img_bwd); }
 
 // ---- MLP forward keeping the hidden activations (for the backward pass) ---------------------------------
 template <int NT, int NH, int L, int ACT>
@@ -274,25 +309,107 @@ __device__ __forceinline__ void mlp_bwd(const float *__restrict__ bn, int lane, 
 
 // ---- phase B: one dW tile = sum over rows of G[row][16] (x) Act[row][16] ----------------------------------
 __device__ __forceinline__ f32x4 contract_rows(const float *stg, int rows_pad, int ct_g, int ct_a, int lane) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // rows_pad is a multiple of 16: four independent accumulators, one per 4-row k-step of a 16-row tile, so the
+    // MFMAs issue back to back (a single chain waits 40 cycles per dependent v_mfma_f32_16x16x4_f32) and the LDS
+    // reads of a tile are all in flight together
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
     const float *G = stg + (size_t)ct_g * rows_pad * 16 + (lane >> 4) * 16 + (lane & 15);
     if (ct_a >= 0) {
         const float *A = stg + (size_t)ct_a * rows_pad * 16 + (lane >> 4) * 16 + (lane & 15);
-        for (int r4 = 0; r4 < rows_pad; r4 += 4) acc = mfma4(G[r4 * 16], A[r4 * 16], acc);
+        for (int r = 0; r < rows_pad; r += 16) {
+            a0 = mfma4(G[(r + 0) * 16], A[(r + 0) * 16], a0);
+            a1 = mfma4(G[(r + 4) * 16], A[(r + 4) * 16], a1);
+            a2 = mfma4(G[(r + 8) * 16], A[(r + 8) * 16], a2);
+            a3 = mfma4(G[(r + 12) * 16], A[(r + 12) * 16], a3);
+        }
     } else {
-        for (int r4 = 0; r4 < rows_pad; r4 += 4) acc = mfma4(G[r4 * 16], 1.0f, acc);  // bias: Act = 1
+        for (int r = 0; r < rows_pad; r += 16) {  // bias: Act = 1
+            a0 = mfma4(G[(r + 0) * 16], 1.0f, a0);
+            a1 = mfma4(G[(r + 4) * 16], 1.0f, a1);
+            a2 = mfma4(G[(r + 8) * 16], 1.0f, a2);
+            a3 = mfma4(G[(r + 12) * 16], 1.0f, a3);
+        }
     }
-    return acc;  // lane (gq, j) reg r  <->  (out feature 4*gq + r, in feature j)
+    return (a0 + a1) + (a2 + a3);  // lane (gq, j) reg r  <->  (out feature 4*gq + r, in feature j)
+}
+
+// per-minibatch Adam scalars (torch/optim/adam.py _single_tensor_adam)
+struct AdamStep {
+    float step_size, inv_bc2s;
+};
+
+// torch.optim.Adam with coupled weight decay (trainer.py:121-122) over the whole packed vector, float4-coalesced,
+// every load of a thread's slice issued before its arithmetic.  Parameters the mask never reaches have an exactly
+// zero gradient (the gradient buffer is zeroed once and never written there) but still take their step, as in the
+// reference.  Each updated weight is scattered to its element of the forward / backward fragment image (position
+// maps built once per flow), which replaces rebuilding both images from the packed vector every minibatch.
+__device__ __forceinline__ void adam_one(const TrainArgs &a, const AdamStep &ad, float &w, float g, float &m, float &v, int fp,
+                                         int bp, float *imgf, float *imgb) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    float gi = g + a.wd * w;
+    m = m + (gi - m) * (1.0f - b1);
+    v = v * b2 + (1.0f - b2) * gi * gi;
+    // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly-rounded sequences: the update is lr * m / denom with
+    // lr = 1e-3, so an ulp of the ratio is ~1e-10 on the weight
+    float denom = __builtin_amdgcn_sqrtf(v) * ad.inv_bc2s + eps;
+    w = w - ad.step_size * (m * __builtin_amdgcn_rcpf(denom));
+    if (fp >= 0) imgf[fp] = w;
+    if (bp >= 0) imgb[bp] = w;
+}
+
+__device__ __forceinline__ void adam_sweep(const TrainArgs &a, const AdamStep &ad, int np, float *imgf, float *imgb) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    constexpr int U = 4;  // float4 groups in flight per thread: the global-load latency is paid once per U groups
+    const int n4 = np >> 2;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += U * blockDim.x) {
+        f32x4 w4[U], g4[U], m4[U], v4[U];
+        i32x4 fp[U], bp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < n4) {
+                w4[u] = reinterpret_cast<const f32x4 *>(a.w)[i];
+                g4[u] = reinterpret_cast<const f32x4 *>(a.grad)[i];
+                m4[u] = reinterpret_cast<const f32x4 *>(a.m)[i];
+                v4[u] = reinterpret_cast<const f32x4 *>(a.v)[i];
+                fp[u] = reinterpret_cast<const i32x4 *>(a.fwd_pos)[i];
+                bp[u] = reinterpret_cast<const i32x4 *>(a.bwd_pos)[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < n4) {
+                float w[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w}, g[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+                float m[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w}, v[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+                const int f[4] = {fp[u].x, fp[u].y, fp[u].z, fp[u].w}, bq[4] = {bp[u].x, bp[u].y, bp[u].z, bp[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) adam_one(a, ad, w[k], g[k], m[k], v[k], f[k], bq[k], imgf, imgb);
+                reinterpret_cast<f32x4 *>(a.w)[i] = (f32x4){w[0], w[1], w[2], w[3]};
+                reinterpret_cast<f32x4 *>(a.m)[i] = (f32x4){m[0], m[1], m[2], m[3]};
+                reinterpret_cast<f32x4 *>(a.v)[i] = (f32x4){v[0], v[1], v[2], v[3]};
+            }
+        }
+    }
+    for (int p = 4 * n4 + threadIdx.x; p < np; p += blockDim.x) {  // tail (np not a multiple of 4)
+        float w = a.w[p], m = a.m[p], v = a.v[p];
+        adam_one(a, ad, w, a.grad[p], m, v, a.fwd_pos[p], a.bwd_pos[p], imgf, imgb);
+        a.w[p] = w; a.m[p] = m; a.v[p] = v;
+    }
 }
 
 template <int NT, int NH, int L>
 __device__ __forceinline__ void weight_grad_jobs(const TrainArgs &a, const float *stg, int rows_pad, int b, int net,
-                                                 int wave, int lane) {
+                                                 int wave, int lane, const AdamStep &ad, float *imgf, float *imgb) {
     typedef StageMap<NT, NH, L> SM;
     const int D = a.s.D, H = a.s.H;
     const int pc = (b + 1) & 1, pt = b & 1;
     const int pb0 = H * D, phid = H * D + H, pWo = H * D + H + L * (H * H + H), pbo = pWo + D * H;
-    float *gp = a.grad + ((size_t)b * 2 + net) * a.s.net_params;
+    const int pbase = (b * 2 + net) * a.s.net_params;
+    // every gradient element has exactly one producer (no atomics): scattered into the packed gradient vector
+    (void)ad; (void)imgf; (void)imgb;
+    auto emit = [&](int idx, float g) { a.grad[pbase + idx] = g; };
     const int gq = lane >> 4, j = lane & 15;
     constexpr int J_W3 = NT * NH, J_B3 = NT, J_W2 = L * NH * NH, J_B2 = L * NH, J_W1 = NH * NT, J_B1 = NH;
     constexpr int NJOBS = J_W3 + J_B3 + J_W2 + J_B2 + J_W1 + J_B1;
@@ -305,7 +422,7 @@ __device__ __forceinline__ void weight_grad_jobs(const TrainArgs &a, const float
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int d = 2 * (16 * tau + 4 * gq + r) + pt;
-                if (d < D) gp[pWo + d * H + 16 * ht + j] = v[r];
+                if (d < D) emit(pWo + d * H + 16 * ht + j, v[r]);
             }
             continue;
         }
@@ -318,7 +435,7 @@ __device__ __forceinline__ void weight_grad_jobs(const TrainArgs &a, const float
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int d = 2 * (16 * tau + 4 * gq + r) + pt;
-                    if (d < D) gp[pbo + d] = v[r];
+                    if (d < D) emit(pbo + d, v[r]);
                 }
             }
             continue;
@@ -329,7 +446,7 @@ __device__ __forceinline__ void weight_grad_jobs(const TrainArgs &a, const float
             f32x4 t = contract_rows(stg, rows_pad, SM::gpre(l, hto), SM::act(l - 1, hti), lane);
             float v[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gp[phid + (l - 1) * (H * H + H) + (16 * hto + 4 * gq + r) * H + 16 * hti + j] = v[r];
+            for (int r = 0; r < 4; ++r) emit(phid + (l - 1) * (H * H + H) + (16 * hto + 4 * gq + r) * H + 16 * hti + j, v[r]);
             continue;
         }
         q -= J_W2;
@@ -339,7 +456,7 @@ __device__ __forceinline__ void weight_grad_jobs(const TrainArgs &a, const float
             float v[4] = {t.x, t.y, t.z, t.w};
             if (j == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gp[phid + (l - 1) * (H * H + H) + H * H + 16 * hto + 4 * gq + r] = v[r];
+                for (int r = 0; r < 4; ++r) emit(phid + (l - 1) * (H * H + H) + H * H + 16 * hto + 4 * gq + r, v[r]);
             }
             continue;
         }
@@ -351,7 +468,7 @@ __device__ __forceinline__ void weight_grad_jobs(const TrainArgs &a, const float
             int d = 2 * (16 * tau + j) + pc;
             if (d < D) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gp[(16 * ht + 4 * gq + r) * D + d] = v[r];
+                for (int r = 0; r < 4; ++r) emit((16 * ht + 4 * gq + r) * D + d, v[r]);
             }
             continue;
         }
@@ -362,7 +479,7 @@ __device__ __forceinline__ void weight_grad_jobs(const TrainArgs &a, const float
             float v[4] = {t.x, t.y, t.z, t.w};
             if (j == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gp[pb0 + 16 * ht + 4 * gq + r] = v[r];
+                for (int r = 0; r < 4; ++r) emit(pb0 + 16 * ht + 4 * gq + r, v[r]);
             }
         }
     }
@@ -375,11 +492,15 @@ __device__ __forceinline__ void weight_grad_jobs(const TrainArgs &a, const float
 template <int NT, int NH, int L>
 __device__ __forceinline__ void block_backward(const TrainArgs &a, float *stg, int rows_pad, int b, int wave, int lane,
                                                bool tile_active, int row, bool row_ok, const f32x4 (&cond)[NT],
-                                               f32x4 (&ytrans)[NT], f32x4 (&gcond)[NT], f32x4 (&gtrans)[NT], float gld) {
+                                               f32x4 (&ytrans)[NT], f32x4 (&gcond)[NT], f32x4 (&gtrans)[NT], float gld,
+                                               const AdamStep &ad, float *imgf, float *imgb, unsigned long long (&ph)[8]) {
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+    (void)q0; (void)q1; (void)q2; (void)q3; (void)q4; (void)ph;
+    TSTAMP(q0);
     typedef StageMap<NT, NH, L> SM;
     const int pt = b & 1;
-    const float *wf = a.img_fwd + (size_t)b * 2 * a.s.net_floats;
-    const float *wb = a.img_bwd + (size_t)b * 2 * a.s.net_floats;
+    const float *wf = imgf + (size_t)b * 2 * a.s.net_floats;
+    const float *wb = imgb + (size_t)b * 2 * a.s.net_floats;
     f32x4 as[L + 1][NH], at[L + 1][NH], ls[NT], t[NT], g_ls[NT], g_t[NT], gm_s[NT], gm_t[NT];
     const int g = lane >> 4;
     if (tile_active) {
@@ -417,12 +538,17 @@ __device__ __forceinline__ void block_backward(const TrainArgs &a, float *stg, i
         }
     }
     __syncthreads();
-    weight_grad_jobs<NT, NH, L>(a, stg, rows_pad, b, 0, wave, lane);
+    TSTAMP(q1);
+    weight_grad_jobs<NT, NH, L>(a, stg, rows_pad, b, 0, wave, lane, ad, imgf, imgb);
     __syncthreads();
+    TSTAMP(q2);
     if (tile_active) mlp_bwd<NT, NH, L, 1>(wb + a.s.net_floats, lane, stg, rows_pad, row, g_t, at, gm_t);
     __syncthreads();
-    weight_grad_jobs<NT, NH, L>(a, stg, rows_pad, b, 1, wave, lane);
+    TSTAMP(q3);
+    weight_grad_jobs<NT, NH, L>(a, stg, rows_pad, b, 1, wave, lane, ad, imgf, imgb);
     __syncthreads();
+    TSTAMP(q4);
+    TACC(ph[1], q1, q0); TACC(ph[2], q2, q1); TACC(ph[3], q3, q2); TACC(ph[4], q4, q3);
     if (tile_active) {
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) gcond[tau] = gcond[tau] + gm_s[tau] + gm_t[tau];  // masked_inputs = inputs * mask
@@ -430,9 +556,14 @@ __device__ __forceinline__ void block_backward(const TrainArgs &a, float *stg, i
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------
-template <int NT, int NH, int L>
+// IMGLDS: the forward and backward fragment images live in LDS next to the staging area (config 2: 2 x 32 KB +
+// 64 KB); otherwise they are read from / updated in global memory (L2).
+template <int NT, int NH, int L, bool IMGLDS>
 __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float stg[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *imgf = IMGLDS ? smem : a.img_fwd;
+    float *imgb = IMGLDS ? smem + a.s.image_floats : a.img_bwd;
+    float *stg = IMGLDS ? smem + 2 * a.s.image_floats : smem;
     __shared__ float red[TRAIN_WAVES];
     __shared__ int ctl[4];      // [0] stop flag, [1] counter, [2] best epoch
     __shared__ float ctlf[2];   // [0] best validation loss
@@ -442,7 +573,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
     const int np = B * 2 * a.s.net_params;
     const float half_log_2pi = 0.91893853320467274f;
 
-    rebuild_images(a);
+    rebuild_images_to(a, imgf, imgb);
     if (a.mode == TRAIN_MODE_GRAD_ONLY)
         for (int i = threadIdx.x; i < np; i += blockDim.x) a.grad[i] = 0.f;
     const bool resume = a.mode == TRAIN_MODE_EPOCHS && (a.flags & NNEST_TRAIN_RESUME);
@@ -465,6 +596,8 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
     int epochs_run = 0;
     float last_train_loss = 0.f;
 
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    (void)p0; (void)p1; (void)p2; (void)p3;
     for (int epoch = 0; epoch < n_epochs; ++epoch) {
         float epoch_loss = 0.f;  // sum of minibatch means (trainer.py:398)
         for (int mb = 0; mb < n_mb; ++mb) {
@@ -476,6 +609,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
             const bool row_ok = tile_active && row < M;
             f32x4 xs[2][NT], gs[2][NT];
             float ld = 0.f;
+            TSTAMP(p0);
             if (tile_active) {
                 // data = X[perm] + jitter * randn  (trainer.py:392)
                 long src = 0;
@@ -505,7 +639,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
                         }
                     }
                 }
-                ld = group_sum(flow_forward_tile<NT, NH>(a.img_fwd, a.s.net_floats, B, L, lane, xs));
+                ld = group_sum(flow_forward_tile<NT, NH>(imgf, a.s.net_floats, B, L, lane, xs));
             }
             // loss = -mean(log_probs)  (trainer.py:394; networks.py:71-76)
             float lp = 0.f;
@@ -530,43 +664,39 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
             loss = -loss / (float)M;
             epoch_loss += loss;
             // d(loss)/du = u/M ; d(loss)/d(logdet) = -1/M
+            TSTAMP(p1);
+            TACC(ph[0], p1, p0);
             const float invM = 1.0f / (float)M, gld = -invM;
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) gs[c][t] = row_ok ? xs[c][t] * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
+            // Adam scalars of this step (torch/optim/adam.py _single_tensor_adam); the update itself is applied
+            // per parameter by the thread that produces its gradient (weight_grad_jobs)
+            AdamStep ad = {0.f, 1.f};
+            if (a.mode == TRAIN_MODE_EPOCHS) {
+                adam_t += 1;
+                const double bc1 = 1.0 - pow(0.9, (double)adam_t), bc2 = 1.0 - pow(0.999, (double)adam_t);
+                ad.step_size = (float)((double)a.lr / bc1);
+                ad.inv_bc2s = (float)(1.0 / sqrt(bc2));
+            }
             for (int b = B - 1; b >= 0; --b) {
-                if (b & 1) block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[0], xs[1], gs[0], gs[1], gld);
-                else       block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[1], xs[0], gs[1], gs[0], gld);
+                if (b & 1) block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[0], xs[1], gs[0], gs[1], gld, ad, imgf, imgb, ph);
+                else       block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[1], xs[0], gs[1], gs[0], gld, ad, imgf, imgb, ph);
             }
             if (a.mode == TRAIN_MODE_GRAD_ONLY) {
                 if (threadIdx.x == 0) *a.loss_out = loss;
                 __syncthreads();
                 return;
             }
-            // Adam with coupled weight decay (torch/optim/adam.py _single_tensor_adam; trainer.py:121-122)
-            adam_t += 1;
-            {
-                const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-                const double bc1 = 1.0 - pow((double)b1, (double)adam_t), bc2 = 1.0 - pow((double)b2, (double)adam_t);
-                const float step_size = (float)((double)a.lr / bc1), bc2s = (float)sqrt(bc2);
-                for (int i = threadIdx.x; i < np; i += blockDim.x) {
-                    float wi = a.w[i];
-                    float gi = a.grad[i] + a.wd * wi;
-                    float mi = a.m[i], vi = a.v[i];
-                    mi = mi + (gi - mi) * (1.0f - b1);
-                    vi = vi * b2 + (1.0f - b2) * gi * gi;
-                    float denom = sqrtf(vi) / bc2s + eps;
-                    a.w[i] = wi - step_size * (mi / denom);
-                    a.m[i] = mi;
-                    a.v[i] = vi;
-                }
-            }
+            TSTAMP(p1);
+            adam_sweep(a, ad, np, imgf, imgb);
             __syncthreads();
-            rebuild_images(a);
-            __syncthreads();
+            TSTAMP(p2);
+            TACC(ph[5], p2, p1);
         }
         // ---- Trainer._validate (trainer.py:405-418): one full batch, loss / len(valid) -----------------------
+        TSTAMP(p0);
         float vsum = 0.f;
         {
             const int vtiles = (a.n_valid + 15) >> 4;
@@ -575,7 +705,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
                 const bool ok = r < a.n_valid;
                 f32x4 xv[2][NT];
                 load_tile<NT>(a.xvalid, r, ok, D, lane, xv);
-                float ldv = group_sum(flow_forward_tile<NT, NH>(a.img_fwd, a.s.net_floats, B, L, lane, xv));
+                float ldv = group_sum(flow_forward_tile<NT, NH>(imgf, a.s.net_floats, B, L, lane, xv));
                 float ss = 0.f;
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
@@ -596,6 +726,8 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
         __syncthreads();
         float vtot = 0.f;
         for (int k = 0; k < TRAIN_WAVES; ++k) vtot += red[k];
+        TSTAMP(p1);
+        TACC(ph[7], p1, p0);
         const float valid_loss = (-vtot / (float)a.n_valid) / (float)a.n_valid;  // mean, then / len(dataset)  :418
         const float train_loss = epoch_loss / (float)a.n_train;                   // trainer.py:403
         last_train_loss = train_loss;
@@ -625,8 +757,12 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
     if (stopped || (a.flags & NNEST_TRAIN_FINALIZE)) {
         for (int i = threadIdx.x; i < np; i += blockDim.x) a.w[i] = a.best_w[i];
         __syncthreads();
-        rebuild_images(a);
     }
+    rebuild_images(a);  // the global images (read by the inference kernels and the next chunk) follow a.w
+#ifdef NNEST_STAMP
+    if (threadIdx.x == 0 && a.losses)
+        for (int i = 0; i < 8; ++i) a.losses[i] = (float)ph[i];
+#endif
     if (threadIdx.x == 0) {
         if (a.adam_step) *a.adam_step = adam_t;
         a.result->epochs_run = a.epoch_offset + epochs_run;
@@ -682,17 +818,24 @@ size_t train_workspace_floats(const FlowShape &s, int batch) {
     return (size_t)s.image_floats + (size_t)s.B * 2 * s.net_params + 64;
 }
 
-template <int NT, int NH, int L>
-static hipError_t launch_train_t(const TrainArgs &a, hipStream_t st) {
-    typedef StageMap<NT, NH, L> SM;
-    const size_t lds = (size_t)SM::count * TRAIN_MAX_ROWS * 16 * sizeof(float);
+template <int NT, int NH, int L, bool IMGLDS>
+static hipError_t launch_train_tt(const TrainArgs &a, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(train_kernel<NT, NH, L>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(train_kernel<NT, NH, L, IMGLDS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((train_kernel<NT, NH, L>), dim3(1), dim3(TRAIN_THREADS), lds, st, a);
+    hipLaunchKernelGGL((train_kernel<NT, NH, L, IMGLDS>), dim3(1), dim3(TRAIN_THREADS), lds, st, a);
     return hipGetLastError();
+}
+
+template <int NT, int NH, int L>
+static hipError_t launch_train_t(const TrainArgs &a, hipStream_t st) {
+    typedef StageMap<NT, NH, L> SM;
+    const size_t stage = (size_t)SM::count * TRAIN_MAX_ROWS * 16 * sizeof(float);
+    const size_t with_img = stage + 2 * (size_t)a.s.image_floats * sizeof(float);
+    if (with_img <= 160 * 1024 - 256) return launch_train_tt<NT, NH, L, true>(a, with_img, st);
+    return launch_train_tt<NT, NH, L, false>(a, stage, st);
 }
 
 static hipError_t dispatch_train(const TrainArgs &a, hipStream_t st) {
@@ -708,12 +851,14 @@ static hipError_t dispatch_train(const TrainArgs &a, hipStream_t st) {
 }
 
 hipError_t launch_loss_grad(const float *packed, const FlowShape &s, const float *x, int M, float *grad, float *loss,
-                            float *workspace, float *img_fwd, hipStream_t st) {
+                            float *workspace, float *img_fwd, const int *fwd_pos, const int *bwd_pos, hipStream_t st) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     a.w = const_cast<float *>(packed);
     a.img_fwd = img_fwd;
     a.img_bwd = workspace;
+    a.fwd_pos = fwd_pos;
+    a.bwd_pos = bwd_pos;
     a.grad = grad;
     a.s = s;
     a.xtrain = x;
@@ -728,11 +873,14 @@ hipError_t launch_train(float *packed, float *adam_m, float *adam_v, float *best
                         const FlowShape &s, const float *xtrain, int n_train, const float *xvalid, int n_valid,
                         const int *perm, const float *noise, uint64_t seed, float jitter, int batch, int max_epochs,
                         int patience, float lr, float wd, int epoch_offset, int flags, float *losses,
-                        nnest_train_result_t *result, float *workspace, hipStream_t st) {
+                        nnest_train_result_t *result, float *workspace, const int *fwd_pos, const int *bwd_pos,
+                        hipStream_t st) {
     TrainArgs a;
     memset(&a, 0, sizeof(a));
     a.w = packed; a.m = adam_m; a.v = adam_v; a.best_w = best_w; a.img_fwd = img;
     a.img_bwd = workspace;
+    a.fwd_pos = fwd_pos;
+    a.bwd_pos = bwd_pos;
     a.grad = workspace + s.image_floats;
     a.adam_step = adam_step_dev;
     a.s = s;

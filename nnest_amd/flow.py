@@ -182,7 +182,7 @@ class HipNVP(object):
         x, _ = self.inverse(noise)
         return x
 
-    def inverse_loglike(self, like_id, like_scale, z, want_x=True):
+    def inverse_loglike(self, like_id, like_scale, z, want_x=True, like_params=None):
         """K3: x = f^-1(z), logdet, box-prior flag, logl = loglike(like_scale * x) in one launch."""
         z = _as_dev_f32(z, self.device)
         N = z.shape[0]
@@ -191,13 +191,14 @@ class HipNVP(object):
         logl = torch.empty(N, dtype=torch.float64, device=self.device)
         inbox = torch.empty(N, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.nnest_nvp_inverse_loglike(self._h, int(like_id), float(like_scale), _lib.ptr(z),
+            lk = _lib.like_spec(like_id, like_scale, like_params)
+            _lib.check(self._lib.nnest_nvp_inverse_loglike(self._h, ctypes.byref(lk), _lib.ptr(z),
                                                            _lib.ptr(x), _lib.ptr(ld), _lib.ptr(logl), _lib.ptr(inbox), N,
                                                            _lib.current_stream(self.device)))
         return x, ld, logl, inbox
 
     def mh_steps(self, like_id, like_scale, z, logl, loglstar, step_size, steps, dynamic=False, noise=None, seed=0,
-                 walker_offset=0, history=False):
+                 walker_offset=0, history=False, like_params=None):
         """K4: `steps` constrained Metropolis steps for all walkers in one launch (Sampler._mcmc_sample,
         sampler.py:229-463).  z [C,D] float32 and logl [C] float64 are updated in place.
         noise = (dz [steps,C,D], u [steps,C]) replays recorded draws; None = in-kernel Philox."""
@@ -218,8 +219,9 @@ class HipNVP(object):
             u = noise[1].to(device=dev, dtype=torch.float32).contiguous()
             assert dz.shape[0] == steps * C and u.numel() == steps * C
         with torch.cuda.device(dev):
+            lk = _lib.like_spec(like_id, like_scale, like_params)
             _lib.check(self._lib.nnest_mh_constrained_steps(
-                self._h, int(like_id), float(like_scale), _lib.ptr(z), _lib.ptr(x), _lib.ptr(logl), float(loglstar),
+                self._h, ctypes.byref(lk), _lib.ptr(z), _lib.ptr(x), _lib.ptr(logl), float(loglstar),
                 float(step_size), int(steps), C, _lib.MH_DYNAMIC_STEP if dynamic else 0, _lib.ptr(dz), _lib.ptr(u),
                 int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), _lib.ptr(hx), _lib.ptr(hl), _lib.ptr(n_acc),
                 _lib.ptr(n_call), _lib.ptr(scale_out), _lib.current_stream(dev)))
@@ -279,12 +281,13 @@ class HipNVP(object):
         return dz, u
 
 
-def loglike(like_id, x_unit, like_scale, device=None):
+def loglike(like_id, x_unit, like_scale, device=None, like_params=None):
     """K6: batched analytic likelihood through safe_loglike (sampler.py:110-133): float64 [N]."""
     device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     x = _as_dev_f32(x_unit, device)
     out = torch.empty(x.shape[0], dtype=torch.float64, device=device)
     with torch.cuda.device(device):
-        _lib.check(_lib.load().nnest_loglike(int(like_id), _lib.ptr(x), float(like_scale), _lib.ptr(out), x.shape[0],
+        lk = _lib.like_spec(like_id, like_scale, like_params)
+        _lib.check(_lib.load().nnest_loglike(ctypes.byref(lk), _lib.ptr(x), _lib.ptr(out), x.shape[0],
                                              x.shape[1], _lib.current_stream(device)))
     return out

@@ -11,6 +11,7 @@ from ._lib import LIKE_IDS
 class Likelihood(object):
     num_derived = 0
     hip_like_id = None
+    hip_like_params = ()
 
     def __init__(self, x_dim):
         self.x_dim = x_dim
@@ -94,3 +95,87 @@ class GaussianMix(Likelihood):
         v = np.zeros(self.x_dim)
         v[:2] = self.positions[int(np.argmax(self.weights))]
         return self(v)
+
+
+class Gaussian(Likelihood):
+    """likelihoods.py:77-94: N(0, Sigma), Sigma = I + corr (11^T - I).  Evaluated in closed form (Sherman-Morrison
+    for the equicorrelated covariance) instead of scipy's Cholesky; same float64 arithmetic domain."""
+    hip_like_id = LIKE_IDS['gaussian']
+
+    def __init__(self, x_dim, corr, lim=5):
+        super(Gaussian, self).__init__(x_dim)
+        self.corr, self.lim = corr, lim
+        self.hip_like_params = (corr,)
+
+    def loglike_rows(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        D, c = self.x_dim, self.corr
+        s1, s2 = np.sum(x, axis=1), np.sum(x * x, axis=1)
+        quad = (s2 - c * s1 * s1 / (1.0 + (D - 1.0) * c)) / (1.0 - c)
+        logdet = (D - 1.0) * np.log(1.0 - c) + np.log(1.0 + (D - 1.0) * c)
+        return -0.5 * quad - 0.5 * logdet - 0.5 * D * np.log(2 * np.pi)
+
+    @property
+    def max_loglike(self):
+        return self(np.zeros(self.x_dim))
+
+
+class Eggbox(Likelihood):
+    """likelihoods.py:97-110 (x_dim = 2)"""
+    hip_like_id = LIKE_IDS['eggbox']
+
+    def __init__(self, x_dim=2):
+        assert x_dim == 2
+        super(Eggbox, self).__init__(x_dim)
+
+    def loglike_rows(self, x):
+        chi = np.cos(x[:, 0] / 2.) * np.cos(x[:, 1] / 2.)
+        return (2. + chi) ** 5
+
+    @property
+    def max_loglike(self):
+        return self(np.zeros(2))
+
+
+class GaussianShell(Likelihood):
+    """likelihoods.py:113-132 (the fused kernel takes a scalar centre)"""
+    hip_like_id = LIKE_IDS['shell']
+
+    def __init__(self, x_dim, sigma=0.1, rshell=2, center=0):
+        super(GaussianShell, self).__init__(x_dim)
+        self.sigma, self.rshell = sigma, rshell
+        if hasattr(center, '__len__'):
+            self.center = np.asarray(center, dtype=np.float64)
+            if np.ptp(self.center) != 0:
+                self.hip_like_id = None
+            c0 = float(self.center[0])
+        else:
+            self.center = np.full(x_dim, float(center))
+            c0 = float(center)
+        self.hip_like_params = (sigma, rshell, c0)
+
+    def loglike_rows(self, x):
+        rad = np.sqrt(np.sum((self.center - np.asarray(x, dtype=np.float64)) ** 2, axis=1))
+        return -((rad - self.rshell) ** 2) / (2 * self.sigma ** 2)
+
+    @property
+    def max_loglike(self):
+        return 0.0
+
+
+class DoubleGaussianShell(Likelihood):
+    """likelihoods.py:135-150"""
+    hip_like_id = LIKE_IDS['double_shell']
+
+    def __init__(self, x_dim, sigmas=(0.1, 0.1), rshells=(2, 2), centers=(-4, 4), weights=(1.0, 1.0)):
+        super(DoubleGaussianShell, self).__init__(x_dim)
+        self.shell1 = GaussianShell(x_dim, sigma=sigmas[0], rshell=rshells[0], center=centers[0])
+        self.shell2 = GaussianShell(x_dim, sigma=sigmas[1], rshell=rshells[1], center=centers[1])
+        self.weights = tuple(weights)
+        if self.weights != (1.0, 1.0):
+            self.hip_like_id = None
+        self.hip_like_params = (sigmas[0], rshells[0], centers[0], sigmas[1], rshells[1], centers[1])
+
+    def loglike_rows(self, x):
+        return np.logaddexp(np.log(self.weights[0]) + self.shell1.loglike_rows(x),
+                            np.log(self.weights[1]) + self.shell2.loglike_rows(x))

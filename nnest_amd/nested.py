@@ -17,6 +17,7 @@ import glob
 import json
 import logging
 import os
+import time
 
 import numpy as np
 
@@ -50,7 +51,8 @@ class NestedSampler(Sampler):
                  param_names=None,
                  num_live_points=1000,
                  fused=True,
-                 mcmc_history=False):
+                 mcmc_history=False,
+                 checkpoint_min_seconds=30.0):
         prior = UniformPrior(x_dim, -1, 1)  # nested.py:76
         super(NestedSampler, self).__init__(x_dim, loglike, transform=transform, append_run_num=append_run_num,
                                             hidden_dim=hidden_dim, num_slow=num_slow, num_derived=num_derived,
@@ -61,6 +63,7 @@ class NestedSampler(Sampler):
                                             param_names=param_names, oversample_rate=oversample_rate, fused=fused,
                                             mcmc_history=mcmc_history)
         self.num_live_points = num_live_points
+        self.checkpoint_min_seconds = checkpoint_min_seconds
         self.sampler = 'nested'
         if self.single_or_primary_process:
             self.logger.info('Num live points [%d]' % self.num_live_points)
@@ -203,6 +206,7 @@ class NestedSampler(Sampler):
                                   'fraction_remain': fraction_remain, 'strategy': strategy,
                                   'expired_strategies': expired_strategies})
 
+        last_checkpoint = time.time()
         first_time = True
         get_samples = True
         nb = 0
@@ -339,7 +343,12 @@ class NestedSampler(Sampler):
                 it += 1
                 if primary:
                     self.trainer.writer.add_scalar('logz', logz, it)
-                if it > 0 and it % log_interval == 0 and primary:
+                # checkpoint cadence as the reference (every log_interval accepted points, nested.py:473-485), but at
+                # most one full dump per `checkpoint_min_seconds`: the dump rewrites every dead point (and chain.txt
+                # as text), which is O(n^2) over a run and dominated the wall clock of long GPU runs
+                if (it > 0 and it % log_interval == 0 and primary
+                        and time.time() - last_checkpoint >= self.checkpoint_min_seconds):
+                    last_checkpoint = time.time()
                     self.samples = np.array(saved_v)
                     self.weights = np.exp(np.array(saved_logwt) - logz)
                     self.loglikes = np.array(saved_logl)

@@ -180,6 +180,7 @@ class Sampler(object):
 
         # can the whole proposal loop run inside the HIP kernel?
         self._fused_like_id = None
+        self._fused_like_params = ()
         if fused:
             self._fused_like_id = self._fused_eligibility()
 
@@ -196,7 +197,8 @@ class Sampler(object):
         # verify the kernel's likelihood against the host callable on a few points before trusting it
         from . import flow
         x = np.random.RandomState(4321).uniform(-1, 1, size=(32, self.x_dim)).astype(np.float32)
-        dev = flow.loglike(like_id, x, self._linear_scale, device=netG.device).cpu().numpy()
+        self._fused_like_params = tuple(getattr(like, 'hip_like_params', ()) or ())
+        dev = flow.loglike(like_id, x, self._linear_scale, device=netG.device, like_params=self._fused_like_params).cpu().numpy()
         host = np.asarray(like(self._linear_scale * x.astype(np.float64)), dtype=np.float64)
         if not np.allclose(dev, host, rtol=1e-5, atol=1e-4):
             self.logger.warning('fused likelihood id %d disagrees with the host callable; using the host protocol' % like_id)
@@ -251,7 +253,7 @@ class Sampler(object):
         z0 = z.clone()
         res = netG.mh_steps(self._fused_like_id, self._linear_scale, z, logl, float(loglstar), float(step_size),
                             int(mcmc_steps), dynamic=dynamic, seed=self._next_seed() if seed is None else seed,
-                            walker_offset=walker_offset, history=self.mcmc_history)
+                            walker_offset=walker_offset, history=self.mcmc_history, like_params=self._fused_like_params)
         ncall = int(res['n_call'].sum().item())
         nacc = int(res['n_accept'].sum().item())
         self.total_calls += ncall

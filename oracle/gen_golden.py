@@ -11,6 +11,7 @@ Fixture families:
                       (nnest/networks.py:24-42, :71-76, :289-309; nnest/trainer.py:247-301)
   G2 like_*.npz       Rosenbrock / GaussianMix / Himmelblau through safe_loglike
                       (nnest/likelihoods.py:51, :70, :182-189; nnest/sampler.py:110-133)
+  G2b like2.npz      Gaussian / Eggbox / GaussianShell / DoubleGaussianShell (nnest/likelihoods.py:77-150)
   G3 prior.npz        UniformPrior box flags through safe_prior (nnest/priors.py:39-43)
   G4 train_*.npz      Trainer._train minibatch steps with recorded shuffle + jitter noise,
                       every gradient, post-Adam weights and moments (nnest/trainer.py:384-418)
@@ -38,7 +39,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from nnest.trainer import Trainer  # noqa: E402
 from nnest.nested import NestedSampler  # noqa: E402
-from nnest.likelihoods import Rosenbrock, GaussianMix, Himmelblau  # noqa: E402
+from nnest.likelihoods import Rosenbrock, GaussianMix, Himmelblau, Gaussian, Eggbox, GaussianShell, DoubleGaussianShell  # noqa: E402
 from nnest.priors import UniformPrior  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
@@ -144,6 +145,37 @@ def gen_like():
     shutil.rmtree(tmp, ignore_errors=True)
     np.savez_compressed(os.path.join(OUT, 'prior.npz'), x=x, flag64=flags64, flag32=flags32)
     print('G3 prior in-box', int(np.sum(flags64 == 0)), 'of', len(x))
+
+
+def gen_like2():
+    """G2b: the remaining analytic likelihoods (nnest/likelihoods.py:77-150) through safe_loglike"""
+    specs = [('gaussian', lambda D: Gaussian(D, 0.99, lim=3), 3.0, [2, 5, 20], (0.99,)),
+             ('gaussian_c0', lambda D: Gaussian(D, 0.3), 3.0, [4], (0.3,)),
+             ('eggbox', lambda D: Eggbox(D), float(5 * np.pi), [2], ()),
+             ('shell', lambda D: GaussianShell(D), 5.0, [2, 10], (0.1, 2, 0)),
+             ('shell_c', lambda D: GaussianShell(D, sigma=0.3, rshell=1.5, center=1), 5.0, [3], (0.3, 1.5, 1)),
+             ('double_shell', lambda D: DoubleGaussianShell(D), 6.0, [2, 5], (0.1, 2, -4, 0.1, 2, 4))]
+    out = {}
+    for name, mk, scale, dims, params in specs:
+        for D in dims:
+            np.random.seed(200 + D)
+            like = mk(D)
+            x64 = np.random.uniform(-1, 1, size=(64, D))
+            x32 = x64.astype(np.float32)
+            tmp = tempfile.mkdtemp()
+            s = NestedSampler(D, like, transform=lambda x, s=scale: s * x, log_dir=tmp, flow='nvp',
+                              num_live_points=10, log_level=logging.WARNING)
+            l64, _ = s.loglike(x64)
+            l32, _ = s.loglike(x32)
+            shutil.rmtree(tmp, ignore_errors=True)
+            key = '%s_d%d' % (name, D)
+            out[key + '_x64'] = x64
+            out[key + '_l64'] = np.asarray(l64, dtype=np.float64)
+            out[key + '_l32'] = np.asarray(l32, dtype=np.float64)
+            out[key + '_scale'] = scale
+            out[key + '_params'] = np.asarray(params, dtype=np.float64)
+            print('G2b', key, np.asarray(l32).dtype, l64[:2], l32[:2])
+    np.savez_compressed(os.path.join(OUT, 'like2.npz'), **out)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -350,11 +382,13 @@ def gen_nested():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['flow', 'like', 'train', 'trainrun', 'mcmc', 'nested']
+    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested']
     if 'flow' in which:
         gen_flow()
     if 'like' in which:
         gen_like()
+    if 'like2' in which:
+        gen_like2()
     if 'train' in which:
         gen_train_steps()
     if 'trainrun' in which:

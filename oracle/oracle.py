@@ -14,7 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, '_build', 'libnnest_oracle.so')
 
-LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'mixture': 1, 'gaussianmix': 1, 'himmelblau': 2}
+LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'mixture': 1, 'gaussianmix': 1, 'himmelblau': 2, 'gaussian': 3,
+            'eggbox': 4, 'shell': 5, 'double_shell': 6}
 
 
 def build(force=False):
@@ -177,13 +178,20 @@ class NVP(object):
                     best_validation_epoch=best_epoch, epochs_run=len(tl))
 
 
-def loglike(name, x_unit, scale):
+def loglike(name, x_unit, scale, params=None):
     """safe_loglike(x) = loglike(transform(x)) (nnest/sampler.py:110-133; nnest/likelihoods.py).
     float32 input follows the reference's float32 arithmetic, float64 input its float64 arithmetic."""
     lid = LIKE_IDS[name.lower()]
     x = np.atleast_2d(x_unit)
     N, D = x.shape
     out = np.empty(N)
+    if lid >= 3:
+        par = np.zeros(6)
+        par[:len(params or ())] = params or ()
+        xi = _f64(x)
+        lib().orc_loglike2_batch(lid, _p(xi, _dp), N, D, ctypes.c_double(scale), _p(par, _dp),
+                                 int(x.dtype == np.float32), _p(out, _dp))
+        return out
     if x.dtype == np.float32:
         xi = _f32(x)
         lib().orc_loglike_batch_f32(lid, _p(xi, _fp), N, D, ctypes.c_float(scale), _p(out, _dp))

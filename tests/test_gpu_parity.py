@@ -105,6 +105,28 @@ def test_likelihoods_vs_golden(hip):
         np.testing.assert_allclose(got, exact, rtol=1e-6, atol=1e-5)
 
 
+def test_likelihoods_second_set_vs_golden(hip):
+    """Gaussian / Eggbox / GaussianShell / DoubleGaussianShell in the fused kernels vs the reference's values on
+    float32 inputs (what _mcmc_sample would compute) and vs the host protocol classes."""
+    from nnest_amd import likelihoods as L
+    g = np.load(os.path.join(G, 'like2.npz'))
+    keys = sorted(set(k[:-4] for k in g.files if k.endswith('_x64')))
+    host = {'gaussian': lambda D, p: L.Gaussian(D, p[0]), 'eggbox': lambda D, p: L.Eggbox(D),
+            'shell': lambda D, p: L.GaussianShell(D, sigma=p[0], rshell=p[1], center=p[2]),
+            'double_shell': lambda D, p: L.DoubleGaussianShell(D, sigmas=(p[0], p[3]), rshells=(p[1], p[4]), centers=(p[2], p[5]))}
+    for key in keys:
+        name = key.split('_d')[0].replace('_c0', '').replace('shell_c', 'shell')
+        D = int(key.split('_d')[-1])
+        x32 = g[key + '_x64'].astype(np.float32)
+        scale, params = float(g[key + '_scale']), tuple(g[key + '_params'])
+        got = cpu(hip.loglike(hip._lib.LIKE_IDS[name], x32, scale, like_params=params))
+        # float64 moments of the float32 inputs; the Gaussian with corr 0.99 amplifies input rounding by 1/(1-c)
+        np.testing.assert_allclose(got, g[key + '_l32'], rtol=3e-6, atol=1e-6)
+        obj = host[name](D, params)
+        assert obj.hip_like_id == hip._lib.LIKE_IDS[name]
+        np.testing.assert_allclose(obj(scale * g[key + '_x64']), g[key + '_l64'], rtol=1e-10, atol=1e-9)
+
+
 def test_fused_inverse_prior_loglike_vs_oracle(hip):
     g = np.load(os.path.join(G, 'mcmc_rosen_d50.npz'))
     nvp = hip.HipNVP(50, 16, 3, 1)

@@ -78,7 +78,8 @@ def test_nested_resume_from_checkpoint(tmp_path):
     np.random.seed(1)
     torch.manual_seed(1)
     like = Rosenbrock(2)
-    kw = dict(transform=lambda x: 5 * x, log_dir=str(tmp_path), num_live_points=100, log_level=30, append_run_num=False)
+    kw = dict(transform=lambda x: 5 * x, log_dir=str(tmp_path), num_live_points=100, log_level=30, append_run_num=False,
+              checkpoint_min_seconds=0.0)
     s = NestedSampler(2, like, trainer=OracleTrainer(2, seed=1), **kw)
     s.run(train_iters=50, mcmc_num_chains=10, max_iters=150, strategy=['mcmc'])
     cps = sorted(int(f.split('_')[1].split('.')[0]) for f in os.listdir(os.path.join(str(tmp_path), 'checkpoint'))

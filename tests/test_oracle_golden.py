@@ -64,6 +64,23 @@ def test_likelihoods():
             assert np.array_equal(l32.astype(np.float32), g[key + '_l32'].astype(np.float32)), key
 
 
+def test_likelihoods_second_set():
+    """Gaussian / Eggbox / GaussianShell / DoubleGaussianShell (likelihoods.py:77-150)"""
+    g = np.load(os.path.join(G, 'like2.npz'))
+    keys = sorted(set(k[:-4] for k in g.files if k.endswith('_x64')))
+    assert len(keys) == 10
+    for key in keys:
+        name = key.split('_d')[0].replace('_c0', '').replace('shell_c', 'shell')
+        x64, scale, params = g[key + '_x64'], float(g[key + '_scale']), tuple(g[key + '_params'])
+        l64 = orc.loglike(name, x64, scale, params)
+        # closed form for the equicorrelated Gaussian vs scipy's Cholesky with corr = 0.99 (1/(1-c) = 100 amplifies
+        # rounding): 1e-10 relative; everything else is the same float64 formula
+        np.testing.assert_allclose(l64, g[key + '_l64'], rtol=1e-10, atol=1e-9)
+        l32 = orc.loglike(name, x64.astype(np.float32), scale, params)
+        tol = 2e-6 if name == 'eggbox' else 1e-10  # eggbox: float32 cos of numpy vs libm
+        np.testing.assert_allclose(l32, g[key + '_l32'], rtol=tol, atol=1e-9)
+
+
 def test_prior_box():
     g = np.load(os.path.join(G, 'prior.npz'))
     assert np.array_equal(orc.prior_inbox(g['x']), g['flag64'])

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) step_kernel(const float *gimg, FlowShape 
         bool pre = ok && u < ratio;
         double lp = 0;
         if (LIKE) {
-            if (F64LIKE) lp = loglike_tile<NT>(0, 5.0f, D, lane, xp);
+            if (F64LIKE) { LikeSpec lk; lk.id = 0; lk.scale = 5.0f; lp = loglike_tile<NT>(lk, D, lane, xp); }
             else {
                 float ss = 0.f;
                 for (int c = 0; c < 2; ++c) for (int t = 0; t < NT; ++t) ss += xp[c][t].x * xp[c][t].y + xp[c][t].z * xp[c][t].w;
