@@ -28,6 +28,7 @@ import torch  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
+MEASURED_TRAFFIC_BYTES = int((439.2 + 1384.7) * 1024)  # profiles/r01b/bench_pmc_summary.txt, per K4 launch
 
 
 def useful_flops_per_eval(D, H, B, L):
@@ -101,11 +102,6 @@ def main():
     loglstar = float(logl0.min())
     step_size = 1.0 / np.sqrt(D)
 
-    def one_step(k):
-        z = z0.clone()
-        logl = logl0.clone()
-        return z, logl
-
     # state buffers are re-seeded outside the timed launches (clone is not part of the hot path)
     zs = [z0.clone() for _ in range(args.steps + args.warmup)]
     ls = [logl0.clone() for _ in range(args.steps + args.warmup)]
@@ -157,8 +153,13 @@ def main():
                        'walkers_per_gpu': C, 'mcmc_steps': S, 'evals_per_step': evals_per_launch,
                        'parallelism': 'walker-sharded x%d, no data-path collective' % world},
             'roofline': {'bound': 'mfma', 'achieved': achieved_tflops, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved_tflops / FP32_PEAK_TFLOPS, 'traffic': None,
-                         'kernel': 'mh_kernel', 'kernel_ms': kern_ms, 'flops_per_eval': fl,
+                         'frac': achieved_tflops / FP32_PEAK_TFLOPS,
+                         # HBM bytes per launch from the committed rocprofv3 PMC passes of this command
+                         # (profiles/r01b/bench_pmc_summary.txt: FETCH_SIZE 439.2 KiB + WRITE_SIZE 1384.7 KiB, raw); only
+                         # valid for the default workload, null otherwise
+                         'traffic': MEASURED_TRAFFIC_BYTES if (D, C, S) == (50, 1000, 250) else None,
+                         'kernel': 'mh_kernel_team' if (C + 15) // 16 <= info['num_cu'] else 'mh_kernel',
+                         'kernel_ms': kern_ms, 'flops_per_eval': fl,
                          'hbm_frac_if_streamed': evals_per_launch * alg_bytes_per_eval(D) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          'note': 'f32-input MFMA peak (= f32 vector peak); %d walker tiles on %d CUs: occupancy-limited '
                                  'at this population' % ((C + 15) // 16, info['num_cu'])},
