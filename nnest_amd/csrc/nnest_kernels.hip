@@ -81,6 +81,7 @@ struct PassArgs {
     double *logl;
     int *inbox;
     int N;
+    int waves_active;  // waves per workgroup that own tiles; the remaining waves only help stage the image
     LikeSpec like;
 };
 
@@ -92,9 +93,10 @@ __global__ void __launch_bounds__(256) flow_pass_kernel(PassArgs a) {
         stage_image(lds_img, a.img, a.s.image_floats);
         img = lds_img;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = a.waves_active;
     const int ntiles = (a.N + 15) >> 4;
     const int w = lane & 15, g = lane >> 4;
+    if (wave >= wpb) return;  // staging helper only (a lone wave needs ~10 us to pull a 32 KB image into LDS)
     for (int tile = blockIdx.x * wpb + wave; tile < ntiles; tile += gridDim.x * wpb) {
         const int row = tile * 16 + w;
         const bool ok = row < a.N;
@@ -607,10 +609,13 @@ static void pick_geometry(int ntiles, int num_cu, int max_wpb, int *block, int *
 }
 
 template <int NT, int NH, int LT>
-static hipError_t launch_pass_t(const PassArgs &a, int num_cu, hipStream_t st) {
-    const int ntiles = (a.N + 15) / 16;
+static hipError_t launch_pass_t(const PassArgs &a_in, int num_cu, hipStream_t st) {
+    const int ntiles = (a_in.N + 15) / 16;
     int block, grid;
     pick_geometry(ntiles, num_cu, 4, &block, &grid);  // flow_pass_kernel: __launch_bounds__(256)
+    PassArgs a = a_in;
+    a.waves_active = block / 64;
+    block = 256;  // always four waves to stage the image; waves_active of them own tiles
     const size_t img_bytes = (size_t)a.s.image_floats * 4;
     // grid-stride over tiles once there are more than ~8 workgroups per CU (amortises the LDS staging)
     if (grid > 8 * num_cu) grid = 8 * num_cu;

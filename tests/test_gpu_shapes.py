@@ -1,0 +1,203 @@
+"""GPU parity over the shapes and edge cases around the default configuration: every instantiated
+(x_dim tile count, hidden width, depth) of the flow, proposal and training kernels against the oracle; empty,
+single-row and maximum sizes; NaN rows.  Run with  pytest -m gpu."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+from oracle import oracle as orc  # noqa: E402  (checker only)
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b))))
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from nnest_amd import flow
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: the -m gpu tests must run on an MI355X')
+    return flow
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def make(hip, D, H, B, L, seed=0):
+    nvp = hip.HipNVP(D, H, B, L, seed=seed)
+    w = nvp.store_packed()
+    # larger weights than the default init so that the layers are far from linear
+    w = (w * 1.7).astype(np.float32)
+    nvp.load_packed(w)
+    return nvp, orc.NVP(D, H, B, L, w)
+
+
+SHAPES = [(1, 16, 3, 1), (2, 16, 3, 1), (31, 16, 3, 1), (33, 16, 3, 1), (64, 16, 3, 1), (65, 16, 3, 1), (97, 16, 2, 1),
+          (128, 16, 3, 1), (10, 16, 4, 0), (10, 16, 3, 2), (40, 16, 3, 3), (9, 32, 3, 1), (64, 32, 2, 2), (20, 64, 5, 1),
+          (32, 64, 2, 2)]
+
+
+@pytest.mark.parametrize('D,H,B,L', SHAPES, ids=['D%d_H%d_B%d_L%d' % s for s in SHAPES])
+def test_flow_every_instantiated_shape(hip, D, H, B, L):
+    nvp, o = make(hip, D, H, B, L)
+    rng = np.random.RandomState(D)
+    x = rng.uniform(-1, 1, size=(53, D)).astype(np.float32)
+    # yardstick: the float64 oracle; allowance: a few times what the float32 ORACLE itself is off by on this input
+    # (a stiff random flow amplifies float32 rounding, most of all through the inverse), floor 3e-5
+    z, ld = nvp.forward(x)
+    z64, ld64 = o.forward(x, f64=True)
+    z32, ld32 = o.forward(x)
+    tol = max(3e-5, 5 * rel(z32, z64), 5 * rel(ld32, ld64))
+    assert rel(cpu(z), z64) < tol and rel(cpu(ld), ld64) < tol
+    zin = z32
+    xi, ldi = nvp.inverse(zin)
+    x64, ldi64 = o.inverse(zin, f64=True)
+    x32, ldi32 = o.inverse(zin)
+    tol = max(3e-5, 5 * rel(x32, x64), 5 * rel(ldi32, ldi64))
+    assert rel(cpu(xi), x64) < tol and rel(cpu(ldi), ldi64) < tol
+    lp64 = o.log_probs(x, f64=True)
+    assert rel(cpu(nvp.log_probs(x)), lp64) < max(5e-5, 5 * rel(o.log_probs(x), lp64))
+    xr, _ = nvp.inverse(z)
+    assert abs(float(torch.max(xr - torch.from_numpy(x).cuda()))) <= 1e-5  # reference tests/test_flows.py:27-30
+
+
+def test_unsupported_shapes_fail_loudly(hip):
+    from nnest_amd import _lib
+    for D, H in [(129, 16), (65, 32), (33, 64), (10, 24), (10, 128)]:
+        with pytest.raises(_lib.NnestHipError):
+            hip.HipNVP(D, H, 3, 1)
+
+
+MH_SHAPES = [(2, 16, 3, 1), (20, 16, 3, 1), (50, 16, 3, 1), (70, 16, 3, 1), (100, 16, 3, 1), (10, 16, 4, 0), (10, 16, 3, 2),
+             (12, 32, 3, 1), (8, 64, 2, 1), (50, 16, 5, 1)]
+
+
+@pytest.mark.parametrize('D,H,B,L', MH_SHAPES, ids=['D%d_H%d_B%d_L%d' % s for s in MH_SHAPES])
+def test_mh_every_kernel_form_and_shape_vs_oracle(hip, D, H, B, L):
+    """C = 40 walkers -> team form where it exists (H 16, B 3, L 1, x_dim <= 64), image form otherwise."""
+    nvp, o = make(hip, D, H, B, L, seed=1)
+    rng = np.random.RandomState(D + H)
+    C, S = 40, 12
+    init = rng.uniform(-0.6, 0.6, size=(C, D))
+    init_logl = orc.loglike('rosenbrock', init, 5.0)
+    dz, u = nvp.fill_noise(S, C, seed=5)
+    z, _ = nvp.forward(init)
+    logl = torch.from_numpy(init_logl).cuda()
+    res = nvp.mh_steps(0, 5.0, z, logl, -1e12, 0.05, S, seed=5, history=True, dynamic=True)
+    bad = 0
+    for g0 in range(0, C, 16):
+        sl = slice(g0, min(g0 + 16, C))
+        so, _, lo, sc, ncall, (acc, rej) = orc.mcmc_sample(o, 'rosenbrock', 5.0, init[sl], init_logl[sl], -1e12, 0.05, True,
+                                                           cpu(dz)[:, sl], cpu(u)[:, sl])
+        if int(res['n_call'][sl].sum()) == ncall and int(res['n_accept'][sl].sum()) == acc:
+            assert rel(cpu(res['hist_x'])[sl], so) < 3e-4   # stiff random flow: float32 rounding amplified by the inverse
+            # logL ~ 1e4 with |dlogL/dx| ~ 1e4..1e5: compare relative to the chain's logL scale
+            hl = cpu(res['hist_logl'])[sl]
+            assert np.max(np.abs(hl - lo)) < 2e-3 * (1.0 + np.max(np.abs(lo)))
+        else:
+            bad += 1  # a borderline decision flipped by float32 rounding
+    assert bad <= 1
+    # production instantiation (no history) lands on the same final state as the diagnostic one
+    z2, _ = nvp.forward(init)
+    logl2 = torch.from_numpy(init_logl).cuda()
+    res2 = nvp.mh_steps(0, 5.0, z2, logl2, -1e12, 0.05, S, seed=5, dynamic=True)
+    assert torch.equal(z2, z) and torch.equal(logl2, logl) and torch.equal(res2['x'], res['x'])
+    assert torch.equal(res2['n_accept'], res['n_accept']) and torch.equal(res2['n_call'], res['n_call'])
+
+
+def test_mh_degenerate_sizes(hip):
+    nvp, o = make(hip, 50, 16, 3, 1)
+    rng = np.random.RandomState(0)
+    init = rng.uniform(-0.5, 0.5, size=(1, 50))
+    l0 = orc.loglike('rosenbrock', init, 5.0)
+    # steps = 0: state untouched, x = f^-1(z)
+    z, _ = nvp.forward(init)
+    z0 = z.clone()
+    logl = torch.from_numpy(l0).cuda()
+    res = nvp.mh_steps(0, 5.0, z, logl, -1e12, 0.1, 0)
+    assert torch.equal(z, z0) and float(logl[0]) == l0[0] and int(res['n_call'][0]) == 0
+    xo, _ = o.inverse(cpu(z0))
+    assert rel(cpu(res['x']), xo) < 3e-5
+    # one walker, many steps: accepted moves satisfy the constraint and the box
+    res = nvp.mh_steps(0, 5.0, z, logl, float(l0[0]) - 5e3, 0.003, 400, seed=3)
+    assert int(res['n_accept'][0]) > 0 and float(logl[0]) > l0[0] - 5e3
+    assert float(res['x'].abs().max()) <= 1.0
+    np.testing.assert_allclose(orc.loglike('rosenbrock', cpu(res['x']), 5.0), cpu(logl), rtol=2e-6, atol=1e-5)
+    # zero walkers
+    ze = torch.empty(0, 50, device='cuda')
+    le = torch.empty(0, dtype=torch.float64, device='cuda')
+    nvp.mh_steps(0, 5.0, ze, le, 0.0, 0.1, 5)
+
+
+def test_hard_constraint_is_respected_for_every_walker(hip):
+    """loglstar above every start: a walker may only move to logL > L*; with L* = max start nothing below it is kept."""
+    nvp, o = make(hip, 50, 16, 3, 1)
+    rng = np.random.RandomState(1)
+    init = rng.uniform(-1, 1, size=(500, 50))
+    l0 = orc.loglike('rosenbrock', init, 5.0)
+    lstar = float(np.median(l0))
+    z, _ = nvp.forward(init)
+    logl = torch.from_numpy(l0).cuda()
+    res = nvp.mh_steps(0, 5.0, z, logl, lstar, 0.05, 60, seed=9)
+    moved = cpu(res['n_accept']) > 0
+    lf = cpu(logl)
+    assert np.all(lf[moved] > lstar)
+    assert np.array_equal(lf[~moved], l0[~moved])
+    assert moved.sum() > 0
+    assert float(res['x'][torch.from_numpy(moved).cuda()].abs().max()) <= 1.0
+    assert np.all(cpu(res['n_call']) >= cpu(res['n_accept']))
+
+
+def test_nan_row_stays_contained(hip):
+    nvp, o = make(hip, 20, 16, 3, 1)
+    rng = np.random.RandomState(2)
+    x = rng.uniform(-1, 1, size=(40, 20)).astype(np.float32)
+    xb = x.copy()
+    xb[7, 3] = np.nan
+    z, ld = nvp.forward(xb)
+    zg, ldg = nvp.forward(x)
+    keep = np.arange(40) != 7
+    assert torch.equal(z[torch.from_numpy(keep).cuda()], zg[torch.from_numpy(keep).cuda()])
+    assert np.isnan(cpu(z)[7]).any() and np.isnan(cpu(ld)[7])
+
+
+TRAIN_SHAPES = [(2, 16, 3, 1), (50, 16, 3, 1), (100, 16, 3, 1), (10, 16, 4, 0), (10, 16, 3, 2), (12, 32, 3, 1), (40, 32, 2, 2),
+                (8, 64, 2, 1), (70, 16, 2, 1)]
+
+
+@pytest.mark.parametrize('D,H,B,L', TRAIN_SHAPES, ids=['D%d_H%d_B%d_L%d' % s for s in TRAIN_SHAPES])
+def test_loss_grad_every_instantiated_shape_vs_oracle(hip, D, H, B, L):
+    nvp, o = make(hip, D, H, B, L, seed=2)
+    rng = np.random.RandomState(D * 3 + L)
+    for M in (100, 37, 128, 1):
+        X = rng.uniform(-1, 1, size=(M, D)).astype(np.float32)
+        loss, grad = nvp.loss_grad(X)
+        lo, go = o.loss_grad(X, f64=True)
+        assert abs(float(loss) - lo) < 3e-5 * (1 + abs(lo))
+        assert np.max(np.abs(cpu(grad) - go)) < 1e-4 * (1e-3 + np.max(np.abs(go))), (M,)
+        assert np.all(cpu(grad)[go == 0] == 0)
+
+
+def test_train_epochs_generic_shape_vs_oracle(hip):
+    """Whole epochs (minibatches 100, 100, 50) on a non-default shape against the oracle's Trainer.train."""
+    D, H, B, L = 12, 32, 3, 1
+    nvp, o = make(hip, D, H, B, L, seed=4)
+    rng = np.random.RandomState(5)
+    live = rng.uniform(-1, 1, size=(278, D))
+    E = 4
+    split = rng.permutation(278)
+    n_valid = 28
+    perms = np.stack([rng.permutation(250) for _ in range(E)]).astype(np.int32)
+    noises = rng.normal(size=(E, 250, D)).astype(np.float32)
+    ro = o.train(live, split, perms, noises, 0.01, E, patience=50)
+    res = nvp.train_epochs(live[split[n_valid:]], live[split[:n_valid]], torch.from_numpy(perms), torch.from_numpy(noises),
+                           jitter=0.01, batch=100, max_epochs=E, patience=50)
+    losses = cpu(res['losses'])[:E]
+    np.testing.assert_allclose(losses[:, 0], ro['train_losses'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(losses[:, 1], ro['valid_losses'], rtol=2e-4, atol=2e-5)
+    assert res['best_epoch'] == ro['best_validation_epoch']
