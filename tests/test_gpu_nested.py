@@ -92,3 +92,46 @@ def test_config2_slice_rosenbrock_50d(tmp_path):
     assert 2 <= s.num_batches <= 12
     assert np.isfinite(s.logz) and s.ncall > 1000
     assert np.all(np.diff(s.loglikes[:1500]) >= 0)  # dead points leave in increasing likelihood order
+
+
+def test_user_callable_likelihood_runs_on_the_host_protocol(tmp_path):
+    """A plain Python `loglike` (the reference's plugin protocol, sampler.py:110-133) is not in the kernels: the flow
+    passes run on the GPU, the likelihood and the accept logic on the host (Sampler._mcmc_sample_host)."""
+    np.random.seed(3)
+    torch.manual_seed(3)
+
+    def rosen(x):  # x: (N, 2) already transformed
+        return -(100.0 * (x[:, 1] - x[:, 0] ** 2) ** 2 + (1 - x[:, 0]) ** 2)
+
+    s = NestedSampler(2, rosen, transform=lambda x: 5 * x, log_dir=str(tmp_path), num_live_points=300, log_level=30)
+    assert s._fused_like_id is None
+    s.run(mcmc_num_chains=20, train_iters=200)
+    assert abs(s.logz - LOGZ_ROSEN2D) <= 0.35, s.logz   # 300 live points: sqrt(h/N) ~ 0.13
+    assert s.total_calls > 300
+
+
+def test_trainer_chunked_launches_equal_one_launch(tmp_path):
+    """Trainer.train issues a long run as 128-epoch launches that carry the early-stopping state; with the same
+    split / shuffles / noise seed the result is bit-identical to a single launch (include/nnest_hip.h)."""
+    from nnest_amd.trainer import Trainer
+    from nnest_amd import trainer as trainer_mod
+    rng = np.random.RandomState(0)
+    D, N, E = 6, 220, 300
+    live = rng.normal(size=(N, D)) * 0.3
+    split = rng.permutation(N)
+    perms = np.stack([rng.permutation(N - 22) for _ in range(E)]).astype(np.int32)
+    outs = []
+    for chunk in (128, 1000):
+        trainer_mod.EPOCH_CHUNK = chunk
+        torch.manual_seed(7)
+        t = Trainer(D, log_dir=None, learning_rate=1e-3, seed=1, log_level=30)
+        t.train(live, max_iters=E, jitter=0.01, split=split, perms=perms, patience=40)
+        outs.append((t.netG.store_packed(), t.best_validation_epoch, t.best_validation_loss, t.total_iters, t.losses.copy()))
+    trainer_mod.EPOCH_CHUNK = 128
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1:4] == outs[1][1:4]
+    assert np.array_equal(outs[0][4], outs[1][4])
+    assert outs[0][3] <= E and outs[0][1] >= 1
+    # jitter < 0: the k-d tree rule of the reference (trainer.py:168-171), computed on the device
+    from oracle import oracle as orc
+    assert abs(t.training_jitter(live) - orc.training_jitter(live)) < 1e-12
