@@ -5,8 +5,8 @@ Metropolis proposals (Sampler._mcmc_sample -> nnest_mh_constrained_steps).
 Same constructor and run() keywords, same result attributes (logz, samples, weights, loglikes) and the same
 on-disk products (results/results.csv, results/final.csv, checkpoint/*.npy + checkpoint_<it>.txt,
 chains/chain.txt) as the reference.  Strategies: 'rejection_prior' and 'mcmc' (the reference default pair,
-nested.py:136-137); 'rejection_flow' / 'density_flow' are low-dimensional conveniences outside this build's
-scope and raise.
+nested.py:136-137), and the low-dimensional 'rejection_flow' / 'density_flow' (nested.py:336-360), which examine
+a block of candidates per flow launch instead of one.
 
 Multi-GPU (torch.distributed, one process per GPU): the live set and the evidence state are replicated on
 every rank; rank 0 draws all host-side randomness and broadcasts it; each MCMC batch is sharded over ranks
@@ -137,8 +137,9 @@ class NestedSampler(Sampler):
         if strategy is None or len(strategy) == 0:
             strategy = ['rejection_prior', 'mcmc']
         for s in strategy:
-            if s not in ('rejection_prior', 'mcmc'):
-                raise NotImplementedError("strategy %r: this build implements 'rejection_prior' and 'mcmc'" % s)
+            if s not in ('rejection_prior', 'rejection_flow', 'density_flow', 'mcmc'):
+                raise NotImplementedError("strategy %r: this build implements 'rejection_prior', 'rejection_flow', "
+                                          "'density_flow' and 'mcmc'" % s)
         expired_strategies = []
         current_method = ''
         N = self.num_live_points
@@ -248,16 +249,24 @@ class NestedSampler(Sampler):
                 self.num_retrains += 1
                 first_time = False
 
-            if current_method == 'rejection_prior':          # nested.py:322-334, :375-396
+            if current_method in ('rejection_prior', 'rejection_flow', 'density_flow'):   # nested.py:322-396
                 if get_samples:
                     nb = 0
                     if primary:
-                        s_x, s_l, s_d, nc = self._rejection_prior_sample(loglstar, num_trials=rejection_trials)
+                        if current_method == 'rejection_prior':
+                            s_x, s_l, s_d, nc = self._rejection_prior_sample(loglstar, num_trials=rejection_trials)
+                        elif current_method == 'rejection_flow':     # nested.py:336-341
+                            s_x, s_l, s_d, nc = self._rejection_flow_sample(
+                                active_u, loglstar, enlargement_factor=rejection_enlargement_factor,
+                                # as the reference: the envelope is REcomputed unless this flag is set (sampler.py:563-569)
+                                cache=it % rejection_cache_interval == 0 or it % update_interval == 0)
+                        else:                                        # nested.py:350-352
+                            s_x, s_l, s_d, nc = self._density_sample(loglstar)
                         pack = np.concatenate([np.ravel(s_x), np.ravel(s_l), [float(nc), float(len(np.ravel(s_l)))]])
                     else:
                         pack = None
                     if self.use_mpi:
-                        n_rows = rejection_trials if rejection_trials else 1
+                        n_rows = rejection_trials if (rejection_trials and current_method == 'rejection_prior') else 1
                         if not primary:
                             pack = np.empty(n_rows * (self.x_dim + 1) + 2)
                         pack = self._broadcast(pack)
@@ -269,12 +278,17 @@ class NestedSampler(Sampler):
                     samples, loglikes, derived_samples = np.atleast_2d(s_x), np.ravel(s_l), s_d
                     ncs.append(nc)
                     mean_calls = np.mean(ncs[-20:]) if len(ncs) > 20 else 0
-                    if expected_vol < volume_switch >= 0 or \
-                            (volume_switch < 0 and mean_calls > mcmc_steps and 'mcmc' in strategy
-                             and 'mcmc' not in expired_strategies):
+                    mcmc_valid = 'mcmc' in strategy and 'mcmc' not in expired_strategies
+                    if current_method == 'rejection_prior':
+                        expire = expected_vol < volume_switch >= 0 or (volume_switch < 0 and mean_calls > mcmc_steps
+                                                                       and mcmc_valid)
+                    else:                                            # nested.py:344-347, :355-358
+                        expire = mean_calls > mcmc_steps and mcmc_valid
+                    if expire:
                         if primary:
-                            self.logger.info('Rejection prior no longer efficient, switching sampling method')
-                        expired_strategies.append('rejection_prior')
+                            self.logger.info('%s no longer efficient, switching sampling method'
+                                             % current_method.replace('_', ' ').capitalize())
+                        expired_strategies.append(current_method)
                         ncs = []
                 for ib in range(nb, samples.shape[0]):
                     nb += 1

@@ -374,6 +374,90 @@ class Sampler(object):
             ncall = num_trials / np.sum(logl > loglstar)
         return x, logl, derived, ncall
 
+    # ---- flow rejection (sampler.py:545-605) and density sampling (sampler.py:607-628) ----------------------------
+    # The reference draws one candidate, inverts it, tests it, and loops.  Candidates are independent, so the same
+    # chain of decisions is taken here over a block of candidates per launch: candidates are examined in order, the
+    # first that passes every test is returned, and `ncall` counts -- as the reference does -- the candidates that
+    # reached the likelihood test (box prior and Jacobian envelope passed) up to and including the accepted one.
+    def _candidate_block(self, z):
+        """x, log|dx/dz|, logl for a block of latent candidates; logl is None when the likelihood is a host callable."""
+        netG = self.trainer.netG
+        if self._fused_like_id is not None:
+            x, ld, logl, inbox = netG.inverse_loglike(self._fused_like_id, self._linear_scale, z,
+                                                      like_params=self._fused_like_params)
+            return x.cpu().numpy().astype(np.float64), ld.cpu().numpy().astype(np.float64), logl.cpu().numpy(), \
+                inbox.cpu().numpy().astype(bool)
+        x, ld = netG.inverse(z)
+        x = x.cpu().numpy().astype(np.float64)
+        return x, ld.cpu().numpy().astype(np.float64), None, self.prior(x) > -1e30
+
+    def _first_accepted(self, x, passed, logl, loglstar, strict):
+        """Walk the candidates that passed the cheap tests in order; returns (index or None, likelihood calls made)."""
+        idx = np.where(passed)[0]
+        if logl is not None:                       # likelihood already evaluated in the launch
+            good = logl[idx] > loglstar if strict else ~(np.isfinite(logl[idx]) & (logl[idx] < loglstar))
+            hit = np.where(good)[0]
+            if len(hit) == 0:
+                self.total_calls += len(idx)
+                return None, len(idx), None, None
+            self.total_calls += int(hit[0]) + 1
+            j = idx[hit[0]]
+            return j, int(hit[0]) + 1, logl[j:j + 1], np.empty((1, 0))
+        calls = 0
+        for lo in range(0, len(idx), 16):          # host callable: evaluate in small groups, stop at the first hit
+            grp = idx[lo:lo + 16]
+            lg, dg = self.loglike(x[grp])
+            good = lg > loglstar if strict else ~(np.isfinite(lg) & (lg < loglstar))
+            hit = np.where(good)[0]
+            if len(hit) > 0:
+                return grp[hit[0]], calls + int(hit[0]) + 1, lg[hit[0]:hit[0] + 1], dg[hit[0]:hit[0] + 1]
+            calls += len(grp)
+        return None, calls, None, None
+
+    def _rejection_flow_sample(self, init_samples, loglstar, enlargement_factor=1.1, constant_efficiency_factor=None,
+                               cache=False, block=256):
+        netG = self.trainer.netG
+
+        def get_cache():
+            z, log_det_J = netG.forward(init_samples)
+            # envelope for the rejection step: max log|dx/dz| over the live points (sampler.py:556-561)
+            self.max_log_det_J = enlargement_factor * float(torch.max(-log_det_J).item())
+            self.max_r = float(np.max(np.linalg.norm(z.cpu().numpy(), axis=1)))
+
+        if not cache or not hasattr(self, 'max_log_det_J'):
+            get_cache()
+        if constant_efficiency_factor is not None:
+            enlargement_factor = (1 / constant_efficiency_factor) ** (1 / self.x_dim)
+        ncall = 0
+        while True:
+            # uniform in the ball of radius enlargement * max_r (sampler.py:579-583)
+            z = np.random.randn(block, self.x_dim)
+            r = enlargement_factor * self.max_r * np.random.rand(block) ** (1. / self.x_dim)
+            z = z * (r / np.sqrt(np.sum(z ** 2, axis=1)))[:, None]
+            rnd_u = np.random.rand(block)
+            x, ld, logl, inbox = self._candidate_block(z)
+            with np.errstate(over='ignore', invalid='ignore'):
+                ratio = np.minimum(np.exp(ld - self.max_log_det_J), 1.0)
+            # first test (sampler.py:593-597): Jacobian envelope; the second (sampler.py:599-604) zeroes the ratio
+            # where logl is finite and below loglstar and repeats rnd_u < ratio
+            passed = inbox & (rnd_u < ratio)
+            j, calls, lj, dj = self._first_accepted(x, passed, logl, loglstar, strict=False)
+            ncall += calls
+            if j is not None:
+                return x[j:j + 1], lj, dj, ncall
+            block = min(4 * block, 65536)
+
+    def _density_sample(self, loglstar, block=256):
+        ncall = 0
+        while True:
+            z = self.trainer.get_prior_samples(block)
+            x, ld, logl, inbox = self._candidate_block(z)
+            j, calls, lj, dj = self._first_accepted(x, inbox, logl, loglstar, strict=True)
+            ncall += calls
+            if j is not None:
+                return x[j:j + 1], lj, dj, ncall
+            block = min(4 * block, 65536)
+
     # ---- chain files (sampler.py:494-527): getdist text format "weight -logL params..." ------------------------
     def _save_samples(self, samples, loglikes, weights=None, derived_samples=None, min_weight=1e-30, outfile='chain'):
         if self.logs is None:

@@ -135,3 +135,25 @@ def test_trainer_chunked_launches_equal_one_launch(tmp_path):
     # jitter < 0: the k-d tree rule of the reference (trainer.py:168-171), computed on the device
     from oracle import oracle as orc
     assert abs(t.training_jitter(live) - orc.training_jitter(live)) < 1e-12
+
+
+@pytest.mark.parametrize('strategy', [['rejection_prior', 'rejection_flow', 'mcmc'], ['rejection_prior', 'density_flow', 'mcmc'],
+                                      ['rejection_flow']])
+def test_flow_rejection_strategies(tmp_path, strategy):
+    """'rejection_flow' (sampler.py:545-605) and 'density_flow' (sampler.py:607-628): blocks of candidates per launch;
+    the evidence must come out the same as with the default strategy pair."""
+    s = run(tmp_path, 2, Rosenbrock(2), 5.0, 400, 11, strategy=strategy, mcmc_num_chains=40, train_iters=300)
+    assert abs(s.logz - LOGZ_ROSEN2D) <= 0.3, s.logz       # sqrt(h/N) ~ 0.11
+    assert s.num_retrains >= 1
+
+
+def test_flow_rejection_with_host_likelihood(tmp_path):
+    np.random.seed(5)
+    torch.manual_seed(5)
+    s = NestedSampler(2, lambda x: -(100.0 * (x[:, 1] - x[:, 0] ** 2) ** 2 + (1 - x[:, 0]) ** 2), transform=lambda x: 5 * x,
+                      log_dir=str(tmp_path), num_live_points=200, log_level=30)
+    assert s._fused_like_id is None
+    s.run(strategy=['rejection_prior', 'rejection_flow'], train_iters=200, max_iters=900)
+    x, logl, derived, ncall = s._density_sample(float(np.median(s.loglikes[-200:])))
+    assert x.shape == (1, 2) and logl.shape == (1,) and ncall >= 1 and logl[0] > np.median(s.loglikes[-200:])
+    assert np.isfinite(s.logz)
