@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 2
+#define NNEST_HIP_ABI_VERSION 3
 
 enum {
     NNEST_OK = 0,
@@ -72,6 +72,14 @@ int nnest_hip_device_info(int *num_cu, int *clock_khz, char *name, int name_len)
 /* SingleSpeedNVP(num_inputs=D, num_hidden=H, num_blocks=B, num_layers=L) -- networks.py:328-347.
  * Allocates device storage for the packed weights, Adam moments and the MFMA-fragment image. */
 int nnest_nvp_create(int D, int H, int B, int L, nnest_nvp_t **out);
+/* SingleSpeedNVP(..., scale=) -- networks.py:328-347: '' (full affine coupling), 'translate'
+ * (CouplingLayer(translate_only=True), networks.py:293-294, :304-305) or 'constant' (translate-only couplings, each
+ * followed by a ScaleLayer, networks.py:312-325: y = x e^s, logdet += s).
+ * Packed layout for every mode: the B blocks as for '' (scale_net then translate_net); with 'translate' and
+ * 'constant' the scale_net slots are unused -- forced to zero on load, never given a gradient -- and with
+ * 'constant' the B ScaleLayer scalars follow the blocks (nnest_nvp_num_params counts them). */
+enum { NNEST_SCALE_AFFINE = 0, NNEST_SCALE_TRANSLATE = 1, NNEST_SCALE_CONSTANT = 2 };
+int nnest_nvp_create_scaled(int D, int H, int B, int L, int scale_mode, nnest_nvp_t **out);
 int nnest_nvp_destroy(nnest_nvp_t *nvp);
 int nnest_nvp_num_params(const nnest_nvp_t *nvp);
 /* netG.load_state_dict / state_dict (trainer.py:102-106, :241): host<->device copy of the packed

@@ -57,6 +57,7 @@ SIGNATURES = {
     'nnest_hip_last_error': [],
     'nnest_hip_device_info': [ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _i],
     'nnest_nvp_create': [_i, _i, _i, _i, ctypes.POINTER(_vp)],
+    'nnest_nvp_create_scaled': [_i, _i, _i, _i, _i, ctypes.POINTER(_vp)],
     'nnest_nvp_destroy': [_vp],
     'nnest_nvp_num_params': [_vp],
     'nnest_nvp_load_weights': [_vp, _vp, _vp],

@@ -34,6 +34,14 @@ struct FlowShape {
     int net_floats;    // floats per (block, net) in the fragment image
     int image_floats;  // B * 2 * net_floats
     int net_params;    // packed parameter count per net (state_dict layout)
+    // SingleSpeedNVP scale variant (networks.py:328-347): 0 '' (affine), 1 'translate' (translate-only couplings),
+    // 2 'constant' (translate-only couplings + one ScaleLayer scalar after each).  In modes 1 and 2 the scale_net
+    // slots of the packed vector stay zero (log_s = 0 exactly) and receive no gradient; in mode 2 the B scalars
+    // follow the B blocks in the packed vector and the image_floats of the fragment image.
+    int scale_mode;
+    __host__ __device__ int nets_params() const { return B * 2 * net_params; }
+    __host__ __device__ int num_params() const { return B * 2 * net_params + (scale_mode == 2 ? B : 0); }
+    __host__ __device__ int image_total() const { return image_floats + (scale_mode == 2 ? B : 0); }
 };
 
 __host__ __device__ inline int frag_off_L1() { return 0; }
@@ -423,25 +431,39 @@ __device__ __forceinline__ float coupling_any(const float *__restrict__ wblk, in
 
 // NormalizingFlow.forward (networks.py:24-32): blocks 0..B-1.  xs[c][tau] = class c tiles.
 // Block b conditions on class (b+1)&1 and transforms class b&1 (mask = arange(D)%2 flipped per block).
+// ScaleLayer (networks.py:312-325; SingleSpeedNVP scale='constant', networks.py:343-344): y = x e^s on every
+// dimension, logdet += s (the scalar itself).  `ld` is a lane partial that is later summed over the four lane
+// groups of a walker, so s is added on lane group 0 only.
+template <int NT>
+__device__ __forceinline__ float scale_layer_tile(float s, bool inverse, int lane, f32x4 (&xs)[2][NT]) {
+    const float e = __expf(inverse ? -s : s);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xs[c][t] = xs[c][t] * e;
+    return lane < 16 ? (inverse ? -s : s) : 0.f;
+}
+
+// blk_scale: the B ScaleLayer scalars (scale='constant'), or nullptr
 template <int NT, int NH, int LT = -1>
 __device__ __forceinline__ float flow_forward_tile(const float *__restrict__ img, int net_floats, int B, int L,
-                                                   int lane, f32x4 (&xs)[2][NT]) {
+                                                   int lane, f32x4 (&xs)[2][NT], const float *blk_scale = nullptr) {
     float ld = 0.f;
     for (int b = 0; b < B; ++b) {
         const float *wblk = img + (size_t)b * 2 * net_floats;
         if (b & 1) ld += coupling_any<NT, NH, LT, false>(wblk, net_floats, L, lane, xs[0], xs[1]);
         else       ld += coupling_any<NT, NH, LT, false>(wblk, net_floats, L, lane, xs[1], xs[0]);
+        if (blk_scale) ld += scale_layer_tile<NT>(blk_scale[b], false, lane, xs);
     }
     return ld;
 }
-
-// NormalizingFlow.inverse (networks.py:34-42): blocks reversed.
 template <int NT, int NH, int LT = -1>
 __device__ __forceinline__ float flow_inverse_tile(const float *__restrict__ img, int net_floats, int B, int L,
-                                                   int lane, f32x4 (&xs)[2][NT]) {
+                                                   int lane, f32x4 (&xs)[2][NT], const float *blk_scale = nullptr) {
     float ld = 0.f;
     for (int b = B - 1; b >= 0; --b) {
         const float *wblk = img + (size_t)b * 2 * net_floats;
+        if (blk_scale) ld += scale_layer_tile<NT>(blk_scale[b], true, lane, xs);
         if (b & 1) ld += coupling_any<NT, NH, LT, true>(wblk, net_floats, L, lane, xs[0], xs[1]);
         else       ld += coupling_any<NT, NH, LT, true>(wblk, net_floats, L, lane, xs[1], xs[0]);
     }

@@ -61,9 +61,17 @@ int nnest_hip_device_info(int *num_cu, int *clock_khz, char *name, int name_len)
 }
 
 int nnest_nvp_create(int D, int H, int B, int L, nnest_nvp_t **out) {
+    return nnest_nvp_create_scaled(D, H, B, L, NNEST_SCALE_AFFINE, out);
+}
+
+int nnest_nvp_create_scaled(int D, int H, int B, int L, int scale_mode, nnest_nvp_t **out) {
     if (!out) return fail(NNEST_E_ARG, "out is NULL");
     *out = nullptr;
     if (D < 1 || H < 1 || B < 1 || L < 0) return fail(NNEST_E_ARG, "bad shape D=%d H=%d B=%d L=%d", D, H, B, L);
+    if (scale_mode < NNEST_SCALE_AFFINE || scale_mode > NNEST_SCALE_CONSTANT)
+        return fail(NNEST_E_ARG, "scale_mode=%d (0 '', 1 'translate', 2 'constant')", scale_mode);
+    if (scale_mode == NNEST_SCALE_CONSTANT && B > 8)
+        return fail(NNEST_E_UNSUPPORTED, "scale='constant' with num_blocks=%d > 8", B);
     if (H % 16 != 0)
         return fail(NNEST_E_UNSUPPORTED, "hidden_dim=%d: the gfx950 kernels tile the hidden layer by 16 (MFMA 16x16x4)", H);
     FlowShape s;
@@ -73,12 +81,13 @@ int nnest_nvp_create(int D, int H, int B, int L, nnest_nvp_t **out) {
     s.net_floats = frag_net_floats(s.NT, s.NH, L);
     s.image_floats = B * 2 * s.net_floats;
     s.net_params = H * D + H + L * (H * H + H) + D * H + D;
+    s.scale_mode = scale_mode;
     if (!shape_supported(s))
         return fail(NNEST_E_UNSUPPORTED, "x_dim=%d hidden_dim=%d not instantiated (x_dim<=128 at H=16, <=64 at H=32, <=32 at H=64)", D, H);
     nnest_nvp *h = new nnest_nvp();
     memset(h, 0, sizeof(*h));
     h->s = s;
-    h->num_params = B * 2 * s.net_params;
+    h->num_params = s.num_params();
     if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(NNEST_E_HIP, "hipGetDevice failed (no GPU?)"); }
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, h->device) != hipSuccess) { delete h; return fail(NNEST_E_HIP, "hipGetDeviceProperties failed"); }
@@ -90,7 +99,7 @@ int nnest_nvp_create(int D, int H, int B, int L, nnest_nvp_t **out) {
     if (e == hipSuccess) e = hipMalloc((void **)&h->adam_m, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&h->adam_v, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&h->best_w, nb);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->img, (size_t)s.image_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->img, (size_t)s.image_total() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->adam_step, sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->train_ws, h->train_ws_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->fwd_pos, nb);
@@ -101,7 +110,7 @@ int nnest_nvp_create(int D, int H, int B, int L, nnest_nvp_t **out) {
     if (e == hipSuccess) e = hipMemset(h->adam_m, 0, nb);
     if (e == hipSuccess) e = hipMemset(h->adam_v, 0, nb);
     if (e == hipSuccess) e = hipMemset(h->adam_step, 0, sizeof(int));
-    if (e == hipSuccess) e = hipMemset(h->img, 0, (size_t)s.image_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->img, 0, (size_t)s.image_total() * sizeof(float));
     if (e != hipSuccess) {
         nnest_nvp_destroy(h);
         return fail(NNEST_E_HIP, "device allocation failed: %s", hipGetErrorString(e));
@@ -124,6 +133,7 @@ int nnest_nvp_load_weights(nnest_nvp_t *h, const float *packed_host, void *strea
     if (!h || !packed_host) return fail(NNEST_E_ARG, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(h->w, packed_host, (size_t)h->num_params * sizeof(float), hipMemcpyHostToDevice, st));
+    if (h->s.scale_mode != NNEST_SCALE_AFFINE) HIP_TRY(launch_zero_scale_nets(h->w, h->s, st));  // unused slots stay 0
     HIP_TRY(launch_repack(h->w, h->img, h->s, st));
     HIP_TRY(hipStreamSynchronize(st));
     return NNEST_OK;

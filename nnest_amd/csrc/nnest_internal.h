@@ -11,6 +11,7 @@ enum { PASS_FORWARD = 0, PASS_INVERSE = 1, PASS_LOGPROB = 2, PASS_INVERSE_LOGLIK
 
 bool shape_supported(const FlowShape &s);
 hipError_t launch_repack(const float *packed, float *img, const FlowShape &s, hipStream_t st);
+hipError_t launch_zero_scale_nets(float *packed, const FlowShape &s, hipStream_t st);
 hipError_t launch_pass(const float *img, const FlowShape &s, int mode, const float *in, float *out, float *logdet,
                        double *logl, int *inbox, int N, const LikeSpec &like, int num_cu, hipStream_t st);
 hipError_t launch_mh(const float *img, const FlowShape &s, const LikeSpec &like, float *z, float *x, double *logl,

@@ -58,6 +58,15 @@ __global__ void repack_fragments_kernel(const float *__restrict__ packed, float 
         }
         img[idx] = v;
     }
+    // ScaleLayer scalars (scale='constant') ride behind the fragments
+    if (s.scale_mode == 2 && blockIdx.x == 0 && threadIdx.x < s.B) img[total + threadIdx.x] = packed[s.nets_params() + threadIdx.x];
+}
+
+// scale='translate' / 'constant': the scale_net slots of the packed vector are unused and must read as log_s = 0
+__global__ void zero_scale_nets_kernel(float *__restrict__ packed, FlowShape s) {
+    const int n = s.nets_params();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (((i / s.net_params) & 1) == 0) packed[i] = 0.f;
 }
 
 // cooperative copy of the fragment image into LDS (float4, coalesced)
@@ -93,6 +102,7 @@ __global__ void __launch_bounds__(256) flow_pass_kernel(PassArgs a) {
         stage_image(lds_img, a.img, a.s.image_floats);
         img = lds_img;
     }
+    const float *blk_scale = a.s.scale_mode == 2 ? a.img + a.s.image_floats : nullptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = a.waves_active;
     const int ntiles = (a.N + 15) >> 4;
     const int w = lane & 15, g = lane >> 4;
@@ -104,9 +114,9 @@ __global__ void __launch_bounds__(256) flow_pass_kernel(PassArgs a) {
         load_tile<NT>(a.in, row, ok, a.s.D, lane, xs);
         float ld;
         if (a.mode == PASS_FORWARD || a.mode == PASS_LOGPROB)
-            ld = flow_forward_tile<NT, NH, LT>(img, a.s.net_floats, a.s.B, a.s.L, lane, xs);
+            ld = flow_forward_tile<NT, NH, LT>(img, a.s.net_floats, a.s.B, a.s.L, lane, xs, blk_scale);
         else
-            ld = flow_inverse_tile<NT, NH, LT>(img, a.s.net_floats, a.s.B, a.s.L, lane, xs);
+            ld = flow_inverse_tile<NT, NH, LT>(img, a.s.net_floats, a.s.B, a.s.L, lane, xs, blk_scale);
         ld = group_sum(ld);
         if (a.mode == PASS_LOGPROB) {
             // MVN(0,I).log_prob(u) + logdet  (networks.py:51-57, :71-76)
@@ -357,11 +367,12 @@ template <int NT, int NH, int LT>
 struct ImageInverse {
     const float *img;
     int net_floats, B, L, lane;
+    const float *blk_scale;
 #ifdef NNEST_STAMP
     unsigned long long t_mlp = 0, t_xch = 0, t_upd = 0;
 #endif
     __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
-        return flow_inverse_tile<NT, NH, LT>(img, net_floats, B, L, lane, xs);
+        return flow_inverse_tile<NT, NH, LT>(img, net_floats, B, L, lane, xs, blk_scale);
     }
 };
 
@@ -376,7 +387,7 @@ __global__ void __launch_bounds__(512, 3) mh_kernel(MhArgs a) {  // >= 3 waves/S
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int tile = blockIdx.x * wpb + wave;
     if (tile >= ((a.C + 15) >> 4)) return;
-    ImageInverse<NT, NH, LT> inv = {img, a.s.net_floats, a.s.B, a.s.L, lane};
+    ImageInverse<NT, NH, LT> inv = {img, a.s.net_floats, a.s.B, a.s.L, lane, a.s.scale_mode == 2 ? a.img + a.s.image_floats : nullptr};
     XoshiroNoise<NT> noise;
     noise.init(a.seed, a.walker_offset + (uint64_t)(tile * 16 + (lane & 15)), lane >> 4, a.s.D);
     mh_body<NT, DBG>(a, tile, lane, inv, noise, true);
@@ -633,14 +644,14 @@ template <int NT, int NH, int LT>
 static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
     const int ntiles = (a.C + 15) / 16;
     if constexpr (LT == 1 && NH == 1 && NT <= 2) {  // NT >= 3 would spill: those shapes stay on the image form
-        if (a.s.B == 3 && ntiles <= num_cu && !a.noise_dz) {  // fewer tiles than CUs: three waves per tile (team form)
+        if (a.s.B == 3 && ntiles <= num_cu && !a.noise_dz && a.s.scale_mode != 2) {  // fewer tiles than CUs: three waves per tile (team form)
             if (a.hist_x || a.hist_logl)
                 hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, true>), dim3(ntiles), dim3(192), 0, st, a);
             else
                 hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, false>), dim3(ntiles), dim3(192), 0, st, a);
             return hipGetLastError();
         }
-        if (a.s.B == 3 && ntiles <= 4 * num_cu) {  // one wave per SIMD available; SingleSpeedNVP defaults: hidden_dim 16, num_blocks 3, num_layers 1 (nnest/sampler.py:37-43)
+        if (a.s.B == 3 && ntiles <= 4 * num_cu && a.s.scale_mode != 2) {  // one wave per SIMD available; SingleSpeedNVP defaults: hidden_dim 16, num_blocks 3, num_layers 1 (nnest/sampler.py:37-43)
             if (a.noise_dz || a.hist_x || a.hist_logl)
                 hipLaunchKernelGGL((mh_kernel_reg<NT, 1, 1, 3, true>), dim3(ntiles), dim3(64), 0, st, a);
             else
@@ -704,6 +715,11 @@ bool shape_supported(const FlowShape &s) {
     if (s.NH == 2) return s.NT >= 1 && s.NT <= 2;
     if (s.NH == 4) return s.NT == 1;
     return false;
+}
+
+hipError_t launch_zero_scale_nets(float *packed, const FlowShape &s, hipStream_t st) {
+    hipLaunchKernelGGL(zero_scale_nets_kernel, dim3(64), dim3(256), 0, st, packed, s);
+    return hipGetLastError();
 }
 
 hipError_t launch_repack(const float *packed, float *img, const FlowShape &s, hipStream_t st) {

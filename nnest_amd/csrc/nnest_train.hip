@@ -135,7 +135,7 @@ __global__ void build_pos_kernel(int *__restrict__ fwd_pos, int *__restrict__ bw
 }
 
 hipError_t launch_build_pos(int *fwd_pos, int *bwd_pos, const FlowShape &s, hipStream_t st) {
-    const size_t nb = (size_t)s.B * 2 * s.net_params * sizeof(int);
+    const size_t nb = (size_t)s.num_params() * sizeof(int);  // ScaleLayer scalars (scale='constant') have no image element
     hipError_t e = hipMemsetAsync(fwd_pos, 0xFF, nb, st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(bwd_pos, 0xFF, nb, st);
@@ -153,7 +153,11 @@ __device__ __forceinline__ void rebuild_images_to(const TrainArgs &a, float *img
     }
 }
 
-__device__ __forceinline__ void rebuild_images(const TrainArgs &a) { rebuild_images_to(a, a.img_fwd, a.img_bwd); }
+__device__ __forceinline__ void rebuild_images(const TrainArgs &a) {
+    rebuild_images_to(a, a.img_fwd, a.img_bwd);
+    if (a.s.scale_mode == 2 && threadIdx.x < a.s.B)  // the inference kernels read the ScaleLayer scalars behind the fragments
+        a.img_fwd[a.s.image_floats + threadIdx.x] = a.w[a.s.nets_params() + threadIdx.x];
+}
 
 // ---- MLP forward keeping the hidden activations (for the backward pass) ---------------------------------
 template <int NT, int NH, int L, int ACT>
@@ -503,8 +507,14 @@ __device__ __forceinline__ void block_backward(const TrainArgs &a, float *stg, i
     const float *wb = imgb + (size_t)b * 2 * a.s.net_floats;
     f32x4 as[L + 1][NH], at[L + 1][NH], ls[NT], t[NT], g_ls[NT], g_t[NT], gm_s[NT], gm_t[NT];
     const int g = lane >> 4;
+    // translate-only couplings (scale='translate' / 'constant', networks.py:293-294): no scale net, log_s = 0
+    const bool affine = a.s.scale_mode == 0;
     if (tile_active) {
-        mlp_fwd_keep<NT, NH, L, 0>(wf, lane, cond, as, ls);
+        if (affine) mlp_fwd_keep<NT, NH, L, 0>(wf, lane, cond, as, ls);
+        else {
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) ls[tau] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         mlp_fwd_keep<NT, NH, L, 1>(wf + a.s.net_floats, lane, cond, at, t);
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
@@ -529,7 +539,11 @@ __device__ __forceinline__ void block_backward(const TrainArgs &a, float *stg, i
             gtrans[tau] = (f32x4){o_gx[0], o_gx[1], o_gx[2], o_gx[3]};
         }
         // scale net: stage G, activations and the shared conditioning input m
-        mlp_bwd<NT, NH, L, 0>(wb, lane, stg, rows_pad, row, g_ls, as, gm_s);
+        if (affine) mlp_bwd<NT, NH, L, 0>(wb, lane, stg, rows_pad, row, g_ls, as, gm_s);
+        else {
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) gm_s[tau] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
             f32x4 mv = cond[tau];
@@ -537,10 +551,12 @@ __device__ __forceinline__ void block_backward(const TrainArgs &a, float *stg, i
             stage_tile(stg, rows_pad, SM::m(tau), row, lane, mv);
         }
     }
-    __syncthreads();
-    TSTAMP(q1);
-    weight_grad_jobs<NT, NH, L>(a, stg, rows_pad, b, 0, wave, lane, ad, imgf, imgb);
-    __syncthreads();
+    if (affine) {
+        __syncthreads();
+        TSTAMP(q1);
+        weight_grad_jobs<NT, NH, L>(a, stg, rows_pad, b, 0, wave, lane, ad, imgf, imgb);
+        __syncthreads();
+    }
     TSTAMP(q2);
     if (tile_active) mlp_bwd<NT, NH, L, 1>(wb + a.s.net_floats, lane, stg, rows_pad, row, g_t, at, gm_t);
     __syncthreads();
@@ -570,7 +586,10 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int w = lane & 15, g = lane >> 4;
     const int D = a.s.D, B = a.s.B;
-    const int np = B * 2 * a.s.net_params;
+    const int np = a.s.num_params();
+    // ScaleLayer scalars (scale='constant'): read from the packed vector, which Adam updates in place
+    const float *blk_scale = a.s.scale_mode == 2 ? a.w + a.s.nets_params() : nullptr;
+    __shared__ float sred[8 * TRAIN_WAVES];  // per (block, wave) partials of dLoss/ds_b; B <= 8 checked by the launcher
     const float half_log_2pi = 0.91893853320467274f;
 
     rebuild_images_to(a, imgf, imgb);
@@ -639,7 +658,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
                         }
                     }
                 }
-                ld = group_sum(flow_forward_tile<NT, NH>(imgf, a.s.net_floats, B, L, lane, xs));
+                ld = group_sum(flow_forward_tile<NT, NH>(imgf, a.s.net_floats, B, L, lane, xs, blk_scale));
             }
             // loss = -mean(log_probs)  (trainer.py:394; networks.py:71-76)
             float lp = 0.f;
@@ -681,8 +700,38 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
                 ad.inv_bc2s = (float)(1.0 / sqrt(bc2));
             }
             for (int b = B - 1; b >= 0; --b) {
+                if (blk_scale) {
+                    // ScaleLayer b (networks.py:318-320): y = c e^s, logdet += s.  dLoss/ds = sum_rows (gy . y) + M gld;
+                    // then c = y e^{-s}, gc = gy e^s.
+                    const float sb = blk_scale[b], e = __expf(sb), ei = __expf(-sb);
+                    float part = 0.f;
+                    if (tile_active) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) {
+                                const f32x4 y = xs[c][t], gy = gs[c][t];
+                                part += (gy.x * y.x + gy.y * y.y) + (gy.z * y.z + gy.w * y.w);
+                                xs[c][t] = y * ei;
+                                gs[c][t] = gy * e;
+                            }
+                        part = group_sum(part);
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) part += __shfl_xor(part, o);
+                    }
+                    if (lane == 0) sred[b * TRAIN_WAVES + wave] = tile_active ? part : 0.f;
+                }
                 if (b & 1) block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[0], xs[1], gs[0], gs[1], gld, ad, imgf, imgb, ph);
                 else       block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[1], xs[0], gs[1], gs[0], gld, ad, imgf, imgb, ph);
+            }
+            if (blk_scale) {
+                __syncthreads();
+                if (threadIdx.x < B) {
+                    float gsum = 0.f;
+                    for (int k = 0; k < TRAIN_WAVES; ++k) gsum += sred[threadIdx.x * TRAIN_WAVES + k];
+                    a.grad[a.s.nets_params() + threadIdx.x] = gsum + (float)M * gld;
+                }
+                __syncthreads();
             }
             if (a.mode == TRAIN_MODE_GRAD_ONLY) {
                 if (threadIdx.x == 0) *a.loss_out = loss;
@@ -705,7 +754,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
                 const bool ok = r < a.n_valid;
                 f32x4 xv[2][NT];
                 load_tile<NT>(a.xvalid, r, ok, D, lane, xv);
-                float ldv = group_sum(flow_forward_tile<NT, NH>(imgf, a.s.net_floats, B, L, lane, xv));
+                float ldv = group_sum(flow_forward_tile<NT, NH>(imgf, a.s.net_floats, B, L, lane, xv, blk_scale));
                 float ss = 0.f;
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
@@ -815,7 +864,7 @@ hipError_t launch_training_jitter(const double *samples, int N, int D, double *o
 // workspace layout (floats): [img_bwd: image_floats][grad: num_params]
 size_t train_workspace_floats(const FlowShape &s, int batch) {
     (void)batch;
-    return (size_t)s.image_floats + (size_t)s.B * 2 * s.net_params + 64;
+    return (size_t)s.image_floats + (size_t)s.num_params() + 64;
 }
 
 template <int NT, int NH, int L, bool IMGLDS>

@@ -24,20 +24,31 @@ def _as_dev_f32(x, device):
     return x.contiguous()
 
 
-class HipNVP(object):
-    """num_inputs=D, num_hidden=H, num_blocks=B, num_layers=L as SingleSpeedNVP (networks.py:330-331)."""
+SCALE_MODES = {'': 0, 'translate': 1, 'constant': 2}
 
-    def __init__(self, num_inputs, num_hidden=16, num_blocks=3, num_layers=1, device=None, seed=None):
+
+class HipNVP(object):
+    """num_inputs=D, num_hidden=H, num_blocks=B, num_layers=L, scale as SingleSpeedNVP (networks.py:328-347).
+
+    scale='translate' / 'constant' (translate-only couplings; 'constant' adds a ScaleLayer scalar after each block):
+    state_dict() has the reference's keys (no scale nets; `flow.flows.<2b+1>.scale` scalars); the packed vector of
+    the C ABI keeps the scale_net slots (zero) and appends the scalars (include/nnest_hip.h)."""
+
+    def __init__(self, num_inputs, num_hidden=16, num_blocks=3, num_layers=1, device=None, seed=None, scale=''):
         if not torch.cuda.is_available():
             raise _lib.NnestHipError('HipNVP needs an MI355X visible to PyTorch-ROCm (torch.cuda.is_available() is False); '
                                      'there is no CPU fallback')
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.D, self.H, self.B, self.L = int(num_inputs), int(num_hidden), int(num_blocks), int(num_layers)
         self.num_inputs = self.D
+        if scale not in SCALE_MODES:
+            raise ValueError("scale=%r: expected '', 'translate' or 'constant' (networks.py:330-332)" % (scale,))
+        self.scale = scale
         self._lib = _lib.load()
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.nnest_nvp_create(self.D, self.H, self.B, self.L, ctypes.byref(self._h)))
+            _lib.check(self._lib.nnest_nvp_create_scaled(self.D, self.H, self.B, self.L, SCALE_MODES[scale],
+                                                         ctypes.byref(self._h)))
         self.num_params = self._lib.nnest_nvp_num_params(self._h)
         self.prior = torch.distributions.MultivariateNormal(torch.zeros(self.D, device=self.device),
                                                             torch.eye(self.D, device=self.device))
@@ -53,15 +64,26 @@ class HipNVP(object):
 
     # ---- weights ---------------------------------------------------------------------------------
     def layer_shapes(self):
-        """[(name, shape)] in torch state_dict order"""
+        """[(name, shape, offset into the packed vector)] in torch state_dict order; with
+        scale='translate'/'constant' a block has no scale_net, and with 'constant' the flows alternate coupling /
+        ScaleLayer (networks.py:336-346)"""
         out = []
         D, H, L = self.D, self.H, self.L
+        ns = H * D + H + L * (H * H + H) + D * H + D
+        stride = 2 if self.scale == 'constant' else 1
         for b in range(self.B):
-            for net in ('scale_net', 'translate_net'):
+            for n, net in enumerate(('scale_net', 'translate_net')):
+                if n == 0 and self.scale != '':
+                    continue
+                off = (2 * b + n) * ns
                 dims = [(H, D)] + [(H, H)] * L + [(D, H)]
                 for i, (o, k) in enumerate(dims):
-                    out.append(('flow.flows.%d.%s.%d.weight' % (b, net, 2 * i), (o, k)))
-                    out.append(('flow.flows.%d.%s.%d.bias' % (b, net, 2 * i), (o,)))
+                    out.append(('flow.flows.%d.%s.%d.weight' % (stride * b, net, 2 * i), (o, k), off))
+                    off += o * k
+                    out.append(('flow.flows.%d.%s.%d.bias' % (stride * b, net, 2 * i), (o,), off))
+                    off += o
+            if self.scale == 'constant':
+                out.append(('flow.flows.%d.scale' % (2 * b + 1), (), 2 * self.B * ns + b))
         return out
 
     def default_init(self, seed=None):
@@ -73,16 +95,19 @@ class HipNVP(object):
             g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
         else:
             g.manual_seed(int(seed))
-        parts = []
-        for name, shape in self.layer_shapes():
+        packed = np.zeros(self.num_params, np.float32)
+        for name, shape, off in self.layer_shapes():
+            if len(shape) == 0:
+                continue                     # ScaleLayer scalar starts at 0 (networks.py:316)
             fan_in = shape[1] if len(shape) == 2 else None
             if fan_in is None:
                 fan_in = last_fan_in
             else:
                 last_fan_in = fan_in
             bound = 1.0 / math.sqrt(fan_in)
-            parts.append((torch.rand(int(np.prod(shape)), generator=g) * 2 - 1) * bound)
-        return torch.cat(parts).numpy().astype(np.float32)
+            n = int(np.prod(shape))
+            packed[off:off + n] = ((torch.rand(n, generator=g) * 2 - 1) * bound).numpy()
+        return packed
 
     def load_packed(self, packed):
         packed = np.ascontiguousarray(packed, dtype=np.float32)
@@ -101,17 +126,33 @@ class HipNVP(object):
 
     def state_dict(self):
         packed = self.store_packed()
-        sd, off = {}, 0
-        for name, shape in self.layer_shapes():
+        sd = {}
+        for name, shape, off in self.layer_shapes():
             n = int(np.prod(shape))
             sd[name] = torch.from_numpy(packed[off:off + n].reshape(shape).copy())
-            off += n
         return sd
 
     def load_state_dict(self, sd):
-        self.load_packed(np.concatenate([np.asarray(sd[name].detach().cpu().numpy() if torch.is_tensor(sd[name])
-                                                    else sd[name], dtype=np.float32).ravel()
-                                         for name, _ in self.layer_shapes()]))
+        packed = np.zeros(self.num_params, np.float32)
+        for name, shape, off in self.layer_shapes():
+            v = sd[name]
+            v = np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v, dtype=np.float32).ravel()
+            packed[off:off + v.size] = v
+        self.load_packed(packed)
+
+    def reference_vector(self, packed=None):
+        """the concatenated state_dict (what the reference's parameters() hold) out of a packed-layout vector"""
+        packed = self.store_packed() if packed is None else np.asarray(packed)
+        return np.concatenate([packed[off:off + int(np.prod(shape))] for _, shape, off in self.layer_shapes()])
+
+    def load_reference_vector(self, vec):
+        packed = np.zeros(self.num_params, np.float32)
+        pos = 0
+        for _, shape, off in self.layer_shapes():
+            n = int(np.prod(shape))
+            packed[off:off + n] = vec[pos:pos + n]
+            pos += n
+        self.load_packed(packed)
 
     def adam_step_count(self):
         n = ctypes.c_int(0)

@@ -50,8 +50,9 @@ class Trainer(object):
                                       "Choleksy flows of the reference are outside its scope (DESIGN.md)" % flow)
         if num_slow != 0:
             raise NotImplementedError('num_slow > 0 (fast/slow hierarchy) is outside the scope of this build')
-        if scale not in ('', None):
-            raise NotImplementedError("scale=%r: only the full affine coupling (scale='') is implemented" % scale)
+        scale = '' if scale is None else scale
+        if scale not in ('', 'translate', 'constant'):
+            raise NotImplementedError("scale=%r: SingleSpeedNVP knows '', 'translate' and 'constant' (networks.py:330-332)" % scale)
         if base_dist is not None:
             raise NotImplementedError('only the N(0, I) base distribution is implemented')
         if batch_size > 128:
@@ -69,7 +70,7 @@ class Trainer(object):
         self.num_slow = 0
         self.learning_rate = learning_rate
         self.weight_decay = weight_decay
-        self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed)
+        self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed, scale=scale)
         if load_model:
             self.path = os.path.join(log_dir, load_model)
             self.netG.load_state_dict(torch.load(os.path.join(self.path, 'models', 'netG.pt')))
@@ -82,7 +83,7 @@ class Trainer(object):
         self.logger = create_logger(__name__, level=log_level)
         self.log = log
         self.writer = ScalarWriter(self.path)
-        self.logger.info('Number of network params: [%s]' % self.netG.num_params)
+        self.logger.info('Number of network params: [%s]' % self.netG.reference_vector().size)
         self.logger.info('Device [%s]' % self.device)
 
     # ------------------------------------------------------------------------------------------------

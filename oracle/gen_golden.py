@@ -20,6 +20,8 @@ Fixture families:
   G6 nested_cfg1.json seeded end-to-end NestedSampler.run on config 1 (nnest/nested.py:97-510)
   G7 trainrun_*.npz   Trainer.train() for a few epochs: split, per-epoch perms, noise, losses
                       (nnest/trainer.py:134-245)
+  G8 scale_*.npz      SingleSpeedNVP with scale='translate' / 'constant' (nnest/networks.py:289-347): passes,
+                      gradients and Adam steps
 """
 import os
 import sys
@@ -381,8 +383,82 @@ def gen_nested():
     print('G6', res)
 
 
+# ----------------------------------------------------------------------------------------------
+# G8: SingleSpeedNVP scale variants (networks.py:328-347): scale='translate' (translate-only couplings) and
+# scale='constant' (translate-only couplings + one ScaleLayer scalar after each): passes, a trained state, and
+# minibatch steps with every gradient.  Vectors are the concatenated state_dict (no scale nets in these variants).
+# ----------------------------------------------------------------------------------------------
+def gen_scale_variants():
+    for scale in ('translate', 'constant'):
+        for name, D, L in [('d5', 5, 1), ('d50', 50, 1), ('d8_l2', 8, 2)]:
+            np.random.seed(0)
+            torch.manual_seed(4)
+            t = Trainer(D, hidden_dim=16, num_blocks=3, num_layers=L, flow='nvp', log_dir=None, scale=scale,
+                        learning_rate=1e-3, log_level=logging.WARNING)
+            if scale == 'constant':   # ScaleLayer scalars start at 0 (networks.py:316): move them off zero
+                with torch.no_grad():
+                    for k, v in t.netG.state_dict().items():
+                        if k.endswith('.scale'):
+                            v.fill_(float(np.random.uniform(-0.3, 0.3)))
+            x = np.random.uniform(-1, 1, size=(64, D))
+            out = {'D': D, 'H': 16, 'B': 3, 'L': L, 'x': x, 'keys': np.array(list(t.netG.state_dict().keys()))}
+            w0 = pack_state_dict(t.netG)
+            # minibatch steps (as G4) from the initial state
+            n, jitter = 230, 0.02
+            X = np.random.uniform(-1, 1, size=(n, D)).astype(np.float32)
+            t2 = copy.deepcopy(t)
+            t2.optimizer = torch.optim.Adam(t2.netG.parameters(), lr=1e-3, weight_decay=1e-6)
+            torch.manual_seed(11)
+            rng_state = torch.get_rng_state()
+            perms, noises = [], []
+            for e in range(2):
+                pp, nz = replay_loader_rng(n, 100, D)
+                perms.append(pp)
+                noises.append(nz)
+            losses, grads, ws = [], [], []
+            t2.netG.train()
+            Xt = torch.from_numpy(X)
+            for e in range(2):
+                for b in range(0, n, 100):
+                    idx = torch.from_numpy(perms[e][b:b + 100].astype(np.int64))
+                    data = Xt[idx] + jitter * torch.from_numpy(noises[e][b:b + 100])
+                    t2.optimizer.zero_grad()
+                    loss = -t2.netG.log_probs(data).mean()
+                    loss.backward()
+                    grads.append(pack_grads(t2.netG))
+                    t2.optimizer.step()
+                    losses.append(loss.item())
+                    ws.append(pack_state_dict(t2.netG))
+            # pass outputs at the initial state, before the reference's own _train moves `t`
+            z, ldf = t.forward(x, to_numpy=True)
+            xb, ldi = t.inverse(z, to_numpy=True)
+            out.update(w_init=w0, z_init=z, ldf_init=ldf, xb_init=xb, ldi_init=ldi, lp_init=t.log_probs(x, to_numpy=True))
+            tt = t
+            torch.set_rng_state(rng_state)
+            ds = torch.utils.data.TensorDataset(Xt)
+            loader = torch.utils.data.DataLoader(ds, batch_size=100, shuffle=True)
+            for e in range(2):
+                tt._train(e + 1, loader, jitter=jitter)
+            assert np.array_equal(pack_state_dict(tt.netG), ws[-1]), 'replay differs from reference _train'
+            out.update(X=X, jitter=jitter, w0=w0, perms=np.stack(perms), noises=np.stack(noises),
+                       losses=np.array(losses), grads=np.stack(grads), ws=np.stack(ws))
+            for tag in ('trained',):
+                np.random.seed(1)
+                torch.manual_seed(1)
+                t.train(np.random.uniform(-1, 1, size=(300, D)), max_iters=20, jitter=0.01)
+                z, ldf = t.forward(x, to_numpy=True)
+                xb, ldi = t.inverse(z, to_numpy=True)
+                lp = t.log_probs(x, to_numpy=True)
+                out.update({'w_' + tag: pack_state_dict(t.netG), 'z_' + tag: z, 'ldf_' + tag: ldf,
+                            'xb_' + tag: xb, 'ldi_' + tag: ldi, 'lp_' + tag: lp})
+            np.savez_compressed(os.path.join(OUT, 'scale_%s_%s.npz' % (scale, name)), **out)
+            print('G8 scale', scale, name, 'nparams', w0.size, 'loss0', losses[0])
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested']
+    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested', 'scale']
+    if 'scale' in which:
+        gen_scale_variants()
     if 'flow' in which:
         gen_flow()
     if 'like' in which:

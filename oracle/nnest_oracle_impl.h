@@ -17,6 +17,14 @@
  *   scale_net:     W0[H,D] b0[H] (W[H,H] b[H])xL  Wout[D,H] bout[D]
  *   translate_net: same shapes
  * nn.Linear weight is [out,in] row-major.
+ *
+ * scale variants of SingleSpeedNVP (networks.py:328-347), selected with orc_set_scale_mode():
+ *   0  scale=''           full affine coupling
+ *   1  scale='translate'  CouplingLayer(translate_only=True): y = x + t, logdet 0 (networks.py:293-294, :304-305)
+ *   2  scale='constant'   translate-only couplings, each followed by a ScaleLayer (networks.py:312-325):
+ *                         y = x e^s for every dimension, logdet += s  (the scalar itself, not D s)
+ * In modes 1 and 2 the packed vector keeps the scale_net slots (unused; zero, zero gradient) so that one layout
+ * serves every mode; in mode 2 the B ScaleLayer scalars follow the B blocks.
  */
 
 #ifndef REAL
@@ -65,7 +73,8 @@ static REAL FN(coupling_fwd_row)(const float *pb, int D, int H, int L, int b, RE
     REAL m[512], ls[512], t[512];
     int ns = FN(net_size)(D, H, L);
     for (int d = 0; d < D; ++d) m[d] = ((d + b) & 1) ? x[d] : (REAL)0; /* inputs * mask */
-    FN(mlp)(pb, D, H, L, 0, m, ls, acts_s);
+    if (orc_scale_mode == 0) FN(mlp)(pb, D, H, L, 0, m, ls, acts_s);
+    else for (int d = 0; d < D; ++d) ls[d] = 0; /* translate_only: y = x + t, logdet 0 */
     FN(mlp)(pb + ns, D, H, L, 1, m, t, acts_t);
     REAL ld = 0;
     for (int d = 0; d < D; ++d) {
@@ -85,7 +94,8 @@ static REAL FN(coupling_inv_row)(const float *pb, int D, int H, int L, int b, RE
     REAL m[512], ls[512], t[512];
     int ns = FN(net_size)(D, H, L);
     for (int d = 0; d < D; ++d) m[d] = ((d + b) & 1) ? x[d] : (REAL)0;
-    FN(mlp)(pb, D, H, L, 0, m, ls, NULL);
+    if (orc_scale_mode == 0) FN(mlp)(pb, D, H, L, 0, m, ls, NULL);
+    else for (int d = 0; d < D; ++d) ls[d] = 0;
     FN(mlp)(pb + ns, D, H, L, 1, m, t, NULL);
     REAL ld = 0;
     for (int d = 0; d < D; ++d) {
@@ -96,6 +106,20 @@ static REAL FN(coupling_inv_row)(const float *pb, int D, int H, int L, int b, RE
     return ld;
 }
 
+/* ScaleLayer.forward / .inverse (networks.py:318-325) after / before coupling b; s_b = w[B*bs + b] */
+static REAL FN(scale_fwd_row)(const float *w, int D, int B, int bs, int b, REAL *x) {
+    if (orc_scale_mode != 2) return 0;
+    REAL s = (REAL)w[(size_t)B * bs + b], e = FN(expr)(s);
+    for (int d = 0; d < D; ++d) x[d] *= e;
+    return s;
+}
+static REAL FN(scale_inv_row)(const float *w, int D, int B, int bs, int b, REAL *x) {
+    if (orc_scale_mode != 2) return 0;
+    REAL s = (REAL)w[(size_t)B * bs + b], e = FN(expr)(-s);
+    for (int d = 0; d < D; ++d) x[d] *= e;
+    return -s;
+}
+
 /* NormalizingFlow.forward (networks.py:24-32): blocks 0..B-1, log_det accumulated */
 void FN(nvp_forward)(const float *w, int D, int H, int B, int L, const REAL *x, int N, REAL *z, REAL *logdet) {
     int bs = 2 * FN(net_size)(D, H, L);
@@ -103,7 +127,10 @@ void FN(nvp_forward)(const float *w, int D, int H, int B, int L, const REAL *x, 
         REAL r[512];
         for (int d = 0; d < D; ++d) r[d] = x[(size_t)n * D + d];
         REAL ld = 0;
-        for (int b = 0; b < B; ++b) ld += FN(coupling_fwd_row)(w + (size_t)b * bs, D, H, L, b, r, NULL, NULL, NULL);
+        for (int b = 0; b < B; ++b) {
+            ld += FN(coupling_fwd_row)(w + (size_t)b * bs, D, H, L, b, r, NULL, NULL, NULL);
+            ld += FN(scale_fwd_row)(w, D, B, bs, b, r);
+        }
         for (int d = 0; d < D; ++d) z[(size_t)n * D + d] = r[d];
         logdet[n] = ld;
     }
@@ -116,7 +143,10 @@ void FN(nvp_inverse)(const float *w, int D, int H, int B, int L, const REAL *z, 
         REAL r[512];
         for (int d = 0; d < D; ++d) r[d] = z[(size_t)n * D + d];
         REAL ld = 0;
-        for (int b = B - 1; b >= 0; --b) ld += FN(coupling_inv_row)(w + (size_t)b * bs, D, H, L, b, r);
+        for (int b = B - 1; b >= 0; --b) {
+            ld += FN(scale_inv_row)(w, D, B, bs, b, r);
+            ld += FN(coupling_inv_row)(w + (size_t)b * bs, D, H, L, b, r);
+        }
         for (int d = 0; d < D; ++d) x[(size_t)n * D + d] = r[d];
         logdet[n] = ld;
     }
@@ -131,7 +161,10 @@ void FN(nvp_log_probs)(const float *w, int D, int H, int B, int L, const REAL *x
         REAL r[512];
         for (int d = 0; d < D; ++d) r[d] = x[(size_t)n * D + d];
         REAL ld = 0;
-        for (int b = 0; b < B; ++b) ld += FN(coupling_fwd_row)(w + (size_t)b * bs, D, H, L, b, r, NULL, NULL, NULL);
+        for (int b = 0; b < B; ++b) {
+            ld += FN(coupling_fwd_row)(w + (size_t)b * bs, D, H, L, b, r, NULL, NULL, NULL);
+            ld += FN(scale_fwd_row)(w, D, B, bs, b, r);
+        }
         REAL ss = 0;
         for (int d = 0; d < D; ++d) ss += r[d] * r[d];
         lp[n] = (REAL)(-0.5) * ss - (REAL)(D * half_log_2pi) + ld;
@@ -198,7 +231,7 @@ static void FN(mlp_bwd)(const float *p, float *gp_unused, REAL *gp, int D, int H
 
 /* loss and dloss/dw for a minibatch X[M,D].  grad has num_params entries (zeroed here). Returns loss. */
 double FN(nvp_loss_grad)(const float *w, int D, int H, int B, int L, const REAL *X, int M, REAL *grad) {
-    int ns = FN(net_size)(D, H, L), bs = 2 * ns, np_ = B * bs;
+    int ns = FN(net_size)(D, H, L), bs = 2 * ns, np_ = B * bs + (orc_scale_mode == 2 ? B : 0);
     const double half_log_2pi = 0.91893853320467274178;
     for (int i = 0; i < np_; ++i) grad[i] = 0;
     REAL *xin = (REAL *)malloc(sizeof(REAL) * (size_t)B * D);
@@ -214,6 +247,7 @@ double FN(nvp_loss_grad)(const float *w, int D, int H, int B, int L, const REAL 
             memcpy(xin + (size_t)b * D, r, sizeof(REAL) * D);
             ld += FN(coupling_fwd_row)(w + (size_t)b * bs, D, H, L, b, r, lss + (size_t)b * D,
                                        as + (size_t)b * (L + 1) * H, at + (size_t)b * (L + 1) * H);
+            ld += FN(scale_fwd_row)(w, D, B, bs, b, r);
         }
         REAL ss = 0;
         for (int d = 0; d < D; ++d) ss += r[d] * r[d];
@@ -225,6 +259,11 @@ double FN(nvp_loss_grad)(const float *w, int D, int H, int B, int L, const REAL 
         for (int b = B - 1; b >= 0; --b) {
             const REAL *x = xin + (size_t)b * D, *ls = lss + (size_t)b * D;
             REAL m[512], gls[512], gt[512], gm[512];
+            if (orc_scale_mode == 2) { /* ScaleLayer: y = c e^s, logdet += s;  r holds y on entry */
+                REAL e = FN(expr)((REAL)w[(size_t)B * bs + b]), gs = gld;
+                for (int d = 0; d < D; ++d) { gs += gy[d] * r[d]; gy[d] *= e; }
+                grad[(size_t)B * bs + b] += gs;
+            }
             for (int d = 0; d < D; ++d) {
                 int cond = (d + b) & 1;
                 m[d] = cond ? x[d] : (REAL)0;
@@ -237,11 +276,13 @@ double FN(nvp_loss_grad)(const float *w, int D, int H, int B, int L, const REAL 
                     gy[d] = gy[d] * e; /* direct path dy/dx */
                 }
             }
-            FN(mlp_bwd)(w + (size_t)b * bs, NULL, grad + (size_t)b * bs, D, H, L, 0, m, as + (size_t)b * (L + 1) * H, gls, gm);
+            if (orc_scale_mode == 0)
+                FN(mlp_bwd)(w + (size_t)b * bs, NULL, grad + (size_t)b * bs, D, H, L, 0, m, as + (size_t)b * (L + 1) * H, gls, gm);
             FN(mlp_bwd)(w + (size_t)b * bs + ns, NULL, grad + (size_t)b * bs + ns, D, H, L, 1, m,
                         at + (size_t)b * (L + 1) * H, gt, gm);
             for (int d = 0; d < D; ++d)
                 if ((d + b) & 1) gy[d] += gm[d]; /* masked_inputs = inputs * mask */
+            memcpy(r, x, sizeof(REAL) * D); /* r = this block's input = the previous ScaleLayer's output */
         }
     }
     free(xin); free(lss); free(as); free(at);

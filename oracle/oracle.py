@@ -58,8 +58,27 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
-def num_params(D, H, B, L):
+SCALE_MODES = {'': 0, 'translate': 1, 'constant': 2}
+
+
+def num_params(D, H, B, L, scale=''):
+    lib().orc_set_scale_mode(SCALE_MODES[scale])
     return lib().orc_num_params(D, H, B, L)
+
+
+def reference_index_map(D, H, B, L, scale=''):
+    """index into the packed vector of every entry of the reference's state_dict, in state_dict order
+    (networks.py:328-347: with scale='translate'/'constant' a block has no scale_net; with 'constant' a ScaleLayer
+    scalar follows each coupling block)"""
+    ns = H * D + H + L * (H * H + H) + D * H + D
+    if scale == '':
+        return np.arange(B * 2 * ns)
+    idx = []
+    for b in range(B):
+        idx.append(np.arange(ns) + (2 * b + 1) * ns)
+        if scale == 'constant':
+            idx.append(np.array([B * 2 * ns + b]))
+    return np.concatenate(idx)
 
 
 class NVP(object):
@@ -67,9 +86,10 @@ class NVP(object):
 
     Restates SingleSpeedNVP / NormalizingFlowModel (nnest/networks.py:17-84, :248-347)."""
 
-    def __init__(self, D, H=16, B=3, L=1, weights=None):
+    def __init__(self, D, H=16, B=3, L=1, weights=None, scale=''):
         self.D, self.H, self.B, self.L = int(D), int(H), int(B), int(L)
-        self.n = num_params(D, H, B, L)
+        self.scale = scale
+        self.n = num_params(D, H, B, L, scale)
         self.w = np.zeros(self.n, np.float32) if weights is None else _f32(weights).copy()
         assert self.w.size == self.n, (self.w.size, self.n)
         self.m = np.zeros(self.n, np.float32)  # Adam exp_avg
@@ -77,7 +97,16 @@ class NVP(object):
         self.t = 0                             # Adam step count
 
     def _cfg(self):
+        lib().orc_set_scale_mode(SCALE_MODES[self.scale])
         return (_p(self.w, _fp), self.D, self.H, self.B, self.L)
+
+    def load_reference_vector(self, vec):
+        """weights given as the concatenated reference state_dict (scale variants: no scale nets)"""
+        self.w[:] = 0
+        self.w[reference_index_map(self.D, self.H, self.B, self.L, self.scale)] = _f32(vec)
+
+    def reference_vector(self, arr=None):
+        return (self.w if arr is None else arr)[reference_index_map(self.D, self.H, self.B, self.L, self.scale)]
 
     def _run(self, fn32, fn64, x, f64, two_out=True):
         x = np.atleast_2d(x)
@@ -131,6 +160,7 @@ class NVP(object):
         nz = None if noise is None else _f32(noise)
         g = np.empty(self.n, np.float32)
         self.t += 1
+        lib().orc_set_scale_mode(SCALE_MODES[self.scale])
         loss = lib().orc_train_step(_p(self.w, _fp), _p(self.m, _fp), _p(self.v, _fp), self.D, self.H, self.B,
                                     self.L, _p(X, _fp), _p(idx, _ip), None if nz is None else _p(nz, _fp), M,
                                     ctypes.c_float(jitter), self.t, ctypes.c_float(lr), ctypes.c_float(wd),
@@ -223,6 +253,7 @@ def mcmc_sample(nvp, like, like_scale, init, init_logl, loglstar, step, dynamic,
     loglikes = np.empty((C, S + 1))
     scale = ctypes.c_double(step)
     acc = ctypes.c_long(0); rej = ctypes.c_long(0)
+    lib().orc_set_scale_mode(SCALE_MODES[nvp.scale])
     ncall = lib().orc_mcmc_sample(_p(nvp.w, _fp), nvp.D, nvp.H, nvp.B, nvp.L, LIKE_IDS[like.lower()],
                                   ctypes.c_float(like_scale), _p(init, _dp), _p(init_logl, _dp), C, S,
                                   ctypes.c_double(loglstar), ctypes.byref(scale), int(bool(dynamic)), _p(dz, _fp),

@@ -194,3 +194,70 @@ def test_philox_known_answers():
     assert orc.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert orc.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+SCALE_FILES = sorted(glob.glob(os.path.join(G, 'scale_*.npz')))
+
+
+@pytest.mark.parametrize('path', SCALE_FILES, ids=[os.path.basename(p)[6:-4] for p in SCALE_FILES])
+def test_scale_variants(path):
+    """SingleSpeedNVP(scale='translate' | 'constant') (networks.py:289-347): translate-only couplings and the
+    ScaleLayer scalars; fixture vectors are the reference's state_dict (no scale nets in these variants)."""
+    g = np.load(path)
+    scale = os.path.basename(path).split('_')[1]
+    D, H, B, L = int(g['D']), int(g['H']), int(g['B']), int(g['L'])
+    keys = list(g['keys'])
+    assert not any('scale_net' in k for k in keys)
+    assert sum(k.endswith('.scale') for k in keys) == (B if scale == 'constant' else 0)
+    x = g['x']
+    nvp = orc.NVP(D, H, B, L, scale=scale)
+    assert orc.reference_index_map(D, H, B, L, scale).size == g['w0'].size
+    for tag in ('init', 'trained'):
+        nvp.load_reference_vector(g['w_' + tag])
+        z, ldf = nvp.forward(x)
+        assert rel(z, g['z_' + tag]) < 1e-5
+        # translate: logdet is identically 0; constant: sum of the ScaleLayer scalars (the scalar, not D * s)
+        assert np.max(np.abs(ldf - g['ldf_' + tag])) < 1e-6
+        xb, ldi = nvp.inverse(g['z_' + tag])
+        assert rel(xb, g['xb_' + tag]) < 1e-5
+        assert np.max(np.abs(ldi - g['ldi_' + tag])) < 1e-6
+        assert rel(nvp.log_probs(x), g['lp_' + tag]) < 2e-5
+        if scale == 'constant':
+            s = g['w_' + tag][[i for i, k in enumerate(_flat_keys(g, D, H, L)) if k]]
+            assert np.allclose(ldf, np.sum(s), atol=1e-6)
+    # minibatch steps against the reference trajectory
+    X, jitter = g['X'], float(g['jitter'])
+    n = X.shape[0]
+    k = 0
+    nvp.load_reference_vector(g['w0'])
+    for e in range(g['perms'].shape[0]):
+        for b in range(0, n, 100):
+            idx = g['perms'][e][b:b + 100]
+            loss, grad = nvp.train_step(X, idx, g['noises'][e][b:b + 100], jitter, 1e-3, 1e-6)
+            assert abs(loss - g['losses'][k]) < 3e-5 * (1 + abs(g['losses'][k])), k
+            gref = g['grads'][k]
+            if k == 0:
+                assert np.max(np.abs(nvp.reference_vector(grad) - gref)) < 2e-5 * (1e-3 + np.max(np.abs(gref)))
+                # the unused scale_net slots carry no gradient and stay zero
+                mask = np.ones(nvp.n, bool)
+                mask[orc.reference_index_map(D, H, B, L, scale)] = False
+                assert np.all(grad[mask] == 0) and np.all(nvp.w[mask] == 0)
+            k += 1
+    # six Adam steps: movement ~6e-3; trajectories agree to a small fraction of it
+    dref = g['ws'][-1] - g['w0']
+    dour = nvp.reference_vector() - g['w0']
+    assert np.sqrt(np.mean((dour - dref) ** 2)) < 0.03 * np.sqrt(np.mean(dref ** 2))
+
+
+def _flat_keys(g, D, H, L):
+    """True at the positions of the ScaleLayer scalars in the concatenated state_dict"""
+    out = []
+    sizes = {'0.weight': H * D, '0.bias': H, '%d.weight' % (2 * L + 2): D * H, '%d.bias' % (2 * L + 2): D}
+    for k in g['keys']:
+        k = str(k)
+        if k.endswith('.scale'):
+            out.append(True)
+            continue
+        tail = '.'.join(k.split('.')[-2:])
+        out.extend([False] * sizes.get(tail, H * H if tail.endswith('weight') else H))
+    return out
