@@ -54,7 +54,14 @@ class Trainer(object):
         if scale not in ('', 'translate', 'constant'):
             raise NotImplementedError("scale=%r: SingleSpeedNVP knows '', 'translate' and 'constant' (networks.py:330-332)" % scale)
         if base_dist is not None:
-            raise NotImplementedError('only the N(0, I) base distribution is implemented')
+            # the kernels hard-wire the reference's default base N(0, I) (networks.py:51-57); an explicit
+            # MultivariateNormal(0, I) -- what the reference's notebooks pass -- is that same distribution
+            ok = isinstance(base_dist, torch.distributions.MultivariateNormal)
+            if ok:
+                mean, cov = base_dist.mean.detach().cpu(), base_dist.covariance_matrix.detach().cpu()
+                ok = mean.shape == (x_dim,) and bool(torch.all(mean == 0)) and bool(torch.equal(cov, torch.eye(x_dim)))
+            if not ok:
+                raise NotImplementedError('only the N(0, I) base distribution is implemented')
         if batch_size > 128:
             raise NotImplementedError('batch_size > 128: one workgroup holds a minibatch (nnest_train.hip)')
         # host_tensors=True: forward/inverse/... return CPU tensors and `.device` reads 'cpu' while the arithmetic
@@ -102,8 +109,9 @@ class Trainer(object):
         randomness (tests); by default the split comes from numpy's global RNG exactly as sklearn's
         train_test_split consumes it, the per-epoch shuffles from torch's CUDA generator and the jitter
         noise from the in-kernel Philox stream seeded from torch's CPU generator."""
-        if l2_norm != 0.0:
-            raise NotImplementedError('l2_norm != 0 (the reference default is 0; nested.py:313 never sets it)')
+        # l2_norm (trainer.py:395-399): loss += l2_norm * sum(param^2) after the reported loss is taken, i.e. the
+        # gradient gains 2 * l2_norm * w -- the same term Adam's coupled weight decay adds (g += weight_decay * w)
+        weight_decay = self.weight_decay + 2.0 * float(l2_norm)
         start_time = time.time()
         samples = np.asarray(samples)
         if self.path:
@@ -133,7 +141,7 @@ class Trainer(object):
             nz = None if noises is None else torch.as_tensor(noises[done:done + chunk])
             res = self.netG.train_epochs(x_train, x_valid, perm, nz, seed=seed, jitter=training_jitter,
                                          batch=self.batch_size, max_epochs=chunk, patience=patience,
-                                         lr=self.learning_rate, weight_decay=self.weight_decay, epoch_offset=done,
+                                         lr=self.learning_rate, weight_decay=weight_decay, epoch_offset=done,
                                          resume=result is not None, finalize=(done + chunk >= max_iters), result=result)
             result = res['result']
             ran = res['epochs_run'] - done

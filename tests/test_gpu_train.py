@@ -165,3 +165,29 @@ def test_training_jitter_vs_oracle(hip):
     out = torch.zeros(1, dtype=torch.float64, device='cuda')
     _lib.check(_lib.load().nnest_training_jitter(_lib.ptr(xd), 500, 20, _lib.ptr(out), _lib.current_stream(xd.device)))
     assert abs(float(out) - orc.training_jitter(X)) < 1e-12
+
+
+def test_l2_norm_and_explicit_standard_normal_base(hip, tmp_path):
+    """Trainer.train(l2_norm=...) (trainer.py:395-399) adds 2 * l2_norm * w to every gradient, which is Adam's coupled
+    weight decay with weight_decay + 2 * l2_norm; base_dist = MultivariateNormal(0, I) is the default base."""
+    from nnest_amd.trainer import Trainer
+    rng = np.random.RandomState(0)
+    D, N, E = 5, 230, 3
+    live = rng.uniform(-1, 1, size=(N, D))
+    split = rng.permutation(N)
+    perms = np.stack([rng.permutation(N - 23) for _ in range(E)]).astype(np.int32)
+    noises = rng.normal(size=(E, N - 23, D)).astype(np.float32)
+    outs = []
+    for l2, wd in ((0.01, 1e-6), (0.0, 1e-6 + 0.02)):
+        base = torch.distributions.MultivariateNormal(torch.zeros(D), torch.eye(D))
+        t = Trainer(D, log_dir=None, learning_rate=1e-3, weight_decay=wd, seed=1, log_level=30, base_dist=base)
+        t.train(live, max_iters=E, jitter=0.01, split=split, perms=perms, noises=noises, l2_norm=l2)
+        outs.append(t.netG.store_packed())
+    assert np.max(np.abs(outs[0] - outs[1])) < 1e-7
+    w0 = Trainer(D, log_dir=None, seed=1, log_level=30).netG.store_packed()
+    o = orc.NVP(D, 16, 3, 1, w0)
+    o.train(live, split, perms, noises, 0.01, E, wd=1e-6 + 0.02)
+    d_ref, d_our = o.w - w0, outs[0] - w0
+    assert np.sqrt(np.mean((d_our - d_ref) ** 2)) < 0.03 * np.sqrt(np.mean(d_ref ** 2))
+    with pytest.raises(NotImplementedError):
+        Trainer(D, log_dir=None, base_dist=torch.distributions.MultivariateNormal(torch.ones(D), torch.eye(D)))
