@@ -20,6 +20,8 @@ Fixture families:
   G6 nested_cfg1.json seeded end-to-end NestedSampler.run on config 1 (nnest/nested.py:97-510)
   G7 trainrun_*.npz   Trainer.train() for a few epochs: split, per-epoch perms, noise, losses
                       (nnest/trainer.py:134-245)
+  G9 spline_*.npz     SingleSpeedSpline (nnest/networks.py:393-715): passes before / after ActNorm's data-dependent
+                      initialisation, gradients and Adam steps, a trained state
   G8 scale_*.npz      SingleSpeedNVP with scale='translate' / 'constant' (nnest/networks.py:289-347): passes,
                       gradients and Adam steps
 """
@@ -455,8 +457,91 @@ def gen_scale_variants():
             print('G8 scale', scale, name, 'nparams', w0.size, 'loss0', losses[0])
 
 
+# ----------------------------------------------------------------------------------------------
+# G9: neural-spline flow, SingleSpeedSpline (networks.py:393-715): [ActNorm, Invertible1x1Conv, NSF_CL] x B.
+# The fixed permutations P of the 1x1 convs are plain attributes (not in the state_dict): stored beside the weights.
+# Sequence recorded (ActNorm initialises itself from the first batch that is pushed FORWARD, networks.py:698-705):
+#   raw state -> inverse(z0) -> forward(x_first) [data-dependent init happens here] -> forward / inverse / log_probs
+#   on a second batch -> one loss + autograd gradient -> Adam minibatch steps -> a trained state.
+# ----------------------------------------------------------------------------------------------
+def spline_P(netG):
+    return np.stack([f.P.detach().cpu().numpy().astype(np.float32) for f in netG.flow.flows if hasattr(f, 'P')])
+
+
+def gen_spline():
+    for name, D, H, B in [('d2', 2, 16, 3), ('d5', 5, 16, 3), ('d8_h32', 8, 32, 2), ('d50', 50, 16, 3)]:
+        np.random.seed(0)
+        torch.manual_seed(6)
+        t = Trainer(D, hidden_dim=H, num_blocks=B, flow='spline', log_dir=None, learning_rate=1e-3,
+                    log_level=logging.WARNING)
+        out = {'D': D, 'H': H, 'B': B, 'K': 8, 'tail': 3.0, 'P': spline_P(t.netG),
+               'keys': np.array(list(t.netG.state_dict().keys()))}
+        out['w_raw'] = pack_state_dict(t.netG)
+        z0 = (0.8 * np.random.randn(48, D)).astype(np.float32)
+        z0[:3] *= 5.0                                   # rows reaching outside the spline interval [-3, 3]
+        xi, ldi = t.inverse(z0, to_numpy=True)
+        out.update(z0=z0, x_inv_raw=xi, ld_inv_raw=ldi)
+        x_first = np.random.uniform(-1, 1, size=(100, D)).astype(np.float32)
+        zf, ldf = t.forward(x_first, to_numpy=True)     # ActNorm data-dependent init
+        out.update(x_first=x_first, z_first=zf, ld_first=ldf, w_init=pack_state_dict(t.netG))
+        x = np.random.uniform(-1, 1, size=(64, D)).astype(np.float32)
+        x[:2] *= 6.0
+        # gradient + Adam steps from the initialised state
+        n, jitter = 230, 0.02
+        X = np.random.uniform(-1, 1, size=(n, D)).astype(np.float32)
+        t2 = copy.deepcopy(t)
+        t2.optimizer = torch.optim.Adam(t2.netG.parameters(), lr=1e-3, weight_decay=1e-6)
+        torch.manual_seed(11)
+        rng_state = torch.get_rng_state()
+        perms, noises = [], []
+        for e in range(2):
+            pp, nz = replay_loader_rng(n, 100, D)
+            perms.append(pp)
+            noises.append(nz)
+        losses, grads, ws = [], [], []
+        Xt = torch.from_numpy(X)
+        t2.netG.train()
+        for e in range(2):
+            for b in range(0, n, 100):
+                idx = torch.from_numpy(perms[e][b:b + 100].astype(np.int64))
+                data = Xt[idx] + jitter * torch.from_numpy(noises[e][b:b + 100])
+                t2.optimizer.zero_grad()
+                loss = -t2.netG.log_probs(data).mean()
+                loss.backward()
+                grads.append(pack_grads(t2.netG))
+                t2.optimizer.step()
+                losses.append(loss.item())
+                ws.append(pack_state_dict(t2.netG))
+        out.update(X=X, jitter=jitter, perms=np.stack(perms), noises=np.stack(noises), losses=np.array(losses),
+                   grads=np.stack(grads[:2]), ws=np.stack([ws[0], ws[-1]]))
+        for tag in ('init', 'trained'):
+            if tag == 'trained':
+                # the reference's own _train on the same generator state must land on the replayed weights
+                torch.set_rng_state(rng_state)
+                ds = torch.utils.data.TensorDataset(Xt)
+                loader = torch.utils.data.DataLoader(ds, batch_size=100, shuffle=True)
+                for e in range(2):
+                    t._train(e + 1, loader, jitter=jitter)
+                assert np.array_equal(pack_state_dict(t.netG), ws[-1]), 'replay differs from reference _train'
+                np.random.seed(1)
+                torch.manual_seed(1)
+                t.train(np.random.uniform(-1, 1, size=(300, D)), max_iters=30, jitter=0.01)
+            z, ldz = t.forward(x, to_numpy=True)
+            xb, ldb = t.inverse(z, to_numpy=True)
+            lp = t.log_probs(x, to_numpy=True)
+            zs = (0.9 * np.random.RandomState(3).randn(64, D)).astype(np.float32)
+            xs, lds = t.inverse(zs, to_numpy=True)
+            out.update({'w_' + tag: pack_state_dict(t.netG), 'x': x, 'z_' + tag: z, 'ldf_' + tag: ldz, 'xb_' + tag: xb,
+                        'ldi_' + tag: ldb, 'lp_' + tag: lp, 'zs': zs, 'xs_' + tag: xs, 'lds_' + tag: lds})
+        np.savez_compressed(os.path.join(OUT, 'spline_%s.npz' % name), **out)
+        print('G9 spline', name, 'nparams', out['w_raw'].size, 'loss0', losses[0], 'roundtrip',
+              np.abs(out['xb_trained'] - x).max())
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested', 'scale']
+    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested', 'scale', 'spline']
+    if 'spline' in which:
+        gen_spline()
     if 'scale' in which:
         gen_scale_variants()
     if 'flow' in which:

@@ -20,7 +20,7 @@ LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'mixture': 1, 'gaussianmix': 1, 'him
 
 def build(force=False):
     """Compile the C restatement (gcc; seconds)."""
-    src = [os.path.join(_HERE, f) for f in ('nnest_oracle.c', 'nnest_oracle_impl.h', 'Makefile')]
+    src = [os.path.join(_HERE, f) for f in ('nnest_oracle.c', 'nnest_oracle_impl.h', 'spline_oracle_impl.h', 'Makefile')]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(['make', '-C', _HERE, '--no-print-directory'], stdout=subprocess.DEVNULL)
     return _SO
@@ -42,6 +42,9 @@ def lib():
                      'orc_valid_loss', 'orc_training_jitter', 'orc32_nvp_loss_grad', 'orc64_nvp_loss_grad'):
             getattr(L, name).restype = ctypes.c_double
         L.orc_mcmc_sample.restype = ctypes.c_int
+        L.orc_spline_num_params.restype = ctypes.c_int
+        L.spl32_spline_log_probs.restype = ctypes.c_double
+        L.spl64_spline_log_probs.restype = ctypes.c_double
         _lib = L
     return _lib
 
@@ -206,6 +209,73 @@ class NVP(object):
         self.w = best_w
         return dict(train_losses=np.array(tl), valid_losses=np.array(vl), best_validation_loss=best,
                     best_validation_epoch=best_epoch, epochs_run=len(tl))
+
+
+class Spline(object):
+    """SingleSpeedSpline (nnest/networks.py:708-715): [ActNorm, Invertible1x1Conv, NSF_CL] x B with packed
+    (state_dict-order) fp32 weights and the B fixed permutation matrices P (not part of the state_dict)."""
+
+    def __init__(self, D, H=16, B=3, K=8, tail=3.0, weights=None, P=None):
+        self.D, self.H, self.B, self.K, self.tail = int(D), int(H), int(B), int(K), float(tail)
+        self.n = lib().orc_spline_num_params(self.D, self.H, self.B, self.K)
+        self.w = np.zeros(self.n, np.float32) if weights is None else _f32(weights).copy()
+        assert self.w.size == self.n, (self.w.size, self.n)
+        self.P = _f32(np.tile(np.eye(self.D), (self.B, 1, 1)) if P is None else P).reshape(self.B, self.D, self.D).copy()
+
+    def _args(self, f64):
+        t = ctypes.c_double(self.tail) if f64 else ctypes.c_float(self.tail)
+        return (_p(self.w, _fp), _p(self.P, _fp), self.D, self.H, self.B, self.K, t)
+
+    def forward(self, x, f64=False, data_init=False):
+        """NormalizingFlow.forward (networks.py:24-32); data_init: ActNorm's first-batch initialisation
+        (networks.py:698-705), written into self.w"""
+        x = np.atleast_2d(x)
+        N = x.shape[0]
+        if f64:
+            xi = _f64(x); z = np.empty((N, self.D)); ld = np.empty(N)
+            lib().spl64_spline_forward(*self._args(True), _p(xi, _dp), N, _p(z, _dp), _p(ld, _dp), int(data_init))
+        else:
+            xi = _f32(x); z = np.empty((N, self.D), np.float32); ld = np.empty(N, np.float32)
+            lib().spl32_spline_forward(*self._args(False), _p(xi, _fp), N, _p(z, _fp), _p(ld, _fp), int(data_init))
+        return z, ld
+
+    def inverse(self, z, f64=False):
+        """NormalizingFlow.inverse (networks.py:34-42)"""
+        z = np.atleast_2d(z)
+        N = z.shape[0]
+        if f64:
+            zi = _f64(z); x = np.empty((N, self.D)); ld = np.empty(N)
+            lib().spl64_spline_inverse(*self._args(True), _p(zi, _dp), N, _p(x, _dp), _p(ld, _dp))
+        else:
+            zi = _f32(z); x = np.empty((N, self.D), np.float32); ld = np.empty(N, np.float32)
+            lib().spl32_spline_inverse(*self._args(False), _p(zi, _fp), N, _p(x, _fp), _p(ld, _fp))
+        return x, ld
+
+    def log_probs(self, x, f64=False, data_init=False):
+        """NormalizingFlowModel.log_probs (networks.py:71-76) -> (log_probs, -mean)"""
+        x = np.atleast_2d(x)
+        N = x.shape[0]
+        if f64:
+            xi = _f64(x); lp = np.empty(N)
+            loss = lib().spl64_spline_log_probs(*self._args(True), _p(xi, _dp), N, _p(lp, _dp), int(data_init))
+        else:
+            xi = _f32(x); lp = np.empty(N, np.float32)
+            loss = lib().spl32_spline_log_probs(*self._args(False), _p(xi, _fp), N, _p(lp, _fp), int(data_init))
+        return lp, loss
+
+    def fd_grad(self, X, idx, h=5e-5):
+        """central finite differences (float64 arithmetic, float32 weights) of loss = -mean(log_probs(X)) for the
+        packed parameters `idx`: the yardstick for hand-written backward passes"""
+        out = np.empty(len(idx))
+        for k, i in enumerate(idx):
+            w0 = self.w[i]
+            self.w[i] = np.float32(w0 + h); hp = float(self.w[i]) - float(w0)
+            lp_ = self.log_probs(X, f64=True)[1]
+            self.w[i] = np.float32(w0 - h); hm = float(w0) - float(self.w[i])
+            lm_ = self.log_probs(X, f64=True)[1]
+            self.w[i] = w0
+            out[k] = (lp_ - lm_) / (hp + hm)
+        return out
 
 
 def loglike(name, x_unit, scale, params=None):

@@ -261,3 +261,63 @@ def _flat_keys(g, D, H, L):
         tail = '.'.join(k.split('.')[-2:])
         out.extend([False] * sizes.get(tail, H * H if tail.endswith('weight') else H))
     return out
+
+
+SPLINE_FILES = sorted(glob.glob(os.path.join(G, 'spline_*.npz')))
+
+
+@pytest.mark.parametrize('path', SPLINE_FILES, ids=[os.path.basename(p)[7:-4] for p in SPLINE_FILES])
+def test_spline_flow(path):
+    """SingleSpeedSpline (networks.py:393-715): ActNorm -> 1x1 conv -> RQ-spline coupling, per block."""
+    g = np.load(path)
+    D, H, B, K = int(g['D']), int(g['H']), int(g['B']), int(g['K'])
+    sp = orc.Spline(D, H, B, K, float(g['tail']), g['w_raw'], g['P'])
+    assert sp.n == g['w_raw'].size
+    # 1. inverse on the raw (randn ActNorm) state, including rows outside the spline interval
+    # (randn s: e^{-s} factors of up to ~10 per block amplify float32 rounding; the allowance is a few times what this
+    # file's own float32 path is off its float64 path by, floor 2e-5)
+    xi, ldi = sp.inverse(g['z0'])
+    xi64, ldi64 = sp.inverse(g['z0'], f64=True)
+    tol = max(2e-5, 4 * rel(xi, xi64))
+    assert rel(xi, g['x_inv_raw']) < tol and rel(xi64, g['x_inv_raw']) < tol
+    assert rel(ldi, g['ld_inv_raw']) < tol
+    # 2. first forward = data-dependent ActNorm initialisation (networks.py:698-705)
+    zf, ldf = sp.forward(g['x_first'], data_init=True)
+    assert rel(zf, g['z_first']) < 3e-5
+    assert rel(ldf, g['ld_first']) < 3e-5
+    s_t = np.concatenate([np.arange(2 * D) + b * (sp.n // B) for b in range(B)])
+    assert np.max(np.abs(sp.w[s_t] - g['w_init'][s_t])) < 2e-5
+    other = np.setdiff1d(np.arange(sp.n), s_t)
+    assert np.array_equal(sp.w[other], g['w_raw'][other])
+    # 3. passes on the initialised and on the trained state
+    for tag in ('init', 'trained'):
+        sp = orc.Spline(D, H, B, K, float(g['tail']), g['w_' + tag], g['P'])
+        x = g['x']
+        z, ld = sp.forward(x)
+        assert rel(z, g['z_' + tag]) < 2e-5
+        assert rel(ld, g['ldf_' + tag]) < 2e-5
+        xb, ldb = sp.inverse(g['z_' + tag])
+        assert rel(xb, g['xb_' + tag]) < 3e-5
+        assert rel(ldb, g['ldi_' + tag]) < 3e-5
+        xs, lds = sp.inverse(g['zs'])
+        assert rel(xs, g['xs_' + tag]) < 3e-5
+        assert rel(lds, g['lds_' + tag]) < 3e-5
+        lp, _ = sp.log_probs(x)
+        assert rel(lp, g['lp_' + tag]) < 3e-5
+        # float64 yardstick: agrees with the reference's float32 and round-trips
+        z64, ld64 = sp.forward(x, f64=True)
+        assert rel(z64, g['z_' + tag]) < 2e-5
+        xb64, ldb64 = sp.inverse(z64, f64=True)
+        assert np.max(np.abs(xb64 - x)) < 1e-9 and np.max(np.abs(ld64 + ldb64)) < 1e-9
+    # 4. loss of the first recorded minibatch, and the reference's autograd gradient against finite differences
+    sp = orc.Spline(D, H, B, K, float(g['tail']), g['w_init'], g['P'])
+    data = g['X'][g['perms'][0][:100]] + np.float32(g['jitter']) * g['noises'][0][:100]
+    _, loss = sp.log_probs(data)
+    assert abs(loss - g['losses'][0]) < 2e-5 * (1 + abs(g['losses'][0]))
+    gref = g['grads'][0]
+    rng = np.random.RandomState(0)
+    big = np.argsort(-np.abs(gref))[:200]
+    idx = np.concatenate([rng.choice(big, 12, replace=False), rng.choice(sp.n, 12, replace=False)])
+    fd = sp.fd_grad(data, idx)
+    # the loss is piecewise smooth (LeakyReLU kinks, bin edges): differences across a kink cost a fraction of a percent
+    assert np.max(np.abs(fd - gref[idx])) < 1e-2 * np.max(np.abs(gref)) + 1e-5
