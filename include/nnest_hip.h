@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 3
+#define NNEST_HIP_ABI_VERSION 4
 
 enum {
     NNEST_OK = 0,
@@ -185,6 +185,35 @@ int nnest_nvp_loss_grad(nnest_nvp_t *nvp, const float *x_dev, int M, float *grad
 /* training jitter when jitter < 0 (trainer.py:168-171): 0.2 * mean of the 2-nearest-neighbour distance
  * table (self distance 0 included) of samples_dev [N,D] float64; result to out_dev float64[1]. */
 int nnest_training_jitter(const double *samples_dev, int N, int D, double *out_dev, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Neural-spline flow: SingleSpeedSpline(num_inputs=D, hidden_dim=H, num_blocks=B, num_bins=K, tail_bound)
+ * (networks.py:708-715) = [ActNorm (:661-705), Invertible1x1Conv (:625-658), NSF_CL (:559-622)] x B.
+ * Inference entry points (this round); the training entry point follows the RealNVP one.
+ * Packed weights = the concatenated state_dict: per block  s[D] t[D] | L[D,D] S[D] U[D,D] |
+ *   f1.net.{0,2,4,6}.{weight,bias} | f2.net.{0,2,4,6}.{weight,bias}.
+ * perm = the B fixed permutation matrices P [B,D,D] of the 1x1 convolutions (networks.py:634-635: a plain attribute
+ * of the reference module, NOT in its state_dict); identity until loaded.
+ * Same calling conventions as the nnest_nvp_* functions they parallel.  num_bins must be 8 (the reference's value).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct nnest_spline nnest_spline_t;
+int nnest_spline_create(int D, int H, int B, int K, float tail_bound, nnest_spline_t **out);
+int nnest_spline_destroy(nnest_spline_t *spl);
+int nnest_spline_num_params(const nnest_spline_t *spl);
+int nnest_spline_load_weights(nnest_spline_t *spl, const float *packed_host, const float *perm_host, void *stream);
+int nnest_spline_store_weights(nnest_spline_t *spl, float *packed_host, float *perm_host, void *stream);
+/* NormalizingFlow.forward / .inverse (networks.py:24-42), NormalizingFlowModel.log_probs (networks.py:71-76) */
+int nnest_spline_forward(nnest_spline_t *spl, const float *x_dev, float *z_dev, float *logdet_dev, int N, void *stream);
+int nnest_spline_inverse(nnest_spline_t *spl, const float *z_dev, float *x_dev, float *logdet_dev, int N, void *stream);
+int nnest_spline_log_probs(nnest_spline_t *spl, const float *x_dev, float *logp_dev, int N, void *stream);
+int nnest_spline_inverse_loglike(nnest_spline_t *spl, const nnest_like_t *like, const float *z_dev, float *x_dev,
+                                 float *logdet_dev, double *logl_dev, int *inbox_dev, int N, void *stream);
+/* Sampler._mcmc_sample (sampler.py:229-463) with the spline inverse: arguments as nnest_mh_constrained_steps */
+int nnest_spline_mh_constrained_steps(nnest_spline_t *spl, const nnest_like_t *like, float *z_dev, float *x_dev,
+                                      double *logl_dev, double loglstar, float step_size, int steps, int C, int flags,
+                                      const float *noise_dz_dev, const float *noise_u_dev, uint64_t seed,
+                                      uint64_t walker_offset, float *hist_x_dev, double *hist_logl_dev, int *n_accept_dev,
+                                      int *n_call_dev, float *scale_out_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,11 @@ SIGNATURES = {
     'nnest_hip_last_error': [],
     'nnest_hip_device_info': [ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _i],
     'nnest_nvp_create': [_i, _i, _i, _i, ctypes.POINTER(_vp)],
+    'nnest_spline_create': [_i, _i, _i, _i, _f, ctypes.POINTER(_vp)],
+    'nnest_spline_destroy': [_vp],
+    'nnest_spline_num_params': [_vp],
+    'nnest_spline_load_weights': [_vp, _vp, _vp, _vp],
+    'nnest_spline_store_weights': [_vp, _vp, _vp, _vp],
     'nnest_nvp_create_scaled': [_i, _i, _i, _i, _i, ctypes.POINTER(_vp)],
     'nnest_nvp_destroy': [_vp],
     'nnest_nvp_num_params': [_vp],
@@ -73,6 +78,12 @@ SIGNATURES = {
     'nnest_loglike': [_vp, _vp, _vp, _i, _i, _vp],
     'nnest_mh_constrained_steps': [_vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i, _i, _vp, _vp, _u64, _u64,
                                    _vp, _vp, _vp, _vp, _vp, _vp],
+    'nnest_spline_forward': [_vp, _vp, _vp, _vp, _i, _vp],
+    'nnest_spline_inverse': [_vp, _vp, _vp, _vp, _i, _vp],
+    'nnest_spline_log_probs': [_vp, _vp, _vp, _i, _vp],
+    'nnest_spline_inverse_loglike': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    'nnest_spline_mh_constrained_steps': [_vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i, _i, _vp, _vp, _u64, _u64,
+                                          _vp, _vp, _vp, _vp, _vp, _vp],
     'nnest_mh_num_groups': [_vp, _i],
     'nnest_mh_fill_noise': [_vp, _vp, _i, _i, _i, _u64, _u64, _vp],
     'nnest_nvp_train': [_vp, _vp, _i, _vp, _i, _vp, _vp, _u64, _f, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp],

@@ -35,6 +35,10 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+namespace nnest {
+void set_last_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+}  // namespace nnest
+
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e__ = (expr);                                                                        \

@@ -3,12 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "flow_tile.h"
+#include "spline_tile.h"
 #include "../../include/nnest_hip.h"
 
 namespace nnest {
 
 enum { PASS_FORWARD = 0, PASS_INVERSE = 1, PASS_LOGPROB = 2, PASS_INVERSE_LOGLIKE = 3 };
 
+void set_last_error(const char *msg);  // nnest_abi.hip: the string behind nnest_hip_last_error()
 bool shape_supported(const FlowShape &s);
 hipError_t launch_repack(const float *packed, float *img, const FlowShape &s, hipStream_t st);
 hipError_t launch_zero_scale_nets(float *packed, const FlowShape &s, hipStream_t st);
@@ -22,6 +24,15 @@ hipError_t launch_loglike(const LikeSpec &like, const float *x, double *logl, in
 hipError_t launch_fill_noise(float *dz, float *u, int steps, int C, int D, uint64_t seed, uint64_t walker_offset,
                              hipStream_t st);
 int mh_num_groups(int C);
+
+// neural-spline flow (spline_kernels.h inside nnest_kernels.hip; host side in nnest_spline.hip)
+bool spline_shape_supported(const SplineShape &s);
+hipError_t launch_spline_pass(const float *img, const SplineShape &sp, int mode, const float *in, float *out, float *logdet,
+                              double *logl, int *inbox, int N, const LikeSpec &like, int num_cu, hipStream_t st);
+hipError_t launch_spline_mh(const float *img, const SplineShape &sp, const LikeSpec &like, float *z, float *x, double *logl,
+                            double loglstar, float step_size, int steps, int C, int flags, const float *noise_dz,
+                            const float *noise_u, uint64_t seed, uint64_t walker_offset, float *hist_x, double *hist_logl,
+                            int *n_accept, int *n_call, float *scale_out, int num_cu, hipStream_t st);
 
 // training (nnest_train.hip)
 struct TrainArgs;

@@ -778,4 +778,6 @@ hipError_t launch_fill_noise(float *dz, float *u, int steps, int C, int D, uint6
 
 int mh_num_groups(int C) { return (C + 15) / 16; }
 
+#include "spline_kernels.h"
+
 }  // namespace nnest

@@ -1,0 +1,162 @@
+// spline_kernels.h -- kernels of the neural-spline flow; part of the nnest_kernels.hip translation unit (included at
+// its end, inside namespace nnest) so that the proposal loop (mh_body), the noise streams, the likelihood / prior tile
+// code and the row-major tile I/O are the SAME code the RealNVP path runs.
+//
+//   spline_pass_kernel   forward / inverse / log_probs / inverse + box + likelihood   (networks.py:24-42, :71-76)
+//   spline_mh_kernel     Sampler._mcmc_sample's constrained Metropolis loop with the spline inverse (sampler.py:229-463)
+//
+// One wave per 16 walkers.  The state lives in the parity-class tiles of flow_tile.h (what mh_body, loglike_tile,
+// inbox_tile and load/store_tile work on); around each flow evaluation it is re-laid into the contiguous-halves tiles
+// of spline_tile.h through a 16 x (D+1) float LDS buffer private to the wave.  The weight image (258 KB at x_dim 50) is
+// read from global memory / L2: every fragment load is one coalesced 256-byte line per wave.
+#pragma once
+#include "spline_tile.h"
+
+struct SplArgs {
+    const float *img;
+    SplineShape sp;
+};
+
+template <int NT, int NH>
+__global__ void __launch_bounds__(256) spline_pass_kernel(PassArgs a, SplArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float lds_buf[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    float *buf = lds_buf + (size_t)wave * 16 * (q.sp.D + 1);
+    const int ntiles = (a.N + 15) >> 4;
+    const int w = lane & 15, g = lane >> 4;
+    const int D = q.sp.D;
+    for (int tile = blockIdx.x * wpb + wave; tile < ntiles; tile += gridDim.x * wpb) {
+        const int row = tile * 16 + w;
+        const bool ok = row < a.N;
+        f32x4 xs[2][NT], sp[2][NT];
+        load_tile<NT>(a.in, row, ok, D, lane, xs);
+        spl_from_parity<NT>(buf, D, q.sp.nl, lane, xs, sp);
+        float ld;
+        if (a.mode == PASS_FORWARD || a.mode == PASS_LOGPROB) ld = spline_forward_tile<NT, NH>(q.img, q.sp, lane, sp);
+        else ld = spline_inverse_tile<NT, NH>(q.img, q.sp, lane, sp);
+        ld = group_sum(ld);
+        spl_to_parity<NT>(buf, D, q.sp.nl, lane, sp, xs);
+        if (a.mode == PASS_LOGPROB) {
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int tau = 0; tau < NT; ++tau) {
+                    f32x4 v = xs[c][tau];
+                    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
+            ss = group_sum(ss);
+            if (ok && g == 0) a.out[row] = -0.5f * ss - 0.91893853320467274f * (float)D + ld;
+            continue;
+        }
+        if (a.out) store_tile<NT>(a.out, row, ok, D, lane, xs);
+        if (a.logdet && ok && g == 0) a.logdet[row] = ld;
+        if (a.mode == PASS_INVERSE_LOGLIKE) {
+            int inb = inbox_tile<NT>(xs, lane);
+            double ll = loglike_tile<NT>(a.like, D, lane, xs);
+            if (ok && g == 0) {
+                a.logl[row] = ll;
+                if (a.inbox) a.inbox[row] = inb;
+            }
+        }
+    }
+}
+
+template <int NT, int NH>
+struct SplineInverse {
+    const float *img;
+    SplineShape sp;
+    float *buf;
+    int lane;
+#ifdef NNEST_STAMP
+    unsigned long long t_mlp = 0, t_xch = 0, t_upd = 0;
+#endif
+    __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
+        f32x4 t[2][NT];
+        spl_from_parity<NT>(buf, sp.D, sp.nl, lane, xs, t);
+        const float ld = spline_inverse_tile<NT, NH>(img, sp, lane, t);
+        spl_to_parity<NT>(buf, sp.D, sp.nl, lane, t, xs);
+        return ld;
+    }
+};
+
+template <int NT, int NH, bool DBG>
+__global__ void __launch_bounds__(256) spline_mh_kernel(MhArgs a, SplArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float lds_buf[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int tile = blockIdx.x * wpb + wave;
+    if (tile >= ((a.C + 15) >> 4)) return;
+    SplineInverse<NT, NH> inv = {q.img, q.sp, lds_buf + (size_t)wave * 16 * (q.sp.D + 1), lane};
+    XoshiroNoise<NT> noise;
+    noise.init(a.seed, a.walker_offset + (uint64_t)(tile * 16 + (lane & 15)), lane >> 4, q.sp.D);
+    mh_body<NT, DBG>(a, tile, lane, inv, noise, true);
+}
+
+bool spline_shape_supported(const SplineShape &s) {
+    if (s.K != SPL_K) return false;
+    if (s.NH == 1) return s.NTh >= 1 && s.NTh <= 4;
+    if (s.NH == 2) return s.NTh >= 1 && s.NTh <= 2;
+    return false;
+}
+
+#define DISPATCH_SPLINE(FN, sp, ...)                                               \
+    do {                                                                           \
+        const int key__ = (sp).NTh * 10 + (sp).NH;                                 \
+        switch (key__) {                                                           \
+            case 11: return FN<1, 1>(__VA_ARGS__);                                 \
+            case 21: return FN<2, 1>(__VA_ARGS__);                                 \
+            case 31: return FN<3, 1>(__VA_ARGS__);                                 \
+            case 41: return FN<4, 1>(__VA_ARGS__);                                 \
+            case 12: return FN<1, 2>(__VA_ARGS__);                                 \
+            case 22: return FN<2, 2>(__VA_ARGS__);                                 \
+            default: return hipErrorInvalidConfiguration;                          \
+        }                                                                          \
+    } while (0)
+
+template <int NT, int NH>
+static hipError_t launch_spline_pass_t(const PassArgs &a, const SplArgs &q, int num_cu, hipStream_t st) {
+    const int ntiles = (a.N + 15) / 16;
+    int block, grid;
+    pick_geometry(ntiles, num_cu, 4, &block, &grid);
+    if (grid > 8 * num_cu) grid = 8 * num_cu;
+    const size_t lds = (size_t)(block / 64) * 16 * (q.sp.D + 1) * sizeof(float);
+    hipLaunchKernelGGL((spline_pass_kernel<NT, NH>), dim3(grid), dim3(block), lds, st, a, q);
+    return hipGetLastError();
+}
+
+template <int NT, int NH>
+static hipError_t launch_spline_mh_t(const MhArgs &a, const SplArgs &q, int num_cu, hipStream_t st) {
+    const int ntiles = (a.C + 15) / 16;
+    int block, grid;
+    pick_geometry(ntiles, num_cu, 4, &block, &grid);
+    const size_t lds = (size_t)(block / 64) * 16 * (q.sp.D + 1) * sizeof(float);
+    if (a.noise_dz || a.hist_x || a.hist_logl)
+        hipLaunchKernelGGL((spline_mh_kernel<NT, NH, true>), dim3(grid), dim3(block), lds, st, a, q);
+    else
+        hipLaunchKernelGGL((spline_mh_kernel<NT, NH, false>), dim3(grid), dim3(block), lds, st, a, q);
+    return hipGetLastError();
+}
+
+hipError_t launch_spline_pass(const float *img, const SplineShape &sp, int mode, const float *in, float *out, float *logdet,
+                              double *logl, int *inbox, int N, const LikeSpec &like, int num_cu, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    PassArgs a{};
+    a.mode = mode; a.in = in; a.out = out; a.logdet = logdet; a.logl = logl; a.inbox = inbox; a.N = N; a.like = like;
+    a.s.D = sp.D;
+    SplArgs q = {img, sp};
+    DISPATCH_SPLINE(launch_spline_pass_t, sp, a, q, num_cu, st);
+}
+
+hipError_t launch_spline_mh(const float *img, const SplineShape &sp, const LikeSpec &like, float *z, float *x, double *logl,
+                            double loglstar, float step_size, int steps, int C, int flags, const float *noise_dz,
+                            const float *noise_u, uint64_t seed, uint64_t walker_offset, float *hist_x, double *hist_logl,
+                            int *n_accept, int *n_call, float *scale_out, int num_cu, hipStream_t st) {
+    if (C <= 0) return hipSuccess;
+    MhArgs a{};
+    a.s.D = sp.D;
+    a.z = z; a.x = x; a.logl = logl; a.loglstar = loglstar; a.step_size = step_size; a.steps = steps; a.C = C; a.flags = flags;
+    a.like = like; a.noise_dz = noise_dz; a.noise_u = noise_u; a.seed = seed; a.walker_offset = walker_offset;
+    a.hist_x = hist_x; a.hist_logl = hist_logl; a.n_accept = n_accept; a.n_call = n_call; a.scale_out = scale_out;
+    SplArgs q = {img, sp};
+    DISPATCH_SPLINE(launch_spline_mh_t, sp, a, q, num_cu, st);
+}

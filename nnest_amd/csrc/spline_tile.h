@@ -1,0 +1,365 @@
+// spline_tile.h -- device tile code of the neural-spline flow (reference nnest/networks.py:393-715,
+// SingleSpeedSpline = [ActNorm, Invertible1x1Conv, NSF_CL] x num_blocks) for gfx950, one wave64 per 16 walkers.
+//
+// Same transposed-MFMA formulation as flow_tile.h (weights = A operand, walkers = B columns, v_mfma_f32_16x16x4_f32),
+// with a layout chosen for the spline:
+//   * the vector is held as its two CONTIGUOUS halves (NSF_CL splits lower = x[:, :nl], upper = x[:, nl:],
+//     networks.py:578-581), each padded to NTh tiles of 16 slots;  slot (t, g, r) of a half  <->  dimension
+//     j = 16 t + 4 r + g of that half, held by lane (g, w) register r of tile t for walker w.  With this numbering
+//     k-step r of tile t feeds dims {16t + 4r + g : g = 0..3} to the MFMA, i.e. a tile is at once an accumulator
+//     (C/D layout) and the B operand of the next product;
+//   * ActNorm and the 1x1 convolution are folded (at image-build time, host side) into ONE affine map per block and
+//     direction:  forward  z = x A_f + b_f  with A_f = diag(e^s) W, b_f = t W;   inverse  x = z A_b + b_b  with
+//     A_b = W^-1 diag(e^-s), b_b = -t e^-s;  their log-determinant is a per-block constant;
+//   * the last conditioner layer has (3K-1) = 23 outputs per transformed dimension.  Its rows are ordered so that one
+//     "super-tile" of 6 MFMA tiles delivers to lane (g, w) all 23 spline parameters (+1 pad) of dimension 4s + g of
+//     walker w in 24 registers: the rational-quadratic spline is then evaluated entirely in registers, with no
+//     cross-lane traffic, for 4 dimensions x 16 walkers per wave at a time.
+#pragma once
+#include "flow_tile.h"
+
+namespace nnest {
+
+enum { SPL_K = 8, SPL_P = 3 * SPL_K - 1, SPL_QT = 6 };  // bins, conditioner outputs per dim, MFMA tiles per super-tile
+
+struct SplineShape {
+    int D, H, B, K;
+    float tail;
+    int nl, nu;  // dims in the lower / upper half (nl = nu + (D odd))
+    int NTh;     // 16-slot tiles per half
+    int NH;      // H / 16
+    int SL, SU;  // super-tiles (4 dims each) of the lower / upper half
+    // image (floats), per block: [aff_f | aff_b | cond f1 | cond f2 | ldconst(4)]
+    int aff_floats;      // (2 NTh)^2 * 256 weights + 2 NTh * 16 bias
+    int f1_floats, f2_floats;
+    int blk_floats, image_floats;
+    int blk_params, num_params;  // packed (state_dict order) parameter counts
+};
+
+__host__ __device__ inline int spl_cond_hidden_floats(int NTh, int NH) {  // L1 + L2 + L3 + b1 b2 b3
+    return NH * NTh * 256 + 2 * NH * NH * 256 + 3 * 16 * NH;
+}
+__host__ __device__ inline int spl_cond_floats(int NTh, int NH, int S) {
+    return spl_cond_hidden_floats(NTh, NH) + S * SPL_QT * NH * 256 + S * SPL_QT * 16;
+}
+
+__device__ __forceinline__ f32x4 lrelu4(f32x4 v) {  // nn.LeakyReLU(0.2), networks.py:400
+    f32x4 o;
+    o.x = v.x > 0.f ? v.x : 0.2f * v.x; o.y = v.y > 0.f ? v.y : 0.2f * v.y;
+    o.z = v.z > 0.f ? v.z : 0.2f * v.z; o.w = v.w > 0.f ? v.w : 0.2f * v.w;
+    return o;
+}
+
+__device__ __forceinline__ float reg_of(const f32x4 &v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
+__device__ __forceinline__ void set_reg(f32x4 &v, int r, float x) {
+    if (r == 0) v.x = x; else if (r == 1) v.y = x; else if (r == 2) v.z = x; else v.w = x;
+}
+
+// ---- the folded ActNorm + 1x1 conv: out = in A + b over both halves ----------------------------------------------
+// image: weights [to (2 NTh)][ti (2 NTh)][r][64] then bias [to][g][r]
+template <int NTh>
+__device__ __forceinline__ void spl_affine(const float *__restrict__ aff, int lane, const f32x4 (&in)[2][NTh], f32x4 (&out)[2][NTh]) {
+    constexpr int T2 = 2 * NTh;
+    const int g = lane >> 4;
+    const float *bias = aff + T2 * T2 * 256;
+#pragma unroll
+    for (int to = 0; to < T2; ++to) {
+        f32x4 acc0 = *reinterpret_cast<const f32x4 *>(bias + (to * 4 + g) * 4);
+        f32x4 acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ti = 0; ti < T2; ++ti) {
+            const f32x4 v = in[ti / NTh][ti % NTh];
+            const float *a = aff + (size_t)((to * T2 + ti) * 4) * 64 + lane;
+            acc0 = mfma4(a[0], v.x, acc0);
+            acc1 = mfma4(a[64], v.y, acc1);
+            acc0 = mfma4(a[128], v.z, acc0);
+            acc1 = mfma4(a[192], v.w, acc1);
+        }
+        out[to / NTh][to % NTh] = acc0 + acc1;
+    }
+}
+
+// ---- conditioner trunk (networks.py:393-409): Linear(n,H) LReLU Linear(H,H) LReLU Linear(H,H) LReLU -------------
+// image: L1 [ht][t][r][64] | L2 [hto][hti][r][64] | L3 | b1[H] b2[H] b3[H]
+template <int NTh, int NH>
+__device__ __forceinline__ void spl_hidden(const float *__restrict__ net, int lane, const f32x4 (&in)[NTh], f32x4 (&h)[NH]) {
+    const int g = lane >> 4;
+    const float *L1 = net, *L2 = net + NH * NTh * 256, *L3 = L2 + NH * NH * 256, *b = L3 + NH * NH * 256;
+    f32x4 acc[NH];
+#pragma unroll
+    for (int ht = 0; ht < NH; ++ht) {
+        f32x4 a0 = *reinterpret_cast<const f32x4 *>(b + 16 * ht + 4 * g), a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NTh; ++t) {
+            const float *a = L1 + (size_t)((ht * NTh + t) * 4) * 64 + lane;
+            a0 = mfma4(a[0], in[t].x, a0);
+            a1 = mfma4(a[64], in[t].y, a1);
+            a0 = mfma4(a[128], in[t].z, a0);
+            a1 = mfma4(a[192], in[t].w, a1);
+        }
+        acc[ht] = lrelu4(a0 + a1);
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const float *Lw = l == 0 ? L2 : L3;
+        const float *bl = b + 16 * NH * (l + 1);
+        f32x4 nxt[NH];
+#pragma unroll
+        for (int hto = 0; hto < NH; ++hto) {
+            f32x4 a0 = *reinterpret_cast<const f32x4 *>(bl + 16 * hto + 4 * g), a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hti = 0; hti < NH; ++hti) {
+                const float *a = Lw + (size_t)((hto * NH + hti) * 4) * 64 + lane;
+                a0 = mfma4(a[0], acc[hti].x, a0);
+                a1 = mfma4(a[64], acc[hti].y, a1);
+                a0 = mfma4(a[128], acc[hti].z, a0);
+                a1 = mfma4(a[192], acc[hti].w, a1);
+            }
+            nxt[hto] = lrelu4(a0 + a1);
+        }
+#pragma unroll
+        for (int hto = 0; hto < NH; ++hto) acc[hto] = nxt[hto];
+    }
+#pragma unroll
+    for (int ht = 0; ht < NH; ++ht) h[ht] = acc[ht];
+}
+
+// ---- rational-quadratic spline of one scalar (networks.py:425-556, through NSF_CL's :583-587) --------------------
+// raw[24]: widths logits [0,8), heights logits [8,16), inner-derivative logits [16,23), pad.  Identity outside
+// [-tail, tail].  The reference applies softmax twice to widths/heights (NSF_CL, scaled by 2B; then RQS) and
+// softplus twice to the inner derivatives: restated as is.  Returns y; *ld += log|dy/dx|.
+__device__ __forceinline__ float spl_softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+
+__device__ __forceinline__ void spl_softmax8(const float (&in)[SPL_K], float (&out)[SPL_K]) {
+    float mx = in[0];
+#pragma unroll
+    for (int k = 1; k < SPL_K; ++k) mx = fmaxf(mx, in[k]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) { out[k] = expf(in[k] - mx); s += out[k]; }
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) out[k] = out[k] / s;
+}
+
+// knots of one axis: unnormalised -> softmax -> min bin + cumsum -> [-tail, tail]; returns the K+1 edges and K sizes
+__device__ __forceinline__ void spl_knots(const float (&logits)[SPL_K], float tail, float (&edge)[SPL_K + 1], float (&size)[SPL_K]) {
+    float a[SPL_K], u[SPL_K], p[SPL_K];
+    spl_softmax8(logits, a);
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) u[k] = 2.f * tail * a[k];
+    spl_softmax8(u, p);
+    float c = 0.f;
+    edge[0] = -tail;
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) {
+        float wk = 1e-3f + (1.f - 1e-3f * SPL_K) * p[k];
+        c += wk;
+        edge[k + 1] = (2.f * tail) * c + (-tail);
+    }
+    edge[SPL_K] = tail;
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) size[k] = edge[k + 1] - edge[k];
+}
+
+template <bool INV>
+__device__ __forceinline__ float spl_rqs(const f32x4 (&raw)[SPL_QT], float tail, float x, float &ld) {
+    float lw[SPL_K] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w};
+    float lh[SPL_K] = {raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
+    float ldv[SPL_K - 1] = {raw[4].x, raw[4].y, raw[4].z, raw[4].w, raw[5].x, raw[5].y, raw[5].z};
+    const bool inside = x >= -tail && x <= tail;
+    float cw[SPL_K + 1], wd[SPL_K], ch[SPL_K + 1], ht[SPL_K], dv[SPL_K + 1];
+    spl_knots(lw, tail, cw, wd);
+    spl_knots(lh, tail, ch, ht);
+    const float constant = logf(expf(1.f - 1e-3f) - 1.f);  // networks.py:437
+    dv[0] = 1e-3f + spl_softplus(constant);
+    dv[SPL_K] = dv[0];
+#pragma unroll
+    for (int k = 1; k < SPL_K; ++k) dv[k] = 1e-3f + spl_softplus(spl_softplus(ldv[k - 1]));
+    // searchsorted (networks.py:417-422): edges <= x, last edge + 1e-6
+    int bin = -1;
+#pragma unroll
+    for (int k = 0; k <= SPL_K; ++k) {
+        float e = INV ? ch[k] : cw[k];
+        if (k == SPL_K) e += 1e-6f;
+        bin += (x >= e) ? 1 : 0;
+    }
+    bin = bin < 0 ? 0 : (bin > SPL_K - 1 ? SPL_K - 1 : bin);
+    float icw = cw[0], ibw = wd[0], ich = ch[0], ih = ht[0], d0 = dv[0], d1 = dv[1];
+#pragma unroll
+    for (int k = 1; k < SPL_K; ++k) {
+        const bool s = bin == k;
+        icw = s ? cw[k] : icw; ibw = s ? wd[k] : ibw; ich = s ? ch[k] : ich; ih = s ? ht[k] : ih;
+        d0 = s ? dv[k] : d0; d1 = s ? dv[k + 1] : d1;
+    }
+    const float delta = ih / ibw;
+    float out, lad;
+    if (INV) {  // networks.py:515-539
+        const float dx = x - ich, sdd = d0 + d1 - 2.f * delta;
+        const float a = dx * sdd + ih * (delta - d0);
+        const float b = ih * d0 - dx * sdd;
+        const float c = -delta * dx;
+        const float disc = b * b - 4.f * a * c;
+        const float root = (2.f * c) / (-b - sqrtf(disc));
+        out = root * ibw + icw;
+        const float tomt = root * (1.f - root);
+        const float den = delta + sdd * tomt;
+        const float num = delta * delta * (d1 * root * root + 2.f * delta * tomt + d0 * (1.f - root) * (1.f - root));
+        lad = -(logf(num) - 2.f * logf(den));
+    } else {  // networks.py:541-556
+        const float theta = (x - icw) / ibw;
+        const float tomt = theta * (1.f - theta);
+        const float numer = ih * (delta * theta * theta + d0 * tomt);
+        const float den = delta + (d0 + d1 - 2.f * delta) * tomt;
+        out = ich + numer / den;
+        const float num = delta * delta * (d1 * theta * theta + 2.f * delta * tomt + d0 * (1.f - theta) * (1.f - theta));
+        lad = logf(num) - 2.f * logf(den);
+    }
+    ld += inside ? lad : 0.f;
+    return inside ? out : x;
+}
+
+// ---- one RQ-spline coupling: the `n_out` dims of `tr` are transformed, conditioned on `cond` ----------------------
+// net image: hidden part (spl_hidden) | L4 [s][q][hti][r][64] | b4 [s][q][g][r]
+template <int NTh, int NH, bool INV>
+__device__ __forceinline__ float spl_coupling(const float *__restrict__ net, int S, int n_out, float tail, int lane,
+                                              const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh]) {
+    const int g = lane >> 4;
+    f32x4 h[NH];
+    spl_hidden<NTh, NH>(net, lane, cond, h);
+    const float *L4 = net + spl_cond_hidden_floats(NTh, NH);
+    const float *b4 = L4 + (size_t)S * SPL_QT * NH * 256;
+    float ld = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4 * NTh; ++s) {
+        if (s < S) {  // uniform over the wave
+            f32x4 raw[SPL_QT];
+#pragma unroll
+            for (int q = 0; q < SPL_QT; ++q) {
+                f32x4 acc = *reinterpret_cast<const f32x4 *>(b4 + ((s * SPL_QT + q) * 4 + g) * 4);
+#pragma unroll
+                for (int hti = 0; hti < NH; ++hti) {
+                    const float *a = L4 + (size_t)(((s * SPL_QT + q) * NH + hti) * 4) * 64 + lane;
+                    acc = mfma4(a[0], h[hti].x, acc);
+                    acc = mfma4(a[64], h[hti].y, acc);
+                    acc = mfma4(a[128], h[hti].z, acc);
+                    acc = mfma4(a[192], h[hti].w, acc);
+                }
+                raw[q] = acc;
+            }
+            // lane (g, w): dimension 4 s + g of the transformed half = slot (t = s >> 2, g, r = s & 3)
+            const float x = reg_of(tr[s >> 2], s & 3);
+            float l = 0.f;
+            const float y = spl_rqs<INV>(raw, tail, x, l);
+            const bool valid = 4 * s + g < n_out;
+            set_reg(tr[s >> 2], s & 3, valid ? y : 0.f);
+            ld += valid ? l : 0.f;
+        }
+    }
+    return ld;
+}
+
+// ---- the stack -----------------------------------------------------------------------------------------------
+// xs[0] = lower half tiles, xs[1] = upper half tiles.  Returns this lane's log-det partial (sum over the 4 lanes of a
+// walker = the row's log-det); the per-block constants are added on lane group 0.
+template <int NTh, int NH>
+__device__ __forceinline__ float spline_forward_tile(const float *__restrict__ img, const SplineShape &s, int lane, f32x4 (&xs)[2][NTh]) {
+    float ld = 0.f;
+    for (int b = 0; b < s.B; ++b) {
+        const float *blk = img + (size_t)b * s.blk_floats;
+        f32x4 y[2][NTh];
+        spl_affine<NTh>(blk, lane, xs, y);
+        const float *f1 = blk + 2 * s.aff_floats, *f2 = f1 + s.f1_floats;
+        ld += spl_coupling<NTh, NH, false>(f1, s.SU, s.nu, s.tail, lane, y[0], y[1]);   // upper | lower  (networks.py:582-588)
+        ld += spl_coupling<NTh, NH, false>(f2, s.SL, s.nl, s.tail, lane, y[1], y[0]);   // lower | new upper (:589-598)
+        if (lane < 16) ld += (f2 + s.f2_floats)[0];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < NTh; ++t) xs[c][t] = y[c][t];
+    }
+    return ld;
+}
+
+template <int NTh, int NH>
+__device__ __forceinline__ float spline_inverse_tile(const float *__restrict__ img, const SplineShape &s, int lane, f32x4 (&xs)[2][NTh]) {
+    float ld = 0.f;
+    for (int b = s.B - 1; b >= 0; --b) {
+        const float *blk = img + (size_t)b * s.blk_floats;
+        const float *f1 = blk + 2 * s.aff_floats, *f2 = f1 + s.f1_floats;
+        ld += spl_coupling<NTh, NH, true>(f2, s.SL, s.nl, s.tail, lane, xs[1], xs[0]);  // networks.py:605-614
+        ld += spl_coupling<NTh, NH, true>(f1, s.SU, s.nu, s.tail, lane, xs[0], xs[1]);  // :615-621
+        f32x4 y[2][NTh];
+        spl_affine<NTh>(blk + s.aff_floats, lane, xs, y);
+        if (lane < 16) ld -= (f2 + s.f2_floats)[0];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < NTh; ++t) xs[c][t] = y[c][t];
+    }
+    return ld;
+}
+
+// ---- layout exchange with the row-major / parity-class tiles of flow_tile.h (one wave, through LDS) ----------------
+// buf: 16 rows x (D + 1) floats owned by this wave
+template <int NT>
+__device__ __forceinline__ void spl_from_parity(float *buf, int D, int nl, int lane, const f32x4 (&xs)[2][NT], f32x4 (&sp)[2][NT]) {
+    const int w = lane & 15, g = lane >> 4;
+    float *row = buf + w * (D + 1);
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        float v[8] = {xs[0][tau].x, xs[1][tau].x, xs[0][tau].y, xs[1][tau].y, xs[0][tau].z, xs[1][tau].z, xs[0][tau].w, xs[1][tau].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = 32 * tau + 8 * g + j;
+            if (d < D) row[d] = v[j];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are visible to its own lanes
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * t + 4 * r + g, n = hf ? D - nl : nl;
+                v[r] = j < n ? row[(hf ? nl : 0) + j] : 0.f;
+            }
+            sp[hf][t] = (f32x4){v[0], v[1], v[2], v[3]};
+        }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NT>
+__device__ __forceinline__ void spl_to_parity(float *buf, int D, int nl, int lane, const f32x4 (&sp)[2][NT], f32x4 (&xs)[2][NT]) {
+    const int w = lane & 15, g = lane >> 4;
+    float *row = buf + w * (D + 1);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float v[4] = {sp[hf][t].x, sp[hf][t].y, sp[hf][t].z, sp[hf][t].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * t + 4 * r + g, n = hf ? D - nl : nl;
+                if (j < n) row[(hf ? nl : 0) + j] = v[r];
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = 32 * tau + 8 * g + j;
+            v[j] = d < D ? row[d] : 0.f;
+        }
+        xs[0][tau] = (f32x4){v[0], v[2], v[4], v[6]};
+        xs[1][tau] = (f32x4){v[1], v[3], v[5], v[7]};
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace nnest

@@ -27,7 +27,110 @@ def _as_dev_f32(x, device):
 SCALE_MODES = {'': 0, 'translate': 1, 'constant': 2}
 
 
-class HipNVP(object):
+class _HipFlow(object):
+    """What the two flow families share: the pass / proposal entry points differ only in the C symbol
+    (`self._sym[...]`, set by the subclass) -- same tensors in, same tensors out."""
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def parameters(self):
+        return list(self.state_dict().values())
+
+    def _pass(self, fn, x, want_logdet=True):
+        x = _as_dev_f32(x, self.device)
+        N = x.shape[0]
+        if x.shape[1] != self.D:
+            raise ValueError('expected [N, %d], got %s' % (self.D, tuple(x.shape)))
+        out = torch.empty_like(x)
+        ld = torch.empty(N, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(fn(self._h, _lib.ptr(x), _lib.ptr(out), _lib.ptr(ld), N, _lib.current_stream(self.device)))
+        return out, ld
+
+    def forward(self, x):
+        """NormalizingFlow.forward (networks.py:24-32): (z, log_det)"""
+        return self._pass(self._sym['forward'], x)
+
+    def inverse(self, z):
+        """NormalizingFlow.inverse (networks.py:34-42): (x, log_det)"""
+        return self._pass(self._sym['inverse'], z)
+
+    def log_probs(self, x):
+        """NormalizingFlowModel.log_probs (networks.py:71-76)"""
+        x = _as_dev_f32(x, self.device)
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._sym['log_probs'](self._h, _lib.ptr(x), _lib.ptr(out), x.shape[0],
+                                              _lib.current_stream(self.device)))
+        return out
+
+    def sample(self, num_samples=None, noise=None):
+        """NormalizingFlowModel.sample (networks.py:78-84)"""
+        if noise is None:
+            noise = torch.randn(num_samples, self.D, device=self.device)
+        x, _ = self.inverse(noise)
+        return x
+
+    def inverse_loglike(self, like_id, like_scale, z, want_x=True, like_params=None):
+        """K3: x = f^-1(z), logdet, box-prior flag, logl = loglike(like_scale * x) in one launch."""
+        z = _as_dev_f32(z, self.device)
+        N = z.shape[0]
+        x = torch.empty_like(z) if want_x else None
+        ld = torch.empty(N, dtype=torch.float32, device=self.device)
+        logl = torch.empty(N, dtype=torch.float64, device=self.device)
+        inbox = torch.empty(N, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            lk = _lib.like_spec(like_id, like_scale, like_params)
+            _lib.check(self._sym['inverse_loglike'](self._h, ctypes.byref(lk), _lib.ptr(z),
+                                                    _lib.ptr(x), _lib.ptr(ld), _lib.ptr(logl), _lib.ptr(inbox), N,
+                                                    _lib.current_stream(self.device)))
+        return x, ld, logl, inbox
+
+    def mh_steps(self, like_id, like_scale, z, logl, loglstar, step_size, steps, dynamic=False, noise=None, seed=0,
+                 walker_offset=0, history=False, like_params=None):
+        """K4: `steps` constrained Metropolis steps for all walkers in one launch (Sampler._mcmc_sample,
+        sampler.py:229-463).  z [C,D] float32 and logl [C] float64 are updated in place.
+        noise = (dz [steps,C,D], u [steps,C]) replays recorded draws; None = in-kernel Philox."""
+        assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()
+        assert logl.is_cuda and logl.dtype == torch.float64 and logl.is_contiguous()
+        C = z.shape[0]
+        dev = self.device
+        x = torch.empty_like(z)
+        n_acc = torch.zeros(C, dtype=torch.int32, device=dev)
+        n_call = torch.zeros(C, dtype=torch.int32, device=dev)
+        ngroups = (C + 15) // 16
+        scale_out = torch.empty(max(ngroups, 1), dtype=torch.float32, device=dev)
+        hx = torch.empty(C, steps + 1, self.D, dtype=torch.float32, device=dev) if history else None
+        hl = torch.empty(C, steps + 1, dtype=torch.float64, device=dev) if history else None
+        dz = u = None
+        if noise is not None:
+            dz = _as_dev_f32(noise[0].reshape(-1, self.D), dev)
+            u = noise[1].to(device=dev, dtype=torch.float32).contiguous()
+            assert dz.shape[0] == steps * C and u.numel() == steps * C
+        with torch.cuda.device(dev):
+            lk = _lib.like_spec(like_id, like_scale, like_params)
+            _lib.check(self._sym['mh'](
+                self._h, ctypes.byref(lk), _lib.ptr(z), _lib.ptr(x), _lib.ptr(logl), float(loglstar),
+                float(step_size), int(steps), C, _lib.MH_DYNAMIC_STEP if dynamic else 0, _lib.ptr(dz), _lib.ptr(u),
+                int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), _lib.ptr(hx), _lib.ptr(hl), _lib.ptr(n_acc),
+                _lib.ptr(n_call), _lib.ptr(scale_out), _lib.current_stream(dev)))
+        return dict(x=x, n_accept=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl)
+
+    def fill_noise(self, steps, C, seed=0, walker_offset=0):
+        dz = torch.empty(steps, C, self.D, dtype=torch.float32, device=self.device)
+        u = torch.empty(steps, C, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_mh_fill_noise(_lib.ptr(dz), _lib.ptr(u), steps, C, self.D,
+                                                     int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset),
+                                                     _lib.current_stream(self.device)))
+        return dz, u
+
+
+class HipNVP(_HipFlow):
     """num_inputs=D, num_hidden=H, num_blocks=B, num_layers=L, scale as SingleSpeedNVP (networks.py:328-347).
 
     scale='translate' / 'constant' (translate-only couplings; 'constant' adds a ScaleLayer scalar after each block):
@@ -45,6 +148,9 @@ class HipNVP(object):
             raise ValueError("scale=%r: expected '', 'translate' or 'constant' (networks.py:330-332)" % (scale,))
         self.scale = scale
         self._lib = _lib.load()
+        L = self._lib
+        self._sym = dict(forward=L.nnest_nvp_forward, inverse=L.nnest_nvp_inverse, log_probs=L.nnest_nvp_log_probs,
+                         inverse_loglike=L.nnest_nvp_inverse_loglike, mh=L.nnest_mh_constrained_steps)
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.nnest_nvp_create_scaled(self.D, self.H, self.B, self.L, SCALE_MODES[scale],
@@ -177,97 +283,6 @@ class HipNVP(object):
                                                      v.ctypes.data_as(ctypes.c_void_p), _lib.current_stream(self.device)))
             _lib.check(self._lib.nnest_nvp_adam_state(self._h, None, int(step), 0, _lib.current_stream(self.device)))
 
-    # nn.Module look-alikes the reference's Sampler calls (sampler.py:246, :553, :611, :647)
-    def eval(self):
-        return self
-
-    def train(self, mode=True):
-        return self
-
-    def parameters(self):
-        return list(self.state_dict().values())
-
-    # ---- flow passes -----------------------------------------------------------------------------
-    def _pass(self, fn, x, want_logdet=True):
-        x = _as_dev_f32(x, self.device)
-        N = x.shape[0]
-        if x.shape[1] != self.D:
-            raise ValueError('expected [N, %d], got %s' % (self.D, tuple(x.shape)))
-        out = torch.empty_like(x)
-        ld = torch.empty(N, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(fn(self._h, _lib.ptr(x), _lib.ptr(out), _lib.ptr(ld), N, _lib.current_stream(self.device)))
-        return out, ld
-
-    def forward(self, x):
-        """NormalizingFlow.forward (networks.py:24-32): (z, log_det)"""
-        return self._pass(self._lib.nnest_nvp_forward, x)
-
-    def inverse(self, z):
-        """NormalizingFlow.inverse (networks.py:34-42): (x, log_det)"""
-        return self._pass(self._lib.nnest_nvp_inverse, z)
-
-    def log_probs(self, x):
-        """NormalizingFlowModel.log_probs (networks.py:71-76)"""
-        x = _as_dev_f32(x, self.device)
-        out = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(self._lib.nnest_nvp_log_probs(self._h, _lib.ptr(x), _lib.ptr(out), x.shape[0],
-                                                     _lib.current_stream(self.device)))
-        return out
-
-    def sample(self, num_samples=None, noise=None):
-        """NormalizingFlowModel.sample (networks.py:78-84)"""
-        if noise is None:
-            noise = torch.randn(num_samples, self.D, device=self.device)
-        x, _ = self.inverse(noise)
-        return x
-
-    def inverse_loglike(self, like_id, like_scale, z, want_x=True, like_params=None):
-        """K3: x = f^-1(z), logdet, box-prior flag, logl = loglike(like_scale * x) in one launch."""
-        z = _as_dev_f32(z, self.device)
-        N = z.shape[0]
-        x = torch.empty_like(z) if want_x else None
-        ld = torch.empty(N, dtype=torch.float32, device=self.device)
-        logl = torch.empty(N, dtype=torch.float64, device=self.device)
-        inbox = torch.empty(N, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
-            lk = _lib.like_spec(like_id, like_scale, like_params)
-            _lib.check(self._lib.nnest_nvp_inverse_loglike(self._h, ctypes.byref(lk), _lib.ptr(z),
-                                                           _lib.ptr(x), _lib.ptr(ld), _lib.ptr(logl), _lib.ptr(inbox), N,
-                                                           _lib.current_stream(self.device)))
-        return x, ld, logl, inbox
-
-    def mh_steps(self, like_id, like_scale, z, logl, loglstar, step_size, steps, dynamic=False, noise=None, seed=0,
-                 walker_offset=0, history=False, like_params=None):
-        """K4: `steps` constrained Metropolis steps for all walkers in one launch (Sampler._mcmc_sample,
-        sampler.py:229-463).  z [C,D] float32 and logl [C] float64 are updated in place.
-        noise = (dz [steps,C,D], u [steps,C]) replays recorded draws; None = in-kernel Philox."""
-        assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()
-        assert logl.is_cuda and logl.dtype == torch.float64 and logl.is_contiguous()
-        C = z.shape[0]
-        dev = self.device
-        x = torch.empty_like(z)
-        n_acc = torch.zeros(C, dtype=torch.int32, device=dev)
-        n_call = torch.zeros(C, dtype=torch.int32, device=dev)
-        ngroups = self._lib.nnest_mh_num_groups(self._h, C)
-        scale_out = torch.empty(max(ngroups, 1), dtype=torch.float32, device=dev)
-        hx = torch.empty(C, steps + 1, self.D, dtype=torch.float32, device=dev) if history else None
-        hl = torch.empty(C, steps + 1, dtype=torch.float64, device=dev) if history else None
-        dz = u = None
-        if noise is not None:
-            dz = _as_dev_f32(noise[0].reshape(-1, self.D), dev)
-            u = noise[1].to(device=dev, dtype=torch.float32).contiguous()
-            assert dz.shape[0] == steps * C and u.numel() == steps * C
-        with torch.cuda.device(dev):
-            lk = _lib.like_spec(like_id, like_scale, like_params)
-            _lib.check(self._lib.nnest_mh_constrained_steps(
-                self._h, ctypes.byref(lk), _lib.ptr(z), _lib.ptr(x), _lib.ptr(logl), float(loglstar),
-                float(step_size), int(steps), C, _lib.MH_DYNAMIC_STEP if dynamic else 0, _lib.ptr(dz), _lib.ptr(u),
-                int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), _lib.ptr(hx), _lib.ptr(hl), _lib.ptr(n_acc),
-                _lib.ptr(n_call), _lib.ptr(scale_out), _lib.current_stream(dev)))
-        return dict(x=x, n_accept=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl)
-
     def loss_grad(self, x):
         """loss = -mean(log_probs(x)) and dloss/dw (packed order) for one minibatch of <= 128 rows
         (loss.backward(), trainer.py:394-400), no weight update."""
@@ -311,15 +326,6 @@ class HipNVP(object):
         fl = r[2:4].view(torch.float32)
         return dict(losses=losses, epochs_run=int(r[0]), best_epoch=int(r[1]), best_validation_loss=float(fl[0]),
                     last_train_loss=float(fl[1]), counter=int(r[4]), stopped=bool(int(r[5])), result=result)
-
-    def fill_noise(self, steps, C, seed=0, walker_offset=0):
-        dz = torch.empty(steps, C, self.D, dtype=torch.float32, device=self.device)
-        u = torch.empty(steps, C, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(self._lib.nnest_mh_fill_noise(_lib.ptr(dz), _lib.ptr(u), steps, C, self.D,
-                                                     int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset),
-                                                     _lib.current_stream(self.device)))
-        return dz, u
 
 
 def loglike(like_id, x_unit, like_scale, device=None, like_params=None):

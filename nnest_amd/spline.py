@@ -1,0 +1,138 @@
+"""HipSpline: the neural-spline flow resident on one MI355X, driven through the C ABI.
+
+Mirrors SingleSpeedSpline (reference nnest/networks.py:708-715): [ActNorm, Invertible1x1Conv, NSF_CL] x num_blocks,
+rational-quadratic splines with num_bins = 8 on [-tail_bound, tail_bound].  forward / inverse / log_probs / sample and
+the fused proposal kernel run as HIP kernels (nnest_amd/csrc/spline_tile.h); no PyTorch arithmetic is used for the flow.
+
+state_dict() has the reference's keys and order (flow.flows.<3b>.s/.t, <3b+1>.L/.S/.U, <3b+2>.f1/f2.net.{0,2,4,6}).
+The fixed permutations P of the 1x1 convolutions are plain attributes of the reference module (networks.py:634-635),
+absent from its state_dict: they travel as `P` ([num_blocks, D, D]).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .flow import _HipFlow
+
+
+class HipSpline(_HipFlow):
+
+    def __init__(self, num_inputs, hidden_dim=16, num_blocks=3, num_bins=8, tail_bound=3.0, device=None, seed=None):
+        if not torch.cuda.is_available():
+            raise _lib.NnestHipError('HipSpline needs an MI355X visible to PyTorch-ROCm (torch.cuda.is_available() is '
+                                     'False); there is no CPU fallback')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.D, self.H, self.B, self.K = int(num_inputs), int(hidden_dim), int(num_blocks), int(num_bins)
+        self.tail_bound = float(tail_bound)
+        self.num_inputs = self.D
+        self.nu = self.D // 2
+        self.nl = self.D - self.nu
+        self._lib = _lib.load()
+        L = self._lib
+        self._sym = dict(forward=L.nnest_spline_forward, inverse=L.nnest_spline_inverse, log_probs=L.nnest_spline_log_probs,
+                         inverse_loglike=L.nnest_spline_inverse_loglike, mh=L.nnest_spline_mh_constrained_steps)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.nnest_spline_create(self.D, self.H, self.B, self.K, ctypes.c_float(self.tail_bound),
+                                             ctypes.byref(self._h)))
+        self.num_params = L.nnest_spline_num_params(self._h)
+        self.prior = torch.distributions.MultivariateNormal(torch.zeros(self.D, device=self.device),
+                                                            torch.eye(self.D, device=self.device))
+        self.data_dep_init_done = False
+        w, P = self.default_init(seed)
+        self.load_packed(w, P)
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None) is not None and self._h.value:
+                self._lib.nnest_spline_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def layer_shapes(self):
+        """[(name, shape)] in torch state_dict order"""
+        out = []
+        D, H, Pn = self.D, self.H, 3 * self.K - 1
+        for b in range(self.B):
+            out += [('flow.flows.%d.s' % (3 * b), (1, D)), ('flow.flows.%d.t' % (3 * b), (1, D))]
+            out += [('flow.flows.%d.L' % (3 * b + 1), (D, D)), ('flow.flows.%d.S' % (3 * b + 1), (D,)),
+                    ('flow.flows.%d.U' % (3 * b + 1), (D, D))]
+            for f, nin, nout in (('f1', self.nl, Pn * self.nu), ('f2', self.nu, Pn * self.nl)):
+                dims = [(H, nin), (H, H), (H, H), (nout, H)]
+                for i, (o, k) in enumerate(dims):
+                    out.append(('flow.flows.%d.%s.net.%d.weight' % (3 * b + 2, f, 2 * i), (o, k)))
+                    out.append(('flow.flows.%d.%s.net.%d.bias' % (3 * b + 2, f, 2 * i), (o,)))
+        return out
+
+    def default_init(self, seed=None):
+        """The reference's construction (networks.py:630-638, :669-670, nn.Linear defaults): ActNorm s, t ~ N(0,1)
+        (replaced by the data-dependent initialisation on the first forward batch); 1x1 conv from the LU
+        decomposition of a random orthogonal matrix; Linear layers U(-1/sqrt(fan_in), 1/sqrt(fan_in))."""
+        g = torch.Generator()
+        g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()) if seed is None else int(seed))
+        D = self.D
+        parts, Ps = [], []
+        for name, shape in self.layer_shapes():
+            leaf = name.split('.')[-1]
+            if leaf in ('s', 't'):
+                parts.append(torch.randn(D, generator=g))
+            elif leaf == 'L':
+                Q = torch.linalg.qr(torch.randn(D, D, generator=g, dtype=torch.float64))[0]
+                P, L, U = torch.linalg.lu(Q)
+                Ps.append(P.to(torch.float32))
+                self._lu = (L, U)
+                parts.append(L.to(torch.float32).reshape(-1))
+            elif leaf == 'S':
+                parts.append(torch.diagonal(self._lu[1]).to(torch.float32))
+            elif leaf == 'U':
+                parts.append(torch.triu(self._lu[1], diagonal=1).to(torch.float32).reshape(-1))
+            else:
+                fan_in = shape[1] if len(shape) == 2 else last_fan_in
+                last_fan_in = fan_in
+                n = int(np.prod(shape))
+                parts.append((torch.rand(n, generator=g) * 2 - 1) / math.sqrt(fan_in))
+        return torch.cat(parts).numpy().astype(np.float32), torch.stack(Ps).numpy()
+
+    def load_packed(self, packed, P=None):
+        packed = np.ascontiguousarray(packed, dtype=np.float32)
+        if packed.size != self.num_params:
+            raise ValueError('expected %d packed weights, got %d' % (self.num_params, packed.size))
+        pp = None
+        if P is not None:
+            P = np.ascontiguousarray(P, dtype=np.float32)
+            if P.shape != (self.B, self.D, self.D):
+                raise ValueError('P: expected %s, got %s' % ((self.B, self.D, self.D), P.shape))
+            pp = P.ctypes.data_as(ctypes.c_void_p)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_spline_load_weights(self._h, packed.ctypes.data_as(ctypes.c_void_p), pp,
+                                                           _lib.current_stream(self.device)))
+
+    def store_packed(self):
+        out = np.empty(self.num_params, np.float32)
+        _lib.check(self._lib.nnest_spline_store_weights(self._h, out.ctypes.data_as(ctypes.c_void_p), None, None))
+        return out
+
+    @property
+    def P(self):
+        out = np.empty((self.B, self.D, self.D), np.float32)
+        _lib.check(self._lib.nnest_spline_store_weights(self._h, None, out.ctypes.data_as(ctypes.c_void_p), None))
+        return out
+
+    def state_dict(self):
+        packed = self.store_packed()
+        sd, off = {}, 0
+        for name, shape in self.layer_shapes():
+            n = int(np.prod(shape))
+            sd[name] = torch.from_numpy(packed[off:off + n].reshape(shape).copy())
+            off += n
+        return sd
+
+    def load_state_dict(self, sd, P=None):
+        self.load_packed(np.concatenate([np.asarray(sd[name].detach().cpu().numpy() if torch.is_tensor(sd[name])
+                                                    else sd[name], dtype=np.float32).ravel()
+                                         for name, _ in self.layer_shapes()]), P)
