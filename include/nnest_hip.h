@@ -189,7 +189,6 @@ int nnest_training_jitter(const double *samples_dev, int N, int D, double *out_d
 /* ---------------------------------------------------------------------------------------------------------------
  * Neural-spline flow: SingleSpeedSpline(num_inputs=D, hidden_dim=H, num_blocks=B, num_bins=K, tail_bound)
  * (networks.py:708-715) = [ActNorm (:661-705), Invertible1x1Conv (:625-658), NSF_CL (:559-622)] x B.
- * Inference entry points (this round); the training entry point follows the RealNVP one.
  * Packed weights = the concatenated state_dict: per block  s[D] t[D] | L[D,D] S[D] U[D,D] |
  *   f1.net.{0,2,4,6}.{weight,bias} | f2.net.{0,2,4,6}.{weight,bias}.
  * perm = the B fixed permutation matrices P [B,D,D] of the 1x1 convolutions (networks.py:634-635: a plain attribute
@@ -214,6 +213,21 @@ int nnest_spline_mh_constrained_steps(nnest_spline_t *spl, const nnest_like_t *l
                                       const float *noise_dz_dev, const float *noise_u_dev, uint64_t seed,
                                       uint64_t walker_offset, float *hist_x_dev, double *hist_logl_dev, int *n_accept_dev,
                                       int *n_call_dev, float *scale_out_dev, void *stream);
+
+/* Training.  ActNorm's data-dependent initialisation (networks.py:698-705): s = -log std(x) (unbiased), t = -mean(x e^s)
+ * block after block from the batch x_dev [N,D] -- in the reference this happens inside the first forward pass of a
+ * fresh model, which under Trainer.train is the first (jittered) minibatch. */
+int nnest_spline_actnorm_init(nnest_spline_t *spl, const float *x_dev, int N, void *stream);
+/* loss = -mean(log_probs(x)) and its gradient wrt the packed weights (loss.backward(), trainer.py:394-400) */
+int nnest_spline_loss_grad(nnest_spline_t *spl, const float *x_dev, int M, float *grad_dev, float *loss_dev, void *stream);
+/* Trainer.train's epoch loop (trainer.py:198-241) as nnest_nvp_train, except that the loop is driven from the host
+ * (six small launches per minibatch, one read-back per epoch): losses_host [max_epochs,2] and result_host are HOST
+ * pointers, the best-validation weights are restored on return and the call synchronises `stream`.  The Adam moments
+ * persist across calls like torch.optim.Adam's state. */
+int nnest_spline_train(nnest_spline_t *spl, const float *xtrain_dev, int n_train, const float *xvalid_dev, int n_valid,
+                       const int *perm_dev, const float *noise_dev, uint64_t seed, float jitter, int batch, int max_epochs,
+                       int patience, float lr, float weight_decay, float *losses_host, nnest_train_result_t *result_host,
+                       void *stream);
 
 #ifdef __cplusplus
 }

@@ -18,17 +18,10 @@
 
 using namespace nnest;
 
-struct nnest_spline {
-    SplineShape s;
-    int device, num_cu;
-    std::vector<float> w;     // packed weights, state_dict order (host master copy)
-    std::vector<float> perm;  // B x D x D permutation matrices P (fixed, not part of the state_dict)
-    std::vector<float> img_host;
-    float *img;               // device fragment image
-};
+#include "spline_host.h"
 
 static thread_local char g_serr[512] = "";
-static int sfail(int code, const char *fmt, ...) {
+int nnest::spline_fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_serr, sizeof(g_serr), fmt, ap);
@@ -36,13 +29,9 @@ static int sfail(int code, const char *fmt, ...) {
     nnest::set_last_error(g_serr);  // read back through nnest_hip_last_error()
     return code;
 }
-#define SHIP_TRY(expr)                                                                                  \
-    do {                                                                                                \
-        hipError_t e__ = (expr);                                                                        \
-        if (e__ != hipSuccess) return sfail(NNEST_E_HIP, "%s: %s", #expr, hipGetErrorString(e__));      \
-    } while (0)
 
-static int mlp_params(int nin, int nout, int H) { return H * nin + H + 2 * (H * H + H) + nout * H + nout; }
+
+int nnest::spline_mlp_params(int nin, int nout, int H) { return H * nin + H + 2 * (H * H + H) + nout * H + nout; }
 
 static SplineShape make_shape(int D, int H, int B, int K, float tail) {
     SplineShape s;
@@ -58,7 +47,7 @@ static SplineShape make_shape(int D, int H, int B, int K, float tail) {
     s.blk_floats = 2 * s.aff_floats + s.f1_floats + s.f2_floats + 4;
     s.image_floats = B * s.blk_floats;
     const int P = 3 * K - 1;
-    s.blk_params = 2 * D + (2 * D * D + D) + mlp_params(s.nl, P * s.nu, H) + mlp_params(s.nu, P * s.nl, H);
+    s.blk_params = 2 * D + (2 * D * D + D) + spline_mlp_params(s.nl, P * s.nu, H) + spline_mlp_params(s.nu, P * s.nl, H);
     s.num_params = B * s.blk_params;
     return s;
 }
@@ -160,7 +149,7 @@ static bool invert(std::vector<double> &A, int D, std::vector<double> &Ai) {  //
     return true;
 }
 
-static int build_image(nnest_spline *h) {
+int nnest::spline_build_image(nnest_spline *h) {
     const SplineShape &s = h->s;
     const int D = s.D;
     h->img_host.assign((size_t)s.image_floats, 0.f);
@@ -168,7 +157,7 @@ static int build_image(nnest_spline *h) {
     for (int b = 0; b < s.B; ++b) {
         const float *pb = h->w.data() + (size_t)b * s.blk_params;
         const float *sv = pb, *tv = pb + D, *Lp = pb + 2 * D, *Sp = Lp + D * D, *Up = Sp + D, *f1 = Up + D * D;
-        const float *f2 = f1 + mlp_params(s.nl, SPL_P * s.nu, s.H);
+        const float *f2 = f1 + spline_mlp_params(s.nl, SPL_P * s.nu, s.H);
         const float *Pm = h->perm.data() + (size_t)b * D * D;
         for (int i = 0; i < D; ++i)
             for (int j = 0; j < D; ++j) Lm[(size_t)i * D + j] = j < i ? (double)Lp[i * D + j] : (i == j ? 1.0 : 0.0);
@@ -187,7 +176,7 @@ static int build_image(nnest_spline *h) {
             }
         for (int d = 0; d < D; ++d) ldc += (double)sv[d] + log(fabs((double)Sp[d]));
         Wc = W;
-        if (!invert(Wc, D, Wi)) return sfail(NNEST_E_ARG, "block %d: the 1x1 convolution matrix is singular", b);
+        if (!invert(Wc, D, Wi)) return spline_fail(NNEST_E_ARG, "block %d: the 1x1 convolution matrix is singular", b);
         float *blk = h->img_host.data() + (size_t)b * s.blk_floats;
         for (int i = 0; i < D; ++i)
             for (int j = 0; j < D; ++j) M[(size_t)i * D + j] = exp((double)sv[i]) * W[(size_t)i * D + j];
@@ -211,20 +200,20 @@ static int build_image(nnest_spline *h) {
 extern "C" {
 
 int nnest_spline_create(int D, int H, int B, int K, float tail_bound, nnest_spline_t **out) {
-    if (!out) return sfail(NNEST_E_ARG, "out is NULL");
+    if (!out) return spline_fail(NNEST_E_ARG, "out is NULL");
     *out = nullptr;
-    if (D < 2 || H < 1 || B < 1 || K < 1 || !(tail_bound > 0)) return sfail(NNEST_E_ARG, "bad shape D=%d H=%d B=%d K=%d", D, H, B, K);
-    if (H % 16 != 0) return sfail(NNEST_E_UNSUPPORTED, "hidden_dim=%d: the gfx950 kernels tile the hidden layers by 16", H);
+    if (D < 2 || H < 1 || B < 1 || K < 1 || !(tail_bound > 0)) return spline_fail(NNEST_E_ARG, "bad shape D=%d H=%d B=%d K=%d", D, H, B, K);
+    if (H % 16 != 0) return spline_fail(NNEST_E_UNSUPPORTED, "hidden_dim=%d: the gfx950 kernels tile the hidden layers by 16", H);
     SplineShape s = make_shape(D, H, B, K, tail_bound);
     if (!spline_shape_supported(s))
-        return sfail(NNEST_E_UNSUPPORTED, "spline flow: x_dim=%d hidden_dim=%d num_bins=%d not instantiated (num_bins 8; x_dim <= 128 at "
+        return spline_fail(NNEST_E_UNSUPPORTED, "spline flow: x_dim=%d hidden_dim=%d num_bins=%d not instantiated (num_bins 8; x_dim <= 128 at "
                      "hidden_dim 16, <= 64 at 32)", D, H, K);
     nnest_spline *h = new nnest_spline();
     h->s = s;
     h->img = nullptr;
-    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return sfail(NNEST_E_HIP, "hipGetDevice failed (no GPU?)"); }
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return spline_fail(NNEST_E_HIP, "hipGetDevice failed (no GPU?)"); }
     hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, h->device) != hipSuccess) { delete h; return sfail(NNEST_E_HIP, "hipGetDeviceProperties failed"); }
+    if (hipGetDeviceProperties(&p, h->device) != hipSuccess) { delete h; return spline_fail(NNEST_E_HIP, "hipGetDeviceProperties failed"); }
     h->num_cu = p.multiProcessorCount;
     h->w.assign((size_t)s.num_params, 0.f);
     h->perm.assign((size_t)B * D * D, 0.f);
@@ -232,7 +221,7 @@ int nnest_spline_create(int D, int H, int B, int K, float tail_bound, nnest_spli
         for (int i = 0; i < D; ++i) h->perm[((size_t)b * D + i) * D + i] = 1.f;
     if (hipMalloc((void **)&h->img, (size_t)s.image_floats * sizeof(float)) != hipSuccess) {
         delete h;
-        return sfail(NNEST_E_HIP, "device allocation failed");
+        return spline_fail(NNEST_E_HIP, "device allocation failed");
     }
     *out = h;
     return NNEST_OK;
@@ -241,6 +230,9 @@ int nnest_spline_create(int D, int H, int B, int K, float tail_bound, nnest_spli
 int nnest_spline_destroy(nnest_spline_t *h) {
     if (!h) return NNEST_OK;
     (void)hipFree(h->img);
+    (void)hipFree(h->w_dev); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->best_w); (void)hipFree(h->pi_dev);
+    (void)hipFree(h->wmat); (void)hipFree(h->timg); (void)hipFree(h->partial); (void)hipFree(h->grad); (void)hipFree(h->gwsum);
+    (void)hipFree(h->stash); (void)hipFree(h->losses_dev);
     delete h;
     return NNEST_OK;
 }
@@ -248,10 +240,11 @@ int nnest_spline_destroy(nnest_spline_t *h) {
 int nnest_spline_num_params(const nnest_spline_t *h) { return h ? h->s.num_params : -1; }
 
 int nnest_spline_load_weights(nnest_spline_t *h, const float *packed_host, const float *perm_host, void *stream) {
-    if (!h || !packed_host) return sfail(NNEST_E_ARG, "NULL argument");
+    if (!h || !packed_host) return spline_fail(NNEST_E_ARG, "NULL argument");
     memcpy(h->w.data(), packed_host, h->w.size() * sizeof(float));
     if (perm_host) memcpy(h->perm.data(), perm_host, h->perm.size() * sizeof(float));
-    int rc = build_image(h);
+    h->w_dev_current = false;  // the training copy on the device is refreshed on its next use
+    int rc = spline_build_image(h);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     SHIP_TRY(hipMemcpyAsync(h->img, h->img_host.data(), h->img_host.size() * sizeof(float), hipMemcpyHostToDevice, st));
@@ -261,24 +254,24 @@ int nnest_spline_load_weights(nnest_spline_t *h, const float *packed_host, const
 
 int nnest_spline_store_weights(nnest_spline_t *h, float *packed_host, float *perm_host, void *stream) {
     (void)stream;
-    if (!h) return sfail(NNEST_E_ARG, "NULL handle");
+    if (!h) return spline_fail(NNEST_E_ARG, "NULL handle");
     if (packed_host) memcpy(packed_host, h->w.data(), h->w.size() * sizeof(float));
     if (perm_host) memcpy(perm_host, h->perm.data(), h->perm.size() * sizeof(float));
     return NNEST_OK;
 }
 
 static int scheck_rows(const nnest_spline_t *h, const void *a, const void *b, int N) {
-    if (!h) return sfail(NNEST_E_ARG, "NULL handle");
-    if (N < 0) return sfail(NNEST_E_ARG, "N=%d < 0", N);
-    if (N > 0 && (!a || !b)) return sfail(NNEST_E_ARG, "NULL device buffer");
+    if (!h) return spline_fail(NNEST_E_ARG, "NULL handle");
+    if (N < 0) return spline_fail(NNEST_E_ARG, "N=%d < 0", N);
+    if (N > 0 && (!a || !b)) return spline_fail(NNEST_E_ARG, "NULL device buffer");
     return NNEST_OK;
 }
 
 static int scheck_like(const nnest_like_t *like, int D, LikeSpec *out) {
-    if (!like) return sfail(NNEST_E_ARG, "like is NULL");
-    if (like->id < 0 || like->id >= NNEST_LIKE_COUNT) return sfail(NNEST_E_ARG, "unknown likelihood id %d", like->id);
-    if (like->id == NNEST_LIKE_EGGBOX && D != 2) return sfail(NNEST_E_ARG, "Eggbox is defined for x_dim = 2 (likelihoods.py:97-102)");
-    if (like->id == NNEST_LIKE_GAUSSMIX && D < 2) return sfail(NNEST_E_ARG, "GaussianMix needs x_dim >= 2");
+    if (!like) return spline_fail(NNEST_E_ARG, "like is NULL");
+    if (like->id < 0 || like->id >= NNEST_LIKE_COUNT) return spline_fail(NNEST_E_ARG, "unknown likelihood id %d", like->id);
+    if (like->id == NNEST_LIKE_EGGBOX && D != 2) return spline_fail(NNEST_E_ARG, "Eggbox is defined for x_dim = 2 (likelihoods.py:97-102)");
+    if (like->id == NNEST_LIKE_GAUSSMIX && D < 2) return spline_fail(NNEST_E_ARG, "GaussianMix needs x_dim >= 2");
     out->id = like->id;
     out->scale = like->scale;
     for (int i = 0; i < 6; ++i) out->p[i] = like->params[i];
@@ -329,9 +322,9 @@ int nnest_spline_mh_constrained_steps(nnest_spline_t *h, const nnest_like_t *lik
     if (rc) return rc;
     LikeSpec lk;
     if ((rc = scheck_like(like, h->s.D, &lk))) return rc;
-    if (steps < 0) return sfail(NNEST_E_ARG, "steps=%d < 0", steps);
+    if (steps < 0) return spline_fail(NNEST_E_ARG, "steps=%d < 0", steps);
     if ((noise_dz_dev == nullptr) != (noise_u_dev == nullptr))
-        return sfail(NNEST_E_ARG, "noise_dz_dev and noise_u_dev must both be given or both be NULL");
+        return spline_fail(NNEST_E_ARG, "noise_dz_dev and noise_u_dev must both be given or both be NULL");
     SHIP_TRY(launch_spline_mh(h->img, h->s, lk, z_dev, x_dev, logl_dev, loglstar, step_size, steps, C, flags, noise_dz_dev,
                               noise_u_dev, seed, walker_offset, hist_x_dev, hist_logl_dev, n_accept_dev, n_call_dev,
                               scale_out_dev, h->num_cu, (hipStream_t)stream));

@@ -1,0 +1,939 @@
+// nnest_spline_train.hip -- Trainer.train for the neural-spline flow (reference nnest/trainer.py:134-245, :384-418 on
+// SingleSpeedSpline, networks.py:393-715).
+//
+// Per minibatch (<= 128 rows), all on the device:
+//   1 spl_assemble_kernel   W = P (tril(L,-1)+I) (triu(U,1)+diag(S)) per block (networks.py:640-645)
+//   2 spl_timage_kernel     MFMA fragment images of W, W^T and of both conditioners (forward and transposed)
+//   3 spl_grad_kernel       one wave per 16 rows: forward (block inputs stashed), loss, hand-written backward one block
+//                           at a time (spline_train_tile.h); per-wave partial gradients, no atomics
+//   4 spl_reduce_kernel     fixed-order sum of the partials (+ the constant log-det terms of ActNorm / conv)
+//   5 spl_lu_grad_kernel    dLoss/dW -> dLoss/d(L, S, U)
+//   6 spl_adam_kernel       torch.optim.Adam with coupled weight decay (trainer.py:121-122)
+// Per epoch one forward-only launch of (3) gives the validation loss; the host reads back the epoch's losses (one
+// small copy) and keeps the reference's early-stopping bookkeeping (trainer.py:198-241).  ActNorm's data-dependent
+// initialisation (networks.py:698-705) runs as spl_init_kernel on the first batch pushed forward through a fresh flow.
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+#include "spline_host.h"
+#include "spline_train_tile.h"
+
+using namespace nnest;
+
+namespace nnest {
+
+static SplTrainShape make_train_shape(const SplineShape &s) {
+    SplTrainShape t;
+    memset(&t, 0, sizeof(t));
+    t.s = s;
+    const int T2 = 2 * s.NTh;
+    t.conv_floats = T2 * T2 * 256;
+    t.cf[0] = s.f1_floats; t.cf[1] = s.f2_floats;
+    t.cb[0] = spl_cond_bwd_floats(s.NTh, s.NH, s.SU);
+    t.cb[1] = spl_cond_bwd_floats(s.NTh, s.NH, s.SL);
+    t.tblk_floats = 2 * t.conv_floats + t.cf[0] + t.cf[1] + t.cb[0] + t.cb[1] + 4;
+    t.timage_floats = s.B * t.tblk_floats;
+    const int D = s.D;
+    t.p_s = 0; t.p_t = D; t.p_L = 2 * D; t.p_S = t.p_L + D * D; t.p_U = t.p_S + D;
+    t.p_f[0] = t.p_U + D * D;
+    t.p_f[1] = t.p_f[0] + spline_mlp_params(s.nl, SPL_P * s.nu, s.H);
+    t.gw_floats = s.num_params + s.B * D * D + 4;
+    return t;
+}
+
+// slot (half, tile, k-step r, lane group g) -> dimension or -1
+__host__ __device__ inline int tslot_dim(const SplineShape &s, int hf, int t, int r, int g) {
+    const int j = 16 * t + 4 * r + g, n = hf ? s.nu : s.nl;
+    return j < n ? (hf ? s.nl : 0) + j : -1;
+}
+// row i of an MFMA tile (accumulator row 4g+r <-> i) of half hf, tile t -> dimension or -1
+__host__ __device__ inline int trow_dim(const SplineShape &s, int hf, int t, int i) { return tslot_dim(s, hf, t, i & 3, i >> 2); }
+
+// ---- 1: W per block ---------------------------------------------------------------------------------------------
+__global__ void spl_assemble_kernel(const float *__restrict__ w, const int *__restrict__ pi, float *__restrict__ wmat, SplTrainShape ts) {
+    const int D = ts.s.D, n = ts.s.B * D * D;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        const int b = idx / (D * D), i = (idx / D) % D, j = idx % D;
+        const float *pb = w + (size_t)b * ts.s.blk_params;
+        const float *Lp = pb + ts.p_L, *Sp = pb + ts.p_S, *Up = pb + ts.p_U;
+        const int r = pi[b * D + i];  // (P Lm)[i][k] = Lm[r][k]
+        const int kmax = r < j ? r : j;
+        float acc = 0.f;
+        for (int k = 0; k <= kmax; ++k) {
+            const float l = k < r ? Lp[r * D + k] : 1.f;
+            const float u = k < j ? Up[k * D + j] : Sp[k];
+            acc += l * u;
+        }
+        wmat[idx] = acc;
+    }
+}
+
+// ---- 2: training image -------------------------------------------------------------------------------------------
+__device__ inline float cond_fwd_value(const SplineShape &s, const float *p, int nin, int nout, int o) {
+    const int H = s.H, NH = s.NH, NTh = s.NTh, S = (nout + 3) / 4, P = SPL_P;
+    const float *W0 = p, *b0 = W0 + H * nin, *W1 = b0 + H, *b1 = W1 + H * H, *W2 = b1 + H, *b2 = W2 + H * H, *W3 = b2 + H,
+                *b3 = W3 + (size_t)P * nout * H;
+    const int oL2 = NH * NTh * 256, oL3 = oL2 + NH * NH * 256, ob = oL3 + NH * NH * 256, oL4 = ob + 3 * 16 * NH, ob4 = oL4 + S * SPL_QT * NH * 256;
+    if (o < oL2) {
+        const int lane = o & 63, q = o >> 6, r = q & 3, t = (q >> 2) % NTh, ht = (q >> 2) / NTh;
+        const int g = lane >> 4, i = lane & 15, j = 16 * t + 4 * r + g;
+        return j < nin ? W0[(16 * ht + i) * nin + j] : 0.f;
+    } else if (o < ob) {
+        const int oo = o < oL3 ? o - oL2 : o - oL3;
+        const float *W = o < oL3 ? W1 : W2;
+        const int lane = oo & 63, q = oo >> 6, r = q & 3, hti = (q >> 2) % NH, hto = (q >> 2) / NH;
+        const int g = lane >> 4, i = lane & 15;
+        return W[(16 * hto + i) * H + 16 * hti + 4 * g + r];
+    } else if (o < oL4) {
+        const int oo = o - ob, l = oo / H, j = oo % H;
+        return l == 0 ? b0[j] : (l == 1 ? b1[j] : b2[j]);
+    } else if (o < ob4) {
+        const int oo = o - oL4;
+        const int lane = oo & 63, q4 = oo >> 6, r = q4 & 3, hti = (q4 >> 2) % NH, sq = (q4 >> 2) / NH, q = sq % SPL_QT, sidx = sq / SPL_QT;
+        const int g = lane >> 4, i = lane & 15;
+        const int jo = 4 * sidx + (i >> 2), pp = 4 * q + (i & 3);
+        return (jo < nout && pp < P) ? W3[(size_t)(jo * P + pp) * H + 16 * hti + 4 * g + r] : 0.f;
+    } else {
+        const int oo = o - ob4, r = oo & 3, g = (oo >> 2) & 3, sq = oo >> 4, q = sq % SPL_QT, sidx = sq / SPL_QT;
+        const int jo = 4 * sidx + g, pp = 4 * q + r;
+        return (jo < nout && pp < P) ? b3[jo * P + pp] : 0.f;
+    }
+}
+
+__device__ inline float cond_bwd_value(const SplineShape &s, const float *p, int nin, int nout, int o) {
+    const int H = s.H, NH = s.NH, NTh = s.NTh, P = SPL_P;
+    const float *W0 = p, *W1 = W0 + H * nin + H, *W2 = W1 + H * H + H, *W3 = W2 + H * H + H;
+    const int oB2 = NTh * NH * 256, oB3 = oB2 + NH * NH * 256, oB4 = oB3 + NH * NH * 256;
+    if (o < oB2) {  // B1 [t][ht][r][64]: W0[16ht+4g+r][dim of (tile t, row i)]
+        const int lane = o & 63, q = o >> 6, r = q & 3, ht = (q >> 2) % NH, t = (q >> 2) / NH;
+        const int g = lane >> 4, i = lane & 15, j = 16 * t + 4 * (i & 3) + (i >> 2);
+        return j < nin ? W0[(16 * ht + 4 * g + r) * nin + j] : 0.f;
+    } else if (o < oB4) {  // B2 / B3 [hti][hto][r][64]: W[16hto+4g+r][16hti+i]
+        const int oo = o < oB3 ? o - oB2 : o - oB3;
+        const float *W = o < oB3 ? W1 : W2;
+        const int lane = oo & 63, q = oo >> 6, r = q & 3, hto = (q >> 2) % NH, hti = (q >> 2) / NH;
+        const int g = lane >> 4, i = lane & 15;
+        return W[(16 * hto + 4 * g + r) * H + 16 * hti + i];
+    } else {  // B4 [s][q][hto][r][64]: W3[(4s+g)*23 + 4q+r][16hto+i]
+        const int oo = o - oB4;
+        const int lane = oo & 63, q4 = oo >> 6, r = q4 & 3, hto = (q4 >> 2) % NH, sq = (q4 >> 2) / NH, q = sq % SPL_QT, sidx = sq / SPL_QT;
+        const int g = lane >> 4, i = lane & 15;
+        const int jo = 4 * sidx + g, pp = 4 * q + r;
+        return (jo < nout && pp < P) ? W3[(size_t)(jo * P + pp) * H + 16 * hto + i] : 0.f;
+    }
+}
+
+__global__ void spl_timage_kernel(const float *__restrict__ w, const float *__restrict__ wmat, float *__restrict__ timg, SplTrainShape ts) {
+    const SplineShape &s = ts.s;
+    const int D = s.D, NTh = s.NTh, T2 = 2 * NTh;
+    const long total = (long)ts.timage_floats;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / ts.tblk_floats);
+        int o = (int)(idx - (long)b * ts.tblk_floats);
+        const float *pb = w + (size_t)b * s.blk_params;
+        const float *Wm = wmat + (size_t)b * D * D;
+        float v = 0.f;
+        if (o < 2 * ts.conv_floats) {
+            const bool bwd = o >= ts.conv_floats;
+            if (bwd) o -= ts.conv_floats;
+            const int lane = o & 63, q = o >> 6, r = q & 3, ti = (q >> 2) % T2, to = (q >> 2) / T2;
+            const int g = lane >> 4, i = lane & 15;
+            const int dk = tslot_dim(s, ti / NTh, ti % NTh, r, g);   // contracted index
+            const int dm = trow_dim(s, to / NTh, to % NTh, i);       // output row
+            if (dk >= 0 && dm >= 0) v = bwd ? Wm[(size_t)dm * D + dk] : Wm[(size_t)dk * D + dm];  // c = a W ; g_a = g_c W^T
+        } else {
+            o -= 2 * ts.conv_floats;
+            if (o < ts.cf[0]) v = cond_fwd_value(s, pb + ts.p_f[0], s.nl, s.nu, o);
+            else if ((o -= ts.cf[0]) < ts.cf[1]) v = cond_fwd_value(s, pb + ts.p_f[1], s.nu, s.nl, o);
+            else if ((o -= ts.cf[1]) < ts.cb[0]) v = cond_bwd_value(s, pb + ts.p_f[0], s.nl, s.nu, o);
+            else if ((o -= ts.cb[0]) < ts.cb[1]) v = cond_bwd_value(s, pb + ts.p_f[1], s.nu, s.nl, o);
+            else if ((o -= ts.cb[1]) == 0) {  // log|det| of ActNorm + conv (networks.py:650, :676)
+                float acc = 0.f;
+                for (int d = 0; d < D; ++d) acc += pb[ts.p_s + d] + logf(fabsf(pb[ts.p_S + d]));
+                v = acc;
+            }
+        }
+        timg[idx] = v;
+    }
+}
+
+// ---- 3: forward / backward ----------------------------------------------------------------------------------------
+enum { SPL_MODE_GRAD = 0, SPL_MODE_LOSS = 1 };
+
+struct SplGradArgs {
+    const float *timg;
+    const float *w;
+    SplTrainShape ts;
+    const float *x;     // [n_rows, D] row-major
+    const int *perm;    // row index of batch row i (NULL: identity)
+    int M;              // rows in this batch
+    int mtot;           // the mean's denominator
+    const float *noise; // recorded jitter noise rows (batch order) or NULL
+    uint64_t seed;
+    long noise_row0;    // index of batch row 0 in the epoch (in-kernel stream position)
+    int epoch;
+    float jitter;
+    float *partial;     // [tiles][gw_floats]
+    float *stash;       // [tiles][B][2 NTh][64] f32x4
+    int mode;
+};
+
+template <int NTh>
+__device__ __forceinline__ void spl_actnorm_vecs(const SplTrainShape &ts, const float *pb, int lane, f32x4 (&es)[2][NTh], f32x4 (&tv)[2][NTh]) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int t = 0; t < NTh; ++t) {
+            float e[4], tt[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = tslot_dim(ts.s, hf, t, r, g);
+                e[r] = d >= 0 ? expf(pb[ts.p_s + d]) : 0.f;
+                tt[r] = d >= 0 ? pb[ts.p_t + d] : 0.f;
+            }
+            es[hf][t] = (f32x4){e[0], e[1], e[2], e[3]};
+            tv[hf][t] = (f32x4){tt[0], tt[1], tt[2], tt[3]};
+        }
+}
+
+// c = a W (no bias): the conv fragments have the layout of spl_affine's weights
+template <int NTh>
+__device__ __forceinline__ void spl_matmul(const float *__restrict__ frag, int lane, const f32x4 (&in)[2][NTh], f32x4 (&out)[2][NTh]) {
+    constexpr int T2 = 2 * NTh;
+#pragma unroll
+    for (int to = 0; to < T2; ++to) {
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ti = 0; ti < T2; ++ti) {
+            const f32x4 v = in[ti / NTh][ti % NTh];
+            const float *a = frag + (size_t)((to * T2 + ti) * 4) * 64 + lane;
+            acc0 = mfma4(a[0], v.x, acc0);
+            acc1 = mfma4(a[64], v.y, acc1);
+            acc0 = mfma4(a[128], v.z, acc0);
+            acc1 = mfma4(a[192], v.w, acc1);
+        }
+        out[to / NTh][to % NTh] = acc0 + acc1;
+    }
+}
+
+// sum over the 16 rows (lanes w) of a tile; valid in every lane
+__device__ __forceinline__ f32x4 rows_sum(f32x4 v) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+    }
+    return v;
+}
+
+// Backward of one coupling: `tr` (n_out dims, S super-tiles) was transformed conditioned on `cond` by the conditioner
+// at packed offset pnet / images cf (forward) and cbw (transposed).  On entry g_tr = dLoss/d(outputs of the transformed
+// half), x_tr = the half BEFORE the transform; on exit g_tr = dLoss/d(x_tr) and g_cond has the conditioner path added.
+template <int NTh, int NH>
+__device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const float *__restrict__ cf, const float *__restrict__ cbw, int pnet,
+                                                 int nin, int nout, int S, int lane, bool row_ok, float gld, float *lds17, float *gp,
+                                                 const f32x4 (&cond)[NTh], const f32x4 (&x_tr)[NTh], f32x4 (&g_tr)[NTh], f32x4 (&g_cond)[NTh]) {
+    const int g = lane >> 4, w = lane & 15, H = ts.s.H;
+    const float tail = ts.s.tail;
+    f32x4 h[3][NH];
+    spl_hidden_keep<NTh, NH>(cf, lane, cond, h);
+    const float *L4 = cf + spl_cond_hidden_floats(NTh, NH);
+    const float *b4 = L4 + (size_t)S * SPL_QT * NH * 256;
+    const float *B1 = cbw, *B2 = cbw + NTh * NH * 256, *B3 = B2 + NH * NH * 256, *B4 = B3 + NH * NH * 256;
+    // packed offsets of this conditioner's parameters
+    const int pW0 = pnet, pb0 = pW0 + H * nin, pW1 = pb0 + H, pb1 = pW1 + H * H, pW2 = pb1 + H, pb2 = pW2 + H * H, pW3 = pb2 + H,
+              pb3 = pW3 + SPL_P * nout * H;
+    float hT[3][NH][4];  // activations transposed for the weight-gradient contractions
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) tile_transpose(lds17, lane, h[l][ht], hT[l][ht]);
+    f32x4 g_h[NH];
+#pragma unroll
+    for (int ht = 0; ht < NH; ++ht) g_h[ht] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4 * NTh; ++s) {
+        if (s < S) {
+            f32x4 raw[SPL_QT], graw[SPL_QT];
+            spl_raw<NH>(L4, b4, s, lane, h[2], raw);
+            const bool valid = row_ok && (4 * s + g < nout);
+            const float x = reg_of(x_tr[s >> 2], s & 3);
+            const float gy = valid ? reg_of(g_tr[s >> 2], s & 3) : 0.f;
+            float y, lad;
+            const float gx = spl_rqs_fwd_bwd(raw, tail, x, gy, valid ? gld : 0.f, y, lad, graw);
+            set_reg(g_tr[s >> 2], s & 3, valid ? gx : 0.f);
+#pragma unroll
+            for (int q = 0; q < SPL_QT; ++q) {
+                if (!valid) graw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // last layer: dW3 = G^T h3 (rows contracted), db3 = sum over rows, g_h3 += W3^T G
+                float gT[4];
+                tile_transpose(lds17, lane, graw[q], gT);
+#pragma unroll
+                for (int hto = 0; hto < NH; ++hto) {
+                    const f32x4 dW = contract16(gT, hT[2][hto]);  // lane (g,j) reg r: feature (dim 4s+g, param 4q+r) x hidden 16hto+j
+                    const float dv[4] = {dW.x, dW.y, dW.z, dW.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int jo = 4 * s + g, pp = 4 * q + r;
+                        if (jo < nout && pp < SPL_P) gp[pW3 + (jo * SPL_P + pp) * H + 16 * hto + w] = dv[r];
+                    }
+                }
+                const f32x4 db = rows_sum(graw[q]);
+                if (w == 0) {
+                    const float dv[4] = {db.x, db.y, db.z, db.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int jo = 4 * s + g, pp = 4 * q + r;
+                        if (jo < nout && pp < SPL_P) gp[pb3 + jo * SPL_P + pp] = dv[r];
+                    }
+                }
+#pragma unroll
+                for (int hto = 0; hto < NH; ++hto) {
+                    const float *a = B4 + (size_t)(((s * SPL_QT + q) * NH + hto) * 4) * 64 + lane;
+                    g_h[hto] = mfma4(a[0], graw[q].x, g_h[hto]);
+                    g_h[hto] = mfma4(a[64], graw[q].y, g_h[hto]);
+                    g_h[hto] = mfma4(a[128], graw[q].z, g_h[hto]);
+                    g_h[hto] = mfma4(a[192], graw[q].w, g_h[hto]);
+                }
+            }
+        }
+    }
+    // hidden layers 3 and 2 (W2 over h[1], W1 over h[0])
+#pragma unroll
+    for (int l = 2; l >= 1; --l) {
+        const float *Bl = l == 2 ? B3 : B2;
+        const int pW = l == 2 ? pW2 : pW1, pb = l == 2 ? pb2 : pb1;
+        f32x4 g_pre[NH], g_prev[NH];
+        float gT[NH][4];
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) {
+            g_pre[ht] = lrelu_grad4(g_h[ht], h[l][ht]);
+            tile_transpose(lds17, lane, g_pre[ht], gT[ht]);
+            const f32x4 db = rows_sum(g_pre[ht]);
+            if (w == 0) {
+                gp[pb + 16 * ht + 4 * g + 0] = db.x; gp[pb + 16 * ht + 4 * g + 1] = db.y;
+                gp[pb + 16 * ht + 4 * g + 2] = db.z; gp[pb + 16 * ht + 4 * g + 3] = db.w;
+            }
+        }
+#pragma unroll
+        for (int hto = 0; hto < NH; ++hto)
+#pragma unroll
+            for (int hti = 0; hti < NH; ++hti) {
+                const f32x4 dW = contract16(gT[hto], hT[l - 1][hti]);  // [out 16hto+4g+r][in 16hti+w]
+                gp[pW + (16 * hto + 4 * g + 0) * H + 16 * hti + w] = dW.x; gp[pW + (16 * hto + 4 * g + 1) * H + 16 * hti + w] = dW.y;
+                gp[pW + (16 * hto + 4 * g + 2) * H + 16 * hti + w] = dW.z; gp[pW + (16 * hto + 4 * g + 3) * H + 16 * hti + w] = dW.w;
+            }
+#pragma unroll
+        for (int hti = 0; hti < NH; ++hti) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hto = 0; hto < NH; ++hto) {
+                const float *a = Bl + (size_t)((hti * NH + hto) * 4) * 64 + lane;
+                acc = mfma4(a[0], g_pre[hto].x, acc);
+                acc = mfma4(a[64], g_pre[hto].y, acc);
+                acc = mfma4(a[128], g_pre[hto].z, acc);
+                acc = mfma4(a[192], g_pre[hto].w, acc);
+            }
+            g_prev[hti] = acc;
+        }
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) g_h[ht] = g_prev[ht];
+    }
+    // first layer: W0 over the conditioning half
+    {
+        f32x4 g_pre[NH];
+        float gT[NH][4];
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) {
+            g_pre[ht] = lrelu_grad4(g_h[ht], h[0][ht]);
+            tile_transpose(lds17, lane, g_pre[ht], gT[ht]);
+            const f32x4 db = rows_sum(g_pre[ht]);
+            if (w == 0) {
+                gp[pb0 + 16 * ht + 4 * g + 0] = db.x; gp[pb0 + 16 * ht + 4 * g + 1] = db.y;
+                gp[pb0 + 16 * ht + 4 * g + 2] = db.z; gp[pb0 + 16 * ht + 4 * g + 3] = db.w;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTh; ++t) {
+            f32x4 cin = cond[t];
+            if (!row_ok) cin = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float cT[4];
+            tile_transpose(lds17, lane, cin, cT);
+            const int j = 16 * t + 4 * (w & 3) + (w >> 2);  // input dim of tile row w
+#pragma unroll
+            for (int ht = 0; ht < NH; ++ht) {
+                const f32x4 dW = contract16(gT[ht], cT);  // [hidden 16ht+4g+r][tile row w]
+                if (j < nin) {
+                    gp[pW0 + (16 * ht + 4 * g + 0) * nin + j] = dW.x; gp[pW0 + (16 * ht + 4 * g + 1) * nin + j] = dW.y;
+                    gp[pW0 + (16 * ht + 4 * g + 2) * nin + j] = dW.z; gp[pW0 + (16 * ht + 4 * g + 3) * nin + j] = dW.w;
+                }
+            }
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ht = 0; ht < NH; ++ht) {
+                const float *a = B1 + (size_t)((t * NH + ht) * 4) * 64 + lane;
+                acc = mfma4(a[0], g_pre[ht].x, acc);
+                acc = mfma4(a[64], g_pre[ht].y, acc);
+                acc = mfma4(a[128], g_pre[ht].z, acc);
+                acc = mfma4(a[192], g_pre[ht].w, acc);
+            }
+            g_cond[t] = g_cond[t] + acc;
+        }
+    }
+}
+
+template <int NTh, int NH>
+__global__ void __launch_bounds__(64) spl_grad_kernel(SplGradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const SplTrainShape &ts = a.ts;
+    const SplineShape &s = ts.s;
+    const int lane = threadIdx.x, w = lane & 15, g = lane >> 4, tile = blockIdx.x;
+    const int D = s.D, B = s.B;
+    float *buf = lds;                    // 16 x (D+1): layout exchange
+    float *lds17 = lds + 16 * (D + 1);   // 16 x 17: tile transposes
+    const int row = tile * 16 + w;
+    const bool ok = row < a.M;
+    float *gp = a.partial + (size_t)tile * ts.gw_floats;
+    f32x4 *stash = reinterpret_cast<f32x4 *>(a.stash) + (size_t)tile * B * 2 * NTh * 64;
+
+    // data = X[perm] + jitter * randn  (trainer.py:392)
+    f32x4 xp[2][NTh], xs[2][NTh];
+    long src = 0;
+    if (ok) src = a.perm ? a.perm[row] : row;
+    load_tile<NTh>(a.x, src, ok, D, lane, xp);
+    if (a.mode == SPL_MODE_GRAD && a.jitter != 0.f) {
+        if (a.noise) {
+            f32x4 nz[2][NTh];
+            load_tile<NTh>(a.noise, row, ok, D, lane, nz);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int t = 0; t < NTh; ++t) xp[c][t] = xp[c][t] + nz[c][t] * a.jitter;
+        } else {
+            const long p = a.noise_row0 + row;
+#pragma unroll
+            for (int t = 0; t < NTh; ++t) {
+                f32x4 n0 = noise_normal4(a.seed, (uint64_t)p, (uint32_t)a.epoch, (uint32_t)(8 * t + 2 * g), NOISE_STREAM_JITTER);
+                f32x4 n1 = noise_normal4(a.seed, (uint64_t)p, (uint32_t)a.epoch, (uint32_t)(8 * t + 2 * g + 1), NOISE_STREAM_JITTER);
+                const int d0 = 32 * t + 8 * g;
+                if (ok) {
+                    if (d0 + 0 < D) xp[0][t].x += n0.x * a.jitter; if (d0 + 1 < D) xp[1][t].x += n0.y * a.jitter;
+                    if (d0 + 2 < D) xp[0][t].y += n0.z * a.jitter; if (d0 + 3 < D) xp[1][t].y += n0.w * a.jitter;
+                    if (d0 + 4 < D) xp[0][t].z += n1.x * a.jitter; if (d0 + 5 < D) xp[1][t].z += n1.y * a.jitter;
+                    if (d0 + 6 < D) xp[0][t].w += n1.z * a.jitter; if (d0 + 7 < D) xp[1][t].w += n1.w * a.jitter;
+                }
+            }
+        }
+    }
+    spl_from_parity<NTh>(buf, D, s.nl, lane, xp, xs);
+
+    // ---- forward (networks.py:24-32), block inputs stashed -----------------------------------------------------------
+    float ld = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float *blk = a.timg + (size_t)b * ts.tblk_floats;
+        const float *pb = a.w + (size_t)b * s.blk_params;
+        if (a.mode == SPL_MODE_GRAD) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int t = 0; t < NTh; ++t) stash[((size_t)b * 2 * NTh + c * NTh + t) * 64 + lane] = xs[c][t];
+        }
+        f32x4 es[2][NTh], tv[2][NTh], av[2][NTh], c[2][NTh];
+        spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int t = 0; t < NTh; ++t) av[hf][t] = xs[hf][t] * es[hf][t] + tv[hf][t];
+        spl_matmul<NTh>(blk, lane, av, c);
+        const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
+        ld += spl_coupling<NTh, NH, false>(f1, s.SU, s.nu, s.tail, lane, c[0], c[1]);
+        ld += spl_coupling<NTh, NH, false>(f2, s.SL, s.nl, s.tail, lane, c[1], c[0]);
+        if (lane < 16) ld += blk[ts.tblk_floats - 4];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int t = 0; t < NTh; ++t) xs[hf][t] = c[hf][t];
+    }
+    ld = group_sum(ld);
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < NTh; ++t) {
+            f32x4 v = xs[c][t];
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    ss = group_sum(ss);
+    float lp = (ok && g == 0) ? (-0.5f * ss - 0.91893853320467274f * (float)D + ld) : 0.f;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) lp += __shfl_xor(lp, o);
+    if (lane == 0) gp[ts.gw_floats - 4] = lp;  // sum of log_probs over this tile's rows
+    if (a.mode == SPL_MODE_LOSS) return;
+
+    // ---- backward: loss = -mean(log_probs)  (trainer.py:394) ---------------------------------------------------------
+    const float invM = 1.0f / (float)a.mtot, gld = -invM;
+    f32x4 gs[2][NTh];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < NTh; ++t) gs[c][t] = ok ? xs[c][t] * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = B - 1; b >= 0; --b) {
+        const float *blk = a.timg + (size_t)b * ts.tblk_floats;
+        const float *pb = a.w + (size_t)b * s.blk_params;
+        const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0], *f1b = f2 + ts.cf[1], *f2b = f1b + ts.cb[0];
+        const int pblk = b * s.blk_params;
+        f32x4 xin[2][NTh], es[2][NTh], tv[2][NTh], av[2][NTh], c[2][NTh];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int t = 0; t < NTh; ++t) xin[cc][t] = stash[((size_t)b * 2 * NTh + cc * NTh + t) * 64 + lane];
+        spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int t = 0; t < NTh; ++t) av[hf][t] = xin[hf][t] * es[hf][t] + tv[hf][t];
+        spl_matmul<NTh>(blk, lane, av, c);
+        // upper' = RQS(upper; f1(lower)) is the conditioning input of the second coupling
+        f32x4 up2[NTh];
+#pragma unroll
+        for (int t = 0; t < NTh; ++t) up2[t] = c[1][t];
+        spl_coupling<NTh, NH, false>(f1, s.SU, s.nu, s.tail, lane, c[0], up2);
+        // second coupling: lower' = RQS(lower; f2(upper'))   (networks.py:589-598)
+        spl_coupling_bwd<NTh, NH>(ts, f2, f2b, pblk + ts.p_f[1], s.nu, s.nl, s.SL, lane, ok, gld, lds17, gp, up2, c[0], gs[0], gs[1]);
+        // first coupling: upper' = RQS(upper; f1(lower))      (networks.py:582-588)
+        spl_coupling_bwd<NTh, NH>(ts, f1, f1b, pblk + ts.p_f[0], s.nl, s.nu, s.SU, lane, ok, gld, lds17, gp, c[0], c[1], gs[1], gs[0]);
+        // 1x1 conv c = a W: dLoss/dW[i][o] = sum_rows a[i] g_c[o];  g_a = g_c W^T
+        {
+            constexpr int T2 = 2 * NTh;
+            float aT[T2][4], gT[T2][4];
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+                f32x4 v = av[t / NTh][t % NTh];
+                if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                tile_transpose(lds17, lane, v, aT[t]);
+                tile_transpose(lds17, lane, gs[t / NTh][t % NTh], gT[t]);
+            }
+            float *gW = gp + s.num_params + (size_t)b * D * D;
+#pragma unroll
+            for (int ti = 0; ti < T2; ++ti)
+#pragma unroll
+                for (int to = 0; to < T2; ++to) {
+                    const f32x4 dW = contract16(aT[ti], gT[to]);  // [a row 4g+r of tile ti][g_c row w of tile to]
+                    const int dout = trow_dim(s, to / NTh, to % NTh, w);
+                    const float dv[4] = {dW.x, dW.y, dW.z, dW.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int din = trow_dim(s, ti / NTh, ti % NTh, 4 * g + r);
+                        if (din >= 0 && dout >= 0) gW[(size_t)din * D + dout] = dv[r];
+                    }
+                }
+        }
+        f32x4 ga[2][NTh];
+        spl_matmul<NTh>(blk + ts.conv_floats, lane, gs, ga);
+        // ActNorm a = x e^s + t: g_s = sum_rows g_a x e^s, g_t = sum_rows g_a, g_x = g_a e^s  (the -1 of log|det| is added by the reducer)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int t = 0; t < NTh; ++t) {
+                const f32x4 gx = ga[hf][t] * es[hf][t];
+                const f32x4 dsum = rows_sum(gx * xin[hf][t]);
+                const f32x4 tsum = rows_sum(ga[hf][t]);
+                if (w == 0) {
+                    const float dsv[4] = {dsum.x, dsum.y, dsum.z, dsum.w}, dtv[4] = {tsum.x, tsum.y, tsum.z, tsum.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int d = tslot_dim(s, hf, t, r, g);
+                        if (d >= 0) { gp[pblk + ts.p_s + d] = dsv[r]; gp[pblk + ts.p_t + d] = dtv[r]; }
+                    }
+                }
+                gs[hf][t] = gx;
+            }
+    }
+}
+
+// ---- 4: reduce ------------------------------------------------------------------------------------------------------
+__global__ void spl_reduce_kernel(const float *__restrict__ partial, int tiles, SplTrainShape ts, const float *__restrict__ w,
+                                  float *__restrict__ grad, float *__restrict__ gwsum, float *__restrict__ loss_out, float loss_scale) {
+    const int np = ts.s.num_params, D = ts.s.D, n = ts.gw_floats;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        if (i < np) {
+            const int o = i % ts.s.blk_params;
+            if (o >= ts.p_L && o < ts.p_f[0]) continue;  // L, S, U: from dLoss/dW (spl_lu_grad_kernel)
+            for (int t = 0; t < tiles; ++t) acc += partial[(size_t)t * n + i];
+            if (o < ts.p_t) acc -= 1.0f;  // d(-mean sum(s))/ds
+            grad[i] = acc;
+        } else if (i < np + ts.s.B * D * D) {
+            for (int t = 0; t < tiles; ++t) acc += partial[(size_t)t * n + i];
+            gwsum[i - np] = acc;
+        } else if (i == n - 4) {
+            for (int t = 0; t < tiles; ++t) acc += partial[(size_t)t * n + i];
+            if (loss_out) *loss_out = acc * loss_scale;
+        }
+    }
+}
+
+// ---- 5: W = (P Lm) Um  ->  L, S, U -------------------------------------------------------------------------------------
+__global__ void spl_lu_grad_kernel(const float *__restrict__ w, const int *__restrict__ pi_inv, const int *__restrict__ pi,
+                                   const float *__restrict__ gwsum, float *__restrict__ grad, SplTrainShape ts) {
+    const int D = ts.s.D, per = 2 * D * D, n = ts.s.B * per;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        const int b = idx / per, o = idx % per;
+        const float *pb = w + (size_t)b * ts.s.blk_params;
+        const float *Lp = pb + ts.p_L, *Sp = pb + ts.p_S, *Up = pb + ts.p_U;
+        const float *gW = gwsum + (size_t)b * D * D;
+        float *gb = grad + (size_t)b * ts.s.blk_params;
+        if (o < D * D) {  // dLoss/dL[r][k] = sum_j gW[pi^-1(r)][j] Um[k][j]   (k < r; other entries are unused: 0)
+            const int r = o / D, k = o % D;
+            float acc = 0.f;
+            if (k < r) {
+                const int i = pi_inv[b * D + r];
+                for (int j = k; j < D; ++j) acc += gW[(size_t)i * D + j] * (j > k ? Up[k * D + j] : Sp[k]);
+            }
+            gb[ts.p_L + o] = acc;
+        } else {  // dLoss/dUm[k][j] = sum_i gW[i][j] Lm[pi(i)][k]   (k <= j)
+            const int k = (o - D * D) / D, j = (o - D * D) % D;
+            float acc = 0.f;
+            if (k <= j)
+                for (int i = 0; i < D; ++i) {
+                    const int r = pi[b * D + i];
+                    const float l = k < r ? Lp[r * D + k] : (k == r ? 1.f : 0.f);
+                    acc += gW[(size_t)i * D + j] * l;
+                }
+            if (k < j) gb[ts.p_U + k * D + j] = acc;
+            else if (k == j) { gb[ts.p_S + k] = acc - 1.0f / Sp[k]; gb[ts.p_U + k * D + j] = 0.f; }  // d(-mean sum log|S|)/dS
+            else gb[ts.p_U + k * D + j] = 0.f;
+        }
+    }
+}
+
+// ---- 6: Adam (torch/optim/adam.py _single_tensor_adam, coupled weight decay) -----------------------------------------------
+__global__ void spl_adam_kernel(float *__restrict__ w, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, int n,
+                                float step_size, float inv_bc2s, float wd) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float gi = grad[i] + wd * w[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        w[i] = w[i] - step_size * (mi / (sqrtf(vi) * inv_bc2s + eps));
+    }
+}
+
+// ---- ActNorm data-dependent initialisation (networks.py:698-705): one workgroup, rows in tiles of 16 -------------------------
+struct SplInitArgs {
+    const float *timg;
+    float *w;
+    SplTrainShape ts;
+    const float *x;  // [N, D] rows already jittered / gathered
+    int N;
+    float *scratch;  // [tiles][2 NTh][64] f32x4
+};
+
+template <int NTh, int NH>
+__global__ void __launch_bounds__(512) spl_init_kernel(SplInitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const SplTrainShape &ts = a.ts;
+    const SplineShape &s = ts.s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, w = lane & 15, g = lane >> 4;
+    const int D = s.D, ntiles = (a.N + 15) >> 4;
+    constexpr int T2 = 2 * NTh;
+    float *buf = lds + (size_t)wave * 16 * (D + 1);
+    float *red = lds + (size_t)nw * 16 * (D + 1);  // [nw][T2*16] partial sums, then [T2*16] results
+    float *res = red + nw * T2 * 16;
+    f32x4 *scr = reinterpret_cast<f32x4 *>(a.scratch);
+    for (int tile = wave; tile < ntiles; tile += nw) {
+        const int row = tile * 16 + w;
+        f32x4 xp[2][NTh], xs[2][NTh];
+        load_tile<NTh>(a.x, row, row < a.N, D, lane, xp);
+        spl_from_parity<NTh>(buf, D, s.nl, lane, xp, xs);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < NTh; ++t) scr[((size_t)tile * T2 + c * NTh + t) * 64 + lane] = xs[c][t];
+    }
+    __syncthreads();
+    for (int b = 0; b < s.B; ++b) {
+        float *pb = a.w + (size_t)b * s.blk_params;
+        // pass 0: mean; pass 1: unbiased variance
+        for (int pass = 0; pass < 2; ++pass) {
+            f32x4 acc[2][NTh];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int t = 0; t < NTh; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int tile = wave; tile < ntiles; tile += nw) {
+                const bool ok = tile * 16 + w < a.N;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int t = 0; t < NTh; ++t) {
+                        f32x4 v = scr[((size_t)tile * T2 + c * NTh + t) * 64 + lane];
+                        if (pass == 1) {
+                            const f32x4 mu = *reinterpret_cast<const f32x4 *>(res + ((c * NTh + t) * 4 + g) * 4);
+                            v = (v - mu) * (v - mu);
+                        }
+                        if (ok) acc[c][t] = acc[c][t] + v;
+                    }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int t = 0; t < NTh; ++t) {
+                    const f32x4 sm = rows_sum(acc[c][t]);
+                    if (w == 0) *reinterpret_cast<f32x4 *>(red + (size_t)wave * T2 * 16 + ((c * NTh + t) * 4 + g) * 4) = sm;
+                }
+            __syncthreads();
+            for (int i = threadIdx.x; i < T2 * 16; i += blockDim.x) {
+                float tot = 0.f;
+                for (int k = 0; k < nw; ++k) tot += red[(size_t)k * T2 * 16 + i];
+                const int tt = i >> 4, gg = (i >> 2) & 3, r = i & 3;
+                const int d = tslot_dim(s, tt / NTh, tt % NTh, r, gg);
+                if (pass == 0) res[i] = tot / (float)a.N;
+                else if (d >= 0) {
+                    const float mean = res[i];
+                    const float sv = -logf(sqrtf(tot / (float)(a.N - 1)));  // s = -log std (unbiased)
+                    pb[ts.p_s + d] = sv;
+                    pb[ts.p_t + d] = -(mean * expf(sv));                   // t = -mean(x e^s)
+                }
+            }
+            __syncthreads();
+        }
+        __threadfence();
+        __syncthreads();
+        // push the rows through block b
+        const float *blk = a.timg + (size_t)b * ts.tblk_floats;
+        const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
+        for (int tile = wave; tile < ntiles; tile += nw) {
+            f32x4 xs[2][NTh], es[2][NTh], tv[2][NTh], av[2][NTh], c[2][NTh];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int t = 0; t < NTh; ++t) xs[cc][t] = scr[((size_t)tile * T2 + cc * NTh + t) * 64 + lane];
+            spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int t = 0; t < NTh; ++t) av[hf][t] = xs[hf][t] * es[hf][t] + tv[hf][t];
+            spl_matmul<NTh>(blk, lane, av, c);
+            spl_coupling<NTh, NH, false>(f1, s.SU, s.nu, s.tail, lane, c[0], c[1]);
+            spl_coupling<NTh, NH, false>(f2, s.SL, s.nl, s.tail, lane, c[1], c[0]);
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int t = 0; t < NTh; ++t) scr[((size_t)tile * T2 + cc * NTh + t) * 64 + lane] = c[cc][t];
+        }
+        __syncthreads();
+    }
+}
+
+#define DISPATCH_SPLT(KERNEL, sp, grid, block, ldsb, st, arg)                                                         \
+    do {                                                                                                              \
+        const int key__ = (sp).NTh * 10 + (sp).NH;                                                                    \
+        switch (key__) {                                                                                              \
+            case 11: hipLaunchKernelGGL((KERNEL<1, 1>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
+            case 21: hipLaunchKernelGGL((KERNEL<2, 1>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
+            case 31: hipLaunchKernelGGL((KERNEL<3, 1>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
+            case 41: hipLaunchKernelGGL((KERNEL<4, 1>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
+            case 12: hipLaunchKernelGGL((KERNEL<1, 2>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
+            case 22: hipLaunchKernelGGL((KERNEL<2, 2>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
+            default: return hipErrorInvalidConfiguration;                                                             \
+        }                                                                                                             \
+    } while (0)
+
+static hipError_t launch_grad(const SplGradArgs &a, hipStream_t st) {
+    const int tiles = (a.M + 15) / 16;
+    const size_t ldsb = (size_t)(16 * (a.ts.s.D + 1) + 16 * 17) * sizeof(float);
+    DISPATCH_SPLT(spl_grad_kernel, a.ts.s, tiles, 64, ldsb, st, a);
+    return hipGetLastError();
+}
+
+static hipError_t launch_init(const SplInitArgs &a, hipStream_t st) {
+    const int nw = 8, T2 = 2 * a.ts.s.NTh;
+    const size_t ldsb = (size_t)(nw * 16 * (a.ts.s.D + 1) + nw * T2 * 16 + T2 * 16) * sizeof(float);
+    DISPATCH_SPLT(spl_init_kernel, a.ts.s, 1, 64 * nw, ldsb, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace nnest
+
+// ---- host orchestration ----------------------------------------------------------------------------------------------------
+static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
+    const SplTrainShape ts = make_train_shape(h->s);
+    const int D = h->s.D, B = h->s.B;
+    const size_t nb = (size_t)h->s.num_params * sizeof(float);
+    if (!h->w_dev) {
+        SHIP_TRY(hipMalloc((void **)&h->w_dev, nb));
+        SHIP_TRY(hipMalloc((void **)&h->adam_m, nb));
+        SHIP_TRY(hipMalloc((void **)&h->adam_v, nb));
+        SHIP_TRY(hipMalloc((void **)&h->best_w, nb));
+        SHIP_TRY(hipMalloc((void **)&h->grad, nb));
+        SHIP_TRY(hipMalloc((void **)&h->pi_dev, (size_t)2 * B * D * sizeof(int)));
+        SHIP_TRY(hipMalloc((void **)&h->wmat, (size_t)B * D * D * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->gwsum, (size_t)B * D * D * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->timg, (size_t)ts.timage_floats * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->losses_dev, 1024 * sizeof(float)));
+        SHIP_TRY(hipMemsetAsync(h->adam_m, 0, nb, st));
+        SHIP_TRY(hipMemsetAsync(h->adam_v, 0, nb, st));
+        h->adam_step = 0;
+        h->w_dev_current = false;
+    }
+    const int tiles = (max_rows + 15) / 16;
+    if (tiles > h->partial_tiles) {
+        if (h->partial) { (void)hipFree(h->partial); (void)hipFree(h->stash); }
+        SHIP_TRY(hipMalloc((void **)&h->partial, (size_t)tiles * ts.gw_floats * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->stash, (size_t)tiles * B * 2 * h->s.NTh * 64 * 4 * sizeof(float)));
+        h->partial_tiles = tiles;
+    }
+    if (!h->w_dev_current) {
+        SHIP_TRY(hipMemcpyAsync(h->w_dev, h->w.data(), nb, hipMemcpyHostToDevice, st));
+        std::vector<int> pi((size_t)2 * B * D, 0);  // [pi | pi^-1]
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < D; ++i)
+                for (int k = 0; k < D; ++k)
+                    if (h->perm[((size_t)b * D + i) * D + k] != 0.f) { pi[b * D + i] = k; pi[(size_t)B * D + b * D + k] = i; }
+        SHIP_TRY(hipMemcpyAsync(h->pi_dev, pi.data(), pi.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        SHIP_TRY(hipStreamSynchronize(st));
+        h->w_dev_current = true;
+    }
+    return NNEST_OK;
+}
+
+static int build_timage(nnest_spline *h, const SplTrainShape &ts, hipStream_t st) {
+    hipLaunchKernelGGL(spl_assemble_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev, h->wmat, ts);
+    hipLaunchKernelGGL(spl_timage_kernel, dim3(512), dim3(256), 0, st, h->w_dev, h->wmat, h->timg, ts);
+    SHIP_TRY(hipGetLastError());
+    return NNEST_OK;
+}
+
+// after training (or an init): bring the packed weights back to the host master copy and rebuild the inference image
+static int sync_to_host(nnest_spline *h, hipStream_t st) {
+    SHIP_TRY(hipMemcpyAsync(h->w.data(), h->w_dev, (size_t)h->s.num_params * sizeof(float), hipMemcpyDeviceToHost, st));
+    SHIP_TRY(hipStreamSynchronize(st));
+    int rc = spline_build_image(h);
+    if (rc) return rc;
+    SHIP_TRY(hipMemcpyAsync(h->img, h->img_host.data(), h->img_host.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    SHIP_TRY(hipStreamSynchronize(st));
+    return NNEST_OK;
+}
+
+extern "C" {
+
+int nnest_spline_actnorm_init(nnest_spline_t *h, const float *x_dev, int N, void *stream) {
+    if (!h || !x_dev) return spline_fail(NNEST_E_ARG, "NULL argument");
+    if (N < 2) return spline_fail(NNEST_E_ARG, "ActNorm's data-dependent initialisation needs >= 2 rows (unbiased std), got %d", N);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_train_state(h, 128, st);
+    if (rc) return rc;
+    const SplTrainShape ts = make_train_shape(h->s);
+    if ((rc = build_timage(h, ts, st))) return rc;
+    float *scratch = nullptr;
+    const int tiles = (N + 15) / 16;
+    SHIP_TRY(hipMalloc((void **)&scratch, (size_t)tiles * 2 * h->s.NTh * 64 * 4 * sizeof(float)));
+    SplInitArgs a;
+    a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = x_dev; a.N = N; a.scratch = scratch;
+    hipError_t e = launch_init(a, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(scratch);
+    if (e != hipSuccess) return spline_fail(NNEST_E_HIP, "spl_init_kernel: %s", hipGetErrorString(e));
+    return sync_to_host(h, st);
+}
+
+int nnest_spline_loss_grad(nnest_spline_t *h, const float *x_dev, int M, float *grad_dev, float *loss_dev, void *stream) {
+    if (!h || !x_dev || !grad_dev || !loss_dev) return spline_fail(NNEST_E_ARG, "NULL argument");
+    if (M < 1) return spline_fail(NNEST_E_ARG, "M=%d", M);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_train_state(h, M > 128 ? M : 128, st);
+    if (rc) return rc;
+    const SplTrainShape ts = make_train_shape(h->s);
+    if ((rc = build_timage(h, ts, st))) return rc;
+    SplGradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = x_dev; a.M = M; a.mtot = M; a.partial = h->partial; a.stash = h->stash;
+    a.mode = SPL_MODE_GRAD;
+    SHIP_TRY(launch_grad(a, st));
+    const int tiles = (M + 15) / 16;
+    hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, grad_dev, h->gwsum, loss_dev,
+                       -1.0f / (float)M);
+    hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts);
+    SHIP_TRY(hipGetLastError());
+    return NNEST_OK;
+}
+
+int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, const float *xvalid_dev, int n_valid,
+                       const int *perm_dev, const float *noise_dev, uint64_t seed, float jitter, int batch, int max_epochs,
+                       int patience, float lr, float weight_decay, float *losses_host, nnest_train_result_t *result_host,
+                       void *stream) {
+    if (!h || !xtrain_dev || !xvalid_dev || !perm_dev || !result_host) return spline_fail(NNEST_E_ARG, "NULL argument");
+    if (n_train < 1 || n_valid < 1 || batch < 1 || max_epochs < 0)
+        return spline_fail(NNEST_E_ARG, "bad sizes n_train=%d n_valid=%d batch=%d max_epochs=%d", n_train, n_valid, batch, max_epochs);
+    if (batch > 128) return spline_fail(NNEST_E_UNSUPPORTED, "batch_size=%d > 128", batch);
+    hipStream_t st = (hipStream_t)stream;
+    const int max_rows = n_valid > 128 ? n_valid : 128;
+    int rc = ensure_train_state(h, max_rows, st);
+    if (rc) return rc;
+    const SplTrainShape ts = make_train_shape(h->s);
+    const int np = h->s.num_params, D = h->s.D, B = h->s.B;
+    const int n_mb = (n_train + batch - 1) / batch;
+    if (n_mb + 1 > 1024) return spline_fail(NNEST_E_UNSUPPORTED, "more than 1023 minibatches per epoch");
+    const size_t nb = (size_t)np * sizeof(float);
+    SHIP_TRY(hipMemcpyAsync(h->best_w, h->w_dev, nb, hipMemcpyDeviceToDevice, st));  // best_model = deepcopy(netG)  trainer.py:194
+    float best = INFINITY;
+    int best_epoch = 0, counter = 0, epochs_run = 0, stopped = 0;
+    float last_train = 0.f;
+    std::vector<float> lh((size_t)n_mb + 1);
+    for (int epoch = 0; epoch < max_epochs; ++epoch) {
+        for (int mb = 0; mb < n_mb; ++mb) {
+            const int M = batch < n_train - mb * batch ? batch : n_train - mb * batch;
+            SplGradArgs a;
+            memset(&a, 0, sizeof(a));
+            a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = xtrain_dev; a.perm = perm_dev + (size_t)epoch * n_train + (size_t)mb * batch;
+            a.M = M; a.mtot = M; a.noise = noise_dev ? noise_dev + ((size_t)epoch * n_train + (size_t)mb * batch) * D : nullptr;
+            a.seed = seed; a.noise_row0 = (long)mb * batch; a.epoch = epoch; a.jitter = jitter;
+            a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_GRAD;
+            if ((rc = build_timage(h, ts, st))) return rc;
+            SHIP_TRY(launch_grad(a, st));
+            const int tiles = (M + 15) / 16;
+            hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, h->grad, h->gwsum,
+                               h->losses_dev + mb, -1.0f / (float)M);
+            hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + B * D, h->pi_dev, h->gwsum, h->grad, ts);
+            h->adam_step += 1;
+            const double bc1 = 1.0 - pow(0.9, (double)h->adam_step), bc2 = 1.0 - pow(0.999, (double)h->adam_step);
+            hipLaunchKernelGGL(spl_adam_kernel, dim3(256), dim3(256), 0, st, h->w_dev, h->grad, h->adam_m, h->adam_v, np,
+                               (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), weight_decay);
+        }
+        // Trainer._validate (trainer.py:405-418): one full batch; mean, then / len(dataset)
+        if ((rc = build_timage(h, ts, st))) return rc;
+        {
+            SplGradArgs a;
+            memset(&a, 0, sizeof(a));
+            a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = xvalid_dev; a.M = n_valid; a.mtot = n_valid;
+            a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_LOSS;
+            SHIP_TRY(launch_grad(a, st));
+            hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, (n_valid + 15) / 16, ts, h->w_dev, h->grad,
+                               h->gwsum, h->losses_dev + n_mb, -1.0f / (float)n_valid);
+        }
+        SHIP_TRY(hipMemcpyAsync(lh.data(), h->losses_dev, ((size_t)n_mb + 1) * sizeof(float), hipMemcpyDeviceToHost, st));
+        SHIP_TRY(hipStreamSynchronize(st));
+        float tl = 0.f;
+        for (int mb = 0; mb < n_mb; ++mb) tl += lh[mb];
+        const float train_loss = tl / (float)n_train;          // trainer.py:403
+        const float valid_loss = lh[n_mb] / (float)n_valid;    // trainer.py:418
+        last_train = train_loss;
+        epochs_run = epoch + 1;
+        if (losses_host) { losses_host[2 * epoch] = train_loss; losses_host[2 * epoch + 1] = valid_loss; }
+        if (valid_loss < best) {                                // trainer.py:205-209
+            best = valid_loss; best_epoch = epoch + 1; counter = 0;
+            SHIP_TRY(hipMemcpyAsync(h->best_w, h->w_dev, nb, hipMemcpyDeviceToDevice, st));
+        }
+        counter += 1;                                           // trainer.py:223-232
+        if (counter > patience) { stopped = 1; break; }
+    }
+    SHIP_TRY(hipMemcpyAsync(h->w_dev, h->best_w, nb, hipMemcpyDeviceToDevice, st));  // netG.load_state_dict(best_model)  trainer.py:241
+    result_host->epochs_run = epochs_run; result_host->best_epoch = best_epoch; result_host->best_validation_loss = best;
+    result_host->last_train_loss = last_train; result_host->counter = counter; result_host->stopped = stopped;
+    return sync_to_host(h, st);
+}
+
+}  // extern "C"

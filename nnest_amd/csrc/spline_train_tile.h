@@ -1,0 +1,231 @@
+// spline_train_tile.h -- device code of the spline flow's training step (reference nnest/trainer.py:384-403 on
+// SingleSpeedSpline, networks.py:393-715): forward with the block inputs stashed, then a hand-written backward that
+// recomputes one block at a time (ActNorm -> 1x1 conv -> two RQ-spline couplings), one wave64 per 16 rows.
+//
+// Tiles and slot numbering are those of spline_tile.h.  Parameter gradients are contractions over the 16 rows of the
+// tile: both operands are transposed through a 16x17 LDS tile and multiplied on the matrix cores
+// (out[m][n] = sum_row G[m][row] A[n][row]); every wave writes its partial sums to its own slice of the gradient
+// workspace, which the optimiser kernel adds up in a fixed order (no atomics: training is bitwise reproducible).
+#pragma once
+#include "spline_tile.h"
+
+namespace nnest {
+
+// training image of one block (rebuilt on the device from the packed weights before every minibatch):
+//   [ conv fwd: W as A-fragments of c = a W | conv bwd: fragments of g_a = g_c W^T | f1 fwd | f2 fwd | f1 bwd | f2 bwd ]
+// conditioner fwd = the inference layout (spline_tile.h); conditioner bwd = [B1 | B2 | B3 | B4]:
+//   B1 [t][ht][r][64]      g_in[tile t]  += W0^T g_pre1      lane(g,i) = W0[16ht+4g+r][dim of (tile t, row i)]
+//   B2 [hti][hto][r][64]   g_h1[hti]     += W1^T g_pre2      lane(g,i) = W1[16hto+4g+r][16hti+i]
+//   B3 likewise for W2;
+//   B4 [s][q][hto][r][64]  g_h3[hto]     += W3^T g_raw       lane(g,i) = W3[(4s+g)*23 + 4q+r][16hto+i]
+struct SplTrainShape {
+    SplineShape s;
+    int conv_floats;         // (2 NTh)^2 * 256, one direction
+    int cf[2], cb[2];        // conditioner fwd / bwd fragment floats (f1, f2)
+    int tblk_floats, timage_floats;
+    int p_s, p_t, p_L, p_S, p_U, p_f[2];  // offsets inside a packed block
+    int gw_floats;           // workspace per wave: packed gradient slice + B * D * D (dLoss/dW of the convs) + 4 (loss)
+};
+
+__host__ __device__ inline int spl_cond_bwd_floats(int NTh, int NH, int S) { return NTh * NH * 256 + 2 * NH * NH * 256 + S * SPL_QT * NH * 256; }
+
+// 16x16 tile transpose through LDS: in (C/D layout) lane (g,w) reg r = V[4g+r][w]  ->  out[kk] of lane (gq,i) = V[i][4kk+gq],
+// i.e. the A (or B) operand of a product contracted over the 16 rows/walkers of the tile
+__device__ __forceinline__ void tile_transpose(float *lds17, int lane, f32x4 v, float (&out)[4]) {
+    const int w = lane & 15, g = lane >> 4;
+    lds17[(4 * g + 0) * 17 + w] = v.x; lds17[(4 * g + 1) * 17 + w] = v.y;
+    lds17[(4 * g + 2) * 17 + w] = v.z; lds17[(4 * g + 3) * 17 + w] = v.w;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) out[kk] = lds17[w * 17 + 4 * kk + g];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// out[m][n] = sum_row G[m][row] A[n][row]; operands already transposed; result lane (g,j) reg r = out[4g+r][j]
+__device__ __forceinline__ f32x4 contract16(const float (&gt)[4], const float (&at)[4]) {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = mfma4(gt[kk], at[kk], acc);
+    return acc;
+}
+
+__device__ __forceinline__ f32x4 lrelu_grad4(f32x4 g, f32x4 post) {  // post-activation sign = pre-activation sign
+    f32x4 o;
+    o.x = post.x > 0.f ? g.x : 0.2f * g.x; o.y = post.y > 0.f ? g.y : 0.2f * g.y;
+    o.z = post.z > 0.f ? g.z : 0.2f * g.z; o.w = post.w > 0.f ? g.w : 0.2f * g.w;
+    return o;
+}
+
+// conditioner trunk keeping the three hidden activations
+template <int NTh, int NH>
+__device__ __forceinline__ void spl_hidden_keep(const float *__restrict__ net, int lane, const f32x4 (&in)[NTh], f32x4 (&h)[3][NH]) {
+    const int g = lane >> 4;
+    const float *L1 = net, *L2 = net + NH * NTh * 256, *L3 = L2 + NH * NH * 256, *b = L3 + NH * NH * 256;
+#pragma unroll
+    for (int ht = 0; ht < NH; ++ht) {
+        f32x4 a0 = *reinterpret_cast<const f32x4 *>(b + 16 * ht + 4 * g), a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NTh; ++t) {
+            const float *a = L1 + (size_t)((ht * NTh + t) * 4) * 64 + lane;
+            a0 = mfma4(a[0], in[t].x, a0);
+            a1 = mfma4(a[64], in[t].y, a1);
+            a0 = mfma4(a[128], in[t].z, a0);
+            a1 = mfma4(a[192], in[t].w, a1);
+        }
+        h[0][ht] = lrelu4(a0 + a1);
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const float *Lw = l == 0 ? L2 : L3;
+        const float *bl = b + 16 * NH * (l + 1);
+#pragma unroll
+        for (int hto = 0; hto < NH; ++hto) {
+            f32x4 a0 = *reinterpret_cast<const f32x4 *>(bl + 16 * hto + 4 * g), a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hti = 0; hti < NH; ++hti) {
+                const float *a = Lw + (size_t)((hto * NH + hti) * 4) * 64 + lane;
+                a0 = mfma4(a[0], h[l][hti].x, a0);
+                a1 = mfma4(a[64], h[l][hti].y, a1);
+                a0 = mfma4(a[128], h[l][hti].z, a0);
+                a1 = mfma4(a[192], h[l][hti].w, a1);
+            }
+            h[l + 1][hto] = lrelu4(a0 + a1);
+        }
+    }
+}
+
+// raw spline parameters of super-tile s from the last hidden activation
+template <int NH>
+__device__ __forceinline__ void spl_raw(const float *__restrict__ L4, const float *__restrict__ b4, int s, int lane, const f32x4 (&h3)[NH],
+                                        f32x4 (&raw)[SPL_QT]) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < SPL_QT; ++q) {
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(b4 + ((s * SPL_QT + q) * 4 + g) * 4);
+#pragma unroll
+        for (int hti = 0; hti < NH; ++hti) {
+            const float *a = L4 + (size_t)(((s * SPL_QT + q) * NH + hti) * 4) * 64 + lane;
+            acc = mfma4(a[0], h3[hti].x, acc);
+            acc = mfma4(a[64], h3[hti].y, acc);
+            acc = mfma4(a[128], h3[hti].z, acc);
+            acc = mfma4(a[192], h3[hti].w, acc);
+        }
+        raw[q] = acc;
+    }
+}
+
+// ---- reverse mode through one axis' knot construction (spl_knots): gradient wrt the 8 logits -----------------------
+// edge_k = -B + 2B sum_{i<k} w_i, size_k = 2B w_k, w = m + (1 - mK) softmax(2B softmax(logits))
+// g_edge = dLoss/d(edge of the selected bin), g_size = dLoss/d(size of the selected bin)
+__device__ __forceinline__ void spl_knots_bwd(const float (&logits)[SPL_K], float tail, int bin, float g_edge, float g_size, float (&g_logits)[SPL_K]) {
+    float a[SPL_K], u[SPL_K], p[SPL_K];
+    spl_softmax8(logits, a);
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) u[k] = 2.f * tail * a[k];
+    spl_softmax8(u, p);
+    float gp[SPL_K], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) {
+        const float gw = 2.f * tail * ((k < bin ? g_edge : 0.f) + (k == bin ? g_size : 0.f));
+        gp[k] = (1.f - 1e-3f * SPL_K) * gw;
+        dot += p[k] * gp[k];
+    }
+    float ga[SPL_K], dot2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) {
+        const float gu = p[k] * (gp[k] - dot);
+        ga[k] = 2.f * tail * gu;
+        dot2 += a[k] * ga[k];
+    }
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) g_logits[k] = a[k] * (ga[k] - dot2);
+}
+
+__device__ __forceinline__ float spl_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+
+// Forward RQ spline of one scalar with its reverse mode: given gy = dLoss/dy and gl = dLoss/d(log|dy/dx|), returns
+// dLoss/dx and dLoss/d(raw[24]) (0 outside the interval, where the map is the identity).  y and the log-derivative are
+// returned as in spl_rqs<false>.
+__device__ __forceinline__ float spl_rqs_fwd_bwd(const f32x4 (&raw)[SPL_QT], float tail, float x, float gy, float gl, float &y, float &lad,
+                                                 f32x4 (&graw)[SPL_QT]) {
+    float lw[SPL_K] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w};
+    float lh[SPL_K] = {raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
+    float ldv[SPL_K - 1] = {raw[4].x, raw[4].y, raw[4].z, raw[4].w, raw[5].x, raw[5].y, raw[5].z};
+    const bool inside = x >= -tail && x <= tail;
+    float cw[SPL_K + 1], wd[SPL_K], ch[SPL_K + 1], ht[SPL_K], dv[SPL_K + 1], ddv[SPL_K + 1];
+    spl_knots(lw, tail, cw, wd);
+    spl_knots(lh, tail, ch, ht);
+    const float constant = logf(expf(1.f - 1e-3f) - 1.f);
+    dv[0] = 1e-3f + spl_softplus(constant);
+    dv[SPL_K] = dv[0];
+    ddv[0] = 0.f; ddv[SPL_K] = 0.f;
+#pragma unroll
+    for (int k = 1; k < SPL_K; ++k) {
+        const float s1 = spl_softplus(ldv[k - 1]);
+        dv[k] = 1e-3f + spl_softplus(s1);
+        ddv[k] = spl_sigmoid(s1) * spl_sigmoid(ldv[k - 1]);  // d dv / d logit
+    }
+    int bin = -1;
+#pragma unroll
+    for (int k = 0; k <= SPL_K; ++k) {
+        float e = cw[k];
+        if (k == SPL_K) e += 1e-6f;
+        bin += (x >= e) ? 1 : 0;
+    }
+    bin = bin < 0 ? 0 : (bin > SPL_K - 1 ? SPL_K - 1 : bin);
+    float icw = cw[0], ibw = wd[0], ich = ch[0], ih = ht[0], d0 = dv[0], d1 = dv[1];
+#pragma unroll
+    for (int k = 1; k < SPL_K; ++k) {
+        const bool s = bin == k;
+        icw = s ? cw[k] : icw; ibw = s ? wd[k] : ibw; ich = s ? ch[k] : ich; ih = s ? ht[k] : ih;
+        d0 = s ? dv[k] : d0; d1 = s ? dv[k + 1] : d1;
+    }
+    // forward (networks.py:541-556)
+    const float delta = ih / ibw;
+    const float theta = (x - icw) / ibw;
+    const float tomt = theta * (1.f - theta);
+    const float sdd = d0 + d1 - 2.f * delta;
+    const float Nn = ih * (delta * theta * theta + d0 * tomt);
+    const float Dn = delta + sdd * tomt;
+    const float Q = d1 * theta * theta + 2.f * delta * tomt + d0 * (1.f - theta) * (1.f - theta);
+    const float dn = delta * delta * Q;
+    y = inside ? ich + Nn / Dn : x;
+    lad = inside ? logf(dn) - 2.f * logf(Dn) : 0.f;
+    // reverse
+    float g_ich = gy, g_N = gy / Dn, g_Dn = -gy * Nn / (Dn * Dn) - 2.f * gl / Dn;
+    const float g_dn = gl / dn;
+    float g_delta = g_dn * (2.f * delta * Q + delta * delta * 2.f * tomt);
+    const float g_Q = g_dn * delta * delta;
+    float g_d1 = g_Q * theta * theta, g_d0 = g_Q * (1.f - theta) * (1.f - theta);
+    float g_theta = g_Q * (2.f * d1 * theta - 2.f * d0 * (1.f - theta));
+    float g_t = g_Q * 2.f * delta;
+    g_delta += g_Dn * (1.f - 2.f * tomt);
+    g_d0 += g_Dn * tomt; g_d1 += g_Dn * tomt;
+    g_t += g_Dn * sdd;
+    float g_ih = g_N * (delta * theta * theta + d0 * tomt);
+    g_delta += g_N * ih * theta * theta;
+    g_theta += g_N * ih * delta * 2.f * theta;
+    g_d0 += g_N * ih * tomt;
+    g_t += g_N * ih * d0;
+    g_theta += g_t * (1.f - 2.f * theta);
+    g_ih += g_delta / ibw;
+    float g_ibw = -g_delta * ih / (ibw * ibw);
+    const float gx = g_theta / ibw;
+    const float g_icw = -g_theta / ibw;
+    g_ibw += -g_theta * theta / ibw;
+    float glw[SPL_K], glh[SPL_K];
+    spl_knots_bwd(lw, tail, bin, g_icw, g_ibw, glw);
+    spl_knots_bwd(lh, tail, bin, g_ich, g_ih, glh);
+    float gld[SPL_K];  // index k-1 for inner knot k
+#pragma unroll
+    for (int k = 1; k < SPL_K; ++k) gld[k - 1] = ((bin == k) ? g_d0 : 0.f) * ddv[k] + ((bin + 1 == k) ? g_d1 : 0.f) * ddv[k];
+    gld[SPL_K - 1] = 0.f;
+    const float m = inside ? 1.f : 0.f;
+    graw[0] = (f32x4){glw[0], glw[1], glw[2], glw[3]} * m; graw[1] = (f32x4){glw[4], glw[5], glw[6], glw[7]} * m;
+    graw[2] = (f32x4){glh[0], glh[1], glh[2], glh[3]} * m; graw[3] = (f32x4){glh[4], glh[5], glh[6], glh[7]} * m;
+    graw[4] = (f32x4){gld[0], gld[1], gld[2], gld[3]} * m; graw[5] = (f32x4){gld[4], gld[5], gld[6], 0.f} * m;
+    return inside ? gx : gy;
+}
+
+}  // namespace nnest

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .flow import _HipFlow
+from .flow import _HipFlow, _as_dev_f32
 
 
 class HipSpline(_HipFlow):
@@ -136,3 +136,67 @@ class HipSpline(_HipFlow):
         self.load_packed(np.concatenate([np.asarray(sd[name].detach().cpu().numpy() if torch.is_tensor(sd[name])
                                                     else sd[name], dtype=np.float32).ravel()
                                          for name, _ in self.layer_shapes()]), P)
+
+    # ---- ActNorm's data-dependent initialisation (networks.py:698-705) -------------------------------
+    # The reference initialises s, t of every ActNorm from the first batch that is pushed FORWARD through a freshly
+    # constructed model (forward / log_probs / the first training minibatch); `data_dep_init_done` is a plain attribute
+    # there too, so a state_dict loaded into a new object is re-initialised by its first forward batch -- kept as is.
+    def actnorm_init(self, x):
+        x = _as_dev_f32(x, self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_spline_actnorm_init(self._h, _lib.ptr(x), x.shape[0], _lib.current_stream(self.device)))
+        self.data_dep_init_done = True
+
+    def forward(self, x):
+        if not self.data_dep_init_done:
+            self.actnorm_init(x)
+        return super().forward(x)
+
+    def log_probs(self, x):
+        if not self.data_dep_init_done:
+            self.actnorm_init(x)
+        return super().log_probs(x)
+
+    # ---- training ---------------------------------------------------------------------------------
+    epoch_chunk = 1 << 30   # Trainer.train hands the whole run to one call (the epoch loop is host-driven here)
+
+    def loss_grad(self, x):
+        """loss = -mean(log_probs(x)) and dloss/dw (packed order), no weight update (trainer.py:394-400)"""
+        x = _as_dev_f32(x, self.device)
+        grad = torch.empty(self.num_params, dtype=torch.float32, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_spline_loss_grad(self._h, _lib.ptr(x), x.shape[0], _lib.ptr(grad), _lib.ptr(loss),
+                                                        _lib.current_stream(self.device)))
+        return loss, grad
+
+    def train_epochs(self, xtrain, xvalid, perm, noise=None, seed=0, jitter=0.0, batch=100, max_epochs=1, patience=50,
+                     lr=1e-3, weight_decay=1e-6, epoch_offset=0, resume=False, finalize=True, result=None):
+        """Trainer.train's epoch loop (trainer.py:198-241); same arguments and return value as HipNVP.train_epochs.  The
+        best-validation weights are restored on return."""
+        assert not resume and epoch_offset == 0, 'the spline trainer takes a run in one call'
+        dev = self.device
+        xtrain = _as_dev_f32(xtrain, dev)
+        xvalid = _as_dev_f32(xvalid, dev)
+        perm = perm.to(device=dev, dtype=torch.int32).contiguous()
+        n_train, n_valid = xtrain.shape[0], xvalid.shape[0]
+        assert perm.numel() == max_epochs * n_train
+        if noise is not None:
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+            assert noise.numel() == max_epochs * n_train * self.D
+        if not self.data_dep_init_done and max_epochs > 0:
+            m = min(int(batch), n_train)
+            first = xtrain[perm.view(max_epochs, n_train)[0, :m].long()]
+            nz = noise.view(max_epochs, n_train, self.D)[0, :m] if noise is not None else torch.randn(m, self.D, device=dev)
+            self.actnorm_init(first + float(jitter) * nz)
+        losses = np.zeros((max(max_epochs, 1), 2), np.float32)
+        res = _lib.TrainResult()
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.nnest_spline_train(self._h, _lib.ptr(xtrain), n_train, _lib.ptr(xvalid), n_valid, _lib.ptr(perm),
+                                                    _lib.ptr(noise), int(seed) & 0xFFFFFFFFFFFFFFFF, float(jitter), int(batch),
+                                                    int(max_epochs), int(patience), float(lr), float(weight_decay),
+                                                    losses.ctypes.data_as(ctypes.c_void_p), ctypes.byref(res),
+                                                    _lib.current_stream(dev)))
+        return dict(losses=torch.from_numpy(losses), epochs_run=res.epochs_run, best_epoch=res.best_epoch,
+                    best_validation_loss=res.best_validation_loss, last_train_loss=res.last_train_loss, counter=res.counter,
+                    stopped=bool(res.stopped), result=None)
