@@ -36,7 +36,7 @@ class NestedSampler(Sampler):
                  num_slow=0,
                  num_derived=0,
                  batch_size=100,
-                 flow='nvp',
+                 flow='spline',
                  num_blocks=3,
                  num_layers=1,
                  learning_rate=0.001,
@@ -100,10 +100,15 @@ class NestedSampler(Sampler):
             return
         if self.mpi_rank == 0:
             self.trainer.train(active_u, max_iters=train_iters, jitter=jitter)
-        w = self.trainer.netG.store_packed()
-        w = self._broadcast(w, src=0)
-        if self.mpi_rank != 0:
-            self.trainer.netG.load_packed(w)
+        netG = self.trainer.netG
+        w = self._broadcast(netG.store_packed(), src=0)
+        if hasattr(netG, 'P'):  # spline flow: the fixed permutations of the 1x1 convs are not part of the weights
+            P = self._broadcast(netG.P, src=0)
+            if self.mpi_rank != 0:
+                netG.load_packed(w, P)
+                netG.data_dep_init_done = True
+        elif self.mpi_rank != 0:
+            netG.load_packed(w)
 
     def _checkpoint(self, it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt, state):
         cp = self.logs['checkpoint']

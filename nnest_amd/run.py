@@ -66,7 +66,7 @@ if __name__ == '__main__':
     p.add_argument('--switch', type=float, default=-1)
     p.add_argument('--hidden_dim', type=int, default=16)
     p.add_argument('--num_layers', type=int, default=1)
-    p.add_argument('--flow', type=str, default='nvp')
+    p.add_argument('--flow', type=str, default='spline')
     p.add_argument('--num_blocks', type=int, default=3)
     p.add_argument('--jitter', type=float, default=-1)
     p.add_argument('--log_dir', type=str, default='logs')

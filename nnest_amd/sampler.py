@@ -48,7 +48,7 @@ class Sampler(object):
                  num_slow=0,
                  num_derived=0,
                  batch_size=100,
-                 flow='nvp',
+                 flow='spline',
                  num_blocks=3,
                  num_layers=1,
                  learning_rate=0.001,

@@ -1,4 +1,4 @@
-"""Trainer: drop-in for the reference's nnest.trainer.Trainer on the path flow='nvp', num_slow=0, N(0,I) base.
+"""Trainer: drop-in for the reference's nnest.trainer.Trainer on the paths flow='nvp' and flow='spline', num_slow=0, N(0,I) base.
 
 Same constructor keywords, attributes and method contracts as the reference (nnest/trainer.py:28-301), so
 that `NestedSampler(..., trainer=Trainer(...))` -- the reference's own injection point (nnest/sampler.py:50,
@@ -27,7 +27,7 @@ class Trainer(object):
                  hidden_dim=16,
                  num_slow=0,
                  batch_size=100,
-                 flow='nvp',
+                 flow='spline',
                  scale='',
                  num_blocks=3,
                  num_layers=1,
@@ -45,9 +45,10 @@ class Trainer(object):
         if not torch.cuda.is_available():
             raise _lib.NnestHipError('nnest_amd.Trainer needs an MI355X (torch.cuda.is_available() is False); '
                                      'there is no CPU fallback')
-        if flow.lower() != 'nvp':
-            raise NotImplementedError("flow=%r: this build implements the RealNVP path (flow='nvp'); the spline and "
-                                      "Choleksy flows of the reference are outside its scope (DESIGN.md)" % flow)
+        if flow.lower() not in ('nvp', 'spline'):
+            raise NotImplementedError("flow=%r: this build implements flow='nvp' (RealNVP) and flow='spline' (neural spline "
+                                      "flow); the Choleksy flow of the reference is outside its scope (DESIGN.md)" % flow)
+        self.flow = flow.lower()
         if num_slow != 0:
             raise NotImplementedError('num_slow > 0 (fast/slow hierarchy) is outside the scope of this build')
         scale = '' if scale is None else scale
@@ -77,7 +78,11 @@ class Trainer(object):
         self.num_slow = 0
         self.learning_rate = learning_rate
         self.weight_decay = weight_decay
-        self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed, scale=scale)
+        if self.flow == 'spline':    # SingleSpeedSpline(x_dim, hidden_dim, num_blocks, tail_bound=3)  (trainer.py:97-98)
+            from .spline import HipSpline
+            self.netG = HipSpline(x_dim, hidden_dim, num_blocks, num_bins=8, tail_bound=3.0, device=self.gpu, seed=seed)
+        else:
+            self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed, scale=scale)
         if load_model:
             self.path = os.path.join(log_dir, load_model)
             self.netG.load_state_dict(torch.load(os.path.join(self.path, 'models', 'netG.pt')))
@@ -90,7 +95,8 @@ class Trainer(object):
         self.logger = create_logger(__name__, level=log_level)
         self.log = log
         self.writer = ScalarWriter(self.path)
-        self.logger.info('Number of network params: [%s]' % self.netG.reference_vector().size)
+        self.logger.info('Number of network params: [%s]' % (self.netG.reference_vector().size if self.flow == 'nvp'
+                                                             else self.netG.num_params))
         self.logger.info('Device [%s]' % self.device)
 
     # ------------------------------------------------------------------------------------------------
@@ -133,7 +139,7 @@ class Trainer(object):
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
         result, res, done, all_losses = None, None, 0, []
         while done < max_iters:
-            chunk = min(EPOCH_CHUNK, max_iters - done)
+            chunk = min(getattr(self.netG, 'epoch_chunk', EPOCH_CHUNK), max_iters - done)
             if perms is not None:
                 perm = torch.as_tensor(perms[done:done + chunk])
             else:  # DataLoader(shuffle=True): a fresh permutation per epoch (trainer.py:185)

@@ -28,7 +28,7 @@ def run(tmp, D, like, scale, N, seed, **kw):
     np.random.seed(seed)
     torch.manual_seed(seed)
     s = NestedSampler(D, like, transform=lambda x: scale * x, log_dir=str(tmp), num_live_points=N, log_level=30,
-                      hidden_dim=16, num_blocks=3, num_layers=1)
+                      hidden_dim=16, num_blocks=3, num_layers=1, flow=kw.pop('flow', 'nvp'))
     assert s._fused_like_id is not None, 'fused HIP path not selected'
     s.run(**kw)
     return s
@@ -103,7 +103,7 @@ def test_user_callable_likelihood_runs_on_the_host_protocol(tmp_path):
     def rosen(x):  # x: (N, 2) already transformed
         return -(100.0 * (x[:, 1] - x[:, 0] ** 2) ** 2 + (1 - x[:, 0]) ** 2)
 
-    s = NestedSampler(2, rosen, transform=lambda x: 5 * x, log_dir=str(tmp_path), num_live_points=300, log_level=30)
+    s = NestedSampler(2, rosen, transform=lambda x: 5 * x, log_dir=str(tmp_path), num_live_points=300, log_level=30, flow='nvp')
     assert s._fused_like_id is None
     s.run(mcmc_num_chains=20, train_iters=200)
     assert abs(s.logz - LOGZ_ROSEN2D) <= 0.35, s.logz   # 300 live points: sqrt(h/N) ~ 0.13
@@ -124,7 +124,7 @@ def test_trainer_chunked_launches_equal_one_launch(tmp_path):
     for chunk in (128, 1000):
         trainer_mod.EPOCH_CHUNK = chunk
         torch.manual_seed(7)
-        t = Trainer(D, log_dir=None, learning_rate=1e-3, seed=1, log_level=30)
+        t = Trainer(D, log_dir=None, learning_rate=1e-3, seed=1, log_level=30, flow='nvp')
         t.train(live, max_iters=E, jitter=0.01, split=split, perms=perms, patience=40)
         outs.append((t.netG.store_packed(), t.best_validation_epoch, t.best_validation_loss, t.total_iters, t.losses.copy()))
     trainer_mod.EPOCH_CHUNK = 128
@@ -151,9 +151,36 @@ def test_flow_rejection_with_host_likelihood(tmp_path):
     np.random.seed(5)
     torch.manual_seed(5)
     s = NestedSampler(2, lambda x: -(100.0 * (x[:, 1] - x[:, 0] ** 2) ** 2 + (1 - x[:, 0]) ** 2), transform=lambda x: 5 * x,
-                      log_dir=str(tmp_path), num_live_points=200, log_level=30)
+                      log_dir=str(tmp_path), num_live_points=200, log_level=30, flow='nvp')
     assert s._fused_like_id is None
     s.run(strategy=['rejection_prior', 'rejection_flow'], train_iters=200, max_iters=900)
     x, logl, derived, ncall = s._density_sample(float(np.median(s.loglikes[-200:])))
     assert x.shape == (1, 2) and logl.shape == (1,) and ncall >= 1 and logl[0] > np.median(s.loglikes[-200:])
     assert np.isfinite(s.logz)
+
+
+def test_spline_flow_rosenbrock_2d_reference_integration_test(tmp_path):
+    """The reference's own integration test (tests/test_nested.py:10-19) on its default flow, the neural spline flow:
+    Rosenbrock 2-D, 1000 live points, 10 chains, fixed step; |logZ + 5.80| <= 0.2."""
+    s = run(tmp_path, 2, Rosenbrock(2), 5.0, 1000, 0, flow='spline', mcmc_num_chains=10, mcmc_dynamic_step_size=False)
+    from nnest_amd.spline import HipSpline
+    assert isinstance(s.trainer.netG, HipSpline) and s.trainer.netG.data_dep_init_done
+    assert abs(s.logz - LOGZ_ROSEN2D) <= 0.2, s.logz
+    mean = np.sum(s.samples * s.weights[:, None], 0)
+    assert abs(mean[0] - 1.0) < 0.15 and abs(mean[1] - 1.5) < 0.25
+
+
+def test_spline_flow_default_and_wide_batch(tmp_path):
+    """flow='spline' is the default of the reference (nested.py:35) and of this build; one walker per live point."""
+    np.random.seed(4)
+    torch.manual_seed(4)
+    s = NestedSampler(2, Rosenbrock(2), transform=lambda x: 5 * x, log_dir=str(tmp_path), num_live_points=500, log_level=30)
+    assert type(s.trainer.netG).__name__ == 'HipSpline' and s._fused_like_id is not None
+    s.run(mcmc_num_chains=500, train_iters=300)
+    assert abs(s.logz - LOGZ_ROSEN2D) <= 0.3, s.logz
+
+
+def test_spline_flow_gaussian_mixture_5d(tmp_path):
+    # 5-D mixture of 4 unit Gaussians inside [-10,10]^5: Z = 20^-5 up to tails
+    s = run(tmp_path, 5, GaussianMix(5), 10.0, 500, 6, flow='spline', mcmc_num_chains=100, train_iters=300)
+    assert abs(s.logz - 5 * math.log(1 / 20.0)) <= 0.5, s.logz

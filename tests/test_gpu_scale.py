@@ -143,7 +143,7 @@ def test_nested_run_with_scale_variant(tmp_path, scale):
     np.random.seed(2)
     torch.manual_seed(2)
     s = NestedSampler(2, Rosenbrock(2), transform=lambda x: 5 * x, log_dir=str(tmp_path), num_live_points=400, log_level=30,
-                      scale=scale)
+                      scale=scale, flow='nvp')
     assert s._fused_like_id is not None and s.trainer.netG.scale == scale
     s.run(mcmc_num_chains=40, train_iters=300)
     logz = math.log(math.pi / 10 * (1 - 0.5 * math.erfc(math.sqrt(5) - 1)) / 100)

@@ -52,6 +52,7 @@ def test_passes_vs_reference_fixture(hip, path):
     assert rel(cpu(xi), g['x_inv_raw']) < tol and rel(cpu(ldi), g['ld_inv_raw']) < tol
     for tag in ('init', 'trained'):
         sp.load_packed(g['w_' + tag], g['P'])
+        sp.data_dep_init_done = True   # these weights are past ActNorm's first-batch initialisation (networks.py:696)
         assert np.array_equal(sp.store_packed(), g['w_' + tag]) and np.array_equal(sp.P, g['P'])
         x = g['x']
         # measured against the float64 oracle the kernels sit at 1e-6..2e-6, the level of the reference's own float32
@@ -78,6 +79,7 @@ def test_ragged_sizes_and_fused_eval(hip):
     D, H, B, K = 5, 16, 3, 8
     sp = hip.HipSpline(D, H, B, K, 3.0)
     sp.load_packed(g['w_trained'], g['P'])
+    sp.data_dep_init_done = True
     o = orc.Spline(D, H, B, K, 3.0, g['w_trained'], g['P'])
     rng = np.random.RandomState(0)
     for N in (0, 1, 15, 16, 17, 1000, 70001):
@@ -104,6 +106,7 @@ def test_fused_proposal_kernel_vs_oracle(hip, name, C):
     D, H, B, K = int(g['D']), int(g['H']), int(g['B']), int(g['K'])
     sp = hip.HipSpline(D, H, B, K, 3.0)
     sp.load_packed(g['w_trained'], g['P'])
+    sp.data_dep_init_done = True
     o = orc.Spline(D, H, B, K, 3.0, g['w_trained'], g['P'])
     rng = np.random.RandomState(C)
     S = 8

@@ -180,11 +180,11 @@ def test_l2_norm_and_explicit_standard_normal_base(hip, tmp_path):
     outs = []
     for l2, wd in ((0.01, 1e-6), (0.0, 1e-6 + 0.02)):
         base = torch.distributions.MultivariateNormal(torch.zeros(D), torch.eye(D))
-        t = Trainer(D, log_dir=None, learning_rate=1e-3, weight_decay=wd, seed=1, log_level=30, base_dist=base)
+        t = Trainer(D, log_dir=None, learning_rate=1e-3, weight_decay=wd, seed=1, log_level=30, base_dist=base, flow='nvp')
         t.train(live, max_iters=E, jitter=0.01, split=split, perms=perms, noises=noises, l2_norm=l2)
         outs.append(t.netG.store_packed())
     assert np.max(np.abs(outs[0] - outs[1])) < 1e-7
-    w0 = Trainer(D, log_dir=None, seed=1, log_level=30).netG.store_packed()
+    w0 = Trainer(D, log_dir=None, seed=1, log_level=30, flow='nvp').netG.store_packed()
     o = orc.NVP(D, 16, 3, 1, w0)
     o.train(live, split, perms, noises, 0.01, E, wd=1e-6 + 0.02)
     d_ref, d_our = o.w - w0, outs[0] - w0
