@@ -128,7 +128,14 @@ __device__ __forceinline__ void spl_hidden(const float *__restrict__ net, int la
 // raw[24]: widths logits [0,8), heights logits [8,16), inner-derivative logits [16,23), pad.  Identity outside
 // [-tail, tail].  The reference applies softmax twice to widths/heights (NSF_CL, scaled by 2B; then RQS) and
 // softplus twice to the inner derivatives: restated as is.  Returns y; *ld += log|dy/dx|.
-__device__ __forceinline__ float spl_softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }
+// v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32 (1 ulp each; quarter rate) instead of the correctly-rounded library
+// sequences: the spline evaluation is VALU-bound (about 40 exponentials per dimension and direction), and with the
+// library calls it cost ~6x more than the matrix work around it.  Measured against the float64 oracle the passes stay at
+// the 1e-6 level of the reference's own float32 (tools/spline_err.py).
+__device__ __forceinline__ float spl_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
+__device__ __forceinline__ float spl_log(float v) { return __builtin_amdgcn_logf(v) * 0.6931471805599453f; }
+__device__ __forceinline__ float spl_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float spl_softplus(float v) { return v > 20.f ? v : spl_log(1.f + spl_exp(v)); }
 
 __device__ __forceinline__ void spl_softmax8(const float (&in)[SPL_K], float (&out)[SPL_K]) {
     float mx = in[0];
@@ -136,9 +143,10 @@ __device__ __forceinline__ void spl_softmax8(const float (&in)[SPL_K], float (&o
     for (int k = 1; k < SPL_K; ++k) mx = fmaxf(mx, in[k]);
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < SPL_K; ++k) { out[k] = expf(in[k] - mx); s += out[k]; }
+    for (int k = 0; k < SPL_K; ++k) { out[k] = spl_exp(in[k] - mx); s += out[k]; }
+    const float rs = spl_rcp(s);
 #pragma unroll
-    for (int k = 0; k < SPL_K; ++k) out[k] = out[k] / s;
+    for (int k = 0; k < SPL_K; ++k) out[k] = out[k] * rs;
 }
 
 // knots of one axis: unnormalised -> softmax -> min bin + cumsum -> [-tail, tail]; returns the K+1 edges and K sizes
@@ -161,20 +169,25 @@ __device__ __forceinline__ void spl_knots(const float (&logits)[SPL_K], float ta
     for (int k = 0; k < SPL_K; ++k) size[k] = edge[k + 1] - edge[k];
 }
 
+// inner-knot derivative k (1..K-1) from its logit: min_derivative + softplus(softplus(v)); the end knots are
+// min_derivative + softplus(log(e^{1 - min_derivative} - 1)) = 1 (networks.py:436-439, :486)
+__device__ __forceinline__ float spl_knot_deriv(const float (&ldv)[SPL_K - 1], int k) {
+    float v = ldv[0];
+#pragma unroll
+    for (int i = 1; i < SPL_K - 1; ++i) v = (k == i + 1) ? ldv[i] : v;
+    const float d = 1e-3f + spl_softplus(spl_softplus(v));
+    return (k <= 0 || k >= SPL_K) ? 1.0f : d;
+}
+
 template <bool INV>
 __device__ __forceinline__ float spl_rqs(const f32x4 (&raw)[SPL_QT], float tail, float x, float &ld) {
     float lw[SPL_K] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w, raw[1].x, raw[1].y, raw[1].z, raw[1].w};
     float lh[SPL_K] = {raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
     float ldv[SPL_K - 1] = {raw[4].x, raw[4].y, raw[4].z, raw[4].w, raw[5].x, raw[5].y, raw[5].z};
     const bool inside = x >= -tail && x <= tail;
-    float cw[SPL_K + 1], wd[SPL_K], ch[SPL_K + 1], ht[SPL_K], dv[SPL_K + 1];
+    float cw[SPL_K + 1], wd[SPL_K], ch[SPL_K + 1], ht[SPL_K];
     spl_knots(lw, tail, cw, wd);
     spl_knots(lh, tail, ch, ht);
-    const float constant = logf(expf(1.f - 1e-3f) - 1.f);  // networks.py:437
-    dv[0] = 1e-3f + spl_softplus(constant);
-    dv[SPL_K] = dv[0];
-#pragma unroll
-    for (int k = 1; k < SPL_K; ++k) dv[k] = 1e-3f + spl_softplus(spl_softplus(ldv[k - 1]));
     // searchsorted (networks.py:417-422): edges <= x, last edge + 1e-6
     int bin = -1;
 #pragma unroll
@@ -184,14 +197,15 @@ __device__ __forceinline__ float spl_rqs(const f32x4 (&raw)[SPL_QT], float tail,
         bin += (x >= e) ? 1 : 0;
     }
     bin = bin < 0 ? 0 : (bin > SPL_K - 1 ? SPL_K - 1 : bin);
-    float icw = cw[0], ibw = wd[0], ich = ch[0], ih = ht[0], d0 = dv[0], d1 = dv[1];
+    float icw = cw[0], ibw = wd[0], ich = ch[0], ih = ht[0];
 #pragma unroll
     for (int k = 1; k < SPL_K; ++k) {
         const bool s = bin == k;
         icw = s ? cw[k] : icw; ibw = s ? wd[k] : ibw; ich = s ? ch[k] : ich; ih = s ? ht[k] : ih;
-        d0 = s ? dv[k] : d0; d1 = s ? dv[k + 1] : d1;
     }
-    const float delta = ih / ibw;
+    const float d0 = spl_knot_deriv(ldv, bin), d1 = spl_knot_deriv(ldv, bin + 1);
+    const float ribw = spl_rcp(ibw);
+    const float delta = ih * ribw;
     float out, lad;
     if (INV) {  // networks.py:515-539
         const float dx = x - ich, sdd = d0 + d1 - 2.f * delta;
@@ -199,20 +213,20 @@ __device__ __forceinline__ float spl_rqs(const f32x4 (&raw)[SPL_QT], float tail,
         const float b = ih * d0 - dx * sdd;
         const float c = -delta * dx;
         const float disc = b * b - 4.f * a * c;
-        const float root = (2.f * c) / (-b - sqrtf(disc));
+        const float root = (2.f * c) * spl_rcp(-b - __builtin_amdgcn_sqrtf(disc));
         out = root * ibw + icw;
         const float tomt = root * (1.f - root);
         const float den = delta + sdd * tomt;
         const float num = delta * delta * (d1 * root * root + 2.f * delta * tomt + d0 * (1.f - root) * (1.f - root));
-        lad = -(logf(num) - 2.f * logf(den));
+        lad = -(spl_log(num) - 2.f * spl_log(den));
     } else {  // networks.py:541-556
-        const float theta = (x - icw) / ibw;
+        const float theta = (x - icw) * ribw;
         const float tomt = theta * (1.f - theta);
         const float numer = ih * (delta * theta * theta + d0 * tomt);
         const float den = delta + (d0 + d1 - 2.f * delta) * tomt;
-        out = ich + numer / den;
+        out = ich + numer * spl_rcp(den);
         const float num = delta * delta * (d1 * theta * theta + 2.f * delta * tomt + d0 * (1.f - theta) * (1.f - theta));
-        lad = logf(num) - 2.f * logf(den);
+        lad = spl_log(num) - 2.f * spl_log(den);
     }
     ld += inside ? lad : 0.f;
     return inside ? out : x;

@@ -142,7 +142,7 @@ __device__ __forceinline__ void spl_knots_bwd(const float (&logits)[SPL_K], floa
     for (int k = 0; k < SPL_K; ++k) g_logits[k] = a[k] * (ga[k] - dot2);
 }
 
-__device__ __forceinline__ float spl_sigmoid(float v) { return 1.f / (1.f + expf(-v)); }
+__device__ __forceinline__ float spl_sigmoid(float v) { return spl_rcp(1.f + spl_exp(-v)); }
 
 // Forward RQ spline of one scalar with its reverse mode: given gy = dLoss/dy and gl = dLoss/d(log|dy/dx|), returns
 // dLoss/dx and dLoss/d(raw[24]) (0 outside the interval, where the map is the identity).  y and the log-derivative are
@@ -153,19 +153,9 @@ __device__ __forceinline__ float spl_rqs_fwd_bwd(const f32x4 (&raw)[SPL_QT], flo
     float lh[SPL_K] = {raw[2].x, raw[2].y, raw[2].z, raw[2].w, raw[3].x, raw[3].y, raw[3].z, raw[3].w};
     float ldv[SPL_K - 1] = {raw[4].x, raw[4].y, raw[4].z, raw[4].w, raw[5].x, raw[5].y, raw[5].z};
     const bool inside = x >= -tail && x <= tail;
-    float cw[SPL_K + 1], wd[SPL_K], ch[SPL_K + 1], ht[SPL_K], dv[SPL_K + 1], ddv[SPL_K + 1];
+    float cw[SPL_K + 1], wd[SPL_K], ch[SPL_K + 1], ht[SPL_K];
     spl_knots(lw, tail, cw, wd);
     spl_knots(lh, tail, ch, ht);
-    const float constant = logf(expf(1.f - 1e-3f) - 1.f);
-    dv[0] = 1e-3f + spl_softplus(constant);
-    dv[SPL_K] = dv[0];
-    ddv[0] = 0.f; ddv[SPL_K] = 0.f;
-#pragma unroll
-    for (int k = 1; k < SPL_K; ++k) {
-        const float s1 = spl_softplus(ldv[k - 1]);
-        dv[k] = 1e-3f + spl_softplus(s1);
-        ddv[k] = spl_sigmoid(s1) * spl_sigmoid(ldv[k - 1]);  // d dv / d logit
-    }
     int bin = -1;
 #pragma unroll
     for (int k = 0; k <= SPL_K; ++k) {
@@ -174,27 +164,36 @@ __device__ __forceinline__ float spl_rqs_fwd_bwd(const f32x4 (&raw)[SPL_QT], flo
         bin += (x >= e) ? 1 : 0;
     }
     bin = bin < 0 ? 0 : (bin > SPL_K - 1 ? SPL_K - 1 : bin);
-    float icw = cw[0], ibw = wd[0], ich = ch[0], ih = ht[0], d0 = dv[0], d1 = dv[1];
+    float icw = cw[0], ibw = wd[0], ich = ch[0], ih = ht[0];
 #pragma unroll
     for (int k = 1; k < SPL_K; ++k) {
         const bool s = bin == k;
         icw = s ? cw[k] : icw; ibw = s ? wd[k] : ibw; ich = s ? ch[k] : ich; ih = s ? ht[k] : ih;
-        d0 = s ? dv[k] : d0; d1 = s ? dv[k + 1] : d1;
     }
+    // the two knot derivatives of the selected bin and d(knot)/d(logit) = sigmoid(softplus(v)) sigmoid(v)
+    float v0 = ldv[0], v1 = ldv[0];
+#pragma unroll
+    for (int i = 1; i < SPL_K - 1; ++i) { v0 = (bin == i + 1) ? ldv[i] : v0; v1 = (bin + 1 == i + 1) ? ldv[i] : v1; }
+    const bool in0 = bin >= 1, in1 = bin + 1 <= SPL_K - 1;  // inner knots carry a parameter, the end knots are 1
+    const float s0 = spl_softplus(v0), s1 = spl_softplus(v1);
+    const float d0 = in0 ? 1e-3f + spl_softplus(s0) : 1.0f, d1 = in1 ? 1e-3f + spl_softplus(s1) : 1.0f;
+    const float dd0 = in0 ? spl_sigmoid(s0) * spl_sigmoid(v0) : 0.f, dd1 = in1 ? spl_sigmoid(s1) * spl_sigmoid(v1) : 0.f;
     // forward (networks.py:541-556)
-    const float delta = ih / ibw;
-    const float theta = (x - icw) / ibw;
+    const float ribw = spl_rcp(ibw);
+    const float delta = ih * ribw;
+    const float theta = (x - icw) * ribw;
     const float tomt = theta * (1.f - theta);
     const float sdd = d0 + d1 - 2.f * delta;
     const float Nn = ih * (delta * theta * theta + d0 * tomt);
     const float Dn = delta + sdd * tomt;
+    const float rDn = spl_rcp(Dn);
     const float Q = d1 * theta * theta + 2.f * delta * tomt + d0 * (1.f - theta) * (1.f - theta);
     const float dn = delta * delta * Q;
-    y = inside ? ich + Nn / Dn : x;
-    lad = inside ? logf(dn) - 2.f * logf(Dn) : 0.f;
+    y = inside ? ich + Nn * rDn : x;
+    lad = inside ? spl_log(dn) - 2.f * spl_log(Dn) : 0.f;
     // reverse
-    float g_ich = gy, g_N = gy / Dn, g_Dn = -gy * Nn / (Dn * Dn) - 2.f * gl / Dn;
-    const float g_dn = gl / dn;
+    float g_ich = gy, g_N = gy * rDn, g_Dn = -gy * Nn * rDn * rDn - 2.f * gl * rDn;
+    const float g_dn = gl * spl_rcp(dn);
     float g_delta = g_dn * (2.f * delta * Q + delta * delta * 2.f * tomt);
     const float g_Q = g_dn * delta * delta;
     float g_d1 = g_Q * theta * theta, g_d0 = g_Q * (1.f - theta) * (1.f - theta);
@@ -209,17 +208,17 @@ __device__ __forceinline__ float spl_rqs_fwd_bwd(const f32x4 (&raw)[SPL_QT], flo
     g_d0 += g_N * ih * tomt;
     g_t += g_N * ih * d0;
     g_theta += g_t * (1.f - 2.f * theta);
-    g_ih += g_delta / ibw;
-    float g_ibw = -g_delta * ih / (ibw * ibw);
-    const float gx = g_theta / ibw;
-    const float g_icw = -g_theta / ibw;
-    g_ibw += -g_theta * theta / ibw;
+    g_ih += g_delta * ribw;
+    float g_ibw = -g_delta * ih * ribw * ribw;
+    const float gx = g_theta * ribw;
+    const float g_icw = -g_theta * ribw;
+    g_ibw += -g_theta * theta * ribw;
     float glw[SPL_K], glh[SPL_K];
     spl_knots_bwd(lw, tail, bin, g_icw, g_ibw, glw);
     spl_knots_bwd(lh, tail, bin, g_ich, g_ih, glh);
     float gld[SPL_K];  // index k-1 for inner knot k
 #pragma unroll
-    for (int k = 1; k < SPL_K; ++k) gld[k - 1] = ((bin == k) ? g_d0 : 0.f) * ddv[k] + ((bin + 1 == k) ? g_d1 : 0.f) * ddv[k];
+    for (int k = 1; k < SPL_K; ++k) gld[k - 1] = ((bin == k) ? g_d0 * dd0 : 0.f) + ((bin + 1 == k) ? g_d1 * dd1 : 0.f);
     gld[SPL_K - 1] = 0.f;
     const float m = inside ? 1.f : 0.f;
     graw[0] = (f32x4){glw[0], glw[1], glw[2], glw[3]} * m; graw[1] = (f32x4){glw[4], glw[5], glw[6], glw[7]} * m;

@@ -16,6 +16,7 @@ for path in sorted(glob.glob('tests/golden/spline_*.npz')):
     sp = spline.HipSpline(D, H, B, K, 3.0)
     for tag in ('init', 'trained'):
         sp.load_packed(g['w_' + tag], g['P'])
+        sp.data_dep_init_done = True
         o = orc.Spline(D, H, B, K, 3.0, g['w_' + tag], g['P'])
         x = g['x']
         z64, ld64 = o.forward(x, f64=True)
