@@ -177,6 +177,8 @@ struct SplGradArgs {
     float *partial;     // [tiles][gw_floats]
     float *stash;       // [tiles][B][2 NTh][64] f32x4
     int mode;
+    int rows_per_tile;  // 16, 8 or 4: a minibatch is only 100 rows, so the tiles are made shallower to spread them over
+                        // more waves / CUs (the matrix-core columns of the unused walkers idle; the launch is latency-bound)
 };
 
 template <int NTh>
@@ -392,8 +394,8 @@ __global__ void __launch_bounds__(64) spl_grad_kernel(SplGradArgs a) {
     const int D = s.D, B = s.B;
     float *buf = lds;                    // 16 x (D+1): layout exchange
     float *lds17 = lds + 16 * (D + 1);   // 16 x 17: tile transposes
-    const int row = tile * 16 + w;
-    const bool ok = row < a.M;
+    const int row = tile * a.rows_per_tile + w;
+    const bool ok = w < a.rows_per_tile && row < a.M;
     float *gp = a.partial + (size_t)tile * ts.gw_floats;
     f32x4 *stash = reinterpret_cast<f32x4 *>(a.stash) + (size_t)tile * B * 2 * NTh * 64;
 
@@ -742,8 +744,10 @@ __global__ void __launch_bounds__(512) spl_init_kernel(SplInitArgs a) {
         }                                                                                                             \
     } while (0)
 
+static int grad_tiles(const SplGradArgs &a) { return (a.M + a.rows_per_tile - 1) / a.rows_per_tile; }
+
 static hipError_t launch_grad(const SplGradArgs &a, hipStream_t st) {
-    const int tiles = (a.M + 15) / 16;
+    const int tiles = grad_tiles(a);
     const size_t ldsb = (size_t)(16 * (a.ts.s.D + 1) + 16 * 17) * sizeof(float);
     DISPATCH_SPLT(spl_grad_kernel, a.ts.s, tiles, 64, ldsb, st, a);
     return hipGetLastError();
@@ -779,7 +783,7 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
         h->adam_step = 0;
         h->w_dev_current = false;
     }
-    const int tiles = (max_rows + 15) / 16;
+    const int tiles = (max_rows + 15) / 16 > 32 ? (max_rows + 15) / 16 : 32;  // batches of <= 128 rows run 4 rows per tile: 32 tiles
     if (tiles > h->partial_tiles) {
         if (h->partial) { (void)hipFree(h->partial); (void)hipFree(h->stash); }
         SHIP_TRY(hipMalloc((void **)&h->partial, (size_t)tiles * ts.gw_floats * sizeof(float)));
@@ -799,6 +803,9 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
     }
     return NNEST_OK;
 }
+
+// the per-wave instruction stream does not shrink with fewer rows per tile (measured: no gain from 4-row tiles), so 16
+static int rows_per_tile(int M) { (void)M; return 16; }
 
 static int build_timage(nnest_spline *h, const SplTrainShape &ts, hipStream_t st) {
     hipLaunchKernelGGL(spl_assemble_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev, h->wmat, ts);
@@ -852,8 +859,9 @@ int nnest_spline_loss_grad(nnest_spline_t *h, const float *x_dev, int M, float *
     memset(&a, 0, sizeof(a));
     a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = x_dev; a.M = M; a.mtot = M; a.partial = h->partial; a.stash = h->stash;
     a.mode = SPL_MODE_GRAD;
+    a.rows_per_tile = rows_per_tile(M);
     SHIP_TRY(launch_grad(a, st));
-    const int tiles = (M + 15) / 16;
+    const int tiles = grad_tiles(a);
     hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, grad_dev, h->gwsum, loss_dev,
                        -1.0f / (float)M);
     hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts);
@@ -892,9 +900,10 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             a.M = M; a.mtot = M; a.noise = noise_dev ? noise_dev + ((size_t)epoch * n_train + (size_t)mb * batch) * D : nullptr;
             a.seed = seed; a.noise_row0 = (long)mb * batch; a.epoch = epoch; a.jitter = jitter;
             a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_GRAD;
+            a.rows_per_tile = rows_per_tile(M);
             if ((rc = build_timage(h, ts, st))) return rc;
             SHIP_TRY(launch_grad(a, st));
-            const int tiles = (M + 15) / 16;
+            const int tiles = grad_tiles(a);
             hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, h->grad, h->gwsum,
                                h->losses_dev + mb, -1.0f / (float)M);
             hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + B * D, h->pi_dev, h->gwsum, h->grad, ts);
@@ -910,8 +919,9 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             memset(&a, 0, sizeof(a));
             a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = xvalid_dev; a.M = n_valid; a.mtot = n_valid;
             a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_LOSS;
+            a.rows_per_tile = rows_per_tile(n_valid);
             SHIP_TRY(launch_grad(a, st));
-            hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, (n_valid + 15) / 16, ts, h->w_dev, h->grad,
+            hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, grad_tiles(a), ts, h->w_dev, h->grad,
                                h->gwsum, h->losses_dev + n_mb, -1.0f / (float)n_valid);
         }
         SHIP_TRY(hipMemcpyAsync(lh.data(), h->losses_dev, ((size_t)n_mb + 1) * sizeof(float), hipMemcpyDeviceToHost, st));

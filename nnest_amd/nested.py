@@ -335,12 +335,15 @@ class NestedSampler(Sampler):
                     loglikes = np.stack([ends[:, -1], ends[:, -1]], axis=1)
                     derived_samples = s_d
                     self.num_batches += 1
+                    # per-candidate quantities of the consumption loop below, once per batch instead of once per look
+                    moved = np.all(samples[:, 0, :] != samples[:, -1, :], axis=1)
+                    end_v = self.transform(samples[:, -1, :])
                 for ib in range(nb, samples.shape[0]):
                     nb += 1
                     get_samples = nb == samples.shape[0]
-                    if np.all(samples[ib, 0, :] != samples[ib, -1, :]) and loglikes[ib, -1] > loglstar:
+                    if moved[ib] and loglikes[ib, -1] > loglstar:    # nested.py:432
                         active_u[worst] = samples[ib, -1, :]
-                        active_v[worst] = self.transform(active_u[worst])
+                        active_v[worst] = end_v[ib]
                         active_logl[worst] = loglikes[ib, -1]
                         if self.num_derived > 0 and not self.use_mpi:
                             active_derived[worst] = derived_samples[ib, -1, :]
