@@ -92,6 +92,50 @@ __global__ void __launch_bounds__(256) spline_mh_kernel(MhArgs a, SplArgs q) {
     mh_body<NT, DBG>(a, tile, lane, inv, noise, true);
 }
 
+// Team form for small populations (fewer walker tiles than CUs): one workgroup of four waves per tile.  All four carry the
+// same proposal state (same noise streams, same decisions); only the spline evaluations of the flow inverse are divided
+// (spl_coupling TEAM = 4), and the log-det partials are summed through LDS.  Wave 0 writes the results.
+template <int NT, int NH, int TEAM>
+struct SplineInverseTeam {
+    const float *img;
+    SplineShape sp;
+    float *buf;     // this wave's 16 x (D+1) layout-exchange buffer
+    f32x4 *xch;     // [TEAM][NT][64]
+    float *ldred;   // [TEAM][16]
+    int lane, wv;
+#ifdef NNEST_STAMP
+    unsigned long long t_mlp = 0, t_xch = 0, t_upd = 0;
+#endif
+    __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
+        f32x4 t[2][NT];
+        spl_from_parity<NT>(buf, sp.D, sp.nl, lane, xs, t);
+        float ld = group_sum(spline_inverse_tile<NT, NH, TEAM>(img, sp, lane, t, wv, xch));
+        if (lane < 16) ldred[wv * 16 + lane] = ld;
+        __syncthreads();
+        const int w = lane & 15;
+        ld = 0.f;
+#pragma unroll
+        for (int k = 0; k < TEAM; ++k) ld += ldred[k * 16 + w];
+        __syncthreads();
+        spl_to_parity<NT>(buf, sp.D, sp.nl, lane, t, xs);
+        return 0.25f * ld;  // the caller sums the four lanes of a walker
+    }
+};
+
+template <int NT, int NH, int TEAM, bool DBG>
+__global__ void __launch_bounds__(64 * TEAM) spline_mh_kernel_team(MhArgs a, SplArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float lds_buf[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x;
+    float *bufs = lds_buf;                                                        // TEAM x 16 x (D+1)
+    f32x4 *xch = reinterpret_cast<f32x4 *>(lds_buf + ((TEAM * 16 * (q.sp.D + 1) + 3) & ~3));  // TEAM x NT x 64 f32x4
+    float *ldred = reinterpret_cast<float *>(xch + TEAM * NT * 64);               // TEAM x 16
+    SplineInverseTeam<NT, NH, TEAM> inv = {q.img, q.sp, bufs + (size_t)wv * 16 * (q.sp.D + 1), xch, ldred, lane, wv};
+    XoshiroNoise<NT> noise;
+    noise.init(a.seed, a.walker_offset + (uint64_t)(tile * 16 + (lane & 15)), lane >> 4, q.sp.D);
+    mh_body<NT, DBG>(a, tile, lane, inv, noise, wv == 0);
+}
+
 bool spline_shape_supported(const SplineShape &s) {
     if (s.K != SPL_K) return false;
     if (s.NH == 1) return s.NTh >= 1 && s.NTh <= 4;
@@ -127,6 +171,15 @@ static hipError_t launch_spline_pass_t(const PassArgs &a, const SplArgs &q, int 
 template <int NT, int NH>
 static hipError_t launch_spline_mh_t(const MhArgs &a, const SplArgs &q, int num_cu, hipStream_t st) {
     const int ntiles = (a.C + 15) / 16;
+    const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
+    // (eight waves per tile measured slower than four: 12.0 vs 8.0 ms at x_dim 50 -- the 512-thread workgroup halves the
+    // register budget and the redundant trunk / affine work grows)
+    if (ntiles <= 2 * num_cu) {  // small population: four waves per walker tile
+        const size_t ldsb = (size_t)(((4 * 16 * (q.sp.D + 1) + 3) & ~3) + 4 * NT * 64 * 4 + 4 * 16) * sizeof(float);
+        if (dbg) hipLaunchKernelGGL((spline_mh_kernel_team<NT, NH, 4, true>), dim3(ntiles), dim3(256), ldsb, st, a, q);
+        else hipLaunchKernelGGL((spline_mh_kernel_team<NT, NH, 4, false>), dim3(ntiles), dim3(256), ldsb, st, a, q);
+        return hipGetLastError();
+    }
     int block, grid;
     pick_geometry(ntiles, num_cu, 4, &block, &grid);
     const size_t lds = (size_t)(block / 64) * 16 * (q.sp.D + 1) * sizeof(float);

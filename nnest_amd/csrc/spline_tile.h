@@ -234,9 +234,12 @@ __device__ __forceinline__ float spl_rqs(const f32x4 (&raw)[SPL_QT], float tail,
 
 // ---- one RQ-spline coupling: the `n_out` dims of `tr` are transformed, conditioned on `cond` ----------------------
 // net image: hidden part (spl_hidden) | L4 [s][q][hti][r][64] | b4 [s][q][g][r]
-template <int NTh, int NH, bool INV>
+// TEAM = 4 or 8: the waves of a workgroup hold the same tile; wave `wv` evaluates the super-tiles s = wv (mod TEAM) and the
+// results are merged through `xch` ([TEAM][NTh][64] f32x4 of LDS).  The trunk is
+// recomputed by every wave (16 MFMAs against 24 per super-tile).
+template <int NTh, int NH, bool INV, int TEAM = 1>
 __device__ __forceinline__ float spl_coupling(const float *__restrict__ net, int S, int n_out, float tail, int lane,
-                                              const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh]) {
+                                              const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv = 0, f32x4 *xch = nullptr) {
     const int g = lane >> 4;
     f32x4 h[NH];
     spl_hidden<NTh, NH>(net, lane, cond, h);
@@ -245,7 +248,7 @@ __device__ __forceinline__ float spl_coupling(const float *__restrict__ net, int
     float ld = 0.f;
 #pragma unroll
     for (int s = 0; s < 4 * NTh; ++s) {
-        if (s < S) {  // uniform over the wave
+        if (s < S && (TEAM == 1 || (s & (TEAM - 1)) == wv)) {  // uniform over the wave
             f32x4 raw[SPL_QT];
 #pragma unroll
             for (int q = 0; q < SPL_QT; ++q) {
@@ -269,23 +272,34 @@ __device__ __forceinline__ float spl_coupling(const float *__restrict__ net, int
             ld += valid ? l : 0.f;
         }
     }
+    if (TEAM > 1) {  // super-tile s = 4t + r (register r of tile t) comes from wave s mod TEAM
+#pragma unroll
+        for (int t = 0; t < NTh; ++t) xch[(wv * NTh + t) * 64 + lane] = tr[t];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NTh; ++t)
+            tr[t] = (f32x4){xch[(((4 * t + 0) & (TEAM - 1)) * NTh + t) * 64 + lane].x, xch[(((4 * t + 1) & (TEAM - 1)) * NTh + t) * 64 + lane].y,
+                            xch[(((4 * t + 2) & (TEAM - 1)) * NTh + t) * 64 + lane].z, xch[(((4 * t + 3) & (TEAM - 1)) * NTh + t) * 64 + lane].w};
+        __syncthreads();
+    }
     return ld;
 }
 
 // ---- the stack -----------------------------------------------------------------------------------------------
 // xs[0] = lower half tiles, xs[1] = upper half tiles.  Returns this lane's log-det partial (sum over the 4 lanes of a
 // walker = the row's log-det); the per-block constants are added on lane group 0.
-template <int NTh, int NH>
-__device__ __forceinline__ float spline_forward_tile(const float *__restrict__ img, const SplineShape &s, int lane, f32x4 (&xs)[2][NTh]) {
+template <int NTh, int NH, int TEAM = 1>
+__device__ __forceinline__ float spline_forward_tile(const float *__restrict__ img, const SplineShape &s, int lane, f32x4 (&xs)[2][NTh],
+                                                     int wv = 0, f32x4 *xch = nullptr) {
     float ld = 0.f;
     for (int b = 0; b < s.B; ++b) {
         const float *blk = img + (size_t)b * s.blk_floats;
         f32x4 y[2][NTh];
         spl_affine<NTh>(blk, lane, xs, y);
         const float *f1 = blk + 2 * s.aff_floats, *f2 = f1 + s.f1_floats;
-        ld += spl_coupling<NTh, NH, false>(f1, s.SU, s.nu, s.tail, lane, y[0], y[1]);   // upper | lower  (networks.py:582-588)
-        ld += spl_coupling<NTh, NH, false>(f2, s.SL, s.nl, s.tail, lane, y[1], y[0]);   // lower | new upper (:589-598)
-        if (lane < 16) ld += (f2 + s.f2_floats)[0];
+        ld += spl_coupling<NTh, NH, false, TEAM>(f1, s.SU, s.nu, s.tail, lane, y[0], y[1], wv, xch);   // upper | lower  (networks.py:582-588)
+        ld += spl_coupling<NTh, NH, false, TEAM>(f2, s.SL, s.nl, s.tail, lane, y[1], y[0], wv, xch);   // lower | new upper (:589-598)
+        if (lane < 16 && wv == 0) ld += (f2 + s.f2_floats)[0];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -294,17 +308,18 @@ __device__ __forceinline__ float spline_forward_tile(const float *__restrict__ i
     return ld;
 }
 
-template <int NTh, int NH>
-__device__ __forceinline__ float spline_inverse_tile(const float *__restrict__ img, const SplineShape &s, int lane, f32x4 (&xs)[2][NTh]) {
+template <int NTh, int NH, int TEAM = 1>
+__device__ __forceinline__ float spline_inverse_tile(const float *__restrict__ img, const SplineShape &s, int lane, f32x4 (&xs)[2][NTh],
+                                                     int wv = 0, f32x4 *xch = nullptr) {
     float ld = 0.f;
     for (int b = s.B - 1; b >= 0; --b) {
         const float *blk = img + (size_t)b * s.blk_floats;
         const float *f1 = blk + 2 * s.aff_floats, *f2 = f1 + s.f1_floats;
-        ld += spl_coupling<NTh, NH, true>(f2, s.SL, s.nl, s.tail, lane, xs[1], xs[0]);  // networks.py:605-614
-        ld += spl_coupling<NTh, NH, true>(f1, s.SU, s.nu, s.tail, lane, xs[0], xs[1]);  // :615-621
+        ld += spl_coupling<NTh, NH, true, TEAM>(f2, s.SL, s.nl, s.tail, lane, xs[1], xs[0], wv, xch);  // networks.py:605-614
+        ld += spl_coupling<NTh, NH, true, TEAM>(f1, s.SU, s.nu, s.tail, lane, xs[0], xs[1], wv, xch);  // :615-621
         f32x4 y[2][NTh];
         spl_affine<NTh>(blk + s.aff_floats, lane, xs, y);
-        if (lane < 16) ld -= (f2 + s.f2_floats)[0];
+        if (lane < 16 && wv == 0) ld -= (f2 + s.f2_floats)[0];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll

@@ -98,7 +98,7 @@ def test_ragged_sizes_and_fused_eval(hip):
     assert np.all(np.isfinite(cpu(xl)))
 
 
-@pytest.mark.parametrize('name,C', [('d5', 40), ('d50', 40), ('d8_h32', 100), ('d50', 3000)])
+@pytest.mark.parametrize('name,C', [('d5', 40), ('d50', 40), ('d8_h32', 100), ('d50', 3000), ('d5', 9000)])
 def test_fused_proposal_kernel_vs_oracle(hip, name, C):
     """K4 with the spline inverse: the kernel's own noise draws (nnest_mh_fill_noise) replayed through the oracle-side
     restatement of Sampler._mcmc_sample's hard-constraint branch (sampler.py:291-444)."""
