@@ -232,10 +232,14 @@ __device__ __forceinline__ f32x4 rows_sum(f32x4 v) {
 // Backward of one coupling: `tr` (n_out dims, S super-tiles) was transformed conditioned on `cond` by the conditioner
 // at packed offset pnet / images cf (forward) and cbw (transposed).  On entry g_tr = dLoss/d(outputs of the transformed
 // half), x_tr = the half BEFORE the transform; on exit g_tr = dLoss/d(x_tr) and g_cond has the conditioner path added.
-template <int NTh, int NH>
+// Team of four waves per tile (TEAM = 4): wave wv owns the super-tiles s = wv (mod 4) -- their spline reverse mode, last-layer
+// weight gradients and share of g_h3 -- and the hidden layers' weight gradients are dealt out one layer per wave; the
+// delta propagation through the trunk is repeated by every wave so that all four leave with the same g_tr / g_cond.
+template <int NTh, int NH, int TEAM>
 __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const float *__restrict__ cf, const float *__restrict__ cbw, int pnet,
                                                  int nin, int nout, int S, int lane, bool row_ok, float gld, float *lds17, float *gp,
-                                                 const f32x4 (&cond)[NTh], const f32x4 (&x_tr)[NTh], f32x4 (&g_tr)[NTh], f32x4 (&g_cond)[NTh]) {
+                                                 const f32x4 (&cond)[NTh], const f32x4 (&x_tr)[NTh], f32x4 (&g_tr)[NTh], f32x4 (&g_cond)[NTh],
+                                                 int wv, f32x4 *xch) {
     const int g = lane >> 4, w = lane & 15, H = ts.s.H;
     const float tail = ts.s.tail;
     f32x4 h[3][NH];
@@ -256,7 +260,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
     for (int ht = 0; ht < NH; ++ht) g_h[ht] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4 * NTh; ++s) {
-        if (s < S) {
+        if (s < S && (TEAM == 1 || (s & (TEAM - 1)) == wv)) {
             f32x4 raw[SPL_QT], graw[SPL_QT];
             spl_raw<NH>(L4, b4, s, lane, h[2], raw);
             const bool valid = row_ok && (4 * s + g < nout);
@@ -301,9 +305,29 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
             }
         }
     }
+    if (TEAM > 1) {  // merge the transformed-half gradients (register r of tile t from wave (4t + r) mod TEAM) and sum g_h3
+#pragma unroll
+        for (int t = 0; t < NTh; ++t) xch[(wv * NTh + t) * 64 + lane] = g_tr[t];
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) xch[(TEAM * NTh + wv * NH + ht) * 64 + lane] = g_h[ht];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NTh; ++t)
+            g_tr[t] = (f32x4){xch[(((4 * t + 0) & (TEAM - 1)) * NTh + t) * 64 + lane].x, xch[(((4 * t + 1) & (TEAM - 1)) * NTh + t) * 64 + lane].y,
+                              xch[(((4 * t + 2) & (TEAM - 1)) * NTh + t) * 64 + lane].z, xch[(((4 * t + 3) & (TEAM - 1)) * NTh + t) * 64 + lane].w};
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) {
+            f32x4 acc = xch[(TEAM * NTh + 0 * NH + ht) * 64 + lane];
+#pragma unroll
+            for (int k = 1; k < TEAM; ++k) acc = acc + xch[(TEAM * NTh + k * NH + ht) * 64 + lane];
+            g_h[ht] = acc;
+        }
+        __syncthreads();
+    }
     // hidden layers 3 and 2 (W2 over h[1], W1 over h[0])
 #pragma unroll
     for (int l = 2; l >= 1; --l) {
+        const bool mine = TEAM == 1 || wv == (l == 2 ? 0 : 1);  // this layer's weight gradients are this wave's to write
         const float *Bl = l == 2 ? B3 : B2;
         const int pW = l == 2 ? pW2 : pW1, pb = l == 2 ? pb2 : pb1;
         f32x4 g_pre[NH], g_prev[NH];
@@ -311,21 +335,25 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
 #pragma unroll
         for (int ht = 0; ht < NH; ++ht) {
             g_pre[ht] = lrelu_grad4(g_h[ht], h[l][ht]);
-            tile_transpose(lds17, lane, g_pre[ht], gT[ht]);
-            const f32x4 db = rows_sum(g_pre[ht]);
-            if (w == 0) {
-                gp[pb + 16 * ht + 4 * g + 0] = db.x; gp[pb + 16 * ht + 4 * g + 1] = db.y;
-                gp[pb + 16 * ht + 4 * g + 2] = db.z; gp[pb + 16 * ht + 4 * g + 3] = db.w;
+            if (mine) {
+                tile_transpose(lds17, lane, g_pre[ht], gT[ht]);
+                const f32x4 db = rows_sum(g_pre[ht]);
+                if (w == 0) {
+                    gp[pb + 16 * ht + 4 * g + 0] = db.x; gp[pb + 16 * ht + 4 * g + 1] = db.y;
+                    gp[pb + 16 * ht + 4 * g + 2] = db.z; gp[pb + 16 * ht + 4 * g + 3] = db.w;
+                }
             }
         }
+        if (mine) {
 #pragma unroll
-        for (int hto = 0; hto < NH; ++hto)
+            for (int hto = 0; hto < NH; ++hto)
 #pragma unroll
-            for (int hti = 0; hti < NH; ++hti) {
-                const f32x4 dW = contract16(gT[hto], hT[l - 1][hti]);  // [out 16hto+4g+r][in 16hti+w]
-                gp[pW + (16 * hto + 4 * g + 0) * H + 16 * hti + w] = dW.x; gp[pW + (16 * hto + 4 * g + 1) * H + 16 * hti + w] = dW.y;
-                gp[pW + (16 * hto + 4 * g + 2) * H + 16 * hti + w] = dW.z; gp[pW + (16 * hto + 4 * g + 3) * H + 16 * hti + w] = dW.w;
-            }
+                for (int hti = 0; hti < NH; ++hti) {
+                    const f32x4 dW = contract16(gT[hto], hT[l - 1][hti]);  // [out 16hto+4g+r][in 16hti+w]
+                    gp[pW + (16 * hto + 4 * g + 0) * H + 16 * hti + w] = dW.x; gp[pW + (16 * hto + 4 * g + 1) * H + 16 * hti + w] = dW.y;
+                    gp[pW + (16 * hto + 4 * g + 2) * H + 16 * hti + w] = dW.z; gp[pW + (16 * hto + 4 * g + 3) * H + 16 * hti + w] = dW.w;
+                }
+        }
 #pragma unroll
         for (int hti = 0; hti < NH; ++hti) {
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -344,31 +372,36 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
     }
     // first layer: W0 over the conditioning half
     {
+        const bool mine = TEAM == 1 || wv == 2;
         f32x4 g_pre[NH];
         float gT[NH][4];
 #pragma unroll
         for (int ht = 0; ht < NH; ++ht) {
             g_pre[ht] = lrelu_grad4(g_h[ht], h[0][ht]);
-            tile_transpose(lds17, lane, g_pre[ht], gT[ht]);
-            const f32x4 db = rows_sum(g_pre[ht]);
-            if (w == 0) {
-                gp[pb0 + 16 * ht + 4 * g + 0] = db.x; gp[pb0 + 16 * ht + 4 * g + 1] = db.y;
-                gp[pb0 + 16 * ht + 4 * g + 2] = db.z; gp[pb0 + 16 * ht + 4 * g + 3] = db.w;
+            if (mine) {
+                tile_transpose(lds17, lane, g_pre[ht], gT[ht]);
+                const f32x4 db = rows_sum(g_pre[ht]);
+                if (w == 0) {
+                    gp[pb0 + 16 * ht + 4 * g + 0] = db.x; gp[pb0 + 16 * ht + 4 * g + 1] = db.y;
+                    gp[pb0 + 16 * ht + 4 * g + 2] = db.z; gp[pb0 + 16 * ht + 4 * g + 3] = db.w;
+                }
             }
         }
 #pragma unroll
         for (int t = 0; t < NTh; ++t) {
-            f32x4 cin = cond[t];
-            if (!row_ok) cin = (f32x4){0.f, 0.f, 0.f, 0.f};
-            float cT[4];
-            tile_transpose(lds17, lane, cin, cT);
-            const int j = 16 * t + 4 * (w & 3) + (w >> 2);  // input dim of tile row w
+            if (mine) {
+                f32x4 cin = cond[t];
+                if (!row_ok) cin = (f32x4){0.f, 0.f, 0.f, 0.f};
+                float cT[4];
+                tile_transpose(lds17, lane, cin, cT);
+                const int j = 16 * t + 4 * (w & 3) + (w >> 2);  // input dim of tile row w
 #pragma unroll
-            for (int ht = 0; ht < NH; ++ht) {
-                const f32x4 dW = contract16(gT[ht], cT);  // [hidden 16ht+4g+r][tile row w]
-                if (j < nin) {
-                    gp[pW0 + (16 * ht + 4 * g + 0) * nin + j] = dW.x; gp[pW0 + (16 * ht + 4 * g + 1) * nin + j] = dW.y;
-                    gp[pW0 + (16 * ht + 4 * g + 2) * nin + j] = dW.z; gp[pW0 + (16 * ht + 4 * g + 3) * nin + j] = dW.w;
+                for (int ht = 0; ht < NH; ++ht) {
+                    const f32x4 dW = contract16(gT[ht], cT);  // [hidden 16ht+4g+r][tile row w]
+                    if (j < nin) {
+                        gp[pW0 + (16 * ht + 4 * g + 0) * nin + j] = dW.x; gp[pW0 + (16 * ht + 4 * g + 1) * nin + j] = dW.y;
+                        gp[pW0 + (16 * ht + 4 * g + 2) * nin + j] = dW.z; gp[pW0 + (16 * ht + 4 * g + 3) * nin + j] = dW.w;
+                    }
                 }
             }
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -385,19 +418,27 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
     }
 }
 
+// One workgroup of SPL_TEAM waves per 16-row tile.  Every wave carries the tile's rows; the spline work (the bulk of the
+// instruction stream) and the weight-gradient contractions are divided among them (spl_coupling / spl_coupling_bwd).
+enum { SPL_TEAM = 4 };
+
 template <int NTh, int NH>
-__global__ void __launch_bounds__(64) spl_grad_kernel(SplGradArgs a) {
+__global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TEAM = SPL_TEAM;
     const SplTrainShape &ts = a.ts;
     const SplineShape &s = ts.s;
-    const int lane = threadIdx.x, w = lane & 15, g = lane >> 4, tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, w = lane & 15, g = lane >> 4, tile = blockIdx.x;
     const int D = s.D, B = s.B;
-    float *buf = lds;                    // 16 x (D+1): layout exchange
-    float *lds17 = lds + 16 * (D + 1);   // 16 x 17: tile transposes
+    const int per_wave = ((16 * (D + 1) + 16 * 17) + 3) & ~3;
+    float *buf = lds + (size_t)wv * per_wave;   // 16 x (D+1): layout exchange (per wave)
+    float *lds17 = buf + 16 * (D + 1);           // 16 x 17: tile transposes (per wave)
+    f32x4 *xch = reinterpret_cast<f32x4 *>(lds + (size_t)TEAM * per_wave);  // [TEAM][NTh + NH][64]
+    float *ldred = reinterpret_cast<float *>(xch + TEAM * (NTh + NH) * 64);  // [TEAM][16]
     const int row = tile * a.rows_per_tile + w;
     const bool ok = w < a.rows_per_tile && row < a.M;
     float *gp = a.partial + (size_t)tile * ts.gw_floats;
-    f32x4 *stash = reinterpret_cast<f32x4 *>(a.stash) + (size_t)tile * B * 2 * NTh * 64;
+    f32x4 *stash = reinterpret_cast<f32x4 *>(a.stash) + ((size_t)tile * TEAM + wv) * B * 2 * NTh * 64;
 
     // data = X[perm] + jitter * randn  (trainer.py:392)
     f32x4 xp[2][NTh], xs[2][NTh];
@@ -449,15 +490,23 @@ __global__ void __launch_bounds__(64) spl_grad_kernel(SplGradArgs a) {
             for (int t = 0; t < NTh; ++t) av[hf][t] = xs[hf][t] * es[hf][t] + tv[hf][t];
         spl_matmul<NTh>(blk, lane, av, c);
         const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
-        ld += spl_coupling<NTh, NH, false>(f1, s.SU, s.nu, s.tail, lane, c[0], c[1]);
-        ld += spl_coupling<NTh, NH, false>(f2, s.SL, s.nl, s.tail, lane, c[1], c[0]);
-        if (lane < 16) ld += blk[ts.tblk_floats - 4];
+        ld += spl_coupling<NTh, NH, false, TEAM>(f1, s.SU, s.nu, s.tail, lane, c[0], c[1], wv, xch);
+        ld += spl_coupling<NTh, NH, false, TEAM>(f2, s.SL, s.nl, s.tail, lane, c[1], c[0], wv, xch);
+        if (lane < 16 && wv == 0) ld += blk[ts.tblk_floats - 4];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int t = 0; t < NTh; ++t) xs[hf][t] = c[hf][t];
     }
     ld = group_sum(ld);
+    if (TEAM > 1) {  // the waves hold the log-det of their own super-tiles: add them up
+        if (lane < 16) ldred[wv * 16 + lane] = ld;
+        __syncthreads();
+        ld = 0.f;
+#pragma unroll
+        for (int k = 0; k < TEAM; ++k) ld += ldred[k * 16 + w];
+        __syncthreads();
+    }
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -470,7 +519,7 @@ __global__ void __launch_bounds__(64) spl_grad_kernel(SplGradArgs a) {
     float lp = (ok && g == 0) ? (-0.5f * ss - 0.91893853320467274f * (float)D + ld) : 0.f;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) lp += __shfl_xor(lp, o);
-    if (lane == 0) gp[ts.gw_floats - 4] = lp;  // sum of log_probs over this tile's rows
+    if (lane == 0 && wv == 0) gp[ts.gw_floats - 4] = lp;  // sum of log_probs over this tile's rows
     if (a.mode == SPL_MODE_LOSS) return;
 
     // ---- backward: loss = -mean(log_probs)  (trainer.py:394) ---------------------------------------------------------
@@ -500,11 +549,11 @@ __global__ void __launch_bounds__(64) spl_grad_kernel(SplGradArgs a) {
         f32x4 up2[NTh];
 #pragma unroll
         for (int t = 0; t < NTh; ++t) up2[t] = c[1][t];
-        spl_coupling<NTh, NH, false>(f1, s.SU, s.nu, s.tail, lane, c[0], up2);
+        spl_coupling<NTh, NH, false, TEAM>(f1, s.SU, s.nu, s.tail, lane, c[0], up2, wv, xch);
         // second coupling: lower' = RQS(lower; f2(upper'))   (networks.py:589-598)
-        spl_coupling_bwd<NTh, NH>(ts, f2, f2b, pblk + ts.p_f[1], s.nu, s.nl, s.SL, lane, ok, gld, lds17, gp, up2, c[0], gs[0], gs[1]);
+        spl_coupling_bwd<NTh, NH, TEAM>(ts, f2, f2b, pblk + ts.p_f[1], s.nu, s.nl, s.SL, lane, ok, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch);
         // first coupling: upper' = RQS(upper; f1(lower))      (networks.py:582-588)
-        spl_coupling_bwd<NTh, NH>(ts, f1, f1b, pblk + ts.p_f[0], s.nl, s.nu, s.SU, lane, ok, gld, lds17, gp, c[0], c[1], gs[1], gs[0]);
+        spl_coupling_bwd<NTh, NH, TEAM>(ts, f1, f1b, pblk + ts.p_f[0], s.nl, s.nu, s.SU, lane, ok, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch);
         // 1x1 conv c = a W: dLoss/dW[i][o] = sum_rows a[i] g_c[o];  g_a = g_c W^T
         {
             constexpr int T2 = 2 * NTh;
@@ -521,6 +570,7 @@ __global__ void __launch_bounds__(64) spl_grad_kernel(SplGradArgs a) {
             for (int ti = 0; ti < T2; ++ti)
 #pragma unroll
                 for (int to = 0; to < T2; ++to) {
+                    if (TEAM > 1 && (to & (TEAM - 1)) != wv) continue;  // output tiles dealt out over the team
                     const f32x4 dW = contract16(aT[ti], gT[to]);  // [a row 4g+r of tile ti][g_c row w of tile to]
                     const int dout = trow_dim(s, to / NTh, to % NTh, w);
                     const float dv[4] = {dW.x, dW.y, dW.z, dW.w};
@@ -541,7 +591,7 @@ __global__ void __launch_bounds__(64) spl_grad_kernel(SplGradArgs a) {
                 const f32x4 gx = ga[hf][t] * es[hf][t];
                 const f32x4 dsum = rows_sum(gx * xin[hf][t]);
                 const f32x4 tsum = rows_sum(ga[hf][t]);
-                if (w == 0) {
+                if (w == 0 && wv == 0) {
                     const float dsv[4] = {dsum.x, dsum.y, dsum.z, dsum.w}, dtv[4] = {tsum.x, tsum.y, tsum.z, tsum.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -748,8 +798,9 @@ static int grad_tiles(const SplGradArgs &a) { return (a.M + a.rows_per_tile - 1)
 
 static hipError_t launch_grad(const SplGradArgs &a, hipStream_t st) {
     const int tiles = grad_tiles(a);
-    const size_t ldsb = (size_t)(16 * (a.ts.s.D + 1) + 16 * 17) * sizeof(float);
-    DISPATCH_SPLT(spl_grad_kernel, a.ts.s, tiles, 64, ldsb, st, a);
+    const int per_wave = ((16 * (a.ts.s.D + 1) + 16 * 17) + 3) & ~3;
+    const size_t ldsb = (size_t)(SPL_TEAM * per_wave + SPL_TEAM * (a.ts.s.NTh + a.ts.s.NH) * 64 * 4 + SPL_TEAM * 16) * sizeof(float);
+    DISPATCH_SPLT(spl_grad_kernel, a.ts.s, tiles, 64 * SPL_TEAM, ldsb, st, a);
     return hipGetLastError();
 }
 
@@ -787,7 +838,7 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
     if (tiles > h->partial_tiles) {
         if (h->partial) { (void)hipFree(h->partial); (void)hipFree(h->stash); }
         SHIP_TRY(hipMalloc((void **)&h->partial, (size_t)tiles * ts.gw_floats * sizeof(float)));
-        SHIP_TRY(hipMalloc((void **)&h->stash, (size_t)tiles * B * 2 * h->s.NTh * 64 * 4 * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->stash, (size_t)tiles * SPL_TEAM * B * 2 * h->s.NTh * 64 * 4 * sizeof(float)));
         h->partial_tiles = tiles;
     }
     if (!h->w_dev_current) {
