@@ -77,6 +77,7 @@ def main():
     ap.add_argument('--mcmc-steps', type=int, default=0, help='MH steps per launch (0 = 5*x_dim)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-saturation', action='store_true')
+    ap.add_argument('--no-spline', action='store_true')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -192,6 +193,27 @@ def main():
             out['saturated'] = {'walkers': Cs, 'mcmc_steps': Ss, 'kernel_ms': ms, 'evals_per_s': Cs * Ss / (ms * 1e-3),
                                 'tflops': Cs * Ss * fl / (ms * 1e-3) / 1e12,
                                 'frac_of_fp32_peak': Cs * Ss * fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+        if not args.no_spline and world == 1:
+            # the same workload on the reference's default flow (neural spline flow): reported beside,
+            # never as `value` (BASELINE's metric is quoted on the RealNVP path)
+            from nnest_amd.spline import HipSpline
+            sp = HipSpline(D, H, B, seed=0)
+            sp.actnorm_init(u0[:min(C, 100)])
+            zsp, _ = sp.forward(u0)
+            t_ms = []
+            for k in range(3):
+                zz, ll = zsp.clone(), logl0.clone()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                sp.mh_steps(0, 5.0, zz, ll, loglstar, step_size, S, seed=7 + k, walker_offset=rank * C)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                t_ms.append(e0.elapsed_time(e1))
+            ms = float(np.median(t_ms[1:]))
+            out['spline_flow'] = {'kernel': 'spline_mh_kernel_team' if (C + 15) // 16 <= 2 * info['num_cu'] else 'spline_mh_kernel',
+                                  'kernel_ms': ms, 'evals_per_s': C * S / (ms * 1e-3),
+                                  'note': 'SingleSpeedSpline hidden=%d blocks=%d bins=8; VALU-bound on the spline arithmetic' % (H, B)}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(D, H, B, L, nvp.store_packed(), C)
         print(json.dumps(out))

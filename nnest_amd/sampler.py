@@ -360,6 +360,34 @@ class Sampler(object):
 
     # ---- prior rejection (sampler.py:529-543) ---------------------------------------------------------------
     def _rejection_prior_sample(self, loglstar, num_trials=None):
+        if num_trials is None and self._fused_like_id is not None:
+            # The reference draws one prior sample per likelihood call until one passes (sampler.py:531-538).  The
+            # draws are independent, so the same rule is applied to a block per launch of the likelihood kernel: the
+            # first candidate above loglstar is returned and ncall counts the candidates up to and including it.
+            from . import flow
+            ncall, block = 0, getattr(self, '_prior_block', 64)
+            while True:
+                x = self.sample_prior(block)
+                logl = flow.loglike(self._fused_like_id, x, self._linear_scale, device=self.trainer.netG.device,
+                                    like_params=self._fused_like_params).cpu().numpy()
+                hit = np.where(logl > loglstar)[0]
+                found = None
+                for j in hit:   # the kernel works on float32(x); the stored value is the reference's float64 one
+                    calls = self.total_calls
+                    l64, d64 = self.loglike(x[j:j + 1])
+                    self.total_calls = calls
+                    if l64[0] > loglstar:
+                        found = (int(j), l64, d64)
+                        break
+                if found is not None:
+                    j, l64, d64 = found
+                    self.total_calls += j + 1
+                    # next block ~ 2 / (acceptance rate seen), bounded
+                    self._prior_block = int(min(65536, max(64, 2 * block / max(1, len(hit)))))
+                    return x[j:j + 1], l64, d64, ncall + j + 1
+                self.total_calls += block
+                ncall += block
+                block = min(65536, 4 * block)
         if num_trials is None:
             ncall = 0
             while True:

@@ -85,7 +85,17 @@ class Trainer(object):
             self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed, scale=scale)
         if load_model:
             self.path = os.path.join(log_dir, load_model)
-            self.netG.load_state_dict(torch.load(os.path.join(self.path, 'models', 'netG.pt')))
+            sd = torch.load(os.path.join(self.path, 'models', 'netG.pt'))
+            if self.flow == 'spline':
+                # the 1x1 convs' permutations are not in the reference's state_dict (networks.py:634-635); this build
+                # writes them beside it (netG_P.npy).  A loaded model counts as initialised (stated deviation: the
+                # reference would re-run ActNorm's data-dependent init on the first forward batch and discard the
+                # loaded s, t).
+                pfile = os.path.join(self.path, 'models', 'netG_P.npy')
+                self.netG.load_state_dict(sd, np.load(pfile) if os.path.exists(pfile) else None)
+                self.netG.data_dep_init_done = True
+            else:
+                self.netG.load_state_dict(sd)
         elif log_dir is not None:
             self.path = log_dir
             for sub in ('models', 'data', 'chains', 'plots'):
@@ -168,6 +178,8 @@ class Trainer(object):
         self.best_validation_loss = res['best_validation_loss'] if res else float('inf')
         if self.path:
             torch.save(self.netG.state_dict(), os.path.join(self.path, 'models', 'netG.pt'))
+            if self.flow == 'spline':
+                np.save(os.path.join(self.path, 'models', 'netG_P.npy'), self.netG.P)
         self.logger.info('Best epoch [%i] validation loss [%5.4f] train time (s) [%5.4f]]'
                          % (self.best_validation_epoch, self.best_validation_loss, time.time() - start_time))
 

@@ -3,7 +3,7 @@
 set -u
 W=${1:-32768}; S=${2:-50}
 OUT=$PWD/gpurun_out/pmc_sat; mkdir -p "$OUT"; export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-saturation --walkers $W --mcmc-steps $S"
+BENCH="python3 $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-saturation --no-spline --walkers $W --mcmc-steps $S"
 cd /tmp
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d "$OUT/a" -- $BENCH > "$OUT/bench.json" 2> "$OUT/a.log"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/b" -- $BENCH > /dev/null 2> "$OUT/b.log"

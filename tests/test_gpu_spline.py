@@ -272,3 +272,19 @@ def test_training_improves_and_is_reproducible(hip):
     l = outs[0][1]
     assert l[-1, 1] < l[0, 1] and l[-1, 0] < l[0, 0]
     assert np.all(np.isfinite(l))
+
+
+def test_trainer_spline_save_and_load_model(hip, tmp_path):
+    """Trainer(flow='spline') writes models/netG.pt (reference keys) plus the permutations; load_model restores the flow"""
+    from nnest_amd.trainer import Trainer
+    rng = np.random.RandomState(0)
+    live = rng.normal(size=(300, 4)) * 0.3
+    t = Trainer(4, log_dir=str(tmp_path / 'run'), log_level=30)
+    assert type(t.netG).__name__ == 'HipSpline'
+    t.train(live, max_iters=5, jitter=0.01)
+    x = rng.uniform(-1, 1, size=(20, 4)).astype(np.float32)
+    lp = cpu(t.log_probs(x))
+    z = cpu(t.get_latent_samples(x))
+    t2 = Trainer(4, log_dir=str(tmp_path), load_model='run', log_level=30)
+    assert np.array_equal(cpu(t2.log_probs(x)), lp) and np.array_equal(cpu(t2.get_latent_samples(x)), z)
+    assert t.best_validation_epoch >= 1 and t.losses.shape == (5, 2)
