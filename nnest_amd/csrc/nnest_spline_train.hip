@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     const int row = tile * a.rows_per_tile + w;
     const bool ok = w < a.rows_per_tile && row < a.M;
     float *gp = a.partial + (size_t)tile * ts.gw_floats;
-    f32x4 *stash = reinterpret_cast<f32x4 *>(a.stash) + ((size_t)tile * TEAM + wv) * B * 2 * NTh * 64;
+    f32x4 *stash = reinterpret_cast<f32x4 *>(a.stash) + ((size_t)tile * TEAM + wv) * B * 3 * NTh * 64;  // per block: input halves + upper'
 
     // data = X[perm] + jitter * randn  (trainer.py:392)
     f32x4 xp[2][NTh], xs[2][NTh];
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int t = 0; t < NTh; ++t) stash[((size_t)b * 2 * NTh + c * NTh + t) * 64 + lane] = xs[c][t];
+                for (int t = 0; t < NTh; ++t) stash[((size_t)b * 3 * NTh + c * NTh + t) * 64 + lane] = xs[c][t];
         }
         f32x4 es[2][NTh], tv[2][NTh], av[2][NTh], c[2][NTh];
         spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);
@@ -491,6 +491,10 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         spl_matmul<NTh>(blk, lane, av, c);
         const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
         ld += spl_coupling<NTh, NH, false, TEAM>(f1, s.SU, s.nu, s.tail, lane, c[0], c[1], wv, xch);
+        if (a.mode == SPL_MODE_GRAD) {  // upper' conditions the second coupling: kept for the backward pass
+#pragma unroll
+            for (int t = 0; t < NTh; ++t) stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
+        }
         ld += spl_coupling<NTh, NH, false, TEAM>(f2, s.SL, s.nl, s.tail, lane, c[1], c[0], wv, xch);
         if (lane < 16 && wv == 0) ld += blk[ts.tblk_floats - 4];
 #pragma unroll
@@ -538,7 +542,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-            for (int t = 0; t < NTh; ++t) xin[cc][t] = stash[((size_t)b * 2 * NTh + cc * NTh + t) * 64 + lane];
+            for (int t = 0; t < NTh; ++t) xin[cc][t] = stash[((size_t)b * 3 * NTh + cc * NTh + t) * 64 + lane];
         spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -548,8 +552,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         // upper' = RQS(upper; f1(lower)) is the conditioning input of the second coupling
         f32x4 up2[NTh];
 #pragma unroll
-        for (int t = 0; t < NTh; ++t) up2[t] = c[1][t];
-        spl_coupling<NTh, NH, false, TEAM>(f1, s.SU, s.nu, s.tail, lane, c[0], up2, wv, xch);
+        for (int t = 0; t < NTh; ++t) up2[t] = stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane];
         // second coupling: lower' = RQS(lower; f2(upper'))   (networks.py:589-598)
         spl_coupling_bwd<NTh, NH, TEAM>(ts, f2, f2b, pblk + ts.p_f[1], s.nu, s.nl, s.SL, lane, ok, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch);
         // first coupling: upper' = RQS(upper; f1(lower))      (networks.py:582-588)
@@ -838,7 +841,7 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
     if (tiles > h->partial_tiles) {
         if (h->partial) { (void)hipFree(h->partial); (void)hipFree(h->stash); }
         SHIP_TRY(hipMalloc((void **)&h->partial, (size_t)tiles * ts.gw_floats * sizeof(float)));
-        SHIP_TRY(hipMalloc((void **)&h->stash, (size_t)tiles * SPL_TEAM * B * 2 * h->s.NTh * 64 * 4 * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->stash, (size_t)tiles * SPL_TEAM * B * 3 * h->s.NTh * 64 * 4 * sizeof(float)));
         h->partial_tiles = tiles;
     }
     if (!h->w_dev_current) {
