@@ -312,29 +312,32 @@ __device__ __forceinline__ void mlp_bwd(const float *__restrict__ bn, int lane, 
 }
 
 // ---- phase B: one dW tile = sum over rows of G[row][16] (x) Act[row][16] ----------------------------------
-__device__ __forceinline__ f32x4 contract_rows(const float *stg, int rows_pad, int ct_g, int ct_a, int lane) {
+// WITH_BIAS: the bias gradient (column sums of G = the same product with Act = 1) rides on the G operands this job loads
+// anyway, instead of being a job of its own: 5 jobs for 8 waves at the default shape rather than 9 (one wave used to run
+// two jobs back to back while seven waited at the barrier).
+template <bool WITH_BIAS>
+__device__ __forceinline__ f32x4 contract_rows(const float *stg, int rows_pad, int ct_g, int ct_a, int lane, f32x4 &bias) {
     // rows_pad is a multiple of 16: four independent accumulators, one per 4-row k-step of a 16-row tile, so the
     // MFMAs issue back to back (a single chain waits 40 cycles per dependent v_mfma_f32_16x16x4_f32) and the LDS
     // reads of a tile are all in flight together
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
+    f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4, b0 = zero4, b1 = zero4, b2 = zero4, b3 = zero4;
     const float *G = stg + (size_t)ct_g * rows_pad * 16 + (lane >> 4) * 16 + (lane & 15);
-    if (ct_a >= 0) {
-        const float *A = stg + (size_t)ct_a * rows_pad * 16 + (lane >> 4) * 16 + (lane & 15);
-        for (int r = 0; r < rows_pad; r += 16) {
-            a0 = mfma4(G[(r + 0) * 16], A[(r + 0) * 16], a0);
-            a1 = mfma4(G[(r + 4) * 16], A[(r + 4) * 16], a1);
-            a2 = mfma4(G[(r + 8) * 16], A[(r + 8) * 16], a2);
-            a3 = mfma4(G[(r + 12) * 16], A[(r + 12) * 16], a3);
-        }
-    } else {
-        for (int r = 0; r < rows_pad; r += 16) {  // bias: Act = 1
-            a0 = mfma4(G[(r + 0) * 16], 1.0f, a0);
-            a1 = mfma4(G[(r + 4) * 16], 1.0f, a1);
-            a2 = mfma4(G[(r + 8) * 16], 1.0f, a2);
-            a3 = mfma4(G[(r + 12) * 16], 1.0f, a3);
+    const float *A = stg + (size_t)ct_a * rows_pad * 16 + (lane >> 4) * 16 + (lane & 15);
+    for (int r = 0; r < rows_pad; r += 16) {
+        const float g0 = G[(r + 0) * 16], g1 = G[(r + 4) * 16], g2 = G[(r + 8) * 16], g3 = G[(r + 12) * 16];
+        a0 = mfma4(g0, A[(r + 0) * 16], a0);
+        a1 = mfma4(g1, A[(r + 4) * 16], a1);
+        a2 = mfma4(g2, A[(r + 8) * 16], a2);
+        a3 = mfma4(g3, A[(r + 12) * 16], a3);
+        if (WITH_BIAS) {
+            b0 = mfma4(g0, 1.0f, b0);
+            b1 = mfma4(g1, 1.0f, b1);
+            b2 = mfma4(g2, 1.0f, b2);
+            b3 = mfma4(g3, 1.0f, b3);
         }
     }
+    if (WITH_BIAS) bias = (b0 + b1) + (b2 + b3);
     return (a0 + a1) + (a2 + a3);  // lane (gq, j) reg r  <->  (out feature 4*gq + r, in feature j)
 }
 
@@ -415,75 +418,50 @@ __device__ __forceinline__ void weight_grad_jobs(const TrainArgs &a, const float
     (void)ad; (void)imgf; (void)imgb;
     auto emit = [&](int idx, float g) { a.grad[pbase + idx] = g; };
     const int gq = lane >> 4, j = lane & 15;
-    constexpr int J_W3 = NT * NH, J_B3 = NT, J_W2 = L * NH * NH, J_B2 = L * NH, J_W1 = NH * NT, J_B1 = NH;
-    constexpr int NJOBS = J_W3 + J_B3 + J_W2 + J_B2 + J_W1 + J_B1;
+    constexpr int J_W3 = NT * NH, J_W2 = L * NH * NH, J_W1 = NH * NT;
+    constexpr int NJOBS = J_W3 + J_W2 + J_W1;
+    f32x4 bt = {0.f, 0.f, 0.f, 0.f};
     for (int job = wave; job < NJOBS; job += TRAIN_WAVES) {
         int q = job;
-        if (q < J_W3) {  // dWout[slot][hidden]
+        if (q < J_W3) {  // dWout[slot][hidden]  (+ dbout with the first hidden tile)
             int tau = q / NH, ht = q % NH;
-            f32x4 t = contract_rows(stg, rows_pad, SM::gout(tau), SM::act(L, ht), lane);
-            float v[4] = {t.x, t.y, t.z, t.w};
+            f32x4 t = ht == 0 ? contract_rows<true>(stg, rows_pad, SM::gout(tau), SM::act(L, ht), lane, bt)
+                              : contract_rows<false>(stg, rows_pad, SM::gout(tau), SM::act(L, ht), lane, bt);
+            float v[4] = {t.x, t.y, t.z, t.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int d = 2 * (16 * tau + 4 * gq + r) + pt;
-                if (d < D) emit(pWo + d * H + 16 * ht + j, v[r]);
-            }
-            continue;
-        }
-        q -= J_W3;
-        if (q < J_B3) {
-            int tau = q;
-            f32x4 t = contract_rows(stg, rows_pad, SM::gout(tau), -1, lane);
-            float v[4] = {t.x, t.y, t.z, t.w};
-            if (j == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int d = 2 * (16 * tau + 4 * gq + r) + pt;
-                    if (d < D) emit(pbo + d, v[r]);
+                if (d < D) {
+                    emit(pWo + d * H + 16 * ht + j, v[r]);
+                    if (ht == 0 && j == 0) emit(pbo + d, bv[r]);
                 }
             }
             continue;
         }
-        q -= J_B3;
-        if (q < J_W2) {  // hidden layer l = 1..L : dW_l[out][in]
+        q -= J_W3;
+        if (q < J_W2) {  // hidden layer l = 1..L : dW_l[out][in]  (+ db_l with the first input tile)
             int l = q / (NH * NH) + 1, hto = (q / NH) % NH, hti = q % NH;
-            f32x4 t = contract_rows(stg, rows_pad, SM::gpre(l, hto), SM::act(l - 1, hti), lane);
-            float v[4] = {t.x, t.y, t.z, t.w};
+            f32x4 t = hti == 0 ? contract_rows<true>(stg, rows_pad, SM::gpre(l, hto), SM::act(l - 1, hti), lane, bt)
+                               : contract_rows<false>(stg, rows_pad, SM::gpre(l, hto), SM::act(l - 1, hti), lane, bt);
+            float v[4] = {t.x, t.y, t.z, t.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) emit(phid + (l - 1) * (H * H + H) + (16 * hto + 4 * gq + r) * H + 16 * hti + j, v[r]);
+            for (int r = 0; r < 4; ++r) {
+                emit(phid + (l - 1) * (H * H + H) + (16 * hto + 4 * gq + r) * H + 16 * hti + j, v[r]);
+                if (hti == 0 && j == 0) emit(phid + (l - 1) * (H * H + H) + H * H + 16 * hto + 4 * gq + r, bv[r]);
+            }
             continue;
         }
         q -= J_W2;
-        if (q < J_B2) {
-            int l = q / NH + 1, hto = q % NH;
-            f32x4 t = contract_rows(stg, rows_pad, SM::gpre(l, hto), -1, lane);
-            float v[4] = {t.x, t.y, t.z, t.w};
-            if (j == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) emit(phid + (l - 1) * (H * H + H) + H * H + 16 * hto + 4 * gq + r, v[r]);
-            }
-            continue;
-        }
-        q -= J_B2;
-        if (q < J_W1) {  // dW0[hidden][dim]
+        {  // dW0[hidden][dim]  (+ db0 with the first slot tile)
             int ht = q / NT, tau = q % NT;
-            f32x4 t = contract_rows(stg, rows_pad, SM::gpre(0, ht), SM::m(tau), lane);
-            float v[4] = {t.x, t.y, t.z, t.w};
+            f32x4 t = tau == 0 ? contract_rows<true>(stg, rows_pad, SM::gpre(0, ht), SM::m(tau), lane, bt)
+                               : contract_rows<false>(stg, rows_pad, SM::gpre(0, ht), SM::m(tau), lane, bt);
+            float v[4] = {t.x, t.y, t.z, t.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
             int d = 2 * (16 * tau + j) + pc;
-            if (d < D) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) emit((16 * ht + 4 * gq + r) * D + d, v[r]);
-            }
-            continue;
-        }
-        q -= J_W1;
-        {
-            int ht = q;
-            f32x4 t = contract_rows(stg, rows_pad, SM::gpre(0, ht), -1, lane);
-            float v[4] = {t.x, t.y, t.z, t.w};
-            if (j == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) emit(pb0 + 16 * ht + 4 * gq + r, v[r]);
+            for (int r = 0; r < 4; ++r) {
+                if (d < D) emit((16 * ht + 4 * gq + r) * D + d, v[r]);
+                if (tau == 0 && j == 0) emit(pb0 + 16 * ht + 4 * gq + r, bv[r]);
             }
         }
     }
