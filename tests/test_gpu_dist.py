@@ -1,0 +1,65 @@
+"""Two ranks on real kernels: the multi-process path of NestedSampler (replicated evidence state, MCMC batch sharded by
+rank with disjoint noise streams, endpoints all-gathered, rank-0 retrain + weight broadcast) with both ranks driving
+the one GPU of the test box over gloo.  (The 8-GPU RCCL run is the driver's; the collectives are the same calls.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp, flow, out):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from nnest_amd.nested import NestedSampler
+        from nnest_amd.likelihoods import Rosenbrock
+        np.random.seed(100 + rank)      # different per rank on purpose: rank 0's draws must win
+        torch.manual_seed(100 + rank)
+        s = NestedSampler(2, Rosenbrock(2), transform=lambda x: 5 * x, log_dir=tmp, num_live_points=300, log_level=40, flow=flow)
+        assert s.use_mpi and s.mpi_size == world and s._fused_like_id is not None
+        s.run(train_iters=200, mcmc_num_chains=33)   # 33 chains over 2 ranks: padded shard
+        netG = s.trainer.netG
+        out.put((rank, float(s.logz), int(s.niter), int(s.ncall), float(np.sum(s.samples)), float(np.sum(netG.store_packed())),
+                 float(np.sum(netG.P)) if hasattr(netG, 'P') else 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('flow', ['nvp', 'spline'])
+def test_two_ranks_one_gpu(tmp_path, flow):
+    world = 2
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), flow, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = res
+    assert a[1:] == b[1:]                       # identical evidence, iteration count, calls, samples, weights (and P)
+    assert abs(a[1] + 5.80) <= 0.45, a[1]       # 300 live points: sqrt(h/N) ~ 0.13
