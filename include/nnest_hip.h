@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 4
+#define NNEST_HIP_ABI_VERSION 5
 
 enum {
     NNEST_OK = 0,
@@ -82,6 +82,11 @@ enum { NNEST_SCALE_AFFINE = 0, NNEST_SCALE_TRANSLATE = 1, NNEST_SCALE_CONSTANT =
 int nnest_nvp_create_scaled(int D, int H, int B, int L, int scale_mode, nnest_nvp_t **out);
 int nnest_nvp_destroy(nnest_nvp_t *nvp);
 int nnest_nvp_num_params(const nnest_nvp_t *nvp);
+/* Base distribution of the flow (NormalizingFlowModel(prior=...), networks.py:47-59; Trainer(base_dist=...), trainer.py:41):
+ * beta = 0 (default) is MultivariateNormal(0, I); beta > 0 is the reference's GeneralisedNormal(loc 0, scale 1, beta)
+ * (nnest/distributions/generalised_normal.py:66-71; examples/nested/run.py --base_dist gen_normal --beta 8).  It enters
+ * log_probs and therefore the training loss; forward / inverse and the proposal kernel do not depend on it. */
+int nnest_nvp_set_base(nnest_nvp_t *nvp, float beta);
 /* netG.load_state_dict / state_dict (trainer.py:102-106, :241): host<->device copy of the packed
  * weights.  These two synchronise `stream` before returning. */
 int nnest_nvp_load_weights(nnest_nvp_t *nvp, const float *packed_host, void *stream);
@@ -199,6 +204,7 @@ typedef struct nnest_spline nnest_spline_t;
 int nnest_spline_create(int D, int H, int B, int K, float tail_bound, nnest_spline_t **out);
 int nnest_spline_destroy(nnest_spline_t *spl);
 int nnest_spline_num_params(const nnest_spline_t *spl);
+int nnest_spline_set_base(nnest_spline_t *spl, float beta);   /* as nnest_nvp_set_base */
 int nnest_spline_load_weights(nnest_spline_t *spl, const float *packed_host, const float *perm_host, void *stream);
 int nnest_spline_store_weights(nnest_spline_t *spl, float *packed_host, float *perm_host, void *stream);
 /* NormalizingFlow.forward / .inverse (networks.py:24-42), NormalizingFlowModel.log_probs (networks.py:71-76) */

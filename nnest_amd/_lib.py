@@ -65,6 +65,8 @@ SIGNATURES = {
     'nnest_nvp_create_scaled': [_i, _i, _i, _i, _i, ctypes.POINTER(_vp)],
     'nnest_nvp_destroy': [_vp],
     'nnest_nvp_num_params': [_vp],
+    'nnest_nvp_set_base': [_vp, _f],
+    'nnest_spline_set_base': [_vp, _f],
     'nnest_nvp_load_weights': [_vp, _vp, _vp],
     'nnest_nvp_store_weights': [_vp, _vp, _vp],
     'nnest_nvp_device_ptrs': [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)],

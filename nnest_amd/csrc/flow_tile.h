@@ -39,6 +39,10 @@ struct FlowShape {
     // slots of the packed vector stay zero (log_s = 0 exactly) and receive no gradient; in mode 2 the B scalars
     // follow the B blocks in the packed vector and the image_floats of the fragment image.
     int scale_mode;
+    // base distribution of the flow (NormalizingFlowModel.prior): base_beta = 0 is N(0, I) (networks.py:51-57); > 0 the
+    // reference's GeneralisedNormal(0, 1, beta) (nnest/distributions/generalised_normal.py:66-71).  base_const = the
+    // per-dimension constant of its log density.
+    float base_beta, base_const;
     __host__ __device__ int nets_params() const { return B * 2 * net_params; }
     __host__ __device__ int num_params() const { return B * 2 * net_params + (scale_mode == 2 ? B : 0); }
     __host__ __device__ int image_total() const { return image_floats + (scale_mode == 2 ? B : 0); }
@@ -70,6 +74,17 @@ __device__ __forceinline__ f32x4 activate(f32x4 v) {
     }
     return o;
 }
+
+// ---- base density ------------------------------------------------------------------------------------
+// log p(u) = -sum_d E(u_d) + D * base_const with E(u) = u^2 / 2 (beta = 0) or |u|^beta; base_dE = dE/du
+__device__ __forceinline__ float base_pow(float a, float beta) { return __builtin_amdgcn_exp2f(beta * __builtin_amdgcn_logf(a)); }
+__device__ __forceinline__ float base_E(float u, float beta) { return beta == 0.f ? 0.5f * u * u : base_pow(fabsf(u), beta); }
+__device__ __forceinline__ float base_dE(float u, float beta) {
+    if (beta == 0.f) return u;
+    return u == 0.f ? 0.f : beta * base_pow(fabsf(u), beta) / u;  // beta |u|^(beta-1) sign(u)
+}
+__device__ __forceinline__ float base_E4(f32x4 v, float beta) { return (base_E(v.x, beta) + base_E(v.y, beta)) + (base_E(v.z, beta) + base_E(v.w, beta)); }
+__device__ __forceinline__ f32x4 base_dE4(f32x4 v, float beta) { return (f32x4){base_dE(v.x, beta), base_dE(v.y, beta), base_dE(v.z, beta), base_dE(v.w, beta)}; }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

@@ -1,5 +1,6 @@
 // nnest_abi.hip -- the extern "C" surface of libnnest_hip.so (include/nnest_hip.h): handle management,
 // argument checks, error reporting.  No torch types, no exceptions across the boundary.
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 #include <stdarg.h>
@@ -86,6 +87,8 @@ int nnest_nvp_create_scaled(int D, int H, int B, int L, int scale_mode, nnest_nv
     s.image_floats = B * 2 * s.net_floats;
     s.net_params = H * D + H + L * (H * H + H) + D * H + D;
     s.scale_mode = scale_mode;
+    s.base_beta = 0.f;
+    s.base_const = -0.91893853320467274f;  // -log(2 pi) / 2
     if (!shape_supported(s))
         return fail(NNEST_E_UNSUPPORTED, "x_dim=%d hidden_dim=%d not instantiated (x_dim<=128 at H=16, <=64 at H=32, <=32 at H=64)", D, H);
     nnest_nvp *h = new nnest_nvp();
@@ -132,6 +135,14 @@ int nnest_nvp_destroy(nnest_nvp_t *h) {
 }
 
 int nnest_nvp_num_params(const nnest_nvp_t *h) { return h ? h->num_params : -1; }
+
+int nnest_nvp_set_base(nnest_nvp_t *h, float beta) {
+    if (!h) return fail(NNEST_E_ARG, "NULL handle");
+    if (!(beta >= 0.f)) return fail(NNEST_E_ARG, "beta=%g: 0 selects N(0, I), beta > 0 GeneralisedNormal(0, 1, beta)", (double)beta);
+    h->s.base_beta = beta;
+    h->s.base_const = beta == 0.f ? -0.91893853320467274f : (float)(log((double)beta) - log(2.0) - lgamma(1.0 / (double)beta));
+    return NNEST_OK;
+}
 
 int nnest_nvp_load_weights(nnest_nvp_t *h, const float *packed_host, void *stream) {
     if (!h || !packed_host) return fail(NNEST_E_ARG, "NULL argument");

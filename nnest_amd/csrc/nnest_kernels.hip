@@ -120,16 +120,13 @@ __global__ void __launch_bounds__(256) flow_pass_kernel(PassArgs a) {
         ld = group_sum(ld);
         if (a.mode == PASS_LOGPROB) {
             // MVN(0,I).log_prob(u) + logdet  (networks.py:51-57, :71-76)
-            float ss = 0.f;
+            float ss = 0.f;  // padded slots hold 0 and E(0) = 0
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int tau = 0; tau < NT; ++tau) {
-                    f32x4 v = xs[c][tau];
-                    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-                }
+                for (int tau = 0; tau < NT; ++tau) ss += base_E4(xs[c][tau], a.s.base_beta);
             ss = group_sum(ss);
-            if (ok && g == 0) a.out[row] = -0.5f * ss - 0.91893853320467274f * (float)a.s.D + ld;
+            if (ok && g == 0) a.out[row] = -ss + a.s.base_const * (float)a.s.D + ld;
             continue;
         }
         if (a.out) store_tile<NT>(a.out, row, ok, a.s.D, lane, xs);

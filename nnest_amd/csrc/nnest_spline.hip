@@ -49,6 +49,8 @@ static SplineShape make_shape(int D, int H, int B, int K, float tail) {
     const int P = 3 * K - 1;
     s.blk_params = 2 * D + (2 * D * D + D) + spline_mlp_params(s.nl, P * s.nu, H) + spline_mlp_params(s.nu, P * s.nl, H);
     s.num_params = B * s.blk_params;
+    s.base_beta = 0.f;
+    s.base_const = -0.91893853320467274f;
     return s;
 }
 
@@ -238,6 +240,14 @@ int nnest_spline_destroy(nnest_spline_t *h) {
 }
 
 int nnest_spline_num_params(const nnest_spline_t *h) { return h ? h->s.num_params : -1; }
+
+int nnest_spline_set_base(nnest_spline_t *h, float beta) {
+    if (!h) return spline_fail(NNEST_E_ARG, "NULL handle");
+    if (!(beta >= 0.f)) return spline_fail(NNEST_E_ARG, "beta=%g: 0 selects N(0, I), beta > 0 GeneralisedNormal(0, 1, beta)", (double)beta);
+    h->s.base_beta = beta;
+    h->s.base_const = beta == 0.f ? -0.91893853320467274f : (float)(log((double)beta) - log(2.0) - lgamma(1.0 / (double)beta));
+    return NNEST_OK;
+}
 
 int nnest_spline_load_weights(nnest_spline_t *h, const float *packed_host, const float *perm_host, void *stream) {
     if (!h || !packed_host) return spline_fail(NNEST_E_ARG, "NULL argument");

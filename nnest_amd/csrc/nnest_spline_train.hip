@@ -515,12 +515,9 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int t = 0; t < NTh; ++t) {
-            f32x4 v = xs[c][t];
-            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        }
+        for (int t = 0; t < NTh; ++t) ss += base_E4(xs[c][t], s.base_beta);
     ss = group_sum(ss);
-    float lp = (ok && g == 0) ? (-0.5f * ss - 0.91893853320467274f * (float)D + ld) : 0.f;
+    float lp = (ok && g == 0) ? (-ss + s.base_const * (float)D + ld) : 0.f;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) lp += __shfl_xor(lp, o);
     if (lane == 0 && wv == 0) gp[ts.gw_floats - 4] = lp;  // sum of log_probs over this tile's rows
@@ -532,7 +529,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int t = 0; t < NTh; ++t) gs[c][t] = ok ? xs[c][t] * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTh; ++t) gs[c][t] = ok ? base_dE4(xs[c][t], s.base_beta) * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int b = B - 1; b >= 0; --b) {
         const float *blk = a.timg + (size_t)b * ts.tblk_floats;
         const float *pb = a.w + (size_t)b * s.blk_params;

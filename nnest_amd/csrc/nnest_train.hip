@@ -568,7 +568,6 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
     // ScaleLayer scalars (scale='constant'): read from the packed vector, which Adam updates in place
     const float *blk_scale = a.s.scale_mode == 2 ? a.w + a.s.nets_params() : nullptr;
     __shared__ float sred[8 * TRAIN_WAVES];  // per (block, wave) partials of dLoss/ds_b; B <= 8 checked by the launcher
-    const float half_log_2pi = 0.91893853320467274f;
 
     rebuild_images_to(a, imgf, imgb);
     if (a.mode == TRAIN_MODE_GRAD_ONLY)
@@ -645,12 +644,9 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        f32x4 v = xs[c][t];
-                        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-                    }
+                    for (int t = 0; t < NT; ++t) ss += base_E4(xs[c][t], a.s.base_beta);
                 ss = group_sum(ss);
-                lp = (row_ok && g == 0) ? (-0.5f * ss - half_log_2pi * (float)D + ld) : 0.f;
+                lp = (row_ok && g == 0) ? (-ss + a.s.base_const * (float)D + ld) : 0.f;
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) lp += __shfl_xor(lp, o);
             }
@@ -660,14 +656,14 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
             for (int k = 0; k < TRAIN_WAVES; ++k) loss += red[k];
             loss = -loss / (float)M;
             epoch_loss += loss;
-            // d(loss)/du = u/M ; d(loss)/d(logdet) = -1/M
+            // d(loss)/du = dE/du / M (= u/M for the N(0,I) base) ; d(loss)/d(logdet) = -1/M
             TSTAMP(p1);
             TACC(ph[0], p1, p0);
             const float invM = 1.0f / (float)M, gld = -invM;
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) gs[c][t] = row_ok ? xs[c][t] * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < NT; ++t) gs[c][t] = row_ok ? base_dE4(xs[c][t], a.s.base_beta) * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
             // Adam scalars of this step (torch/optim/adam.py _single_tensor_adam); the update itself is applied
             // per parameter by the thread that produces its gradient (weight_grad_jobs)
             AdamStep ad = {0.f, 1.f};
@@ -737,12 +733,9 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        f32x4 v = xv[c][t];
-                        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-                    }
+                    for (int t = 0; t < NT; ++t) ss += base_E4(xv[c][t], a.s.base_beta);
                 ss = group_sum(ss);
-                float lpv = (ok && g == 0) ? (-0.5f * ss - half_log_2pi * (float)D + ldv) : 0.f;
+                float lpv = (ok && g == 0) ? (-ss + a.s.base_const * (float)D + ldv) : 0.f;
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) lpv += __shfl_xor(lpv, o);
                 vsum += lpv;

@@ -41,12 +41,9 @@ __global__ void __launch_bounds__(256) spline_pass_kernel(PassArgs a, SplArgs q)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int tau = 0; tau < NT; ++tau) {
-                    f32x4 v = xs[c][tau];
-                    ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-                }
+                for (int tau = 0; tau < NT; ++tau) ss += base_E4(xs[c][tau], q.sp.base_beta);
             ss = group_sum(ss);
-            if (ok && g == 0) a.out[row] = -0.5f * ss - 0.91893853320467274f * (float)D + ld;
+            if (ok && g == 0) a.out[row] = -ss + q.sp.base_const * (float)D + ld;
             continue;
         }
         if (a.out) store_tile<NT>(a.out, row, ok, D, lane, xs);

@@ -34,6 +34,7 @@ struct SplineShape {
     int f1_floats, f2_floats;
     int blk_floats, image_floats;
     int blk_params, num_params;  // packed (state_dict order) parameter counts
+    float base_beta, base_const;  // base distribution, as FlowShape
 };
 
 __host__ __device__ inline int spl_cond_hidden_floats(int NTh, int NH) {  // L1 + L2 + L3 + b1 b2 b3

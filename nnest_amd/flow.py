@@ -31,6 +31,31 @@ class _HipFlow(object):
     """What the two flow families share: the pass / proposal entry points differ only in the C symbol
     (`self._sym[...]`, set by the subclass) -- same tensors in, same tensors out."""
 
+    base_beta = 0.0   # 0: N(0, I); > 0: GeneralisedNormal(0, 1, beta)
+    base_dist = None  # the distribution object handed to Trainer(base_dist=...), if any
+
+    def set_base(self, base_dist):
+        """NormalizingFlowModel(prior=...) (networks.py:47-59): None / MultivariateNormal(0, I) or GeneralisedNormal(0, 1, beta)"""
+        beta = 0.0
+        if base_dist is not None and hasattr(base_dist, 'beta'):
+            loc = torch.as_tensor(base_dist.loc, dtype=torch.float32).detach().cpu()
+            scale = torch.as_tensor(base_dist.scale, dtype=torch.float32).detach().cpu()
+            if not (bool(torch.all(loc == 0)) and bool(torch.all(scale == 1))):
+                raise NotImplementedError('GeneralisedNormal base: only loc = 0, scale = 1 (what the reference constructs)')
+            beta = float(base_dist.beta.item()) if torch.is_tensor(base_dist.beta) else float(base_dist.beta)
+            if not beta > 0:
+                raise ValueError('beta must be > 0')
+            self.base_dist = base_dist
+        with torch.cuda.device(self.device):
+            _lib.check(self._sym['set_base'](self._h, ctypes.c_float(beta)))
+        self.base_beta = beta
+
+    def prior_sample(self, num_samples):
+        """self.prior.sample((n,)) (networks.py:80): N(0, I) draws, or scipy gennorm draws for the generalised normal"""
+        if self.base_dist is not None:
+            return _as_dev_f32(self.base_dist.sample((int(num_samples),)).reshape(int(num_samples), self.D), self.device)
+        return torch.randn(int(num_samples), self.D, device=self.device)
+
     def eval(self):
         return self
 
@@ -71,7 +96,7 @@ class _HipFlow(object):
     def sample(self, num_samples=None, noise=None):
         """NormalizingFlowModel.sample (networks.py:78-84)"""
         if noise is None:
-            noise = torch.randn(num_samples, self.D, device=self.device)
+            noise = self.prior_sample(num_samples)
         x, _ = self.inverse(noise)
         return x
 
@@ -150,7 +175,7 @@ class HipNVP(_HipFlow):
         self._lib = _lib.load()
         L = self._lib
         self._sym = dict(forward=L.nnest_nvp_forward, inverse=L.nnest_nvp_inverse, log_probs=L.nnest_nvp_log_probs,
-                         inverse_loglike=L.nnest_nvp_inverse_loglike, mh=L.nnest_mh_constrained_steps)
+                         inverse_loglike=L.nnest_nvp_inverse_loglike, mh=L.nnest_mh_constrained_steps, set_base=L.nnest_nvp_set_base)
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.nnest_nvp_create_scaled(self.D, self.H, self.B, self.L, SCALE_MODES[scale],

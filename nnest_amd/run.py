@@ -36,9 +36,14 @@ def main(args):
         np.random.seed(args.seed)
         torch.manual_seed(args.seed)
     log_dir = os.path.join(args.log_dir, args.likelihood) + args.log_suffix
+    base_dist = None
+    if args.base_dist == 'gen_normal':   # examples/nested/run.py:20-21
+        from .distributions import GeneralisedNormal
+        base_dist = GeneralisedNormal(torch.zeros(args.x_dim), torch.ones(args.x_dim), torch.tensor(args.beta))
     sampler = NestedSampler(like.x_dim, like, transform=lambda x: scale * x, log_dir=log_dir,
                             num_live_points=args.num_live_points, hidden_dim=args.hidden_dim,
-                            num_layers=args.num_layers, num_blocks=args.num_blocks, flow=args.flow)
+                            num_layers=args.num_layers, num_blocks=args.num_blocks, flow=args.flow, base_dist=base_dist,
+                            scale=args.scale)
     start = time.time()
     sampler.run(train_iters=args.train_iters, mcmc_steps=args.mcmc_steps, volume_switch=args.switch, jitter=args.jitter,
                 mcmc_num_chains=args.mcmc_num_chains, mcmc_dynamic_step_size=not args.mcmc_fixed_step_size,
@@ -75,4 +80,7 @@ if __name__ == '__main__':
     p.add_argument('--max_iters', type=int, default=1000000)
     p.add_argument('--seed', type=int, default=-1)
     p.add_argument('--corr', type=float, default=0.99)
+    p.add_argument('--base_dist', type=str, default='')
+    p.add_argument('--beta', type=float, default=8.0)
+    p.add_argument('--scale', type=str, default='')
     main(p.parse_args())

@@ -458,10 +458,13 @@ class Sampler(object):
             enlargement_factor = (1 / constant_efficiency_factor) ** (1 / self.x_dim)
         ncall = 0
         while True:
-            # uniform in the ball of radius enlargement * max_r (sampler.py:579-583)
-            z = np.random.randn(block, self.x_dim)
-            r = enlargement_factor * self.max_r * np.random.rand(block) ** (1. / self.x_dim)
-            z = z * (r / np.sqrt(np.sum(z ** 2, axis=1)))[:, None]
+            prior = getattr(netG, 'prior', None)
+            if hasattr(prior, 'usample'):   # sampler.py:575-576: uniform box of the generalised-normal base
+                z = np.asarray(prior.usample(sample_shape=(block,))).reshape(block, self.x_dim) * enlargement_factor
+            else:                           # uniform in the ball of radius enlargement * max_r (sampler.py:579-583)
+                z = np.random.randn(block, self.x_dim)
+                r = enlargement_factor * self.max_r * np.random.rand(block) ** (1. / self.x_dim)
+                z = z * (r / np.sqrt(np.sum(z ** 2, axis=1)))[:, None]
             rnd_u = np.random.rand(block)
             x, ld, logl, inbox = self._candidate_block(z)
             with np.errstate(over='ignore', invalid='ignore'):

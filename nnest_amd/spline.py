@@ -33,7 +33,8 @@ class HipSpline(_HipFlow):
         self._lib = _lib.load()
         L = self._lib
         self._sym = dict(forward=L.nnest_spline_forward, inverse=L.nnest_spline_inverse, log_probs=L.nnest_spline_log_probs,
-                         inverse_loglike=L.nnest_spline_inverse_loglike, mh=L.nnest_spline_mh_constrained_steps)
+                         inverse_loglike=L.nnest_spline_inverse_loglike, mh=L.nnest_spline_mh_constrained_steps,
+                         set_base=L.nnest_spline_set_base)
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(L.nnest_spline_create(self.D, self.H, self.B, self.K, ctypes.c_float(self.tail_bound),

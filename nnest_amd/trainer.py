@@ -54,15 +54,19 @@ class Trainer(object):
         scale = '' if scale is None else scale
         if scale not in ('', 'translate', 'constant'):
             raise NotImplementedError("scale=%r: SingleSpeedNVP knows '', 'translate' and 'constant' (networks.py:330-332)" % scale)
+        gen_normal = None
         if base_dist is not None:
-            # the kernels hard-wire the reference's default base N(0, I) (networks.py:51-57); an explicit
-            # MultivariateNormal(0, I) -- what the reference's notebooks pass -- is that same distribution
-            ok = isinstance(base_dist, torch.distributions.MultivariateNormal)
-            if ok:
-                mean, cov = base_dist.mean.detach().cpu(), base_dist.covariance_matrix.detach().cpu()
-                ok = mean.shape == (x_dim,) and bool(torch.all(mean == 0)) and bool(torch.equal(cov, torch.eye(x_dim)))
-            if not ok:
-                raise NotImplementedError('only the N(0, I) base distribution is implemented')
+            # N(0, I) -- the reference's default base (networks.py:51-57), which its notebooks also pass explicitly -- or
+            # its GeneralisedNormal(0, 1, beta) (nnest/distributions/generalised_normal.py; run.py --base_dist gen_normal)
+            if hasattr(base_dist, 'beta') and hasattr(base_dist, 'usample'):
+                gen_normal = base_dist
+            else:
+                ok = isinstance(base_dist, torch.distributions.MultivariateNormal)
+                if ok:
+                    mean, cov = base_dist.mean.detach().cpu(), base_dist.covariance_matrix.detach().cpu()
+                    ok = mean.shape == (x_dim,) and bool(torch.all(mean == 0)) and bool(torch.equal(cov, torch.eye(x_dim)))
+                if not ok:
+                    raise NotImplementedError('base_dist: N(0, I) or GeneralisedNormal(0, 1, beta)')
         if batch_size > 128:
             raise NotImplementedError('batch_size > 128: one workgroup holds a minibatch (nnest_train.hip)')
         # host_tensors=True: forward/inverse/... return CPU tensors and `.device` reads 'cpu' while the arithmetic
@@ -83,6 +87,9 @@ class Trainer(object):
             self.netG = HipSpline(x_dim, hidden_dim, num_blocks, num_bins=8, tail_bound=3.0, device=self.gpu, seed=seed)
         else:
             self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed, scale=scale)
+        if gen_normal is not None:
+            self.netG.set_base(gen_normal)
+            self.netG.prior = gen_normal
         if load_model:
             self.path = os.path.join(log_dir, load_model)
             sd = torch.load(os.path.join(self.path, 'models', 'netG.pt'))
@@ -199,8 +206,8 @@ class Trainer(object):
         return self._out(x), self._out(log_det_J)
 
     def get_prior_samples(self, num_samples, to_numpy=False):
-        z = torch.randn(num_samples, self.x_dim, device=self.device)
-        return z.cpu().numpy() if to_numpy else z
+        z = self.netG.prior_sample(num_samples)   # netG.prior.sample((n,))  trainer.py:272
+        return z.cpu().numpy() if to_numpy else self._out(z)
 
     def _out(self, t):
         return t.cpu() if self.host_tensors else t

@@ -22,6 +22,8 @@ Fixture families:
                       (nnest/trainer.py:134-245)
   G9 spline_*.npz     SingleSpeedSpline (nnest/networks.py:393-715): passes before / after ActNorm's data-dependent
                       initialisation, gradients and Adam steps, a trained state
+  G10 base_gennormal_*.npz  generalised-normal base distribution (nnest/distributions/generalised_normal.py): log_probs,
+                      gradients, Adam steps for both flows
   G8 scale_*.npz      SingleSpeedNVP with scale='translate' / 'constant' (nnest/networks.py:289-347): passes,
                       gradients and Adam steps
 """
@@ -538,8 +540,61 @@ def gen_spline():
               np.abs(out['xb_trained'] - x).max())
 
 
+# ----------------------------------------------------------------------------------------------
+# G10: generalised-normal base distribution (nnest/distributions/generalised_normal.py; examples/nested/run.py:20-21,
+# --base_dist gen_normal --beta 8): log_probs, the loss gradient and Adam steps for both flows
+# ----------------------------------------------------------------------------------------------
+def gen_base_dist():
+    from nnest.distributions.generalised_normal import GeneralisedNormal
+    for flow, D in (('nvp', 5), ('spline', 5), ('nvp', 50)):
+        np.random.seed(0)
+        torch.manual_seed(8)
+        beta = 8.0
+        base = GeneralisedNormal(torch.zeros(D), torch.ones(D), torch.tensor(beta))
+        t = Trainer(D, hidden_dim=16, num_blocks=3, num_layers=1, flow=flow, log_dir=None, learning_rate=1e-3,
+                    base_dist=base, log_level=logging.WARNING)
+        out = {'D': D, 'beta': beta, 'flow': flow}
+        if flow == 'spline':
+            out['P'] = spline_P(t.netG)
+            x_first = np.random.uniform(-1, 1, size=(100, D)).astype(np.float32)
+            t.forward(x_first)           # ActNorm data-dependent init
+        out['w0'] = pack_state_dict(t.netG)
+        x = np.random.uniform(-1, 1, size=(64, D)).astype(np.float32)
+        out['x'] = x
+        out['lp0'] = t.log_probs(x, to_numpy=True)
+        n, jitter = 230, 0.02
+        X = np.random.uniform(-1, 1, size=(n, D)).astype(np.float32)
+        torch.manual_seed(11)
+        perms, noises = [], []
+        for e in range(2):
+            pp, nz = replay_loader_rng(n, 100, D)
+            perms.append(pp)
+            noises.append(nz)
+        opt = torch.optim.Adam(t.netG.parameters(), lr=1e-3, weight_decay=1e-6)
+        losses, grads, ws = [], [], []
+        Xt = torch.from_numpy(X)
+        t.netG.train()
+        for e in range(2):
+            for b in range(0, n, 100):
+                idx = torch.from_numpy(perms[e][b:b + 100].astype(np.int64))
+                data = Xt[idx] + jitter * torch.from_numpy(noises[e][b:b + 100])
+                opt.zero_grad()
+                loss = -t.netG.log_probs(data).mean()
+                loss.backward()
+                grads.append(pack_grads(t.netG))
+                opt.step()
+                losses.append(loss.item())
+                ws.append(pack_state_dict(t.netG))
+        out.update(X=X, jitter=jitter, perms=np.stack(perms), noises=np.stack(noises), losses=np.array(losses),
+                   grads=np.stack(grads[:2]), ws=np.stack([ws[0], ws[-1]]), lp1=t.log_probs(x, to_numpy=True))
+        np.savez_compressed(os.path.join(OUT, 'base_gennormal_%s_d%d.npz' % (flow, D)), **out)
+        print('G10 base', flow, D, 'loss0', losses[0], 'lp0', out['lp0'][:2])
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested', 'scale', 'spline']
+    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested', 'scale', 'spline', 'base']
+    if 'base' in which:
+        gen_base_dist()
     if 'spline' in which:
         gen_spline()
     if 'scale' in which:

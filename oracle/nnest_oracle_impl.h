@@ -152,11 +152,31 @@ void FN(nvp_inverse)(const float *w, int D, int H, int B, int L, const REAL *z, 
     }
 }
 
+
+/* log density of the base distribution at u[D] and (optionally) d(-log density)/du */
+static REAL FN(base_logp)(const REAL *u, int D, REAL *gneg) {
+    if (orc_base_beta == 0.0) {
+        const double half_log_2pi = 0.91893853320467274178;
+        REAL ss = 0;
+        for (int d = 0; d < D; ++d) { ss += u[d] * u[d]; if (gneg) gneg[d] = u[d]; }
+        return (REAL)(-0.5) * ss - (REAL)(D * half_log_2pi);
+    }
+    const REAL beta = (REAL)orc_base_beta;
+    const REAL cst = (REAL)(log(orc_base_beta) - log(2.0) - lgamma(1.0 / orc_base_beta));
+    REAL acc = 0;
+    for (int d = 0; d < D; ++d) {
+        REAL a = u[d] < 0 ? -u[d] : u[d];
+        REAL p = sizeof(REAL) == 4 ? (REAL)powf((float)a, (float)beta) : (REAL)pow((double)a, (double)beta);
+        acc += -p + cst;
+        if (gneg) gneg[d] = a == 0 ? (REAL)0 : beta * p / u[d]; /* beta |u|^(beta-1) sign(u) */
+    }
+    return acc;
+}
+
 /* NormalizingFlowModel.log_probs (networks.py:71-76) with the N(0,I) base (networks.py:51-57):
  * MVN(0,I).log_prob(u) = -0.5*|u|^2 - (D/2) log(2 pi) */
 void FN(nvp_log_probs)(const float *w, int D, int H, int B, int L, const REAL *x, int N, REAL *lp) {
     int bs = 2 * FN(net_size)(D, H, L);
-    const double half_log_2pi = 0.91893853320467274178;
     for (int n = 0; n < N; ++n) {
         REAL r[512];
         for (int d = 0; d < D; ++d) r[d] = x[(size_t)n * D + d];
@@ -165,9 +185,7 @@ void FN(nvp_log_probs)(const float *w, int D, int H, int B, int L, const REAL *x
             ld += FN(coupling_fwd_row)(w + (size_t)b * bs, D, H, L, b, r, NULL, NULL, NULL);
             ld += FN(scale_fwd_row)(w, D, B, bs, b, r);
         }
-        REAL ss = 0;
-        for (int d = 0; d < D; ++d) ss += r[d] * r[d];
-        lp[n] = (REAL)(-0.5) * ss - (REAL)(D * half_log_2pi) + ld;
+        lp[n] = FN(base_logp)(r, D, NULL) + ld;
     }
 }
 
@@ -232,7 +250,6 @@ static void FN(mlp_bwd)(const float *p, float *gp_unused, REAL *gp, int D, int H
 /* loss and dloss/dw for a minibatch X[M,D].  grad has num_params entries (zeroed here). Returns loss. */
 double FN(nvp_loss_grad)(const float *w, int D, int H, int B, int L, const REAL *X, int M, REAL *grad) {
     int ns = FN(net_size)(D, H, L), bs = 2 * ns, np_ = B * bs + (orc_scale_mode == 2 ? B : 0);
-    const double half_log_2pi = 0.91893853320467274178;
     for (int i = 0; i < np_; ++i) grad[i] = 0;
     REAL *xin = (REAL *)malloc(sizeof(REAL) * (size_t)B * D);
     REAL *lss = (REAL *)malloc(sizeof(REAL) * (size_t)B * D);
@@ -249,13 +266,11 @@ double FN(nvp_loss_grad)(const float *w, int D, int H, int B, int L, const REAL 
                                        as + (size_t)b * (L + 1) * H, at + (size_t)b * (L + 1) * H);
             ld += FN(scale_fwd_row)(w, D, B, bs, b, r);
         }
-        REAL ss = 0;
-        for (int d = 0; d < D; ++d) ss += r[d] * r[d];
-        REAL lp = (REAL)(-0.5) * ss - (REAL)(D * half_log_2pi) + ld;
-        loss += -(double)lp / M;
-        /* d(-lp/M)/du = u/M ; d/d(logdet) = -1/M */
         REAL gy[512], gld = (REAL)(-1.0 / M);
-        for (int d = 0; d < D; ++d) gy[d] = r[d] / (REAL)M;
+        REAL lp = FN(base_logp)(r, D, gy) + ld;
+        loss += -(double)lp / M;
+        /* d(-lp/M)/du = -dlog p(u)/du / M (= u/M for the N(0,I) base) ; d/d(logdet) = -1/M */
+        for (int d = 0; d < D; ++d) gy[d] = gy[d] / (REAL)M;
         for (int b = B - 1; b >= 0; --b) {
             const REAL *x = xin + (size_t)b * D, *ls = lss + (size_t)b * D;
             REAL m[512], gls[512], gt[512], gm[512];

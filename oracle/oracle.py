@@ -89,9 +89,10 @@ class NVP(object):
 
     Restates SingleSpeedNVP / NormalizingFlowModel (nnest/networks.py:17-84, :248-347)."""
 
-    def __init__(self, D, H=16, B=3, L=1, weights=None, scale=''):
+    def __init__(self, D, H=16, B=3, L=1, weights=None, scale='', base_beta=0.0):
         self.D, self.H, self.B, self.L = int(D), int(H), int(B), int(L)
         self.scale = scale
+        self.base_beta = float(base_beta)   # 0: N(0,I); > 0: GeneralisedNormal(0, 1, beta) (distributions/generalised_normal.py)
         self.n = num_params(D, H, B, L, scale)
         self.w = np.zeros(self.n, np.float32) if weights is None else _f32(weights).copy()
         assert self.w.size == self.n, (self.w.size, self.n)
@@ -101,6 +102,7 @@ class NVP(object):
 
     def _cfg(self):
         lib().orc_set_scale_mode(SCALE_MODES[self.scale])
+        lib().orc_set_base_beta(ctypes.c_double(self.base_beta))
         return (_p(self.w, _fp), self.D, self.H, self.B, self.L)
 
     def load_reference_vector(self, vec):
@@ -164,6 +166,7 @@ class NVP(object):
         g = np.empty(self.n, np.float32)
         self.t += 1
         lib().orc_set_scale_mode(SCALE_MODES[self.scale])
+        lib().orc_set_base_beta(ctypes.c_double(self.base_beta))
         loss = lib().orc_train_step(_p(self.w, _fp), _p(self.m, _fp), _p(self.v, _fp), self.D, self.H, self.B,
                                     self.L, _p(X, _fp), _p(idx, _ip), None if nz is None else _p(nz, _fp), M,
                                     ctypes.c_float(jitter), self.t, ctypes.c_float(lr), ctypes.c_float(wd),
@@ -215,14 +218,16 @@ class Spline(object):
     """SingleSpeedSpline (nnest/networks.py:708-715): [ActNorm, Invertible1x1Conv, NSF_CL] x B with packed
     (state_dict-order) fp32 weights and the B fixed permutation matrices P (not part of the state_dict)."""
 
-    def __init__(self, D, H=16, B=3, K=8, tail=3.0, weights=None, P=None):
+    def __init__(self, D, H=16, B=3, K=8, tail=3.0, weights=None, P=None, base_beta=0.0):
         self.D, self.H, self.B, self.K, self.tail = int(D), int(H), int(B), int(K), float(tail)
+        self.base_beta = float(base_beta)
         self.n = lib().orc_spline_num_params(self.D, self.H, self.B, self.K)
         self.w = np.zeros(self.n, np.float32) if weights is None else _f32(weights).copy()
         assert self.w.size == self.n, (self.w.size, self.n)
         self.P = _f32(np.tile(np.eye(self.D), (self.B, 1, 1)) if P is None else P).reshape(self.B, self.D, self.D).copy()
 
     def _args(self, f64):
+        lib().orc_set_base_beta(ctypes.c_double(self.base_beta))
         t = ctypes.c_double(self.tail) if f64 else ctypes.c_float(self.tail)
         return (_p(self.w, _fp), _p(self.P, _fp), self.D, self.H, self.B, self.K, t)
 

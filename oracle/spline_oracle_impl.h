@@ -300,18 +300,31 @@ void FN(spline_inverse)(const float *w, const float *Pm, int D, int H, int B, in
     free(W); free(Wi); free(row);
 }
 
+/* log density of the base distribution (N(0,I), or GeneralisedNormal(0,1,beta) when orc_base_beta > 0) */
+static REAL FN(sbase_logp)(const REAL *u, int D) {
+    if (orc_base_beta == 0.0) {
+        REAL ss = 0;
+        for (int d = 0; d < D; ++d) ss += u[d] * u[d];
+        return (REAL)(-0.5) * ss - (REAL)(D * 0.91893853320467274178);
+    }
+    const REAL cst = (REAL)(log(orc_base_beta) - log(2.0) - lgamma(1.0 / orc_base_beta));
+    REAL acc = 0;
+    for (int d = 0; d < D; ++d) {
+        REAL a = u[d] < 0 ? -u[d] : u[d];
+        acc += -(sizeof(REAL) == 4 ? (REAL)powf((float)a, (float)orc_base_beta) : (REAL)pow((double)a, orc_base_beta)) + cst;
+    }
+    return acc;
+}
+
 /* NormalizingFlowModel.log_probs (networks.py:71-76) with the N(0,I) base; returns -mean (the training loss,
  * trainer.py:394) and fills lp[N] */
 double FN(spline_log_probs)(float *w, const float *Pm, int D, int H, int B, int K, REAL tail, const REAL *x, int N, REAL *lp,
                             int data_init) {
-    const double half_log_2pi = 0.91893853320467274178;
     REAL *z = (REAL *)malloc(sizeof(REAL) * (size_t)N * D);
     FN(spline_forward)(w, Pm, D, H, B, K, tail, x, N, z, lp, data_init);
     double tot = 0;
     for (int n = 0; n < N; ++n) {
-        REAL ss = 0;
-        for (int d = 0; d < D; ++d) ss += z[(size_t)n * D + d] * z[(size_t)n * D + d];
-        lp[n] = (REAL)(-0.5) * ss - (REAL)(D * half_log_2pi) + lp[n];
+        lp[n] = FN(sbase_logp)(z + (size_t)n * D, D) + lp[n];
         tot += (double)lp[n];
     }
     free(z);

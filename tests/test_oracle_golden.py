@@ -321,3 +321,32 @@ def test_spline_flow(path):
     fd = sp.fd_grad(data, idx)
     # the loss is piecewise smooth (LeakyReLU kinks, bin edges): differences across a kink cost a fraction of a percent
     assert np.max(np.abs(fd - gref[idx])) < 1e-2 * np.max(np.abs(gref)) + 1e-5
+
+
+BASE_FILES = sorted(glob.glob(os.path.join(G, 'base_gennormal_*.npz')))
+
+
+@pytest.mark.parametrize('path', BASE_FILES, ids=[os.path.basename(p)[15:-4] for p in BASE_FILES])
+def test_generalised_normal_base(path):
+    """base_dist = GeneralisedNormal(0, 1, beta) (nnest/distributions/generalised_normal.py:66-71; run.py --base_dist gen_normal)"""
+    g = np.load(path)
+    D, beta, flow = int(g['D']), float(g['beta']), str(g['flow'])
+    data = g['X'][g['perms'][0][:100]] + np.float32(g['jitter']) * g['noises'][0][:100]
+    if flow == 'nvp':
+        o = orc.NVP(D, 16, 3, 1, g['w0'], base_beta=beta)
+        assert rel(o.log_probs(g['x']), g['lp0']) < 3e-5
+        loss, grad = o.loss_grad(data)
+        assert abs(loss - g['losses'][0]) < 3e-5 * (1 + abs(g['losses'][0]))
+        gref = g['grads'][0]
+        assert np.max(np.abs(grad - gref)) < 5e-5 * (1e-3 + np.max(np.abs(gref)))
+        # the N(0, I) oracle gives a different loss: the switch is live
+        assert abs(orc.NVP(D, 16, 3, 1, g['w0']).loss_grad(data)[0] - loss) > 1e-3
+    else:
+        o = orc.Spline(D, 16, 3, 8, 3.0, g['w0'], g['P'], base_beta=beta)
+        lp, _ = o.log_probs(g['x'])
+        # |u|^8 amplifies float32 rounding of u by 8 |u|^7: compare relative to the float32-vs-float64 spread of this file
+        lp64, _ = o.log_probs(g['x'], f64=True)
+        tol = max(3e-5, 4 * rel(lp, lp64))
+        assert rel(lp, g['lp0']) < tol and rel(lp64, g['lp0']) < tol
+        _, loss = o.log_probs(data)
+        assert abs(loss - g['losses'][0]) < max(3e-5, tol) * (1 + abs(g['losses'][0]))
