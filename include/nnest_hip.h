@@ -60,6 +60,9 @@ typedef struct {
 /* flags for nnest_mh_constrained_steps */
 enum {
     NNEST_MH_DYNAMIC_STEP = 1, /* sampler.py:422-431 step-size adaptation (see DESIGN.md for the group rule) */
+    NNEST_MH_UNCONSTRAINED = 2, /* loglstar = None (sampler.py:371-410): plain Metropolis with the likelihood and the box
+                                 * prior in the ratio, min(1, exp(dlogdet + dlogl)); `loglstar` is ignored and every
+                                 * proposal counts as one likelihood call */
 };
 
 typedef struct nnest_nvp nnest_nvp_t; /* opaque: RealNVP coupling stack + Adam state on one device */

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get('NNEST_HIP_LIB', os.path.join(_HERE, 'libnnest_hip.so'
 NNEST_OK = 0
 LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'himmelblau': 2, 'gaussian': 3, 'eggbox': 4, 'shell': 5, 'double_shell': 6}
 MH_DYNAMIC_STEP = 1
+MH_UNCONSTRAINED = 2
 TRAIN_RESUME = 1
 TRAIN_FINALIZE = 2
 

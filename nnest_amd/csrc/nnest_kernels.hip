@@ -228,6 +228,7 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
     const LikeSpec like = a.like;
     const double loglstar = a.loglstar;
     const bool dynamic = (a.flags & NNEST_MH_DYNAMIC_STEP) != 0;
+    const bool free_mode = (a.flags & NNEST_MH_UNCONSTRAINED) != 0;
 
     f32x4 z[2][NT], x[2][NT];
     load_tile<NT>(a.z, row, ok, D, lane, z);
@@ -308,8 +309,13 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
 #else
         double lp = loglike_tile<NT>(like, D, lane, xp);
 #endif
-        const bool acc = pre && (lp > loglstar);  // finite is guaranteed by the -1e100 clamp  :361
-        n_call += pre ? 1 : 0;
+        bool acc = pre && (lp > loglstar);  // finite is guaranteed by the -1e100 clamp  :361
+        if (free_mode) {  // sampler.py:396-410: float32 log-det difference + float64 likelihood difference, box prior
+            const double lr = inb ? (double)(ldp - ld) + (lp - logl) : -INFINITY;
+            const double rt = fmin(exp(lr), 1.0);
+            acc = ok && ((double)u < rt);
+        }
+        n_call += (free_mode ? ok : pre) ? 1 : 0;
         n_acc += acc ? 1 : 0;
 #pragma unroll
         for (int c = 0; c < 2; ++c)

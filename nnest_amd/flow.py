@@ -119,7 +119,10 @@ class _HipFlow(object):
                  walker_offset=0, history=False, like_params=None):
         """K4: `steps` constrained Metropolis steps for all walkers in one launch (Sampler._mcmc_sample,
         sampler.py:229-463).  z [C,D] float32 and logl [C] float64 are updated in place.
-        noise = (dz [steps,C,D], u [steps,C]) replays recorded draws; None = in-kernel Philox."""
+        noise = (dz [steps,C,D], u [steps,C]) replays recorded draws; None = in-kernel Philox.
+        loglstar None / NaN = the unconstrained branch (sampler.py:371-410): likelihood and box prior in the ratio."""
+        free = loglstar is None or loglstar != loglstar
+        loglstar = 0.0 if free else loglstar
         assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()
         assert logl.is_cuda and logl.dtype == torch.float64 and logl.is_contiguous()
         C = z.shape[0]
@@ -140,7 +143,8 @@ class _HipFlow(object):
             lk = _lib.like_spec(like_id, like_scale, like_params)
             _lib.check(self._sym['mh'](
                 self._h, ctypes.byref(lk), _lib.ptr(z), _lib.ptr(x), _lib.ptr(logl), float(loglstar),
-                float(step_size), int(steps), C, _lib.MH_DYNAMIC_STEP if dynamic else 0, _lib.ptr(dz), _lib.ptr(u),
+                float(step_size), int(steps), C, (_lib.MH_DYNAMIC_STEP if dynamic else 0) | (_lib.MH_UNCONSTRAINED if free else 0),
+                _lib.ptr(dz), _lib.ptr(u),
                 int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), _lib.ptr(hx), _lib.ptr(hl), _lib.ptr(n_acc),
                 _lib.ptr(n_call), _lib.ptr(scale_out), _lib.current_stream(dev)))
         return dict(x=x, n_accept=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl)

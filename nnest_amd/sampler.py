@@ -232,8 +232,8 @@ class Sampler(object):
         last state unless the sampler was built with mcmc_history=True (nested.py:432-437 reads only those)."""
         if step_size <= 0.0:
             step_size = 2 / self.x_dim ** 0.5
-        fused = (self._fused_like_id is not None and loglstar is not None and init_samples is not None
-                 and init_loglikes is not None and prior_volume_steps == 1)
+        fused = (self._fused_like_id is not None and init_samples is not None and init_loglikes is not None
+                 and prior_volume_steps == 1)   # loglstar None = the unconstrained branch, also in the kernel
         if fused:
             return self._mcmc_sample_fused(mcmc_steps, step_size, dynamic_step_size, init_samples, init_loglikes,
                                            loglstar, walker_offset, seed)
@@ -251,7 +251,7 @@ class Sampler(object):
         if not self.mcmc_history:
             x0, _ = netG.inverse(z)                                    # sampler.py:266
         z0 = z.clone()
-        res = netG.mh_steps(self._fused_like_id, self._linear_scale, z, logl, float(loglstar), float(step_size),
+        res = netG.mh_steps(self._fused_like_id, self._linear_scale, z, logl, None if loglstar is None else float(loglstar), float(step_size),
                             int(mcmc_steps), dynamic=dynamic, seed=self._next_seed() if seed is None else seed,
                             walker_offset=walker_offset, history=self.mcmc_history, like_params=self._fused_like_params)
         ncall = int(res['n_call'].sum().item())

@@ -317,7 +317,9 @@ def gen_train_run():
 def gen_mcmc():
     cases = [('rosen_d2', Rosenbrock, 2, 5.0, 16, 24, False), ('rosen_d2_dyn', Rosenbrock, 2, 5.0, 10, 40, True),
              ('rosen_d50', Rosenbrock, 50, 5.0, 16, 12, False), ('rosen_d50_dyn', Rosenbrock, 50, 5.0, 16, 30, True),
-             ('gmix_d20', GaussianMix, 20, 10.0, 16, 12, False), ('himmel_d2', Himmelblau, 2, 5.0, 16, 16, True)]
+             ('gmix_d20', GaussianMix, 20, 10.0, 16, 12, False), ('himmel_d2', Himmelblau, 2, 5.0, 16, 16, True),
+             # loglstar=None: likelihood and prior in the proposal ratio (sampler.py:371-410); stored as loglstar = NaN
+             ('free_rosen_d2', Rosenbrock, 2, 5.0, 16, 40, True), ('free_gmix_d20', GaussianMix, 20, 10.0, 16, 20, False)]
     for name, cls, D, scale, C, S, dyn in cases:
         np.random.seed(9)
         torch.manual_seed(9)
@@ -333,11 +335,11 @@ def gen_mcmc():
         live_logl = live_logl[order[100:]]
         s.trainer.train(live_u, max_iters=15, jitter=0.01)
         s.trainer.path = None
-        loglstar = float(np.min(live_logl))
+        loglstar = None if name.startswith('free_') else float(np.min(live_logl))
         idx = np.random.randint(0, live_u.shape[0], size=C)
         init = live_u[idx]
         init_l = live_logl[idx]
-        step = 1.0 / np.sqrt(D)
+        step = (0.2 if name.startswith('free_') else 1.0) / np.sqrt(D)
         torch.manual_seed(77)
         rng_state = torch.get_rng_state()
         dz = np.stack([torch.randn(C, D).numpy() for _ in range(1)])  # placeholder to learn the order
@@ -353,7 +355,7 @@ def gen_mcmc():
             loglstar=loglstar, step_size=step, dynamic_step_size=dyn, plot_trace=False)
         np.savez_compressed(
             os.path.join(OUT, 'mcmc_%s.npz' % name), D=D, H=16, B=3, L=1, like=cls.__name__, scale=scale,
-            w=pack_state_dict(s.trainer.netG), init=init, init_logl=init_l, loglstar=loglstar, step=step,
+            w=pack_state_dict(s.trainer.netG), init=init, init_logl=init_l, loglstar=np.nan if loglstar is None else loglstar, step=step,
             dynamic=dyn, dz=np.stack(dzs), u=np.stack(us), samples=samples, latent=latent,
             loglikes=loglikes, scale_out=scale_out, ncall=ncall, total_calls=s.total_calls - calls0,
             total_accepted=int(s.total_accepted), total_rejected=int(s.total_rejected))
