@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 5
+#define NNEST_HIP_ABI_VERSION 6
 
 enum {
     NNEST_OK = 0,
@@ -189,6 +189,15 @@ int nnest_nvp_train(nnest_nvp_t *nvp, const float *xtrain_dev, int n_train, cons
 /* One minibatch: loss and dloss/dw (before weight decay) into grad_dev [num_params], no update.
  * For tests (reference: loss.backward(), trainer.py:400). x_dev [M,D]. loss_dev float32[1]. */
 int nnest_nvp_loss_grad(nnest_nvp_t *nvp, const float *x_dev, int M, float *grad_dev, float *loss_dev, void *stream);
+
+/* The flow as one stage of a composite model (FastSlowNormalizingFlowModel, networks.py:86-150): vector-Jacobian product
+ * of one batch (M <= 128 rows).  With L = sum_rows gz . f(x) + gld * sum_rows logdet(x):  grad_dev = dL/dw (packed order),
+ * gx_dev = dL/dx [M,D]. */
+int nnest_nvp_vjp(nnest_nvp_t *nvp, const float *x_dev, const float *gz_dev, float gld, int M, float *grad_dev, float *gx_dev,
+                  void *stream);
+/* one torch.optim.Adam step (coupled weight decay, trainer.py:121-122) from a gradient computed outside nnest_nvp_train;
+ * uses and advances the handle's Adam state; synchronises `stream` */
+int nnest_nvp_adam_step(nnest_nvp_t *nvp, const float *grad_dev, float lr, float weight_decay, void *stream);
 
 /* training jitter when jitter < 0 (trainer.py:168-171): 0.2 * mean of the 2-nearest-neighbour distance
  * table (self distance 0 included) of samples_dev [N,D] float64; result to out_dev float64[1]. */

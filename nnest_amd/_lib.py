@@ -67,6 +67,8 @@ SIGNATURES = {
     'nnest_nvp_destroy': [_vp],
     'nnest_nvp_num_params': [_vp],
     'nnest_nvp_set_base': [_vp, _f],
+    'nnest_nvp_vjp': [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
+    'nnest_nvp_adam_step': [_vp, _vp, _f, _f, _vp],
     'nnest_spline_set_base': [_vp, _f],
     'nnest_nvp_load_weights': [_vp, _vp, _vp],
     'nnest_nvp_store_weights': [_vp, _vp, _vp],

@@ -326,6 +326,28 @@ int nnest_nvp_loss_grad(nnest_nvp_t *h, const float *x_dev, int M, float *grad_d
     return NNEST_OK;
 }
 
+int nnest_nvp_vjp(nnest_nvp_t *h, const float *x_dev, const float *gz_dev, float gld, int M, float *grad_dev, float *gx_dev, void *stream) {
+    if (!h || !x_dev || !gz_dev || !grad_dev || !gx_dev) return fail(NNEST_E_ARG, "NULL argument");
+    if (M < 1 || M > 128) return fail(NNEST_E_UNSUPPORTED, "M=%d outside [1,128]", M);
+    HIP_TRY(launch_vjp(h->w, h->s, x_dev, gz_dev, gld, M, grad_dev, gx_dev, h->train_ws, h->img, h->fwd_pos, h->bwd_pos, (hipStream_t)stream));
+    return NNEST_OK;
+}
+
+int nnest_nvp_adam_step(nnest_nvp_t *h, const float *grad_dev, float lr, float weight_decay, void *stream) {
+    if (!h || !grad_dev) return fail(NNEST_E_ARG, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    int step = 0;
+    HIP_TRY(hipMemcpyAsync(&step, h->adam_step, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    step += 1;
+    HIP_TRY(launch_adam_packed(h->w, grad_dev, h->adam_m, h->adam_v, h->num_params, step, lr, weight_decay, st));
+    HIP_TRY(hipMemcpyAsync(h->adam_step, &step, sizeof(int), hipMemcpyHostToDevice, st));
+    if (h->s.scale_mode != NNEST_SCALE_AFFINE) HIP_TRY(launch_zero_scale_nets(h->w, h->s, st));
+    HIP_TRY(launch_repack(h->w, h->img, h->s, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NNEST_OK;
+}
+
 int nnest_training_jitter(const double *samples_dev, int N, int D, double *out_dev, void *stream) {
     if (!samples_dev || !out_dev || N < 2 || D < 1) return fail(NNEST_E_ARG, "bad arguments");
     HIP_TRY(launch_training_jitter(samples_dev, N, D, out_dev, (hipStream_t)stream));

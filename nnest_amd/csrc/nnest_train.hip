@@ -33,7 +33,9 @@ namespace nnest {
 #define TACC(acc, t1, t0) do { } while (0)
 #endif
 
-enum { TRAIN_MODE_EPOCHS = 0, TRAIN_MODE_GRAD_ONLY = 1 };
+// GRAD_ONLY: loss and dLoss/dw of one batch.  VJP: the flow as one stage of a composite model (fast/slow hierarchy): given the
+// batch x, an upstream gradient gz = dL/d(output) and gld = dL/d(logdet) per row, it returns dL/dw and gx = dL/dx.
+enum { TRAIN_MODE_EPOCHS = 0, TRAIN_MODE_GRAD_ONLY = 1, TRAIN_MODE_VJP = 2 };
 static const int TRAIN_THREADS = 512;  // 8 waves
 static const int TRAIN_WAVES = 8;
 static const int TRAIN_MAX_ROWS = 128;
@@ -58,6 +60,9 @@ struct TrainArgs {
     float *loss_out;
     int mode;
     int epoch_offset, flags;
+    const float *gz;  // VJP: upstream gradient [M, D]
+    float *gx;        // VJP: gradient wrt the input rows [M, D]
+    float gld_in;     // VJP: dL/d(logdet), the same for every row
 };
 
 // ---- fragment images -----------------------------------------------------------------------------------
@@ -570,7 +575,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
     __shared__ float sred[8 * TRAIN_WAVES];  // per (block, wave) partials of dLoss/ds_b; B <= 8 checked by the launcher
 
     rebuild_images_to(a, imgf, imgb);
-    if (a.mode == TRAIN_MODE_GRAD_ONLY)
+    if (a.mode != TRAIN_MODE_EPOCHS)
         for (int i = threadIdx.x; i < np; i += blockDim.x) a.grad[i] = 0.f;
     const bool resume = a.mode == TRAIN_MODE_EPOCHS && (a.flags & NNEST_TRAIN_RESUME);
     if (threadIdx.x == 0) {
@@ -586,8 +591,8 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
         }
     __syncthreads();
 
-    const int n_mb = a.mode == TRAIN_MODE_GRAD_ONLY ? 1 : (a.n_train + a.batch - 1) / a.batch;
-    const int n_epochs = a.mode == TRAIN_MODE_GRAD_ONLY ? 1 : a.max_epochs;
+    const int n_mb = a.mode != TRAIN_MODE_EPOCHS ? 1 : (a.n_train + a.batch - 1) / a.batch;
+    const int n_epochs = a.mode != TRAIN_MODE_EPOCHS ? 1 : a.max_epochs;
     int adam_t = a.adam_step ? *a.adam_step : 0;
     int epochs_run = 0;
     float last_train_loss = 0.f;
@@ -597,7 +602,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
     for (int epoch = 0; epoch < n_epochs; ++epoch) {
         float epoch_loss = 0.f;  // sum of minibatch means (trainer.py:398)
         for (int mb = 0; mb < n_mb; ++mb) {
-            const int M = a.mode == TRAIN_MODE_GRAD_ONLY ? a.n_train : min(a.batch, a.n_train - mb * a.batch);
+            const int M = a.mode != TRAIN_MODE_EPOCHS ? a.n_train : min(a.batch, a.n_train - mb * a.batch);
             const int ntile = (M + 15) >> 4;
             const int rows_pad = ntile * 16;
             const bool tile_active = wave < ntile;
@@ -609,7 +614,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
             if (tile_active) {
                 // data = X[perm] + jitter * randn  (trainer.py:392)
                 long src = 0;
-                if (row_ok) src = a.mode == TRAIN_MODE_GRAD_ONLY ? row : a.perm[(size_t)epoch * a.n_train + mb * a.batch + row];
+                if (row_ok) src = a.mode != TRAIN_MODE_EPOCHS ? row : a.perm[(size_t)epoch * a.n_train + mb * a.batch + row];
                 load_tile<NT>(a.xtrain, src, row_ok, D, lane, xs);
                 if (a.mode == TRAIN_MODE_EPOCHS && a.jitter != 0.f) {
                     const long p = (long)mb * a.batch + row;
@@ -659,11 +664,15 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
             // d(loss)/du = dE/du / M (= u/M for the N(0,I) base) ; d(loss)/d(logdet) = -1/M
             TSTAMP(p1);
             TACC(ph[0], p1, p0);
-            const float invM = 1.0f / (float)M, gld = -invM;
+            const float invM = 1.0f / (float)M, gld = a.mode == TRAIN_MODE_VJP ? a.gld_in : -invM;
+            if (a.mode == TRAIN_MODE_VJP) {
+                if (tile_active) load_tile<NT>(a.gz, row, row_ok, D, lane, gs);
+            } else {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) gs[c][t] = row_ok ? base_dE4(xs[c][t], a.s.base_beta) * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int t = 0; t < NT; ++t) gs[c][t] = row_ok ? base_dE4(xs[c][t], a.s.base_beta) * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
             // Adam scalars of this step (torch/optim/adam.py _single_tensor_adam); the update itself is applied
             // per parameter by the thread that produces its gradient (weight_grad_jobs)
             AdamStep ad = {0.f, 1.f};
@@ -709,6 +718,11 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
             }
             if (a.mode == TRAIN_MODE_GRAD_ONLY) {
                 if (threadIdx.x == 0) *a.loss_out = loss;
+                __syncthreads();
+                return;
+            }
+            if (a.mode == TRAIN_MODE_VJP) {
+                if (tile_active) store_tile<NT>(a.gx, row, row_ok, D, lane, gs);
                 __syncthreads();
                 return;
             }
@@ -899,6 +913,45 @@ hipError_t launch_loss_grad(const float *packed, const FlowShape &s, const float
     a.loss_out = loss;
     a.mode = TRAIN_MODE_GRAD_ONLY;
     return dispatch_train(a, st);
+}
+
+hipError_t launch_vjp(const float *packed, const FlowShape &s, const float *x, const float *gz, float gld, int M, float *grad, float *gx,
+                      float *workspace, float *img_fwd, const int *fwd_pos, const int *bwd_pos, hipStream_t st) {
+    TrainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = const_cast<float *>(packed);
+    a.img_fwd = img_fwd;
+    a.img_bwd = workspace;
+    a.fwd_pos = fwd_pos;
+    a.bwd_pos = bwd_pos;
+    a.grad = grad;
+    a.s = s;
+    a.xtrain = x;
+    a.n_train = M;
+    a.batch = M;
+    a.gz = gz; a.gx = gx; a.gld_in = gld;
+    a.mode = TRAIN_MODE_VJP;
+    return dispatch_train(a, st);
+}
+
+// torch.optim.Adam (coupled weight decay) over the packed vector from an externally supplied gradient: the optimiser step
+// of a composite model whose stages are separate handles (fast/slow hierarchy)
+__global__ void adam_packed_kernel(float *__restrict__ w, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, int n,
+                                   float step_size, float inv_bc2s, float wd) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float gi = grad[i] + wd * w[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        w[i] = w[i] - step_size * (mi / (sqrtf(vi) * inv_bc2s + eps));
+    }
+}
+
+hipError_t launch_adam_packed(float *w, const float *grad, float *m, float *v, int n, int step, float lr, float wd, hipStream_t st) {
+    const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
+    hipLaunchKernelGGL(adam_packed_kernel, dim3(64), dim3(256), 0, st, w, grad, m, v, n, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), wd);
+    return hipGetLastError();
 }
 
 hipError_t launch_train(float *packed, float *adam_m, float *adam_v, float *best_w, float *img, int *adam_step_dev,

@@ -67,14 +67,13 @@ class Sampler(object):
         self.x_dim = x_dim
         self.num_derived = num_derived
         self.num_params = x_dim + num_derived
-        if num_slow != 0:
-            raise NotImplementedError('num_slow > 0 (fast/slow hierarchy) is outside the scope of this build')
-        self.num_slow = 0
-        self.num_fast = x_dim
+        assert x_dim > num_slow                       # sampler.py:87
+        self.num_slow = num_slow
+        self.num_fast = x_dim - num_slow
         self.param_names = param_names
         if self.param_names is not None:
             assert len(param_names) == self.num_params
-        self.oversample_rate = oversample_rate if oversample_rate > 0 else 1.0
+        self.oversample_rate = oversample_rate if oversample_rate > 0 else self.num_fast / self.x_dim   # sampler.py:95
         self.mcmc_history = mcmc_history
         self._user_loglike = loglike
         self._user_prior = prior
@@ -308,6 +307,10 @@ class Sampler(object):
             x_t, log_det_J = tr.inverse(z)
             x = x_t.cpu().numpy()
             dz = torch.randn_like(z) * scale
+            fast = False
+            if self.num_slow > 0 and np.random.uniform() < self.oversample_rate:   # sampler.py:311-315, :378-382
+                fast = True
+                dz[:, 0:self.num_slow] = 0.0
             z_prime = z + dz
             x_prime_t, log_det_J_prime = tr.inverse(z_prime)
             x_prime = x_prime_t.cpu().numpy()
@@ -324,11 +327,15 @@ class Sampler(object):
                     lp, der = self.loglike(x_prime[idx])
                     ok = np.isfinite(lp) & (lp > loglstar)
                     ncall += len(idx)
+                    if fast:
+                        self.total_fast_calls += len(idx)
                     logl_prime[idx[ok]] = lp[ok]
                     derived_prime[idx[ok]] = der[ok]
                     mask[idx[~ok]] = False
             else:
                 ncall += num_chains
+                if fast:
+                    self.total_fast_calls += num_chains
                 logl_prime, derived_prime = self.loglike(x_prime)
                 log_ratio = log_ratio + torch.as_tensor(logl_prime - logl) + torch.as_tensor(logl_prior_prime - logl_prior)
                 rnd_u = torch.rand(log_ratio.shape)

@@ -50,7 +50,11 @@ class Trainer(object):
                                       "flow); the Choleksy flow of the reference is outside its scope (DESIGN.md)" % flow)
         self.flow = flow.lower()
         if num_slow != 0:
-            raise NotImplementedError('num_slow > 0 (fast/slow hierarchy) is outside the scope of this build')
+            assert x_dim > num_slow                      # trainer.py:79
+            if flow.lower() != 'nvp':
+                raise NotImplementedError("num_slow > 0 is implemented for flow='nvp' (FastSlowNVP); FastSlowSpline is not")
+            if scale not in ('', None) or base_dist is not None:
+                raise NotImplementedError('num_slow > 0 with a scale variant or a non-default base distribution')
         scale = '' if scale is None else scale
         if scale not in ('', 'translate', 'constant'):
             raise NotImplementedError("scale=%r: SingleSpeedNVP knows '', 'translate' and 'constant' (networks.py:330-332)" % scale)
@@ -79,12 +83,15 @@ class Trainer(object):
         self.z_dim = x_dim
         self.batch_size = batch_size
         self.total_iters = 0
-        self.num_slow = 0
+        self.num_slow = num_slow
         self.learning_rate = learning_rate
         self.weight_decay = weight_decay
         if self.flow == 'spline':    # SingleSpeedSpline(x_dim, hidden_dim, num_blocks, tail_bound=3)  (trainer.py:97-98)
             from .spline import HipSpline
             self.netG = HipSpline(x_dim, hidden_dim, num_blocks, num_bins=8, tail_bound=3.0, device=self.gpu, seed=seed)
+        elif num_slow > 0:           # FastSlowNVP(num_fast, num_slow, hidden_dim, num_blocks, num_layers)  (trainer.py:86-88)
+            from .fastslow import HipFastSlowNVP
+            self.netG = HipFastSlowNVP(x_dim - num_slow, num_slow, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed)
         else:
             self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed, scale=scale)
         if gen_normal is not None:
@@ -112,8 +119,8 @@ class Trainer(object):
         self.logger = create_logger(__name__, level=log_level)
         self.log = log
         self.writer = ScalarWriter(self.path)
-        self.logger.info('Number of network params: [%s]' % (self.netG.reference_vector().size if self.flow == 'nvp'
-                                                             else self.netG.num_params))
+        self.logger.info('Number of network params: [%s]' % (self.netG.reference_vector().size
+                                                             if hasattr(self.netG, 'reference_vector') else self.netG.num_params))
         self.logger.info('Device [%s]' % self.device)
 
     # ------------------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@ Fixture families:
                       initialisation, gradients and Adam steps, a trained state
   G10 base_gennormal_*.npz  generalised-normal base distribution (nnest/distributions/generalised_normal.py): log_probs,
                       gradients, Adam steps for both flows
+  G11 fastslow_*.npz  FastSlowNVP (nnest/networks.py:86-150, :350-380): passes, gradients, Adam steps
   G8 scale_*.npz      SingleSpeedNVP with scale='translate' / 'constant' (nnest/networks.py:289-347): passes,
                       gradients and Adam steps
 """
@@ -593,8 +594,61 @@ def gen_base_dist():
         print('G10 base', flow, D, 'loss0', losses[0], 'lp0', out['lp0'][:2])
 
 
+# ----------------------------------------------------------------------------------------------
+# G11: fast/slow hierarchy, FastSlowNVP (networks.py:86-150, :350-380; Trainer(num_slow=...), trainer.py:85-88): a slow NVP on
+# the first num_slow dims, a fast NVP on the rest, then one coupling (hidden 64, 1 layer) conditioned on the slow block
+# ----------------------------------------------------------------------------------------------
+def gen_fastslow():
+    for S, F in [(2, 3), (5, 5), (4, 12)]:
+        D = S + F
+        np.random.seed(0)
+        torch.manual_seed(12)
+        t = Trainer(D, num_slow=S, hidden_dim=16, num_blocks=3, num_layers=1, flow='nvp', log_dir=None, learning_rate=1e-3,
+                    log_level=logging.WARNING)
+        out = {'S': S, 'F': F, 'D': D, 'H': 16, 'B': 3, 'L': 1, 'keys': np.array(list(t.netG.state_dict().keys())),
+               'shapes': np.array([str(tuple(v.shape)) for v in t.netG.state_dict().values()])}
+        out['w0'] = pack_state_dict(t.netG)
+        x = np.random.normal(size=(64, D)).astype(np.float32)
+        n, jitter = 230, 0.02
+        X = np.random.uniform(-1, 1, size=(n, D)).astype(np.float32)
+        torch.manual_seed(11)
+        perms, noises = [], []
+        for e in range(2):
+            pp, nz = replay_loader_rng(n, 100, D)
+            perms.append(pp)
+            noises.append(nz)
+        for tag in ('init', 'trained'):
+            if tag == 'trained':
+                opt = torch.optim.Adam(t.netG.parameters(), lr=1e-3, weight_decay=1e-6)
+                losses, grads, ws = [], [], []
+                Xt = torch.from_numpy(X)
+                t.netG.train()
+                for e in range(2):
+                    for b in range(0, n, 100):
+                        idx = torch.from_numpy(perms[e][b:b + 100].astype(np.int64))
+                        data = Xt[idx] + jitter * torch.from_numpy(noises[e][b:b + 100])
+                        opt.zero_grad()
+                        loss = -t.netG.log_probs(data).mean()
+                        loss.backward()
+                        grads.append(pack_grads(t.netG))
+                        opt.step()
+                        losses.append(loss.item())
+                        ws.append(pack_state_dict(t.netG))
+                out.update(X=X, jitter=jitter, perms=np.stack(perms), noises=np.stack(noises), losses=np.array(losses),
+                           grads=np.stack(grads[:2]), ws=np.stack([ws[0], ws[-1]]))
+            z, ldf = t.forward(x, to_numpy=True)
+            xb, ldi = t.inverse(z, to_numpy=True)
+            lp = t.log_probs(x, to_numpy=True)
+            out.update({'x': x, 'w_' + tag: pack_state_dict(t.netG), 'z_' + tag: z, 'ldf_' + tag: ldf, 'xb_' + tag: xb,
+                        'ldi_' + tag: ldi, 'lp_' + tag: lp})
+        np.savez_compressed(os.path.join(OUT, 'fastslow_s%d_f%d.npz' % (S, F)), **out)
+        print('G11 fastslow', S, F, 'nparams', out['w0'].size, 'loss0', out['losses'][0], list(out['keys'][-6:]))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested', 'scale', 'spline', 'base']
+    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested', 'scale', 'spline', 'base', 'fastslow']
+    if 'fastslow' in which:
+        gen_fastslow()
     if 'base' in which:
         gen_base_dist()
     if 'spline' in which:

@@ -349,3 +349,69 @@ def philox4x32_10(ctr, key):
     o = (ctypes.c_uint32 * 4)()
     lib().orc_philox4x32_10(c, k, o)
     return [int(v) for v in o]
+
+
+class FastSlowNVP(object):
+    """FastSlowNVP (nnest/networks.py:86-150, :350-380): slow NVP on x[:, :S], fast NVP on x[:, S:], then one coupling layer
+    (hidden 64, one hidden layer) with mask = (1,)*S + (0,)*F.  Weights: the concatenated reference state_dict
+    (fast_flow, slow_flow, flow).  Composition of the pinned NVP pieces; the block-mask coupling is restated in numpy."""
+
+    def __init__(self, S, F, H=16, B=3, L=1, weights=None):
+        self.S, self.F, self.D = int(S), int(F), int(S) + int(F)
+        self.fast = NVP(F, H, B, L)
+        self.slow = NVP(S, H, B, L)
+        D, Hc = self.D, 64
+        self.cshapes = [(Hc, D), (Hc,), (Hc, Hc), (Hc,), (D, Hc), (D,)]
+        self.n = self.fast.n + self.slow.n + 2 * sum(int(np.prod(s)) for s in self.cshapes)
+        if weights is not None:
+            self.load(weights)
+
+    def load(self, w):
+        w = _f32(w)
+        assert w.size == self.n
+        self.fast.w[:] = w[:self.fast.n]
+        self.slow.w[:] = w[self.fast.n:self.fast.n + self.slow.n]
+        off = self.fast.n + self.slow.n
+        self.c = {}
+        for net in ('scale', 'translate'):
+            self.c[net] = []
+            for shp in self.cshapes:
+                k = int(np.prod(shp))
+                self.c[net].append(w[off:off + k].reshape(shp))
+                off += k
+
+    def _mlp(self, net, m, act, dt):
+        W0, b0, W1, b1, W2, b2 = [a.astype(dt) for a in self.c[net]]
+        f = np.tanh if act == 'tanh' else (lambda v: np.maximum(v, 0))
+        h = f(m @ W0.T + b0)
+        h = f(h @ W1.T + b1)
+        return h @ W2.T + b2
+
+    def _coupling(self, y, inverse, dt):
+        """CouplingLayer.forward / inverse (networks.py:289-309) with the slow|fast block mask"""
+        mask = np.concatenate([np.ones(self.S), np.zeros(self.F)]).astype(dt)
+        m = y * mask
+        ls = self._mlp('scale', m, 'tanh', dt) * (1 - mask)
+        t = self._mlp('translate', m, 'relu', dt) * (1 - mask)
+        if inverse:
+            return (y - t) * np.exp(-ls), -ls.sum(-1)
+        return y * np.exp(ls) + t, ls.sum(-1)
+
+    def forward(self, x, f64=False):
+        dt = np.float64 if f64 else np.float32
+        x = np.atleast_2d(x).astype(dt)
+        s, lds = self.slow.forward(x[:, :self.S], f64=f64)
+        f, ldf = self.fast.forward(x[:, self.S:], f64=f64)
+        z, ldc = self._coupling(np.concatenate([s, f], 1).astype(dt), False, dt)
+        return z, lds + ldf + ldc
+
+    def inverse(self, z, f64=False):
+        dt = np.float64 if f64 else np.float32
+        y, ldc = self._coupling(np.atleast_2d(z).astype(dt), True, dt)
+        s, lds = self.slow.inverse(y[:, :self.S], f64=f64)
+        f, ldf = self.fast.inverse(y[:, self.S:], f64=f64)
+        return np.concatenate([s, f], 1), ldc + lds + ldf
+
+    def log_probs(self, x, f64=False):
+        z, ld = self.forward(x, f64=f64)
+        return -0.5 * np.sum(z * z, axis=1) - 0.5 * self.D * np.log(2 * np.pi) + ld

@@ -352,3 +352,27 @@ def test_generalised_normal_base(path):
         assert rel(lp, g['lp0']) < tol and rel(lp64, g['lp0']) < tol
         _, loss = o.log_probs(data)
         assert abs(loss - g['losses'][0]) < max(3e-5, tol) * (1 + abs(g['losses'][0]))
+
+
+FS_FILES = sorted(glob.glob(os.path.join(G, 'fastslow_*.npz')))
+
+
+@pytest.mark.parametrize('path', FS_FILES, ids=[os.path.basename(p)[9:-4] for p in FS_FILES])
+def test_fast_slow_nvp(path):
+    """FastSlowNVP (networks.py:86-150, :350-380): passes on the initial and on a trained state; a move of the fast latent block
+    leaves the slow physical coordinates exactly unchanged (tests/test_flows.py:107-113)"""
+    g = np.load(path)
+    S, F = int(g['S']), int(g['F'])
+    x = g['x']
+    for tag in ('init', 'trained'):
+        o = orc.FastSlowNVP(S, F, 16, 3, 1, g['w_' + tag])
+        assert o.n == g['w_' + tag].size
+        z, ld = o.forward(x)
+        assert rel(z, g['z_' + tag]) < 2e-5 and rel(ld, g['ldf_' + tag]) < 2e-5
+        xb, ldi = o.inverse(g['z_' + tag])
+        assert rel(xb, g['xb_' + tag]) < 2e-5 and rel(ldi, g['ldi_' + tag]) < 2e-5
+        assert rel(o.log_probs(x), g['lp_' + tag]) < 3e-5
+        dz = np.zeros_like(z)
+        dz[:, S:] = 0.01 * np.random.RandomState(0).normal(size=(z.shape[0], F))
+        xp, _ = o.inverse(z + dz)
+        assert np.array_equal(xp[:, :S], o.inverse(z)[0][:, :S]) and not np.array_equal(xp[:, S:], o.inverse(z)[0][:, S:])
