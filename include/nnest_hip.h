@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 6
+#define NNEST_HIP_ABI_VERSION 7
 
 enum {
     NNEST_OK = 0,
@@ -242,6 +242,10 @@ int nnest_spline_loss_grad(nnest_spline_t *spl, const float *x_dev, int M, float
  * (six small launches per minibatch, one read-back per epoch): losses_host [max_epochs,2] and result_host are HOST
  * pointers, the best-validation weights are restored on return and the call synchronises `stream`.  The Adam moments
  * persist across calls like torch.optim.Adam's state. */
+/* the spline flow as one stage of a composite model (FastSlowSpline, networks.py:718-731): as nnest_nvp_vjp / nnest_nvp_adam_step */
+int nnest_spline_vjp(nnest_spline_t *spl, const float *x_dev, const float *gz_dev, float gld, int M, float *grad_dev, float *gx_dev,
+                     void *stream);
+int nnest_spline_adam_step(nnest_spline_t *spl, const float *grad_dev, float lr, float weight_decay, void *stream);
 int nnest_spline_train(nnest_spline_t *spl, const float *xtrain_dev, int n_train, const float *xvalid_dev, int n_valid,
                        const int *perm_dev, const float *noise_dev, uint64_t seed, float jitter, int batch, int max_epochs,
                        int patience, float lr, float weight_decay, float *losses_host, nnest_train_result_t *result_host,

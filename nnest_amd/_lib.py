@@ -89,6 +89,8 @@ SIGNATURES = {
     'nnest_spline_inverse_loglike': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     'nnest_spline_mh_constrained_steps': [_vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i, _i, _vp, _vp, _u64, _u64,
                                           _vp, _vp, _vp, _vp, _vp, _vp],
+    'nnest_spline_vjp': [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
+    'nnest_spline_adam_step': [_vp, _vp, _f, _f, _vp],
     'nnest_spline_actnorm_init': [_vp, _vp, _i, _vp],
     'nnest_spline_loss_grad': [_vp, _vp, _i, _vp, _vp, _vp],
     'nnest_spline_train': [_vp, _vp, _i, _vp, _i, _vp, _vp, _u64, _f, _i, _i, _i, _f, _f, _vp, _vp, _vp],

@@ -159,7 +159,8 @@ __global__ void spl_timage_kernel(const float *__restrict__ w, const float *__re
 }
 
 // ---- 3: forward / backward ----------------------------------------------------------------------------------------
-enum { SPL_MODE_GRAD = 0, SPL_MODE_LOSS = 1 };
+// VJP: the flow as one stage of a composite model: upstream gradient gz and dL/d(logdet) in, dL/dw and gx = dL/dx out
+enum { SPL_MODE_GRAD = 0, SPL_MODE_LOSS = 1, SPL_MODE_VJP = 2 };
 
 struct SplGradArgs {
     const float *timg;
@@ -177,6 +178,9 @@ struct SplGradArgs {
     float *partial;     // [tiles][gw_floats]
     float *stash;       // [tiles][B][2 NTh][64] f32x4
     int mode;
+    const float *gz;    // VJP: upstream gradient [M, D]
+    float *gx;          // VJP: gradient wrt the input rows [M, D]
+    float gld_in;       // VJP: dL/d(logdet)
     int rows_per_tile;  // 16, 8 or 4: a minibatch is only 100 rows, so the tiles are made shallower to spread them over
                         // more waves / CUs (the matrix-core columns of the unused walkers idle; the launch is latency-bound)
 };
@@ -476,7 +480,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     for (int b = 0; b < B; ++b) {
         const float *blk = a.timg + (size_t)b * ts.tblk_floats;
         const float *pb = a.w + (size_t)b * s.blk_params;
-        if (a.mode == SPL_MODE_GRAD) {
+        if (a.mode != SPL_MODE_LOSS) {
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -491,7 +495,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         spl_matmul<NTh>(blk, lane, av, c);
         const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
         ld += spl_coupling<NTh, NH, false, TEAM>(f1, s.SU, s.nu, s.tail, lane, c[0], c[1], wv, xch);
-        if (a.mode == SPL_MODE_GRAD) {  // upper' conditions the second coupling: kept for the backward pass
+        if (a.mode != SPL_MODE_LOSS) {  // upper' conditions the second coupling: kept for the backward pass
 #pragma unroll
             for (int t = 0; t < NTh; ++t) stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
         }
@@ -524,12 +528,18 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     if (a.mode == SPL_MODE_LOSS) return;
 
     // ---- backward: loss = -mean(log_probs)  (trainer.py:394) ---------------------------------------------------------
-    const float invM = 1.0f / (float)a.mtot, gld = -invM;
+    const float invM = 1.0f / (float)a.mtot, gld = a.mode == SPL_MODE_VJP ? a.gld_in : -invM;
     f32x4 gs[2][NTh];
+    if (a.mode == SPL_MODE_VJP) {
+        f32x4 gp4[2][NTh];
+        load_tile<NTh>(a.gz, row, ok, D, lane, gp4);
+        spl_from_parity<NTh>(buf, D, s.nl, lane, gp4, gs);
+    } else {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int t = 0; t < NTh; ++t) gs[c][t] = ok ? base_dE4(xs[c][t], s.base_beta) * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NTh; ++t) gs[c][t] = ok ? base_dE4(xs[c][t], s.base_beta) * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     for (int b = B - 1; b >= 0; --b) {
         const float *blk = a.timg + (size_t)b * ts.tblk_floats;
         const float *pb = a.w + (size_t)b * s.blk_params;
@@ -602,11 +612,17 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
                 gs[hf][t] = gx;
             }
     }
+    if (a.mode == SPL_MODE_VJP) {
+        f32x4 gp4[2][NTh];
+        spl_to_parity<NTh>(buf, D, s.nl, lane, gs, gp4);
+        if (wv == 0) store_tile<NTh>(a.gx, row, ok, D, lane, gp4);
+    }
 }
 
 // ---- 4: reduce ------------------------------------------------------------------------------------------------------
 __global__ void spl_reduce_kernel(const float *__restrict__ partial, int tiles, SplTrainShape ts, const float *__restrict__ w,
-                                  float *__restrict__ grad, float *__restrict__ gwsum, float *__restrict__ loss_out, float loss_scale) {
+                                  float *__restrict__ grad, float *__restrict__ gwsum, float *__restrict__ loss_out, float loss_scale,
+                                  float ldw /* sum over rows of dL/d(logdet): -1 for loss = -mean(log_probs) */) {
     const int np = ts.s.num_params, D = ts.s.D, n = ts.gw_floats;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float acc = 0.f;
@@ -614,7 +630,7 @@ __global__ void spl_reduce_kernel(const float *__restrict__ partial, int tiles, 
             const int o = i % ts.s.blk_params;
             if (o >= ts.p_L && o < ts.p_f[0]) continue;  // L, S, U: from dLoss/dW (spl_lu_grad_kernel)
             for (int t = 0; t < tiles; ++t) acc += partial[(size_t)t * n + i];
-            if (o < ts.p_t) acc -= 1.0f;  // d(-mean sum(s))/ds
+            if (o < ts.p_t) acc += ldw;  // logdet of ActNorm = sum(s) on every row
             grad[i] = acc;
         } else if (i < np + ts.s.B * D * D) {
             for (int t = 0; t < tiles; ++t) acc += partial[(size_t)t * n + i];
@@ -628,7 +644,7 @@ __global__ void spl_reduce_kernel(const float *__restrict__ partial, int tiles, 
 
 // ---- 5: W = (P Lm) Um  ->  L, S, U -------------------------------------------------------------------------------------
 __global__ void spl_lu_grad_kernel(const float *__restrict__ w, const int *__restrict__ pi_inv, const int *__restrict__ pi,
-                                   const float *__restrict__ gwsum, float *__restrict__ grad, SplTrainShape ts) {
+                                   const float *__restrict__ gwsum, float *__restrict__ grad, SplTrainShape ts, float ldw) {
     const int D = ts.s.D, per = 2 * D * D, n = ts.s.B * per;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
         const int b = idx / per, o = idx % per;
@@ -654,7 +670,7 @@ __global__ void spl_lu_grad_kernel(const float *__restrict__ w, const int *__res
                     acc += gW[(size_t)i * D + j] * l;
                 }
             if (k < j) gb[ts.p_U + k * D + j] = acc;
-            else if (k == j) { gb[ts.p_S + k] = acc - 1.0f / Sp[k]; gb[ts.p_U + k * D + j] = 0.f; }  // d(-mean sum log|S|)/dS
+            else if (k == j) { gb[ts.p_S + k] = acc + ldw / Sp[k]; gb[ts.p_U + k * D + j] = 0.f; }  // logdet of the conv = sum log|S| on every row
             else gb[ts.p_U + k * D + j] = 0.f;
         }
     }
@@ -914,10 +930,46 @@ int nnest_spline_loss_grad(nnest_spline_t *h, const float *x_dev, int M, float *
     SHIP_TRY(launch_grad(a, st));
     const int tiles = grad_tiles(a);
     hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, grad_dev, h->gwsum, loss_dev,
-                       -1.0f / (float)M);
-    hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts);
+                       -1.0f / (float)M, -1.0f);
+    hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts, -1.0f);
     SHIP_TRY(hipGetLastError());
     return NNEST_OK;
+}
+
+int nnest_spline_vjp(nnest_spline_t *h, const float *x_dev, const float *gz_dev, float gld, int M, float *grad_dev, float *gx_dev,
+                     void *stream) {
+    if (!h || !x_dev || !gz_dev || !grad_dev || !gx_dev) return spline_fail(NNEST_E_ARG, "NULL argument");
+    if (M < 1) return spline_fail(NNEST_E_ARG, "M=%d", M);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_train_state(h, M > 128 ? M : 128, st);
+    if (rc) return rc;
+    const SplTrainShape ts = make_train_shape(h->s);
+    if ((rc = build_timage(h, ts, st))) return rc;
+    SplGradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = x_dev; a.M = M; a.mtot = M; a.partial = h->partial; a.stash = h->stash;
+    a.mode = SPL_MODE_VJP; a.gz = gz_dev; a.gx = gx_dev; a.gld_in = gld;
+    a.rows_per_tile = rows_per_tile(M);
+    SHIP_TRY(launch_grad(a, st));
+    hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, grad_tiles(a), ts, h->w_dev, grad_dev, h->gwsum,
+                       (float *)nullptr, 0.f, (float)M * gld);
+    hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts,
+                       (float)M * gld);
+    SHIP_TRY(hipGetLastError());
+    return NNEST_OK;
+}
+
+int nnest_spline_adam_step(nnest_spline_t *h, const float *grad_dev, float lr, float weight_decay, void *stream) {
+    if (!h || !grad_dev) return spline_fail(NNEST_E_ARG, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_train_state(h, 128, st);
+    if (rc) return rc;
+    h->adam_step += 1;
+    const double bc1 = 1.0 - pow(0.9, (double)h->adam_step), bc2 = 1.0 - pow(0.999, (double)h->adam_step);
+    hipLaunchKernelGGL(spl_adam_kernel, dim3(256), dim3(256), 0, st, h->w_dev, grad_dev, h->adam_m, h->adam_v, h->s.num_params,
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), weight_decay);
+    SHIP_TRY(hipGetLastError());
+    return sync_to_host(h, st);
 }
 
 int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, const float *xvalid_dev, int n_valid,
@@ -956,8 +1008,8 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             SHIP_TRY(launch_grad(a, st));
             const int tiles = grad_tiles(a);
             hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, h->grad, h->gwsum,
-                               h->losses_dev + mb, -1.0f / (float)M);
-            hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + B * D, h->pi_dev, h->gwsum, h->grad, ts);
+                               h->losses_dev + mb, -1.0f / (float)M, -1.0f);
+            hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + B * D, h->pi_dev, h->gwsum, h->grad, ts, -1.0f);
             h->adam_step += 1;
             const double bc1 = 1.0 - pow(0.9, (double)h->adam_step), bc2 = 1.0 - pow(0.999, (double)h->adam_step);
             hipLaunchKernelGGL(spl_adam_kernel, dim3(256), dim3(256), 0, st, h->w_dev, h->grad, h->adam_m, h->adam_v, np,
@@ -973,7 +1025,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             a.rows_per_tile = rows_per_tile(n_valid);
             SHIP_TRY(launch_grad(a, st));
             hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, grad_tiles(a), ts, h->w_dev, h->grad,
-                               h->gwsum, h->losses_dev + n_mb, -1.0f / (float)n_valid);
+                               h->gwsum, h->losses_dev + n_mb, -1.0f / (float)n_valid, -1.0f);
         }
         SHIP_TRY(hipMemcpyAsync(lh.data(), h->losses_dev, ((size_t)n_mb + 1) * sizeof(float), hipMemcpyDeviceToHost, st));
         SHIP_TRY(hipStreamSynchronize(st));

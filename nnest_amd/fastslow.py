@@ -22,6 +22,12 @@ from .flow import HipNVP, _as_dev_f32
 
 
 class HipFastSlowNVP(object):
+    kind = 'nvp'
+
+    def _make_stages(self, device, seeds):
+        fast = HipNVP(self.F, self.H, self.B, self.L, device=device, seed=seeds[0])
+        slow = HipNVP(self.S, self.H, self.B, self.L, device=device, seed=seeds[1])
+        return fast, slow
 
     def __init__(self, num_fast, num_slow, num_hidden=16, num_blocks=3, num_layers=1, device=None, seed=None):
         self.F, self.S = int(num_fast), int(num_slow)
@@ -32,8 +38,7 @@ class HipFastSlowNVP(object):
             raise _lib.NnestHipError('fast/slow hierarchy: max(num_slow, num_fast) = %d > 16 (the hidden-64 coupling kernel is '
                                      'instantiated for 32 interleaved dimensions)' % self.m)
         seeds = [None] * 3 if seed is None else [int(seed), int(seed) + 1, int(seed) + 2]
-        self.fast = HipNVP(self.F, self.H, self.B, self.L, device=device, seed=seeds[0])
-        self.slow = HipNVP(self.S, self.H, self.B, self.L, device=device, seed=seeds[1])
+        self.fast, self.slow = self._make_stages(device, seeds)
         self.coupling = HipNVP(2 * self.m, 64, 1, 1, device=device, seed=seeds[2])
         self.device = self.fast.device
         self._lib = self.fast._lib
@@ -126,8 +131,8 @@ class HipFastSlowNVP(object):
 
     # ---- weights (reference state_dict order: fast_flow, slow_flow, flow) -----------------------------------------------
     def layer_shapes(self):
-        out = [(n.replace('flow.flows', 'fast_flow.flows', 1), s) for n, s, _ in self.fast.layer_shapes()]
-        out += [(n.replace('flow.flows', 'slow_flow.flows', 1), s) for n, s, _ in self.slow.layer_shapes()]
+        out = [(t[0].replace('flow.flows', 'fast_flow.flows', 1), t[1]) for t in self.fast.layer_shapes()]
+        out += [(t[0].replace('flow.flows', 'slow_flow.flows', 1), t[1]) for t in self.slow.layer_shapes()]
         for net in ('scale_net', 'translate_net'):
             out += [('flow.flows.0.%s.%s' % (net, leaf), shape) for leaf, shape in self._coupling_shapes()]
         return out
@@ -144,11 +149,14 @@ class HipFastSlowNVP(object):
                 sd['flow.flows.0.%s.%s' % (net, leaf)] = torch.from_numpy(np.asarray(ref[net][leaf], np.float32).reshape(shape).copy())
         return sd
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, P=None):
         def arr(v):
             return np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v, dtype=np.float32)
-        self.fast.load_state_dict({k.replace('fast_flow.flows', 'flow.flows', 1): v for k, v in sd.items() if k.startswith('fast_flow.')})
-        self.slow.load_state_dict({k.replace('slow_flow.flows', 'flow.flows', 1): v for k, v in sd.items() if k.startswith('slow_flow.')})
+        extra = ({}, {}) if P is None else ({'P': P['fast']}, {'P': P['slow']})   # spline stages: the 1x1 convs' permutations
+        self.fast.load_state_dict({k.replace('fast_flow.flows', 'flow.flows', 1): v for k, v in sd.items() if k.startswith('fast_flow.')},
+                                  **extra[0])
+        self.slow.load_state_dict({k.replace('slow_flow.flows', 'flow.flows', 1): v for k, v in sd.items() if k.startswith('slow_flow.')},
+                                  **extra[1])
         ref = {net: {leaf: arr(sd['flow.flows.0.%s.%s' % (net, leaf)]) for leaf, _ in self._coupling_shapes()}
                for net in ('scale_net', 'translate_net')}
         self._load_coupling(ref)
@@ -157,7 +165,7 @@ class HipFastSlowNVP(object):
         """the concatenated reference state_dict"""
         return np.concatenate([v.numpy().ravel() for v in self.state_dict().values()]).astype(np.float32)
 
-    def load_packed(self, packed):
+    def load_packed(self, packed, P=None):
         packed = np.asarray(packed, dtype=np.float32)
         sd, off = {}, 0
         for name, shape in self.layer_shapes():
@@ -166,7 +174,7 @@ class HipFastSlowNVP(object):
             off += n
         if off != packed.size:
             raise ValueError('expected %d packed weights, got %d' % (off, packed.size))
-        self.load_state_dict(sd)
+        self.load_state_dict(sd, P)
 
     def used_mask(self):
         """True for the entries of store_packed() that the model's output depends on (the masks never reach the rest)"""
@@ -233,15 +241,16 @@ class HipFastSlowNVP(object):
         M = x.shape[0]
         grad = torch.empty(net.num_params, dtype=torch.float32, device=self.device)
         gx = torch.empty_like(x)
+        fn = self._lib.nnest_nvp_vjp if isinstance(net, HipNVP) else self._lib.nnest_spline_vjp
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.nnest_nvp_vjp(net._h, _lib.ptr(x), _lib.ptr(gz.contiguous()), ctypes.c_float(gld), M, _lib.ptr(grad),
-                                               _lib.ptr(gx), _lib.current_stream(self.device)))
+            _lib.check(fn(net._h, _lib.ptr(x), _lib.ptr(gz.contiguous()), ctypes.c_float(gld), M, _lib.ptr(grad), _lib.ptr(gx),
+                          _lib.current_stream(self.device)))
         return grad, gx
 
     def _adam(self, net, grad, lr, wd):
+        fn = self._lib.nnest_nvp_adam_step if isinstance(net, HipNVP) else self._lib.nnest_spline_adam_step
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.nnest_nvp_adam_step(net._h, _lib.ptr(grad), ctypes.c_float(lr), ctypes.c_float(wd),
-                                                     _lib.current_stream(self.device)))
+            _lib.check(fn(net._h, _lib.ptr(grad), ctypes.c_float(lr), ctypes.c_float(wd), _lib.current_stream(self.device)))
 
     def loss_grad(self, x):
         """loss = -mean(log_probs(x)) and its gradient in the three stages' packed layouts (fast, slow, coupling)"""
@@ -293,6 +302,7 @@ class HipFastSlowNVP(object):
         losses = np.zeros((max(max_epochs, 1), 2), np.float32)
         best, best_epoch, counter, stopped, epochs_run = float('inf'), 0, 0, False, 0
         best_w = self.store_packed()
+        keep_P = getattr(self, 'P', None)
         for epoch in range(max_epochs):
             tot = 0.0
             for b0 in range(0, n_train, batch):
@@ -316,6 +326,37 @@ class HipFastSlowNVP(object):
             if counter > patience:
                 stopped = True
                 break
-        self.load_packed(best_w)
+        self.load_packed(best_w, keep_P)
+        if keep_P is not None:
+            self.fast.data_dep_init_done = self.slow.data_dep_init_done = True
         return dict(losses=torch.from_numpy(losses), epochs_run=epochs_run, best_epoch=best_epoch, best_validation_loss=best,
                     last_train_loss=float(losses[max(epochs_run - 1, 0), 0]), counter=counter, stopped=stopped, result=None)
+
+
+class HipFastSlowSpline(HipFastSlowNVP):
+    """FastSlowSpline (nnest/networks.py:718-731): as above with neural-spline stages -- the fast stage always with hidden
+    width 16 (networks.py:722), the slow stage with `hidden_dim` -- and the same hidden-64 NVP coupling on top."""
+    kind = 'spline'
+
+    def _make_stages(self, device, seeds):
+        from .spline import HipSpline
+        fast = HipSpline(self.F, 16, self.B, device=device, seed=seeds[0])
+        slow = HipSpline(self.S, self.H, self.B, device=device, seed=seeds[1])
+        return fast, slow
+
+    def __init__(self, num_fast, num_slow, hidden_dim=16, num_blocks=3, device=None, seed=None):
+        if num_fast < 2 or num_slow < 2:
+            raise ValueError('NSF_CL needs at least 2 dimensions per block (networks.py:565-574)')
+        super().__init__(num_fast, num_slow, hidden_dim, num_blocks, 1, device=device, seed=seed)
+
+    @property
+    def P(self):
+        return {'fast': self.fast.P, 'slow': self.slow.P}
+
+    @property
+    def data_dep_init_done(self):
+        return self.fast.data_dep_init_done and self.slow.data_dep_init_done
+
+    @data_dep_init_done.setter
+    def data_dep_init_done(self, value):
+        self.fast.data_dep_init_done = self.slow.data_dep_init_done = bool(value)

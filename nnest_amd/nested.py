@@ -103,7 +103,8 @@ class NestedSampler(Sampler):
         netG = self.trainer.netG
         w = self._broadcast(netG.store_packed(), src=0)
         if hasattr(netG, 'P'):  # spline flow: the fixed permutations of the 1x1 convs are not part of the weights
-            P = self._broadcast(netG.P, src=0)
+            P = netG.P
+            P = {k: self._broadcast(v, src=0) for k, v in P.items()} if isinstance(P, dict) else self._broadcast(P, src=0)
             if self.mpi_rank != 0:
                 netG.load_packed(w, P)
                 netG.data_dep_init_done = True

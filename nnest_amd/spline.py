@@ -134,6 +134,8 @@ class HipSpline(_HipFlow):
         return sd
 
     def load_state_dict(self, sd, P=None):
+        if P is None:
+            P = self.P   # keep the permutations already loaded
         self.load_packed(np.concatenate([np.asarray(sd[name].detach().cpu().numpy() if torch.is_tensor(sd[name])
                                                     else sd[name], dtype=np.float32).ravel()
                                          for name, _ in self.layer_shapes()]), P)

@@ -51,8 +51,6 @@ class Trainer(object):
         self.flow = flow.lower()
         if num_slow != 0:
             assert x_dim > num_slow                      # trainer.py:79
-            if flow.lower() != 'nvp':
-                raise NotImplementedError("num_slow > 0 is implemented for flow='nvp' (FastSlowNVP); FastSlowSpline is not")
             if scale not in ('', None) or base_dist is not None:
                 raise NotImplementedError('num_slow > 0 with a scale variant or a non-default base distribution')
         scale = '' if scale is None else scale
@@ -86,7 +84,10 @@ class Trainer(object):
         self.num_slow = num_slow
         self.learning_rate = learning_rate
         self.weight_decay = weight_decay
-        if self.flow == 'spline':    # SingleSpeedSpline(x_dim, hidden_dim, num_blocks, tail_bound=3)  (trainer.py:97-98)
+        if self.flow == 'spline' and num_slow > 0:   # FastSlowSpline(num_fast, num_slow, hidden_dim, num_blocks)  (trainer.py:93-95)
+            from .fastslow import HipFastSlowSpline
+            self.netG = HipFastSlowSpline(x_dim - num_slow, num_slow, hidden_dim, num_blocks, device=self.gpu, seed=seed)
+        elif self.flow == 'spline':  # SingleSpeedSpline(x_dim, hidden_dim, num_blocks, tail_bound=3)  (trainer.py:97-98)
             from .spline import HipSpline
             self.netG = HipSpline(x_dim, hidden_dim, num_blocks, num_bins=8, tail_bound=3.0, device=self.gpu, seed=seed)
         elif num_slow > 0:           # FastSlowNVP(num_fast, num_slow, hidden_dim, num_blocks, num_layers)  (trainer.py:86-88)
@@ -102,11 +103,15 @@ class Trainer(object):
             sd = torch.load(os.path.join(self.path, 'models', 'netG.pt'))
             if self.flow == 'spline':
                 # the 1x1 convs' permutations are not in the reference's state_dict (networks.py:634-635); this build
-                # writes them beside it (netG_P.npy).  A loaded model counts as initialised (stated deviation: the
+                # writes them beside it (netG_P.npz).  A loaded model counts as initialised (stated deviation: the
                 # reference would re-run ActNorm's data-dependent init on the first forward batch and discard the
                 # loaded s, t).
-                pfile = os.path.join(self.path, 'models', 'netG_P.npy')
-                self.netG.load_state_dict(sd, np.load(pfile) if os.path.exists(pfile) else None)
+                pfile = os.path.join(self.path, 'models', 'netG_P.npz')
+                P = None
+                if os.path.exists(pfile):
+                    P = dict(np.load(pfile))
+                    P = P['P'] if 'P' in P else P
+                self.netG.load_state_dict(sd, P)
                 self.netG.data_dep_init_done = True
             else:
                 self.netG.load_state_dict(sd)
@@ -193,7 +198,8 @@ class Trainer(object):
         if self.path:
             torch.save(self.netG.state_dict(), os.path.join(self.path, 'models', 'netG.pt'))
             if self.flow == 'spline':
-                np.save(os.path.join(self.path, 'models', 'netG_P.npy'), self.netG.P)
+                P = self.netG.P
+                np.savez(os.path.join(self.path, 'models', 'netG_P.npz'), **(P if isinstance(P, dict) else {'P': P}))
         self.logger.info('Best epoch [%i] validation loss [%5.4f] train time (s) [%5.4f]]'
                          % (self.best_validation_epoch, self.best_validation_loss, time.time() - start_time))
 

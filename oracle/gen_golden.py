@@ -645,8 +645,63 @@ def gen_fastslow():
         print('G11 fastslow', S, F, 'nparams', out['w0'].size, 'loss0', out['losses'][0], list(out['keys'][-6:]))
 
 
+# ----------------------------------------------------------------------------------------------
+# G12: FastSlowSpline (networks.py:718-731): spline stages (fast: hidden 16 always) + the hidden-64 NVP coupling
+# ----------------------------------------------------------------------------------------------
+def gen_fastslow_spline():
+    for S, F in [(2, 3), (5, 4)]:
+        D = S + F
+        np.random.seed(0)
+        torch.manual_seed(13)
+        t = Trainer(D, num_slow=S, hidden_dim=16, num_blocks=3, flow='spline', log_dir=None, learning_rate=1e-3,
+                    log_level=logging.WARNING)
+        out = {'S': S, 'F': F, 'D': D, 'H': 16, 'B': 3, 'keys': np.array(list(t.netG.state_dict().keys())),
+               'P_fast': np.stack([f.P.numpy() for f in t.netG.fast_flow.flows if hasattr(f, 'P')]).astype(np.float32),
+               'P_slow': np.stack([f.P.numpy() for f in t.netG.slow_flow.flows if hasattr(f, 'P')]).astype(np.float32)}
+        out['w_raw'] = pack_state_dict(t.netG)
+        x_first = np.random.uniform(-1, 1, size=(100, D)).astype(np.float32)
+        zf_, ldf_ = t.forward(x_first, to_numpy=True)     # ActNorm data-dependent init of both stages
+        out.update(x_first=x_first, z_first=zf_, ld_first=ldf_, w_init=pack_state_dict(t.netG))
+        x = np.random.uniform(-1, 1, size=(64, D)).astype(np.float32)
+        n, jitter = 230, 0.02
+        X = np.random.uniform(-1, 1, size=(n, D)).astype(np.float32)
+        torch.manual_seed(11)
+        perms, noises = [], []
+        for e in range(2):
+            pp, nz = replay_loader_rng(n, 100, D)
+            perms.append(pp)
+            noises.append(nz)
+        for tag in ('init', 'trained'):
+            if tag == 'trained':
+                opt = torch.optim.Adam(t.netG.parameters(), lr=1e-3, weight_decay=1e-6)
+                losses, grads, ws = [], [], []
+                Xt = torch.from_numpy(X)
+                for e in range(2):
+                    for b in range(0, n, 100):
+                        idx = torch.from_numpy(perms[e][b:b + 100].astype(np.int64))
+                        data = Xt[idx] + jitter * torch.from_numpy(noises[e][b:b + 100])
+                        opt.zero_grad()
+                        loss = -t.netG.log_probs(data).mean()
+                        loss.backward()
+                        grads.append(pack_grads(t.netG))
+                        opt.step()
+                        losses.append(loss.item())
+                        ws.append(pack_state_dict(t.netG))
+                out.update(X=X, jitter=jitter, perms=np.stack(perms), noises=np.stack(noises), losses=np.array(losses),
+                           grads=np.stack(grads[:2]), ws=np.stack([ws[0], ws[-1]]))
+            z, ldz = t.forward(x, to_numpy=True)
+            xb, ldi = t.inverse(z, to_numpy=True)
+            out.update({'x': x, 'w_' + tag: pack_state_dict(t.netG), 'z_' + tag: z, 'ldf_' + tag: ldz, 'xb_' + tag: xb,
+                        'ldi_' + tag: ldi, 'lp_' + tag: t.log_probs(x, to_numpy=True)})
+        np.savez_compressed(os.path.join(OUT, 'fastslowspline_s%d_f%d.npz' % (S, F)), **out)
+        print('G12 fastslow spline', S, F, 'nparams', out['w_raw'].size, 'loss0', out['losses'][0])
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested', 'scale', 'spline', 'base', 'fastslow']
+    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested', 'scale', 'spline', 'base', 'fastslow',
+                             'fastslowspline']
+    if 'fastslowspline' in which:
+        gen_fastslow_spline()
     if 'fastslow' in which:
         gen_fastslow()
     if 'base' in which:
