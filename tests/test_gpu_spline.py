@@ -288,3 +288,41 @@ def test_trainer_spline_save_and_load_model(hip, tmp_path):
     t2 = Trainer(4, log_dir=str(tmp_path), load_model='run', log_level=30)
     assert np.array_equal(cpu(t2.log_probs(x)), lp) and np.array_equal(cpu(t2.get_latent_samples(x)), z)
     assert t.best_validation_epoch >= 1 and t.losses.shape == (5, 2)
+
+
+@pytest.mark.parametrize('D,H', [(70, 16), (100, 16), (33, 32), (64, 32)])
+def test_wider_shapes_vs_oracle(hip, D, H):
+    """the other instantiated tile shapes (3 and 4 tiles per half at hidden 16, 2 at hidden 32) against the oracle: passes,
+    ActNorm initialisation, loss, gradient (finite differences of the oracle's float64 loss + linearity over batches)"""
+    sp = hip.HipSpline(D, H, 2, seed=D)
+    w, P = sp.store_packed(), sp.P
+    rng = np.random.RandomState(D)
+    x0 = rng.uniform(-1, 1, size=(90, D)).astype(np.float32)
+    o = orc.Spline(D, H, 2, 8, 3.0, w, P)
+    z, ld = sp.forward(x0)                       # data-dependent init on both sides
+    zo, ldo = o.forward(x0, data_init=True)
+    assert rel(cpu(z), zo) < 5e-5 and rel(cpu(ld), ldo) < 5e-5
+    assert np.max(np.abs(sp.store_packed() - o.w)) < 5e-5
+    o.w[:] = sp.store_packed()
+    x = rng.uniform(-1, 1, size=(50, D)).astype(np.float32)
+    z, ld = sp.forward(x)
+    z64, ld64 = o.forward(x, f64=True)
+    assert rel(cpu(z), z64) < 1e-5 and rel(cpu(ld), ld64) < 1e-5
+    zs = (0.8 * rng.randn(40, D)).astype(np.float32)
+    xi, ldi = sp.inverse(zs)
+    xi64, ldi64 = o.inverse(zs, f64=True)
+    assert rel(cpu(xi), xi64) < 2e-5 and rel(cpu(ldi), ldi64) < 2e-5
+    loss, grad = sp.loss_grad(x)
+    lo = o.log_probs(x, f64=True)[1]
+    assert abs(float(loss) - lo) < 3e-5 * (1 + abs(lo))
+    gr = cpu(grad).astype(np.float64)
+    idx = rng.choice(np.argsort(-np.abs(gr))[:400], 8, replace=False)
+    fd = o.fd_grad(x, idx)
+    assert np.median(np.abs(fd - gr[idx])) < 5e-3 * np.max(np.abs(gr))
+    ga, gb = cpu(sp.loss_grad(x[:20])[1]).astype(np.float64), cpu(sp.loss_grad(x[20:])[1]).astype(np.float64)
+    assert np.max(np.abs(20 * ga + 30 * gb - 50 * gr)) < 2e-4 * 50 * np.max(np.abs(gr))
+    # a short training run moves the loss down
+    perms = torch.stack([torch.randperm(80) for _ in range(4)]).int()
+    res = sp.train_epochs(x0[:80], x0[80:], perms, None, seed=1, jitter=0.01, batch=100, max_epochs=4, patience=50)
+    l = res['losses'].numpy()
+    assert np.all(np.isfinite(l)) and l[-1, 0] < l[0, 0]
