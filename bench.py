@@ -28,7 +28,7 @@ import torch  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
-MEASURED_TRAFFIC_BYTES = int((439.2 + 1384.7) * 1024)  # profiles/r01b/bench_pmc_summary.txt, per K4 launch
+MEASURED_TRAFFIC_BYTES = int((452.2 + 1384.7) * 1024)  # profiles/r01d/bench_pmc_summary.txt, per K4 launch
 
 
 def useful_flops_per_eval(D, H, B, L):
@@ -165,7 +165,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved_tflops, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved_tflops / FP32_PEAK_TFLOPS,
                          # HBM bytes per launch from the committed rocprofv3 PMC passes of this command
-                         # (profiles/r01b/bench_pmc_summary.txt: FETCH_SIZE 439.2 KiB + WRITE_SIZE 1384.7 KiB, raw); only
+                         # (profiles/r01d/bench_pmc_summary.txt: FETCH_SIZE 452.2 KiB + WRITE_SIZE 1384.7 KiB, raw); only
                          # valid for the default workload, null otherwise
                          'traffic': MEASURED_TRAFFIC_BYTES if (D, C, S) == (50, 1000, 250) else None,
                          'kernel': 'mh_kernel_team' if (C + 15) // 16 <= info['num_cu'] else 'mh_kernel',
