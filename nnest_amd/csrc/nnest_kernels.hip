@@ -456,11 +456,15 @@ __global__ void __launch_bounds__(64) mh_kernel_reg(MhArgs a) {
 // block through LDS (each wave publishes its ls / t tiles, one barrier, each reads the other's and applies the
 // same affine update, so both hold bit-identical state), and the noise leaves the critical path.  Waves 0 and 1
 // evaluate prior / likelihood / accept redundantly on identical values; wave 0 writes the results.
-template <int NT, int L, int B>
+// WREG: this wave's fragments live in its registers (x_dim <= 64); otherwise (3-4 tiles per class: the proposal state alone
+// takes ~160 VGPRs) they are read from a copy of the image in LDS -- the split over three waves stays.
+template <int NT, int L, int B, bool WREG = (NT <= 2)>
 struct TeamInverse {
     typedef FragCount<NT, 1, L> FC;
     static constexpr int NBIAS = 16 * (1 + L) + 16 * NT;
-    RegFrags<FC::N> w[B];  // this wave's net only
+    RegFrags<WREG ? FC::N : 1> w[B];  // this wave's net only
+    const float *wl;       // !WREG: LDS image + lane
+    int net_floats;
     const float *bias;     // LDS [b][net][NBIAS]
     f32x4 *xch;            // LDS [parity][net][NT][64 lanes]
     int lane, role;
@@ -477,12 +481,23 @@ struct TeamInverse {
             unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
             (void)s0; (void)s1; (void)s2; (void)s3;
             STAMP(s0);
-            if (b & 1) {
-                if (role == 0) mlp_core<NT, 1, L, 0>(w[b], nb, xs[0], mine);
-                else           mlp_core<NT, 1, L, 1>(w[b], nb, xs[0], mine);
+            if constexpr (WREG) {
+                if (b & 1) {
+                    if (role == 0) mlp_core<NT, 1, L, 0>(w[b], nb, xs[0], mine);
+                    else           mlp_core<NT, 1, L, 1>(w[b], nb, xs[0], mine);
+                } else {
+                    if (role == 0) mlp_core<NT, 1, L, 0>(w[b], nb, xs[1], mine);
+                    else           mlp_core<NT, 1, L, 1>(w[b], nb, xs[1], mine);
+                }
             } else {
-                if (role == 0) mlp_core<NT, 1, L, 0>(w[b], nb, xs[1], mine);
-                else           mlp_core<NT, 1, L, 1>(w[b], nb, xs[1], mine);
+                const ImageFrags fr = {wl + (size_t)(b * 2 + role) * net_floats};
+                if (b & 1) {
+                    if (role == 0) mlp_core<NT, 1, L, 0>(fr, nb, xs[0], mine);
+                    else           mlp_core<NT, 1, L, 1>(fr, nb, xs[0], mine);
+                } else {
+                    if (role == 0) mlp_core<NT, 1, L, 0>(fr, nb, xs[1], mine);
+                    else           mlp_core<NT, 1, L, 1>(fr, nb, xs[1], mine);
+                }
             }
             f32x4 *slot = xch + (size_t)((b & 1) * 2) * NT * 64;  // double-buffered by block parity
             STAMP(s1);
@@ -524,6 +539,8 @@ struct LdsNoise {
 template <int NT, int L, int B, bool DBG>
 __global__ void __launch_bounds__(192, 2) mh_kernel_team(MhArgs a) {  // min 2 waves/SIMD: <= 256 VGPRs, MFMA results stay in VGPRs
     typedef TeamInverse<NT, L, B> TI;
+    constexpr bool WREG = NT <= 2;
+    extern __shared__ __attribute__((aligned(16))) float team_img[];  // !WREG: the fragment image
     __shared__ __attribute__((aligned(16))) float bias_lds[B * 2 * TI::NBIAS];
     __shared__ __attribute__((aligned(16))) f32x4 xch[2 * 2 * NT * 64];
     __shared__ float nbuf[2 * NT * 8 * 64];
@@ -535,6 +552,7 @@ __global__ void __launch_bounds__(192, 2) mh_kernel_team(MhArgs a) {  // min 2 w
         int bn = i / TI::NBIAS, o = i - bn * TI::NBIAS;
         bias_lds[i] = a.img[(size_t)bn * net_floats + frag_off_b1(NT, 1, L) + o];
     }
+    if (!WREG) stage_image(team_img, a.img, a.s.image_floats);
     __syncthreads();
     if (role == 2) {  // noise producer: S+1 buffers, each published by the barrier the consumers wait on
         XoshiroNoise<NT> gen;
@@ -564,11 +582,15 @@ __global__ void __launch_bounds__(192, 2) mh_kernel_team(MhArgs a) {  // min 2 w
 #ifdef NNEST_STAMP
     inv.t_mlp = inv.t_xch = inv.t_upd = 0;
 #endif
+    inv.wl = team_img + lane;
+    inv.net_floats = net_floats;
+    if constexpr (WREG) {
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const float *src = a.img + (size_t)(b * 2 + role) * net_floats;
+        for (int b = 0; b < B; ++b) {
+            const float *src = a.img + (size_t)(b * 2 + role) * net_floats;
 #pragma unroll
-        for (int i = 0; i < TI::FC::N; ++i) inv.w[b].v[i] = src[i * 64 + lane];
+            for (int i = 0; i < TI::FC::N; ++i) inv.w[b].v[i] = src[i * 64 + lane];
+        }
     }
     LdsNoise<NT> noise = {nbuf, ubuf, lane, 0};
     mh_body<NT, DBG>(a, tile, lane, inv, noise, role == 0);
@@ -646,14 +668,22 @@ static hipError_t launch_pass_t(const PassArgs &a_in, int num_cu, hipStream_t st
 template <int NT, int NH, int LT>
 static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
     const int ntiles = (a.C + 15) / 16;
-    if constexpr (LT == 1 && NH == 1 && NT <= 2) {  // NT >= 3 would spill: those shapes stay on the image form
+    if constexpr (LT == 1 && NH == 1) {
         if (a.s.B == 3 && ntiles <= num_cu && !a.noise_dz && a.s.scale_mode != 2) {  // fewer tiles than CUs: three waves per tile (team form)
-            if (a.hist_x || a.hist_logl)
-                hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, true>), dim3(ntiles), dim3(192), 0, st, a);
-            else
-                hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, false>), dim3(ntiles), dim3(192), 0, st, a);
+            const size_t timg = NT <= 2 ? 0 : (size_t)a.s.image_floats * 4;  // 3-4 tiles per class: fragments from an LDS image
+            if (a.hist_x || a.hist_logl) {
+                hipError_t e = allow_lds(mh_kernel_team<NT, 1, 3, true>, timg + 48 * 1024);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, true>), dim3(ntiles), dim3(192), timg, st, a);
+            } else {
+                hipError_t e = allow_lds(mh_kernel_team<NT, 1, 3, false>, timg + 48 * 1024);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, false>), dim3(ntiles), dim3(192), timg, st, a);
+            }
             return hipGetLastError();
         }
+    }
+    if constexpr (LT == 1 && NH == 1 && NT <= 2) {  // register form: NT >= 3 would spill
         if (a.s.B == 3 && ntiles <= 4 * num_cu && a.s.scale_mode != 2) {  // one wave per SIMD available; SingleSpeedNVP defaults: hidden_dim 16, num_blocks 3, num_layers 1 (nnest/sampler.py:37-43)
             if (a.noise_dz || a.hist_x || a.hist_logl)
                 hipLaunchKernelGGL((mh_kernel_reg<NT, 1, 1, 3, true>), dim3(ntiles), dim3(64), 0, st, a);
