@@ -557,12 +557,13 @@ __device__ __forceinline__ void block_backward(const TrainArgs &a, float *stg, i
 // ---- the kernel ------------------------------------------------------------------------------------------
 // IMGLDS: the forward and backward fragment images live in LDS next to the staging area (config 2: 2 x 32 KB +
 // 64 KB); otherwise they are read from / updated in global memory (L2).
-template <int NT, int NH, int L, bool IMGLDS>
+// (IMGLDS = 1: only the forward image fits beside the staging area -- 3-4 tiles per class; the transposed image stays in L2)
+template <int NT, int NH, int L, int IMGLDS>
 __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *imgf = IMGLDS ? smem : a.img_fwd;
-    float *imgb = IMGLDS ? smem + a.s.image_floats : a.img_bwd;
-    float *stg = IMGLDS ? smem + 2 * a.s.image_floats : smem;
+    float *imgf = IMGLDS >= 1 ? smem : a.img_fwd;
+    float *imgb = IMGLDS == 2 ? smem + a.s.image_floats : a.img_bwd;
+    float *stg = smem + IMGLDS * a.s.image_floats;
     __shared__ float red[TRAIN_WAVES];
     __shared__ int ctl[4];      // [0] stop flag, [1] counter, [2] best epoch
     __shared__ float ctlf[2];   // [0] best validation loss
@@ -864,7 +865,7 @@ size_t train_workspace_floats(const FlowShape &s, int batch) {
     return (size_t)s.image_floats + (size_t)s.num_params() + 64;
 }
 
-template <int NT, int NH, int L, bool IMGLDS>
+template <int NT, int NH, int L, int IMGLDS>
 static hipError_t launch_train_tt(const TrainArgs &a, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(train_kernel<NT, NH, L, IMGLDS>),
@@ -880,8 +881,10 @@ static hipError_t launch_train_t(const TrainArgs &a, hipStream_t st) {
     typedef StageMap<NT, NH, L> SM;
     const size_t stage = (size_t)SM::count * TRAIN_MAX_ROWS * 16 * sizeof(float);
     const size_t with_img = stage + 2 * (size_t)a.s.image_floats * sizeof(float);
-    if (with_img <= 160 * 1024 - 256) return launch_train_tt<NT, NH, L, true>(a, with_img, st);
-    return launch_train_tt<NT, NH, L, false>(a, stage, st);
+    const size_t with_fwd = stage + (size_t)a.s.image_floats * sizeof(float);
+    if (with_img <= 160 * 1024 - 256) return launch_train_tt<NT, NH, L, 2>(a, with_img, st);
+    if (with_fwd <= 160 * 1024 - 256) return launch_train_tt<NT, NH, L, 1>(a, with_fwd, st);
+    return launch_train_tt<NT, NH, L, 0>(a, stage, st);
 }
 
 static hipError_t dispatch_train(const TrainArgs &a, hipStream_t st) {
