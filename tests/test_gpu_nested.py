@@ -197,3 +197,28 @@ def test_spline_flow_reproduces_published_rosenbrock_10d_evidence(tmp_path):
     assert abs(s.logzerr - 0.193) < 0.03
     assert abs(s.h - 37.226) < 4.0
     assert abs(s.logz - (-43.364)) <= 0.7, s.logz
+
+
+def test_mcmc_sampler_front_end(tmp_path):
+    """MCMCSampler.run (mcmc.py:79-130): train on samples, then unconstrained Metropolis in the latent space; a 2-D
+    correlated Gaussian target must come back with its mean and covariance"""
+    import nnest_amd
+    rng = np.random.RandomState(0)
+    cov = np.array([[1.0, 0.8], [0.8, 1.0]])
+    icov = np.linalg.inv(cov)
+    train = rng.multivariate_normal([1.0, -2.0], cov, size=2000)
+
+    def loglike(x):
+        d = x - np.array([1.0, -2.0])
+        return -0.5 * np.einsum('ni,ij,nj->n', d, icov, d)
+
+    np.random.seed(1)
+    torch.manual_seed(1)
+    s = nnest_amd.MCMCSampler(2, loglike, log_dir=str(tmp_path), log_level=30, flow='nvp')
+    s.run(400, 50, train, init_samples=(train[:50] - train.mean(0)) / train.std(0))
+    assert s.samples.shape == (50, 401, 2) and s.loglikes.shape == (50, 401)
+    flat = s.samples[:, 100:, :].reshape(-1, 2)
+    assert np.all(np.abs(flat.mean(0) - np.array([1.0, -2.0])) < 0.25)
+    c = np.cov(flat.T)
+    assert abs(c[0, 0] - 1) < 0.3 and abs(c[1, 1] - 1) < 0.3 and abs(c[0, 1] - 0.8) < 0.3
+    assert s.total_calls == 50 * 400 + 50   # the initial likelihoods of the chains count too (sampler.py:268-270)
