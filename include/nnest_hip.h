@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 7
+#define NNEST_HIP_ABI_VERSION 8
 
 enum {
     NNEST_OK = 0,
@@ -250,6 +250,24 @@ int nnest_spline_train(nnest_spline_t *spl, const float *xtrain_dev, int n_train
                        const int *perm_dev, const float *noise_dev, uint64_t seed, float jitter, int batch, int max_epochs,
                        int patience, float lr, float weight_decay, float *losses_host, nnest_train_result_t *result_host,
                        void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * 'choleksy' flow: SingleSpeedCholeksy(num_inputs=D) (networks.py:162-239): y = L x + b, L lower triangular with
+ * diag = softplus(unconstrained_diag) + 1e-3.  Packed weights = state_dict order: bias[D], lower_entries[D(D-1)/2]
+ * (np.tril_indices(D, -1) order), unconstrained_diag[D].  Conventions as the nnest_nvp_* functions.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct nnest_chol nnest_chol_t;
+int nnest_chol_create(int D, nnest_chol_t **out);
+int nnest_chol_destroy(nnest_chol_t *chol);
+int nnest_chol_num_params(const nnest_chol_t *chol);
+int nnest_chol_set_base(nnest_chol_t *chol, float beta);
+int nnest_chol_load_weights(nnest_chol_t *chol, const float *packed_host, void *stream);
+int nnest_chol_store_weights(nnest_chol_t *chol, float *packed_host, void *stream);
+int nnest_chol_forward(nnest_chol_t *chol, const float *x_dev, float *z_dev, float *logdet_dev, int N, void *stream);
+int nnest_chol_inverse(nnest_chol_t *chol, const float *z_dev, float *x_dev, float *logdet_dev, int N, void *stream);
+int nnest_chol_log_probs(nnest_chol_t *chol, const float *x_dev, float *logp_dev, int N, void *stream);
+int nnest_chol_loss_grad(nnest_chol_t *chol, const float *x_dev, int M, float *grad_dev, float *loss_dev, void *stream);
+int nnest_chol_adam_step(nnest_chol_t *chol, const float *grad_dev, float lr, float weight_decay, void *stream);
 
 #ifdef __cplusplus
 }

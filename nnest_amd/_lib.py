@@ -94,6 +94,17 @@ SIGNATURES = {
     'nnest_spline_actnorm_init': [_vp, _vp, _i, _vp],
     'nnest_spline_loss_grad': [_vp, _vp, _i, _vp, _vp, _vp],
     'nnest_spline_train': [_vp, _vp, _i, _vp, _i, _vp, _vp, _u64, _f, _i, _i, _i, _f, _f, _vp, _vp, _vp],
+    'nnest_chol_create': [_i, ctypes.POINTER(_vp)],
+    'nnest_chol_destroy': [_vp],
+    'nnest_chol_num_params': [_vp],
+    'nnest_chol_set_base': [_vp, _f],
+    'nnest_chol_load_weights': [_vp, _vp, _vp],
+    'nnest_chol_store_weights': [_vp, _vp, _vp],
+    'nnest_chol_forward': [_vp, _vp, _vp, _vp, _i, _vp],
+    'nnest_chol_inverse': [_vp, _vp, _vp, _vp, _i, _vp],
+    'nnest_chol_log_probs': [_vp, _vp, _vp, _i, _vp],
+    'nnest_chol_loss_grad': [_vp, _vp, _i, _vp, _vp, _vp],
+    'nnest_chol_adam_step': [_vp, _vp, _f, _f, _vp],
     'nnest_mh_num_groups': [_vp, _i],
     'nnest_mh_fill_noise': [_vp, _vp, _i, _i, _i, _u64, _u64, _vp],
     'nnest_nvp_train': [_vp, _vp, _i, _vp, _i, _vp, _vp, _u64, _f, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp],

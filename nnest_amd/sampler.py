@@ -188,7 +188,7 @@ class Sampler(object):
         like = self._user_loglike
         like_id = getattr(like, 'hip_like_id', None)
         netG = getattr(self.trainer, 'netG', None)
-        if like_id is None or not hasattr(netG, 'mh_steps') or self._linear_scale is None or self.num_derived != 0:
+        if like_id is None or getattr(netG, 'mh_steps', None) is None or self._linear_scale is None or self.num_derived != 0:
             return None
         prior = self._user_prior
         if prior is None or self._transform_prior or not getattr(prior, 'is_unit_box', lambda: False)():

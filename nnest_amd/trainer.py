@@ -45,9 +45,8 @@ class Trainer(object):
         if not torch.cuda.is_available():
             raise _lib.NnestHipError('nnest_amd.Trainer needs an MI355X (torch.cuda.is_available() is False); '
                                      'there is no CPU fallback')
-        if flow.lower() not in ('nvp', 'spline'):
-            raise NotImplementedError("flow=%r: this build implements flow='nvp' (RealNVP) and flow='spline' (neural spline "
-                                      "flow); the Choleksy flow of the reference is outside its scope (DESIGN.md)" % flow)
+        if flow.lower() not in ('nvp', 'spline', 'choleksy'):
+            raise NotImplementedError('flow=%r (trainer.py:83-100 knows choleksy, nvp, spline)' % flow)
         self.flow = flow.lower()
         if num_slow != 0:
             assert x_dim > num_slow                      # trainer.py:79
@@ -84,7 +83,10 @@ class Trainer(object):
         self.num_slow = num_slow
         self.learning_rate = learning_rate
         self.weight_decay = weight_decay
-        if self.flow == 'spline' and num_slow > 0:   # FastSlowSpline(num_fast, num_slow, hidden_dim, num_blocks)  (trainer.py:93-95)
+        if self.flow == 'choleksy':  # SingleSpeedCholeksy(x_dim)  (trainer.py:83-84; the reference ignores num_slow here too)
+            from .cholesky import HipCholesky
+            self.netG = HipCholesky(x_dim, device=self.gpu, seed=seed)
+        elif self.flow == 'spline' and num_slow > 0:   # FastSlowSpline(num_fast, num_slow, hidden_dim, num_blocks)  (trainer.py:93-95)
             from .fastslow import HipFastSlowSpline
             self.netG = HipFastSlowSpline(x_dim - num_slow, num_slow, hidden_dim, num_blocks, device=self.gpu, seed=seed)
         elif self.flow == 'spline':  # SingleSpeedSpline(x_dim, hidden_dim, num_blocks, tail_bound=3)  (trainer.py:97-98)

@@ -697,7 +697,53 @@ def gen_fastslow_spline():
         print('G12 fastslow spline', S, F, 'nparams', out['w_raw'].size, 'loss0', out['losses'][0])
 
 
+# ----------------------------------------------------------------------------------------------
+# G13: 'choleksy' flow (networks.py:162-239)
+# ----------------------------------------------------------------------------------------------
+def gen_cholesky():
+    for D in (2, 5, 20):
+        np.random.seed(0)
+        torch.manual_seed(14)
+        t = Trainer(D, flow='choleksy', log_dir=None, learning_rate=1e-3, log_level=logging.WARNING)
+        with torch.no_grad():   # move off the identity so that every parameter matters
+            for p_ in t.netG.parameters():
+                p_.add_(0.3 * torch.randn_like(p_))
+        out = {'D': D, 'keys': np.array(list(t.netG.state_dict().keys())), 'w0': pack_state_dict(t.netG)}
+        x = np.random.normal(size=(64, D)).astype(np.float32)
+        z, ldf = t.forward(x, to_numpy=True)
+        xb, ldi = t.inverse(z, to_numpy=True)
+        out.update(x=x, z=z, ldf=ldf, xb=xb, ldi=ldi, lp=t.log_probs(x, to_numpy=True))
+        n, jitter = 230, 0.02
+        X = np.random.uniform(-1, 1, size=(n, D)).astype(np.float32)
+        torch.manual_seed(11)
+        perms, noises = [], []
+        for e in range(2):
+            pp, nz = replay_loader_rng(n, 100, D)
+            perms.append(pp)
+            noises.append(nz)
+        opt = torch.optim.Adam(t.netG.parameters(), lr=1e-3, weight_decay=1e-6)
+        losses, grads, ws = [], [], []
+        Xt = torch.from_numpy(X)
+        for e in range(2):
+            for b in range(0, n, 100):
+                idx = torch.from_numpy(perms[e][b:b + 100].astype(np.int64))
+                data = Xt[idx] + jitter * torch.from_numpy(noises[e][b:b + 100])
+                opt.zero_grad()
+                loss = -t.netG.log_probs(data).mean()
+                loss.backward()
+                grads.append(pack_grads(t.netG))
+                opt.step()
+                losses.append(loss.item())
+                ws.append(pack_state_dict(t.netG))
+        out.update(X=X, jitter=jitter, perms=np.stack(perms), noises=np.stack(noises), losses=np.array(losses), grads=np.stack(grads[:2]),
+                   ws=np.stack([ws[0], ws[-1]]))
+        np.savez_compressed(os.path.join(OUT, 'cholesky_d%d.npz' % D), **out)
+        print('G13 cholesky', D, list(out['keys']), 'loss0', losses[0])
+
+
 if __name__ == '__main__':
+    if 'cholesky' in (sys.argv[1:] or ['cholesky']):
+        gen_cholesky()
     which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested', 'scale', 'spline', 'base', 'fastslow',
                              'fastslowspline']
     if 'fastslowspline' in which:

@@ -415,3 +415,39 @@ class FastSlowNVP(object):
     def log_probs(self, x, f64=False):
         z, ld = self.forward(x, f64=f64)
         return -0.5 * np.sum(z * z, axis=1) - 0.5 * self.D * np.log(2 * np.pi) + ld
+
+
+class Cholesky(object):
+    """SingleSpeedCholeksy (nnest/networks.py:162-239): y = L x + b, L lower triangular with diag = softplus(u) + 1e-3.
+    Weights: bias[D], lower_entries[D(D-1)/2] (np.tril_indices(D, -1) order), unconstrained_diag[D].  numpy restatement."""
+
+    def __init__(self, D, weights):
+        self.D = int(D)
+        self.w = _f32(weights).copy()
+
+    def _parts(self, dt):
+        D = self.D
+        nl = D * (D - 1) // 2
+        b, lo, ud = self.w[:D].astype(dt), self.w[D:D + nl].astype(dt), self.w[D + nl:].astype(dt)
+        L = np.zeros((D, D), dt)
+        L[np.tril_indices(D, -1)] = lo
+        diag = np.log1p(np.exp(ud)) + dt(1e-3)
+        L[np.diag_indices(D)] = diag
+        return L, b, diag
+
+    def forward(self, x, f64=False):
+        dt = np.float64 if f64 else np.float32
+        L, b, diag = self._parts(dt)
+        x = np.atleast_2d(x).astype(dt)
+        return x @ L.T + b, np.full(x.shape[0], np.sum(np.log(diag)), dt)
+
+    def inverse(self, z, f64=False):
+        dt = np.float64 if f64 else np.float32
+        L, b, diag = self._parts(dt)
+        z = np.atleast_2d(z).astype(dt)
+        x = np.linalg.solve(L.astype(np.float64), (z - b).T.astype(np.float64)).T.astype(dt)
+        return x, np.full(z.shape[0], -np.sum(np.log(diag)), dt)
+
+    def log_probs(self, x, f64=False):
+        y, ld = self.forward(x, f64=f64)
+        return -0.5 * np.sum(y * y, axis=1) - 0.5 * self.D * np.log(2 * np.pi) + ld

@@ -376,3 +376,18 @@ def test_fast_slow_nvp(path):
         dz[:, S:] = 0.01 * np.random.RandomState(0).normal(size=(z.shape[0], F))
         xp, _ = o.inverse(z + dz)
         assert np.array_equal(xp[:, :S], o.inverse(z)[0][:, :S]) and not np.array_equal(xp[:, S:], o.inverse(z)[0][:, S:])
+
+
+CHOL_FILES = sorted(glob.glob(os.path.join(G, 'cholesky_*.npz')))
+
+
+@pytest.mark.parametrize('path', CHOL_FILES, ids=[os.path.basename(p)[9:-4] for p in CHOL_FILES])
+def test_cholesky_flow(path):
+    """SingleSpeedCholeksy (networks.py:162-239)"""
+    g = np.load(path)
+    o = orc.Cholesky(int(g['D']), g['w0'])
+    z, ld = o.forward(g['x'])
+    assert rel(z, g['z']) < 1e-5 and rel(ld, g['ldf']) < 1e-5
+    xb, ldi = o.inverse(g['z'])
+    assert rel(xb, g['xb']) < 1e-5 and rel(ldi, g['ldi']) < 1e-5
+    assert rel(o.log_probs(g['x']), g['lp']) < 2e-5
