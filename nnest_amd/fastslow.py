@@ -92,12 +92,9 @@ class HipFastSlowNVP(object):
         return ref
 
     def _coupling_mask(self):
-        """1 for the packed entries of the interleaved coupling that are real parameters, 0 for the padding"""
+        """1 for the packed entries of the interleaved coupling that are real parameters, 0 for the zero padding (first-layer
+        columns and last-layer rows / biases at positions where no real dimension sits)"""
         ones = {net: {leaf: np.ones(shape, np.float32) for leaf, shape in self._coupling_shapes()} for net in ('scale_net', 'translate_net')}
-        return self._coupling_to_packed(ones) if self.S == self.m and self.F == self.m else self._mask_from(ones)
-
-    def _mask_from(self, ones):
-        # biases / hidden layers are all real; first-layer columns and last-layer rows only where a real dim sits
         return self._coupling_to_packed(ones)
 
     def _coupling_reference_init(self, packed_default):
