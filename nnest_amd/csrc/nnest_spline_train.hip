@@ -195,9 +195,10 @@ __device__ __forceinline__ void spl_actnorm_vecs(const SplTrainShape &ts, const 
             float e[4], tt[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int d = tslot_dim(ts.s, hf, t, r, g);
-                e[r] = d >= 0 ? expf(pb[ts.p_s + d]) : 0.f;
-                tt[r] = d >= 0 ? pb[ts.p_t + d] : 0.f;
+                const int d = tslot_dim(ts.s, hf, t, r, g), dc = d >= 0 ? d : 0;  // unconditional loads: they issue together
+                const float sv = pb[ts.p_s + dc], tl = pb[ts.p_t + dc];
+                e[r] = d >= 0 ? expf(sv) : 0.f;
+                tt[r] = d >= 0 ? tl : 0.f;
             }
             es[hf][t] = (f32x4){e[0], e[1], e[2], e[3]};
             tv[hf][t] = (f32x4){tt[0], tt[1], tt[2], tt[3]};
@@ -225,12 +226,17 @@ __device__ __forceinline__ void spl_matmul(const float *__restrict__ frag, int l
 }
 
 // sum over the 16 rows (lanes w) of a tile; valid in every lane
-__device__ __forceinline__ f32x4 rows_sum(f32x4 v) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
-    }
+// (the 16 lanes of a lane group are one DPP row: quad swaps, then the half-row and row mirrors -- four VALU adds per value
+// instead of four ds_bpermute round trips)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
     return v;
+}
+__device__ __forceinline__ f32x4 rows_sum(f32x4 v) {
+    return (f32x4){row16_sum(v.x), row16_sum(v.y), row16_sum(v.z), row16_sum(v.w)};
 }
 
 // Backward of one coupling: `tr` (n_out dims, S super-tiles) was transformed conditioned on `cond` by the conditioner
@@ -474,6 +480,13 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         }
     }
     spl_from_parity<NTh>(buf, D, s.nl, lane, xp, xs);
+#ifdef NNEST_STAMP
+    long long st_t[6] = {0, 0, 0, 0, 0, 0}, st_0 = wall_clock64(), st_a;
+#define SPL_STAMP(i) { const long long st_n = wall_clock64(); st_t[i] += st_n - st_a; st_a = st_n; }
+    st_a = st_0;
+#else
+#define SPL_STAMP(i)
+#endif
 
     // ---- forward (networks.py:24-32), block inputs stashed -----------------------------------------------------------
     float ld = 0.f;
@@ -526,6 +539,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     for (int o = 1; o < 16; o <<= 1) lp += __shfl_xor(lp, o);
     if (lane == 0 && wv == 0) gp[ts.gw_floats - 4] = lp;  // sum of log_probs over this tile's rows
     if (a.mode == SPL_MODE_LOSS) return;
+    SPL_STAMP(0)
 
     // ---- backward: loss = -mean(log_probs)  (trainer.py:394) ---------------------------------------------------------
     const float invM = 1.0f / (float)a.mtot, gld = a.mode == SPL_MODE_VJP ? a.gld_in : -invM;
@@ -561,9 +575,12 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #pragma unroll
         for (int t = 0; t < NTh; ++t) up2[t] = stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane];
         // second coupling: lower' = RQS(lower; f2(upper'))   (networks.py:589-598)
+        SPL_STAMP(1)
         spl_coupling_bwd<NTh, NH, TEAM>(ts, f2, f2b, pblk + ts.p_f[1], s.nu, s.nl, s.SL, lane, ok, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch);
+        SPL_STAMP(2)
         // first coupling: upper' = RQS(upper; f1(lower))      (networks.py:582-588)
         spl_coupling_bwd<NTh, NH, TEAM>(ts, f1, f1b, pblk + ts.p_f[0], s.nl, s.nu, s.SU, lane, ok, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch);
+        SPL_STAMP(3)
         // 1x1 conv c = a W: dLoss/dW[i][o] = sum_rows a[i] g_c[o];  g_a = g_c W^T
         {
             constexpr int T2 = 2 * NTh;
@@ -611,7 +628,12 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
                 }
                 gs[hf][t] = gx;
             }
+        SPL_STAMP(4)
     }
+#ifdef NNEST_STAMP
+    if (tile == 0 && lane == 0)
+        printf("spl_grad wave %d: fwd %lld recompute %lld c2_bwd %lld c1_bwd %lld conv_actnorm %lld (x10 ns)\n", wv, st_t[0], st_t[1], st_t[2], st_t[3], st_t[4]);
+#endif
     if (a.mode == SPL_MODE_VJP) {
         f32x4 gp4[2][NTh];
         spl_to_parity<NTh>(buf, D, s.nl, lane, gs, gp4);
