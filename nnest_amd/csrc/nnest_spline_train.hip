@@ -225,6 +225,10 @@ __device__ __forceinline__ void spl_matmul(const float *__restrict__ frag, int l
     }
 }
 
+// Values made opaque to the optimiser (see the block loops of spl_grad_kernel)
+__device__ __forceinline__ int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ int opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
+
 // sum over the 16 rows (lanes w) of a tile; valid in every lane
 // (the 16 lanes of a lane group are one DPP row: quad swaps, then the half-row and row mirrors -- four VALU adds per value
 // instead of four ds_bpermute round trips)
@@ -262,9 +266,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
               pb3 = pW3 + SPL_P * nout * H;
     float hT[3][NH][4];  // activations transposed for the weight-gradient contractions
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int ht = 0; ht < NH; ++ht) tile_transpose(lds17, lane, h[l][ht], hT[l][ht]);
+    for (int l = 0; l < 3; ++l) tile_transpose_batch<NH>(lds17, lane, h[l], hT[l]);
     f32x4 g_h[NH];
 #pragma unroll
     for (int ht = 0; ht < NH; ++ht) g_h[ht] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -438,17 +440,37 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     constexpr int TEAM = SPL_TEAM;
     const SplTrainShape &ts = a.ts;
     const SplineShape &s = ts.s;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, w = lane & 15, g = lane >> 4, tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, w = lane & 15, g = lane >> 4, tile = blockIdx.x, lane_k = lane;
     const int D = s.D, B = s.B;
-    const int per_wave = ((16 * (D + 1) + 16 * 17) + 3) & ~3;
+    const int per_wave = ((16 * (D + 1) + SPL_TBATCH * 16 * 17) + 3) & ~3;
     float *buf = lds + (size_t)wv * per_wave;   // 16 x (D+1): layout exchange (per wave)
-    float *lds17 = buf + 16 * (D + 1);           // 16 x 17: tile transposes (per wave)
+    float *lds17 = buf + 16 * (D + 1);           // SPL_TBATCH x 16 x 17: tile transposes (per wave)
     f32x4 *xch = reinterpret_cast<f32x4 *>(lds + (size_t)TEAM * per_wave);  // [TEAM][NTh + NH][64]
     float *ldred = reinterpret_cast<float *>(xch + TEAM * (NTh + NH) * 64);  // [TEAM][16]
     const int row = tile * a.rows_per_tile + w;
     const bool ok = w < a.rows_per_tile && row < a.M;
     float *gp = a.partial + (size_t)tile * ts.gw_floats;
     f32x4 *stash = reinterpret_cast<f32x4 *>(a.stash) + ((size_t)tile * TEAM + wv) * B * 3 * NTh * 64;  // per block: input halves + upper'
+
+    // The image was written by another kernel, i.e. into other XCDs' L2s: from here every fragment load of the pass would be
+    // a cold miss (1.5-2 us each, and the layers consume them in small dependent batches -- by the stamps that was most of the
+    // kernel).  One dword per 128-byte line, all in flight at once, brings the image into this XCD's L2 first.
+    {
+        const char *base = reinterpret_cast<const char *>(a.timg);
+        const int n_lines = (int)(((size_t)B * ts.tblk_floats * sizeof(float) + 127) >> 7);
+        float sink = 0.f;
+        for (int i = threadIdx.x; i < n_lines; i += 64 * TEAM) {
+            const char *p = base + ((size_t)i << 7);
+            asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
+        }
+        // (and the ActNorm vectors of every block, the only packed parameters the pass reads: 2 D floats at the head of a block)
+        const int lines_an = (2 * D * (int)sizeof(float) + 127 + 127) >> 7;
+        for (int i = threadIdx.x; i < B * lines_an; i += 64 * TEAM) {
+            const char *p = reinterpret_cast<const char *>(a.w + (size_t)(i / lines_an) * s.blk_params) + ((size_t)(i % lines_an) << 7);
+            asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");  // the target register is free again only now
+    }
 
     // data = X[perm] + jitter * randn  (trainer.py:392)
     f32x4 xp[2][NTh], xs[2][NTh];
@@ -481,7 +503,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     }
     spl_from_parity<NTh>(buf, D, s.nl, lane, xp, xs);
 #ifdef NNEST_STAMP
-    long long st_t[6] = {0, 0, 0, 0, 0, 0}, st_0 = wall_clock64(), st_a;
+    long long st_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_0 = wall_clock64(), st_a;
 #define SPL_STAMP(i) { const long long st_n = wall_clock64(); st_t[i] += st_n - st_a; st_a = st_n; }
     st_a = st_0;
 #else
@@ -491,6 +513,9 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     // ---- forward (networks.py:24-32), block inputs stashed -----------------------------------------------------------
     float ld = 0.f;
     for (int b = 0; b < B; ++b) {
+        // (lane- and shape-derived values kept opaque per block: see the backward loop)
+        const int lane_o = opaque_v(lane_k), nu_o = opaque_s(s.nu), nl_o = opaque_s(s.nl), SL_o = opaque_s(s.SL), SU_o = opaque_s(s.SU);
+        const int lane = lane_o;
         const float *blk = a.timg + (size_t)b * ts.tblk_floats;
         const float *pb = a.w + (size_t)b * s.blk_params;
         if (a.mode != SPL_MODE_LOSS) {
@@ -507,12 +532,12 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
             for (int t = 0; t < NTh; ++t) av[hf][t] = xs[hf][t] * es[hf][t] + tv[hf][t];
         spl_matmul<NTh>(blk, lane, av, c);
         const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
-        ld += spl_coupling<NTh, NH, false, TEAM>(f1, s.SU, s.nu, s.tail, lane, c[0], c[1], wv, xch);
+        ld += spl_coupling<NTh, NH, false, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch);
         if (a.mode != SPL_MODE_LOSS) {  // upper' conditions the second coupling: kept for the backward pass
 #pragma unroll
             for (int t = 0; t < NTh; ++t) stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
         }
-        ld += spl_coupling<NTh, NH, false, TEAM>(f2, s.SL, s.nl, s.tail, lane, c[1], c[0], wv, xch);
+        ld += spl_coupling<NTh, NH, false, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch);
         if (lane < 16 && wv == 0) ld += blk[ts.tblk_floats - 4];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -555,6 +580,11 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
             for (int t = 0; t < NTh; ++t) gs[c][t] = ok ? base_dE4(xs[c][t], s.base_beta) * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     for (int b = B - 1; b >= 0; --b) {
+        // Everything the unrolled body derives from the lane index and the half sizes is invariant over the blocks; hoisted
+        // out of this loop it came to ~500 spilled SGPRs (and as many VGPR copies) that each iteration re-read one by one.
+        // Kept opaque per iteration, the masks and offsets are recomputed where they are used.
+        const int lane_o = opaque_v(lane_k), nu_o = opaque_s(s.nu), nl_o = opaque_s(s.nl), SL_o = opaque_s(s.SL), SU_o = opaque_s(s.SU);
+        const int lane = lane_o, w = lane & 15, g = lane >> 4;
         const float *blk = a.timg + (size_t)b * ts.tblk_floats;
         const float *pb = a.w + (size_t)b * s.blk_params;
         const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0], *f1b = f2 + ts.cf[1], *f2b = f1b + ts.cb[0];
@@ -569,6 +599,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int t = 0; t < NTh; ++t) av[hf][t] = xin[hf][t] * es[hf][t] + tv[hf][t];
+        SPL_STAMP(5)
         spl_matmul<NTh>(blk, lane, av, c);
         // upper' = RQS(upper; f1(lower)) is the conditioning input of the second coupling
         f32x4 up2[NTh];
@@ -576,22 +607,24 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         for (int t = 0; t < NTh; ++t) up2[t] = stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane];
         // second coupling: lower' = RQS(lower; f2(upper'))   (networks.py:589-598)
         SPL_STAMP(1)
-        spl_coupling_bwd<NTh, NH, TEAM>(ts, f2, f2b, pblk + ts.p_f[1], s.nu, s.nl, s.SL, lane, ok, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch);
+        spl_coupling_bwd<NTh, NH, TEAM>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch);
         SPL_STAMP(2)
         // first coupling: upper' = RQS(upper; f1(lower))      (networks.py:582-588)
-        spl_coupling_bwd<NTh, NH, TEAM>(ts, f1, f1b, pblk + ts.p_f[0], s.nl, s.nu, s.SU, lane, ok, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch);
+        spl_coupling_bwd<NTh, NH, TEAM>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch);
         SPL_STAMP(3)
         // 1x1 conv c = a W: dLoss/dW[i][o] = sum_rows a[i] g_c[o];  g_a = g_c W^T
         {
             constexpr int T2 = 2 * NTh;
             float aT[T2][4], gT[T2][4];
+            f32x4 av0[T2], gs0[T2];
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
-                f32x4 v = av[t / NTh][t % NTh];
-                if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                tile_transpose(lds17, lane, v, aT[t]);
-                tile_transpose(lds17, lane, gs[t / NTh][t % NTh], gT[t]);
+                av0[t] = ok ? av[t / NTh][t % NTh] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                gs0[t] = gs[t / NTh][t % NTh];
             }
+            tile_transpose_batch<T2>(lds17, lane, av0, aT);
+            tile_transpose_batch<T2>(lds17, lane, gs0, gT);
+            SPL_STAMP(6)
             float *gW = gp + s.num_params + (size_t)b * D * D;
 #pragma unroll
             for (int ti = 0; ti < T2; ++ti)
@@ -608,8 +641,13 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
                     }
                 }
         }
+#ifdef NNEST_STAMP
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+        SPL_STAMP(7)
         f32x4 ga[2][NTh];
         spl_matmul<NTh>(blk + ts.conv_floats, lane, gs, ga);
+        SPL_STAMP(8)
         // ActNorm a = x e^s + t: g_s = sum_rows g_a x e^s, g_t = sum_rows g_a, g_x = g_a e^s  (the -1 of log|det| is added by the reducer)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -618,13 +656,10 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
                 const f32x4 gx = ga[hf][t] * es[hf][t];
                 const f32x4 dsum = rows_sum(gx * xin[hf][t]);
                 const f32x4 tsum = rows_sum(ga[hf][t]);
-                if (w == 0 && wv == 0) {
-                    const float dsv[4] = {dsum.x, dsum.y, dsum.z, dsum.w}, dtv[4] = {tsum.x, tsum.y, tsum.z, tsum.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int d = tslot_dim(s, hf, t, r, g);
-                        if (d >= 0) { gp[pblk + ts.p_s + d] = dsv[r]; gp[pblk + ts.p_t + d] = dtv[r]; }
-                    }
+                // every lane of every wave holds the sums: lane w < 4 of wave (hf NTh + t) mod TEAM writes register r = w
+                if (w < 4 && (TEAM == 1 || wv == ((hf * NTh + t) & (TEAM - 1)))) {
+                    const int d = tslot_dim(s, hf, t, w, g);
+                    if (d >= 0) { gp[pblk + ts.p_s + d] = reg_of(dsum, w); gp[pblk + ts.p_t + d] = reg_of(tsum, w); }
                 }
                 gs[hf][t] = gx;
             }
@@ -632,7 +667,8 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     }
 #ifdef NNEST_STAMP
     if (tile == 0 && lane == 0)
-        printf("spl_grad wave %d: fwd %lld recompute %lld c2_bwd %lld c1_bwd %lld conv_actnorm %lld (x10 ns)\n", wv, st_t[0], st_t[1], st_t[2], st_t[3], st_t[4]);
+        printf("spl_grad wave %d: fwd %lld | stash+actnorm %lld matmul %lld | c2_bwd %lld c1_bwd %lld | transposes %lld dW %lld matmulT %lld actnorm %lld (x10 ns)\n", wv,
+               st_t[0], st_t[5], st_t[1], st_t[2], st_t[3], st_t[6], st_t[7], st_t[8], st_t[4]);
 #endif
     if (a.mode == SPL_MODE_VJP) {
         f32x4 gp4[2][NTh];
@@ -818,16 +854,26 @@ __global__ void __launch_bounds__(512) spl_init_kernel(SplInitArgs a) {
     }
 }
 
+// (above 64 KiB of dynamic LDS a kernel has to be told so once)
+#define SPLT_LAUNCH(K, grid, block, ldsb, st, arg)                                                                    \
+    do {                                                                                                              \
+        if ((size_t)(ldsb) > 64 * 1024) {                                                                             \
+            hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ldsb)); \
+            if (e__ != hipSuccess) return e__;                                                                        \
+        }                                                                                                             \
+        hipLaunchKernelGGL((K), dim3(grid), dim3(block), ldsb, st, arg);                                              \
+    } while (0)
+
 #define DISPATCH_SPLT(KERNEL, sp, grid, block, ldsb, st, arg)                                                         \
     do {                                                                                                              \
         const int key__ = (sp).NTh * 10 + (sp).NH;                                                                    \
         switch (key__) {                                                                                              \
-            case 11: hipLaunchKernelGGL((KERNEL<1, 1>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
-            case 21: hipLaunchKernelGGL((KERNEL<2, 1>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
-            case 31: hipLaunchKernelGGL((KERNEL<3, 1>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
-            case 41: hipLaunchKernelGGL((KERNEL<4, 1>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
-            case 12: hipLaunchKernelGGL((KERNEL<1, 2>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
-            case 22: hipLaunchKernelGGL((KERNEL<2, 2>), dim3(grid), dim3(block), ldsb, st, arg); break;               \
+            case 11: SPLT_LAUNCH((KERNEL<1, 1>), grid, block, ldsb, st, arg); break;               \
+            case 21: SPLT_LAUNCH((KERNEL<2, 1>), grid, block, ldsb, st, arg); break;               \
+            case 31: SPLT_LAUNCH((KERNEL<3, 1>), grid, block, ldsb, st, arg); break;               \
+            case 41: SPLT_LAUNCH((KERNEL<4, 1>), grid, block, ldsb, st, arg); break;               \
+            case 12: SPLT_LAUNCH((KERNEL<1, 2>), grid, block, ldsb, st, arg); break;               \
+            case 22: SPLT_LAUNCH((KERNEL<2, 2>), grid, block, ldsb, st, arg); break;               \
             default: return hipErrorInvalidConfiguration;                                                             \
         }                                                                                                             \
     } while (0)
@@ -836,7 +882,7 @@ static int grad_tiles(const SplGradArgs &a) { return (a.M + a.rows_per_tile - 1)
 
 static hipError_t launch_grad(const SplGradArgs &a, hipStream_t st) {
     const int tiles = grad_tiles(a);
-    const int per_wave = ((16 * (a.ts.s.D + 1) + 16 * 17) + 3) & ~3;
+    const int per_wave = ((16 * (a.ts.s.D + 1) + SPL_TBATCH * 16 * 17) + 3) & ~3;
     const size_t ldsb = (size_t)(SPL_TEAM * per_wave + SPL_TEAM * (a.ts.s.NTh + a.ts.s.NH) * 64 * 4 + SPL_TEAM * 16) * sizeof(float);
     DISPATCH_SPLT(spl_grad_kernel, a.ts.s, tiles, 64 * SPL_TEAM, ldsb, st, a);
     return hipGetLastError();

@@ -42,6 +42,27 @@ __device__ __forceinline__ void tile_transpose(float *lds17, int lane, f32x4 v, 
     __builtin_amdgcn_wave_barrier();
 }
 
+// N tiles in one LDS round trip (scratch: N x 16 x 17 floats, N <= SPL_TBATCH)
+enum { SPL_TBATCH = 8 };
+template <int N>
+__device__ __forceinline__ void tile_transpose_batch(float *lds17, int lane, const f32x4 (&v)[N], float (&out)[N][4]) {
+    static_assert(N <= SPL_TBATCH, "scratch holds SPL_TBATCH tiles");
+    const int w = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float *t = lds17 + i * (16 * 17);
+        t[(4 * g + 0) * 17 + w] = v[i].x; t[(4 * g + 1) * 17 + w] = v[i].y;
+        t[(4 * g + 2) * 17 + w] = v[i].z; t[(4 * g + 3) * 17 + w] = v[i].w;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) out[i][kk] = lds17[i * (16 * 17) + w * 17 + 4 * kk + g];
+    __builtin_amdgcn_wave_barrier();
+}
+
 // out[m][n] = sum_row G[m][row] A[n][row]; operands already transposed; result lane (g,j) reg r = out[4g+r][j]
 __device__ __forceinline__ f32x4 contract16(const float (&gt)[4], const float (&at)[4]) {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
