@@ -59,10 +59,14 @@ __global__ void spl_assemble_kernel(const float *__restrict__ w, const int *__re
         const float *Lp = pb + ts.p_L, *Sp = pb + ts.p_S, *Up = pb + ts.p_U;
         const int r = pi[b * D + i];  // (P Lm)[i][k] = Lm[r][k]
         const int kmax = r < j ? r : j;
+        // (the loads are unconditional and the loop is unrolled so that eight steps' loads are in flight together: one load
+        // round trip per step made this tiny kernel 11 us)
         float acc = 0.f;
+#pragma unroll 8
         for (int k = 0; k <= kmax; ++k) {
-            const float l = k < r ? Lp[r * D + k] : 1.f;
-            const float u = k < j ? Up[k * D + j] : Sp[k];
+            const float lv = Lp[r * D + k], uv = Up[k * D + j], sv = Sp[k];
+            const float l = k < r ? lv : 1.f;
+            const float u = k < j ? uv : sv;
             acc += l * u;
         }
         wmat[idx] = acc;
@@ -224,10 +228,6 @@ __device__ __forceinline__ void spl_matmul(const float *__restrict__ frag, int l
         out[to / NTh][to % NTh] = acc0 + acc1;
     }
 }
-
-// Values made opaque to the optimiser (see the block loops of spl_grad_kernel)
-__device__ __forceinline__ int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
-__device__ __forceinline__ int opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
 
 // sum over the 16 rows (lanes w) of a tile; valid in every lane
 // (the 16 lanes of a lane group are one DPP row: quad swaps, then the half-row and row mirrors -- four VALU adds per value
@@ -514,7 +514,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     float ld = 0.f;
     for (int b = 0; b < B; ++b) {
         // (lane- and shape-derived values kept opaque per block: see the backward loop)
-        const int lane_o = opaque_v(lane_k), nu_o = opaque_s(s.nu), nl_o = opaque_s(s.nl), SL_o = opaque_s(s.SL), SU_o = opaque_s(s.SU);
+        const int lane_o = spl_opaque_v(lane_k), nu_o = spl_opaque_s(s.nu), nl_o = spl_opaque_s(s.nl), SL_o = spl_opaque_s(s.SL), SU_o = spl_opaque_s(s.SU);
         const int lane = lane_o;
         const float *blk = a.timg + (size_t)b * ts.tblk_floats;
         const float *pb = a.w + (size_t)b * s.blk_params;
@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         // Everything the unrolled body derives from the lane index and the half sizes is invariant over the blocks; hoisted
         // out of this loop it came to ~500 spilled SGPRs (and as many VGPR copies) that each iteration re-read one by one.
         // Kept opaque per iteration, the masks and offsets are recomputed where they are used.
-        const int lane_o = opaque_v(lane_k), nu_o = opaque_s(s.nu), nl_o = opaque_s(s.nl), SL_o = opaque_s(s.SL), SU_o = opaque_s(s.SU);
+        const int lane_o = spl_opaque_v(lane_k), nu_o = spl_opaque_s(s.nu), nl_o = spl_opaque_s(s.nl), SL_o = spl_opaque_s(s.SL), SU_o = spl_opaque_s(s.SU);
         const int lane = lane_o, w = lane & 15, g = lane >> 4;
         const float *blk = a.timg + (size_t)b * ts.tblk_floats;
         const float *pb = a.w + (size_t)b * s.blk_params;
@@ -704,6 +704,10 @@ __global__ void spl_reduce_kernel(const float *__restrict__ partial, int tiles, 
 __global__ void spl_lu_grad_kernel(const float *__restrict__ w, const int *__restrict__ pi_inv, const int *__restrict__ pi,
                                    const float *__restrict__ gwsum, float *__restrict__ grad, SplTrainShape ts, float ldw) {
     const int D = ts.s.D, per = 2 * D * D, n = ts.s.B * per;
+    extern __shared__ int lu_perm[];  // [pi | pi_inv], B x D each: the permutation look-ups leave the dependent-load chains
+    int *spi = lu_perm, *spi_inv = lu_perm + ts.s.B * D;
+    for (int i = threadIdx.x; i < ts.s.B * D; i += blockDim.x) { spi[i] = pi[i]; spi_inv[i] = pi_inv[i]; }
+    __syncthreads();
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
         const int b = idx / per, o = idx % per;
         const float *pb = w + (size_t)b * ts.s.blk_params;
@@ -714,19 +718,27 @@ __global__ void spl_lu_grad_kernel(const float *__restrict__ w, const int *__res
             const int r = o / D, k = o % D;
             float acc = 0.f;
             if (k < r) {
-                const int i = pi_inv[b * D + r];
-                for (int j = k; j < D; ++j) acc += gW[(size_t)i * D + j] * (j > k ? Up[k * D + j] : Sp[k]);
+                const int i = spi_inv[b * D + r];
+                const float sk = Sp[k];
+#pragma unroll 8
+                for (int j = k; j < D; ++j) {
+                    const float gv = gW[(size_t)i * D + j], uv = Up[k * D + j];
+                    acc += gv * (j > k ? uv : sk);
+                }
             }
             gb[ts.p_L + o] = acc;
         } else {  // dLoss/dUm[k][j] = sum_i gW[i][j] Lm[pi(i)][k]   (k <= j)
             const int k = (o - D * D) / D, j = (o - D * D) % D;
             float acc = 0.f;
-            if (k <= j)
+            if (k <= j) {
+#pragma unroll 16
                 for (int i = 0; i < D; ++i) {
-                    const int r = pi[b * D + i];
-                    const float l = k < r ? Lp[r * D + k] : (k == r ? 1.f : 0.f);
-                    acc += gW[(size_t)i * D + j] * l;
+                    const int r = spi[b * D + i];
+                    const float lv = Lp[r * D + k], gv = gW[(size_t)i * D + j];
+                    const float l = k < r ? lv : (k == r ? 1.f : 0.f);
+                    acc += gv * l;
                 }
+            }
             if (k < j) gb[ts.p_U + k * D + j] = acc;
             else if (k == j) { gb[ts.p_S + k] = acc + ldw / Sp[k]; gb[ts.p_U + k * D + j] = 0.f; }  // logdet of the conv = sum log|S| on every row
             else gb[ts.p_U + k * D + j] = 0.f;
@@ -999,7 +1011,7 @@ int nnest_spline_loss_grad(nnest_spline_t *h, const float *x_dev, int M, float *
     const int tiles = grad_tiles(a);
     hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, grad_dev, h->gwsum, loss_dev,
                        -1.0f / (float)M, -1.0f);
-    hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts, -1.0f);
+    hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts, -1.0f);
     SHIP_TRY(hipGetLastError());
     return NNEST_OK;
 }
@@ -1021,7 +1033,7 @@ int nnest_spline_vjp(nnest_spline_t *h, const float *x_dev, const float *gz_dev,
     SHIP_TRY(launch_grad(a, st));
     hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, grad_tiles(a), ts, h->w_dev, grad_dev, h->gwsum,
                        (float *)nullptr, 0.f, (float)M * gld);
-    hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts,
+    hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts,
                        (float)M * gld);
     SHIP_TRY(hipGetLastError());
     return NNEST_OK;
@@ -1077,7 +1089,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             const int tiles = grad_tiles(a);
             hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, h->grad, h->gwsum,
                                h->losses_dev + mb, -1.0f / (float)M, -1.0f);
-            hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev + B * D, h->pi_dev, h->gwsum, h->grad, ts, -1.0f);
+            hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + B * D, h->pi_dev, h->gwsum, h->grad, ts, -1.0f);
             h->adam_step += 1;
             const double bc1 = 1.0 - pow(0.9, (double)h->adam_step), bc2 = 1.0 - pow(0.999, (double)h->adam_step);
             hipLaunchKernelGGL(spl_adam_kernel, dim3(256), dim3(256), 0, st, h->w_dev, h->grad, h->adam_m, h->adam_v, np,

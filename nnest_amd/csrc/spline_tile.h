@@ -286,6 +286,14 @@ __device__ __forceinline__ float spl_coupling(const float *__restrict__ net, int
     return ld;
 }
 
+// Values made opaque to the optimiser at the top of every block iteration of the TRAINING kernel.  The unrolled coupling
+// bodies derive dozens of masks and offsets from the lane index and the half sizes; all of them are invariant over the
+// blocks, so they were hoisted out of the loops, spilled (250-500 SGPRs, VGPR copies in scratch) and re-read one by one on
+// every iteration: over the three blocks of a gradient pass that cost more than recomputing them in place (1.3x on the
+// epoch).  The MH kernels run the same body 750 times per launch and keep the hoisting (made opaque there: 8.0 -> 11.6 ms).
+__device__ __forceinline__ int spl_opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ int spl_opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
+
 // ---- the stack -----------------------------------------------------------------------------------------------
 // xs[0] = lower half tiles, xs[1] = upper half tiles.  Returns this lane's log-det partial (sum over the 4 lanes of a
 // walker = the row's log-det); the per-block constants are added on lane group 0.
@@ -294,12 +302,13 @@ __device__ __forceinline__ float spline_forward_tile(const float *__restrict__ i
                                                      int wv = 0, f32x4 *xch = nullptr) {
     float ld = 0.f;
     for (int b = 0; b < s.B; ++b) {
+        const int nu = s.nu, nl = s.nl, SU = s.SU, SL = s.SL;
         const float *blk = img + (size_t)b * s.blk_floats;
         f32x4 y[2][NTh];
         spl_affine<NTh>(blk, lane, xs, y);
         const float *f1 = blk + 2 * s.aff_floats, *f2 = f1 + s.f1_floats;
-        ld += spl_coupling<NTh, NH, false, TEAM>(f1, s.SU, s.nu, s.tail, lane, y[0], y[1], wv, xch);   // upper | lower  (networks.py:582-588)
-        ld += spl_coupling<NTh, NH, false, TEAM>(f2, s.SL, s.nl, s.tail, lane, y[1], y[0], wv, xch);   // lower | new upper (:589-598)
+        ld += spl_coupling<NTh, NH, false, TEAM>(f1, SU, nu, s.tail, lane, y[0], y[1], wv, xch);   // upper | lower  (networks.py:582-588)
+        ld += spl_coupling<NTh, NH, false, TEAM>(f2, SL, nl, s.tail, lane, y[1], y[0], wv, xch);   // lower | new upper (:589-598)
         if (lane < 16 && wv == 0) ld += (f2 + s.f2_floats)[0];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -314,10 +323,11 @@ __device__ __forceinline__ float spline_inverse_tile(const float *__restrict__ i
                                                      int wv = 0, f32x4 *xch = nullptr) {
     float ld = 0.f;
     for (int b = s.B - 1; b >= 0; --b) {
+        const int nu = s.nu, nl = s.nl, SU = s.SU, SL = s.SL;
         const float *blk = img + (size_t)b * s.blk_floats;
         const float *f1 = blk + 2 * s.aff_floats, *f2 = f1 + s.f1_floats;
-        ld += spl_coupling<NTh, NH, true, TEAM>(f2, s.SL, s.nl, s.tail, lane, xs[1], xs[0], wv, xch);  // networks.py:605-614
-        ld += spl_coupling<NTh, NH, true, TEAM>(f1, s.SU, s.nu, s.tail, lane, xs[0], xs[1], wv, xch);  // :615-621
+        ld += spl_coupling<NTh, NH, true, TEAM>(f2, SL, nl, s.tail, lane, xs[1], xs[0], wv, xch);  // networks.py:605-614
+        ld += spl_coupling<NTh, NH, true, TEAM>(f1, SU, nu, s.tail, lane, xs[0], xs[1], wv, xch);  // :615-621
         f32x4 y[2][NTh];
         spl_affine<NTh>(blk + s.aff_floats, lane, xs, y);
         if (lane < 16 && wv == 0) ld -= (f2 + s.f2_floats)[0];
