@@ -51,7 +51,11 @@ __host__ __device__ inline int tslot_dim(const SplineShape &s, int hf, int t, in
 __host__ __device__ inline int trow_dim(const SplineShape &s, int hf, int t, int i) { return tslot_dim(s, hf, t, i & 3, i >> 2); }
 
 // ---- 1: W per block ---------------------------------------------------------------------------------------------
-__global__ void spl_assemble_kernel(const float *__restrict__ w, const int *__restrict__ pi, float *__restrict__ wmat, SplTrainShape ts) {
+// `stop` (every training kernel): the early-stopping flag of the running nnest_spline_train call, or NULL.  Once it is set,
+// the launches that are already queued leave the state as it is.
+__global__ void spl_assemble_kernel(const float *__restrict__ w, const int *__restrict__ pi, float *__restrict__ wmat, SplTrainShape ts,
+                                    const int *__restrict__ stop) {
+    if (stop && *stop) return;
     const int D = ts.s.D, n = ts.s.B * D * D;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
         const int b = idx / (D * D), i = (idx / D) % D, j = idx % D;
@@ -128,7 +132,9 @@ __device__ inline float cond_bwd_value(const SplineShape &s, const float *p, int
     }
 }
 
-__global__ void spl_timage_kernel(const float *__restrict__ w, const float *__restrict__ wmat, float *__restrict__ timg, SplTrainShape ts) {
+__global__ void spl_timage_kernel(const float *__restrict__ w, const float *__restrict__ wmat, float *__restrict__ timg, SplTrainShape ts,
+                                  const int *__restrict__ stop) {
+    if (stop && *stop) return;
     const SplineShape &s = ts.s;
     const int D = s.D, NTh = s.NTh, T2 = 2 * NTh;
     const long total = (long)ts.timage_floats;
@@ -185,6 +191,7 @@ struct SplGradArgs {
     const float *gz;    // VJP: upstream gradient [M, D]
     float *gx;          // VJP: gradient wrt the input rows [M, D]
     float gld_in;       // VJP: dL/d(logdet)
+    const int *stop;    // early-stopping flag (see spl_assemble_kernel) or NULL
     int rows_per_tile;  // 16, 8 or 4: a minibatch is only 100 rows, so the tiles are made shallower to spread them over
                         // more waves / CUs (the matrix-core columns of the unused walkers idle; the launch is latency-bound)
 };
@@ -438,6 +445,7 @@ template <int NTh, int NH>
 __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TEAM = SPL_TEAM;
+    if (a.stop && *a.stop) return;
     const SplTrainShape &ts = a.ts;
     const SplineShape &s = ts.s;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, w = lane & 15, g = lane >> 4, tile = blockIdx.x, lane_k = lane;
@@ -680,7 +688,8 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 // ---- 4: reduce ------------------------------------------------------------------------------------------------------
 __global__ void spl_reduce_kernel(const float *__restrict__ partial, int tiles, SplTrainShape ts, const float *__restrict__ w,
                                   float *__restrict__ grad, float *__restrict__ gwsum, float *__restrict__ loss_out, float loss_scale,
-                                  float ldw /* sum over rows of dL/d(logdet): -1 for loss = -mean(log_probs) */) {
+                                  float ldw /* sum over rows of dL/d(logdet): -1 for loss = -mean(log_probs) */, const int *__restrict__ stop) {
+    if (stop && *stop) return;
     const int np = ts.s.num_params, D = ts.s.D, n = ts.gw_floats;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float acc = 0.f;
@@ -702,7 +711,9 @@ __global__ void spl_reduce_kernel(const float *__restrict__ partial, int tiles, 
 
 // ---- 5: W = (P Lm) Um  ->  L, S, U -------------------------------------------------------------------------------------
 __global__ void spl_lu_grad_kernel(const float *__restrict__ w, const int *__restrict__ pi_inv, const int *__restrict__ pi,
-                                   const float *__restrict__ gwsum, float *__restrict__ grad, SplTrainShape ts, float ldw) {
+                                   const float *__restrict__ gwsum, float *__restrict__ grad, SplTrainShape ts, float ldw,
+                                   const int *__restrict__ stop) {
+    if (stop && *stop) return;  // (uniform: before the barrier)
     const int D = ts.s.D, per = 2 * D * D, n = ts.s.B * per;
     extern __shared__ int lu_perm[];  // [pi | pi_inv], B x D each: the permutation look-ups leave the dependent-load chains
     int *spi = lu_perm, *spi_inv = lu_perm + ts.s.B * D;
@@ -748,7 +759,8 @@ __global__ void spl_lu_grad_kernel(const float *__restrict__ w, const int *__res
 
 // ---- 6: Adam (torch/optim/adam.py _single_tensor_adam, coupled weight decay) -----------------------------------------------
 __global__ void spl_adam_kernel(float *__restrict__ w, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, int n,
-                                float step_size, float inv_bc2s, float wd) {
+                                float step_size, float inv_bc2s, float wd, const int *__restrict__ stop) {
+    if (stop && *stop) return;
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float gi = grad[i] + wd * w[i];
@@ -757,6 +769,37 @@ __global__ void spl_adam_kernel(float *__restrict__ w, const float *__restrict__
         m[i] = mi; v[i] = vi;
         w[i] = w[i] - step_size * (mi / (sqrtf(vi) * inv_bc2s + eps));
     }
+}
+
+// ---- 7: end of an epoch (trainer.py:198-232), on the device so that the host does not have to drain the stream per epoch ----
+struct SplTrainCtl {
+    float best, last_train;
+    int best_epoch, counter, epochs_run, stopped, improved;
+};
+
+__global__ void spl_epoch_end_kernel(SplTrainCtl *__restrict__ c, const float *__restrict__ losses, int n_mb, int n_train, int n_valid,
+                                     int epoch, int patience, float *__restrict__ epoch_losses) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || c->stopped) return;
+    float tl = 0.f;
+    for (int mb = 0; mb < n_mb; ++mb) tl += losses[mb];
+    const float train_loss = tl / (float)n_train;            // trainer.py:403
+    const float valid_loss = losses[n_mb] / (float)n_valid;  // trainer.py:418
+    epoch_losses[2 * epoch] = train_loss;
+    epoch_losses[2 * epoch + 1] = valid_loss;
+    c->last_train = train_loss;
+    c->epochs_run = epoch + 1;
+    const int improved = valid_loss < c->best;               // trainer.py:205-209
+    if (improved) { c->best = valid_loss; c->best_epoch = epoch + 1; c->counter = 0; }
+    c->improved = improved;
+    c->counter += 1;                                         // trainer.py:223-232
+    if (c->counter > patience) c->stopped = 1;
+}
+
+// best_model = deepcopy(netG) when the epoch improved the validation loss.  After the stop the weights no longer change and
+// a repeated copy is the same copy.
+__global__ void spl_keep_best_kernel(const SplTrainCtl *__restrict__ c, const float *__restrict__ w, float *__restrict__ best_w, int n) {
+    if (!c->improved) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) best_w[i] = w[i];
 }
 
 // ---- ActNorm data-dependent initialisation (networks.py:698-705): one workgroup, rows in tiles of 16 -------------------------
@@ -954,9 +997,9 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
 // the per-wave instruction stream does not shrink with fewer rows per tile (measured: no gain from 4-row tiles), so 16
 static int rows_per_tile(int M) { (void)M; return 16; }
 
-static int build_timage(nnest_spline *h, const SplTrainShape &ts, hipStream_t st) {
-    hipLaunchKernelGGL(spl_assemble_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev, h->wmat, ts);
-    hipLaunchKernelGGL(spl_timage_kernel, dim3(512), dim3(256), 0, st, h->w_dev, h->wmat, h->timg, ts);
+static int build_timage(nnest_spline *h, const SplTrainShape &ts, hipStream_t st, const int *stop = nullptr) {
+    hipLaunchKernelGGL(spl_assemble_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev, h->wmat, ts, stop);
+    hipLaunchKernelGGL(spl_timage_kernel, dim3(512), dim3(256), 0, st, h->w_dev, h->wmat, h->timg, ts, stop);
     SHIP_TRY(hipGetLastError());
     return NNEST_OK;
 }
@@ -1010,8 +1053,8 @@ int nnest_spline_loss_grad(nnest_spline_t *h, const float *x_dev, int M, float *
     SHIP_TRY(launch_grad(a, st));
     const int tiles = grad_tiles(a);
     hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, grad_dev, h->gwsum, loss_dev,
-                       -1.0f / (float)M, -1.0f);
-    hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts, -1.0f);
+                       -1.0f / (float)M, -1.0f, (const int *)nullptr);
+    hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts, -1.0f, (const int *)nullptr);
     SHIP_TRY(hipGetLastError());
     return NNEST_OK;
 }
@@ -1032,9 +1075,9 @@ int nnest_spline_vjp(nnest_spline_t *h, const float *x_dev, const float *gz_dev,
     a.rows_per_tile = rows_per_tile(M);
     SHIP_TRY(launch_grad(a, st));
     hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, grad_tiles(a), ts, h->w_dev, grad_dev, h->gwsum,
-                       (float *)nullptr, 0.f, (float)M * gld);
+                       (float *)nullptr, 0.f, (float)M * gld, (const int *)nullptr);
     hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts,
-                       (float)M * gld);
+                       (float)M * gld, (const int *)nullptr);
     SHIP_TRY(hipGetLastError());
     return NNEST_OK;
 }
@@ -1047,7 +1090,7 @@ int nnest_spline_adam_step(nnest_spline_t *h, const float *grad_dev, float lr, f
     h->adam_step += 1;
     const double bc1 = 1.0 - pow(0.9, (double)h->adam_step), bc2 = 1.0 - pow(0.999, (double)h->adam_step);
     hipLaunchKernelGGL(spl_adam_kernel, dim3(256), dim3(256), 0, st, h->w_dev, grad_dev, h->adam_m, h->adam_v, h->s.num_params,
-                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), weight_decay);
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), weight_decay, (const int *)nullptr);
     SHIP_TRY(hipGetLastError());
     return sync_to_host(h, st);
 }
@@ -1070,11 +1113,34 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
     if (n_mb + 1 > 1024) return spline_fail(NNEST_E_UNSUPPORTED, "more than 1023 minibatches per epoch");
     const size_t nb = (size_t)np * sizeof(float);
     SHIP_TRY(hipMemcpyAsync(h->best_w, h->w_dev, nb, hipMemcpyDeviceToDevice, st));  // best_model = deepcopy(netG)  trainer.py:194
-    float best = INFINITY;
-    int best_epoch = 0, counter = 0, epochs_run = 0, stopped = 0;
-    float last_train = 0.f;
-    std::vector<float> lh((size_t)n_mb + 1);
-    for (int epoch = 0; epoch < max_epochs; ++epoch) {
+    // The epoch bookkeeping (losses, best model, patience) runs on the device (spl_epoch_end_kernel): the host queues epochs
+    // without draining the stream and looks at the state once per chunk of epochs, one chunk behind the queue; launches queued
+    // past the stop do nothing.
+    if (!h->ctl_dev) {
+        SHIP_TRY(hipMalloc(&h->ctl_dev, sizeof(SplTrainCtl)));
+        SHIP_TRY(hipHostMalloc(&h->ctl_host, 2 * sizeof(SplTrainCtl), hipHostMallocDefault));
+    }
+    if (h->epoch_losses_cap < max_epochs) {
+        if (h->epoch_losses_dev) (void)hipFree(h->epoch_losses_dev);
+        h->epoch_losses_dev = nullptr; h->epoch_losses_cap = 0;
+        SHIP_TRY(hipMalloc((void **)&h->epoch_losses_dev, 2 * (size_t)(max_epochs > 0 ? max_epochs : 1) * sizeof(float)));
+        h->epoch_losses_cap = max_epochs;
+    }
+    SplTrainCtl *ctl = (SplTrainCtl *)h->ctl_dev, *snap = (SplTrainCtl *)h->ctl_host;
+    const int *stop = &ctl->stopped;
+    SplTrainCtl c0;
+    memset(&c0, 0, sizeof(c0));
+    c0.best = INFINITY;
+    snap[0] = c0; snap[1] = c0;
+    SHIP_TRY(hipMemcpyAsync(ctl, &snap[0], sizeof(SplTrainCtl), hipMemcpyHostToDevice, st));
+    const int adam_step0 = h->adam_step;
+    const int CHUNK = 8;
+    hipEvent_t ev[2];
+    SHIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    SHIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    int chunks = 0;
+    bool stopped_seen = false;
+    for (int epoch = 0; epoch < max_epochs && !stopped_seen; ++epoch) {
         for (int mb = 0; mb < n_mb; ++mb) {
             const int M = batch < n_train - mb * batch ? batch : n_train - mb * batch;
             SplGradArgs a;
@@ -1082,50 +1148,56 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = xtrain_dev; a.perm = perm_dev + (size_t)epoch * n_train + (size_t)mb * batch;
             a.M = M; a.mtot = M; a.noise = noise_dev ? noise_dev + ((size_t)epoch * n_train + (size_t)mb * batch) * D : nullptr;
             a.seed = seed; a.noise_row0 = (long)mb * batch; a.epoch = epoch; a.jitter = jitter;
-            a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_GRAD;
+            a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_GRAD; a.stop = stop;
             a.rows_per_tile = rows_per_tile(M);
-            if ((rc = build_timage(h, ts, st))) return rc;
+            // (the image of the validation pass that closed the previous epoch is still the current one)
+            if (mb > 0 || epoch == 0) { if ((rc = build_timage(h, ts, st, stop))) return rc; }
             SHIP_TRY(launch_grad(a, st));
             const int tiles = grad_tiles(a);
             hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, h->grad, h->gwsum,
-                               h->losses_dev + mb, -1.0f / (float)M, -1.0f);
-            hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + B * D, h->pi_dev, h->gwsum, h->grad, ts, -1.0f);
+                               h->losses_dev + mb, -1.0f / (float)M, -1.0f, stop);
+            hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + B * D, h->pi_dev, h->gwsum, h->grad, ts, -1.0f, stop);
             h->adam_step += 1;
             const double bc1 = 1.0 - pow(0.9, (double)h->adam_step), bc2 = 1.0 - pow(0.999, (double)h->adam_step);
             hipLaunchKernelGGL(spl_adam_kernel, dim3(256), dim3(256), 0, st, h->w_dev, h->grad, h->adam_m, h->adam_v, np,
-                               (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), weight_decay);
+                               (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), weight_decay, stop);
         }
         // Trainer._validate (trainer.py:405-418): one full batch; mean, then / len(dataset)
-        if ((rc = build_timage(h, ts, st))) return rc;
+        if ((rc = build_timage(h, ts, st, stop))) return rc;
         {
             SplGradArgs a;
             memset(&a, 0, sizeof(a));
             a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = xvalid_dev; a.M = n_valid; a.mtot = n_valid;
-            a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_LOSS;
+            a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_LOSS; a.stop = stop;
             a.rows_per_tile = rows_per_tile(n_valid);
             SHIP_TRY(launch_grad(a, st));
             hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, grad_tiles(a), ts, h->w_dev, h->grad,
-                               h->gwsum, h->losses_dev + n_mb, -1.0f / (float)n_valid, -1.0f);
+                               h->gwsum, h->losses_dev + n_mb, -1.0f / (float)n_valid, -1.0f, stop);
         }
-        SHIP_TRY(hipMemcpyAsync(lh.data(), h->losses_dev, ((size_t)n_mb + 1) * sizeof(float), hipMemcpyDeviceToHost, st));
-        SHIP_TRY(hipStreamSynchronize(st));
-        float tl = 0.f;
-        for (int mb = 0; mb < n_mb; ++mb) tl += lh[mb];
-        const float train_loss = tl / (float)n_train;          // trainer.py:403
-        const float valid_loss = lh[n_mb] / (float)n_valid;    // trainer.py:418
-        last_train = train_loss;
-        epochs_run = epoch + 1;
-        if (losses_host) { losses_host[2 * epoch] = train_loss; losses_host[2 * epoch + 1] = valid_loss; }
-        if (valid_loss < best) {                                // trainer.py:205-209
-            best = valid_loss; best_epoch = epoch + 1; counter = 0;
-            SHIP_TRY(hipMemcpyAsync(h->best_w, h->w_dev, nb, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(64), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch, patience,
+                           h->epoch_losses_dev);
+        hipLaunchKernelGGL(spl_keep_best_kernel, dim3(128), dim3(256), 0, st, ctl, h->w_dev, h->best_w, np);
+        SHIP_TRY(hipGetLastError());
+        if ((epoch + 1) % CHUNK == 0 && epoch + 1 < max_epochs) {
+            SHIP_TRY(hipMemcpyAsync(&snap[chunks & 1], ctl, sizeof(SplTrainCtl), hipMemcpyDeviceToHost, st));
+            SHIP_TRY(hipEventRecord(ev[chunks & 1], st));
+            if (chunks > 0) {  // the state after the chunk before this one
+                SHIP_TRY(hipEventSynchronize(ev[(chunks - 1) & 1]));
+                stopped_seen = snap[(chunks - 1) & 1].stopped != 0;
+            }
+            chunks += 1;
         }
-        counter += 1;                                           // trainer.py:223-232
-        if (counter > patience) { stopped = 1; break; }
     }
     SHIP_TRY(hipMemcpyAsync(h->w_dev, h->best_w, nb, hipMemcpyDeviceToDevice, st));  // netG.load_state_dict(best_model)  trainer.py:241
-    result_host->epochs_run = epochs_run; result_host->best_epoch = best_epoch; result_host->best_validation_loss = best;
-    result_host->last_train_loss = last_train; result_host->counter = counter; result_host->stopped = stopped;
+    SHIP_TRY(hipMemcpyAsync(&snap[0], ctl, sizeof(SplTrainCtl), hipMemcpyDeviceToHost, st));
+    SHIP_TRY(hipStreamSynchronize(st));
+    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    const SplTrainCtl fin = snap[0];
+    if (losses_host && fin.epochs_run > 0)
+        SHIP_TRY(hipMemcpy(losses_host, h->epoch_losses_dev, 2 * (size_t)fin.epochs_run * sizeof(float), hipMemcpyDeviceToHost));
+    h->adam_step = adam_step0 + fin.epochs_run * n_mb;  // the steps queued past the stop did not happen
+    result_host->epochs_run = fin.epochs_run; result_host->best_epoch = fin.best_epoch; result_host->best_validation_loss = fin.best;
+    result_host->last_train_loss = fin.last_train; result_host->counter = fin.counter; result_host->stopped = fin.stopped;
     return sync_to_host(h, st);
 }
 

@@ -20,6 +20,10 @@ struct nnest_spline {
     float *gwsum;             // reduced dLoss/dW of the convs [B][D][D]
     float *stash;             // block inputs of the forward pass
     float *losses_dev;        // per-step losses of an epoch + validation
+    void *ctl_dev;            // SplTrainCtl: the early-stopping state of a training call (kept on the device)
+    void *ctl_host;           // pinned: two snapshots of it
+    float *epoch_losses_dev;  // [2 * epoch_losses_cap]: train / validation loss per epoch
+    int epoch_losses_cap;
     int partial_tiles;
     int adam_step;
     bool w_dev_current;       // w_dev holds the same weights as w

@@ -39,8 +39,10 @@ def main():
             print('K4-spline D=%d walkers=%d steps=%d: %.3f ms per launch -> %.3e evals/s (accept %.2f)' % (
                 D, C, S, ms, C * S / (ms * 1e-3), float(res['n_accept'].sum()) / (C * S)))
         # training
-        E = 20
+        E = 40
         perms = torch.stack([torch.randperm(900) for _ in range(E)]).int()
+        sp.train_epochs(live[100:], live[:100], perms[:2], None, seed=1, jitter=0.01, batch=100, max_epochs=2, patience=50)  # allocations
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = sp.train_epochs(live[100:], live[:100], perms, None, seed=1, jitter=0.01, batch=100, max_epochs=E, patience=50)
         torch.cuda.synchronize()
