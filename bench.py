@@ -214,6 +214,17 @@ def main():
             out['spline_flow'] = {'kernel': 'spline_mh_kernel_team' if (C + 15) // 16 <= 2 * info['num_cu'] else 'spline_mh_kernel',
                                   'kernel_ms': ms, 'evals_per_s': C * S / (ms * 1e-3),
                                   'note': 'SingleSpeedSpline hidden=%d blocks=%d bins=8; VALU-bound on the spline arithmetic' % (H, B)}
+            if C >= 200:  # its training epoch at this population (90 % train / 10 % validation, batch 100: trainer.py:159-176)
+                nv = C // 10
+                E = 20
+                perms = torch.stack([torch.randperm(C - nv) for _ in range(E)]).int()
+                kw = dict(seed=1, jitter=0.01, batch=100, patience=50)
+                sp.train_epochs(u0[nv:], u0[:nv], perms[:2], None, max_epochs=2, **kw)   # allocations
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                res = sp.train_epochs(u0[nv:], u0[:nv], perms, None, max_epochs=E, **kw)
+                torch.cuda.synchronize(dev)
+                out['spline_flow']['train_ms_per_epoch'] = (time.perf_counter() - t0) / max(1, res['epochs_run']) * 1e3
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(D, H, B, L, nvp.store_packed(), C)
         print(json.dumps(out))
