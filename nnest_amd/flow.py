@@ -31,6 +31,8 @@ def _as_dev_f32(x, device):
     cast) with numpy and go through one pinned staging buffer; torch's own host-side cast/copy goes through its CPU thread
     pool, which on a many-core host measured 3-6 ms per call inside a run (tools/run_timing.py) against 0.1 ms here."""
     device = torch.device(device)
+    if torch.is_tensor(x) and x.device.type == 'cpu' and device.type == 'cuda':
+        x = x.detach().numpy()
     if not torch.is_tensor(x) and device.type == 'cuda':
         a = np.ascontiguousarray(x, dtype=np.float32)
         if a.ndim == 1:
