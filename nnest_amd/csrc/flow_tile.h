@@ -90,6 +90,14 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Fragment image addressing.  The four K-step fragments (r = 0..3) of one (output tile, input tile) pair -- fragment numbers
+// 4q .. 4q+3 -- sit together per lane: element (fragment idx, lane) is at ((idx >> 2) * 64 + lane) * 4 + (idx & 3) of its
+// (block, net) region, so one 16-byte read (ds_read_b128 from the LDS copy) feeds four MFMAs instead of four 4-byte reads.
+__host__ __device__ inline int frag_elem(int idx, int lane) { return (((idx >> 2) * 64 + lane) << 2) + (idx & 3); }
+__device__ __forceinline__ f32x4 frag_quad(const float *__restrict__ region_lane /* region + 4 * lane */, int q) {
+    return *reinterpret_cast<const f32x4 *>(region_lane + q * 256);
+}
+
 // One MLP of a coupling layer (networks.py:271-282) on a 16-walker tile.
 //   wn   : base of this (block, net) in the fragment image (LDS or global)
 //   in   : conditioning-class tiles; out: transformed-class tiles (ls or t), both in C/D layout
@@ -97,9 +105,9 @@ template <int NT, int NH, int ACT>
 __device__ __forceinline__ void mlp_tile(const float *__restrict__ wn, int L, int lane, const f32x4 (&in)[NT],
                                          f32x4 (&out)[NT]) {
     const int g4 = (lane >> 4) * 4;
-    const float *fL1 = wn + frag_off_L1() + lane;
-    const float *fL2 = wn + frag_off_L2(NT, NH) + lane;
-    const float *fL3 = wn + frag_off_L3(NT, NH, L) + lane;
+    const float *fL1 = wn + frag_off_L1() + 4 * lane;
+    const float *fL2 = wn + frag_off_L2(NT, NH) + 4 * lane;
+    const float *fL3 = wn + frag_off_L3(NT, NH, L) + 4 * lane;
     const float *b1 = wn + frag_off_b1(NT, NH, L) + g4;
     const float *b2 = wn + frag_off_b2(NT, NH, L) + g4;
     const float *b3 = wn + frag_off_b3(NT, NH, L) + g4;
@@ -109,11 +117,11 @@ __device__ __forceinline__ void mlp_tile(const float *__restrict__ wn, int L, in
         f32x4 acc = *reinterpret_cast<const f32x4 *>(b1 + 16 * ht);
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
-            const float *f = fL1 + ((ht * NT + tau) * 4) * 64;
-            acc = mfma4(f[0], in[tau].x, acc);
-            acc = mfma4(f[64], in[tau].y, acc);
-            acc = mfma4(f[128], in[tau].z, acc);
-            acc = mfma4(f[192], in[tau].w, acc);
+            const f32x4 f = frag_quad(fL1, ht * NT + tau);
+            acc = mfma4(f.x, in[tau].x, acc);
+            acc = mfma4(f.y, in[tau].y, acc);
+            acc = mfma4(f.z, in[tau].z, acc);
+            acc = mfma4(f.w, in[tau].w, acc);
         }
         h[ht] = activate<ACT>(acc);
     }
@@ -124,11 +132,11 @@ __device__ __forceinline__ void mlp_tile(const float *__restrict__ wn, int L, in
             f32x4 acc = *reinterpret_cast<const f32x4 *>(b2 + (l * NH + hto) * 16);
 #pragma unroll
             for (int hti = 0; hti < NH; ++hti) {
-                const float *f = fL2 + (((l * NH + hto) * NH + hti) * 4) * 64;
-                acc = mfma4(f[0], h[hti].x, acc);
-                acc = mfma4(f[64], h[hti].y, acc);
-                acc = mfma4(f[128], h[hti].z, acc);
-                acc = mfma4(f[192], h[hti].w, acc);
+                const f32x4 f = frag_quad(fL2, (l * NH + hto) * NH + hti);
+                acc = mfma4(f.x, h[hti].x, acc);
+                acc = mfma4(f.y, h[hti].y, acc);
+                acc = mfma4(f.z, h[hti].z, acc);
+                acc = mfma4(f.w, h[hti].w, acc);
             }
             h2[hto] = activate<ACT>(acc);
         }
@@ -140,11 +148,11 @@ __device__ __forceinline__ void mlp_tile(const float *__restrict__ wn, int L, in
         f32x4 acc = *reinterpret_cast<const f32x4 *>(b3 + 16 * tau);
 #pragma unroll
         for (int ht = 0; ht < NH; ++ht) {
-            const float *f = fL3 + ((tau * NH + ht) * 4) * 64;
-            acc = mfma4(f[0], h[ht].x, acc);
-            acc = mfma4(f[64], h[ht].y, acc);
-            acc = mfma4(f[128], h[ht].z, acc);
-            acc = mfma4(f[192], h[ht].w, acc);
+            const f32x4 f = frag_quad(fL3, tau * NH + ht);
+            acc = mfma4(f.x, h[ht].x, acc);
+            acc = mfma4(f.y, h[ht].y, acc);
+            acc = mfma4(f.z, h[ht].z, acc);
+            acc = mfma4(f.w, h[ht].w, acc);
         }
         out[tau] = acc;
     }
@@ -186,10 +194,12 @@ __device__ __forceinline__ float coupling_tile(const float *__restrict__ wblk, i
 // K-accumulation is split over two accumulators, so four independent chains are in flight per layer.
 // Fragment accessors: fragment number idx within one (block, net) -- L1 [o][tau][r], then L2 [l][o][i][r],
 // then L3 [tau][i][r] -- read either from the image (LDS or global; pointer already offset by the lane) or from
-// a per-lane register array filled once per kernel.
+// a per-lane register array filled once per kernel (image element of fragment idx for a lane: frag_elem).
 struct ImageFrags {
-    const float *p;
-    __device__ __forceinline__ float operator()(int idx) const { return p[idx * 64]; }
+    const float *p;  // (block, net) region + 4 * lane, 16-byte aligned
+    __device__ __forceinline__ float operator()(int idx) const {
+        return static_cast<const float *>(__builtin_assume_aligned(p, 16))[(idx >> 2) * 256 + (idx & 3)];
+    }
 };
 template <int N> struct RegFrags {
     float v[N];
@@ -407,7 +417,7 @@ __device__ __forceinline__ float affine_update(const f32x4 (&ls)[NT], const f32x
 template <int NT, int NH, int L, bool INVERSE>
 __device__ __forceinline__ float coupling_tile_il(const float *__restrict__ wblk, int net_floats, int lane,
                                                   const f32x4 (&cond)[NT], f32x4 (&trans)[NT]) {
-    ImageFrags fs = {wblk + lane}, ft = {wblk + net_floats + lane};
+    ImageFrags fs = {wblk + 4 * lane}, ft = {wblk + net_floats + 4 * lane};
     const int ob = frag_off_b1(NT, NH, L);
     return coupling_core<NT, NH, L, INVERSE>(fs, ft, wblk + ob, wblk + net_floats + ob, lane, cond, trans);
 }

@@ -30,20 +30,20 @@ __global__ void repack_fragments_kernel(const float *__restrict__ packed, float 
         const int pc = (b + 1) & 1, pt = b & 1;  // conditioning / transformed parity class of block b
         const int pW0 = 0, pb0 = H * D, phid = H * D + H, pWo = H * D + H + L * (H * H + H), pbo = pWo + D * H;
         float v = 0.f;
-        if (o < frag_off_L2(NT, NH)) {  // L1 [ht][tau][r][lane]
-            int lane = o & 63, q = o >> 6, r = q & 3, tau = (q >> 2) % NT, ht = (q >> 2) / NT;
+        if (o < frag_off_L2(NT, NH)) {  // L1 [ht][tau][lane][r]
+            int r = o & 3, lane = (o >> 2) & 63, q = (o >> 8) << 2, tau = (q >> 2) % NT, ht = (q >> 2) / NT;
             int g = lane >> 4, i = lane & 15;
             int j = 16 * ht + i, d = 2 * (16 * tau + 4 * g + r) + pc;
             if (d < D) v = p[pW0 + j * D + d];
-        } else if (o < frag_off_L3(NT, NH, L)) {  // L2 [l][hto][hti][r][lane]
+        } else if (o < frag_off_L3(NT, NH, L)) {  // L2 [l][hto][hti][lane][r]
             int oo = o - frag_off_L2(NT, NH);
-            int lane = oo & 63, q = oo >> 6, r = q & 3, hti = (q >> 2) % NH, hto = ((q >> 2) / NH) % NH,
+            int r = oo & 3, lane = (oo >> 2) & 63, q = (oo >> 8) << 2, hti = (q >> 2) % NH, hto = ((q >> 2) / NH) % NH,
                 l = (q >> 2) / (NH * NH);
             int g = lane >> 4, i = lane & 15;
             v = p[phid + l * (H * H + H) + (16 * hto + i) * H + 16 * hti + 4 * g + r];
-        } else if (o < frag_off_b1(NT, NH, L)) {  // L3 [tau][ht][r][lane]
+        } else if (o < frag_off_b1(NT, NH, L)) {  // L3 [tau][ht][lane][r]
             int oo = o - frag_off_L3(NT, NH, L);
-            int lane = oo & 63, q = oo >> 6, r = q & 3, ht = (q >> 2) % NH, tau = (q >> 2) / NH;
+            int r = oo & 3, lane = (oo >> 2) & 63, q = (oo >> 8) << 2, ht = (q >> 2) % NH, tau = (q >> 2) / NH;
             int g = lane >> 4, i = lane & 15;
             int d = 2 * (16 * tau + i) + pt;
             if (d < D) v = p[pWo + d * H + 16 * ht + 4 * g + r];
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(64) mh_kernel_reg(MhArgs a) {
         for (int n = 0; n < 2; ++n) {
             const float *src = a.img + (size_t)(b * 2 + n) * net_floats;
 #pragma unroll
-            for (int i = 0; i < RI::FC::N; ++i) inv.w[b][n].v[i] = src[i * 64 + lane];
+            for (int i = 0; i < RI::FC::N; ++i) inv.w[b][n].v[i] = src[frag_elem(i, lane)];
             for (int i = lane; i < RI::NBIAS; i += 64) bias_lds[(b * 2 + n) * RI::NBIAS + i] = src[frag_off_b1(NT, NH, L) + i];
         }
     __syncthreads();
@@ -463,7 +463,7 @@ struct TeamInverse {
     typedef FragCount<NT, 1, L> FC;
     static constexpr int NBIAS = 16 * (1 + L) + 16 * NT;
     RegFrags<WREG ? FC::N : 1> w[B];  // this wave's net only
-    const float *wl;       // !WREG: LDS image + lane
+    const float *wl;       // !WREG: LDS image + 4 * lane
     int net_floats;
     const float *bias;     // LDS [b][net][NBIAS]
     f32x4 *xch;            // LDS [parity][net][NT][64 lanes]
@@ -582,14 +582,14 @@ __global__ void __launch_bounds__(192, 2) mh_kernel_team(MhArgs a) {  // min 2 w
 #ifdef NNEST_STAMP
     inv.t_mlp = inv.t_xch = inv.t_upd = 0;
 #endif
-    inv.wl = team_img + lane;
+    inv.wl = team_img + 4 * lane;
     inv.net_floats = net_floats;
     if constexpr (WREG) {
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             const float *src = a.img + (size_t)(b * 2 + role) * net_floats;
 #pragma unroll
-            for (int i = 0; i < TI::FC::N; ++i) inv.w[b].v[i] = src[i * 64 + lane];
+            for (int i = 0; i < TI::FC::N; ++i) inv.w[b].v[i] = src[frag_elem(i, lane)];
         }
     }
     LdsNoise<NT> noise = {nbuf, ubuf, lane, 0};

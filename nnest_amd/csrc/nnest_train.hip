@@ -76,17 +76,17 @@ __host__ __device__ inline int fwd_image_src(const FlowShape &s, int idx) {
     const int pc = (b + 1) & 1, pt = b & 1;
     const int pb0 = H * D, phid = H * D + H, pWo = H * D + H + L * (H * H + H), pbo = pWo + D * H;
     if (o < frag_off_L2(NT, NH)) {
-        int lane = o & 63, q = o >> 6, r = q & 3, tau = (q >> 2) % NT, ht = (q >> 2) / NT;
+        int r = o & 3, lane = (o >> 2) & 63, q = (o >> 8) << 2, tau = (q >> 2) % NT, ht = (q >> 2) / NT;
         int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + 4 * g + r) + pc;
         return d < D ? base + (16 * ht + i) * D + d : -1;
     } else if (o < frag_off_L3(NT, NH, L)) {
         int oo = o - frag_off_L2(NT, NH);
-        int lane = oo & 63, q = oo >> 6, r = q & 3, hti = (q >> 2) % NH, hto = ((q >> 2) / NH) % NH, l = (q >> 2) / (NH * NH);
+        int r = oo & 3, lane = (oo >> 2) & 63, q = (oo >> 8) << 2, hti = (q >> 2) % NH, hto = ((q >> 2) / NH) % NH, l = (q >> 2) / (NH * NH);
         int g = lane >> 4, i = lane & 15;
         return base + phid + l * (H * H + H) + (16 * hto + i) * H + 16 * hti + 4 * g + r;
     } else if (o < frag_off_b1(NT, NH, L)) {
         int oo = o - frag_off_L3(NT, NH, L);
-        int lane = oo & 63, q = oo >> 6, r = q & 3, ht = (q >> 2) % NH, tau = (q >> 2) / NH;
+        int r = oo & 3, lane = (oo >> 2) & 63, q = (oo >> 8) << 2, ht = (q >> 2) % NH, tau = (q >> 2) / NH;
         int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + i) + pt;
         return d < D ? base + pWo + d * H + 16 * ht + 4 * g + r : -1;
     } else if (o < frag_off_b2(NT, NH, L)) {
@@ -112,17 +112,17 @@ __host__ __device__ inline int bwd_image_src(const FlowShape &s, int idx) {
     const int pc = (b + 1) & 1, pt = b & 1;
     const int phid = H * D + H, pWo = H * D + H + L * (H * H + H);
     if (o < frag_off_L2(NT, NH)) {
-        int lane = o & 63, q = o >> 6, r = q & 3, tau = (q >> 2) % NT, ht = (q >> 2) / NT;
+        int r = o & 3, lane = (o >> 2) & 63, q = (o >> 8) << 2, tau = (q >> 2) % NT, ht = (q >> 2) / NT;
         int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + 4 * g + r) + pt;
         return d < D ? base + pWo + d * H + 16 * ht + i : -1;
     } else if (o < frag_off_L3(NT, NH, L)) {
         int oo = o - frag_off_L2(NT, NH);
-        int lane = oo & 63, q = oo >> 6, r = q & 3, hto = (q >> 2) % NH, hti = ((q >> 2) / NH) % NH, l = (q >> 2) / (NH * NH);
+        int r = oo & 3, lane = (oo >> 2) & 63, q = (oo >> 8) << 2, hto = (q >> 2) % NH, hti = ((q >> 2) / NH) % NH, l = (q >> 2) / (NH * NH);
         int g = lane >> 4, i = lane & 15;
         return base + phid + l * (H * H + H) + (16 * hto + 4 * g + r) * H + 16 * hti + i;
     } else if (o < frag_off_b1(NT, NH, L)) {
         int oo = o - frag_off_L3(NT, NH, L);
-        int lane = oo & 63, q = oo >> 6, r = q & 3, ht = (q >> 2) % NH, tau = (q >> 2) / NH;
+        int r = oo & 3, lane = (oo >> 2) & 63, q = (oo >> 8) << 2, ht = (q >> 2) % NH, tau = (q >> 2) / NH;
         int g = lane >> 4, i = lane & 15, d = 2 * (16 * tau + i) + pc;
         return d < D ? base + (16 * ht + 4 * g + r) * D + d : -1;
     }
@@ -169,9 +169,9 @@ template <int NT, int NH, int L, int ACT>
 __device__ __forceinline__ void mlp_fwd_keep(const float *__restrict__ wn, int lane, const f32x4 (&in)[NT],
                                              f32x4 (&acts)[L + 1][NH], f32x4 (&out)[NT]) {
     const int g4 = (lane >> 4) * 4;
-    const float *fL1 = wn + frag_off_L1() + lane;
-    const float *fL2 = wn + frag_off_L2(NT, NH) + lane;
-    const float *fL3 = wn + frag_off_L3(NT, NH, L) + lane;
+    const float *fL1 = wn + frag_off_L1() + 4 * lane;
+    const float *fL2 = wn + frag_off_L2(NT, NH) + 4 * lane;
+    const float *fL3 = wn + frag_off_L3(NT, NH, L) + 4 * lane;
     const float *b1 = wn + frag_off_b1(NT, NH, L) + g4;
     const float *b2 = wn + frag_off_b2(NT, NH, L) + g4;
     const float *b3 = wn + frag_off_b3(NT, NH, L) + g4;
@@ -180,11 +180,11 @@ __device__ __forceinline__ void mlp_fwd_keep(const float *__restrict__ wn, int l
         f32x4 acc = *reinterpret_cast<const f32x4 *>(b1 + 16 * ht);
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
-            const float *f = fL1 + ((ht * NT + tau) * 4) * 64;
-            acc = mfma4(f[0], in[tau].x, acc);
-            acc = mfma4(f[64], in[tau].y, acc);
-            acc = mfma4(f[128], in[tau].z, acc);
-            acc = mfma4(f[192], in[tau].w, acc);
+            const f32x4 f = frag_quad(fL1, (ht * NT + tau));
+            acc = mfma4(f.x, in[tau].x, acc);
+            acc = mfma4(f.y, in[tau].y, acc);
+            acc = mfma4(f.z, in[tau].z, acc);
+            acc = mfma4(f.w, in[tau].w, acc);
         }
         acts[0][ht] = activate<ACT>(acc);
     }
@@ -195,11 +195,11 @@ __device__ __forceinline__ void mlp_fwd_keep(const float *__restrict__ wn, int l
             f32x4 acc = *reinterpret_cast<const f32x4 *>(b2 + (l * NH + hto) * 16);
 #pragma unroll
             for (int hti = 0; hti < NH; ++hti) {
-                const float *f = fL2 + (((l * NH + hto) * NH + hti) * 4) * 64;
-                acc = mfma4(f[0], acts[l][hti].x, acc);
-                acc = mfma4(f[64], acts[l][hti].y, acc);
-                acc = mfma4(f[128], acts[l][hti].z, acc);
-                acc = mfma4(f[192], acts[l][hti].w, acc);
+                const f32x4 f = frag_quad(fL2, ((l * NH + hto) * NH + hti));
+                acc = mfma4(f.x, acts[l][hti].x, acc);
+                acc = mfma4(f.y, acts[l][hti].y, acc);
+                acc = mfma4(f.z, acts[l][hti].z, acc);
+                acc = mfma4(f.w, acts[l][hti].w, acc);
             }
             acts[l + 1][hto] = activate<ACT>(acc);
         }
@@ -209,11 +209,11 @@ __device__ __forceinline__ void mlp_fwd_keep(const float *__restrict__ wn, int l
         f32x4 acc = *reinterpret_cast<const f32x4 *>(b3 + 16 * tau);
 #pragma unroll
         for (int ht = 0; ht < NH; ++ht) {
-            const float *f = fL3 + ((tau * NH + ht) * 4) * 64;
-            acc = mfma4(f[0], acts[L][ht].x, acc);
-            acc = mfma4(f[64], acts[L][ht].y, acc);
-            acc = mfma4(f[128], acts[L][ht].z, acc);
-            acc = mfma4(f[192], acts[L][ht].w, acc);
+            const f32x4 f = frag_quad(fL3, (tau * NH + ht));
+            acc = mfma4(f.x, acts[L][ht].x, acc);
+            acc = mfma4(f.y, acts[L][ht].y, acc);
+            acc = mfma4(f.z, acts[L][ht].z, acc);
+            acc = mfma4(f.w, acts[L][ht].w, acc);
         }
         out[tau] = acc;
     }
@@ -252,9 +252,9 @@ template <int NT, int NH, int L, int ACT>
 __device__ __forceinline__ void mlp_bwd(const float *__restrict__ bn, int lane, float *stg, int rows_pad, int row,
                                         const f32x4 (&g_out)[NT], const f32x4 (&acts)[L + 1][NH], f32x4 (&g_m)[NT]) {
     typedef StageMap<NT, NH, L> SM;
-    const float *B3 = bn + frag_off_L1() + lane;
-    const float *B2 = bn + frag_off_L2(NT, NH) + lane;
-    const float *B1 = bn + frag_off_L3(NT, NH, L) + lane;
+    const float *B3 = bn + frag_off_L1() + 4 * lane;
+    const float *B2 = bn + frag_off_L2(NT, NH) + 4 * lane;
+    const float *B1 = bn + frag_off_L3(NT, NH, L) + 4 * lane;
     f32x4 gh[NH];
 #pragma unroll
     for (int tau = 0; tau < NT; ++tau) stage_tile(stg, rows_pad, SM::gout(tau), row, lane, g_out[tau]);
@@ -263,11 +263,11 @@ __device__ __forceinline__ void mlp_bwd(const float *__restrict__ bn, int lane, 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
-            const float *f = B3 + ((ht * NT + tau) * 4) * 64;
-            acc = mfma4(f[0], g_out[tau].x, acc);
-            acc = mfma4(f[64], g_out[tau].y, acc);
-            acc = mfma4(f[128], g_out[tau].z, acc);
-            acc = mfma4(f[192], g_out[tau].w, acc);
+            const f32x4 f = frag_quad(B3, (ht * NT + tau));
+            acc = mfma4(f.x, g_out[tau].x, acc);
+            acc = mfma4(f.y, g_out[tau].y, acc);
+            acc = mfma4(f.z, g_out[tau].z, acc);
+            acc = mfma4(f.w, g_out[tau].w, acc);
         }
         gh[ht] = acc;
     }
@@ -285,11 +285,11 @@ __device__ __forceinline__ void mlp_bwd(const float *__restrict__ bn, int lane, 
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hto = 0; hto < NH; ++hto) {
-                const float *f = B2 + ((((l - 1) * NH + hti) * NH + hto) * 4) * 64;
-                acc = mfma4(f[0], gpre[hto].x, acc);
-                acc = mfma4(f[64], gpre[hto].y, acc);
-                acc = mfma4(f[128], gpre[hto].z, acc);
-                acc = mfma4(f[192], gpre[hto].w, acc);
+                const f32x4 f = frag_quad(B2, (((l - 1) * NH + hti) * NH + hto));
+                acc = mfma4(f.x, gpre[hto].x, acc);
+                acc = mfma4(f.y, gpre[hto].y, acc);
+                acc = mfma4(f.z, gpre[hto].z, acc);
+                acc = mfma4(f.w, gpre[hto].w, acc);
             }
             gh[hti] = acc;
         }
@@ -306,11 +306,11 @@ __device__ __forceinline__ void mlp_bwd(const float *__restrict__ bn, int lane, 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ht = 0; ht < NH; ++ht) {
-            const float *f = B1 + ((tau * NH + ht) * 4) * 64;
-            acc = mfma4(f[0], gpre0[ht].x, acc);
-            acc = mfma4(f[64], gpre0[ht].y, acc);
-            acc = mfma4(f[128], gpre0[ht].z, acc);
-            acc = mfma4(f[192], gpre0[ht].w, acc);
+            const f32x4 f = frag_quad(B1, (tau * NH + ht));
+            acc = mfma4(f.x, gpre0[ht].x, acc);
+            acc = mfma4(f.y, gpre0[ht].y, acc);
+            acc = mfma4(f.z, gpre0[ht].z, acc);
+            acc = mfma4(f.w, gpre0[ht].w, acc);
         }
         g_m[tau] = acc;
     }
