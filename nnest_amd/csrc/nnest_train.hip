@@ -42,6 +42,7 @@ static const int TRAIN_MAX_ROWS = 128;
 
 struct TrainArgs {
     float *w, *m, *v, *best_w, *img_fwd, *img_bwd, *grad;
+    float *stash;  // hidden activations of the forward pass, [TRAIN_WAVES][B][2][L+1][NH][64] f32x4 (block_backward reads them back)
     const int *fwd_pos, *bwd_pos;
     int *adam_step;
     FlowShape s;
@@ -246,6 +247,59 @@ template <int NT, int NH, int L> struct StageMap {
     static constexpr int m(int tau) { return NT + 2 * (L + 1) * NH + tau; }
     static constexpr int count = 2 * NT + 2 * (L + 1) * NH;
 };
+
+// the last Linear of mlp_fwd_keep alone, from kept activations (same accumulation order)
+template <int NT, int NH, int L>
+__device__ __forceinline__ void mlp_out_layer(const float *__restrict__ wn, int lane, const f32x4 (&hl)[NH], f32x4 (&out)[NT]) {
+    const int g4 = (lane >> 4) * 4;
+    const float *fL3 = wn + frag_off_L3(NT, NH, L) + 4 * lane;
+    const float *b3 = wn + frag_off_b3(NT, NH, L) + g4;
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(b3 + 16 * tau);
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) {
+            const f32x4 f = frag_quad(fL3, (tau * NH + ht));
+            acc = mfma4(f.x, hl[ht].x, acc);
+            acc = mfma4(f.y, hl[ht].y, acc);
+            acc = mfma4(f.z, hl[ht].z, acc);
+            acc = mfma4(f.w, hl[ht].w, acc);
+        }
+        out[tau] = acc;
+    }
+}
+
+// One block of the training forward pass (CouplingLayer.forward, networks.py:289-298) that leaves the hidden activations of
+// both nets in `stash` (this wave's slice for block b: [net][l][ht][64] f32x4, global memory / L2): the backward pass used
+// to recompute both MLPs from the block input, two of whose three layers this saves.
+template <int NT, int NH, int L>
+__device__ __forceinline__ float block_forward_keep(const float *__restrict__ wf, int net_floats, bool affine, int lane,
+                                                    const f32x4 (&cond)[NT], f32x4 (&trans)[NT], f32x4 *__restrict__ stash) {
+    f32x4 as[L + 1][NH], at[L + 1][NH], ls[NT], t[NT];
+    if (affine) mlp_fwd_keep<NT, NH, L, 0>(wf, lane, cond, as, ls);
+    mlp_fwd_keep<NT, NH, L, 1>(wf + net_floats, lane, cond, at, t);
+#pragma unroll
+    for (int l = 0; l <= L; ++l)
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) {
+            if (affine) stash[((0 * (L + 1) + l) * NH + ht) * 64 + lane] = as[l][ht];
+            stash[((1 * (L + 1) + l) * NH + ht) * 64 + lane] = at[l][ht];
+        }
+    float ld = 0.f;
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        if (affine) {  // inputs * exp(log_s) + t ; +sum(log_s)
+            trans[tau].x = trans[tau].x * __expf(ls[tau].x) + t[tau].x;
+            trans[tau].y = trans[tau].y * __expf(ls[tau].y) + t[tau].y;
+            trans[tau].z = trans[tau].z * __expf(ls[tau].z) + t[tau].z;
+            trans[tau].w = trans[tau].w * __expf(ls[tau].w) + t[tau].w;
+            ld += (ls[tau].x + ls[tau].y) + (ls[tau].z + ls[tau].w);
+        } else {       // translate-only coupling: log_s = 0
+            trans[tau] = trans[tau] + t[tau];
+        }
+    }
+    return ld;
+}
 
 // backward through one MLP; stages G tiles and activations; returns g_m (gradient wrt the conditioning inputs)
 template <int NT, int NH, int L, int ACT>
@@ -480,7 +534,8 @@ template <int NT, int NH, int L>
 __device__ __forceinline__ void block_backward(const TrainArgs &a, float *stg, int rows_pad, int b, int wave, int lane,
                                                bool tile_active, int row, bool row_ok, const f32x4 (&cond)[NT],
                                                f32x4 (&ytrans)[NT], f32x4 (&gcond)[NT], f32x4 (&gtrans)[NT], float gld,
-                                               const AdamStep &ad, float *imgf, float *imgb, unsigned long long (&ph)[8]) {
+                                               const AdamStep &ad, float *imgf, float *imgb, unsigned long long (&ph)[8],
+                                               const f32x4 *__restrict__ stash) {
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
     (void)q0; (void)q1; (void)q2; (void)q3; (void)q4; (void)ph;
     TSTAMP(q0);
@@ -493,12 +548,20 @@ __device__ __forceinline__ void block_backward(const TrainArgs &a, float *stg, i
     // translate-only couplings (scale='translate' / 'constant', networks.py:293-294): no scale net, log_s = 0
     const bool affine = a.s.scale_mode == 0;
     if (tile_active) {
-        if (affine) mlp_fwd_keep<NT, NH, L, 0>(wf, lane, cond, as, ls);
+        // the hidden activations come back from the forward pass's stash; only the output layers are evaluated again
+#pragma unroll
+        for (int l = 0; l <= L; ++l)
+#pragma unroll
+            for (int ht = 0; ht < NH; ++ht) {
+                if (affine) as[l][ht] = stash[((0 * (L + 1) + l) * NH + ht) * 64 + lane];
+                at[l][ht] = stash[((1 * (L + 1) + l) * NH + ht) * 64 + lane];
+            }
+        if (affine) mlp_out_layer<NT, NH, L>(wf, lane, as[L], ls);
         else {
 #pragma unroll
             for (int tau = 0; tau < NT; ++tau) ls[tau] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        mlp_fwd_keep<NT, NH, L, 1>(wf + a.s.net_floats, lane, cond, at, t);
+        mlp_out_layer<NT, NH, L>(wf + a.s.net_floats, lane, at[L], t);
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
             float lsv[4] = {ls[tau].x, ls[tau].y, ls[tau].z, ls[tau].w};
@@ -573,6 +636,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
     const int np = a.s.num_params();
     // ScaleLayer scalars (scale='constant'): read from the packed vector, which Adam updates in place
     const float *blk_scale = a.s.scale_mode == 2 ? a.w + a.s.nets_params() : nullptr;
+    f32x4 *stash_w = reinterpret_cast<f32x4 *>(a.stash) + (size_t)wave * B * 2 * (L + 1) * NH * 64;
     __shared__ float sred[8 * TRAIN_WAVES];  // per (block, wave) partials of dLoss/ds_b; B <= 8 checked by the launcher
 
     rebuild_images_to(a, imgf, imgb);
@@ -641,7 +705,16 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
                         }
                     }
                 }
-                ld = group_sum(flow_forward_tile<NT, NH>(imgf, a.s.net_floats, B, L, lane, xs, blk_scale));
+                const bool affine = a.s.scale_mode == 0;
+                float ldp = 0.f;
+                for (int b = 0; b < B; ++b) {
+                    const float *wf = imgf + (size_t)b * 2 * a.s.net_floats;
+                    f32x4 *sb = stash_w + (size_t)b * 2 * (L + 1) * NH * 64;
+                    if (b & 1) ldp += block_forward_keep<NT, NH, L>(wf, a.s.net_floats, affine, lane, xs[0], xs[1], sb);
+                    else       ldp += block_forward_keep<NT, NH, L>(wf, a.s.net_floats, affine, lane, xs[1], xs[0], sb);
+                    if (blk_scale) ldp += scale_layer_tile<NT>(blk_scale[b], false, lane, xs);
+                }
+                ld = group_sum(ldp);
             }
             // loss = -mean(log_probs)  (trainer.py:394; networks.py:71-76)
             float lp = 0.f;
@@ -705,8 +778,8 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
                     }
                     if (lane == 0) sred[b * TRAIN_WAVES + wave] = tile_active ? part : 0.f;
                 }
-                if (b & 1) block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[0], xs[1], gs[0], gs[1], gld, ad, imgf, imgb, ph);
-                else       block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[1], xs[0], gs[1], gs[0], gld, ad, imgf, imgb, ph);
+                if (b & 1) block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[0], xs[1], gs[0], gs[1], gld, ad, imgf, imgb, ph, stash_w + (size_t)b * 2 * (L + 1) * NH * 64);
+                else       block_backward<NT, NH, L>(a, stg, rows_pad, b, wave, lane, tile_active, row, row_ok, xs[1], xs[0], gs[1], gs[0], gld, ad, imgf, imgb, ph, stash_w + (size_t)b * 2 * (L + 1) * NH * 64);
             }
             if (blk_scale) {
                 __syncthreads();
@@ -859,10 +932,11 @@ hipError_t launch_training_jitter(const double *samples, int N, int D, double *o
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------
-// workspace layout (floats): [img_bwd: image_floats][grad: num_params]
+// workspace layout (floats): [img_bwd: image_floats][grad: num_params + 64][stash]
+static size_t train_stash_floats(const FlowShape &s) { return (size_t)TRAIN_WAVES * s.B * 2 * (s.L + 1) * s.NH * 256; }
 size_t train_workspace_floats(const FlowShape &s, int batch) {
     (void)batch;
-    return (size_t)s.image_floats + (size_t)s.num_params() + 64;
+    return (size_t)s.image_floats + (size_t)s.num_params() + 64 + train_stash_floats(s);
 }
 
 template <int NT, int NH, int L, int IMGLDS>
@@ -906,6 +980,7 @@ hipError_t launch_loss_grad(const float *packed, const FlowShape &s, const float
     a.w = const_cast<float *>(packed);
     a.img_fwd = img_fwd;
     a.img_bwd = workspace;
+    a.stash = workspace + s.image_floats + s.num_params() + 64;
     a.fwd_pos = fwd_pos;
     a.bwd_pos = bwd_pos;
     a.grad = grad;
@@ -925,6 +1000,7 @@ hipError_t launch_vjp(const float *packed, const FlowShape &s, const float *x, c
     a.w = const_cast<float *>(packed);
     a.img_fwd = img_fwd;
     a.img_bwd = workspace;
+    a.stash = workspace + s.image_floats + s.num_params() + 64;
     a.fwd_pos = fwd_pos;
     a.bwd_pos = bwd_pos;
     a.grad = grad;
@@ -967,6 +1043,7 @@ hipError_t launch_train(float *packed, float *adam_m, float *adam_v, float *best
     memset(&a, 0, sizeof(a));
     a.w = packed; a.m = adam_m; a.v = adam_v; a.best_w = best_w; a.img_fwd = img;
     a.img_bwd = workspace;
+    a.stash = workspace + s.image_floats + s.num_params() + 64;
     a.fwd_pos = fwd_pos;
     a.bwd_pos = bwd_pos;
     a.grad = workspace + s.image_floats;
