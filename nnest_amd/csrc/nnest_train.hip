@@ -706,6 +706,8 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
                     }
                 }
                 const bool affine = a.s.scale_mode == 0;
+                TSTAMP(p3);
+                TACC(ph[6], p3, p0);  // (diagnostic build: rows + jitter; the 'rebuild' slot is free)
                 float ldp = 0.f;
                 for (int b = 0; b < B; ++b) {
                     const float *wf = imgf + (size_t)b * 2 * a.s.net_floats;

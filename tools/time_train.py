@@ -18,5 +18,5 @@ for D, N in ((2, 100), (50, 1000), (20, 2000), (100, 8000)):
     mb = (Xt.shape[0] + 99) // 100
     if os.environ.get('NNEST_HIP_LIB', '').endswith('STAMP.so'):
         ph = res['losses'].cpu().numpy().ravel()[:8] / (E * mb)
-        print('   cycles/minibatch: fwd %d | bwd_s+stage %d | jobs_s %d | bwd_t %d | jobs_t %d | adam %d | rebuild %d | validation(per epoch) %d' % (ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7] * mb))
+        print('   cycles/minibatch: fwd %d | bwd_s+stage %d | jobs_s %d | bwd_t %d | jobs_t %d | adam %d | rows+jitter (inside fwd) %d | validation(per epoch) %d' % (ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7] * mb))
     print('D=%d N=%d: %.3f ms/epoch (%d minibatches, %.1f us/minibatch incl. validation share)' % (D, N, dt / E * 1e3, mb, dt / E / mb * 1e6))
