@@ -51,6 +51,23 @@ __host__ __device__ inline int tslot_dim(const SplineShape &s, int hf, int t, in
 __host__ __device__ inline int trow_dim(const SplineShape &s, int hf, int t, int i) { return tslot_dim(s, hf, t, i & 3, i >> 2); }
 
 // ---- 1: W per block ---------------------------------------------------------------------------------------------
+// W[i][j] = sum_k (P Lm)[i][k] Um[k][j] with (P Lm)[i][k] = Lm[r][k], r = the column of the 1 in row i of P
+// (the loads are unconditional and the loop is unrolled so that eight steps' loads are in flight together: one load round trip
+// per step made the tiny assemble kernel 11 us)
+__device__ __forceinline__ float spl_w_entry(const float *__restrict__ Lp, const float *__restrict__ Sp, const float *__restrict__ Up,
+                                             int r, int j, int D) {
+    const int kmax = r < j ? r : j;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k <= kmax; ++k) {
+        const float lv = Lp[r * D + k], uv = Up[k * D + j], sv = Sp[k];
+        const float l = k < r ? lv : 1.f;
+        const float u = k < j ? uv : sv;
+        acc += l * u;
+    }
+    return acc;
+}
+
 // `stop` (every training kernel): the early-stopping flag of the running nnest_spline_train call, or NULL.  Once it is set,
 // the launches that are already queued leave the state as it is.
 __global__ void spl_assemble_kernel(const float *__restrict__ w, const int *__restrict__ pi, float *__restrict__ wmat, SplTrainShape ts,
@@ -60,75 +77,100 @@ __global__ void spl_assemble_kernel(const float *__restrict__ w, const int *__re
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
         const int b = idx / (D * D), i = (idx / D) % D, j = idx % D;
         const float *pb = w + (size_t)b * ts.s.blk_params;
-        const float *Lp = pb + ts.p_L, *Sp = pb + ts.p_S, *Up = pb + ts.p_U;
-        const int r = pi[b * D + i];  // (P Lm)[i][k] = Lm[r][k]
-        const int kmax = r < j ? r : j;
-        // (the loads are unconditional and the loop is unrolled so that eight steps' loads are in flight together: one load
-        // round trip per step made this tiny kernel 11 us)
-        float acc = 0.f;
-#pragma unroll 8
-        for (int k = 0; k <= kmax; ++k) {
-            const float lv = Lp[r * D + k], uv = Up[k * D + j], sv = Sp[k];
-            const float l = k < r ? lv : 1.f;
-            const float u = k < j ? uv : sv;
-            acc += l * u;
-        }
-        wmat[idx] = acc;
+        wmat[idx] = spl_w_entry(pb + ts.p_L, pb + ts.p_S, pb + ts.p_U, pi[b * D + i], j, D);
     }
 }
 
 // ---- 2: training image -------------------------------------------------------------------------------------------
-__device__ inline float cond_fwd_value(const SplineShape &s, const float *p, int nin, int nout, int o) {
+// (index of the conditioner's packed parameter that sits at element o of its forward image, -1 = structural zero)
+__device__ inline int cond_fwd_index(const SplineShape &s, int nin, int nout, int o) {
     const int H = s.H, NH = s.NH, NTh = s.NTh, S = (nout + 3) / 4, P = SPL_P;
-    const float *W0 = p, *b0 = W0 + H * nin, *W1 = b0 + H, *b1 = W1 + H * H, *W2 = b1 + H, *b2 = W2 + H * H, *W3 = b2 + H,
-                *b3 = W3 + (size_t)P * nout * H;
+    const int W0 = 0, b0 = W0 + H * nin, W1 = b0 + H, b1 = W1 + H * H, W2 = b1 + H, b2 = W2 + H * H, W3 = b2 + H,
+              b3 = W3 + P * nout * H;
     const int oL2 = NH * NTh * 256, oL3 = oL2 + NH * NH * 256, ob = oL3 + NH * NH * 256, oL4 = ob + 3 * 16 * NH, ob4 = oL4 + S * SPL_QT * NH * 256;
     if (o < oL2) {
         const int lane = o & 63, q = o >> 6, r = q & 3, t = (q >> 2) % NTh, ht = (q >> 2) / NTh;
         const int g = lane >> 4, i = lane & 15, j = 16 * t + 4 * r + g;
-        return j < nin ? W0[(16 * ht + i) * nin + j] : 0.f;
+        return j < nin ? W0 + (16 * ht + i) * nin + j : -1;
     } else if (o < ob) {
         const int oo = o < oL3 ? o - oL2 : o - oL3;
-        const float *W = o < oL3 ? W1 : W2;
+        const int W = o < oL3 ? W1 : W2;
         const int lane = oo & 63, q = oo >> 6, r = q & 3, hti = (q >> 2) % NH, hto = (q >> 2) / NH;
         const int g = lane >> 4, i = lane & 15;
-        return W[(16 * hto + i) * H + 16 * hti + 4 * g + r];
+        return W + (16 * hto + i) * H + 16 * hti + 4 * g + r;
     } else if (o < oL4) {
         const int oo = o - ob, l = oo / H, j = oo % H;
-        return l == 0 ? b0[j] : (l == 1 ? b1[j] : b2[j]);
+        return (l == 0 ? b0 : (l == 1 ? b1 : b2)) + j;
     } else if (o < ob4) {
         const int oo = o - oL4;
         const int lane = oo & 63, q4 = oo >> 6, r = q4 & 3, hti = (q4 >> 2) % NH, sq = (q4 >> 2) / NH, q = sq % SPL_QT, sidx = sq / SPL_QT;
         const int g = lane >> 4, i = lane & 15;
         const int jo = 4 * sidx + (i >> 2), pp = 4 * q + (i & 3);
-        return (jo < nout && pp < P) ? W3[(size_t)(jo * P + pp) * H + 16 * hti + 4 * g + r] : 0.f;
+        return (jo < nout && pp < P) ? W3 + (jo * P + pp) * H + 16 * hti + 4 * g + r : -1;
     } else {
         const int oo = o - ob4, r = oo & 3, g = (oo >> 2) & 3, sq = oo >> 4, q = sq % SPL_QT, sidx = sq / SPL_QT;
         const int jo = 4 * sidx + g, pp = 4 * q + r;
-        return (jo < nout && pp < P) ? b3[jo * P + pp] : 0.f;
+        return (jo < nout && pp < P) ? b3 + jo * P + pp : -1;
     }
 }
+__device__ inline float cond_fwd_value(const SplineShape &s, const float *p, int nin, int nout, int o) {
+    const int i = cond_fwd_index(s, nin, nout, o);
+    return i >= 0 ? p[i] : 0.f;
+}
 
-__device__ inline float cond_bwd_value(const SplineShape &s, const float *p, int nin, int nout, int o) {
+__device__ inline int cond_bwd_index(const SplineShape &s, int nin, int nout, int o) {
     const int H = s.H, NH = s.NH, NTh = s.NTh, P = SPL_P;
-    const float *W0 = p, *W1 = W0 + H * nin + H, *W2 = W1 + H * H + H, *W3 = W2 + H * H + H;
+    const int W0 = 0, W1 = W0 + H * nin + H, W2 = W1 + H * H + H, W3 = W2 + H * H + H;
     const int oB2 = NTh * NH * 256, oB3 = oB2 + NH * NH * 256, oB4 = oB3 + NH * NH * 256;
     if (o < oB2) {  // B1 [t][ht][r][64]: W0[16ht+4g+r][dim of (tile t, row i)]
         const int lane = o & 63, q = o >> 6, r = q & 3, ht = (q >> 2) % NH, t = (q >> 2) / NH;
         const int g = lane >> 4, i = lane & 15, j = 16 * t + 4 * (i & 3) + (i >> 2);
-        return j < nin ? W0[(16 * ht + 4 * g + r) * nin + j] : 0.f;
+        return j < nin ? W0 + (16 * ht + 4 * g + r) * nin + j : -1;
     } else if (o < oB4) {  // B2 / B3 [hti][hto][r][64]: W[16hto+4g+r][16hti+i]
         const int oo = o < oB3 ? o - oB2 : o - oB3;
-        const float *W = o < oB3 ? W1 : W2;
+        const int W = o < oB3 ? W1 : W2;
         const int lane = oo & 63, q = oo >> 6, r = q & 3, hto = (q >> 2) % NH, hti = (q >> 2) / NH;
         const int g = lane >> 4, i = lane & 15;
-        return W[(16 * hto + 4 * g + r) * H + 16 * hti + i];
+        return W + (16 * hto + 4 * g + r) * H + 16 * hti + i;
     } else {  // B4 [s][q][hto][r][64]: W3[(4s+g)*23 + 4q+r][16hto+i]
         const int oo = o - oB4;
         const int lane = oo & 63, q4 = oo >> 6, r = q4 & 3, hto = (q4 >> 2) % NH, sq = (q4 >> 2) / NH, q = sq % SPL_QT, sidx = sq / SPL_QT;
         const int g = lane >> 4, i = lane & 15;
         const int jo = 4 * sidx + g, pp = 4 * q + r;
-        return (jo < nout && pp < P) ? W3[(size_t)(jo * P + pp) * H + 16 * hto + i] : 0.f;
+        return (jo < nout && pp < P) ? W3 + (jo * P + pp) * H + 16 * hto + i : -1;
+    }
+}
+__device__ inline float cond_bwd_value(const SplineShape &s, const float *p, int nin, int nout, int o) {
+    const int i = cond_bwd_index(s, nin, nout, o);
+    return i >= 0 ? p[i] : 0.f;
+}
+
+// Position maps packed conditioner parameter -> its element of the forward / transposed image (every such parameter occurs
+// at most once in each; -1 = not in that image, e.g. the biases in the transposed one), built once per flow: with them the
+// Adam kernel of the training loop keeps the image current (spl_adam_image_kernel) instead of a rebuild per minibatch.
+__global__ void spl_build_pos_kernel(int *__restrict__ pos_f, int *__restrict__ pos_b, int *__restrict__ conv_src, SplTrainShape ts) {
+    const SplineShape &s = ts.s;
+    const long total = (long)ts.timage_floats;
+    // element of W (row-major index) behind element o of the two conv fragment images of a block, -1 = padding (as spl_timage_kernel)
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < 2 * ts.conv_floats; o += gridDim.x * blockDim.x) {
+        const int NTh = s.NTh, T2 = 2 * NTh, D = s.D;
+        const bool bwd = o >= ts.conv_floats;
+        const int oo = bwd ? o - ts.conv_floats : o;
+        const int lane = oo & 63, q = oo >> 6, r = q & 3, ti = (q >> 2) % T2, to = (q >> 2) / T2;
+        const int g = lane >> 4, i = lane & 15;
+        const int dk = tslot_dim(s, ti / NTh, ti % NTh, r, g), dm = trow_dim(s, to / NTh, to % NTh, i);
+        conv_src[o] = (dk >= 0 && dm >= 0) ? (bwd ? dm * D + dk : dk * D + dm) : -1;
+    }
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / ts.tblk_floats);
+        int o = (int)(idx - (long)b * ts.tblk_floats) - 2 * ts.conv_floats;
+        if (o < 0) continue;
+        const int base = b * s.blk_params;
+        int src;
+        if (o < ts.cf[0]) { if ((src = cond_fwd_index(s, s.nl, s.nu, o)) >= 0) pos_f[base + ts.p_f[0] + src] = (int)idx; }
+        else if ((o -= ts.cf[0]) < ts.cf[1]) { if ((src = cond_fwd_index(s, s.nu, s.nl, o)) >= 0) pos_f[base + ts.p_f[1] + src] = (int)idx; }
+        else if ((o -= ts.cf[1]) < ts.cb[0]) { if ((src = cond_bwd_index(s, s.nl, s.nu, o)) >= 0) pos_b[base + ts.p_f[0] + src] = (int)idx; }
+        else if ((o -= ts.cb[0]) < ts.cb[1]) { if ((src = cond_bwd_index(s, s.nu, s.nl, o)) >= 0) pos_b[base + ts.p_f[1] + src] = (int)idx; }
     }
 }
 
@@ -771,6 +813,71 @@ __global__ void spl_adam_kernel(float *__restrict__ w, const float *__restrict__
     }
 }
 
+// ---- 6b: Adam with the training image kept current (training loop, shapes with at most two tiles per half) ----------------------
+// Workgroup b < B owns the head of block b -- ActNorm s, t and L, S, U, contiguous in the packed vector -- takes their step,
+// then assembles W = P L (U + diag S) from the new values (staged in LDS), writes it to `wmat`, and from it the two conv
+// fragment images and the block's log-det constant.  The other workgroups step the conditioner parameters and scatter each
+// new value to its elements of the forward / transposed image (spl_build_pos_kernel).  Replaces spl_adam_kernel +
+// spl_assemble_kernel + spl_timage_kernel and two launch gaps per minibatch.
+__device__ __forceinline__ float spl_adam_one(float w, float g, float &m, float &v, float step_size, float inv_bc2s, float wd) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const float gi = g + wd * w;
+    m = m + (gi - m) * (1.0f - b1);
+    v = v * b2 + (1.0f - b2) * gi * gi;
+    return w - step_size * (m / (sqrtf(v) * inv_bc2s + eps));
+}
+
+__global__ void __launch_bounds__(1024) spl_adam_image_kernel(float *__restrict__ w, const float *__restrict__ grad, float *__restrict__ m,
+                                                              float *__restrict__ v, float step_size, float inv_bc2s, float wd,
+                                                              const int *__restrict__ pos_f, const int *__restrict__ pos_b,
+                                                              const int *__restrict__ conv_src, const int *__restrict__ pi, float *__restrict__ wmat, float *__restrict__ timg,
+                                                              SplTrainShape ts, const int *__restrict__ stop) {
+    if (stop && *stop) return;
+    extern __shared__ float head[];  // [p_f[0]]: the block head after its step
+    const SplineShape &s = ts.s;
+    const int D = s.D, B = s.B, np = s.num_params, nhead = ts.p_f[0];
+    if ((int)blockIdx.x < B) {
+        const int b = blockIdx.x, base = b * s.blk_params;
+#pragma unroll 3
+        for (int i = threadIdx.x; i < nhead; i += blockDim.x) {
+            float mi = m[base + i], vi = v[base + i];
+            const float wn = spl_adam_one(w[base + i], grad[base + i], mi, vi, step_size, inv_bc2s, wd);
+            m[base + i] = mi; v[base + i] = vi; w[base + i] = wn;
+            head[i] = wn;
+        }
+        __syncthreads();
+        float *Wm = wmat + (size_t)b * D * D;
+        for (int idx = threadIdx.x; idx < D * D; idx += blockDim.x)
+            Wm[idx] = spl_w_entry(head + ts.p_L, head + ts.p_S, head + ts.p_U, pi[b * D + idx / D], idx % D, D);
+        __syncthreads();  // (the block's own global writes are visible to it after the barrier)
+        float *blk = timg + (size_t)b * ts.tblk_floats;
+#pragma unroll 4
+        for (int o = threadIdx.x; o < 2 * ts.conv_floats; o += blockDim.x) {  // the conv fragment images, through the source table
+            const int src = conv_src[o];
+            blk[o] = src >= 0 ? Wm[src] : 0.f;
+        }
+        // log|det| of ActNorm + conv (networks.py:650, :676): the terms in parallel, summed in spl_timage_kernel's order
+        for (int d = threadIdx.x; d < D; d += blockDim.x) head[d] = head[ts.p_s + d] + logf(fabsf(head[ts.p_S + d]));  // (p_s = 0: in place)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float acc = 0.f;
+            for (int d = 0; d < D; ++d) acc += head[d];
+            blk[ts.tblk_floats - 4] = acc;
+        }
+        return;
+    }
+    const int nw = gridDim.x - B;
+    for (int i = (blockIdx.x - B) * blockDim.x + threadIdx.x; i < np; i += nw * blockDim.x) {
+        if (i % s.blk_params < nhead) continue;
+        float mi = m[i], vi = v[i];
+        const float wn = spl_adam_one(w[i], grad[i], mi, vi, step_size, inv_bc2s, wd);
+        m[i] = mi; v[i] = vi; w[i] = wn;
+        const int pf = pos_f[i], pb = pos_b[i];
+        if (pf >= 0) timg[pf] = wn;
+        if (pb >= 0) timg[pb] = wn;
+    }
+}
+
 // ---- 7: end of an epoch (trainer.py:198-232), on the device so that the host does not have to drain the stream per epoch ----
 struct SplTrainCtl {
     float best, last_train;
@@ -968,6 +1075,10 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
         SHIP_TRY(hipMalloc((void **)&h->gwsum, (size_t)B * D * D * sizeof(float)));
         SHIP_TRY(hipMalloc((void **)&h->timg, (size_t)ts.timage_floats * sizeof(float)));
         SHIP_TRY(hipMalloc((void **)&h->losses_dev, 1024 * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->pos_dev, (2 * (size_t)h->s.num_params + 2 * (size_t)ts.conv_floats) * sizeof(int)));
+        SHIP_TRY(hipMemsetAsync(h->pos_dev, 0xFF, 2 * (size_t)h->s.num_params * sizeof(int), st));
+        hipLaunchKernelGGL(spl_build_pos_kernel, dim3(256), dim3(256), 0, st, h->pos_dev, h->pos_dev + h->s.num_params, h->pos_dev + 2 * (size_t)h->s.num_params, ts);
+        SHIP_TRY(hipGetLastError());
         SHIP_TRY(hipMemsetAsync(h->adam_m, 0, nb, st));
         SHIP_TRY(hipMemsetAsync(h->adam_v, 0, nb, st));
         h->adam_step = 0;
@@ -1134,6 +1245,12 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
     snap[0] = c0; snap[1] = c0;
     SHIP_TRY(hipMemcpyAsync(ctl, &snap[0], sizeof(SplTrainCtl), hipMemcpyHostToDevice, st));
     const int adam_step0 = h->adam_step;
+    // shapes with at most two tiles per half: Adam keeps the training image current (spl_adam_image_kernel); the larger ones
+    // rebuild it per minibatch (their conv images are too much work for one workgroup per block)
+    const bool fused = h->s.NTh <= 2;
+    const size_t head_lds = (size_t)ts.p_f[0] * sizeof(float);
+    if (fused && head_lds > 64 * 1024)
+        SHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spl_adam_image_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds));
     const int CHUNK = 8;
     hipEvent_t ev[2];
     SHIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
@@ -1151,7 +1268,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_GRAD; a.stop = stop;
             a.rows_per_tile = rows_per_tile(M);
             // (the image of the validation pass that closed the previous epoch is still the current one)
-            if (mb > 0 || epoch == 0) { if ((rc = build_timage(h, ts, st, stop))) return rc; }
+            if (fused ? (mb == 0 && epoch == 0) : (mb > 0 || epoch == 0)) { if ((rc = build_timage(h, ts, st, stop))) return rc; }
             SHIP_TRY(launch_grad(a, st));
             const int tiles = grad_tiles(a);
             hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, h->grad, h->gwsum,
@@ -1159,11 +1276,16 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + B * D, h->pi_dev, h->gwsum, h->grad, ts, -1.0f, stop);
             h->adam_step += 1;
             const double bc1 = 1.0 - pow(0.9, (double)h->adam_step), bc2 = 1.0 - pow(0.999, (double)h->adam_step);
-            hipLaunchKernelGGL(spl_adam_kernel, dim3(256), dim3(256), 0, st, h->w_dev, h->grad, h->adam_m, h->adam_v, np,
-                               (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), weight_decay, stop);
+            if (fused)
+                hipLaunchKernelGGL(spl_adam_image_kernel, dim3(B + 80), dim3(1024), head_lds, st, h->w_dev, h->grad, h->adam_m, h->adam_v,
+                                   (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), weight_decay, h->pos_dev, h->pos_dev + np,
+                                   h->pos_dev + 2 * (size_t)np, h->pi_dev, h->wmat, h->timg, ts, stop);
+            else
+                hipLaunchKernelGGL(spl_adam_kernel, dim3(256), dim3(256), 0, st, h->w_dev, h->grad, h->adam_m, h->adam_v, np,
+                                   (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), weight_decay, stop);
         }
         // Trainer._validate (trainer.py:405-418): one full batch; mean, then / len(dataset)
-        if ((rc = build_timage(h, ts, st, stop))) return rc;
+        if (!fused && (rc = build_timage(h, ts, st, stop))) return rc;
         {
             SplGradArgs a;
             memset(&a, 0, sizeof(a));

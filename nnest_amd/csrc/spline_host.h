@@ -13,6 +13,7 @@ struct nnest_spline {
     // training state (allocated on first use, nnest_spline_train.hip)
     float *w_dev, *adam_m, *adam_v, *best_w;  // packed, device
     int *pi_dev;              // [B][D]: column of the 1 in row i of P
+    int *pos_dev;             // [2][num_params]: packed conditioner parameter -> element of the forward / transposed training image
     float *wmat;              // [B][D][D] assembled W
     float *timg;              // training image
     float *partial;           // per-wave gradient / loss slices
