@@ -380,7 +380,9 @@ __device__ __forceinline__ f32x4 contract_rows(const float *stg, int rows_pad, i
     // MFMAs issue back to back (a single chain waits 40 cycles per dependent v_mfma_f32_16x16x4_f32) and the LDS
     // reads of a tile are all in flight together
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4, b0 = zero4, b1 = zero4, b2 = zero4, b3 = zero4;
+    f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
+    float bs = 0.f;  // WITH_BIAS: this lane's rows of column (lane & 15) of G, on the VALU (as MFMAs against ones the bias sums
+                     // doubled the matrix-core time of the jobs that carry them, and those jobs set the length of the phase)
     const float *G = stg + (size_t)ct_g * rows_pad * 16 + (lane >> 4) * 16 + (lane & 15);
     const float *A = stg + (size_t)ct_a * rows_pad * 16 + (lane >> 4) * 16 + (lane & 15);
     for (int r = 0; r < rows_pad; r += 16) {
@@ -389,14 +391,14 @@ __device__ __forceinline__ f32x4 contract_rows(const float *stg, int rows_pad, i
         a1 = mfma4(g1, A[(r + 4) * 16], a1);
         a2 = mfma4(g2, A[(r + 8) * 16], a2);
         a3 = mfma4(g3, A[(r + 12) * 16], a3);
-        if (WITH_BIAS) {
-            b0 = mfma4(g0, 1.0f, b0);
-            b1 = mfma4(g1, 1.0f, b1);
-            b2 = mfma4(g2, 1.0f, b2);
-            b3 = mfma4(g3, 1.0f, b3);
-        }
+        if (WITH_BIAS) bs += (g0 + g1) + (g2 + g3);
     }
-    if (WITH_BIAS) bias = (b0 + b1) + (b2 + b3);
+    if (WITH_BIAS) {
+        bs += __shfl_xor(bs, 16);
+        bs += __shfl_xor(bs, 32);  // every lane: the sum over all rows of column (lane & 15)
+        const int q4 = (lane >> 4) * 4;  // lane (gq, j) reg r  <->  out feature 4*gq + r, as the product against ones gave it
+        bias = (f32x4){__shfl(bs, q4 + 0), __shfl(bs, q4 + 1), __shfl(bs, q4 + 2), __shfl(bs, q4 + 3)};
+    }
     return (a0 + a1) + (a2 + a3);  // lane (gq, j) reg r  <->  (out feature 4*gq + r, in feature j)
 }
 
