@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py -- live-point evals/s of the nnest hot path on MI355X.
+"""bench.py -- live-point evals/s (+ log-Z error) of the nnest hot path on MI355X.
 
-One "step" = one launch of the persistent constrained-Metropolis kernel (K4, the GPU form of the
-reference's Sampler._mcmc_sample, nnest/sampler.py:229-463) over the walker population of this rank:
-  walkers x mcmc_steps proposals, each = one coupling-stack inverse (+log-det) of a 50-vector + box prior
-  + one Rosenbrock log-likelihood  (= one "eval").
-Workload = BASELINE.json configs[1]: Rosenbrock x_dim=50, 1000 live points (one walker per live point),
-mcmc_steps = 5*x_dim = 250 (nnest/nested.py:155-156), NVP hidden 16 / 3 blocks / 1 layer.
-Inputs are resident in HBM before the timed region.  Synthetic data: u ~ U(-1,1), seeded default-init
-weights.  N>1: one process per GPU (torchrun), walkers sharded by rank with disjoint Philox streams,
-no data-path collective (weak scaling: 1000 walkers per GPU).
+One "step" = one launch of the persistent constrained-Metropolis kernel (K4, the GPU form of the reference's
+Sampler._mcmc_sample, nnest/sampler.py:229-463) over the walker population of this rank, with the reference's default
+step-size adaptation (mcmc_dynamic_step_size=True, nnest/nested.py:102) applied over the whole batch as the product does:
+  walkers x mcmc_steps proposals, each = one coupling-stack inverse (+log-det) of a D-vector + box prior + one
+  log-likelihood  (= one "eval").
+Workload (default) = BASELINE.json configs[1]: Rosenbrock x_dim=50, 1000 live points (one walker per live point),
+mcmc_steps = 5*x_dim = 250 (nnest/nested.py:155-156), NVP hidden 16 / 3 blocks / 1 layer.  Inputs are resident in HBM
+before the timed region.  Synthetic data: u ~ U(-1,1), seeded default-init weights.
+
+N > 1 (one process per GPU, torchrun): the real per-batch data path of a sharded run -- K4 on this rank's shard of the
+walkers, then ONE RCCL all-gather of the chain endpoints [C/N, 2D+1] float64 (C2) -- inside the timed
+region.  --scaling weak (default): 1000 walkers per GPU; --scaling strong: the configuration's population split over
+the ranks (--config 4: Himmelblau x_dim=32, 4000 live points; --config 5: Rosenbrock x_dim=100, 8000 live points), with
+the kernel form of the whole batch pinned on every shard.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
 """
@@ -28,7 +33,10 @@ import torch  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E spec
-MEASURED_TRAFFIC_BYTES = int((452.2 + 1384.7) * 1024)  # profiles/r01d/bench_pmc_summary.txt, per K4 launch
+METRIC = 'live-point evals/sec (flow-transform + loglike) + log-Z error, x_dim=%d'   # BASELINE.json "metric"
+CONFIGS = {2: ('rosenbrock', 50, 5.0, 1000), 3: ('gaussmix', 20, 10.0, 2000), 4: ('himmelblau', 32, 5.0, 4000),
+           5: ('rosenbrock', 100, 5.0, 8000)}
+LIKE_ID = {'rosenbrock': 0, 'gaussmix': 1, 'himmelblau': 2}
 
 
 def useful_flops_per_eval(D, H, B, L):
@@ -41,30 +49,96 @@ def alg_bytes_per_eval(D):
     return 8 * D + 8
 
 
-def cpu_baseline(D, H, B, L, w, walkers, target_seconds=12.0):
-    """The oracle (plain-C restatement of Sampler._mcmc_sample, single thread) timed on this box's host
-    cores on a bounded sample of the same workload."""
+def _cpu_mcmc(args):
     from oracle import oracle as orc
-    o = orc.NVP(D, H, B, L, w)
+    w, D, like, scale, init, init_logl, loglstar, step, dz, u = args
+    o = orc.NVP(D, 16, 3, 1, w)
+    orc.mcmc_sample(o, like, scale, init, init_logl, loglstar, step, True, dz, u)
+    return init.shape[0] * dz.shape[0]
+
+
+def cpu_baseline(D, w, like, scale, walkers, target_seconds=10.0):
+    """The oracle (plain-C restatement of Sampler._mcmc_sample) timed on this box's host cores on a bounded sample of the
+    same workload: once on ONE thread, once with the walkers split over all cores (walkers are independent; the C code
+    releases the GIL under ctypes)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
     rng = np.random.RandomState(0)
     init = rng.uniform(-1, 1, size=(walkers, D))
-    init_logl = orc.loglike('rosenbrock', init, 5.0)
-    steps = 2
-    dz = rng.normal(size=(steps, walkers, D)).astype(np.float32)
-    u = rng.uniform(size=(steps, walkers)).astype(np.float32)
-    t0 = time.perf_counter()
-    orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, float(init_logl.min()), 1 / np.sqrt(D), False, dz, u)
-    dt = time.perf_counter() - t0
-    per_step = dt / steps
-    steps = int(max(2, min(5000, target_seconds / max(per_step, 1e-9))))
-    dz = rng.normal(size=(steps, walkers, D)).astype(np.float32)
-    u = rng.uniform(size=(steps, walkers)).astype(np.float32)
-    t0 = time.perf_counter()
-    orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, float(init_logl.min()), 1 / np.sqrt(D), False, dz, u)
-    dt = time.perf_counter() - t0
-    return {'value': walkers * steps / dt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d walkers x %d MH steps of the same workload, oracle/nnest_oracle.c single thread '
-                      '(host has %d cores), %.1f s' % (walkers, steps, os.cpu_count(), dt)}
+    init_logl = orc.loglike(like, init, scale)
+    loglstar, step = float(init_logl.min()), 1 / np.sqrt(D)
+
+    def run(steps, threads):
+        dz = rng.normal(size=(steps, walkers, D)).astype(np.float32)
+        u = rng.uniform(size=(steps, walkers)).astype(np.float32)
+        cuts = np.linspace(0, walkers, threads + 1).astype(int)
+        jobs = [(w, D, like, scale, init[a:b], init_logl[a:b], loglstar, step, np.ascontiguousarray(dz[:, a:b]),
+                 np.ascontiguousarray(u[:, a:b])) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        t0 = time.perf_counter()
+        if threads == 1:
+            _cpu_mcmc(jobs[0])
+        else:
+            with ThreadPoolExecutor(threads) as ex:
+                list(ex.map(_cpu_mcmc, jobs))
+        return walkers * steps / (time.perf_counter() - t0)
+
+    cores = os.cpu_count() or 1
+    r1 = run(2, 1)
+    one = run(int(max(2, min(2000, target_seconds * r1 / walkers))), 1)
+    threads = min(cores, walkers)
+    ra = run(2, threads)
+    steps_all = int(max(2, min(4000, target_seconds * ra / walkers)))
+    allc = run(steps_all, threads)
+    return {'value': allc, 'unit': 'evals/s', 'cores': threads, 'kind': 'port',
+            'one_thread': one,
+            'sample': '%d walkers x %d MH steps of the same workload (dynamic step rule), oracle/nnest_oracle.c, walkers '
+                      'split over %d threads of the %d host cores; one_thread = the same code on one core' % (
+                          walkers, steps_all, threads, cores)}
+
+
+def committed_traffic(tag='r02'):
+    """HBM bytes per K4 launch from this round's committed rocprofv3 PMC passes of THIS command (scripts/profile_bench.sh ->
+    profiles/<tag>/bench_pmc.json); None when the profile is absent"""
+    path = os.path.join(ROOT, 'profiles', tag, 'bench_pmc.json')
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    return d.get('traffic_bytes_per_launch'), os.path.relpath(path, ROOT)
+
+
+def logz_report(dev, live_run):
+    """The log-Z half of the metric at config 2: CPU path (oracle-backed host driver, tests/golden/logz_cpu_cfg2.json) against
+    the GPU path on the same number of seeds (tests/golden/logz_gpu_cfg2.json, tools/run_logz_gpu.py), plus one live run."""
+    out = {}
+    cpu_p = os.path.join(ROOT, 'tests', 'golden', 'logz_cpu_cfg2.json')
+    gpu_p = os.path.join(ROOT, 'tests', 'golden', 'logz_gpu_cfg2.json')
+    if os.path.exists(cpu_p):
+        with open(cpu_p) as f:
+            c = json.load(f)
+        out.update(cpu_mean=c['mean'], cpu_stderr=c['stderr'], cpu_seeds=c['seeds'])
+    if os.path.exists(gpu_p):
+        with open(gpu_p) as f:
+            g = json.load(f)
+        out.update(gpu_mean=g['mean'], gpu_stderr=g['stderr'], seeds=g['seeds'])
+    if 'cpu_mean' in out and 'gpu_mean' in out:
+        out['delta'] = out['gpu_mean'] - out['cpu_mean']
+        out['combined_stderr'] = float(np.hypot(out['gpu_stderr'] or 0.0, out['cpu_stderr'] or 0.0))
+    if live_run:
+        import tempfile
+        from nnest_amd.likelihoods import Rosenbrock
+        from nnest_amd.nested import NestedSampler
+        np.random.seed(0)
+        torch.manual_seed(0)
+        s = NestedSampler(50, Rosenbrock(50), transform=lambda x: 5.0 * x, log_dir=tempfile.mkdtemp(dir='/tmp'),
+                          num_live_points=1000, log_level=40, flow='nvp')
+        t0 = time.time()
+        s.run(mcmc_num_chains=1000)
+        out['live_run'] = {'logz': float(s.logz), 'logzerr': float(s.logzerr), 'wall_s': time.time() - t0, 'ncall': int(s.ncall),
+                           'seed': 0, 'delta_vs_cpu_mean': (float(s.logz) - out['cpu_mean']) if 'cpu_mean' in out else None}
+    out['note'] = ('independent noise streams: one run scatters by logzerr ~ sqrt(H/N) ~ 0.43 around the ensemble mean; the '
+                   '+-0.1 statement is on the means (tests/test_gpu_nested.py::test_logz_cfg2_gpu_vs_cpu)')
+    return out
 
 
 def main():
@@ -72,12 +146,16 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--x-dim', type=int, default=50)
-    ap.add_argument('--walkers', type=int, default=1000, help='walkers (live points) per GPU')
+    ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS), help='BASELINE.json configuration')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--walkers', type=int, default=0, help='walkers per GPU (weak) / in total (strong); 0 = the config')
     ap.add_argument('--mcmc-steps', type=int, default=0, help='MH steps per launch (0 = 5*x_dim)')
+    ap.add_argument('--fixed-step', action='store_true', help='no step-size adaptation in the timed launches')
+    ap.add_argument('--lag', type=int, default=-1, help='lag of the batch-wide step rule (-1 = product default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-saturation', action='store_true')
     ap.add_argument('--no-spline', action='store_true')
+    ap.add_argument('--no-logz', action='store_true', help='skip the live nested run (the fixtures are still reported)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -91,9 +169,11 @@ def main():
     dev_index = local_rank if backend == 'nccl' else local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    if world > 1:
+    dist = None
+    if world > 1 or os.environ.get('NNEST_BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
@@ -101,28 +181,45 @@ def main():
 
     from nnest_amd import flow, _lib
 
-    D, H, B, L = args.x_dim, 16, 3, 1
-    C = args.walkers
+    like, D, scale, N_cfg = CONFIGS[args.config]
+    H, B, L = 16, 3, 1
+    if args.scaling == 'weak':
+        C = args.walkers or 1000
+        C_total = C * world
+        form = None
+    else:
+        C_total = args.walkers or N_cfg
+        C = -(-C_total // world)
+        cu = _lib.device_info()['num_cu']
+        form = next((f for f, t, lim in (('quad', 4, cu), ('team', 16, cu), ('reg', 16, 4 * cu)) if -(-C_total // t) <= lim), 'image')
     S = args.mcmc_steps if args.mcmc_steps > 0 else 5 * D
     nvp = flow.HipNVP(D, H, B, L, device=dev, seed=0)
     rng = np.random.RandomState(1234 + rank)
     u0 = rng.uniform(-1, 1, size=(C, D))
     z0, _ = nvp.forward(u0)
-    logl0 = flow.loglike(0, u0, 5.0, device=dev)
+    x_start, _ = nvp.inverse(z0)
+    logl0 = flow.loglike(LIKE_ID[like], u0, scale, device=dev)
     loglstar = float(logl0.min())
     step_size = 1.0 / np.sqrt(D)
+    dynamic = False if args.fixed_step else 'batch'
+    lag = None if args.lag < 0 else args.lag
 
     # state buffers are re-seeded outside the timed launches (clone is not part of the hot path)
     zs = [z0.clone() for _ in range(args.steps + args.warmup)]
     ls = [logl0.clone() for _ in range(args.steps + args.warmup)]
+    gathered = torch.empty(world * C, 2 * D + 1, dtype=torch.float64, device=dev) if dist is not None else None
 
     def launch(i):
-        return nvp.mh_steps(0, 5.0, zs[i], ls[i], loglstar, step_size, S, dynamic=False, seed=42 + i,
-                            walker_offset=rank * C)
+        res = nvp.mh_steps(LIKE_ID[like], scale, zs[i], ls[i], loglstar, step_size, S, dynamic=dynamic, lag=lag, seed=42 + i,
+                           walker_offset=rank * C, form=form)
+        if dist is not None:   # C2: what the nested-sampling loop consumes of a batch, gathered on every rank (device memory)
+            ends = torch.cat([x_start.double(), res['x'].double(), ls[i][:, None]], dim=1)
+            dist.all_gather_into_tensor(gathered, ends)
+        return res
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -131,15 +228,18 @@ def main():
     barrier()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    last = None
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev0[k].record()
-        launch(args.warmup + k)
+        last = launch(args.warmup + k)
         ev1[k].record()
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
-    if world > 1:
+    if last is not None:
+        nvp.check_sync(last)
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -148,52 +248,85 @@ def main():
     total_evals = evals_per_launch * args.steps * world
     value = total_evals / dt
 
-    out = None
     if rank == 0:
         fl = useful_flops_per_eval(D, H, B, L)
         achieved_tflops = evals_per_launch * fl / (kern_ms * 1e-3) / 1e12
         info = _lib.device_info()
+        cu = info['num_cu']
+        kform = form or next((f for f, t, lim in (('quad', 4, cu), ('team', 16, cu), ('reg', 16, 4 * cu)) if -(-C // t) <= lim), 'image')
+        tiles = -(-C // (4 if kform == 'quad' else 16))
+        default_workload = (args.config, C, S, world, dynamic) == (2, 1000, 250, 1, 'batch') and lag is None
+        traffic, traffic_src = committed_traffic() if default_workload else (None, None)
         out = {
-            'metric': 'live-point evals/sec (flow-transform + loglike), x_dim=%d' % D,
+            'metric': METRIC % D,
             'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'Rosenbrock x_dim=%d, %d live points (walkers) per GPU, %d MH steps per launch, '
-                                   'NVP hidden=%d blocks=%d layers=%d' % (D, C, S, H, B, L),
-                       'walkers_per_gpu': C, 'mcmc_steps': S, 'evals_per_step': evals_per_launch,
-                       'parallelism': 'walker-sharded x%d, no data-path collective' % world},
+            'config': {'workload': '%s x_dim=%d, %d live points (walkers) per GPU, %d MH steps per launch, NVP hidden=%d '
+                                   'blocks=%d layers=%d, %s' % (like, D, C, S, H, B, L,
+                                                                'fixed step' if not dynamic else 'batch-wide dynamic step rule'),
+                       'baseline_config': args.config, 'walkers_per_gpu': C, 'walkers_total': C_total, 'mcmc_steps': S,
+                       'evals_per_step': evals_per_launch,
+                       'parallelism': ('single GPU' if world == 1 and dist is None else
+                                       'walkers sharded x%d (%s scaling), one RCCL all-gather of the chain endpoints '
+                                       '[%d, %d] f64 per batch; flow replicas trained per rank (no weight broadcast)'
+                                       % (world, args.scaling, C, 2 * D + 1))},
             'roofline': {'bound': 'mfma', 'achieved': achieved_tflops, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved_tflops / FP32_PEAK_TFLOPS,
-                         # HBM bytes per launch from the committed rocprofv3 PMC passes of this command
-                         # (profiles/r01d/bench_pmc_summary.txt: FETCH_SIZE 452.2 KiB + WRITE_SIZE 1384.7 KiB, raw); only
-                         # valid for the default workload, null otherwise
-                         'traffic': MEASURED_TRAFFIC_BYTES if (D, C, S) == (50, 1000, 250) else None,
-                         'kernel': 'mh_kernel_team' if (C + 15) // 16 <= info['num_cu'] else 'mh_kernel',
-                         'kernel_ms': kern_ms, 'flops_per_eval': fl,
+                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel': 'mh_kernel_%s' % kform, 'kernel_ms': kern_ms, 'flops_per_eval': fl,
                          'hbm_frac_if_streamed': evals_per_launch * alg_bytes_per_eval(D) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         'note': 'f32-input MFMA peak (= f32 vector peak); %d walker tiles on %d CUs: occupancy-limited '
-                                 'at this population' % ((C + 15) // 16, info['num_cu'])},
+                         'note': 'f32-input MFMA peak (= f32 vector peak); %d walker tiles on %d CUs: latency-bound at this '
+                                 'population (a step is a serial chain of 9 small layers), see `saturated`' % (tiles, cu)},
             'device': info['name'],
         }
-        if not args.no_saturation and world == 1:
-            # the same kernel at a population that fills the chip (not the headline: BASELINE's config is 1000)
-            Cs = 16 * 4 * info['num_cu'] * 8  # 8 walker tiles per SIMD
-            us = np.random.RandomState(5).uniform(-1, 1, size=(Cs, D))
-            zz, _ = nvp.forward(us)
-            ll = flow.loglike(0, us, 5.0, device=dev)
-            Ss = 25
-            nvp.mh_steps(0, 5.0, zz, ll, float(ll.min()), step_size, Ss, seed=1)
+        if world == 1 and dist is None:
+            # K3: the single batched pass over all live points (inverse + box prior + likelihood), SURVEY.md 8d
+            for _ in range(3):
+                nvp.inverse_loglike(LIKE_ID[like], scale, z0)
             torch.cuda.synchronize(dev)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            nvp.mh_steps(0, 5.0, zz, ll, float(ll.min()), step_size, Ss, seed=2)
+            for _ in range(50):
+                nvp.inverse_loglike(LIKE_ID[like], scale, z0)
+            b.record()
+            torch.cuda.synchronize(dev)
+            ms = a.elapsed_time(b) / 50
+            out['k3'] = {'what': 'one fused pass (inverse + prior + loglike) over the %d live points, back-to-back launches' % C,
+                         'ms_per_pass': ms, 'evals_per_s': C / (ms * 1e-3)}
+            if dynamic:   # the same launches with a fixed step, and with the exact (lag 0) rule
+                for key, kw in (('fixed_step', dict(dynamic=False)), ('batch_rule_lag0', dict(dynamic='batch', lag=0))):
+                    tms = []
+                    for k in range(4):
+                        zz, ll = z0.clone(), logl0.clone()
+                        torch.cuda.synchronize(dev)
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record()
+                        nvp.mh_steps(LIKE_ID[like], scale, zz, ll, loglstar, step_size, S, seed=7 + k, **kw)
+                        b.record()
+                        torch.cuda.synchronize(dev)
+                        tms.append(a.elapsed_time(b))
+                    ms = float(np.median(tms[1:]))
+                    out[key] = {'kernel_ms': ms, 'evals_per_s': C * S / (ms * 1e-3)}
+        if not args.no_saturation and world == 1 and dist is None:
+            # the same step at a population that fills the chip (not the headline: BASELINE's config is 1000)
+            Cs = 16 * 4 * cu * 8  # 8 walker tiles per SIMD
+            us = np.random.RandomState(5).uniform(-1, 1, size=(Cs, D))
+            zz, _ = nvp.forward(us)
+            ll = flow.loglike(LIKE_ID[like], us, scale, device=dev)
+            Ss = 25
+            nvp.mh_steps(LIKE_ID[like], scale, zz, ll, float(ll.min()), step_size, Ss, seed=1)
+            torch.cuda.synchronize(dev)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            nvp.mh_steps(LIKE_ID[like], scale, zz, ll, float(ll.min()), step_size, Ss, seed=2)
             b.record()
             torch.cuda.synchronize(dev)
             ms = a.elapsed_time(b)
             out['saturated'] = {'walkers': Cs, 'mcmc_steps': Ss, 'kernel_ms': ms, 'evals_per_s': Cs * Ss / (ms * 1e-3),
-                                'tflops': Cs * Ss * fl / (ms * 1e-3) / 1e12,
+                                'tflops': Cs * Ss * fl / (ms * 1e-3) / 1e12, 'kernel': 'mh_kernel (image form)',
                                 'frac_of_fp32_peak': Cs * Ss * fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
-        if not args.no_spline and world == 1:
+        if not args.no_spline and world == 1 and dist is None and args.config == 2:
             # the same workload on the reference's default flow (neural spline flow): reported beside,
             # never as `value` (BASELINE's metric is quoted on the RealNVP path)
             from nnest_amd.spline import HipSpline
@@ -211,7 +344,7 @@ def main():
                 torch.cuda.synchronize(dev)
                 t_ms.append(e0.elapsed_time(e1))
             ms = float(np.median(t_ms[1:]))
-            out['spline_flow'] = {'kernel': 'spline_mh_kernel_team' if (C + 15) // 16 <= 2 * info['num_cu'] else 'spline_mh_kernel',
+            out['spline_flow'] = {'kernel': 'spline_mh_kernel_team' if (C + 15) // 16 <= 2 * cu else 'spline_mh_kernel',
                                   'kernel_ms': ms, 'evals_per_s': C * S / (ms * 1e-3),
                                   'note': 'SingleSpeedSpline hidden=%d blocks=%d bins=8; VALU-bound on the spline arithmetic' % (H, B)}
             if C >= 200:  # its training epoch at this population (90 % train / 10 % validation, batch 100: trainer.py:159-176)
@@ -225,10 +358,25 @@ def main():
                 res = sp.train_epochs(u0[nv:], u0[:nv], perms, None, max_epochs=E, **kw)
                 torch.cuda.synchronize(dev)
                 out['spline_flow']['train_ms_per_epoch'] = (time.perf_counter() - t0) / max(1, res['epochs_run']) * 1e3
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(D, H, B, L, nvp.store_packed(), C)
+        if world == 1 and dist is None and args.config == 2:
+            # K5 beside K4: the NVP training epoch at this population
+            nv = C // 10
+            E = 40
+            perms = torch.stack([torch.randperm(C - nv) for _ in range(E)]).int()
+            kw = dict(seed=1, jitter=0.01, batch=100, patience=1000)
+            tr = flow.HipNVP(D, H, B, L, device=dev, seed=1)
+            tr.train_epochs(u0[nv:], u0[:nv], perms[:2], None, max_epochs=2, **kw)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            res = tr.train_epochs(u0[nv:], u0[:nv], perms, None, max_epochs=E, **kw)
+            torch.cuda.synchronize(dev)
+            out['k5_train'] = {'ms_per_epoch': (time.perf_counter() - t0) / max(1, res['epochs_run']) * 1e3,
+                               'what': 'Trainer.train epoch loop in one launch (nnest_nvp_train), %d live points' % C}
+            out['logz'] = logz_report(dev, live_run=not args.no_logz)
+        if not args.no_cpu_baseline and world == 1 and dist is None:
+            out['cpu_baseline'] = cpu_baseline(D, nvp.store_packed(), like, scale, C)
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

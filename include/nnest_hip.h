@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 8
+#define NNEST_HIP_ABI_VERSION 9
 
 enum {
     NNEST_OK = 0,
@@ -59,11 +59,25 @@ typedef struct {
 
 /* flags for nnest_mh_constrained_steps */
 enum {
-    NNEST_MH_DYNAMIC_STEP = 1, /* sampler.py:422-431 step-size adaptation (see DESIGN.md for the group rule) */
+    NNEST_MH_DYNAMIC_STEP = 1, /* sampler.py:422-431 step-size adaptation applied per group of 16 walkers (one wave): equals
+                                * the reference's rule for batches of <= 16 chains, shard-invariant, no cross-workgroup
+                                * traffic */
     NNEST_MH_UNCONSTRAINED = 2, /* loglstar = None (sampler.py:371-410): plain Metropolis with the likelihood and the box
                                  * prior in the ratio, min(1, exp(dlogdet + dlogl)); `loglstar` is ignored and every
                                  * proposal counts as one likelihood call */
+    NNEST_MH_DYNAMIC_BATCH = 4, /* sampler.py:422-431 over ALL C walkers of the launch, as the reference applies it: every
+                                 * workgroup posts its accepted count per step to `sync_dev`; the scale used from step
+                                 * s + 1 + lag on reflects the batch-wide count of step s.  lag = flags bits 8..11
+                                 * (NNEST_MH_LAG): 0 is the reference's rule exactly (a grid-wide wait per step), lag >= 1
+                                 * takes the wait off the step's critical path (the counts are requested one step ahead).
+                                 * Needs every workgroup resident: NNEST_E_UNSUPPORTED beyond ~16 walkers x 8 x CUs */
 };
+#define NNEST_MH_LAG(n) (((n) & 15) << 8)
+/* flags bits 16..19: pin the kernel form (0 = by population).  A caller that shards ONE batch over ranks pins the form the
+ * whole batch would get, so that a shard reproduces the slice of the unsharded run bit for bit. */
+enum { NNEST_MH_FORM_AUTO = 0, NNEST_MH_FORM_IMAGE = 1, NNEST_MH_FORM_REG = 2, NNEST_MH_FORM_TEAM = 3, NNEST_MH_FORM_QUAD = 4,
+       NNEST_MH_FORM_QUAD1 = 5 /* the quad tile with both nets on one wave (same bits as QUAD; A/B diagnostic) */ };
+#define NNEST_MH_FORM(f) (((f) & 15) << 16)
 
 typedef struct nnest_nvp nnest_nvp_t; /* opaque: RealNVP coupling stack + Adam state on one device */
 
@@ -136,12 +150,16 @@ int nnest_loglike(const nnest_like_t *like, const float *x_unit_dev, double *log
  *   n_call_dev [C]     out int32: likelihood calls per walker (rows that passed the prior/Jacobian test,
  *                      sampler.py:358-363)
  *   scale_out_dev      optional float32 [ngroups]: final scale per adaptation group (sampler.py:422-431)
+ *   sync_dev           NNEST_MH_DYNAMIC_BATCH only (else NULL): nnest_mh_sync_words(steps) 8-byte words, ZEROED by the
+ *                      caller before every launch; the last word is an error flag (non-zero: a bounded wait ran out)
  */
 int nnest_mh_constrained_steps(nnest_nvp_t *nvp, const nnest_like_t *like, float *z_dev, float *x_dev,
                                double *logl_dev, double loglstar, float step_size, int steps, int C, int flags,
                                const float *noise_dz_dev, const float *noise_u_dev, uint64_t seed,
                                uint64_t walker_offset, float *hist_x_dev, double *hist_logl_dev, int *n_accept_dev,
-                               int *n_call_dev, float *scale_out_dev, void *stream);
+                               int *n_call_dev, float *scale_out_dev, void *sync_dev, void *stream);
+/* size of sync_dev in 8-byte words for a launch of `steps` steps */
+int nnest_mh_sync_words(int steps);
 /* number of adaptation groups nnest_mh_constrained_steps uses for C walkers (size of scale_out_dev) */
 int nnest_mh_num_groups(const nnest_nvp_t *nvp, int C);
 
@@ -230,7 +248,7 @@ int nnest_spline_mh_constrained_steps(nnest_spline_t *spl, const nnest_like_t *l
                                       double *logl_dev, double loglstar, float step_size, int steps, int C, int flags,
                                       const float *noise_dz_dev, const float *noise_u_dev, uint64_t seed,
                                       uint64_t walker_offset, float *hist_x_dev, double *hist_logl_dev, int *n_accept_dev,
-                                      int *n_call_dev, float *scale_out_dev, void *stream);
+                                      int *n_call_dev, float *scale_out_dev, void *sync_dev, void *stream);
 
 /* Training.  ActNorm's data-dependent initialisation (networks.py:698-705): s = -log std(x) (unbiased), t = -mean(x e^s)
  * block after block from the batch x_dev [N,D] -- in the reference this happens inside the first forward pass of a

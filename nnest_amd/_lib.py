@@ -15,15 +15,30 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NNEST_HIP_LIB', os.path.join(_HERE, 'libnnest_hip.so'))  # override: developer A/B builds only
 
 NNEST_OK = 0
+NNEST_E_UNSUPPORTED = 3
 LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'himmelblau': 2, 'gaussian': 3, 'eggbox': 4, 'shell': 5, 'double_shell': 6}
-MH_DYNAMIC_STEP = 1
+MH_DYNAMIC_STEP = 1      # per 16-walker group
 MH_UNCONSTRAINED = 2
+MH_DYNAMIC_BATCH = 4     # over the whole launch, as the reference (sampler.py:422-431); lag in bits 8..11
+MH_FORMS = {None: 0, 'auto': 0, 'image': 1, 'reg': 2, 'team': 3, 'quad': 4, 'quad1': 5}
+MH_DEFAULT_LAG = 4      # steps between a step and the scale that reflects its batch-wide count
 TRAIN_RESUME = 1
 TRAIN_FINALIZE = 2
 
 
+def mh_flags(dynamic=False, free=False, lag=None, form=None):
+    """flags word of nnest_mh_constrained_steps.  dynamic: False | True / 'batch' (the reference's batch-wide rule) |
+    'group' (per 16 walkers)"""
+    fl = MH_UNCONSTRAINED if free else 0
+    if dynamic == 'group':
+        fl |= MH_DYNAMIC_STEP
+    elif dynamic:
+        fl |= MH_DYNAMIC_BATCH | ((MH_DEFAULT_LAG if lag is None else int(lag)) & 15) << 8
+    return fl | (MH_FORMS[form] << 16)
+
+
 class NnestHipError(RuntimeError):
-    pass
+    code = None   # NNEST_E_* of the failing call, when it came from the library
 
 
 class LikeSpec(ctypes.Structure):
@@ -82,13 +97,14 @@ SIGNATURES = {
     'nnest_nvp_inverse_loglike': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     'nnest_loglike': [_vp, _vp, _vp, _i, _i, _vp],
     'nnest_mh_constrained_steps': [_vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i, _i, _vp, _vp, _u64, _u64,
-                                   _vp, _vp, _vp, _vp, _vp, _vp],
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'nnest_mh_sync_words': [_i],
     'nnest_spline_forward': [_vp, _vp, _vp, _vp, _i, _vp],
     'nnest_spline_inverse': [_vp, _vp, _vp, _vp, _i, _vp],
     'nnest_spline_log_probs': [_vp, _vp, _vp, _i, _vp],
     'nnest_spline_inverse_loglike': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     'nnest_spline_mh_constrained_steps': [_vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i, _i, _vp, _vp, _u64, _u64,
-                                          _vp, _vp, _vp, _vp, _vp, _vp],
+                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'nnest_spline_vjp': [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
     'nnest_spline_adam_step': [_vp, _vp, _f, _f, _vp],
     'nnest_spline_actnorm_init': [_vp, _vp, _i, _vp],
@@ -134,7 +150,9 @@ def load():
 def check(rc):
     if rc != NNEST_OK:
         msg = load().nnest_hip_last_error()
-        raise NnestHipError('libnnest_hip error %d: %s' % (rc, msg.decode() if msg else '?'))
+        err = NnestHipError('libnnest_hip error %d: %s' % (rc, msg.decode() if msg else '?'))
+        err.code = rc
+        raise err
 
 
 def ptr(t):

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 
 #include "nnest_internal.h"
+#include "mh_common.h"
 
 using namespace nnest;
 
@@ -277,7 +278,7 @@ int nnest_mh_constrained_steps(nnest_nvp_t *h, const nnest_like_t *like, float *
                                double *logl_dev, double loglstar, float step_size, int steps, int C, int flags,
                                const float *noise_dz_dev, const float *noise_u_dev, uint64_t seed,
                                uint64_t walker_offset, float *hist_x_dev, double *hist_logl_dev, int *n_accept_dev,
-                               int *n_call_dev, float *scale_out_dev, void *stream) {
+                               int *n_call_dev, float *scale_out_dev, void *sync_dev, void *stream) {
     int rc = check_rows(h, z_dev, logl_dev, C);
     if (rc) return rc;
     LikeSpec lk;
@@ -285,11 +286,18 @@ int nnest_mh_constrained_steps(nnest_nvp_t *h, const nnest_like_t *like, float *
     if (steps < 0) return fail(NNEST_E_ARG, "steps=%d < 0", steps);
     if ((noise_dz_dev == nullptr) != (noise_u_dev == nullptr))
         return fail(NNEST_E_ARG, "noise_dz_dev and noise_u_dev must both be given or both be NULL");
-    HIP_TRY(launch_mh(h->img, h->s, lk, z_dev, x_dev, logl_dev, loglstar, step_size, steps, C, flags,
-                      noise_dz_dev, noise_u_dev, seed, walker_offset, hist_x_dev, hist_logl_dev, n_accept_dev, n_call_dev,
-                      scale_out_dev, h->num_cu, (hipStream_t)stream));
+    if ((flags & NNEST_MH_DYNAMIC_BATCH) && !sync_dev) return fail(NNEST_E_ARG, "NNEST_MH_DYNAMIC_BATCH needs sync_dev");
+    hipError_t e = launch_mh(h->img, h->s, lk, z_dev, x_dev, logl_dev, loglstar, step_size, steps, C, flags,
+                             noise_dz_dev, noise_u_dev, seed, walker_offset, hist_x_dev, hist_logl_dev, n_accept_dev, n_call_dev,
+                             scale_out_dev, h->w, (unsigned long long *)sync_dev, h->num_cu, (hipStream_t)stream);
+    if (e == hipErrorInvalidConfiguration)
+        return fail(NNEST_E_UNSUPPORTED, "no kernel form for C=%d walkers with flags 0x%x (pinned form not applicable to this "
+                                         "shape / population, or the batch-wide step rule on a grid that may not be resident)", C, flags);
+    if (e != hipSuccess) return fail(NNEST_E_HIP, "launch_mh: %s", hipGetErrorString(e));
     return NNEST_OK;
 }
+
+int nnest_mh_sync_words(int steps) { return steps < 0 ? -1 : (int)mh_sync_words(steps) + 1; }
 
 int nnest_mh_num_groups(const nnest_nvp_t *h, int C) {
     (void)h;

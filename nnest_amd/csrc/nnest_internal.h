@@ -19,7 +19,11 @@ hipError_t launch_pass(const float *img, const FlowShape &s, int mode, const flo
 hipError_t launch_mh(const float *img, const FlowShape &s, const LikeSpec &like, float *z, float *x, double *logl,
                      double loglstar, float step_size, int steps, int C, int flags, const float *noise_dz,
                      const float *noise_u, uint64_t seed, uint64_t walker_offset, float *hist_x, double *hist_logl,
-                     int *n_accept, int *n_call, float *scale_out, int num_cu, hipStream_t st);
+                     int *n_accept, int *n_call, float *scale_out, const float *packed, unsigned long long *sync, int num_cu,
+                     hipStream_t st);
+struct MhArgs;
+bool quad_form_eligible(const MhArgs &a, int num_cu);        // nnest_quad.hip
+hipError_t launch_mh_quad(const MhArgs &a, hipStream_t st);  // nnest_quad.hip
 hipError_t launch_loglike(const LikeSpec &like, const float *x, double *logl, int N, int D, int num_cu, hipStream_t st);
 hipError_t launch_fill_noise(float *dz, float *u, int steps, int C, int D, uint64_t seed, uint64_t walker_offset,
                              hipStream_t st);
@@ -32,7 +36,7 @@ hipError_t launch_spline_pass(const float *img, const SplineShape &sp, int mode,
 hipError_t launch_spline_mh(const float *img, const SplineShape &sp, const LikeSpec &like, float *z, float *x, double *logl,
                             double loglstar, float step_size, int steps, int C, int flags, const float *noise_dz,
                             const float *noise_u, uint64_t seed, uint64_t walker_offset, float *hist_x, double *hist_logl,
-                            int *n_accept, int *n_call, float *scale_out, int num_cu, hipStream_t st);
+                            int *n_accept, int *n_call, float *scale_out, unsigned long long *sync, int num_cu, hipStream_t st);
 
 // training (nnest_train.hip)
 struct TrainArgs;

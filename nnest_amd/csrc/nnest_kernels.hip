@@ -6,16 +6,10 @@
 //   fill_noise_kernel         the in-kernel proposal noise as arrays (tests)
 // Launch wrappers (C++, used by nnest_abi.hip) are at the bottom.  See flow_tile.h for the data layout.
 #include "flow_tile.h"
+#include "mh_common.h"
 #include "nnest_internal.h"
 
 namespace nnest {
-
-// NNEST_STAMP: diagnostic build only (tools/stamp_run.py): s_memtime stamps around the segments of the MH step
-#ifdef NNEST_STAMP
-#define STAMP(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define STAMP(v) do { } while (0)
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // repack: one thread per float of the fragment image
@@ -163,60 +157,9 @@ __global__ void __launch_bounds__(256) loglike_kernel(const float *__restrict__ 
 // One wave = 16 walkers = one step-size adaptation group.  State (z, x, logdet, logl) stays in registers
 // for all `steps`; the only global traffic is the start/end state (plus optional recorded noise / history).
 // ------------------------------------------------------------------------------------------------
-struct MhArgs {
-    const float *img;
-    FlowShape s;
-    float *z;
-    float *x;
-    double *logl;
-    double loglstar;
-    float step_size;
-    int steps;
-    int C;
-    int flags;
-    LikeSpec like;
-    const float *noise_dz;
-    const float *noise_u;
-    uint64_t seed;
-    uint64_t walker_offset;
-    float *hist_x;
-    double *hist_logl;
-    int *n_accept;
-    int *n_call;
-    float *scale_out;
-};
-
 // The step loop, shared by the two kernel forms below; `inv(xs)` inverts the coupling stack on a tile and
 // returns the lane's log-det partial.  DBG = true adds the test/diagnostic I/O (recorded noise replay, per-step
 // history); the production instantiation carries none of those pointers through the step loop.
-// in-wave proposal streams: normals per (walker, lane group); the accept uniform per walker (identical in its 4
-// lanes).  Padded dims get exactly 0 (their weight fragments are 0, but 0 * inf would poison the accumulators).
-template <int NT>
-struct XoshiroNoise {
-    Xoshiro128 rn, ru;
-    unsigned valid_mask;
-    __device__ __forceinline__ void init(uint64_t seed, uint64_t walker, int g, int D) {
-        rn = xoshiro_seed(seed, walker, (uint32_t)g, NOISE_STREAM_DZ);
-        ru = xoshiro_seed(seed, walker, 0xffffffffu, NOISE_STREAM_U);
-        valid_mask = 0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (32 * t + 8 * g + j < D) valid_mask |= 1u << (8 * t + j);
-    }
-    __device__ __forceinline__ void next(float (&nz)[NT][8], float &u) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            xoshiro_normal8(rn, nz[t]);  // dims 32t + 8g + [0,8) = (c0r0, c1r0, c0r1, c1r1, c0r2, c1r2, c0r3, c1r3)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (!((valid_mask >> (8 * t + j)) & 1u)) nz[t][j] = 0.f;
-        }
-        u = xoshiro_uniform(ru);
-    }
-};
-
 template <int NT, bool DBG, class Inv, class Noise>
 __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, const Inv &inv, Noise &noise, bool writer) {
     const int w = lane & 15, g = lane >> 4;
@@ -227,7 +170,10 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
     const int nvalid = min(16, a.C - tile * 16);  // walkers in this adaptation group
     const LikeSpec like = a.like;
     const double loglstar = a.loglstar;
-    const bool dynamic = (a.flags & NNEST_MH_DYNAMIC_STEP) != 0;
+    const bool dynamic = (a.flags & (NNEST_MH_DYNAMIC_STEP | NNEST_MH_DYNAMIC_BATCH)) != 0;
+    const bool batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;
+    const int lag = mh_flag_lag(a.flags);
+    const int ntiles = (a.C + 15) >> 4;
     const bool free_mode = (a.flags & NNEST_MH_UNCONSTRAINED) != 0;
 
     f32x4 z[2][NT], x[2][NT];
@@ -258,6 +204,10 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
     (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)a_noise; (void)a_inv; (void)a_post; (void)a_tot;
     for (int it = 1; it <= S; ++it) {
         STAMP(st4);
+        // batch-wide step rule: the counts of step it - lag are requested now and consumed at the end of the step
+        unsigned long long early = 0;
+        const bool have_total = batch && dynamic && it - lag >= 1;
+        if (have_total && lag > 0) early = mh_sync_read(a.sync, it - lag);
         // proposal z' = z + randn * scale  (sampler.py:310, :316); float32 like torch
         const float fs = (float)scale;
         f32x4 zp[2][NT], xp[2][NT];
@@ -328,12 +278,25 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
             }
         ld = acc ? ldp : ld;
         logl = acc ? lp : logl;
-        if (dynamic) {  // sampler.py:422-431, per adaptation group
-            unsigned long long bal = __ballot(acc && g == 0);
-            int num_accepted = __popcll(bal);
-            if (2 * num_accepted > nvalid) accept += 1; else reject += 1;
-            if (accept > reject) scale *= exp(1.0 / (1 + accept));
-            if (accept < reject) scale /= exp(1.0 / (1 + reject));
+        if (dynamic) {  // sampler.py:422-431: per adaptation group (one wave), or over the whole batch with the
+            //                 counts of step it - lag (NNEST_MH_DYNAMIC_BATCH; mh_common.h)
+            const int tile_accepted = __popcll(__ballot(acc && g == 0));
+            int num_accepted = tile_accepted, num_total = nvalid;
+            bool apply = true;
+            if (batch) {
+                // lag >= 1: consume the counts requested at the top of the step BEFORE posting this step's -- memory operations
+                // retire in order, and an atomic stays outstanding for 600-3000 cycles (MI355X_MICROARCH.md)
+                apply = have_total;
+                if (apply && lag > 0) num_accepted = mh_sync_total(a.sync, it - lag, ntiles, early, a.sync_err);
+                if (writer && lane == 0) mh_sync_post(a.sync, it, tile, tile_accepted);
+                if (apply && lag == 0) num_accepted = mh_sync_total(a.sync, it, ntiles, mh_sync_read(a.sync, it), a.sync_err);
+                num_total = a.C;
+            }
+            if (apply) {
+                if (2 * num_accepted > num_total) accept += 1; else reject += 1;
+                if (accept > reject) scale *= exp(1.0 / (1 + accept));
+                if (accept < reject) scale /= exp(1.0 / (1 + reject));
+            }
         }
 #ifdef NNEST_STAMP
         { unsigned long long e; STAMP(e); a_noise += st1 - st0; a_inv += st3 - st2; a_post += e - st3; a_tot += e - st4; }
@@ -665,11 +628,20 @@ static hipError_t launch_pass_t(const PassArgs &a_in, int num_cu, hipStream_t st
     return hipGetLastError();
 }
 
+// Which form runs (DESIGN.md "K4"): quad (4 walkers per tile, nnest_quad.hip) while its tiles fit the CUs, then team, register,
+// image by population; flags bits 16..19 pin a form (a caller that shards one batch over ranks pins the form the whole
+// batch would get, so a shard reproduces the slice of the unsharded run bit for bit).  The batch-wide step rule needs every
+// workgroup resident: it is refused where the grid could exceed the chip.
 template <int NT, int NH, int LT>
 static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
     const int ntiles = (a.C + 15) / 16;
+    const int form = mh_flag_form(a.flags);
+    const bool batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;
+    if (batch && !a.sync) return hipErrorInvalidValue;
+    if ((form == MH_FORM_AUTO || form == MH_FORM_QUAD || form == MH_FORM_QUAD1) && quad_form_eligible(a, num_cu)) return launch_mh_quad(a, st);
+    if (form == MH_FORM_QUAD || form == MH_FORM_QUAD1) return hipErrorInvalidConfiguration;
     if constexpr (LT == 1 && NH == 1) {
-        if (a.s.B == 3 && ntiles <= num_cu && !a.noise_dz && a.s.scale_mode != 2) {  // fewer tiles than CUs: three waves per tile (team form)
+        if ((form == MH_FORM_AUTO || form == MH_FORM_TEAM) && a.s.B == 3 && ntiles <= num_cu && !a.noise_dz && a.s.scale_mode != 2) {  // fewer tiles than CUs: three waves per tile (team form)
             const size_t timg = NT <= 2 ? 0 : (size_t)a.s.image_floats * 4;  // 3-4 tiles per class: fragments from an LDS image
             if (a.hist_x || a.hist_logl) {
                 hipError_t e = allow_lds(mh_kernel_team<NT, 1, 3, true>, timg + 48 * 1024);
@@ -683,8 +655,9 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
             return hipGetLastError();
         }
     }
+    if (form == MH_FORM_TEAM) return hipErrorInvalidConfiguration;
     if constexpr (LT == 1 && NH == 1 && NT <= 2) {  // register form: NT >= 3 would spill
-        if (a.s.B == 3 && ntiles <= 4 * num_cu && a.s.scale_mode != 2) {  // one wave per SIMD available; SingleSpeedNVP defaults: hidden_dim 16, num_blocks 3, num_layers 1 (nnest/sampler.py:37-43)
+        if ((form == MH_FORM_AUTO || form == MH_FORM_REG) && a.s.B == 3 && ntiles <= 4 * num_cu && a.s.scale_mode != 2) {  // one wave per SIMD available; SingleSpeedNVP defaults: hidden_dim 16, num_blocks 3, num_layers 1 (nnest/sampler.py:37-43)
             if (a.noise_dz || a.hist_x || a.hist_logl)
                 hipLaunchKernelGGL((mh_kernel_reg<NT, 1, 1, 3, true>), dim3(ntiles), dim3(64), 0, st, a);
             else
@@ -692,8 +665,10 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
             return hipGetLastError();
         }
     }
+    if (form == MH_FORM_REG) return hipErrorInvalidConfiguration;
     int block, grid;
     pick_geometry(ntiles, num_cu, 8, &block, &grid);  // mh_kernel: __launch_bounds__(512, 3)
+    if (batch && grid > num_cu) return hipErrorInvalidConfiguration;  // one workgroup per CU is what is certainly resident
     const size_t img_bytes = (size_t)a.s.image_floats * 4;
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
     if (img_bytes <= (size_t)LDS_IMAGE_LIMIT) {
@@ -774,9 +749,13 @@ hipError_t launch_pass(const float *img, const FlowShape &s, int mode, const flo
 hipError_t launch_mh(const float *img, const FlowShape &s, const LikeSpec &like, float *z, float *x, double *logl,
                      double loglstar, float step_size, int steps, int C, int flags, const float *noise_dz,
                      const float *noise_u, uint64_t seed, uint64_t walker_offset, float *hist_x, double *hist_logl,
-                     int *n_accept, int *n_call, float *scale_out, int num_cu, hipStream_t st) {
+                     int *n_accept, int *n_call, float *scale_out, const float *packed, unsigned long long *sync, int num_cu,
+                     hipStream_t st) {
     if (C <= 0) return hipSuccess;
     MhArgs a;
+    a.packed = packed;
+    a.sync = sync;
+    a.sync_err = sync ? reinterpret_cast<int *>(sync + mh_sync_words(steps)) : nullptr;  // the word behind the counters
     a.img = img; a.s = s; a.z = z; a.x = x; a.logl = logl; a.loglstar = loglstar; a.step_size = step_size;
     a.steps = steps; a.C = C; a.flags = flags; a.like = like;
     a.noise_dz = noise_dz; a.noise_u = noise_u; a.seed = seed; a.walker_offset = walker_offset;

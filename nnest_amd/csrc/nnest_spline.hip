@@ -328,7 +328,7 @@ int nnest_spline_mh_constrained_steps(nnest_spline_t *h, const nnest_like_t *lik
                                       double loglstar, float step_size, int steps, int C, int flags, const float *noise_dz_dev,
                                       const float *noise_u_dev, uint64_t seed, uint64_t walker_offset, float *hist_x_dev,
                                       double *hist_logl_dev, int *n_accept_dev, int *n_call_dev, float *scale_out_dev,
-                                      void *stream) {
+                                      void *sync_dev, void *stream) {
     int rc = scheck_rows(h, z_dev, logl_dev, C);
     if (rc) return rc;
     LikeSpec lk;
@@ -336,9 +336,13 @@ int nnest_spline_mh_constrained_steps(nnest_spline_t *h, const nnest_like_t *lik
     if (steps < 0) return spline_fail(NNEST_E_ARG, "steps=%d < 0", steps);
     if ((noise_dz_dev == nullptr) != (noise_u_dev == nullptr))
         return spline_fail(NNEST_E_ARG, "noise_dz_dev and noise_u_dev must both be given or both be NULL");
-    SHIP_TRY(launch_spline_mh(h->img, h->s, lk, z_dev, x_dev, logl_dev, loglstar, step_size, steps, C, flags, noise_dz_dev,
-                              noise_u_dev, seed, walker_offset, hist_x_dev, hist_logl_dev, n_accept_dev, n_call_dev,
-                              scale_out_dev, h->num_cu, (hipStream_t)stream));
+    if ((flags & NNEST_MH_DYNAMIC_BATCH) && !sync_dev) return spline_fail(NNEST_E_ARG, "NNEST_MH_DYNAMIC_BATCH needs sync_dev");
+    hipError_t e = launch_spline_mh(h->img, h->s, lk, z_dev, x_dev, logl_dev, loglstar, step_size, steps, C, flags, noise_dz_dev,
+                                    noise_u_dev, seed, walker_offset, hist_x_dev, hist_logl_dev, n_accept_dev, n_call_dev,
+                                    scale_out_dev, (unsigned long long *)sync_dev, h->num_cu, (hipStream_t)stream);
+    if (e == hipErrorInvalidConfiguration)
+        return spline_fail(NNEST_E_UNSUPPORTED, "batch-wide step rule: C=%d walkers do not fit a resident grid", C);
+    if (e != hipSuccess) return spline_fail(NNEST_E_HIP, "launch_spline_mh: %s", hipGetErrorString(e));
     return NNEST_OK;
 }
 

@@ -171,6 +171,7 @@ static hipError_t launch_spline_mh_t(const MhArgs &a, const SplArgs &q, int num_
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
     // (eight waves per tile measured slower than four: 12.0 vs 8.0 ms at x_dim 50 -- the 512-thread workgroup halves the
     // register budget and the redundant trunk / affine work grows)
+    if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && ntiles > num_cu) return hipErrorInvalidConfiguration;  // batch rule: resident grid only
     if (ntiles <= 2 * num_cu) {  // small population: four waves per walker tile
         const size_t ldsb = (size_t)(((4 * 16 * (q.sp.D + 1) + 3) & ~3) + 4 * NT * 64 * 4 + 4 * 16) * sizeof(float);
         if (dbg) hipLaunchKernelGGL((spline_mh_kernel_team<NT, NH, 4, true>), dim3(ntiles), dim3(256), ldsb, st, a, q);
@@ -179,6 +180,7 @@ static hipError_t launch_spline_mh_t(const MhArgs &a, const SplArgs &q, int num_
     }
     int block, grid;
     pick_geometry(ntiles, num_cu, 4, &block, &grid);
+    if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && grid > num_cu) return hipErrorInvalidConfiguration;  // batch rule: resident grid only
     const size_t lds = (size_t)(block / 64) * 16 * (q.sp.D + 1) * sizeof(float);
     if (a.noise_dz || a.hist_x || a.hist_logl)
         hipLaunchKernelGGL((spline_mh_kernel<NT, NH, true>), dim3(grid), dim3(block), lds, st, a, q);
@@ -200,9 +202,12 @@ hipError_t launch_spline_pass(const float *img, const SplineShape &sp, int mode,
 hipError_t launch_spline_mh(const float *img, const SplineShape &sp, const LikeSpec &like, float *z, float *x, double *logl,
                             double loglstar, float step_size, int steps, int C, int flags, const float *noise_dz,
                             const float *noise_u, uint64_t seed, uint64_t walker_offset, float *hist_x, double *hist_logl,
-                            int *n_accept, int *n_call, float *scale_out, int num_cu, hipStream_t st) {
+                            int *n_accept, int *n_call, float *scale_out, unsigned long long *sync, int num_cu, hipStream_t st) {
     if (C <= 0) return hipSuccess;
+    if ((flags & NNEST_MH_DYNAMIC_BATCH) && !sync) return hipErrorInvalidValue;
     MhArgs a{};
+    a.sync = sync;
+    a.sync_err = sync ? reinterpret_cast<int *>(sync + mh_sync_words(steps)) : nullptr;
     a.s.D = sp.D;
     a.z = z; a.x = x; a.logl = logl; a.loglstar = loglstar; a.step_size = step_size; a.steps = steps; a.C = C; a.flags = flags;
     a.like = like; a.noise_dz = noise_dz; a.noise_u = noise_u; a.seed = seed; a.walker_offset = walker_offset;

@@ -147,11 +147,14 @@ class _HipFlow(object):
         return x, ld, logl, inbox
 
     def mh_steps(self, like_id, like_scale, z, logl, loglstar, step_size, steps, dynamic=False, noise=None, seed=0,
-                 walker_offset=0, history=False, like_params=None):
+                 walker_offset=0, history=False, like_params=None, lag=None, form=None):
         """K4: `steps` constrained Metropolis steps for all walkers in one launch (Sampler._mcmc_sample,
         sampler.py:229-463).  z [C,D] float32 and logl [C] float64 are updated in place.
         noise = (dz [steps,C,D], u [steps,C]) replays recorded draws; None = in-kernel Philox.
-        loglstar None / NaN = the unconstrained branch (sampler.py:371-410): likelihood and box prior in the ratio."""
+        loglstar None / NaN = the unconstrained branch (sampler.py:371-410): likelihood and box prior in the ratio.
+        dynamic: False | True or 'batch' (sampler.py:422-431 over all C walkers; `lag` steps between a step and the
+        scale that reflects its count, 0 = the reference exactly) | 'group' (per 16 walkers, shard-invariant).
+        form: None (by population) | 'quad' | 'team' | 'reg' | 'image' (include/nnest_hip.h NNEST_MH_FORM_*)."""
         free = loglstar is None or loglstar != loglstar
         loglstar = 0.0 if free else loglstar
         assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()
@@ -170,15 +173,24 @@ class _HipFlow(object):
             dz = _as_dev_f32(noise[0].reshape(-1, self.D), dev)
             u = noise[1].to(device=dev, dtype=torch.float32).contiguous()
             assert dz.shape[0] == steps * C and u.numel() == steps * C
+        flags = _lib.mh_flags(dynamic, free, lag, form)
+        sync = None
+        if flags & _lib.MH_DYNAMIC_BATCH:   # per-step batch counters, zeroed for every launch; last word = error flag
+            sync = torch.zeros(self._lib.nnest_mh_sync_words(int(steps)), dtype=torch.int64, device=dev)
         with torch.cuda.device(dev):
             lk = _lib.like_spec(like_id, like_scale, like_params)
             _lib.check(self._sym['mh'](
                 self._h, ctypes.byref(lk), _lib.ptr(z), _lib.ptr(x), _lib.ptr(logl), float(loglstar),
-                float(step_size), int(steps), C, (_lib.MH_DYNAMIC_STEP if dynamic else 0) | (_lib.MH_UNCONSTRAINED if free else 0),
-                _lib.ptr(dz), _lib.ptr(u),
+                float(step_size), int(steps), C, flags, _lib.ptr(dz), _lib.ptr(u),
                 int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), _lib.ptr(hx), _lib.ptr(hl), _lib.ptr(n_acc),
-                _lib.ptr(n_call), _lib.ptr(scale_out), _lib.current_stream(dev)))
-        return dict(x=x, n_accept=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl)
+                _lib.ptr(n_call), _lib.ptr(scale_out), _lib.ptr(sync), _lib.current_stream(dev)))
+        return dict(x=x, n_accept=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl, sync=sync)
+
+    @staticmethod
+    def check_sync(res):
+        """raise if a bounded wait of the batch-wide step rule ran out (a workgroup was not resident); synchronises"""
+        if res.get('sync') is not None and int(res['sync'][-1].item()) != 0:
+            raise _lib.NnestHipError('batch-wide step rule: a wait on the per-step counters ran out')
 
     def fill_noise(self, steps, C, seed=0, walker_offset=0):
         dz = torch.empty(steps, C, self.D, dtype=torch.float32, device=self.device)

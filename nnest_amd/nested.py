@@ -10,7 +10,13 @@ a block of candidates per flow launch instead of one.
 
 Multi-GPU (torch.distributed, one process per GPU): the live set and the evidence state are replicated on
 every rank; rank 0 draws all host-side randomness and broadcasts it; each MCMC batch is sharded over ranks
-and its endpoints are all-gathered; rank 0 retrains the flow and broadcasts the <= 86 KB of weights.
+and its endpoints are all-gathered on device memory (RCCL); every rank retrains its own replica of the flow from
+one broadcast seed -- the training kernels are bitwise reproducible, so the replicas stay identical with no weight
+broadcast (a trainer that cannot promise that is trained on rank 0 and its weights are broadcast).
+
+Deviation from the reference's checkpoint cadence (nested.py:473-485 dumps every dead point and rewrites chain.txt as
+text every `log_interval` accepted points, O(n^2) over a run -- 995 s of a 15 s GPU run): full dumps are limited to one
+per `checkpoint_min_seconds` (default 30; 0 restores the reference's cadence), so a crash loses at most that much work.
 """
 import csv
 import glob
@@ -20,9 +26,28 @@ import os
 import time
 
 import numpy as np
+import torch
 
 from .priors import UniformPrior
 from .sampler import Sampler
+
+
+class _Evidence(object):
+    """Running evidence log Z and information H as dead points arrive with weight logwt = log(volume shell) + logL
+    (the recurrence of nested.py:280-284, applied to the final live points in nested.py:487-495 too)."""
+
+    def __init__(self, logz=-1e300, h=0.0):
+        self.logz, self.h = logz, h
+
+    def add(self, logwt, logl):
+        total = np.logaddexp(self.logz, logwt)
+        self.h = np.exp(logwt - total) * logl + np.exp(self.logz - total) * (self.h + self.logz) - total
+        self.logz = total
+
+
+def _first_live(strategy, expired):
+    """the sampling method in force: the first of `strategy` that has not expired (nested.py:300-306)"""
+    return next((m for m in strategy if m not in expired), '')
 
 
 class NestedSampler(Sampler):
@@ -94,22 +119,50 @@ class NestedSampler(Sampler):
         return out
 
     def _train(self, active_u, train_iters, jitter):
-        """nested.py:311-314.  Distributed: rank 0 trains, the packed weights are broadcast (C3)."""
+        """nested.py:311-314.  Distributed: every rank trains the same replica from one broadcast seed when the trainer is
+        bitwise reproducible (`replicable`); otherwise rank 0 trains and the packed weights are broadcast (C3)."""
         if not self.use_mpi:
             self.trainer.train(active_u, max_iters=train_iters, jitter=jitter)
             return
+        if getattr(self.trainer, 'replicable', False):
+            if not getattr(self, '_replicas_aligned', False):   # once: every rank starts from rank 0's weights
+                self._broadcast_weights()
+                self._replicas_aligned = True
+            seed = np.array([self._next_seed() & 0x7FFFFFFF if self.mpi_rank == 0 else 0], dtype=np.int64)
+            seed = int(self._broadcast(seed)[0])
+            self.trainer.train(active_u, max_iters=train_iters, jitter=jitter, rng_seed=seed)
+            return
         if self.mpi_rank == 0:
             self.trainer.train(active_u, max_iters=train_iters, jitter=jitter)
+        self._broadcast_weights()
+
+    def _broadcast_weights(self):
+        """C3: rank 0's packed weights (<= 86 KB for the NVP shapes) to every rank"""
         netG = self.trainer.netG
         w = self._broadcast(netG.store_packed(), src=0)
         if hasattr(netG, 'P'):  # spline flow: the fixed permutations of the 1x1 convs are not part of the weights
             P = netG.P
             P = {k: self._broadcast(v, src=0) for k, v in P.items()} if isinstance(P, dict) else self._broadcast(P, src=0)
+            # ... and whether ActNorm's data-dependent initialisation has happened is a plain attribute (networks.py:698-705)
+            done = bool(self._broadcast(np.array([int(netG.data_dep_init_done)], dtype=np.int64))[0])
             if self.mpi_rank != 0:
                 netG.load_packed(w, P)
-                netG.data_dep_init_done = True
+                netG.data_dep_init_done = done
         elif self.mpi_rank != 0:
             netG.load_packed(w)
+
+    def _pinned_form(self, C):
+        """the K4 form the WHOLE batch of C chains would run (nnest_kernels.hip launch_mh_t), pinned on every rank's shard so
+        that the sharded batch reproduces the unsharded one bit for bit"""
+        if self.mpi_size == 1 or self._fused_like_id is None:
+            return None
+        from . import _lib
+        cu = getattr(self, '_num_cu', None) or _lib.device_info()['num_cu']
+        self._num_cu = cu
+        for form, tile, lim in (('quad', 4, cu), ('team', 16, cu), ('reg', 16, 4 * cu)):
+            if -(-C // tile) <= lim:
+                return form
+        return 'image'
 
     def _checkpoint(self, it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt, state):
         cp = self.logs['checkpoint']
@@ -187,7 +240,7 @@ class NestedSampler(Sampler):
                 assert it == len(saved_logl)
             if self.use_mpi:
                 raise NotImplementedError('resume from checkpoint with more than one rank')
-            logz, h, logvol = data['logz'], data['h'], data['logvol']
+            ev, logvol = _Evidence(data['logz'], data['h']), data['logvol']
             self.total_calls = int(data['ncall'] / self.mpi_size)
             total_calls = data['ncall']
             fraction_remain = data['fraction_remain']
@@ -202,14 +255,13 @@ class NestedSampler(Sampler):
             if primary:
                 self.logger.info('Step [0] max logl [%5.4e] vol [1.0] ncalls [%d]' % (np.max(active_logl), total_calls))
             saved_v, saved_logl, saved_logwt = [], [], []
-            h = 0.0
-            logz = -1e300
+            ev = _Evidence()
             logvol = np.log(1.0 - np.exp(-1.0 / N))          # nested.py:244
             fraction_remain = 1.0
             it = 0
             if primary:
                 self._checkpoint(it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt,
-                                 {'logz': logz, 'h': h, 'logvol': logvol, 'ncall': total_calls,
+                                 {'logz': ev.logz, 'h': ev.h, 'logvol': logvol, 'ncall': total_calls,
                                   'fraction_remain': fraction_remain, 'strategy': strategy,
                                   'expired_strategies': expired_strategies})
 
@@ -230,25 +282,18 @@ class NestedSampler(Sampler):
             logwt = logvol + active_logl[worst]
             loglstar = active_logl[worst]
             expected_vol = np.exp(-it / N)
-            if accept_point:                                 # nested.py:280-293
-                logz_new = np.logaddexp(logz, logwt)
-                h = (np.exp(logwt - logz_new) * active_logl[worst] + np.exp(logz - logz_new) * (h + logz) - logz_new)
-                logz = logz_new
-                if self.num_derived > 0:
-                    saved_v.append(np.concatenate((active_v[worst], active_derived[worst])))
-                else:
-                    saved_v.append(np.array(active_v[worst], copy=True))
+            if accept_point:
+                # the worst live point dies: it joins the evidence and the chain (nested.py:280-293)
+                ev.add(logwt, loglstar)
+                dead = active_v[worst] if self.num_derived == 0 else np.concatenate((active_v[worst], active_derived[worst]))
+                saved_v.append(np.array(dead, copy=True))
                 saved_logwt.append(logwt)
-                saved_logl.append(active_logl[worst])
+                saved_logl.append(loglstar)
                 accept_point = False
 
-            old_method = current_method
-            for method in strategy:
-                if method not in expired_strategies:
-                    current_method = method
-                    break
-            if current_method != old_method:
-                get_samples = True
+            method = _first_live(strategy, expired_strategies)
+            if method != current_method:
+                current_method, get_samples = method, True
 
             if current_method != 'rejection_prior' and (first_time or it % update_interval == 0):
                 self._train(active_u, train_iters, jitter)   # nested.py:311-314
@@ -258,6 +303,8 @@ class NestedSampler(Sampler):
             if current_method in ('rejection_prior', 'rejection_flow', 'density_flow'):   # nested.py:322-396
                 if get_samples:
                     nb = 0
+                    nd = self.num_derived
+                    pack = None
                     if primary:
                         if current_method == 'rejection_prior':
                             s_x, s_l, s_d, nc = self._rejection_prior_sample(loglstar, num_trials=rejection_trials)
@@ -268,20 +315,18 @@ class NestedSampler(Sampler):
                                 cache=it % rejection_cache_interval == 0 or it % update_interval == 0)
                         else:                                        # nested.py:350-352
                             s_x, s_l, s_d, nc = self._density_sample(loglstar)
-                        pack = np.concatenate([np.ravel(s_x), np.ravel(s_l), [float(nc), float(len(np.ravel(s_l)))]])
-                    else:
-                        pack = None
+                        s_x, s_l = np.atleast_2d(s_x), np.ravel(s_l)
+                        s_d = np.empty((len(s_l), 0)) if nd == 0 else np.asarray(s_d, dtype=np.float64).reshape(len(s_l), nd)
+                        # one row per candidate: [x | logl | derived], then the call count
+                        pack = np.concatenate([np.concatenate([s_x, s_l[:, None], s_d], axis=1).ravel(), [float(nc)]])
                     if self.use_mpi:
                         n_rows = rejection_trials if (rejection_trials and current_method == 'rejection_prior') else 1
                         if not primary:
-                            pack = np.empty(n_rows * (self.x_dim + 1) + 2)
+                            pack = np.empty(n_rows * (self.x_dim + 1 + nd) + 1)
                         pack = self._broadcast(pack)
-                        n_rows = int(pack[-1])
-                        s_x = pack[:n_rows * self.x_dim].reshape(n_rows, self.x_dim)
-                        s_l = pack[n_rows * self.x_dim:n_rows * (self.x_dim + 1)]
-                        s_d = np.empty((n_rows, 0))
-                        nc = pack[-2]
-                    samples, loglikes, derived_samples = np.atleast_2d(s_x), np.ravel(s_l), s_d
+                    rows = pack[:-1].reshape(-1, self.x_dim + 1 + nd)
+                    samples, loglikes, derived_samples = rows[:, :self.x_dim], rows[:, self.x_dim], rows[:, self.x_dim + 1:]
+                    nc = pack[-1]
                     ncs.append(nc)
                     mean_calls = np.mean(ncs[-20:]) if len(ncs) > 20 else 0
                     mcmc_valid = 'mcmc' in strategy and 'mcmc' not in expired_strategies
@@ -296,25 +341,28 @@ class NestedSampler(Sampler):
                                              % current_method.replace('_', ' ').capitalize())
                         expired_strategies.append(current_method)
                         ncs = []
-                for ib in range(nb, samples.shape[0]):
+                while nb < samples.shape[0]:          # consume the candidates in order (nested.py:362-373)
+                    cand = nb
                     nb += 1
                     get_samples = nb == samples.shape[0]
-                    if loglikes[ib] > loglstar:
-                        active_u[worst] = samples[nb - 1, :]
+                    if loglikes[cand] > loglstar:
+                        active_u[worst] = samples[cand]
                         active_v[worst] = self.transform(active_u[worst])
-                        active_logl[worst] = loglikes[nb - 1]
+                        active_logl[worst] = loglikes[cand]
+                        if self.num_derived > 0:
+                            active_derived[worst] = derived_samples[cand]
                         accept_point = True
                         break
                 total_calls = int(self._all_sum(self.total_calls))
                 if accept_point and it > 0 and (it + 1) % log_interval == 0 and primary:
                     self.logger.info('Step [%d] loglstar [%5.4e] max logl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
-                                     'mean calls [%5.4f]' % (it + 1, loglstar, np.max(active_logl), logz, expected_vol,
+                                     'mean calls [%5.4f]' % (it + 1, loglstar, np.max(active_logl), ev.logz, expected_vol,
                                                              total_calls, mean_calls))
 
             elif current_method == 'mcmc':                   # nested.py:398-456
                 if get_samples:
                     nb = 0
-                    C = mcmc_num_chains
+                    C, D, nd = mcmc_num_chains, self.x_dim, self.num_derived
                     per = -(-C // self.mpi_size)
                     ctl = np.zeros(per * self.mpi_size + 1, dtype=np.int64)
                     if primary:
@@ -324,74 +372,77 @@ class NestedSampler(Sampler):
                     ctl = self._broadcast(ctl)
                     lo = self.mpi_rank * per
                     my = ctl[lo:lo + per]
-                    init_derived = active_derived[my, :] if self.num_derived > 0 else np.empty((per, 0))
-                    s_x, _lat, s_d, s_l, scale, nc = self._mcmc_sample(
-                        mcmc_steps, init_samples=active_u[my, :], init_loglikes=active_logl[my], init_derived=init_derived,
-                        loglstar=loglstar, step_size=step_size, dynamic_step_size=mcmc_dynamic_step_size,
-                        walker_offset=lo, seed=int(ctl[-1]))
-                    # only step 0, the last step and its logL are consumed (nested.py:432-437): gather those (C2)
-                    ends = np.concatenate([s_x[:, 0, :], s_x[:, -1, :], s_l[:, -1:]], axis=1).astype(np.float64)
+                    kw = dict(init_samples=active_u[my, :], init_loglikes=active_logl[my], loglstar=loglstar,
+                              walker_offset=lo, seed=int(ctl[-1]), form=self._pinned_form(C))
+                    # what the loop below consumes of a chain is its first x, its last x and the last logL (+ derived): one
+                    # row [x_0 | x_S | logL_S | derived_S] per chain, all-gathered over the ranks (C2) -- on device memory when
+                    # the whole batch ran inside the HIP kernel
+                    if self._fused_like_id is not None and nd == 0:
+                        ends, scale, nc = self._mcmc_endpoints_fused(mcmc_steps, step_size, mcmc_dynamic_step_size, **kw)
+                    else:
+                        s_x, _lat, s_d, s_l, scale, nc = self._mcmc_sample(
+                            mcmc_steps, step_size=step_size, dynamic_step_size=mcmc_dynamic_step_size,
+                            init_derived=active_derived[my, :] if nd > 0 else np.empty((per, 0)), **kw)
+                        ends = np.concatenate([s_x[:, 0, :], s_x[:, -1, :], s_l[:, -1:], s_d[:, -1, :]], axis=1).astype(np.float64)
                     ends = self._all_gather_rows(ends)[:C]
-                    samples = np.stack([ends[:, :self.x_dim], ends[:, self.x_dim:2 * self.x_dim]], axis=1)
-                    loglikes = np.stack([ends[:, -1], ends[:, -1]], axis=1)
-                    derived_samples = s_d
+                    ends = ends.cpu().numpy() if torch.is_tensor(ends) else ends
+                    start_u, end_u, end_logl, end_derived = ends[:, :D], ends[:, D:2 * D], ends[:, 2 * D], ends[:, 2 * D + 1:]
                     self.num_batches += 1
-                    # per-candidate quantities of the consumption loop below, once per batch instead of once per look
-                    moved = np.all(samples[:, 0, :] != samples[:, -1, :], axis=1)
-                    end_v = self.transform(samples[:, -1, :])
-                for ib in range(nb, samples.shape[0]):
+                    # a chain is usable if every coordinate moved (nested.py:432); its transform once per batch
+                    moved = np.all(start_u != end_u, axis=1)
+                    end_v = self.transform(end_u)
+                while nb < C:
+                    cand = nb
                     nb += 1
-                    get_samples = nb == samples.shape[0]
-                    if moved[ib] and loglikes[ib, -1] > loglstar:    # nested.py:432
-                        active_u[worst] = samples[ib, -1, :]
-                        active_v[worst] = end_v[ib]
-                        active_logl[worst] = loglikes[ib, -1]
-                        if self.num_derived > 0 and not self.use_mpi:
-                            active_derived[worst] = derived_samples[ib, -1, :]
+                    get_samples = nb == C
+                    if moved[cand] and end_logl[cand] > loglstar:    # nested.py:432-437
+                        active_u[worst] = end_u[cand]
+                        active_v[worst] = end_v[cand]
+                        active_logl[worst] = end_logl[cand]
+                        if nd > 0:
+                            active_derived[worst] = end_derived[cand]
                         accept_point = True
                         break
                 total_calls = int(self._all_sum(self.total_calls))
                 if accept_point and it > 0 and it % log_interval == 0 and primary:
                     acc = self.total_accepted / max(1, self.total_accepted + self.total_rejected)
                     self.logger.info('Step [%d] loglstar [%5.4e] maxlogl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
-                                     'scale [%5.4f]' % (it, loglstar, np.max(active_logl), logz, expected_vol, total_calls, scale))
+                                     'scale [%5.4f]' % (it, loglstar, np.max(active_logl), ev.logz, expected_vol, total_calls, scale))
                     with open(os.path.join(self.logs['results'], 'results.csv'), 'a') as f:
-                        csv.writer(f).writerow([it, acc, float('nan'), float('nan'), float('nan'), scale, loglstar, logz,
+                        csv.writer(f).writerow([it, acc, float('nan'), float('nan'), float('nan'), scale, loglstar, ev.logz,
                                                 fraction_remain, total_calls])
 
             if accept_point:                                 # nested.py:458-485
                 logvol -= 1.0 / N
                 logz_remain = np.max(active_logl) - it / N
-                fraction_remain = np.logaddexp(logz, logz_remain) - logz
+                fraction_remain = np.logaddexp(ev.logz, logz_remain) - ev.logz
                 it += 1
                 if primary:
-                    self.trainer.writer.add_scalar('logz', logz, it)
+                    self.trainer.writer.add_scalar('logz', ev.logz, it)
                 # checkpoint cadence as the reference (every log_interval accepted points, nested.py:473-485), but at
-                # most one full dump per `checkpoint_min_seconds`: the dump rewrites every dead point (and chain.txt
-                # as text), which is O(n^2) over a run and dominated the wall clock of long GPU runs
+                # most one full dump per `checkpoint_min_seconds` (module docstring)
                 if (it > 0 and it % log_interval == 0 and primary
                         and time.time() - last_checkpoint >= self.checkpoint_min_seconds):
                     last_checkpoint = time.time()
                     self.samples = np.array(saved_v)
-                    self.weights = np.exp(np.array(saved_logwt) - logz)
+                    self.weights = np.exp(np.array(saved_logwt) - ev.logz)
                     self.loglikes = np.array(saved_logl)
                     self._checkpoint(it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt,
-                                     {'logz': logz, 'h': h, 'logvol': logvol, 'ncall': total_calls,
+                                     {'logz': ev.logz, 'h': ev.h, 'logvol': logvol, 'ncall': total_calls,
                                       'fraction_remain': fraction_remain, 'strategy': strategy,
                                       'expired_strategies': expired_strategies})
                     self._save_samples(self.samples, self.loglikes, weights=self.weights)
 
-        # final live points (nested.py:487-495)
+        # the remaining live points share the last volume shell equally (nested.py:487-495)
         logvol = -len(saved_v) / N - np.log(N)
         for i in range(N):
-            logwt = logvol + active_logl[i]
-            logz_new = np.logaddexp(logz, logwt)
-            h = (np.exp(logwt - logz_new) * active_logl[i] + np.exp(logz - logz_new) * (h + logz) - logz_new)
-            logz = logz_new
-            saved_v.append(np.array(active_v[i]))
-            saved_logwt.append(logwt)
+            ev.add(logvol + active_logl[i], active_logl[i])
+            dead = active_v[i] if self.num_derived == 0 else np.concatenate((active_v[i], active_derived[i]))
+            saved_v.append(np.array(dead))
+            saved_logwt.append(logvol + active_logl[i])
             saved_logl.append(active_logl[i])
 
+        logz, h = ev.logz, ev.h
         self.logz = logz
         self.h = h
         self.logzerr = np.sqrt(h / N)

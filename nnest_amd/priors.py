@@ -29,6 +29,11 @@ class UniformPrior(Prior):
             return -np.inf
         return 0
 
+    def log_prob_rows(self, x):
+        """__call__ over the rows of x[N, D] at once (same comparisons, so NaN rows count as inside too)"""
+        out_of_box = np.any(x < self.minimum, axis=1) | np.any(x > self.maximum, axis=1)
+        return np.where(out_of_box, -np.inf, 0.0)
+
     def sample(self, num_samples):
         # numpy global RNG, one uniform block of (n, D) -- same stream consumption as priors.py:45-47
         return self.minimum + (self.maximum - self.minimum) * np.random.uniform(size=(num_samples, self.x_dim))

@@ -9,6 +9,7 @@ a batch are sharded over ranks, and the only data-path collective is one all-gat
 per batch (the reference's mpi4py gather+bcast of full histories, nnest/nested.py:416-427, shrunk to what is
 consumed).
 """
+import itertools
 import json
 import logging
 import os
@@ -16,6 +17,7 @@ import os
 import numpy as np
 import torch
 
+from . import _lib
 from .utils import create_logger, get_or_create_run_dir
 
 
@@ -79,58 +81,13 @@ class Sampler(object):
         self._user_prior = prior
         self._transform_prior = transform_prior
 
-        if transform is None:
-            self.transform = lambda x: x
-        else:
-            def safe_transform(x):  # sampler.py:100-108
-                if isinstance(x, list):
-                    x = np.array(x)
-                if len(x.shape) == 1:
-                    assert x.shape[0] == self.x_dim
-                    x = np.expand_dims(x, 0)
-                return transform(x)
-            self.transform = safe_transform
+        self._user_transform = transform
+        self.transform = self._checked_transform if transform is not None else (lambda x: x)
         self._linear_scale = detect_linear_scale(transform, x_dim)
-
-        def safe_loglike(x):  # sampler.py:110-133
-            if isinstance(x, list):
-                x = np.array(x)
-            if len(x.shape) == 1:
-                assert x.shape[0] == self.x_dim
-                x = np.expand_dims(x, 0)
-            res = loglike(self.transform(x))
-            self.total_calls += x.shape[0]
-            if isinstance(res, tuple):
-                logl, derived = res
-            else:
-                logl = res
-                derived = np.empty((x.shape[0], 0))
-            logl = np.array(logl, dtype=np.float64)  # float64 so that the -1e100 clamp below is representable
-            if len(logl.shape) == 0:
-                logl = np.expand_dims(logl, 0)
-            logl[np.logical_not(np.isfinite(logl))] = -1e100
-            if len(derived.shape) == 1:
-                raise ValueError('Derived should have dimensions (batch size, num derived params)')
-            if derived.shape[1] != self.num_derived:
-                raise ValueError('Is the number of derived parameters correct?')
-            return logl, derived
-        self.loglike = safe_loglike
-
+        self.loglike = self._checked_loglike
         sample_prior = getattr(prior, 'sample', None)
         self.sample_prior = sample_prior if callable(sample_prior) else None
-
-        def safe_prior(x):  # sampler.py:137-163
-            if isinstance(x, list):
-                x = np.array(x)
-            if len(x.shape) == 1:
-                assert x.shape[0] == self.x_dim
-                x = np.expand_dims(x, 0)
-            if prior is None:
-                return np.zeros(x.shape[0])
-            if transform_prior:
-                return np.array([prior(self.transform(r)) for r in x])
-            return np.array([prior(r) for r in x])
-        self.prior = safe_prior
+        self.prior = self._checked_prior
 
         # process group (the reference: mpi4py, sampler.py:165-177)
         self.use_mpi = False
@@ -138,7 +95,9 @@ class Sampler(object):
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.mpi_size = torch.distributed.get_world_size()
             self.mpi_rank = torch.distributed.get_rank()
-            self.use_mpi = self.mpi_size > 1
+            # an initialised process group selects the distributed code path, also with ONE rank (the degenerate case runs
+            # the same collectives; it is how the RCCL branch is exercised on a one-GPU box)
+            self.use_mpi = True
         self.single_or_primary_process = (not self.use_mpi) or self.mpi_rank == 0
 
         if self.single_or_primary_process or (log_dir is not None and os.path.isdir(os.path.join(log_dir, 'info'))):
@@ -183,6 +142,49 @@ class Sampler(object):
         if fused:
             self._fused_like_id = self._fused_eligibility()
 
+    # ---- the user's callables behind shape checks (sampler.py:97-163) ----------------------------------------------
+    def _rows(self, x):
+        """[D] or [N, D] (array or list) -> [N, D]"""
+        x = np.asarray(x) if isinstance(x, list) else x
+        if x.ndim == 1:
+            assert x.shape[0] == self.x_dim
+            x = x[None, :]
+        return x
+
+    def _checked_transform(self, x):
+        return self._user_transform(self._rows(x))
+
+    def _checked_loglike(self, x):
+        """loglike(transform(x)) -> (logl float64 [N], derived [N, num_derived]); counts the rows as likelihood calls;
+        non-finite values become -1e100 (sampler.py:110-133)"""
+        x = self._rows(x)
+        n = x.shape[0]
+        out = self._user_loglike(self.transform(x))
+        self.total_calls += n
+        logl, derived = out if isinstance(out, tuple) else (out, None)
+        logl = np.array(logl, dtype=np.float64, ndmin=1)   # a copy, float64: -1e100 is not representable in float32
+        logl[~np.isfinite(logl)] = -1e100
+        if derived is None:
+            derived = np.empty((n, 0))
+        elif np.ndim(derived) == 1:
+            raise ValueError('Derived should have dimensions (batch size, num derived params)')
+        derived = np.asarray(derived)
+        if derived.shape[1] != self.num_derived:
+            raise ValueError('Is the number of derived parameters correct?')
+        return logl, derived
+
+    def _checked_prior(self, x):
+        """log prior density of every row (sampler.py:137-163): the prior protocol is one row -> one number"""
+        x = self._rows(x)
+        prior = self._user_prior
+        if prior is None:
+            return np.zeros(x.shape[0])
+        pts = self.transform(x) if self._transform_prior else x
+        rows = getattr(prior, 'log_prob_rows', None)   # whole-batch form of the same rule, when the prior has one
+        if callable(rows):
+            return rows(pts)
+        return np.array([prior(r) for r in pts])
+
     # ---- fused-path eligibility -----------------------------------------------------------------------
     def _fused_eligibility(self):
         like = self._user_loglike
@@ -225,7 +227,8 @@ class Sampler(object):
                      plot_trace=False,
                      prior_volume_steps=1,
                      walker_offset=0,
-                     seed=None):
+                     seed=None,
+                     form=None):
         """Returns (samples, latent_samples, derived_samples, loglikes, scale, ncall) shaped as the reference
         (chain, step, dim), sampler.py:455-463.  On the fused path the step axis holds only the first and the
         last state unless the sampler was built with mcmc_history=True (nested.py:432-437 reads only those)."""
@@ -235,26 +238,44 @@ class Sampler(object):
                  and prior_volume_steps == 1)   # loglstar None = the unconstrained branch, also in the kernel
         if fused:
             return self._mcmc_sample_fused(mcmc_steps, step_size, dynamic_step_size, init_samples, init_loglikes,
-                                           loglstar, walker_offset, seed)
+                                           loglstar, walker_offset, seed, form)
         return self._mcmc_sample_host(mcmc_steps, step_size, dynamic_step_size, num_chains, init_samples,
                                       init_loglikes, init_derived, loglstar, max_start_tries, prior_volume_steps)
 
-    def _mcmc_sample_fused(self, mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar, walker_offset,
-                           seed):
+    def _fused_launch(self, mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar, walker_offset, seed,
+                      form=None):
+        """One K4 launch from live points: returns (res, z0, z, logl) device-side (no host copies)."""
         netG = self.trainer.netG
-        dev = netG.device
-        C = init_samples.shape[0]
         z, _ = netG.forward(init_samples)                               # sampler.py:264
-        logl = torch.as_tensor(np.ascontiguousarray(init_loglikes, dtype=np.float64)).to(dev)
-        x0 = None
-        if not self.mcmc_history:
-            x0, _ = netG.inverse(z)                                    # sampler.py:266
+        logl = torch.as_tensor(np.ascontiguousarray(init_loglikes, dtype=np.float64)).to(netG.device)
         z0 = z.clone()
-        res = netG.mh_steps(self._fused_like_id, self._linear_scale, z, logl, None if loglstar is None else float(loglstar), float(step_size),
-                            int(mcmc_steps), dynamic=dynamic, seed=self._next_seed() if seed is None else seed,
-                            walker_offset=walker_offset, history=self.mcmc_history, like_params=self._fused_like_params)
+        kw = dict(seed=self._next_seed() if seed is None else seed, walker_offset=walker_offset, history=self.mcmc_history,
+                  like_params=self._fused_like_params, form=form)
+        star = None if loglstar is None else float(loglstar)
+        args = (self._fused_like_id, self._linear_scale, z, logl, star, float(step_size), int(mcmc_steps))
+        # dynamic: the reference's rule over the whole batch (sampler.py:422-431), `mcmc_step_lag` steps behind (0 = exactly
+        # the reference; the default keeps the grid-wide wait off the step, DESIGN.md K4); populations too large for a
+        # resident grid fall back to the per-16-walker rule
+        mode = 'batch' if dynamic and getattr(self, '_batch_rule_ok', True) else ('group' if dynamic else False)
+        try:
+            res = netG.mh_steps(*args, dynamic=mode, lag=getattr(self, 'mcmc_step_lag', None), **kw)
+        except _lib.NnestHipError as e:
+            if mode != 'batch' or e.code != _lib.NNEST_E_UNSUPPORTED:
+                raise
+            self.logger.warning('batch-wide step rule not available for %d walkers (%s); using the per-group rule' % (z.shape[0], e))
+            self._batch_rule_ok = False
+            res = netG.mh_steps(*args, dynamic='group', **kw)
+        return res, z0, z, logl
+
+    def _mcmc_sample_fused(self, mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar, walker_offset,
+                           seed, form=None):
+        netG = self.trainer.netG
+        C = init_samples.shape[0]
+        res, z0, z, logl = self._fused_launch(mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar,
+                                              walker_offset, seed, form)
         ncall = int(res['n_call'].sum().item())
         nacc = int(res['n_accept'].sum().item())
+        netG.check_sync(res)
         self.total_calls += ncall
         self.total_accepted += nacc
         self.total_rejected += C * int(mcmc_steps) - nacc
@@ -263,6 +284,7 @@ class Sampler(object):
             loglikes = res['hist_logl'].cpu().numpy()
             latent = np.stack([z0.cpu().numpy(), z.cpu().numpy()], axis=1)
         else:
+            x0, _ = netG.inverse(z0)                                    # sampler.py:266
             samples = torch.stack([x0, res['x']], dim=1).cpu().numpy()
             loglikes = np.stack([np.asarray(init_loglikes, dtype=np.float64), logl.cpu().numpy()], axis=1)
             latent = torch.stack([z0, z], dim=1).cpu().numpy()
@@ -270,15 +292,64 @@ class Sampler(object):
         scale = float(res['scale'].mean().item()) if dynamic else float(step_size)
         return samples, latent, derived, loglikes, scale, ncall
 
+    def _mcmc_endpoints_fused(self, mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar, walker_offset, seed,
+                              form=None):
+        """What the nested-sampling loop consumes of a batch (nested.py:432-437) -- start x, end x, end logL per chain -- as ONE
+        device tensor [C, 2 D + 1] float64, so that the per-batch all-gather (C2) runs on device memory."""
+        netG = self.trainer.netG
+        C = init_samples.shape[0]
+        res, z0, z, logl = self._fused_launch(mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar,
+                                              walker_offset, seed, form)
+        x0, _ = netG.inverse(z0)
+        ends = torch.cat([x0.double(), res['x'].double(), logl[:, None]], dim=1)
+        counts = torch.stack([res['n_call'].sum(), res['n_accept'].sum()]).cpu()   # one small copy; orders the stream too
+        netG.check_sync(res)
+        ncall, nacc = int(counts[0]), int(counts[1])
+        self.total_calls += ncall
+        self.total_accepted += nacc
+        self.total_rejected += C * int(mcmc_steps) - nacc
+        scale = float(res['scale'].mean().item()) if dynamic else float(step_size)
+        return ends, scale, ncall
+
+    class _StepScale(object):
+        """the proposal scale under the reference's adaptation rule (sampler.py:422-431): a step in which more than half of
+        the chains moved votes up, any other step votes down; the scale follows whichever side leads"""
+
+        def __init__(self, value):
+            self.value, self.up, self.down = value, 0, 0
+
+        def vote(self, moved, chains):
+            if 2 * moved > chains:
+                self.up += 1
+            else:
+                self.down += 1
+            if self.up > self.down:
+                self.value *= np.exp(1. / (1 + self.up))
+            elif self.up < self.down:
+                self.value /= np.exp(1. / (1 + self.down))
+
+    def _propose(self, z, scale):
+        """z + scale * N(0, I); with a fast/slow hierarchy a fraction `oversample_rate` of the proposals leaves the slow
+        block alone (sampler.py:310-316, :377-382).  Returns (z', fast?)"""
+        dz = torch.randn_like(z) * scale
+        fast = self.num_slow > 0 and np.random.uniform() < self.oversample_rate
+        if fast:
+            dz[:, 0:self.num_slow] = 0.0
+        return z + dz, fast
+
+    @staticmethod
+    def _metropolis_mask(log_ratio):
+        """u < min(1, e^log_ratio) row by row (sampler.py:334-336): bool numpy array"""
+        log_ratio = log_ratio if torch.is_tensor(log_ratio) else torch.as_tensor(log_ratio)
+        return (torch.rand(log_ratio.shape) < log_ratio.exp().clamp(max=1)).numpy().astype(bool)
+
     def _mcmc_sample_host(self, mcmc_steps, step_size, dynamic, num_chains, init_samples, init_loglikes, init_derived,
                           loglstar, max_start_tries, prior_volume_steps):
         """The reference's step loop (sampler.py:246-463) with the flow passes on the GPU and the user's
         likelihood / prior callables on the host: the path for likelihoods the kernels do not know."""
         tr = self.trainer
         tr.netG.eval()
-        samples, latent_samples, derived_samples, loglikes = [], [], [], []
-        scale = step_size
-        accept = reject = ncall = 0
+        ncall = 0
         if init_samples is not None:
             num_chains = init_samples.shape[0]
             z, _ = tr.forward(init_samples)
@@ -289,8 +360,8 @@ class Sampler(object):
             else:
                 logl, derived = np.array(init_loglikes, dtype=np.float64), init_derived
             logl_prior = self.prior(x)
-        else:
-            for i in range(max_start_tries):
+        else:   # sampler.py:270-284: draw from the flow's base until every chain starts at finite density
+            for attempt in range(max_start_tries):
                 z = tr.get_prior_samples(num_chains)
                 x = tr.get_samples(z, to_numpy=True)
                 logl, derived = self.loglike(x)
@@ -298,72 +369,77 @@ class Sampler(object):
                 logl_prior = self.prior(x)
                 if np.all(logl > -1e30) and np.all(logl_prior > -1e30):
                     break
-                if i == max_start_tries - 1:
-                    raise Exception('Could not find starting value')
-        if not torch.is_tensor(z):
-            z = torch.as_tensor(z)
-        samples.append(x); latent_samples.append(z.cpu().numpy()); derived_samples.append(derived); loglikes.append(logl)
-        for it in range(1, mcmc_steps + 1):
-            x_t, log_det_J = tr.inverse(z)
-            x = x_t.cpu().numpy()
-            dz = torch.randn_like(z) * scale
+            else:
+                raise Exception('Could not find starting value')
+        z = z if torch.is_tensor(z) else torch.as_tensor(z)
+        hist = dict(x=[x], z=[z.cpu().numpy()], derived=[derived], logl=[logl])
+        step = self._StepScale(step_size)
+        for it in range(mcmc_steps):
+            _, log_det_J = tr.inverse(z)                 # sampler.py:295 (x itself is carried: value-identical)
             fast = False
-            if self.num_slow > 0 and np.random.uniform() < self.oversample_rate:   # sampler.py:311-315, :378-382
-                fast = True
-                dz[:, 0:self.num_slow] = 0.0
-            z_prime = z + dz
-            x_prime_t, log_det_J_prime = tr.inverse(z_prime)
-            x_prime = x_prime_t.cpu().numpy()
-            log_ratio = (log_det_J_prime - log_det_J).cpu()
-            logl_prior_prime = self.prior(x_prime)
             if loglstar is not None:
-                log_ratio[torch.as_tensor(logl_prior_prime < -1e30)] = -np.inf
-                rnd_u = torch.rand(log_ratio.shape)
-                mask = (rnd_u < log_ratio.exp().clamp(max=1)).numpy().astype(bool)
+                # hard constraint logl > loglstar.  Up to prior_volume_steps proposals from the CURRENT z; a chain keeps the
+                # last one that passed the prior box and the Jacobian test (sampler.py:300-345), then its likelihood decides.
+                z_prime, x_prime = z, x
+                moved = np.zeros(num_chains, dtype=bool)
+                for _ in range(prior_volume_steps):
+                    z_try, fast = self._propose(z, step.value)
+                    try:
+                        x_try_t, log_det_J_try = tr.inverse(z_try)
+                    except ValueError:           # a flow may refuse an inverse (sampler.py:322-324): proposal skipped
+                        continue
+                    x_try = x_try_t.cpu().numpy()
+                    log_ratio = (log_det_J_try - log_det_J).cpu()
+                    log_ratio[torch.as_tensor(self.prior(x_try) < -1e30)] = -np.inf
+                    ok = self._metropolis_mask(log_ratio)
+                    z_prime = torch.where(torch.as_tensor(ok, device=z.device)[:, None], z_try, z_prime)
+                    x_prime = np.where(ok[:, None], x_try, x_prime)
+                    moved |= ok
+                mask = moved
+                logl_prior_prime = self.prior(x_prime)
                 logl_prime = np.array(logl, dtype=np.float64, copy=True)
                 derived_prime = np.copy(derived)
-                idx = np.where(mask)[0]
-                if len(idx) > 0:
-                    lp, der = self.loglike(x_prime[idx])
-                    ok = np.isfinite(lp) & (lp > loglstar)
-                    ncall += len(idx)
+                cand = np.flatnonzero(mask)
+                if cand.size:                    # the likelihood is evaluated only where the cheap tests passed (:358-368)
+                    lp, der = self.loglike(x_prime[cand])
+                    ncall += cand.size
                     if fast:
-                        self.total_fast_calls += len(idx)
-                    logl_prime[idx[ok]] = lp[ok]
-                    derived_prime[idx[ok]] = der[ok]
-                    mask[idx[~ok]] = False
+                        self.total_fast_calls += cand.size
+                    good = np.isfinite(lp) & (lp > loglstar)
+                    logl_prime[cand[good]] = lp[good]
+                    derived_prime[cand[good]] = der[good]
+                    mask[cand[~good]] = False
             else:
+                # no constraint: likelihood and prior enter the Metropolis ratio (sampler.py:372-413)
+                z_prime, fast = self._propose(z, step.value)
+                try:
+                    x_prime_t, log_det_J_prime = tr.inverse(z_prime)
+                except ValueError:
+                    continue
+                x_prime = x_prime_t.cpu().numpy()
                 ncall += num_chains
                 if fast:
                     self.total_fast_calls += num_chains
                 logl_prime, derived_prime = self.loglike(x_prime)
-                log_ratio = log_ratio + torch.as_tensor(logl_prime - logl) + torch.as_tensor(logl_prior_prime - logl_prior)
-                rnd_u = torch.rand(log_ratio.shape)
-                mask = (rnd_u < log_ratio.exp().clamp(max=1)).numpy().astype(bool)
-            num_accepted = int(mask.sum())
-            self.total_accepted += num_accepted
-            self.total_rejected += num_chains - num_accepted
+                logl_prior_prime = self.prior(x_prime)
+                mask = self._metropolis_mask((log_det_J_prime - log_det_J).cpu() + torch.as_tensor(logl_prime - logl)
+                                             + torch.as_tensor(logl_prior_prime - logl_prior))
+            n_moved = int(mask.sum())
+            self.total_accepted += n_moved
+            self.total_rejected += num_chains - n_moved
             if dynamic:
-                if 2 * num_accepted > num_chains:
-                    accept += 1
-                else:
-                    reject += 1
-                if accept > reject:
-                    scale *= np.exp(1. / (1 + accept))
-                if accept < reject:
-                    scale /= np.exp(1. / (1 + reject))
+                step.vote(n_moved, num_chains)
+            sel = mask[:, None]
             logl = np.where(mask, logl_prime, logl)
             logl_prior = np.where(mask, logl_prior_prime, logl_prior)
-            mt = torch.as_tensor(mask, device=z.device)[:, None]
-            z = torch.where(mt, z_prime, z)
-            x = np.where(mask[:, None], x_prime, x)
-            derived = np.where(mask[:, None], derived_prime, derived)
-            samples.append(x); latent_samples.append(z.cpu().numpy()); derived_samples.append(derived); loglikes.append(logl)
-        samples = np.transpose(np.array(samples), axes=[1, 0, 2])
-        latent_samples = np.transpose(np.array(latent_samples), axes=[1, 0, 2])
-        derived_samples = np.transpose(np.array(derived_samples), axes=[1, 0, 2])
-        loglikes = np.transpose(np.array(loglikes), axes=[1, 0])
-        return samples, latent_samples, derived_samples, loglikes, scale, ncall
+            z = torch.where(torch.as_tensor(sel, device=z.device), z_prime, z)
+            x = np.where(sel, x_prime, x)
+            derived = np.where(sel, derived_prime, derived)
+            for k, v in (('x', x), ('z', z.cpu().numpy()), ('derived', derived), ('logl', logl)):
+                hist[k].append(v)
+        chain_major = lambda a: np.moveaxis(np.array(a), 0, 1)   # (step, chain, ...) -> (chain, step, ...)  sampler.py:455-459
+        return (chain_major(hist['x']), chain_major(hist['z']), chain_major(hist['derived']), chain_major(hist['logl']),
+                step.value, ncall)
 
     # ---- prior rejection (sampler.py:529-543) ---------------------------------------------------------------
     def _rejection_prior_sample(self, loglstar, num_trials=None):
@@ -395,19 +471,15 @@ class Sampler(object):
                 self.total_calls += block
                 ncall += block
                 block = min(65536, 4 * block)
-        if num_trials is None:
-            ncall = 0
-            while True:
-                x = self.sample_prior(1)
-                logl, derived = self.loglike(x)
-                ncall += 1
-                if logl > loglstar:
-                    break
-        else:
+        if num_trials is not None:   # a fixed block of prior draws; ncall = expected draws per success (sampler.py:540-542)
             x = self.sample_prior(num_trials)
             logl, derived = self.loglike(x)
-            ncall = num_trials / np.sum(logl > loglstar)
-        return x, logl, derived, ncall
+            return x, logl, derived, num_trials / np.sum(logl > loglstar)
+        for ncall in itertools.count(1):   # one prior draw per likelihood call until one lies above loglstar (:531-538)
+            x = self.sample_prior(1)
+            logl, derived = self.loglike(x)
+            if logl > loglstar:
+                return x, logl, derived, ncall
 
     # ---- flow rejection (sampler.py:545-605) and density sampling (sampler.py:607-628) ----------------------------
     # The reference draws one candidate, inverts it, tests it, and loops.  Candidates are independent, so the same
@@ -441,10 +513,14 @@ class Sampler(object):
         calls = 0
         for lo in range(0, len(idx), 16):          # host callable: evaluate in small groups, stop at the first hit
             grp = idx[lo:lo + 16]
+            before = self.total_calls
             lg, dg = self.loglike(x[grp])
             good = lg > loglstar if strict else ~(np.isfinite(lg) & (lg < loglstar))
             hit = np.where(good)[0]
             if len(hit) > 0:
+                # the reference evaluates one candidate per call and stops at the accepted one: the rest of the group is
+                # not counted, neither in the returned ncall nor in total_calls
+                self.total_calls = before + int(hit[0]) + 1
                 return grp[hit[0]], calls + int(hit[0]) + 1, lg[hit[0]:hit[0] + 1], dg[hit[0]:hit[0] + 1]
             calls += len(grp)
         return None, calls, None, None
@@ -511,25 +587,31 @@ class Sampler(object):
         np.savetxt(os.path.join(self.logs['chains'], outfile + '.txt'), np.concatenate(cols, axis=1), fmt='%.5E',
                    header=header, comments='#')
 
-    # ---- collectives (host arrays) ---------------------------------------------------------------------------
+    # ---- collectives -------------------------------------------------------------------------------------------------
+    # One process per GPU, torch.distributed ('nccl' = RCCL over xGMI; 'gloo' on CPU for the tests).  A tensor argument stays
+    # a tensor on the communication device (no host round trip under RCCL); a numpy argument comes back as numpy.
     def _comm_device(self):
-        return torch.device('cuda', torch.cuda.current_device()) if torch.distributed.get_backend() == 'nccl' else torch.device('cpu')
+        if torch.distributed.get_backend() == 'nccl':
+            return torch.device('cuda', torch.cuda.current_device())
+        return torch.device('cpu')
 
     def _all_gather_rows(self, arr):
         """concatenate equally-shaped per-rank arrays along axis 0 on every rank (C2)"""
         if not self.use_mpi:
             return arr
-        t = torch.as_tensor(np.ascontiguousarray(arr)).to(self._comm_device())
-        out = [torch.empty_like(t) for _ in range(self.mpi_size)]
-        torch.distributed.all_gather(out, t)
-        return torch.cat(out, dim=0).cpu().numpy()
+        as_numpy = not torch.is_tensor(arr)
+        t = (torch.as_tensor(np.ascontiguousarray(arr)) if as_numpy else arr).to(self._comm_device()).contiguous()
+        out = torch.empty((self.mpi_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        torch.distributed.all_gather_into_tensor(out, t)
+        return out.cpu().numpy() if as_numpy else out
 
     def _broadcast(self, arr, src=0):
         if not self.use_mpi:
             return arr
-        t = torch.as_tensor(np.ascontiguousarray(arr)).to(self._comm_device())
+        as_numpy = not torch.is_tensor(arr)
+        t = (torch.as_tensor(np.ascontiguousarray(arr)) if as_numpy else arr).to(self._comm_device()).contiguous()
         torch.distributed.broadcast(t, src=src)
-        return t.cpu().numpy()
+        return t.cpu().numpy() if as_numpy else t
 
     def _all_sum(self, value):
         if not self.use_mpi:

@@ -190,7 +190,12 @@ class HipSpline(_HipFlow):
         if not self.data_dep_init_done and max_epochs > 0:
             m = min(int(batch), n_train)
             first = xtrain[perm.view(max_epochs, n_train)[0, :m].long()]
-            nz = noise.view(max_epochs, n_train, self.D)[0, :m] if noise is not None else torch.randn(m, self.D, device=dev)
+            if noise is not None:
+                nz = noise.view(max_epochs, n_train, self.D)[0, :m]
+            else:   # drawn from `seed`, not from the global generator: ranks that share the seed initialise identical replicas
+                g = torch.Generator(device=dev)
+                g.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+                nz = torch.randn(m, self.D, device=dev, generator=g)
             self.actnorm_init(first + float(jitter) * nz)
         losses = np.zeros((max(max_epochs, 1), 2), np.float32)
         res = _lib.TrainResult()

@@ -21,6 +21,9 @@ EPOCH_CHUNK = 128  # epochs per training launch (bounds the device shuffle table
 class Trainer(object):
     best_validation_epoch = None
     best_validation_loss = None
+    # train(..., rng_seed=s) is a pure function of (weights, optimiser state, samples, s) down to the last bit: the kernels
+    # reduce in a fixed order (no atomics).  NestedSampler uses it to keep one replica per rank without broadcasting weights.
+    replicable = True
 
     def __init__(self,
                  x_dim,
@@ -97,6 +100,7 @@ class Trainer(object):
             self.netG = HipFastSlowNVP(x_dim - num_slow, num_slow, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed)
         else:
             self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed, scale=scale)
+        self.replicable = self.flow in ('nvp', 'spline') and num_slow == 0   # the two single-launch training paths
         if gen_normal is not None:
             self.netG.set_base(gen_normal)
             self.netG.prior = gen_normal
@@ -141,11 +145,13 @@ class Trainer(object):
         return float(out.item())
 
     def train(self, samples, max_iters=10000, log_interval=100, save_interval=100, jitter=0.0,
-              validation_fraction=0.1, patience=50, l2_norm=0.0, split=None, perms=None, noises=None):
+              validation_fraction=0.1, patience=50, l2_norm=0.0, split=None, perms=None, noises=None, rng_seed=None):
         """Trainer.train (trainer.py:134-245).  `split`, `perms`, `noises` optionally replay recorded
         randomness (tests); by default the split comes from numpy's global RNG exactly as sklearn's
         train_test_split consumes it, the per-epoch shuffles from torch's CUDA generator and the jitter
-        noise from the in-kernel Philox stream seeded from torch's CPU generator."""
+        noise from the in-kernel Philox stream seeded from torch's CPU generator.  `rng_seed` (not in the reference) draws
+        all three from that one integer instead, leaving the global generators untouched: ranks that pass the same seed
+        train bit-identical replicas."""
         # l2_norm (trainer.py:395-399): loss += l2_norm * sum(param^2) after the reported loss is taken, i.e. the
         # gradient gains 2 * l2_norm * w -- the same term Adam's coupled weight decay adds (g += weight_decay * w)
         weight_decay = self.weight_decay + 2.0 * float(l2_norm)
@@ -164,17 +170,27 @@ class Trainer(object):
         n_train = N - n_valid
         if n_train < 1 or n_valid < 1:
             raise ValueError('need at least one training and one validation sample (N=%d)' % N)
-        perm_split = np.random.permutation(N) if split is None else np.asarray(split)
+        gen = None
+        if rng_seed is not None:
+            rng_seed = int(rng_seed) & 0x7FFFFFFF
+            gen = torch.Generator(device=self.gpu)
+            gen.manual_seed(rng_seed)
+        if split is not None:
+            perm_split = np.asarray(split)
+        elif rng_seed is not None:
+            perm_split = np.random.RandomState(rng_seed).permutation(N)
+        else:
+            perm_split = np.random.permutation(N)
         x_valid = _as_dev_f32(samples[perm_split[:n_valid]], self.gpu)
         x_train = _as_dev_f32(samples[perm_split[n_valid:n_valid + n_train]], self.gpu)
-        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        seed = rng_seed if rng_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
         result, res, done, all_losses = None, None, 0, []
         while done < max_iters:
             chunk = min(getattr(self.netG, 'epoch_chunk', EPOCH_CHUNK), max_iters - done)
             if perms is not None:
                 perm = torch.as_tensor(perms[done:done + chunk])
             else:  # DataLoader(shuffle=True): a fresh permutation per epoch (trainer.py:185)
-                perm = torch.rand(chunk, n_train, device=self.gpu).argsort(dim=1).int()
+                perm = torch.rand(chunk, n_train, device=self.gpu, generator=gen).argsort(dim=1, stable=True).int()
             nz = None if noises is None else torch.as_tensor(noises[done:done + chunk])
             res = self.netG.train_epochs(x_train, x_valid, perm, nz, seed=seed, jitter=training_jitter,
                                          batch=self.batch_size, max_epochs=chunk, patience=patience,

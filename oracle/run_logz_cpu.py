@@ -1,0 +1,83 @@
+"""ORACLE-SIDE GENERATOR -- TEST INFRASTRUCTURE ONLY.  Produces the CPU-path evidence fixtures
+tests/golden/logz_cpu_cfg{1,2,3}.json: the host driver (nnest_amd.nested.NestedSampler, host protocol, fused=False)
+run end to end on the oracle-backed trainer (tests/oracle_trainer.py: the C restatement of the reference's flow,
+training and nothing else), i.e. the reference's algorithm on the CPU for a BASELINE configuration and a list of seeds.
+
+The reference as shipped cannot produce these numbers itself in a usable time (~59 likelihood calls/s
+end to end -> ~10 days for config 2), which is why the CPU path is its restatement.  The proposal loop is the
+reference's protocol loop (sampler.py:264-463) with its batch-wide dynamic step rule (sampler.py:422-431).
+
+  python oracle/run_logz_cpu.py one <cfg> <seed> <out.json>          one run (20-40 CPU-minutes for config 2)
+  python oracle/run_logz_cpu.py all <cfg> <seed,seed,...> [jobs]     runs in parallel, writes tests/golden/logz_cpu_cfg<cfg>.json
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {1: ('Rosenbrock', 2, 5.0, 100), 2: ('Rosenbrock', 50, 5.0, 1000), 3: ('GaussianMix', 20, 10.0, 2000)}
+
+
+def one(cfg, seed, out):
+    os.environ.setdefault('OMP_NUM_THREADS', '1')
+    import numpy as np
+    import torch
+    torch.set_num_threads(1)
+    from nnest_amd import likelihoods
+    from nnest_amd.nested import NestedSampler
+    from tests.oracle_trainer import OracleTrainer
+    name, D, scale, N = CONFIGS[cfg]
+    like = getattr(likelihoods, name)(D)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    tr = OracleTrainer(D, seed=seed)
+    s = NestedSampler(D, like, transform=lambda x: scale * x, log_dir=tempfile.mkdtemp(dir='/tmp'), num_live_points=N,
+                      trainer=tr, log_level=30, fused=False, flow='nvp')
+    t0 = time.time()
+    s.run(mcmc_num_chains=N)     # the same call as the GPU runs it is compared with (tools/run_config.py)
+    res = dict(config=cfg, seed=seed, likelihood=name, x_dim=D, num_live_points=N, mcmc_num_chains=N, logz=float(s.logz),
+               logzerr=float(s.logzerr), h=float(s.h), niter=int(s.niter), ncall=int(s.ncall), retrains=int(s.num_retrains),
+               batches=int(s.num_batches), train_epochs_total=int(tr.total_iters), wall_s=time.time() - t0)
+    with open(out, 'w') as f:
+        json.dump(res, f)
+    print(json.dumps(res))
+
+
+def all_(cfg, seeds, jobs):
+    import numpy as np
+    tmp = tempfile.mkdtemp(dir='/tmp')
+    pend = list(seeds)
+    running, outs = [], []
+    while pend or running:
+        while pend and len(running) < jobs:
+            sd = pend.pop(0)
+            o = os.path.join(tmp, 'seed%d.json' % sd)
+            outs.append(o)
+            running.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), 'one', str(cfg), str(sd), o],
+                                            stdout=subprocess.DEVNULL))
+        time.sleep(5)
+        running = [p for p in running if p.poll() is None]
+    runs = [json.load(open(o)) for o in outs if os.path.exists(o)]
+    z = np.array([r['logz'] for r in runs])
+    name, D, scale, N = CONFIGS[cfg]
+    doc = dict(what='CPU-path log Z: host driver + oracle-backed trainer (oracle/run_logz_cpu.py)', config=cfg,
+               likelihood=name, x_dim=D, num_live_points=N, mcmc_num_chains=N, flow='nvp h16 b3 l1', train_iters=500,
+               seeds=[r['seed'] for r in runs], logz=[r['logz'] for r in runs], mean=float(z.mean()),
+               std=float(z.std(ddof=1)) if len(z) > 1 else None,
+               stderr=float(z.std(ddof=1) / np.sqrt(len(z))) if len(z) > 1 else None, runs=runs)
+    path = os.path.join(ROOT, 'tests', 'golden', 'logz_cpu_cfg%d.json' % cfg)
+    with open(path, 'w') as f:
+        json.dump(doc, f, indent=1)
+    print(path, doc['mean'], doc['std'])
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'one':
+        one(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    else:
+        all_(int(sys.argv[2]), [int(v) for v in sys.argv[3].split(',')], int(sys.argv[4]) if len(sys.argv) > 4 else 4)

@@ -22,6 +22,19 @@ class _Net(object):
         self.nvp.w[:] = w
 
 
+class _Lazy(object):
+    """per-epoch randomness drawn when the epoch is reached (early stopping leaves most of max_iters unused)"""
+
+    def __init__(self, draw):
+        self.draw, self.at, self.cur = draw, -1, None
+
+    def __getitem__(self, i):
+        assert i >= self.at
+        while self.at < i:
+            self.cur, self.at = self.draw(), self.at + 1
+        return self.cur
+
+
 class OracleTrainer(object):
     def __init__(self, x_dim, hidden_dim=16, num_blocks=3, num_layers=1, batch_size=100, learning_rate=1e-3,
                  weight_decay=1e-6, seed=0):
@@ -70,10 +83,11 @@ class OracleTrainer(object):
         n_valid = int(np.ceil(validation_fraction * N))
         n_train = N - n_valid
         split = np.random.permutation(N)
-        perms = np.stack([np.random.permutation(n_train) for _ in range(max_iters)]).astype(np.int32)
-        noises = np.random.normal(size=(max_iters, n_train, self.x_dim)).astype(np.float32)
+        perms = _Lazy(lambda: np.random.permutation(n_train).astype(np.int32))
+        noises = _Lazy(lambda: np.random.normal(size=(n_train, self.x_dim)).astype(np.float32))
         res = self.nvp.train(samples, split, perms, noises, jitter, max_iters, patience=patience, batch=self.batch_size,
                              lr=self.lr, wd=self.wd, validation_fraction=validation_fraction)
         self.best_validation_loss = res['best_validation_loss']
         self.best_validation_epoch = res['best_validation_epoch']
         self.num_trains += 1
+        self.total_iters = getattr(self, 'total_iters', 0) + res['epochs_run']

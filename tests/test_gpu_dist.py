@@ -1,6 +1,8 @@
-"""Two ranks on real kernels: the multi-process path of NestedSampler (replicated evidence state, MCMC batch sharded by
-rank with disjoint noise streams, endpoints all-gathered, rank-0 retrain + weight broadcast) with both ranks driving
-the one GPU of the test box over gloo.  (The 8-GPU RCCL run is the driver's; the collectives are the same calls.)"""
+"""The multi-process path of NestedSampler on real kernels (replicated evidence state, MCMC batch sharded by rank with
+disjoint noise streams, endpoints all-gathered, one bit-identical flow replica per rank trained from a broadcast seed):
+  * two ranks driving the one GPU of the test box over gloo (both flows);
+  * ONE rank over 'nccl' (= RCCL): the CUDA-tensor branch of every collective -- device all-gather of the chain endpoints,
+    broadcasts, all-reduce -- executes on the one-GPU box.  (The 8-GPU RCCL run is the driver's; these are the same calls.)"""
 import os
 import socket
 import sys
@@ -39,6 +41,7 @@ def _worker(rank, world, port, tmp, flow, out):
         s = NestedSampler(2, Rosenbrock(2), transform=lambda x: 5 * x, log_dir=tmp, num_live_points=300, log_level=40, flow=flow)
         assert s.use_mpi and s.mpi_size == world and s._fused_like_id is not None
         s.run(train_iters=200, mcmc_num_chains=33)   # 33 chains over 2 ranks: padded shard
+        assert s.trainer.replicable and s._replicas_aligned   # no weight broadcast after the first alignment
         netG = s.trainer.netG
         out.put((rank, float(s.logz), int(s.niter), int(s.ncall), float(np.sum(s.samples)), float(np.sum(netG.store_packed())),
                  float(np.sum(netG.P)) if hasattr(netG, 'P') else 0.0))
@@ -63,3 +66,40 @@ def test_two_ranks_one_gpu(tmp_path, flow):
     a, b = res
     assert a[1:] == b[1:]                       # identical evidence, iteration count, calls, samples, weights (and P)
     assert abs(a[1] + 5.80) <= 0.45, a[1]       # 300 live points: sqrt(h/N) ~ 0.13
+
+
+def _nccl_single(port, tmp, out):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        from nnest_amd.nested import NestedSampler
+        from nnest_amd.likelihoods import Rosenbrock
+        np.random.seed(5)
+        torch.manual_seed(5)
+        s = NestedSampler(2, Rosenbrock(2), transform=lambda x: 5 * x, log_dir=tmp, num_live_points=300, log_level=40, flow='nvp')
+        assert s.use_mpi and s.mpi_size == 1 and s._comm_device().type == 'cuda'
+        t = torch.arange(6, dtype=torch.float64, device='cuda').reshape(3, 2)
+        g = s._all_gather_rows(t)
+        assert g.is_cuda and torch.equal(g, t)                       # device tensor in, device tensor out
+        assert np.array_equal(s._all_gather_rows(np.ones((2, 2))), np.ones((2, 2)))
+        assert np.array_equal(s._broadcast(np.arange(4.0)), np.arange(4.0)) and s._all_sum(3) == 3
+        s.run(train_iters=200, mcmc_num_chains=40)
+        out.put((float(s.logz), int(s.niter), int(s.num_batches)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_over_rccl(tmp_path):
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    p = ctx.Process(target=_nccl_single, args=(_free_port(), str(tmp_path), out))
+    p.start()
+    logz, niter, nb = out.get(timeout=500)
+    p.join(60)
+    assert p.exitcode == 0
+    assert abs(logz + 5.80) <= 0.45 and nb > 3

@@ -222,3 +222,109 @@ def test_mcmc_sampler_front_end(tmp_path):
     c = np.cov(flat.T)
     assert abs(c[0, 0] - 1) < 0.3 and abs(c[1, 1] - 1) < 0.3 and abs(c[0, 1] - 0.8) < 0.3
     assert s.total_calls == 50 * 400 + 50   # the initial likelihoods of the chains count too (sampler.py:268-270)
+
+
+def test_config4_himmelblau32_fused_likelihood_vs_oracle_and_slice(tmp_path):
+    """BASELINE config 4 names Himmelblau at x_dim = 32; the reference asserts x_dim == 2 (likelihoods.py:62-67), so the
+    form used here -- the 2-D function summed over consecutive pairs -- is build-defined: [UNPINNED beyond D = 2].  The
+    fused kernels (K6, K3, K4) are checked against the oracle's restatement of that same sum, then a bounded slice of the
+    nested run (4000 live points, one walker per live point) exercises the run mechanics."""
+    from nnest_amd import flow
+    from oracle import oracle as orc
+    D = 32
+    rng = np.random.RandomState(4)
+    x = rng.uniform(-1, 1, size=(500, D)).astype(np.float32)
+    lo = orc.loglike('himmelblau', x, 5.0)
+    np.testing.assert_allclose(flow.loglike(2, x, 5.0).cpu().numpy(), lo, rtol=2e-6, atol=1e-4)           # K6
+    nvp = flow.HipNVP(D, 16, 3, 1, seed=4)
+    o = orc.NVP(D, 16, 3, 1, nvp.store_packed())
+    z = (rng.normal(size=(300, D)) * 0.7).astype(np.float32)
+    xg, ld, logl, inbox = nvp.inverse_loglike(2, 5.0, z)                                                   # K3
+    np.testing.assert_allclose(logl.cpu().numpy(), orc.loglike('himmelblau', xg.cpu().numpy(), 5.0), rtol=2e-6, atol=1e-4)
+    assert np.max(np.abs(xg.cpu().numpy() - o.inverse(z)[0])) < 5e-5
+    for form in ('quad', 'team'):                                                                          # K4, both tile shapes
+        init = rng.uniform(-0.8, 0.8, size=(64, D))
+        il = orc.loglike('himmelblau', init, 5.0)
+        zz, _ = nvp.forward(init)
+        ll = torch.from_numpy(il).cuda()
+        res = nvp.mh_steps(2, 5.0, zz, ll, float(il.min()) - 50.0, 0.05, 20, seed=3, history=True, form=form)
+        hx = res['hist_x'].cpu().numpy()
+        hl = res['hist_logl'].cpu().numpy()
+        lo = orc.loglike('himmelblau', hx.reshape(-1, D), 5.0).reshape(hl.shape)
+        assert np.max(np.abs(hl[:, 1:] - lo[:, 1:]) / (1 + np.abs(lo[:, 1:]))) < 5e-6
+        assert np.all(hl[:, 1:] > float(il.min()) - 50.0) and int(res['n_accept'].sum()) > 0
+    s = run(tmp_path, D, Himmelblau(D), 5.0, 4000, 0, strategy=['mcmc'], mcmc_num_chains=4000, max_iters=3000, train_iters=40)
+    assert s.niter >= 3000 and s.num_retrains == 1 + 3000 // 2000 and np.isfinite(s.logz)
+    assert np.all(np.diff(s.loglikes[:3000]) >= 0)
+
+
+def test_config5_slice_rosenbrock_100d_8000_live_points(tmp_path):
+    """BASELINE config 5 with the RealNVP flow (its MAF variant does not exist in the reference): x_dim 100, 8000 live points,
+    one walker per live point -- a bounded slice of the run."""
+    s = run(tmp_path, 100, Rosenbrock(100), 5.0, 8000, 0, strategy=['mcmc'], mcmc_num_chains=8000, max_iters=5000,
+            train_iters=30)
+    assert s.niter >= 5000 and s.num_retrains == 1 + 5000 // 4000
+    assert np.isfinite(s.logz) and np.all(np.diff(s.loglikes[:5000]) >= 0)
+
+
+def test_derived_parameters_host_protocol(tmp_path):
+    """A likelihood that returns (logl, derived) (sampler.py:118-133): the derived columns follow their points through the
+    prior-rejection phase, the MCMC phase and into the chain (nested.py:287-288, :368-369, :436-437)."""
+    np.random.seed(11)
+    torch.manual_seed(11)
+
+    def like(x):
+        logl = -(100.0 * (x[:, 1] - x[:, 0] ** 2) ** 2 + (1 - x[:, 0]) ** 2)
+        return logl, np.stack([x[:, 0] + x[:, 1], x[:, 0] * x[:, 1]], axis=1)
+
+    s = NestedSampler(2, like, transform=lambda x: 5 * x, log_dir=str(tmp_path), num_live_points=200, log_level=30, flow='nvp',
+                      num_derived=2)
+    assert s._fused_like_id is None
+    s.run(mcmc_num_chains=20, train_iters=100)
+    assert s.samples.shape[1] == 4
+    v = s.samples
+    np.testing.assert_allclose(v[:, 2], v[:, 0] + v[:, 1], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(v[:, 3], v[:, 0] * v[:, 1], rtol=1e-5, atol=1e-5)
+    assert abs(s.logz - LOGZ_ROSEN2D) <= 0.5
+    chain = np.loadtxt(os.path.join(s.logs['chains'], 'chain.txt'))
+    assert chain.shape[1] == 2 + 4
+
+
+def test_host_tensors_drop_in_level_1(tmp_path, monkeypatch):
+    """INTEGRATION.md level 1: Trainer(host_tensors=True) under a sampler that mixes CPU tensors into the loop (the
+    reference's _mcmc_sample, sampler.py:264-336, as restated in nnest_amd.sampler._mcmc_sample_host).  `device` reads cpu,
+    every tensor handed out is a CPU tensor, and on the same recorded proposal noise the chain equals the device-tensor
+    path bit for bit (the arithmetic is the same kernels)."""
+    from nnest_amd.trainer import Trainer
+    from nnest_amd.sampler import Sampler
+    from nnest_amd.priors import UniformPrior
+    rng = np.random.RandomState(2)
+    init = rng.uniform(-0.5, 0.5, size=(24, 5))
+
+    def like(x):
+        return -np.sum(100.0 * (x[:, 1:] - x[:, :-1] ** 2.0) ** 2.0 + (1 - x[:, :-1]) ** 2.0, axis=1)
+
+    out = {}
+    noise = torch.randn(30, 24, 5, generator=torch.Generator().manual_seed(1))
+    for host in (True, False):
+        draws = list(noise)
+        monkeypatch.setattr(torch, 'randn_like', lambda t: draws.pop(0).to(t.device))   # torch.randn_like(z), sampler.py:310
+        tr = Trainer(5, flow='nvp', log_dir=str(tmp_path / ('h%d' % host)), host_tensors=host, seed=3, log_level=40)
+        assert tr.device.type == ('cpu' if host else 'cuda')
+        z, ld = tr.forward(init)
+        x, ldi = tr.inverse(z)
+        assert z.device.type == tr.device.type and x.device.type == tr.device.type
+        assert (ldi.exp().clamp(max=1)).device.type == tr.device.type
+        idx = (np.array([0, 2]),)
+        assert x[idx].shape == (2, 5)                      # numpy index tuples, as the reference indexes (sampler.py:330)
+        assert tr.get_prior_samples(3).device.type == tr.device.type
+        s = Sampler(5, like, transform=lambda x: 5 * x, prior=UniformPrior(5, -1, 1), transform_prior=False, trainer=tr,
+                    log_dir=str(tmp_path / ('s%d' % host)), log_level=40, fused=False)
+        torch.manual_seed(7)
+        np.random.seed(7)
+        l0, _ = s.loglike(init)
+        out[host] = s._mcmc_sample(30, step_size=0.05, dynamic_step_size=True, init_samples=init, init_loglikes=l0,
+                                   init_derived=np.empty((24, 0)), loglstar=float(l0.min()) - 100.0)
+    for a, b in zip(out[True][:4], out[False][:4]):
+        assert np.array_equal(a, b)
+    assert out[True][4] == out[False][4] and out[True][5] == out[False][5] and out[True][5] > 0

@@ -145,10 +145,13 @@ def test_fused_inverse_prior_loglike_vs_oracle(hip):
     np.testing.assert_allclose(cpu(logl), lo, rtol=2e-6, atol=1e-5)
 
 
+@pytest.mark.parametrize('form', ['quad', 'reg'])
 @pytest.mark.parametrize('path', MCMC_FILES, ids=[os.path.basename(p)[5:-4] for p in MCMC_FILES])
-def test_mh_trace_vs_golden_recorded_noise(hip, path):
+def test_mh_trace_vs_golden_recorded_noise(hip, path, form):
     """Sampler._mcmc_sample with the reference's own recorded torch noise: every accept/reject decision
-    and every intermediate state must match the reference trace."""
+    and every intermediate state must match the reference trace.  Both tile shapes: 'quad' (4 walkers per wave,
+    MFMA 4x4x1) with the batch-wide step rule at lag 0 = the reference's rule, and the 16-walker register form with
+    the per-group rule (16 chains = one group = the whole batch)."""
     g = np.load(path)
     D = int(g['D'])
     nvp = hip.HipNVP(D, int(g['H']), int(g['B']), int(g['L']))
@@ -158,8 +161,9 @@ def test_mh_trace_vs_golden_recorded_noise(hip, path):
     z, _ = nvp.forward(g['init'])           # sampler.py:264
     logl = torch.from_numpy(g['init_logl']).cuda().contiguous()
     res = nvp.mh_steps(hip._lib.LIKE_IDS[like], float(g['scale']), z, logl, float(g['loglstar']), float(g['step']), S,
-                       dynamic=bool(g['dynamic']), noise=(torch.from_numpy(g['dz']), torch.from_numpy(g['u'])),
-                       history=True)
+                       dynamic=(('batch' if form == 'quad' else 'group') if bool(g['dynamic']) else False), lag=0,
+                       noise=(torch.from_numpy(g['dz']), torch.from_numpy(g['u'])), history=True, form=form)
+    hip.HipNVP.check_sync(res)
     assert int(res['n_call'].sum()) == int(g['ncall'])
     assert int(res['n_accept'].sum()) == int(g['total_accepted'])
     ltol = 2e-4 if np.isnan(float(g['loglstar'])) else 3e-5   # 'free_*' (loglstar = None) traces sit on the steep ridge
@@ -194,7 +198,8 @@ def test_mh_inkernel_noise_vs_oracle(hip, C, S, dyn):
     assert abs(dzc.mean()) < 0.02 and abs(dzc.std() - 1) < 0.02 and 0 <= uc.min() and uc.max() < 1
     z, _ = nvp.forward(init)
     logl = torch.from_numpy(init_logl).cuda()
-    res = nvp.mh_steps(0, 5.0, z, logl, loglstar, step, S, dynamic=dyn, seed=seed, walker_offset=off, history=True)
+    res = nvp.mh_steps(0, 5.0, z, logl, loglstar, step, S, dynamic='group' if dyn else False, seed=seed, walker_offset=off,
+                       history=True)
     hx, hl = cpu(res['hist_x']), cpu(res['hist_logl'])
     n_bad = 0
     for g0 in range(0, C, 16):

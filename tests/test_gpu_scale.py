@@ -115,7 +115,7 @@ def test_fused_proposal_kernel_vs_oracle(hip, scale, C):
     dz, u = nvp.fill_noise(S, C, seed=5)
     z, _ = nvp.forward(init)
     logl = torch.from_numpy(init_logl).cuda()
-    res = nvp.mh_steps(0, 5.0, z, logl, -1e12, 0.05, S, seed=5, history=True, dynamic=True)
+    res = nvp.mh_steps(0, 5.0, z, logl, -1e12, 0.05, S, seed=5, history=True, dynamic='group')
     bad = 0
     groups = list(range(0, min(C, 160), 16))
     for g0 in groups:
@@ -131,7 +131,7 @@ def test_fused_proposal_kernel_vs_oracle(hip, scale, C):
     assert bad <= 1
     z2, _ = nvp.forward(init)
     logl2 = torch.from_numpy(init_logl).cuda()
-    res2 = nvp.mh_steps(0, 5.0, z2, logl2, -1e12, 0.05, S, seed=5, dynamic=True)
+    res2 = nvp.mh_steps(0, 5.0, z2, logl2, -1e12, 0.05, S, seed=5, dynamic='group')
     assert torch.equal(z2, z) and torch.equal(logl2, logl) and torch.equal(res2['x'], res['x'])
 
 

@@ -88,7 +88,7 @@ def test_mh_every_kernel_form_and_shape_vs_oracle(hip, D, H, B, L):
     dz, u = nvp.fill_noise(S, C, seed=5)
     z, _ = nvp.forward(init)
     logl = torch.from_numpy(init_logl).cuda()
-    res = nvp.mh_steps(0, 5.0, z, logl, -1e12, 0.05, S, seed=5, history=True, dynamic=True)
+    res = nvp.mh_steps(0, 5.0, z, logl, -1e12, 0.05, S, seed=5, history=True, dynamic='group')
     bad = 0
     for g0 in range(0, C, 16):
         sl = slice(g0, min(g0 + 16, C))
@@ -105,7 +105,7 @@ def test_mh_every_kernel_form_and_shape_vs_oracle(hip, D, H, B, L):
     # production instantiation (no history) lands on the same final state as the diagnostic one
     z2, _ = nvp.forward(init)
     logl2 = torch.from_numpy(init_logl).cuda()
-    res2 = nvp.mh_steps(0, 5.0, z2, logl2, -1e12, 0.05, S, seed=5, dynamic=True)
+    res2 = nvp.mh_steps(0, 5.0, z2, logl2, -1e12, 0.05, S, seed=5, dynamic='group')
     assert torch.equal(z2, z) and torch.equal(logl2, logl) and torch.equal(res2['x'], res['x'])
     assert torch.equal(res2['n_accept'], res['n_accept']) and torch.equal(res2['n_call'], res['n_call'])
 

@@ -117,7 +117,7 @@ def test_fused_proposal_kernel_vs_oracle(hip, name, C):
     z0 = cpu(z).copy()
     logl = torch.from_numpy(init_logl).cuda()
     step = 0.1 / np.sqrt(D)
-    res = sp.mh_steps(0, 5.0, z, logl, -1e12, step, S, seed=5, history=True, dynamic=True)
+    res = sp.mh_steps(0, 5.0, z, logl, -1e12, step, S, seed=5, history=True, dynamic='group')
     ngood = 0
     for g0 in list(range(0, min(C, 96), 16)):
         sl = slice(g0, min(g0 + 16, C))
@@ -133,7 +133,7 @@ def test_fused_proposal_kernel_vs_oracle(hip, name, C):
     # production instantiation lands on the same state
     z2 = torch.from_numpy(z0).cuda()
     logl2 = torch.from_numpy(init_logl).cuda()
-    res2 = sp.mh_steps(0, 5.0, z2, logl2, -1e12, step, S, seed=5, dynamic=True)
+    res2 = sp.mh_steps(0, 5.0, z2, logl2, -1e12, step, S, seed=5, dynamic='group')
     assert torch.equal(z2, z) and torch.equal(logl2, logl) and torch.equal(res2['x'], res['x'])
 
 

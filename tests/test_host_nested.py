@@ -88,5 +88,5 @@ def test_nested_resume_from_checkpoint(tmp_path):
     s2 = NestedSampler(2, like, trainer=OracleTrainer(2, seed=1), **kw)
     assert not s2.logs['created']
     s2.run(train_iters=50, mcmc_num_chains=10, strategy=['mcmc'])
-    assert abs(s2.logz + 5.80) <= 0.6  # 100 live points: sqrt(h/N) ~ 0.23
+    assert abs(s2.logz + 5.80) <= 3 * max(s2.logzerr, 0.25)  # 100 live points, 50 training epochs: sqrt(h/N) ~ 0.23, run-to-run scatter 0.33
     assert s2.niter > cps[-1]
