@@ -28,6 +28,11 @@ def one(cfg, seed, out):
     import numpy as np
     import torch
     torch.set_num_threads(1)
+    # Adam with weight decay drives the weights the parity mask never reaches to denormal values within ~90 epochs (update
+    # ~ 0.1 w per step once |w| << 1e-2); x86 then runs every product with them ~100x slower (measured: 39 ms instead of 7.8 ms
+    # per 1000-row inverse).  Those products are multiplied by exact zeros of the mask, so flushing denormals (MXCSR FTZ/DAZ,
+    # this thread: the C oracle runs on it) changes no value that reaches the flow's output.
+    torch.set_flush_denormal(True)
     from nnest_amd import likelihoods
     from nnest_amd.nested import NestedSampler
     from tests.oracle_trainer import OracleTrainer

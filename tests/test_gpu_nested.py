@@ -192,11 +192,17 @@ def test_spline_flow_gaussian_mixture_5d(tmp_path):
 def test_spline_flow_reproduces_published_rosenbrock_10d_evidence(tmp_path):
     """The reference's published run (examples/nested/example.ipynb:869-890): Rosenbrock 10-D, 1000 live points,
     spline flow (3 blocks, hidden 16), rejection_prior -> mcmc, 50 MCMC steps: logZ = -43.364 +- 0.193, H = 37.2.
-    Two independent nested-sampling runs differ by ~sqrt(2) * 0.19; the bound below is ~2.5 sigma of that."""
-    s = run(tmp_path, 10, Rosenbrock(10), 5.0, 1000, 0, flow='spline', mcmc_steps=50, mcmc_num_chains=100)
-    assert abs(s.logzerr - 0.193) < 0.03
-    assert abs(s.h - 37.226) < 4.0
-    assert abs(s.logz - (-43.364)) <= 0.7, s.logz
+    Three seeds under the reference's step rule (batch-wide, lag 0): the mean has standard error 0.19 / sqrt(3), the
+    published value 0.19 of its own; the bound is 2.5 sigma of the difference.  (With 50 steps a chain is not fully
+    decorrelated, so the evidence moves with the step rule by ~0.1-0.3: tools/step_rule_study.py.)"""
+    zs = []
+    for seed in range(3):
+        s = run(tmp_path / str(seed), 10, Rosenbrock(10), 5.0, 1000, seed, flow='spline', mcmc_steps=50, mcmc_num_chains=100,
+                mcmc_step_lag=0)
+        assert abs(s.logzerr - 0.193) < 0.03
+        assert abs(s.h - 37.226) < 4.0
+        zs.append(s.logz)
+    assert abs(np.mean(zs) - (-43.364)) <= 2.5 * 0.193 * math.sqrt(1 + 1 / 3.0), zs
 
 
 def test_mcmc_sampler_front_end(tmp_path):
