@@ -391,6 +391,57 @@ def gen_nested():
 
 
 # ----------------------------------------------------------------------------------------------
+# G14: what the reference writes to disk during the seeded config-1 run (nnest/sampler.py:494-511; nnest/nested.py:92-95,
+# :473-485, :503-506): the text products as they are (first / last lines) and one complete checkpoint set as arrays, so that
+# tests can check format equality and resume a run of this build from a reference-written checkpoint.
+# ----------------------------------------------------------------------------------------------
+def gen_formats():
+    np.random.seed(0)
+    torch.manual_seed(0)
+    tmp = tempfile.mkdtemp()
+    s = NestedSampler(2, Rosenbrock(2), transform=lambda x: 5 * x, log_dir=tmp, num_live_points=100,
+                      hidden_dim=16, num_layers=1, num_blocks=3, flow='nvp', log_level=logging.WARNING)
+    s.run(train_iters=2000, mcmc_num_chains=10)
+    out = os.path.join(OUT, 'formats')
+    os.makedirs(out, exist_ok=True)
+
+    def head_tail(src, dst, nh, nt):
+        with open(src) as f:
+            lines = f.read().split('\n')
+        body = [ln for ln in lines if ln != '']
+        with open(dst, 'w') as f:
+            f.write('\n'.join(body[:nh] + (['...'] if len(body) > nh + nt else []) + (body[-nt:] if nt else [])) + '\n')
+        return len(body)
+
+    n_chain = head_tail(os.path.join(s.logs['chains'], 'chain.txt'), os.path.join(out, 'chain_head_tail.txt'), 6, 3)
+    head_tail(os.path.join(s.logs['results'], 'results.csv'), os.path.join(out, 'results_head.csv'), 3, 0)
+    shutil.copy(os.path.join(s.logs['results'], 'final.csv'), os.path.join(out, 'final.csv'))
+    with open(os.path.join(s.logs['info'], 'params.txt')) as f:
+        params = json.load(f)
+    cps = sorted(int(f.split('_')[1].split('.')[0]) for f in os.listdir(s.logs['checkpoint']) if f.startswith('checkpoint_'))
+    # the LAST checkpoint is the one consistent with saved_*.npy (those are overwritten at every checkpoint)
+    it = cps[-1]
+    cp = s.logs['checkpoint']
+    with open(os.path.join(cp, 'checkpoint_%d.txt' % it)) as f:
+        state = json.load(f)
+    np.savez_compressed(os.path.join(out, 'checkpoint_set.npz'), it=it,
+                        active_u=np.load(os.path.join(cp, 'active_u_%d.npy' % it)),
+                        active_v=np.load(os.path.join(cp, 'active_v_%d.npy' % it)),
+                        active_logl=np.load(os.path.join(cp, 'active_logl_%d.npy' % it)),
+                        active_derived=np.load(os.path.join(cp, 'active_derived_%d.npy' % it)),
+                        saved_v=np.load(os.path.join(cp, 'saved_v.npy')), saved_logl=np.load(os.path.join(cp, 'saved_logl.npy')),
+                        saved_logwt=np.load(os.path.join(cp, 'saved_logwt.npy')))
+    meta = dict(checkpoint_iterations=cps, checkpoint_state=state, params_keys=sorted(params.keys()), chain_rows=n_chain,
+                run_dir_layout=sorted(os.listdir(s.logs['run_dir'])), checkpoint_files=sorted(os.listdir(cp))[:12],
+                final_logz=float(s.logz), config='Rosenbrock x_dim=2, 100 live points, nvp h16 b3 l1, train_iters=2000, '
+                                                 'mcmc_num_chains=10, seeds 0/0 (the G6 run)')
+    with open(os.path.join(out, 'meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1)
+    shutil.rmtree(tmp, ignore_errors=True)
+    print('G14 formats', meta['checkpoint_iterations'][-3:], n_chain)
+
+
+# ----------------------------------------------------------------------------------------------
 # G8: SingleSpeedNVP scale variants (networks.py:328-347): scale='translate' (translate-only couplings) and
 # scale='constant' (translate-only couplings + one ScaleLayer scalar after each): passes, a trained state, and
 # minibatch steps with every gradient.  Vectors are the concatenated state_dict (no scale nets in these variants).
@@ -770,3 +821,5 @@ if __name__ == '__main__':
         gen_mcmc()
     if 'nested' in which:
         gen_nested()
+    if 'formats' in which:
+        gen_formats()

@@ -34,8 +34,13 @@ def _worker(rank, world, port, tmp, out):
         np.random.seed(100 + rank)      # deliberately different per rank: rank 0's draws must win
         torch.manual_seed(100 + rank)
         tr = OracleTrainer(2, seed=7)   # same initial weights on every rank
-        s = NestedSampler(2, Rosenbrock(2), transform=lambda x: 5 * x, log_dir=tmp, num_live_points=200, trainer=tr,
-                          log_level=40)
+        rosen = Rosenbrock(2)
+
+        def like(x):   # with one derived column: it has to travel with its point through both collectives
+            return rosen(x), (x[:, :1] + x[:, 1:2])
+
+        s = NestedSampler(2, like, transform=lambda x: 5 * x, log_dir=tmp, num_live_points=200, trainer=tr,
+                          log_level=40, num_derived=1)
         assert s.use_mpi and s.mpi_size == world and s.mpi_rank == rank
         # collective helpers
         g = s._all_gather_rows(np.full((3, 2), float(rank)))
@@ -44,6 +49,7 @@ def _worker(rank, world, port, tmp, out):
         assert np.array_equal(b, np.arange(5))
         assert s._all_sum(rank + 1) == sum(range(1, world + 1))
         s.run(train_iters=100, mcmc_num_chains=9, mcmc_dynamic_step_size=False)  # 9 chains over 2 ranks: padded shard
+        assert np.allclose(s.samples[:, 2], s.samples[:, 0] + s.samples[:, 1], atol=1e-5)
         w = tr.netG.store_packed()
         out.put((rank, float(s.logz), int(s.niter), int(s.ncall), float(np.sum(s.samples)), float(np.sum(w)),
                  tr.num_trains, s.logs is not None))

@@ -29,10 +29,31 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert r['traffic'] is None or r['traffic'] > 0
     # value = evals per launch / measured time: consistent with ms_per_step
     assert abs(d['value'] - d['config']['evals_per_step'] / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    with open(os.path.join(ROOT, 'BASELINE.json')) as f:
+        assert d['metric'] == json.load(f)['metric']          # both halves: evals/s and the log-Z error
     c = d['cpu_baseline']
-    assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and c['unit'] == 'evals/s'
-    assert d['value'] > 100 * c['value']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'evals/s' and c['one_thread'] > 0
+    assert c['value'] >= 0.8 * c['one_thread']                # all host cores beside one
+    assert d['value'] > 10 * c['value']
     assert d['spline_flow']['evals_per_s'] > 0
+    assert d['k3']['evals_per_s'] > 0 and d['k5_train']['ms_per_epoch'] > 0
+    z = d['logz']
+    assert abs(z['live_run']['logz'] + 242.0) < 3.0            # one live config-2 run: within a few sigma of the ensemble
+    if 'cpu_mean' in z and 'gpu_mean' in z:
+        assert abs(z['delta']) <= max(0.1, 2 * z['combined_stderr'])
+
+
+def test_bench_multi_rank_path_over_rccl_on_one_gpu():
+    """the N > 1 code path of bench.py (K4 on the shard + the RCCL all-gather of the chain endpoints inside the timed region)
+    with a one-rank process group, which is what a one-GPU box can run"""
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533',
+               NNEST_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--config', '4',
+                          '--scaling', 'strong'], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    assert d['scaling'] == 'strong' and 'all-gather' in d['config']['parallelism'] and d['config']['walkers_total'] == 4000
+    assert d['value'] > 0 and d['roofline']['kernel'] == 'mh_kernel_team'
 
 
 def test_smoke_entry_point():

@@ -5,6 +5,7 @@ import csv
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from nnest_amd.nested import NestedSampler
@@ -90,3 +91,26 @@ def test_nested_resume_from_checkpoint(tmp_path):
     s2.run(train_iters=50, mcmc_num_chains=10, strategy=['mcmc'])
     assert abs(s2.logz + 5.80) <= 3 * max(s2.logzerr, 0.25)  # 100 live points, 50 training epochs: sqrt(h/N) ~ 0.23, run-to-run scatter 0.33
     assert s2.niter > cps[-1]
+
+
+def test_derived_parameters_follow_their_points(tmp_path):
+    """loglike -> (logl, derived) (sampler.py:118-133): through prior rejection (nested.py:368-369), MCMC (nested.py:436-437) and
+    into the saved chain (nested.py:287-288), on the host protocol with the oracle-backed trainer"""
+    np.random.seed(4)
+    torch.manual_seed(4)
+
+    def like(x):
+        logl = -(100.0 * (x[:, 1] - x[:, 0] ** 2) ** 2 + (1 - x[:, 0]) ** 2)
+        return logl, np.stack([x[:, 0] - x[:, 1], 2.0 * x[:, 0]], axis=1)
+
+    s = NestedSampler(2, like, transform=lambda x: 5 * x, log_dir=str(tmp_path), num_live_points=100, log_level=30, num_derived=2,
+                      trainer=OracleTrainer(2, seed=4))
+    s.run(train_iters=100, mcmc_num_chains=10)
+    v = s.samples
+    assert v.shape[1] == 4 and v.shape[0] == s.niter - 1 + 100
+    np.testing.assert_allclose(v[:, 2], v[:, 0] - v[:, 1], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(v[:, 3], 2.0 * v[:, 0], rtol=1e-6, atol=1e-6)
+    assert abs(s.logz + 5.80) <= 3 * max(s.logzerr, 0.25)
+    with pytest.raises(ValueError):
+        NestedSampler(2, like, transform=lambda x: 5 * x, log_dir=str(tmp_path / 'bad'), num_live_points=10, log_level=40,
+                      num_derived=1, trainer=OracleTrainer(2, seed=4)).run(max_iters=5)
