@@ -156,7 +156,10 @@ def main():
     ap.add_argument('--no-saturation', action='store_true')
     ap.add_argument('--no-spline', action='store_true')
     ap.add_argument('--no-logz', action='store_true', help='skip the live nested run (the fixtures are still reported)')
+    ap.add_argument('--bare', action='store_true', help='the timed launches only (profiling runs: scripts/profile_bench.sh)')
     args = ap.parse_args()
+    if args.bare:
+        args.no_cpu_baseline = args.no_saturation = args.no_spline = args.no_logz = True
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -280,7 +283,7 @@ def main():
                                  'population (a step is a serial chain of 9 small layers), see `saturated`' % (tiles, cu)},
             'device': info['name'],
         }
-        if world == 1 and dist is None:
+        if world == 1 and dist is None and not args.bare:
             # K3: the single batched pass over all live points (inverse + box prior + likelihood), SURVEY.md 8d
             for _ in range(3):
                 nvp.inverse_loglike(LIKE_ID[like], scale, z0)
@@ -358,7 +361,7 @@ def main():
                 res = sp.train_epochs(u0[nv:], u0[:nv], perms, None, max_epochs=E, **kw)
                 torch.cuda.synchronize(dev)
                 out['spline_flow']['train_ms_per_epoch'] = (time.perf_counter() - t0) / max(1, res['epochs_run']) * 1e3
-        if world == 1 and dist is None and args.config == 2:
+        if world == 1 and dist is None and args.config == 2 and not args.bare:
             # K5 beside K4: the NVP training epoch at this population
             nv = C // 10
             E = 40
