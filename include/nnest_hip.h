@@ -194,10 +194,13 @@ typedef struct {
     float best_validation_loss;
     float last_train_loss;
     int counter;                /* epochs since the last improvement (trainer.py:209, :223) */
-    int stopped;                /* 1 when counter > patience ended the run (trainer.py:225) */
+    int stopped;                /* 1 when counter > patience ended the run (trainer.py:225); 2: internal error (a bounded grid
+                                 * barrier of the multi-CU kernel ran out: results invalid) */
 } nnest_train_result_t;
 
-enum { NNEST_TRAIN_RESUME = 1, NNEST_TRAIN_FINALIZE = 2 };
+enum { NNEST_TRAIN_RESUME = 1, NNEST_TRAIN_FINALIZE = 2,
+       NNEST_TRAIN_ONE_CU = 4 /* keep the epoch loop on ONE workgroup (the round-1 kernel) instead of one workgroup per 16-row tile
+                               * of the minibatch on eight compute units; both produce the same bits (A/B and test switch) */ };
 
 int nnest_nvp_train(nnest_nvp_t *nvp, const float *xtrain_dev, int n_train, const float *xvalid_dev, int n_valid,
                     const int *perm_dev, const float *noise_dev, uint64_t seed, float jitter, int batch,

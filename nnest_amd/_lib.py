@@ -24,6 +24,7 @@ MH_FORMS = {None: 0, 'auto': 0, 'image': 1, 'reg': 2, 'team': 3, 'quad': 4, 'qua
 MH_DEFAULT_LAG = 4      # steps between a step and the scale that reflects its batch-wide count
 TRAIN_RESUME = 1
 TRAIN_FINALIZE = 2
+TRAIN_ONE_CU = 4
 
 
 def mh_flags(dynamic=False, free=False, lag=None, form=None):

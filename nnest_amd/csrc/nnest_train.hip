@@ -61,6 +61,13 @@ struct TrainArgs {
     float *loss_out;
     int mode;
     int epoch_offset, flags;
+    // train_kernel_grid (nnest_train_grid.h): global staging [B*2][CT][128][16], job results, parameter -> job slot, partial sums,
+    // barrier counter, error word
+    float *gstage, *gtile;
+    int *gpos;
+    float *gpart, *grep;
+    unsigned int *gsync;
+    int *gerr;
     const float *gz;  // VJP: upstream gradient [M, D]
     float *gx;        // VJP: gradient wrt the input rows [M, D]
     float gld_in;     // VJP: dL/d(logdet), the same for every row
@@ -938,9 +945,11 @@ hipError_t launch_training_jitter(const double *samples, int N, int D, double *o
 // ---- launchers --------------------------------------------------------------------------------------------
 // workspace layout (floats): [img_bwd: image_floats][grad: num_params + 64][stash]
 static size_t train_stash_floats(const FlowShape &s) { return (size_t)TRAIN_WAVES * s.B * 2 * (s.L + 1) * s.NH * 256; }
+static size_t grid_workspace_floats(const FlowShape &s);
+static size_t single_workspace_floats(const FlowShape &s) { return (size_t)s.image_floats + (size_t)s.num_params() + 64 + train_stash_floats(s); }
 size_t train_workspace_floats(const FlowShape &s, int batch) {
     (void)batch;
-    return (size_t)s.image_floats + (size_t)s.num_params() + 64 + train_stash_floats(s);
+    return single_workspace_floats(s) + 64 + grid_workspace_floats(s);
 }
 
 template <int NT, int NH, int L, int IMGLDS>
@@ -976,6 +985,8 @@ static hipError_t dispatch_train(const TrainArgs &a, hipStream_t st) {
 #undef TRY_SHAPE
     return hipErrorInvalidConfiguration;
 }
+
+#include "nnest_train_grid.h"
 
 hipError_t launch_loss_grad(const float *packed, const FlowShape &s, const float *x, int M, float *grad, float *loss,
                             float *workspace, float *img_fwd, const int *fwd_pos, const int *bwd_pos, hipStream_t st) {
@@ -1059,6 +1070,7 @@ hipError_t launch_train(float *packed, float *adam_m, float *adam_v, float *best
     a.losses = losses; a.result = result;
     a.epoch_offset = epoch_offset; a.flags = flags;
     a.mode = TRAIN_MODE_EPOCHS;
+    if (grid_eligible(a)) return dispatch_train_grid(a, workspace + ((single_workspace_floats(s) + 63) & ~(size_t)63), st);
     return dispatch_train(a, st);
 }
 

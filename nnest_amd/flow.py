@@ -367,7 +367,7 @@ class HipNVP(_HipFlow):
         return loss, grad
 
     def train_epochs(self, xtrain, xvalid, perm, noise=None, seed=0, jitter=0.0, batch=100, max_epochs=1, patience=50,
-                     lr=1e-3, weight_decay=1e-6, epoch_offset=0, resume=False, finalize=True, result=None):
+                     lr=1e-3, weight_decay=1e-6, epoch_offset=0, resume=False, finalize=True, result=None, one_cu=False):
         """K5: Trainer.train's epoch loop (trainer.py:198-241) in one launch.  perm int32 [max_epochs, n_train];
         noise None (in-kernel Philox) or float32 [max_epochs, n_train, D] in loader order.
         A long train() can be split into chunks: pass the previous chunk's `result` tensor with resume=True,
@@ -387,7 +387,7 @@ class HipNVP(_HipFlow):
         if result is None:
             assert not resume
             result = torch.zeros(6, dtype=torch.int32, device=dev)  # nnest_train_result_t
-        flags = (_lib.TRAIN_RESUME if resume else 0) | (_lib.TRAIN_FINALIZE if finalize else 0)
+        flags = (_lib.TRAIN_RESUME if resume else 0) | (_lib.TRAIN_FINALIZE if finalize else 0) | (_lib.TRAIN_ONE_CU if one_cu else 0)
         with torch.cuda.device(dev):
             _lib.check(self._lib.nnest_nvp_train(self._h, _lib.ptr(xtrain), n_train, _lib.ptr(xvalid), n_valid,
                                                  _lib.ptr(perm), _lib.ptr(noise), int(seed) & 0xFFFFFFFFFFFFFFFF,
@@ -395,6 +395,8 @@ class HipNVP(_HipFlow):
                                                  float(weight_decay), int(epoch_offset), flags, _lib.ptr(losses),
                                                  _lib.ptr(result), _lib.current_stream(dev)))
         r = result.cpu()
+        if int(r[5]) == 2:
+            raise _lib.NnestHipError('nnest_nvp_train: a grid barrier of the multi-CU training kernel ran out (results invalid)')
         fl = r[2:4].view(torch.float32)
         return dict(losses=losses, epochs_run=int(r[0]), best_epoch=int(r[1]), best_validation_loss=float(fl[0]),
                     last_train_loss=float(fl[1]), counter=int(r[4]), stopped=bool(int(r[5])), result=result)

@@ -191,3 +191,36 @@ def test_l2_norm_and_explicit_standard_normal_base(hip, tmp_path):
     assert np.sqrt(np.mean((d_our - d_ref) ** 2)) < 0.03 * np.sqrt(np.mean(d_ref ** 2))
     with pytest.raises(NotImplementedError):
         Trainer(D, log_dir=None, base_dist=torch.distributions.MultivariateNormal(torch.ones(D), torch.eye(D)))
+
+
+@pytest.mark.parametrize('D,L,N,batch', [(50, 1, 1000, 100), (7, 2, 230, 64), (100, 1, 500, 128), (2, 0, 100, 100), (20, 1, 333, 100)])
+def test_grid_training_vs_single_workgroup(hip, D, L, N, batch):
+    """K5 on eight compute units (train_kernel_grid: one workgroup per 16-row tile, global staging, two grid barriers per
+    minibatch) against the single-workgroup kernel (NNEST_TRAIN_ONE_CU): weights, Adam moments, per-epoch losses and the
+    early-stopping state, with in-kernel jitter noise, a ragged last minibatch and a chunk boundary in the middle.  The
+    contractions run in the same order in both; what differs is where hipcc fuses a multiply-add, i.e. the last bit of a few
+    elementwise results, which 12 epochs of Adam steps carry along -- so: equal to 1e-4 of the largest element, and the grid
+    kernel equal to ITSELF bit for bit (the property replica training relies on)."""
+    rng = np.random.RandomState(D + L)
+    live = rng.normal(size=(N, D)) * 0.3
+    nv = N // 10
+    E = 12
+    perms = torch.stack([torch.randperm(N - nv, generator=torch.Generator().manual_seed(e)) for e in range(E)]).int()
+    out = {}
+    for key, one_cu in (('one', True), ('grid', False), ('grid2', False)):
+        nvp = hip.HipNVP(D, 16, 3, L, seed=5)
+        kw = dict(seed=77, jitter=0.02, batch=batch, patience=4, lr=1e-3, weight_decay=1e-6, one_cu=one_cu)
+        r1 = nvp.train_epochs(live[nv:], live[:nv], perms[:5], None, max_epochs=5, finalize=False, **kw)
+        r2 = nvp.train_epochs(live[nv:], live[:nv], perms[5:], None, max_epochs=E - 5, epoch_offset=5, resume=True,
+                              result=r1['result'], finalize=True, **kw)
+        m, v = nvp.adam_moments()
+        out[key] = (nvp.store_packed(), m, v, r1['losses'].cpu().numpy(), r2['losses'].cpu().numpy(), r2['epochs_run'],
+                    r2['best_epoch'], r2['stopped'], nvp.adam_step_count(), r2['best_validation_loss'])
+    a, b, c = out['one'], out['grid'], out['grid2']
+    for x, y in zip(b[:5], c[:5]):
+        assert np.array_equal(x, y)                 # deterministic down to the last bit
+    assert b[5:] == c[5:]
+    for x, y in zip(a[:5], b[:5]):
+        assert np.max(np.abs(x - y)) <= 1e-4 * (1e-3 + np.max(np.abs(x)))
+    assert a[5:9] == b[5:9] and abs(a[9] - b[9]) <= 1e-5 * abs(a[9])
+    assert a[5] >= 6 and a[8] > 0 and np.all(np.isfinite(a[3]))

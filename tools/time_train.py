@@ -1,22 +1,32 @@
-"""Developer timing of the training kernel (K5): epochs/s at the BASELINE configs."""
-import os, sys, time
+"""K5 (NVP training) time per epoch at a BASELINE population, multi-CU kernel and single-workgroup kernel (developer diagnostic).
+  python tools/time_train.py [x_dim] [n_live]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from nnest_amd import flow
-for D, N in ((2, 100), (50, 1000), (20, 2000), (100, 8000)):
-    rng = np.random.RandomState(0)
-    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
-    nv = int(np.ceil(0.1 * N)); Xv, Xt = X[:nv], X[nv:]
-    E = 40
-    perm = torch.stack([torch.randperm(Xt.shape[0]) for _ in range(E)]).int().cuda()
-    nvp = flow.HipNVP(D, 16, 3, 1, seed=0)
-    xt, xv = torch.from_numpy(Xt).cuda(), torch.from_numpy(Xv).cuda()
-    nvp.train_epochs(xt, xv, perm[:2], None, seed=1, jitter=0.01, max_epochs=2, patience=50)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    res = nvp.train_epochs(xt, xv, perm, None, seed=1, jitter=0.01, max_epochs=E, patience=1000)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    mb = (Xt.shape[0] + 99) // 100
-    if os.environ.get('NNEST_HIP_LIB', '').endswith('STAMP.so'):
-        ph = res['losses'].cpu().numpy().ravel()[:8] / (E * mb)
-        print('   cycles/minibatch: fwd %d | bwd_s+stage %d | jobs_s %d | bwd_t %d | jobs_t %d | adam %d | rows+jitter (inside fwd) %d | validation(per epoch) %d' % (ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7] * mb))
-    print('D=%d N=%d: %.3f ms/epoch (%d minibatches, %.1f us/minibatch incl. validation share)' % (D, N, dt / E * 1e3, mb, dt / E / mb * 1e6))
+from nnest_amd import flow  # noqa: E402
+
+D = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+rng = np.random.RandomState(0)
+live = rng.uniform(-1, 1, size=(N, D))
+nv = N // 10
+E = 40
+perms = torch.stack([torch.randperm(N - nv) for _ in range(E)]).int()
+for name, one_cu in (('eight CUs (train_kernel_grid)', False), ('one CU   (train_kernel)', True)):
+    nvp = flow.HipNVP(D, 16, 3, 1, seed=1)
+    kw = dict(seed=1, jitter=0.01, batch=100, patience=1000, one_cu=one_cu)
+    nvp.train_epochs(live[nv:], live[:nv], perms[:2], None, max_epochs=2, **kw)
+    torch.cuda.synchronize()
+    ts = []
+    for k in range(3):
+        t0 = time.perf_counter()
+        res = nvp.train_epochs(live[nv:], live[:nv], perms, None, max_epochs=E, **kw)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / res['epochs_run'] * 1e3)
+    print('x_dim %d, %d live points, %-32s %.3f ms per epoch (%d minibatches: %.1f us each)' % (
+        D, N, name, min(ts), (N - nv + 99) // 100, min(ts) * 1e3 / ((N - nv + 99) // 100)))
