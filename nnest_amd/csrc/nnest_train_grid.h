@@ -3,7 +3,8 @@
 // train_kernel runs a minibatch on one workgroup: 7 row tiles share 4 SIMDs, and the weight-gradient contractions (30 tile
 // jobs at the default shape) run 5 at a time between workgroup barriers -- 38 us per minibatch, 72 % of a config-2 run, on
 // 1 of 256 CUs.  train_kernel_grid gives every 16-row tile of the minibatch its own workgroup (G = 8 workgroups, one per CU):
-//   F+B  wave 0 of workgroup g: rows 16g..16g+15 forward and backward through all blocks with no barrier at all (the
+//   F+B  waves 0 and 1 of workgroup g (scale net / translate net of every block, exchanging their outputs through LDS as K4's
+//        team form does): rows 16g..16g+15 forward and backward through all blocks with no grid-level step in between (the
 //        per-row gradients G and activations go to a GLOBAL staging area, one region per (block, net), instead of one LDS
 //        region reused under workgroup barriers);
 //   grid barrier;
@@ -23,7 +24,7 @@
 // vmcnt(0) -> workgroup barrier -> one lane's agent-scope atomic add on a counter -> sc1 poll of the counter by one lane
 // -> workgroup barrier -> loads.  Polls are bounded (a counter that never fills sets the error word and the kernel ends).
 
-enum { GRID_WG = 8, GRID_MAX_POLLS = 1 << 22 };
+enum { GRID_WG = 8, GRID_MAX_POLLS = 1 << 22, NNEST_TRAIN_POS_LDS = 1 << 20 /* internal flag bit, never part of the ABI */ };
 
 // (the s_nop: a VMEM store of more than 8 bytes reads its data registers for up to two cycles after issue, and the compiler's
 // hazard recognizer cannot see inside the asm -- without it the next VALU write corrupted some lanes of some stores)
@@ -115,17 +116,28 @@ __device__ __forceinline__ f32x4 contract_rows_grid(const float *stg, int rows_p
     float bs = 0.f;
     const float *G = stg + (size_t)ct_g * TRAIN_MAX_ROWS * 16 + (lane >> 4) * 16 + (lane & 15);
     const float *A = stg + (size_t)ct_a * TRAIN_MAX_ROWS * 16 + (lane >> 4) * 16 + (lane & 15);
+    // every operand of the job is requested before the first MFMA: an sc1 load is a round trip to the memory side (~1.5 us), and
+    // with the loads inside the row loop the job paid one round trip per 16 rows (20 k cycles per job phase, measured).  Rows
+    // beyond rows_pad hold an earlier minibatch's data: their loads are redirected to tile 0 and their products skipped.
+    constexpr int NIT = TRAIN_MAX_ROWS / 16;
+    float gv[NIT][4], ev[NIT][4];
 #pragma unroll
-    for (int it = 0; it < TRAIN_MAX_ROWS / 16; ++it) {   // unrolled: every tile's loads in flight together; rows beyond
-        const int r = it * 16;                           // rows_pad hold an earlier minibatch's data and are not read
-        if (r < rows_pad) {
-            const float g0 = ld_sc1(G + (r + 0) * 16), g1 = ld_sc1(G + (r + 4) * 16), g2 = ld_sc1(G + (r + 8) * 16), g3 = ld_sc1(G + (r + 12) * 16);
-            const float e0 = ld_sc1(A + (r + 0) * 16), e1 = ld_sc1(A + (r + 4) * 16), e2 = ld_sc1(A + (r + 8) * 16), e3 = ld_sc1(A + (r + 12) * 16);
-            a0 = mfma4(g0, e0, a0);
-            a1 = mfma4(g1, e1, a1);
-            a2 = mfma4(g2, e2, a2);
-            a3 = mfma4(g3, e3, a3);
-            if (WITH_BIAS) bs += (g0 + g1) + (g2 + g3);
+    for (int it = 0; it < NIT; ++it) {
+        const int r = it * 16 < rows_pad ? it * 16 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            gv[it][k] = ld_sc1(G + (r + 4 * k) * 16);
+            ev[it][k] = ld_sc1(A + (r + 4 * k) * 16);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        if (it * 16 < rows_pad) {
+            a0 = mfma4(gv[it][0], ev[it][0], a0);
+            a1 = mfma4(gv[it][1], ev[it][1], a1);
+            a2 = mfma4(gv[it][2], ev[it][2], a2);
+            a3 = mfma4(gv[it][3], ev[it][3], a3);
+            if (WITH_BIAS) bs += (gv[it][0] + gv[it][1]) + (gv[it][2] + gv[it][3]);
         }
     }
     if (WITH_BIAS) {
@@ -268,33 +280,133 @@ __device__ __forceinline__ void block_backward_grid(const TrainArgs &a, int b, i
     for (int tau = 0; tau < NT; ++tau) gcond[tau] = gcond[tau] + gm_s[tau] + gm_t[tau];
 }
 
+// ---- F+B of one tile on TWO waves: wave 0 the scale net, wave 1 the translate net of every block (as K4's team form) ----
+// Workgroup barrier for data exchanged through LDS only: __syncthreads() would also drain the sc1 staging stores in flight.
+__device__ __forceinline__ void lds_barrier_t() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// the two net waves swap NT tiles through one LDS buffer [2 roles][NT][64] (two barriers: publish, then release)
+template <int NT>
+__device__ __forceinline__ void team_swap(f32x4 *xch, int role, int lane, const f32x4 (&mine)[NT], f32x4 (&other)[NT]) {
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) xch[(role * NT + tau) * 64 + lane] = mine[tau];
+    lds_barrier_t();
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) other[tau] = xch[((1 - role) * NT + tau) * 64 + lane];
+    lds_barrier_t();
+}
+enum { TEAM_BARRIERS_FWD = 2, TEAM_BARRIERS_BWD = 4 };  // per block
+
+// block_forward_keep with the two nets on two waves: same arithmetic, same stash layout
+template <int NT, int NH, int L>
+__device__ __forceinline__ float team_block_forward(const float *__restrict__ wf, int net_floats, int role, int lane,
+                                                    const f32x4 (&cond)[NT], f32x4 (&trans)[NT], f32x4 *__restrict__ stash, f32x4 *xch) {
+    f32x4 acts[L + 1][NH], mine[NT], other[NT];
+    if (role == 0) mlp_fwd_keep<NT, NH, L, 0>(wf, lane, cond, acts, mine);
+    else           mlp_fwd_keep<NT, NH, L, 1>(wf + net_floats, lane, cond, acts, mine);
+#pragma unroll
+    for (int l = 0; l <= L; ++l)
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) stash[((role * (L + 1) + l) * NH + ht) * 64 + lane] = acts[l][ht];
+    team_swap<NT>(xch, role, lane, mine, other);
+    float ld = 0.f;
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        const f32x4 ls = role == 0 ? mine[tau] : other[tau], t = role == 0 ? other[tau] : mine[tau];
+        trans[tau].x = trans[tau].x * __expf(ls.x) + t.x;
+        trans[tau].y = trans[tau].y * __expf(ls.y) + t.y;
+        trans[tau].z = trans[tau].z * __expf(ls.z) + t.z;
+        trans[tau].w = trans[tau].w * __expf(ls.w) + t.w;
+        ld += (ls.x + ls.y) + (ls.z + ls.w);
+    }
+    return ld;
+}
+
+// block_backward_grid with the two nets on two waves
+template <int NT, int NH, int L>
+__device__ __forceinline__ void team_block_backward(const TrainArgs &a, int b, int role, int lane, int row, bool row_ok,
+                                                    const f32x4 (&cond)[NT], f32x4 (&ytrans)[NT], f32x4 (&gcond)[NT], f32x4 (&gtrans)[NT],
+                                                    float gld, const float *imgf, const float *imgb, const f32x4 *__restrict__ stash,
+                                                    f32x4 *xch) {
+    typedef StageMap<NT, NH, L> SM;
+    const int pt = b & 1;
+    const float *wf = imgf + ((size_t)b * 2 + role) * a.s.net_floats;
+    const float *wb = imgb + ((size_t)b * 2 + role) * a.s.net_floats;
+    float *stg = a.gstage + (size_t)(b * 2 + role) * SM::count * TRAIN_MAX_ROWS * 16;
+    f32x4 acts[L + 1][NH], mine[NT], other[NT], g_mine[NT], gm[NT], gm_other[NT];
+    const int g = lane >> 4;
+#pragma unroll
+    for (int l = 0; l <= L; ++l)
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) acts[l][ht] = stash[((role * (L + 1) + l) * NH + ht) * 64 + lane];
+    mlp_out_layer<NT, NH, L>(wf, lane, acts[L], mine);
+    team_swap<NT>(xch, role, lane, mine, other);
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        const f32x4 ls = role == 0 ? mine[tau] : other[tau], t = role == 0 ? other[tau] : mine[tau];
+        float lsv[4] = {ls.x, ls.y, ls.z, ls.w};
+        float tv[4] = {t.x, t.y, t.z, t.w};
+        float yv[4] = {ytrans[tau].x, ytrans[tau].y, ytrans[tau].z, ytrans[tau].w};
+        float gv[4] = {gtrans[tau].x, gtrans[tau].y, gtrans[tau].z, gtrans[tau].w};
+        float o_gls[4], o_gt[4], o_x[4], o_gx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = 2 * (16 * tau + 4 * g + r) + pt;
+            const bool valid = row_ok && d < a.s.D;
+            float ymt = yv[r] - tv[r];
+            o_gls[r] = valid ? gv[r] * ymt + gld : 0.f;
+            o_gt[r] = valid ? gv[r] : 0.f;
+            o_x[r] = ymt * __expf(-lsv[r]);
+            o_gx[r] = gv[r] * __expf(lsv[r]);
+        }
+        g_mine[tau] = role == 0 ? (f32x4){o_gls[0], o_gls[1], o_gls[2], o_gls[3]} : (f32x4){o_gt[0], o_gt[1], o_gt[2], o_gt[3]};
+        ytrans[tau] = (f32x4){o_x[0], o_x[1], o_x[2], o_x[3]};
+        gtrans[tau] = (f32x4){o_gx[0], o_gx[1], o_gx[2], o_gx[3]};
+    }
+    if (role == 0) mlp_bwd_grid<NT, NH, L, 0>(wb, lane, stg, row, g_mine, acts, gm);
+    else           mlp_bwd_grid<NT, NH, L, 1>(wb, lane, stg, row, g_mine, acts, gm);
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        f32x4 mv = cond[tau];
+        if (!row_ok) mv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        stage_tile_grid(stg, SM::m(tau), row, lane, mv);
+    }
+    team_swap<NT>(xch, role, lane, gm, gm_other);
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        const f32x4 gm_s = role == 0 ? gm[tau] : gm_other[tau], gm_t = role == 0 ? gm_other[tau] : gm[tau];
+        gcond[tau] = gcond[tau] + gm_s + gm_t;
+    }
+}
+
 // Adam over the whole packed vector (as adam_sweep: float4 groups, U groups in flight per thread) with the gradient gathered
 // from the job results through gpos (sc1 loads: other workgroups wrote them).  Every workgroup steps its OWN replica of
 // (w, exp_avg, exp_avg_sq): a shared copy would be read-modify-written by eight workgroups at different times (a slow one
 // would step values a fast one had already stepped).
 __device__ __forceinline__ void adam_sweep_grid(const TrainArgs &a, const AdamStep &ad, int np, float *imgf, float *imgb, float *rw,
-                                                float *rm, float *rv) {
+                                                float *rm, float *rv, const int *fpos, const int *bpos) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    constexpr int U = 4;
+    constexpr int U = 6;  // 6 x 512 float4 groups cover the default flow's 11 628 parameters in one pass
     const int n4 = np >> 2;
     for (int i0 = threadIdx.x; i0 < n4; i0 += U * blockDim.x) {
         f32x4 w4[U], m4[U], v4[U];
         float g[U][4];
-        i32x4 fp[U], bp[U];
+        i32x4 gp[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < U; ++u) {   // the job slots first (the gathers below depend on them) ...
+            const int i = i0 + u * blockDim.x;
+            gp[u] = i < n4 ? reinterpret_cast<const i32x4 *>(a.gpos)[i] : (i32x4){-1, -1, -1, -1};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {   // ... then every other operand, all in flight together
             const int i = i0 + u * blockDim.x;
             if (i < n4) {
-                const i32x4 gp = reinterpret_cast<const i32x4 *>(a.gpos)[i];
-                g[u][0] = gp.x >= 0 ? ld_sc1(a.gtile + gp.x) : 0.f;
-                g[u][1] = gp.y >= 0 ? ld_sc1(a.gtile + gp.y) : 0.f;
-                g[u][2] = gp.z >= 0 ? ld_sc1(a.gtile + gp.z) : 0.f;
-                g[u][3] = gp.w >= 0 ? ld_sc1(a.gtile + gp.w) : 0.f;
+                g[u][0] = ld_sc1(a.gtile + max(gp[u].x, 0));   // unconditional (no divergent branch per element);
+                g[u][1] = ld_sc1(a.gtile + max(gp[u].y, 0));
+                g[u][2] = ld_sc1(a.gtile + max(gp[u].z, 0));
+                g[u][3] = ld_sc1(a.gtile + max(gp[u].w, 0));
                 w4[u] = reinterpret_cast<const f32x4 *>(rw)[i];
                 m4[u] = reinterpret_cast<const f32x4 *>(rm)[i];
                 v4[u] = reinterpret_cast<const f32x4 *>(rv)[i];
-                fp[u] = reinterpret_cast<const i32x4 *>(a.fwd_pos)[i];
-                bp[u] = reinterpret_cast<const i32x4 *>(a.bwd_pos)[i];
             }
         }
 #pragma unroll
@@ -303,9 +415,13 @@ __device__ __forceinline__ void adam_sweep_grid(const TrainArgs &a, const AdamSt
             if (i < n4) {
                 float w[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
                 float m[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w}, v[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
-                const int f[4] = {fp[u].x, fp[u].y, fp[u].z, fp[u].w}, bq[4] = {bp[u].x, bp[u].y, bp[u].z, bp[u].w};
+                // where the stepped weight sits in the two fragment images: read here (from the LDS copy of the maps when it
+                // fits), not held across the long-latency loads above
+                const i32x4 fp = reinterpret_cast<const i32x4 *>(fpos)[i], bp = reinterpret_cast<const i32x4 *>(bpos)[i];
+                const int f[4] = {fp.x, fp.y, fp.z, fp.w}, bq[4] = {bp.x, bp.y, bp.z, bp.w};
+                const int gq[4] = {gp[u].x, gp[u].y, gp[u].z, gp[u].w};   // < 0: no job produces this gradient: exactly zero
 #pragma unroll
-                for (int k = 0; k < 4; ++k) adam_one(a, ad, w[k], g[u][k], m[k], v[k], f[k], bq[k], imgf, imgb);
+                for (int k = 0; k < 4; ++k) adam_one(a, ad, w[k], gq[k] >= 0 ? g[u][k] : 0.f, m[k], v[k], f[k], bq[k], imgf, imgb);
                 reinterpret_cast<f32x4 *>(rw)[i] = (f32x4){w[0], w[1], w[2], w[3]};
                 reinterpret_cast<f32x4 *>(rm)[i] = (f32x4){m[0], m[1], m[2], m[3]};
                 reinterpret_cast<f32x4 *>(rv)[i] = (f32x4){v[0], v[1], v[2], v[3]};
@@ -315,7 +431,7 @@ __device__ __forceinline__ void adam_sweep_grid(const TrainArgs &a, const AdamSt
     for (int p = 4 * n4 + threadIdx.x; p < np; p += blockDim.x) {  // tail (np not a multiple of 4)
         const int gp = a.gpos[p];
         float w = rw[p], m = rm[p], v = rv[p];
-        adam_one(a, ad, w, gp >= 0 ? ld_sc1(a.gtile + gp) : 0.f, m, v, a.fwd_pos[p], a.bwd_pos[p], imgf, imgb);
+        adam_one(a, ad, w, gp >= 0 ? ld_sc1(a.gtile + gp) : 0.f, m, v, fpos[p], bpos[p], imgf, imgb);
         rw[p] = w; rm[p] = m; rv[p] = v;
     }
 }
@@ -326,6 +442,11 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *imgf = smem;
     float *imgb = smem + a.s.image_floats;
+    // parameter -> image element maps: LDS copies behind the images when they fit (a.flags bit NNEST_TRAIN_POS_LDS, set by the launcher)
+    const bool pos_lds = (a.flags & NNEST_TRAIN_POS_LDS) != 0;
+    int *lfp = reinterpret_cast<int *>(smem + 2 * a.s.image_floats), *lbp = lfp + ((a.s.num_params() + 3) & ~3);
+    const int *fpos = pos_lds ? lfp : a.fwd_pos, *bpos = pos_lds ? lbp : a.bwd_pos;
+    __shared__ f32x4 xch[2 * NT * 64];   // the two net waves' exchange buffer
     __shared__ int ctl[4];      // [0] stop flag, [1] counter, [2] best epoch
     __shared__ float ctlf[2];   // [0] best validation loss
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -341,7 +462,10 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
     int phase = 0;
 
     rebuild_images_to(a, imgf, imgb);
-    for (int i = threadIdx.x; i < np; i += blockDim.x) { rw[i] = a.w[i]; rm[i] = a.m[i]; rv[i] = a.v[i]; }
+    for (int i = threadIdx.x; i < np; i += blockDim.x) {
+        rw[i] = a.w[i]; rm[i] = a.m[i]; rv[i] = a.v[i];
+        if (pos_lds) { lfp[i] = a.fwd_pos[i]; lbp[i] = a.bwd_pos[i]; }
+    }
     const bool resume = (a.flags & NNEST_TRAIN_RESUME) != 0;
     if (threadIdx.x == 0) {
         ctl[0] = 0;
@@ -355,6 +479,8 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
 
     const int n_mb = (a.n_train + a.batch - 1) / a.batch;
     int adam_t = a.adam_step ? *a.adam_step : 0;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0;
+    (void)ph; (void)q0; (void)q1; (void)q2; (void)q3; (void)q4; (void)q5; (void)q6;
     int epochs_run = 0, mbcount = 0;
     float last_train_loss = 0.f;
     bool alive = true;
@@ -365,9 +491,8 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
             const int M = min(a.batch, a.n_train - mb * a.batch);
             const int ntile = (M + 15) >> 4;
             const int rows_pad = ntile * 16;
-            const bool tile_active = wave == 0 && wg < ntile;
             const int row = wg * 16 + w;
-            const bool row_ok = tile_active && row < M;
+            const bool row_ok = wg < ntile && row < M;
             float *part = a.gpart + (mbcount & 1) * 16;
             AdamStep ad;
             {
@@ -376,9 +501,15 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
                 ad.step_size = (float)((double)a.lr / bc1);
                 ad.inv_bc2s = (float)(1.0 / sqrt(bc2));
             }
-            if (wave == 0) {
+            TSTAMP(q0);
+            const bool wg_active = wg < ntile;   // this workgroup owns a tile of this minibatch
+            if (wg_active && wave >= 2) {        // the other waves keep the net waves' LDS barriers company
+                for (int k = 0; k < B * (TEAM_BARRIERS_FWD + TEAM_BARRIERS_BWD); ++k) lds_barrier_t();
+            }
+            if (wave < 2) {
+                const int role = wave;           // 0: scale net, 1: translate net; both carry the tile and take the same steps
                 float lp = 0.f;
-                if (tile_active) {
+                if (wg_active) {
                     f32x4 xs[2][NT], gs[2][NT];
                     // data = X[perm] + jitter * randn  (trainer.py:392)
                     long src = 0;
@@ -412,8 +543,8 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
                     for (int b = 0; b < B; ++b) {
                         const float *wf = imgf + (size_t)b * 2 * a.s.net_floats;
                         f32x4 *sb = stash_w + (size_t)b * 2 * (L + 1) * NH * 64;
-                        if (b & 1) ldp += block_forward_keep<NT, NH, L>(wf, a.s.net_floats, true, lane, xs[0], xs[1], sb);
-                        else       ldp += block_forward_keep<NT, NH, L>(wf, a.s.net_floats, true, lane, xs[1], xs[0], sb);
+                        if (b & 1) ldp += team_block_forward<NT, NH, L>(wf, a.s.net_floats, role, lane, xs[0], xs[1], sb, xch);
+                        else       ldp += team_block_forward<NT, NH, L>(wf, a.s.net_floats, role, lane, xs[1], xs[0], sb, xch);
                     }
                     const float ld = group_sum(ldp);
                     float ss = 0.f;
@@ -425,6 +556,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
                     lp = (row_ok && g == 0) ? (-ss + a.s.base_const * (float)D + ld) : 0.f;
 #pragma unroll
                     for (int o = 1; o < 16; o <<= 1) lp += __shfl_xor(lp, o);
+                    TSTAMP(q1);
                     // d(loss)/du = dE/du / M ; d(loss)/d(logdet) = -1/M
                     const float invM = 1.0f / (float)M, gld = -invM;
 #pragma unroll
@@ -433,14 +565,16 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
                         for (int t = 0; t < NT; ++t) gs[c][t] = row_ok ? base_dE4(xs[c][t], a.s.base_beta) * invM : (f32x4){0.f, 0.f, 0.f, 0.f};
                     for (int b = B - 1; b >= 0; --b) {
                         const f32x4 *sb = stash_w + (size_t)b * 2 * (L + 1) * NH * 64;
-                        if (b & 1) block_backward_grid<NT, NH, L>(a, b, lane, row, row_ok, xs[0], xs[1], gs[0], gs[1], gld, imgf, imgb, sb);
-                        else       block_backward_grid<NT, NH, L>(a, b, lane, row, row_ok, xs[1], xs[0], gs[1], gs[0], gld, imgf, imgb, sb);
+                        if (b & 1) team_block_backward<NT, NH, L>(a, b, role, lane, row, row_ok, xs[0], xs[1], gs[0], gs[1], gld, imgf, imgb, sb, xch);
+                        else       team_block_backward<NT, NH, L>(a, b, role, lane, row, row_ok, xs[1], xs[0], gs[1], gs[0], gld, imgf, imgb, sb, xch);
                     }
                 }
-                if (lane == 0) __hip_atomic_store(part + wg, lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (wave == 0 && lane == 0) __hip_atomic_store(part + wg, lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            TSTAMP(q2);
             alive = grid_barrier(a.gsync, phase, G, a.gerr);
             if (!alive) break;
+            TSTAMP(q3);
             // ---- W: one weight-gradient job per wave of the grid ----
             for (int J = wg * TRAIN_WAVES + wave; J < NJ; J += G * TRAIN_WAVES) {
                 const int bn = J / NJOBS;
@@ -466,15 +600,25 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
                 st_sc1_f32x4(a.gtile + ((size_t)J * 64 + lane) * 4, t);
                 st_sc1_f32x4(a.gtile + ((size_t)NJ * 64 + (size_t)J * 64 + lane) * 4, bt);
             }
+            TSTAMP(q4);
             alive = grid_barrier(a.gsync, phase, G, a.gerr);
             if (!alive) break;
-            // loss = -mean(log_probs)  (trainer.py:394): tile partials in tile order, as train_kernel sums its waves
+            TSTAMP(q5);
+            // loss = -mean(log_probs)  (trainer.py:394): tile partials in tile order, as train_kernel sums its waves (requested
+            // before Adam's loads, summed after: one round trip to the memory side instead of two)
+            float lpart[GRID_WG];
+#pragma unroll
+            for (int k = 0; k < GRID_WG; ++k) lpart[k] = ld_sc1(part + k);
+            adam_sweep_grid(a, ad, np, imgf, imgb, rw, rm, rv, fpos, bpos);
             float loss = 0.f;
-            for (int k = 0; k < GRID_WG; ++k) loss += k < G ? ld_sc1(part + k) : 0.f;
+#pragma unroll
+            for (int k = 0; k < GRID_WG; ++k) loss += k < G ? lpart[k] : 0.f;
             loss = -loss / (float)M;
             epoch_loss += loss;
-            adam_sweep_grid(a, ad, np, imgf, imgb, rw, rm, rv);
             __syncthreads();
+            TSTAMP(q6);
+            if (wave == 0 && q1 > q0) { TACC(ph[0], q1, q0); TACC(ph[1], q2, q1); }
+            TACC(ph[2], q3, q2); TACC(ph[3], q4, q3); TACC(ph[4], q5, q4); TACC(ph[5], q6, q5);
         }
         if (!alive) break;
         // ---- Trainer._validate (trainer.py:405-418): workgroup g takes the tiles wave g of train_kernel takes ----
@@ -540,6 +684,10 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
     }
     __syncthreads();
     rebuild_images(a);
+#ifdef NNEST_STAMP
+    if (threadIdx.x == 0 && a.losses)   // diagnostic build: cycles per phase, summed over the minibatches (workgroup 0, wave 0)
+        for (int i = 0; i < 8; ++i) a.losses[i] = (float)ph[i];
+#endif
     if (threadIdx.x == 0) {
         if (a.adam_step) *a.adam_step = adam_t;
         a.result->epochs_run = a.epoch_offset + epochs_run;
@@ -573,7 +721,12 @@ static hipError_t launch_train_grid_t(TrainArgs a, float *gridws, hipStream_t st
     e = hipMemsetAsync(a.gpart, 0, (64 + 16) * sizeof(float), st);  // partial sums, the barrier counter, the error word
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((grid_gpos_kernel<NT, NH, L>), dim3(32), dim3(256), 0, st, a.gpos, a.s);
-    const size_t lds = 2 * (size_t)a.s.image_floats * sizeof(float);
+    size_t lds = 2 * (size_t)a.s.image_floats * sizeof(float);
+    const size_t pos = 2 * (size_t)((a.s.num_params() + 3) & ~3) * sizeof(int);
+    if (lds + pos + 2 * NT * 1024 <= 160 * 1024 - 512) {   // the two position maps beside the images (and the exchange buffer)
+        lds += pos;
+        a.flags |= NNEST_TRAIN_POS_LDS;
+    }
     if (lds > 64 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(train_kernel_grid<NT, NH, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -257,8 +257,11 @@ class Sampler(object):
         # the reference; the default keeps the grid-wide wait off the step); populations too large for a
         # resident grid fall back to the per-16-walker rule
         mode = 'batch' if dynamic and getattr(self, '_batch_rule_ok', True) else ('group' if dynamic else False)
+        lag = getattr(self, 'mcmc_step_lag', None)
+        if lag is None and int(mcmc_steps) < 100:
+            lag = 0   # short chains: the lag would be a sizeable part of the launch, and the exact rule costs microseconds here
         try:
-            res = netG.mh_steps(*args, dynamic=mode, lag=getattr(self, 'mcmc_step_lag', None), **kw)
+            res = netG.mh_steps(*args, dynamic=mode, lag=lag, **kw)
         except _lib.NnestHipError as e:
             if mode != 'batch' or e.code != _lib.NNEST_E_UNSUPPORTED:
                 raise

@@ -68,6 +68,12 @@ def all_(cfg, seeds, jobs):
         time.sleep(5)
         running = [p for p in running if p.poll() is None]
     runs = [json.load(open(o)) for o in outs if os.path.exists(o)]
+    path = os.path.join(ROOT, 'tests', 'golden', 'logz_cpu_cfg%d.json' % cfg)
+    if os.path.exists(path):   # add to the seeds already there
+        with open(path) as f:
+            old = json.load(f)['runs']
+        runs = [r for r in old if r['seed'] not in [q['seed'] for q in runs]] + runs
+        runs.sort(key=lambda r: r['seed'])
     z = np.array([r['logz'] for r in runs])
     name, D, scale, N = CONFIGS[cfg]
     doc = dict(what='CPU-path log Z: host driver + oracle-backed trainer (oracle/run_logz_cpu.py)', config=cfg,
@@ -75,7 +81,6 @@ def all_(cfg, seeds, jobs):
                seeds=[r['seed'] for r in runs], logz=[r['logz'] for r in runs], mean=float(z.mean()),
                std=float(z.std(ddof=1)) if len(z) > 1 else None,
                stderr=float(z.std(ddof=1) / np.sqrt(len(z))) if len(z) > 1 else None, runs=runs)
-    path = os.path.join(ROOT, 'tests', 'golden', 'logz_cpu_cfg%d.json' % cfg)
     with open(path, 'w') as f:
         json.dump(doc, f, indent=1)
     print(path, doc['mean'], doc['std'])

@@ -334,3 +334,33 @@ def test_host_tensors_drop_in_level_1(tmp_path, monkeypatch):
     for a, b in zip(out[True][:4], out[False][:4]):
         assert np.array_equal(a, b)
     assert out[True][4] == out[False][4] and out[True][5] == out[False][5] and out[True][5] > 0
+
+
+def _cpu_fixture(cfg):
+    with open(os.path.join(G, 'logz_cpu_cfg%d.json' % cfg)) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('cfg', [1, 2])
+def test_logz_gpu_vs_cpu(tmp_path, cfg):
+    """BASELINE's acceptance: log Z of the GPU path against the CPU path (the host driver on the oracle-backed trainer,
+    oracle/run_logz_cpu.py -> tests/golden/logz_cpu_cfg<cfg>.json) for the same configuration, the same run() arguments and
+    the same list of seeds.  The two paths draw from different noise streams, so a run is an independent estimate with scatter
+    ~ sqrt(H/N) (0.2 at config 1, 0.45 at config 2); the comparison is between the MEANS over the seeds:
+    |mean_gpu - mean_cpu| <= max(0.1, 2 combined standard errors), standard errors from the samples themselves."""
+    ref = _cpu_fixture(cfg)
+    like = Rosenbrock(ref['x_dim'])
+    seeds = ref['seeds'] if cfg == 1 else ref['seeds'][:6]
+    cpu = np.array([r['logz'] for r in ref['runs'] if r['seed'] in seeds])
+    gpu = []
+    for seed in seeds:
+        s = run(tmp_path / str(seed), ref['x_dim'], like, 5.0, ref['num_live_points'], seed, mcmc_num_chains=ref['mcmc_num_chains'])
+        gpu.append(s.logz)
+    gpu = np.array(gpu)
+    se = float(np.hypot(gpu.std(ddof=1) / np.sqrt(len(gpu)), cpu.std(ddof=1) / np.sqrt(len(cpu))))
+    delta = float(gpu.mean() - cpu.mean())
+    print('config %d: gpu %.3f +- %.3f, cpu %.3f +- %.3f, delta %.3f, combined standard error %.3f (%d seeds)' % (
+        cfg, gpu.mean(), gpu.std(ddof=1) / np.sqrt(len(gpu)), cpu.mean(), cpu.std(ddof=1) / np.sqrt(len(cpu)), delta, se, len(seeds)))
+    assert abs(delta) <= max(0.1, 2 * se), (delta, se)
+    # and the run-to-run scatter is the same on both sides (within a factor: 6-16 samples)
+    assert 0.4 < gpu.std(ddof=1) / cpu.std(ddof=1) < 2.5

@@ -30,3 +30,10 @@ for name, one_cu in (('eight CUs (train_kernel_grid)', False), ('one CU   (train
         ts.append((time.perf_counter() - t0) / res['epochs_run'] * 1e3)
     print('x_dim %d, %d live points, %-32s %.3f ms per epoch (%d minibatches: %.1f us each)' % (
         D, N, name, min(ts), (N - nv + 99) // 100, min(ts) * 1e3 / ((N - nv + 99) // 100)))
+
+if os.environ.get('NNEST_HIP_LIB', '').endswith('STAMP.so'):   # NNEST_STAMP build: cycles per phase of a minibatch (workgroup 0)
+    nvp = flow.HipNVP(D, 16, 3, 1, seed=1)
+    res = nvp.train_epochs(live[nv:], live[:nv], perms, None, max_epochs=E, seed=1, jitter=0.01, batch=100, patience=1000)
+    ph = res['losses'].cpu().numpy().ravel()[:8] / (E * ((N - nv + 99) // 100))
+    print('grid kernel, cycles per minibatch: forward %d  backward+staging %d  barrier %d  weight-gradient jobs %d  barrier %d  '
+          'loss + Adam %d' % tuple(ph[:6]))
