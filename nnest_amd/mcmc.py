@@ -1,7 +1,8 @@
 """MCMCSampler: the reference's flow-accelerated Metropolis front-end (nnest/mcmc.py:24-130) on this build's Sampler:
 train the flow on a set of (normalised) training samples, then run `_mcmc_sample` with the likelihood and prior in the
-proposal ratio (loglstar = None, sampler.py:371-410).  Chain statistics (getdist ESS etc., sampler.py:474-492) are not
-computed here."""
+proposal ratio (loglstar = None, sampler.py:371-410).  As in the reference, `mcmc_dynamic_step_size` is accepted and not
+forwarded (mcmc.py:118-120): the chains run at the fixed step 2 / sqrt(x_dim).  Chain statistics (getdist ESS etc.,
+sampler.py:474-492) are not computed here (out of scope)."""
 import logging
 
 import numpy as np
@@ -34,7 +35,7 @@ class MCMCSampler(Sampler):
         self.trainer.train(training_samples, jitter=initial_jitter)
         samples, latent_samples, derived_samples, loglikes, scale, ncall = self._mcmc_sample(
             mcmc_steps, num_chains=mcmc_num_chains, stats_interval=stats_interval, output_interval=output_interval,
-            init_samples=init_samples, dynamic_step_size=mcmc_dynamic_step_size)
+            init_samples=init_samples)   # mcmc.py:118-120 does not forward mcmc_dynamic_step_size: the chains keep a fixed step
         samples = self.transform(samples)
         self.samples = np.concatenate((samples, derived_samples), axis=2)
         self.latent_samples = latent_samples
