@@ -350,7 +350,7 @@ def test_logz_gpu_vs_cpu(tmp_path, cfg):
     |mean_gpu - mean_cpu| <= max(0.1, 2 combined standard errors), standard errors from the samples themselves."""
     ref = _cpu_fixture(cfg)
     like = Rosenbrock(ref['x_dim'])
-    seeds = ref['seeds'] if cfg == 1 else ref['seeds'][:6]
+    seeds = ref['seeds']
     cpu = np.array([r['logz'] for r in ref['runs'] if r['seed'] in seeds])
     gpu = []
     for seed in seeds:
