@@ -73,6 +73,10 @@ struct XoshiroNoise {
             for (int j = 0; j < 8; ++j)
                 if (32 * t + 8 * g + j < D) valid_mask |= 1u << (8 * t + j);
     }
+    // the batch-wide step rule relayed by a noise wave (LdsNoise of the team form): not here
+    __device__ __forceinline__ bool relays() const { return false; }
+    __device__ __forceinline__ int relayed_total() const { return 0; }
+    __device__ __forceinline__ void relay_count(int, int) const {}
     __device__ __forceinline__ void next(float (&nz)[NT][8], float &u) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {

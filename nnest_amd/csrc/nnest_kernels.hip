@@ -207,7 +207,7 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
         // batch-wide step rule: the counts of step it - lag are requested now and consumed at the end of the step
         unsigned long long early = 0;
         const bool have_total = batch && dynamic && it - lag >= 1;
-        if (have_total && lag > 0) early = mh_sync_read(a.sync, it - lag);
+        if (have_total && lag > 0 && !noise.relays()) early = mh_sync_read(a.sync, it - lag);
         // proposal z' = z + randn * scale  (sampler.py:310, :316); float32 like torch
         const float fs = (float)scale;
         f32x4 zp[2][NT], xp[2][NT];
@@ -284,12 +284,17 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
             int num_accepted = tile_accepted, num_total = nvalid;
             bool apply = true;
             if (batch) {
-                // lag >= 1: consume the counts requested at the top of the step BEFORE posting this step's -- memory operations
-                // retire in order, and an atomic stays outstanding for 600-3000 cycles (MI355X_MICROARCH.md)
                 apply = have_total;
-                if (apply && lag > 0) num_accepted = mh_sync_total(a.sync, it - lag, ntiles, early, a.sync_err);
-                if (writer && lane == 0) mh_sync_post(a.sync, it, tile, tile_accepted);
-                if (apply && lag == 0) num_accepted = mh_sync_total(a.sync, it, ntiles, mh_sync_read(a.sync, it), a.sync_err);
+                if (noise.relays()) {   // team form, lag >= 2: the noise wave relays count and total through LDS
+                    num_accepted = noise.relayed_total();
+                    if (writer && lane == 0) noise.relay_count(it, tile_accepted);
+                } else {
+                    // lag >= 1: consume the counts requested at the top of the step BEFORE posting this step's -- memory
+                    // operations retire in order, and an atomic stays outstanding for 600-3000 cycles (MI355X_MICROARCH.md)
+                    if (apply && lag > 0) num_accepted = mh_sync_total(a.sync, it - lag, ntiles, early, a.sync_err);
+                    if (writer && lane == 0) mh_sync_post(a.sync, it, tile, tile_accepted);
+                    if (apply && lag == 0) num_accepted = mh_sync_total(a.sync, it, ntiles, mh_sync_read(a.sync, it), a.sync_err);
+                }
                 num_total = a.C;
             }
             if (apply) {
@@ -487,6 +492,16 @@ struct LdsNoise {
     const float *nbuf;  // [2][NT*8][64]
     const float *ubuf;  // [2][64]
     int lane, k;
+    // batch-wide step rule at lag >= 2 (mh_common.h): the noise wave does the global-memory work -- it posts the tile's accepted
+    // count it finds in acc[] and fetches the batch total the net waves will apply -- and hands the total over here, at the
+    // per-step barrier; a step of the net waves then contains no global-memory operation
+    int *acc;          // [2]: accepted count of step s at s & 1 (written by the writer wave)
+    const int *res;    // [2]: batch total to apply in step k at k & 1 (written by the noise wave)
+    bool relay;
+    int total;
+    __device__ __forceinline__ bool relays() const { return relay; }
+    __device__ __forceinline__ int relayed_total() const { return total; }
+    __device__ __forceinline__ void relay_count(int it, int accepted) const { acc[it & 1] = accepted; }
     __device__ __forceinline__ void next(float (&nz)[NT][8], float &u) {
         __syncthreads();  // the noise wave has published buffer k&1
         const float *p = nbuf + (size_t)(k & 1) * NT * 8 * 64 + lane;
@@ -495,6 +510,7 @@ struct LdsNoise {
 #pragma unroll
             for (int j = 0; j < 8; ++j) nz[t][j] = p[(t * 8 + j) * 64];
         u = ubuf[(k & 1) * 64 + lane];
+        if (relay) total = res[k & 1];
         ++k;
     }
 };
@@ -508,9 +524,18 @@ __global__ void __launch_bounds__(192, 2) mh_kernel_team(MhArgs a) {  // min 2 w
     __shared__ __attribute__((aligned(16))) f32x4 xch[2 * 2 * NT * 64];
     __shared__ float nbuf[2 * NT * 8 * 64];
     __shared__ float ubuf[2 * 64];
+    __shared__ int acc_lds[2], res_lds[2];
     const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform
     const int tile = blockIdx.x;
     const int net_floats = a.s.net_floats, S = a.steps;
+    const int ntiles = (a.C + 15) >> 4;
+    const bool batch_rule = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;
+    const int lag_rule = mh_flag_lag(a.flags);
+    const bool relay = batch_rule && lag_rule >= 2;
+    if (tile >= ntiles) {   // the workgroup behind the tiles publishes the batch-wide accept counts (mh_common.h)
+        if (relay && role == 0) mh_sync_publisher(a.sync, S, S - lag_rule, ntiles, lane, a.sync_err);
+        return;
+    }
     for (int i = threadIdx.x; i < B * 2 * TI::NBIAS; i += blockDim.x) {
         int bn = i / TI::NBIAS, o = i - bn * TI::NBIAS;
         bias_lds[i] = a.img[(size_t)bn * net_floats + frag_off_b1(NT, 1, L) + o];
@@ -521,6 +546,14 @@ __global__ void __launch_bounds__(192, 2) mh_kernel_team(MhArgs a) {  // min 2 w
         XoshiroNoise<NT> gen;
         gen.init(a.seed, a.walker_offset + (uint64_t)(tile * 16 + (lane & 15)), lane >> 4, a.s.D);
         for (int k = 0; k <= S; ++k) {
+            // relay: between the barriers k - 1 and k the net waves run step k - 1; the count of step k - 2 is in LDS, and the
+            // total they apply at the end of step k (that of step k - lag) has to be in LDS by barrier k
+            unsigned long long early = 0;
+            const int want = k - lag_rule;
+            if (relay) {
+                if (k >= 2 && lane == 0) mh_sync_post(a.sync, k - 2, tile, acc_lds[k & 1]);
+                if (want >= 1) early = mh_result_load(a.sync, S, want, tile);
+            }
             float nz[NT][8], u;
             gen.next(nz, u);
             float *p = nbuf + (size_t)(k & 1) * NT * 8 * 64 + lane;
@@ -529,6 +562,10 @@ __global__ void __launch_bounds__(192, 2) mh_kernel_team(MhArgs a) {  // min 2 w
 #pragma unroll
                 for (int j = 0; j < 8; ++j) p[(t * 8 + j) * 64] = nz[t][j];
             ubuf[(k & 1) * 64 + lane] = u;
+            if (relay && want >= 1) {
+                const int total = mh_result_wait(a.sync, S, want, tile, early, a.sync_err);
+                if (lane == 0) res_lds[k & 1] = total;
+            }
             if (k == 0)
                 for (int b = 0; b < B; ++b) __syncthreads();  // the consumers' initial inverse
             __syncthreads();                                   // publish buffer k
@@ -555,7 +592,7 @@ __global__ void __launch_bounds__(192, 2) mh_kernel_team(MhArgs a) {  // min 2 w
             for (int i = 0; i < TI::FC::N; ++i) inv.w[b].v[i] = src[frag_elem(i, lane)];
         }
     }
-    LdsNoise<NT> noise = {nbuf, ubuf, lane, 0};
+    LdsNoise<NT> noise = {nbuf, ubuf, lane, 0, acc_lds, res_lds, relay, 0};
     mh_body<NT, DBG>(a, tile, lane, inv, noise, role == 0);
 }
 
@@ -643,14 +680,15 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
     if constexpr (LT == 1 && NH == 1) {
         if ((form == MH_FORM_AUTO || form == MH_FORM_TEAM) && a.s.B == 3 && ntiles <= num_cu && !a.noise_dz && a.s.scale_mode != 2) {  // fewer tiles than CUs: three waves per tile (team form)
             const size_t timg = NT <= 2 ? 0 : (size_t)a.s.image_floats * 4;  // 3-4 tiles per class: fragments from an LDS image
+            const int grid = ntiles + ((batch && mh_flag_lag(a.flags) >= 2) ? 1 : 0);  // + the workgroup that publishes the batch totals
             if (a.hist_x || a.hist_logl) {
                 hipError_t e = allow_lds(mh_kernel_team<NT, 1, 3, true>, timg + 48 * 1024);
                 if (e != hipSuccess) return e;
-                hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, true>), dim3(ntiles), dim3(192), timg, st, a);
+                hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, true>), dim3(grid), dim3(192), timg, st, a);
             } else {
                 hipError_t e = allow_lds(mh_kernel_team<NT, 1, 3, false>, timg + 48 * 1024);
                 if (e != hipSuccess) return e;
-                hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, false>), dim3(ntiles), dim3(192), timg, st, a);
+                hipLaunchKernelGGL((mh_kernel_team<NT, 1, 3, false>), dim3(grid), dim3(192), timg, st, a);
             }
             return hipGetLastError();
         }

@@ -17,8 +17,9 @@ _STAGING = {}
 
 
 def _staging_f32(n, device):
-    """a pinned float32 staging buffer per device, grown on demand"""
-    key = str(device)
+    """a pinned float32 staging buffer per (device, stream), grown on demand: callers on different streams (threads) never
+    share one"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     buf = _STAGING.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.empty(max(int(n), 1 << 16), dtype=torch.float32).pin_memory()

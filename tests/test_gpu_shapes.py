@@ -201,3 +201,46 @@ def test_train_epochs_generic_shape_vs_oracle(hip):
     np.testing.assert_allclose(losses[:, 0], ro['train_losses'], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(losses[:, 1], ro['valid_losses'], rtol=2e-4, atol=2e-5)
     assert res['best_epoch'] == ro['best_validation_epoch']
+
+
+def test_two_handles_on_two_streams_concurrently(hip):
+    """two flows driven from two host threads on two HIP streams at the same time (passes, the proposal kernel with the
+    batch-wide step rule, training): every result equals the one obtained alone on the default stream.  The staging buffer
+    for host arrays is per (device, stream), so concurrent callers do not share it."""
+    import threading
+    D, C, S = 50, 300, 40
+    rng = np.random.RandomState(0)
+    u = rng.uniform(-0.8, 0.8, size=(C, D))
+    live = rng.normal(size=(400, D)) * 0.3
+    perms = torch.stack([torch.randperm(360, generator=torch.Generator().manual_seed(e)) for e in range(6)]).int()
+
+    def work(seed):
+        nvp = hip.HipNVP(D, 16, 3, 1, seed=seed)
+        out = []
+        for rep in range(3):
+            z, ld = nvp.forward(u)
+            logl = hip.loglike(0, u, 5.0)
+            res = nvp.mh_steps(0, 5.0, z, logl, float(logl.min()) - 10.0, 0.1, S, dynamic='batch', seed=seed + rep)
+            nvp.check_sync(res)
+            r = nvp.train_epochs(live[40:], live[:40], perms, None, max_epochs=6, seed=seed, jitter=0.01, batch=100, patience=50)
+            out.append((z.cpu().numpy().copy(), logl.cpu().numpy().copy(), res['x'].cpu().numpy().copy(), nvp.store_packed(),
+                        r['losses'].cpu().numpy().copy()))
+        return out
+
+    alone = {s: work(s) for s in (11, 22)}
+    got = {}
+
+    def runner(seed):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            got[seed] = work(seed)
+            torch.cuda.current_stream().synchronize()
+
+    ts = [threading.Thread(target=runner, args=(s,)) for s in (11, 22)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for s in (11, 22):
+        for a, b in zip(alone[s], got[s]):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
