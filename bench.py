@@ -194,7 +194,7 @@ def main():
         C_total = args.walkers or N_cfg
         C = -(-C_total // world)
         cu = _lib.device_info()['num_cu']
-        form = next((f for f, t, lim in (('quad', 4, cu), ('team', 16, cu), ('reg', 16, 4 * cu)) if -(-C_total // t) <= lim), 'image')
+        form = next((f for f, t, lim in (('quad', 4, (2 if D <= 64 else 1) * cu - 1), ('team', 16, cu), ('reg', 16, 4 * cu)) if -(-C_total // t) <= lim), 'image')
     S = args.mcmc_steps if args.mcmc_steps > 0 else 5 * D
     nvp = flow.HipNVP(D, H, B, L, device=dev, seed=0)
     rng = np.random.RandomState(1234 + rank)
@@ -256,7 +256,7 @@ def main():
         achieved_tflops = evals_per_launch * fl / (kern_ms * 1e-3) / 1e12
         info = _lib.device_info()
         cu = info['num_cu']
-        kform = form or next((f for f, t, lim in (('quad', 4, cu), ('team', 16, cu), ('reg', 16, 4 * cu)) if -(-C // t) <= lim), 'image')
+        kform = form or next((f for f, t, lim in (('quad', 4, (2 if D <= 64 else 1) * cu - 1), ('team', 16, cu), ('reg', 16, 4 * cu)) if -(-C // t) <= lim), 'image')
         tiles = -(-C // (4 if kform == 'quad' else 16))
         default_workload = (args.config, C, S, world, dynamic) == (2, 1000, 250, 1, 'batch') and lag is None
         traffic, traffic_src = committed_traffic() if default_workload else (None, None)

@@ -23,7 +23,7 @@ hipError_t launch_mh(const float *img, const FlowShape &s, const LikeSpec &like,
                      hipStream_t st);
 struct MhArgs;
 bool quad_form_eligible(const MhArgs &a, int num_cu);        // nnest_quad.hip
-hipError_t launch_mh_quad(const MhArgs &a, hipStream_t st);  // nnest_quad.hip
+hipError_t launch_mh_quad(const MhArgs &a, int num_cu, hipStream_t st);  // nnest_quad.hip
 hipError_t launch_loglike(const LikeSpec &like, const float *x, double *logl, int N, int D, int num_cu, hipStream_t st);
 hipError_t launch_fill_noise(float *dz, float *u, int steps, int C, int D, uint64_t seed, uint64_t walker_offset,
                              hipStream_t st);

@@ -675,7 +675,7 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
     const int form = mh_flag_form(a.flags);
     const bool batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;
     if (batch && !a.sync) return hipErrorInvalidValue;
-    if ((form == MH_FORM_AUTO || form == MH_FORM_QUAD || form == MH_FORM_QUAD1) && quad_form_eligible(a, num_cu)) return launch_mh_quad(a, st);
+    if ((form == MH_FORM_AUTO || form == MH_FORM_QUAD || form == MH_FORM_QUAD1) && quad_form_eligible(a, num_cu)) return launch_mh_quad(a, num_cu, st);
     if (form == MH_FORM_QUAD || form == MH_FORM_QUAD1) return hipErrorInvalidConfiguration;
     if constexpr (LT == 1 && NH == 1) {
         if ((form == MH_FORM_AUTO || form == MH_FORM_TEAM) && a.s.B == 3 && ntiles <= num_cu && !a.noise_dz && a.s.scale_mode != 2) {  // fewer tiles than CUs: three waves per tile (team form)

@@ -651,7 +651,11 @@ bool quad_form_eligible(const MhArgs &a, int num_cu) {
     if (s.H != 16 || s.B != 3 || s.L != 1 || s.scale_mode != 0 || s.NT < 1 || s.NT > 4) return false;
     if ((a.flags & NNEST_MH_DYNAMIC_STEP) && !(a.flags & NNEST_MH_DYNAMIC_BATCH)) return false;  // the per-16-walker rule belongs to the 16-walker forms
     const int ntiles = (a.C + 3) / 4;
-    return ntiles <= num_cu;
+    // one tile per CU; two where two workgroups fit a CU's LDS (packed weights + ~14 KB each) -- both resident, which the
+    // batch-wide step rule needs (244 VGPRs: two waves per SIMD)
+    const size_t lds = (size_t)s.nets_params() * sizeof(float) + 16 * 1024;
+    const int per_cu = 2 * lds <= 160 * 1024 ? 2 : 1;
+    return ntiles + 1 <= per_cu * num_cu;
 }
 
 template <int U, bool DBG, bool TEAM>
@@ -667,19 +671,22 @@ static hipError_t launch_quad_k(const MhArgs &a, hipStream_t st) {
 }
 
 template <int U>
-static hipError_t launch_quad_u(const MhArgs &a, hipStream_t st) {
+static hipError_t launch_quad_u(const MhArgs &a, int num_cu, hipStream_t st) {
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
-    const bool team = mh_flag_form(a.flags) != MH_FORM_QUAD1;  // scale / translate nets on two waves unless pinned otherwise
+    // one tile per CU: scale / translate nets on two waves (+ the noise wave).  Two tiles per CU: both nets on one wave, so that
+    // the four waves of a CU's two tiles have a SIMD each (measured at 2000 walkers: 0.60 ms against 0.68 with three waves
+    // per tile and 0.76 for the 16-walker team form).  The two schedules produce the same bits.
+    const bool team = mh_flag_form(a.flags) != MH_FORM_QUAD1 && (a.C + 3) / 4 <= num_cu;
     if (team) return dbg ? launch_quad_k<U, true, true>(a, st) : launch_quad_k<U, false, true>(a, st);
     return dbg ? launch_quad_k<U, true, false>(a, st) : launch_quad_k<U, false, false>(a, st);
 }
 
-hipError_t launch_mh_quad(const MhArgs &a, hipStream_t st) {
+hipError_t launch_mh_quad(const MhArgs &a, int num_cu, hipStream_t st) {
     switch (a.s.NT) {
-        case 1: return launch_quad_u<1>(a, st);
-        case 2: return launch_quad_u<2>(a, st);
-        case 3: return launch_quad_u<3>(a, st);
-        case 4: return launch_quad_u<4>(a, st);
+        case 1: return launch_quad_u<1>(a, num_cu, st);
+        case 2: return launch_quad_u<2>(a, num_cu, st);
+        case 3: return launch_quad_u<3>(a, num_cu, st);
+        case 4: return launch_quad_u<4>(a, num_cu, st);
     }
     return hipErrorInvalidConfiguration;
 }

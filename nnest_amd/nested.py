@@ -159,7 +159,9 @@ class NestedSampler(Sampler):
         from . import _lib
         cu = getattr(self, '_num_cu', None) or _lib.device_info()['num_cu']
         self._num_cu = cu
-        for form, tile, lim in (('quad', 4, cu), ('team', 16, cu), ('reg', 16, 4 * cu)):
+        netG = self.trainer.netG
+        two = 2 * (4 * getattr(netG, 'num_params', 1 << 30) + 16384) <= 160 * 1024   # two quad workgroups per CU (nnest_quad.hip)
+        for form, tile, lim in (('quad', 4, (2 if two else 1) * cu - 1), ('team', 16, cu), ('reg', 16, 4 * cu)):
             if -(-C // tile) <= lim:
                 return form
         return 'image'

@@ -38,7 +38,7 @@ def trained(hip, D=50):
     return nvp, orc.NVP(D, 16, 3, 1, w), g
 
 
-@pytest.mark.parametrize('C,S', [(1000, 30), (37, 25), (3, 40), (1024, 4)])
+@pytest.mark.parametrize('C,S', [(1000, 30), (37, 25), (3, 40), (1024, 4), (2000, 12)])   # 2000: two tiles per CU, both nets on one wave
 def test_quad_inkernel_noise_vs_oracle_per_walker(hip, C, S):
     """Fixed step size: walkers are independent, so every walker's chain is replayed through the oracle on the kernel's own
     noise (nnest_mh_fill_noise).  A walker whose accept/call counts differ took a borderline decision the other way
@@ -101,7 +101,7 @@ def test_quad_shapes_and_likelihoods_vs_oracle(hip, D, like, scale):
     assert torch.equal(res['n_call'], res['n_accept'])
 
 
-@pytest.mark.parametrize('C,form,lag', [(1000, 'quad', 0), (1000, 'quad', 2), (333, 'quad', 1), (2000, 'team', 2),
+@pytest.mark.parametrize('C,form,lag', [(1000, 'quad', 0), (1000, 'quad', 2), (333, 'quad', 1), (2000, 'quad', 4), (2000, 'team', 2),
                                         (2000, 'team', 0), (4800, 'reg', 3)])
 def test_batch_wide_step_rule_vs_oracle(hip, C, form, lag):
     """NNEST_MH_DYNAMIC_BATCH: the accept count is taken over the WHOLE launch (the reference's rule at lag 0; with lag L
@@ -155,7 +155,7 @@ def test_pinned_form_makes_shards_reproduce_the_full_batch(hip):
     """Fixed step: a shard [a, b) launched with walker_offset = a and the form of the full batch pinned equals the slice
     of the full launch bit for bit -- also when the shard alone would have been given another form."""
     nvp, o, g = trained(hip)
-    C = 2048  # 128 tiles of 16: the full batch runs the team form (the quad form stops at 4 x CUs walkers)
+    C = 3072  # 192 tiles of 16: the full batch runs the team form (the quad form stops at two 4-walker tiles per CU)
     init = g['init'][np.arange(C) % g['init'].shape[0]]
     init_logl = orc.loglike('rosenbrock', init, 5.0)
 
