@@ -1,17 +1,21 @@
 // nnest_spline_train.hip -- Trainer.train for the neural-spline flow (reference nnest/trainer.py:134-245, :384-418 on
 // SingleSpeedSpline, networks.py:393-715).
 //
-// Per minibatch (<= 128 rows), all on the device:
+// The gradient of a batch (nnest_spline_loss_grad / _vjp and, for x_dim > 64, the training loop), all on the device:
 //   1 spl_assemble_kernel   W = P (tril(L,-1)+I) (triu(U,1)+diag(S)) per block (networks.py:640-645)
 //   2 spl_timage_kernel     MFMA fragment images of W, W^T and of both conditioners (forward and transposed)
-//   3 spl_grad_kernel       one wave per 16 rows: forward (block inputs stashed), loss, hand-written backward one block
-//                           at a time (spline_train_tile.h); per-wave partial gradients, no atomics
+//   3 spl_grad_kernel       four waves per 16 rows: forward (block inputs stashed), loss, hand-written backward one block
+//                           at a time (spline_train_tile.h); per-tile partial gradients, no atomics; the rows' dLoss/d(raw
+//                           spline parameters) and last hidden activations go to memory
+//   3b spl_w3_kernel        the conditioners' last-layer weight gradients as one contraction over ALL rows
 //   4 spl_reduce_kernel     fixed-order sum of the partials (+ the constant log-det terms of ActNorm / conv)
 //   5 spl_lu_grad_kernel    dLoss/dW -> dLoss/d(L, S, U)
 //   6 spl_adam_kernel       torch.optim.Adam with coupled weight decay (trainer.py:121-122)
-// Per epoch one forward-only launch of (3) gives the validation loss; the host reads back the epoch's losses (one
-// small copy) and keeps the reference's early-stopping bookkeeping (trainer.py:198-241).  ActNorm's data-dependent
-// initialisation (networks.py:698-705) runs as spl_init_kernel on the first batch pushed forward through a fresh flow.
+// The training loop at x_dim <= 64 is two launches per minibatch: (3) and spl_update_kernel = 3b + 4 + 5 + 6 + the images kept
+// current through position maps; the validation pass of an epoch (forward-only tiles of (3)) rides along with the first
+// gradient launch of the next epoch, and the early-stopping bookkeeping (trainer.py:198-241) is a one-workgroup kernel after
+// it, so the host queues epochs without draining the stream.  ActNorm's data-dependent initialisation (networks.py:698-705)
+// runs as spl_init_kernel on the first batch pushed forward through a fresh flow.
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -39,6 +43,7 @@ static SplTrainShape make_train_shape(const SplineShape &s) {
     t.p_f[0] = t.p_U + D * D;
     t.p_f[1] = t.p_f[0] + spline_mlp_params(s.nl, SPL_P * s.nu, s.H);
     t.gw_floats = s.num_params + s.B * D * D + 4;
+    t.SM = s.SU > s.SL ? s.SU : s.SL;
     return t;
 }
 
@@ -147,7 +152,7 @@ __device__ inline float cond_bwd_value(const SplineShape &s, const float *p, int
 
 // Position maps packed conditioner parameter -> its element of the forward / transposed image (every such parameter occurs
 // at most once in each; -1 = not in that image, e.g. the biases in the transposed one), built once per flow: with them the
-// Adam kernel of the training loop keeps the image current (spl_adam_image_kernel) instead of a rebuild per minibatch.
+// update kernel of the training loop keeps the image current (spl_update_kernel) instead of a rebuild per minibatch.
 __global__ void spl_build_pos_kernel(int *__restrict__ pos_f, int *__restrict__ pos_b, int *__restrict__ conv_src, SplTrainShape ts) {
     const SplineShape &s = ts.s;
     const long total = (long)ts.timage_floats;
@@ -234,6 +239,11 @@ struct SplGradArgs {
     float *gx;          // VJP: gradient wrt the input rows [M, D]
     float gld_in;       // VJP: dL/d(logdet)
     const int *stop;    // early-stopping flag (see spl_assemble_kernel) or NULL
+    float *gbuf;        // [B][2][SM][SPL_QT][tiles][64] f32x4: dLoss/d(raw spline parameters) of every row, per coupling
+    float *hbuf;        // [B][2][tiles][NH][64] f32x4: the conditioners' last hidden activations (spl_w3_item contracts the two)
+    int val_tiles;      // training loop: workgroups past the batch's own tiles run the forward-only pass over the validation rows
+    const float *xv;    //   (the previous epoch's validation loss, trainer.py:405-418, in the shadow of this minibatch's gradient pass)
+    int Mv;
     int rows_per_tile;  // 16, 8 or 4: a minibatch is only 100 rows, so the tiles are made shallower to spread them over
                         // more waves / CUs (the matrix-core columns of the unused walkers idle; the launch is latency-bound)
 };
@@ -302,7 +312,17 @@ template <int NTh, int NH, int TEAM>
 __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const float *__restrict__ cf, const float *__restrict__ cbw, int pnet,
                                                  int nin, int nout, int S, int lane, bool row_ok, float gld, float *lds17, float *gp,
                                                  const f32x4 (&cond)[NTh], const f32x4 (&x_tr)[NTh], f32x4 (&g_tr)[NTh], f32x4 (&g_cond)[NTh],
-                                                 int wv, f32x4 *xch) {
+                                                 int wv, f32x4 *xch, f32x4 *__restrict__ gq, f32x4 *__restrict__ hq, int item_stride
+#ifdef NNEST_STAMP
+                                                 , long long *cst
+#endif
+                                                 ) {
+#ifdef NNEST_STAMP
+    long long c_a = wall_clock64();
+#define CB_STAMP(i) { const long long c_n = wall_clock64(); cst[i] += c_n - c_a; c_a = c_n; }
+#else
+#define CB_STAMP(i)
+#endif
     const int g = lane >> 4, w = lane & 15, H = ts.s.H;
     const float tail = ts.s.tail;
     f32x4 h[3][NH];
@@ -313,12 +333,19 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
     // packed offsets of this conditioner's parameters
     const int pW0 = pnet, pb0 = pW0 + H * nin, pW1 = pb0 + H, pb1 = pW1 + H * H, pW2 = pb1 + H, pb2 = pW2 + H * H, pW3 = pb2 + H,
               pb3 = pW3 + SPL_P * nout * H;
-    float hT[3][NH][4];  // activations transposed for the weight-gradient contractions
+    float hT[2][NH][4];  // activations transposed for the weight-gradient contractions
 #pragma unroll
-    for (int l = 0; l < 3; ++l) tile_transpose_batch<NH>(lds17, lane, h[l], hT[l]);
+    for (int l = 0; l < 2; ++l) tile_transpose_batch<NH>(lds17, lane, h[l], hT[l]);
+    // The last layer's weight gradients dW3 = G^T h3 are NOT contracted here, tile by tile on the critical path (they were half of
+    // this function's time): the rows' G (below) and h3 go to memory and spl_w3_item contracts them over ALL rows of the batch.
+    if (TEAM == 1 || wv == TEAM - 1) {
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) hq[ht * 64 + lane] = row_ok ? h[2][ht] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     f32x4 g_h[NH];
 #pragma unroll
     for (int ht = 0; ht < NH; ++ht) g_h[ht] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    CB_STAMP(0)
 #pragma unroll
     for (int s = 0; s < 4 * NTh; ++s) {
         if (s < S && (TEAM == 1 || (s & (TEAM - 1)) == wv)) {
@@ -333,28 +360,8 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
 #pragma unroll
             for (int q = 0; q < SPL_QT; ++q) {
                 if (!valid) graw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                // last layer: dW3 = G^T h3 (rows contracted), db3 = sum over rows, g_h3 += W3^T G
-                float gT[4];
-                tile_transpose(lds17, lane, graw[q], gT);
-#pragma unroll
-                for (int hto = 0; hto < NH; ++hto) {
-                    const f32x4 dW = contract16(gT, hT[2][hto]);  // lane (g,j) reg r: feature (dim 4s+g, param 4q+r) x hidden 16hto+j
-                    const float dv[4] = {dW.x, dW.y, dW.z, dW.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int jo = 4 * s + g, pp = 4 * q + r;
-                        if (jo < nout && pp < SPL_P) gp[pW3 + (jo * SPL_P + pp) * H + 16 * hto + w] = dv[r];
-                    }
-                }
-                const f32x4 db = rows_sum(graw[q]);
-                if (w == 0) {
-                    const float dv[4] = {db.x, db.y, db.z, db.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int jo = 4 * s + g, pp = 4 * q + r;
-                        if (jo < nout && pp < SPL_P) gp[pb3 + jo * SPL_P + pp] = dv[r];
-                    }
-                }
+                // last layer: G to memory (dW3, db3: spl_w3_item), g_h3 += W3^T G
+                gq[(size_t)(s * SPL_QT + q) * item_stride + lane] = graw[q];
 #pragma unroll
                 for (int hto = 0; hto < NH; ++hto) {
                     const float *a = B4 + (size_t)(((s * SPL_QT + q) * NH + hto) * 4) * 64 + lane;
@@ -366,6 +373,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
             }
         }
     }
+    CB_STAMP(1)
     if (TEAM > 1) {  // merge the transformed-half gradients (register r of tile t from wave (4t + r) mod TEAM) and sum g_h3
 #pragma unroll
         for (int t = 0; t < NTh; ++t) xch[(wv * NTh + t) * 64 + lane] = g_tr[t];
@@ -385,10 +393,11 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
         }
         __syncthreads();
     }
+    CB_STAMP(2)
     // hidden layers 3 and 2 (W2 over h[1], W1 over h[0])
 #pragma unroll
     for (int l = 2; l >= 1; --l) {
-        const bool mine = TEAM == 1 || wv == (l == 2 ? 0 : 1);  // this layer's weight gradients are this wave's to write
+        const bool mine = TEAM == 1 || wv == TEAM - 1;  // the trunk's weight gradients: the last wave's (it has the short share of the super-tiles)
         const float *Bl = l == 2 ? B3 : B2;
         const int pW = l == 2 ? pW2 : pW1, pb = l == 2 ? pb2 : pb1;
         f32x4 g_pre[NH], g_prev[NH];
@@ -433,7 +442,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
     }
     // first layer: W0 over the conditioning half
     {
-        const bool mine = TEAM == 1 || wv == 2;
+        const bool mine = TEAM == 1 || wv == TEAM - 1;
         f32x4 g_pre[NH];
         float gT[NH][4];
 #pragma unroll
@@ -477,6 +486,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
             g_cond[t] = g_cond[t] + acc;
         }
     }
+    CB_STAMP(3)
 }
 
 // One workgroup of SPL_TEAM waves per 16-row tile.  Every wave carries the tile's rows; the spline work (the bulk of the
@@ -497,8 +507,11 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     float *lds17 = buf + 16 * (D + 1);           // SPL_TBATCH x 16 x 17: tile transposes (per wave)
     f32x4 *xch = reinterpret_cast<f32x4 *>(lds + (size_t)TEAM * per_wave);  // [TEAM][NTh + NH][64]
     float *ldred = reinterpret_cast<float *>(xch + TEAM * (NTh + NH) * 64);  // [TEAM][16]
-    const int row = tile * a.rows_per_tile + w;
-    const bool ok = w < a.rows_per_tile && row < a.M;
+    const int ntl = (int)gridDim.x - a.val_tiles;  // the batch's own tiles
+    const bool vtile = tile >= ntl;
+    const int mode = vtile ? (int)SPL_MODE_LOSS : a.mode;
+    const int row = (vtile ? tile - ntl : tile) * a.rows_per_tile + w;
+    const bool ok = w < a.rows_per_tile && row < (vtile ? a.Mv : a.M);
     float *gp = a.partial + (size_t)tile * ts.gw_floats;
     f32x4 *stash = reinterpret_cast<f32x4 *>(a.stash) + ((size_t)tile * TEAM + wv) * B * 3 * NTh * 64;  // per block: input halves + upper'
 
@@ -525,9 +538,9 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     // data = X[perm] + jitter * randn  (trainer.py:392)
     f32x4 xp[2][NTh], xs[2][NTh];
     long src = 0;
-    if (ok) src = a.perm ? a.perm[row] : row;
-    load_tile<NTh>(a.x, src, ok, D, lane, xp);
-    if (a.mode == SPL_MODE_GRAD && a.jitter != 0.f) {
+    if (ok) src = (a.perm && !vtile) ? a.perm[row] : row;
+    load_tile<NTh>(vtile ? a.xv : a.x, src, ok, D, lane, xp);
+    if (mode == SPL_MODE_GRAD && a.jitter != 0.f) {
         if (a.noise) {
             f32x4 nz[2][NTh];
             load_tile<NTh>(a.noise, row, ok, D, lane, nz);
@@ -553,7 +566,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     }
     spl_from_parity<NTh>(buf, D, s.nl, lane, xp, xs);
 #ifdef NNEST_STAMP
-    long long st_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_0 = wall_clock64(), st_a;
+    long long st_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_0 = wall_clock64(), st_a, cb_t[4] = {0, 0, 0, 0};
 #define SPL_STAMP(i) { const long long st_n = wall_clock64(); st_t[i] += st_n - st_a; st_a = st_n; }
     st_a = st_0;
 #else
@@ -568,7 +581,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         const int lane = lane_o;
         const float *blk = a.timg + (size_t)b * ts.tblk_floats;
         const float *pb = a.w + (size_t)b * s.blk_params;
-        if (a.mode != SPL_MODE_LOSS) {
+        if (mode != SPL_MODE_LOSS) {
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -583,7 +596,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         spl_matmul<NTh>(blk, lane, av, c);
         const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
         ld += spl_coupling<NTh, NH, false, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch);
-        if (a.mode != SPL_MODE_LOSS) {  // upper' conditions the second coupling: kept for the backward pass
+        if (mode != SPL_MODE_LOSS) {  // upper' conditions the second coupling: kept for the backward pass
 #pragma unroll
             for (int t = 0; t < NTh; ++t) stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
         }
@@ -613,13 +626,13 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) lp += __shfl_xor(lp, o);
     if (lane == 0 && wv == 0) gp[ts.gw_floats - 4] = lp;  // sum of log_probs over this tile's rows
-    if (a.mode == SPL_MODE_LOSS) return;
+    if (mode == SPL_MODE_LOSS) return;
     SPL_STAMP(0)
 
     // ---- backward: loss = -mean(log_probs)  (trainer.py:394) ---------------------------------------------------------
-    const float invM = 1.0f / (float)a.mtot, gld = a.mode == SPL_MODE_VJP ? a.gld_in : -invM;
+    const float invM = 1.0f / (float)a.mtot, gld = mode == SPL_MODE_VJP ? a.gld_in : -invM;
     f32x4 gs[2][NTh];
-    if (a.mode == SPL_MODE_VJP) {
+    if (mode == SPL_MODE_VJP) {
         f32x4 gp4[2][NTh];
         load_tile<NTh>(a.gz, row, ok, D, lane, gp4);
         spl_from_parity<NTh>(buf, D, s.nl, lane, gp4, gs);
@@ -657,10 +670,23 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         for (int t = 0; t < NTh; ++t) up2[t] = stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane];
         // second coupling: lower' = RQS(lower; f2(upper'))   (networks.py:589-598)
         SPL_STAMP(1)
-        spl_coupling_bwd<NTh, NH, TEAM>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch);
+        const int item_stride = ntl * 64;
+        f32x4 *gq2 = reinterpret_cast<f32x4 *>(a.gbuf) + ((size_t)(2 * b + 1) * ts.SM * SPL_QT * ntl + tile) * 64;
+        f32x4 *gq1 = reinterpret_cast<f32x4 *>(a.gbuf) + ((size_t)(2 * b + 0) * ts.SM * SPL_QT * ntl + tile) * 64;
+        f32x4 *hq2 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 1) * ntl + tile) * NH * 64;
+        f32x4 *hq1 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 0) * ntl + tile) * NH * 64;
+        spl_coupling_bwd<NTh, NH, TEAM>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch, gq2, hq2, item_stride
+#ifdef NNEST_STAMP
+            , cb_t
+#endif
+            );
         SPL_STAMP(2)
         // first coupling: upper' = RQS(upper; f1(lower))      (networks.py:582-588)
-        spl_coupling_bwd<NTh, NH, TEAM>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch);
+        spl_coupling_bwd<NTh, NH, TEAM>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch, gq1, hq1, item_stride
+#ifdef NNEST_STAMP
+            , cb_t
+#endif
+            );
         SPL_STAMP(3)
         // 1x1 conv c = a W: dLoss/dW[i][o] = sum_rows a[i] g_c[o];  g_a = g_c W^T
         {
@@ -719,12 +745,102 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     if (tile == 0 && lane == 0)
         printf("spl_grad wave %d: fwd %lld | stash+actnorm %lld matmul %lld | c2_bwd %lld c1_bwd %lld | transposes %lld dW %lld matmulT %lld actnorm %lld (x10 ns)\n", wv,
                st_t[0], st_t[5], st_t[1], st_t[2], st_t[3], st_t[6], st_t[7], st_t[8], st_t[4]);
+    if (tile == 0 && lane == 0)
+        printf("   couplings (6) wave %d: trunk+transposes %lld | super-tiles %lld | merge %lld | trunk backward %lld (x10 ns)\n", wv, cb_t[0], cb_t[1], cb_t[2], cb_t[3]);
 #endif
-    if (a.mode == SPL_MODE_VJP) {
+    if (mode == SPL_MODE_VJP) {
         f32x4 gp4[2][NTh];
         spl_to_parity<NTh>(buf, D, s.nl, lane, gs, gp4);
         if (wv == 0) store_tile<NTh>(a.gx, row, ok, D, lane, gp4);
     }
+}
+
+// ---- 3b: last-layer weight gradients of the conditioners, one GEMM over ALL rows of the batch ---------------------------------
+// Item (coupling, super-tile s, parameter tile q): dW3[(dim 4s+g, param 4q+r)][hidden j] = sum over rows G[row][(g, r)] h3[row][j]
+// and db3 = sum over rows G.  A = G^T and B = h3 are read straight in operand layout from the tiles' stores (lane (i, kk) of
+// k-step m of tile T: row 4m + kk); one wave per item, 4 NH matrix instructions per 16 rows.
+// Result: dW[hto] lane (g, j) reg r <-> packed index pW3 + ((4s+g) 23 + 4q+r) H + 16 hto + j; db (every lane) feature lane & 15.
+template <int NH>
+__device__ __forceinline__ void spl_w3_item(const float *__restrict__ gq_item /* [tiles][64][4] */, const float *__restrict__ hq /* [tiles][NH][64][4] */,
+                                            int tiles, int lane, f32x4 (&dW)[NH], float &db) {
+    const int i = lane & 15, kk = lane >> 4;
+    const int offA = ((i >> 2) * 16 + kk) * 4 + (i & 3);  // + 16 m + 256 T
+#pragma unroll
+    for (int ht = 0; ht < NH; ++ht) dW[ht] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float dsum = 0.f;
+    for (int T0 = 0; T0 < tiles; T0 += 4) {  // 16 + 16 NH loads in flight per round
+        float av[4][4], bv[4][NH][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int T = T0 + u < tiles ? T0 + u : tiles - 1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                av[u][m] = gq_item[(size_t)T * 256 + offA + 16 * m];
+#pragma unroll
+                for (int ht = 0; ht < NH; ++ht) bv[u][ht][m] = hq[((size_t)T * NH + ht) * 256 + offA + 16 * m];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool live = T0 + u < tiles;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float a = live ? av[u][m] : 0.f;
+                dsum += a;
+#pragma unroll
+                for (int ht = 0; ht < NH; ++ht) dW[ht] = mfma4(a, bv[u][ht][m], dW[ht]);
+            }
+        }
+    }
+    dsum += __shfl_xor(dsum, 16);
+    dsum += __shfl_xor(dsum, 32);
+    db = dsum;
+}
+
+// (coupling index, super-tile, parameter tile) of item `it`, or false
+__device__ __forceinline__ bool spl_w3_decode(const SplTrainShape &ts, int it, int &cidx, int &sidx, int &q) {
+    const int per = ts.SM * SPL_QT;
+    cidx = it / per;
+    const int r = it - cidx * per;
+    sidx = r / SPL_QT; q = r - sidx * SPL_QT;
+    return cidx < 2 * ts.s.B && sidx < ((cidx & 1) ? ts.s.SL : ts.s.SU);
+}
+
+// the gradient-returning entry points (nnest_spline_loss_grad / _vjp): dW3, db3 into `grad`
+template <int NTh, int NH>
+__global__ void __launch_bounds__(256) spl_w3_kernel(SplGradArgs a, int tiles, float *__restrict__ grad) {
+    const SplTrainShape &ts = a.ts;
+    const int lane = threadIdx.x & 63, it = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a.stop && *a.stop) return;
+    int cidx, sidx, q;
+    if (!spl_w3_decode(ts, it, cidx, sidx, q)) return;
+    const int b = cidx >> 1, c = cidx & 1, H = ts.s.H;
+    const int nin = c ? ts.s.nu : ts.s.nl, nout = c ? ts.s.nl : ts.s.nu;
+    const int pW3 = b * ts.s.blk_params + ts.p_f[c] + H * nin + H + 2 * (H * H + H), pb3 = pW3 + SPL_P * nout * H;
+    f32x4 dW[NH];
+    float db;
+    spl_w3_item<NH>(a.gbuf + ((size_t)(cidx * ts.SM + sidx) * SPL_QT + q) * tiles * 256, a.hbuf + (size_t)cidx * tiles * NH * 256, tiles, lane, dW, db);
+    const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int ht = 0; ht < NH; ++ht) {
+        const float dv[4] = {dW[ht].x, dW[ht].y, dW[ht].z, dW[ht].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jo = 4 * sidx + g, pp = 4 * q + r;
+            if (jo < nout && pp < SPL_P) grad[pW3 + (jo * SPL_P + pp) * H + 16 * ht + j] = dv[r];
+        }
+    }
+    if (lane < 16) {
+        const int jo = 4 * sidx + (lane >> 2), pp = 4 * q + (lane & 3);
+        if (jo < nout && pp < SPL_P) grad[pb3 + jo * SPL_P + pp] = db;
+    }
+}
+
+// packed offset o inside a block: one of the conditioners' last-layer parameters (the tail of each conditioner)?
+__host__ __device__ inline bool spl_is_w3(const SplTrainShape &ts, int o) {
+    const int H = ts.s.H;
+    const int t0 = ts.p_f[0] + H * ts.s.nl + H + 2 * (H * H + H), t1 = ts.p_f[1] + H * ts.s.nu + H + 2 * (H * H + H);
+    return (o >= t0 && o < ts.p_f[1]) || o >= t1;
 }
 
 // ---- 4: reduce ------------------------------------------------------------------------------------------------------
@@ -738,6 +854,7 @@ __global__ void spl_reduce_kernel(const float *__restrict__ partial, int tiles, 
         if (i < np) {
             const int o = i % ts.s.blk_params;
             if (o >= ts.p_L && o < ts.p_f[0]) continue;  // L, S, U: from dLoss/dW (spl_lu_grad_kernel)
+            if (spl_is_w3(ts, o)) continue;              // W3, b3 of the conditioners: spl_w3_item
             for (int t = 0; t < tiles; ++t) acc += partial[(size_t)t * n + i];
             if (o < ts.p_t) acc += ldw;  // logdet of ActNorm = sum(s) on every row
             grad[i] = acc;
@@ -813,12 +930,7 @@ __global__ void spl_adam_kernel(float *__restrict__ w, const float *__restrict__
     }
 }
 
-// ---- 6b: Adam with the training image kept current (training loop, shapes with at most two tiles per half) ----------------------
-// Workgroup b < B owns the head of block b -- ActNorm s, t and L, S, U, contiguous in the packed vector -- takes their step,
-// then assembles W = P L (U + diag S) from the new values (staged in LDS), writes it to `wmat`, and from it the two conv
-// fragment images and the block's log-det constant.  The other workgroups step the conditioner parameters and scatter each
-// new value to its elements of the forward / transposed image (spl_build_pos_kernel).  Replaces spl_adam_kernel +
-// spl_assemble_kernel + spl_timage_kernel and two launch gaps per minibatch.
+// one Adam step of one parameter (torch/optim/adam.py _single_tensor_adam, coupled weight decay)
 __device__ __forceinline__ float spl_adam_one(float w, float g, float &m, float &v, float step_size, float inv_bc2s, float wd) {
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     const float gi = g + wd * w;
@@ -827,54 +939,167 @@ __device__ __forceinline__ float spl_adam_one(float w, float g, float &m, float 
     return w - step_size * (m / (sqrtf(v) * inv_bc2s + eps));
 }
 
-__global__ void __launch_bounds__(1024) spl_adam_image_kernel(float *__restrict__ w, const float *__restrict__ grad, float *__restrict__ m,
-                                                              float *__restrict__ v, float step_size, float inv_bc2s, float wd,
-                                                              const int *__restrict__ pos_f, const int *__restrict__ pos_b,
-                                                              const int *__restrict__ conv_src, const int *__restrict__ pi, float *__restrict__ wmat, float *__restrict__ timg,
-                                                              SplTrainShape ts, const int *__restrict__ stop) {
-    if (stop && *stop) return;
-    extern __shared__ float head[];  // [p_f[0]]: the block head after its step
+// ---- 6c: the training loop's whole parameter update in ONE launch per minibatch ------------------------------------------------
+// (was: a reduce, an LU-gradient and an Adam/image kernel -- three launches and their gaps, ~30 us of a 170 us step)
+// Workgroup b < B: the head of block b -- sums the tiles' ActNorm and dLoss/dW partials, takes dLoss/dW to dLoss/d(L, S, U)
+//   (old L, S, U staged in LDS), steps the head, assembles W from the new values and writes the conv images and the log-det
+//   constant.
+// The next `n_w3` workgroups: one wave per (coupling, super-tile, parameter tile) item of the conditioners' last layers: dW3,
+//   db3 as one contraction over all rows of the batch (spl_w3_item), stepped in registers and scattered to the images.
+// The rest: the conditioners' trunks -- sum of the tiles' partials, step, scatter.
+struct SplUpdateArgs {
+    float *w, *m, *v;
+    const float *partial;
+    int tiles;
+    const float *gbuf, *hbuf;
+    const int *pos_f, *pos_b, *conv_src, *pi, *pi_inv;
+    float *wmat, *timg;
+    SplTrainShape ts;
+    float step_size, inv_bc2s, wd, ldw;
+    float *loss_out;
+    float loss_scale;
+    const int *stop;
+    int n_w3;
+};
+
+// sum over the tiles' slices of one workspace element, in tile order; eight loads in flight (a load round trip per tile made
+// the sums the longest part of the update)
+__device__ __forceinline__ float spl_sum_tiles(const float *__restrict__ p, size_t stride, int tiles) {
+    float acc = 0.f;
+    for (int t0 = 0; t0 < tiles; t0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(t0 + u < tiles ? t0 + u : tiles - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t0 + u < tiles ? v[u] : 0.f;
+    }
+    return acc;
+}
+
+__device__ __forceinline__ int spi_of(const int *__restrict__ pi, int b, int D, int i) { return pi[b * D + i]; }
+
+struct SplAdamScatter {
+    float *w, *m, *v, *timg;
+    const int *pos_f, *pos_b;
+    float step_size, inv_bc2s, wd;
+    __device__ __forceinline__ void operator()(int p, float g) const {
+        float mi = m[p], vi = v[p];
+        const float wn = spl_adam_one(w[p], g, mi, vi, step_size, inv_bc2s, wd);
+        m[p] = mi; v[p] = vi; w[p] = wn;
+        const int pf = pos_f[p], pb = pos_b[p];
+        if (pf >= 0) timg[pf] = wn;
+        if (pb >= 0) timg[pb] = wn;
+    }
+};
+
+template <int NTh, int NH>
+__global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
+    if (a.stop && *a.stop) return;
+    extern __shared__ float ulds[];
+    const SplTrainShape &ts = a.ts;
     const SplineShape &s = ts.s;
-    const int D = s.D, B = s.B, np = s.num_params, nhead = ts.p_f[0];
+    const int D = s.D, B = s.B, np = s.num_params, nhead = ts.p_f[0], n = ts.gw_floats, tid = threadIdx.x;
     if ((int)blockIdx.x < B) {
         const int b = blockIdx.x, base = b * s.blk_params;
-#pragma unroll 3
-        for (int i = threadIdx.x; i < nhead; i += blockDim.x) {
-            float mi = m[base + i], vi = v[base + i];
-            const float wn = spl_adam_one(w[base + i], grad[base + i], mi, vi, step_size, inv_bc2s, wd);
-            m[base + i] = mi; v[base + i] = vi; w[base + i] = wn;
-            head[i] = wn;
-        }
+        float *hold = ulds, *hnew = ulds + nhead, *gws = hnew + nhead;  // old head, new head, summed dLoss/dW (later W)
+        int *spi = reinterpret_cast<int *>(gws + D * D), *spi_inv = spi + D;
+        for (int i = tid; i < nhead; i += blockDim.x) hold[i] = a.w[base + i];
+        for (int i = tid; i < D; i += blockDim.x) { spi[i] = a.pi[b * D + i]; spi_inv[i] = a.pi_inv[b * D + i]; }
+        // dLoss/dW summed over the tiles, rows permuted as P does: gws[pi(i)][j] = gW[i][j]
+        for (int idx = tid; idx < D * D; idx += blockDim.x)
+            gws[spi_of(a.pi, b, D, idx / D) * D + idx % D] = spl_sum_tiles(a.partial + np + b * D * D + idx, n, a.tiles);
         __syncthreads();
-        float *Wm = wmat + (size_t)b * D * D;
-        for (int idx = threadIdx.x; idx < D * D; idx += blockDim.x)
-            Wm[idx] = spl_w_entry(head + ts.p_L, head + ts.p_S, head + ts.p_U, pi[b * D + idx / D], idx % D, D);
-        __syncthreads();  // (the block's own global writes are visible to it after the barrier)
-        float *blk = timg + (size_t)b * ts.tblk_floats;
-#pragma unroll 4
-        for (int o = threadIdx.x; o < 2 * ts.conv_floats; o += blockDim.x) {  // the conv fragment images, through the source table
-            const int src = conv_src[o];
-            blk[o] = src >= 0 ? Wm[src] : 0.f;
-        }
-        // log|det| of ActNorm + conv (networks.py:650, :676): the terms in parallel, summed in spl_timage_kernel's order
-        for (int d = threadIdx.x; d < D; d += blockDim.x) head[d] = head[ts.p_s + d] + logf(fabsf(head[ts.p_S + d]));  // (p_s = 0: in place)
-        __syncthreads();
-        if (threadIdx.x == 0) {
+        const float *Lp = hold + ts.p_L, *Sp = hold + ts.p_S, *Up = hold + ts.p_U;
+        for (int i = tid; i < nhead; i += blockDim.x) {
             float acc = 0.f;
-            for (int d = 0; d < D; ++d) acc += head[d];
+            if (i < ts.p_L) {  // ActNorm s, t: the tiles' partials (+ the log-det term of s on every row)
+                acc = spl_sum_tiles(a.partial + base + i, n, a.tiles);
+                if (i < ts.p_t) acc += a.ldw;
+            } else if (i < ts.p_S) {  // dLoss/dL[r][k] = sum_{j >= k} gW[pi^-1(r)][j] Um[k][j]  (k < r), Um[k][k] = S[k]
+                const int o = i - ts.p_L, r = o / D, k = o % D;
+                if (k < r) {
+                    acc = gws[r * D + k] * Sp[k];
+#pragma unroll 4
+                    for (int j = k + 1; j < D; ++j) acc += gws[r * D + j] * Up[k * D + j];
+                }
+            } else {  // S[k] (the diagonal, + the conv's log-det term) or Um[k][j], k < j: sum_{r >= k} gW[pi^-1(r)][j] Lm[r][k], Lm[k][k] = 1
+                const bool diag = i < ts.p_U;
+                const int o = i - ts.p_U, k = diag ? i - ts.p_S : o / D, j = diag ? k : o % D;
+                if (diag || k < j) {
+                    acc = gws[k * D + j];
+#pragma unroll 4
+                    for (int r = k + 1; r < D; ++r) acc += gws[r * D + j] * Lp[r * D + k];
+                    if (diag) acc += a.ldw / Sp[k];
+                }
+            }
+            float mi = a.m[base + i], vi = a.v[base + i];
+            const float wn = spl_adam_one(hold[i], acc, mi, vi, a.step_size, a.inv_bc2s, a.wd);
+            a.m[base + i] = mi; a.v[base + i] = vi; a.w[base + i] = wn;
+            hnew[i] = wn;
+        }
+        __syncthreads();
+        float *Wm = a.wmat + (size_t)b * D * D;
+        for (int idx = tid; idx < D * D; idx += blockDim.x) {
+            const float wv = spl_w_entry(hnew + ts.p_L, hnew + ts.p_S, hnew + ts.p_U, spi[idx / D], idx % D, D);
+            Wm[idx] = wv;
+            gws[idx] = wv;
+        }
+        __syncthreads();
+        float *blk = a.timg + (size_t)b * ts.tblk_floats;
+#pragma unroll 4
+        for (int o = tid; o < 2 * ts.conv_floats; o += blockDim.x) {
+            const int src = a.conv_src[o];
+            blk[o] = src >= 0 ? gws[src] : 0.f;
+        }
+        for (int d = tid; d < D; d += blockDim.x) hold[d] = hnew[ts.p_s + d] + logf(fabsf(hnew[ts.p_S + d]));
+        __syncthreads();
+        if (tid == 0) {
+            float acc = 0.f;
+            for (int d = 0; d < D; ++d) acc += hold[d];
             blk[ts.tblk_floats - 4] = acc;
         }
         return;
     }
-    const int nw = gridDim.x - B;
-    for (int i = (blockIdx.x - B) * blockDim.x + threadIdx.x; i < np; i += nw * blockDim.x) {
-        if (i % s.blk_params < nhead) continue;
-        float mi = m[i], vi = v[i];
-        const float wn = spl_adam_one(w[i], grad[i], mi, vi, step_size, inv_bc2s, wd);
-        m[i] = mi; v[i] = vi; w[i] = wn;
-        const int pf = pos_f[i], pb = pos_b[i];
-        if (pf >= 0) timg[pf] = wn;
-        if (pb >= 0) timg[pb] = wn;
+    const SplAdamScatter step = {a.w, a.m, a.v, a.timg, a.pos_f, a.pos_b, a.step_size, a.inv_bc2s, a.wd};
+    const int H = s.H;
+    if ((int)blockIdx.x < B + a.n_w3) {
+        const int lane = tid & 63, it = ((int)blockIdx.x - B) * (int)(blockDim.x >> 6) + (tid >> 6);
+        int cidx, sidx, q;
+        if (!spl_w3_decode(ts, it, cidx, sidx, q)) return;
+        const int b = cidx >> 1, c = cidx & 1;
+        const int nin = c ? s.nu : s.nl, nout = c ? s.nl : s.nu;
+        const int pW3 = b * s.blk_params + ts.p_f[c] + H * nin + H + 2 * (H * H + H), pb3 = pW3 + SPL_P * nout * H;
+        f32x4 dW[NH];
+        float db;
+        spl_w3_item<NH>(a.gbuf + ((size_t)(cidx * ts.SM + sidx) * SPL_QT + q) * a.tiles * 256, a.hbuf + (size_t)cidx * a.tiles * NH * 256, a.tiles, lane, dW, db);
+        const int g = lane >> 4, j = lane & 15;
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) {
+            const float dv[4] = {dW[ht].x, dW[ht].y, dW[ht].z, dW[ht].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jo = 4 * sidx + g, pp = 4 * q + r;
+                if (jo < nout && pp < SPL_P) step(pW3 + (jo * SPL_P + pp) * H + 16 * ht + j, dv[r]);
+            }
+        }
+        if (lane < 16) {
+            const int jo = 4 * sidx + (lane >> 2), pp = 4 * q + (lane & 3);
+            if (jo < nout && pp < SPL_P) step(pb3 + jo * SPL_P + pp, db);
+        }
+        return;
+    }
+    // the trunks: W0, b0, W1, b1, W2, b2 of both conditioners of every block
+    const int tr0 = H * s.nl + H + 2 * (H * H + H), tr1 = H * s.nu + H + 2 * (H * H + H), per = tr0 + tr1;
+    const int nw = (int)gridDim.x - B - a.n_w3, first = (int)blockIdx.x - B - a.n_w3;
+    for (int idx = first * (int)blockDim.x + tid; idx < B * per; idx += nw * (int)blockDim.x) {
+        const int b = idx / per, o = idx - b * per;
+        const int p = b * s.blk_params + (o < tr0 ? ts.p_f[0] + o : ts.p_f[1] + (o - tr0));
+        step(p, spl_sum_tiles(a.partial + p, n, a.tiles));
+    }
+    if (first == 0 && tid == 0 && a.loss_out) {
+        float acc = 0.f;
+        for (int t = 0; t < a.tiles; ++t) acc += a.partial[(size_t)t * n + n - 4];
+        *a.loss_out = acc * a.loss_scale;
     }
 }
 
@@ -884,29 +1109,43 @@ struct SplTrainCtl {
     int best_epoch, counter, epochs_run, stopped, improved;
 };
 
-__global__ void spl_epoch_end_kernel(SplTrainCtl *__restrict__ c, const float *__restrict__ losses, int n_mb, int n_train, int n_valid,
-                                     int epoch, int patience, float *__restrict__ epoch_losses) {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || c->stopped) return;
-    float tl = 0.f;
-    for (int mb = 0; mb < n_mb; ++mb) tl += losses[mb];
-    const float train_loss = tl / (float)n_train;            // trainer.py:403
-    const float valid_loss = losses[n_mb] / (float)n_valid;  // trainer.py:418
-    epoch_losses[2 * epoch] = train_loss;
-    epoch_losses[2 * epoch + 1] = valid_loss;
-    c->last_train = train_loss;
-    c->epochs_run = epoch + 1;
-    const int improved = valid_loss < c->best;               // trainer.py:205-209
-    if (improved) { c->best = valid_loss; c->best_epoch = epoch + 1; c->counter = 0; }
-    c->improved = improved;
-    c->counter += 1;                                         // trainer.py:223-232
-    if (c->counter > patience) c->stopped = 1;
-}
-
-// best_model = deepcopy(netG) when the epoch improved the validation loss.  After the stop the weights no longer change and
-// a repeated copy is the same copy.
-__global__ void spl_keep_best_kernel(const SplTrainCtl *__restrict__ c, const float *__restrict__ w, float *__restrict__ best_w, int n) {
-    if (!c->improved) return;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) best_w[i] = w[i];
+// One workgroup: thread 0 keeps the books, then all threads copy the weights if the epoch improved the validation loss
+// (best_model = deepcopy(netG), trainer.py:205-209).  `vpartial` != NULL: the validation loss comes straight from the `vtiles`
+// per-tile sums of the forward-only tiles (their slots of the gradient workspace, stride `gw` floats) instead of losses[n_mb].
+__global__ void __launch_bounds__(1024) spl_epoch_end_kernel(SplTrainCtl *__restrict__ c, const float *__restrict__ losses, int n_mb, int n_train,
+                                                             int n_valid, int epoch, int patience, float *__restrict__ epoch_losses,
+                                                             const float *__restrict__ vpartial, int gw, int vtiles,
+                                                             const float *__restrict__ w, float *__restrict__ best_w, int np) {
+    __shared__ int flag[2];
+    if (threadIdx.x == 0) {
+        flag[0] = c->stopped;
+        flag[1] = 0;
+        if (!flag[0]) {
+            float tl = 0.f;
+            for (int mb = 0; mb < n_mb; ++mb) tl += losses[mb];
+            const float train_loss = tl / (float)n_train;            // trainer.py:403
+            float vmean = losses[n_mb];
+            if (vpartial) {
+                float acc = 0.f;
+                for (int t = 0; t < vtiles; ++t) acc += vpartial[(size_t)t * gw + gw - 4];
+                vmean = acc * (-1.0f / (float)n_valid);
+            }
+            const float valid_loss = vmean / (float)n_valid;         // trainer.py:418
+            epoch_losses[2 * epoch] = train_loss;
+            epoch_losses[2 * epoch + 1] = valid_loss;
+            c->last_train = train_loss;
+            c->epochs_run = epoch + 1;
+            const int improved = valid_loss < c->best;               // trainer.py:205-209
+            if (improved) { c->best = valid_loss; c->best_epoch = epoch + 1; c->counter = 0; }
+            c->improved = improved;
+            c->counter += 1;                                         // trainer.py:223-232
+            if (c->counter > patience) c->stopped = 1;
+            flag[1] = improved;
+        }
+    }
+    __syncthreads();
+    if (flag[0] || !flag[1]) return;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) best_w[i] = w[i];
 }
 
 // ---- ActNorm data-dependent initialisation (networks.py:698-705): one workgroup, rows in tiles of 16 -------------------------
@@ -1017,25 +1256,25 @@ __global__ void __launch_bounds__(512) spl_init_kernel(SplInitArgs a) {
 }
 
 // (above 64 KiB of dynamic LDS a kernel has to be told so once)
-#define SPLT_LAUNCH(K, grid, block, ldsb, st, arg)                                                                    \
+#define SPLT_LAUNCH(K, grid, block, ldsb, st, ...)                                                                    \
     do {                                                                                                              \
         if ((size_t)(ldsb) > 64 * 1024) {                                                                             \
             hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ldsb)); \
             if (e__ != hipSuccess) return e__;                                                                        \
         }                                                                                                             \
-        hipLaunchKernelGGL((K), dim3(grid), dim3(block), ldsb, st, arg);                                              \
+        hipLaunchKernelGGL((K), dim3(grid), dim3(block), ldsb, st, __VA_ARGS__);                                              \
     } while (0)
 
-#define DISPATCH_SPLT(KERNEL, sp, grid, block, ldsb, st, arg)                                                         \
+#define DISPATCH_SPLT(KERNEL, sp, grid, block, ldsb, st, ...)                                                         \
     do {                                                                                                              \
         const int key__ = (sp).NTh * 10 + (sp).NH;                                                                    \
         switch (key__) {                                                                                              \
-            case 11: SPLT_LAUNCH((KERNEL<1, 1>), grid, block, ldsb, st, arg); break;               \
-            case 21: SPLT_LAUNCH((KERNEL<2, 1>), grid, block, ldsb, st, arg); break;               \
-            case 31: SPLT_LAUNCH((KERNEL<3, 1>), grid, block, ldsb, st, arg); break;               \
-            case 41: SPLT_LAUNCH((KERNEL<4, 1>), grid, block, ldsb, st, arg); break;               \
-            case 12: SPLT_LAUNCH((KERNEL<1, 2>), grid, block, ldsb, st, arg); break;               \
-            case 22: SPLT_LAUNCH((KERNEL<2, 2>), grid, block, ldsb, st, arg); break;               \
+            case 11: SPLT_LAUNCH((KERNEL<1, 1>), grid, block, ldsb, st, __VA_ARGS__); break;               \
+            case 21: SPLT_LAUNCH((KERNEL<2, 1>), grid, block, ldsb, st, __VA_ARGS__); break;               \
+            case 31: SPLT_LAUNCH((KERNEL<3, 1>), grid, block, ldsb, st, __VA_ARGS__); break;               \
+            case 41: SPLT_LAUNCH((KERNEL<4, 1>), grid, block, ldsb, st, __VA_ARGS__); break;               \
+            case 12: SPLT_LAUNCH((KERNEL<1, 2>), grid, block, ldsb, st, __VA_ARGS__); break;               \
+            case 22: SPLT_LAUNCH((KERNEL<2, 2>), grid, block, ldsb, st, __VA_ARGS__); break;               \
             default: return hipErrorInvalidConfiguration;                                                             \
         }                                                                                                             \
     } while (0)
@@ -1046,7 +1285,14 @@ static hipError_t launch_grad(const SplGradArgs &a, hipStream_t st) {
     const int tiles = grad_tiles(a);
     const int per_wave = ((16 * (a.ts.s.D + 1) + SPL_TBATCH * 16 * 17) + 3) & ~3;
     const size_t ldsb = (size_t)(SPL_TEAM * per_wave + SPL_TEAM * (a.ts.s.NTh + a.ts.s.NH) * 64 * 4 + SPL_TEAM * 16) * sizeof(float);
-    DISPATCH_SPLT(spl_grad_kernel, a.ts.s, tiles, 64 * SPL_TEAM, ldsb, st, a);
+    DISPATCH_SPLT(spl_grad_kernel, a.ts.s, tiles + a.val_tiles, 64 * SPL_TEAM, ldsb, st, a);
+    return hipGetLastError();
+}
+
+// dW3, db3 of every conditioner from the rows' stores of the gradient launch
+static hipError_t launch_w3(const SplGradArgs &a, float *grad, hipStream_t st) {
+    const int items = 2 * a.ts.s.B * a.ts.SM * SPL_QT, tiles = grad_tiles(a);
+    DISPATCH_SPLT(spl_w3_kernel, a.ts.s, (items + 3) / 4, 256, 0, st, a, tiles, grad);
     return hipGetLastError();
 }
 
@@ -1086,9 +1332,11 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
     }
     const int tiles = (max_rows + 15) / 16 > 32 ? (max_rows + 15) / 16 : 32;  // batches of <= 128 rows run 4 rows per tile: 32 tiles
     if (tiles > h->partial_tiles) {
-        if (h->partial) { (void)hipFree(h->partial); (void)hipFree(h->stash); }
+        if (h->partial) { (void)hipFree(h->partial); (void)hipFree(h->stash); (void)hipFree(h->gbuf); (void)hipFree(h->hbuf); }
         SHIP_TRY(hipMalloc((void **)&h->partial, (size_t)tiles * ts.gw_floats * sizeof(float)));
         SHIP_TRY(hipMalloc((void **)&h->stash, (size_t)tiles * SPL_TEAM * B * 3 * h->s.NTh * 64 * 4 * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->gbuf, (size_t)2 * B * ts.SM * SPL_QT * tiles * 256 * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->hbuf, (size_t)2 * B * tiles * h->s.NH * 256 * sizeof(float)));
         h->partial_tiles = tiles;
     }
     if (!h->w_dev_current) {
@@ -1159,9 +1407,10 @@ int nnest_spline_loss_grad(nnest_spline_t *h, const float *x_dev, int M, float *
     SplGradArgs a;
     memset(&a, 0, sizeof(a));
     a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = x_dev; a.M = M; a.mtot = M; a.partial = h->partial; a.stash = h->stash;
-    a.mode = SPL_MODE_GRAD;
+    a.mode = SPL_MODE_GRAD; a.gbuf = h->gbuf; a.hbuf = h->hbuf;
     a.rows_per_tile = rows_per_tile(M);
     SHIP_TRY(launch_grad(a, st));
+    SHIP_TRY(launch_w3(a, grad_dev, st));
     const int tiles = grad_tiles(a);
     hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, grad_dev, h->gwsum, loss_dev,
                        -1.0f / (float)M, -1.0f, (const int *)nullptr);
@@ -1182,9 +1431,10 @@ int nnest_spline_vjp(nnest_spline_t *h, const float *x_dev, const float *gz_dev,
     SplGradArgs a;
     memset(&a, 0, sizeof(a));
     a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = x_dev; a.M = M; a.mtot = M; a.partial = h->partial; a.stash = h->stash;
-    a.mode = SPL_MODE_VJP; a.gz = gz_dev; a.gx = gx_dev; a.gld_in = gld;
+    a.mode = SPL_MODE_VJP; a.gz = gz_dev; a.gx = gx_dev; a.gld_in = gld; a.gbuf = h->gbuf; a.hbuf = h->hbuf;
     a.rows_per_tile = rows_per_tile(M);
     SHIP_TRY(launch_grad(a, st));
+    SHIP_TRY(launch_w3(a, grad_dev, st));
     hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, grad_tiles(a), ts, h->w_dev, grad_dev, h->gwsum,
                        (float *)nullptr, 0.f, (float)M * gld, (const int *)nullptr);
     hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts,
@@ -1215,7 +1465,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
         return spline_fail(NNEST_E_ARG, "bad sizes n_train=%d n_valid=%d batch=%d max_epochs=%d", n_train, n_valid, batch, max_epochs);
     if (batch > 128) return spline_fail(NNEST_E_UNSUPPORTED, "batch_size=%d > 128", batch);
     hipStream_t st = (hipStream_t)stream;
-    const int max_rows = n_valid > 128 ? n_valid : 128;
+    const int max_rows = n_valid + 128;  // a minibatch's tiles and the validation tiles share one launch
     int rc = ensure_train_state(h, max_rows, st);
     if (rc) return rc;
     const SplTrainShape ts = make_train_shape(h->s);
@@ -1245,18 +1495,38 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
     snap[0] = c0; snap[1] = c0;
     SHIP_TRY(hipMemcpyAsync(ctl, &snap[0], sizeof(SplTrainCtl), hipMemcpyHostToDevice, st));
     const int adam_step0 = h->adam_step;
-    // shapes with at most two tiles per half: Adam keeps the training image current (spl_adam_image_kernel); the larger ones
-    // rebuild it per minibatch (their conv images are too much work for one workgroup per block)
+    // Shapes with at most two tiles per half (x_dim <= 64): per minibatch TWO launches -- the gradient pass and spl_update_kernel,
+    // which keeps the training image current -- and the validation pass of an epoch rides along with the first gradient pass of
+    // the next one (forward-only tiles on other CUs; the weights do not change in between), followed by the epoch's bookkeeping.
+    // The larger shapes rebuild the image per minibatch (their conv images are too much work for one workgroup per block).
     const bool fused = h->s.NTh <= 2;
-    const size_t head_lds = (size_t)ts.p_f[0] * sizeof(float);
-    if (fused && head_lds > 64 * 1024)
-        SHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(spl_adam_image_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds));
     const int CHUNK = 8;
     hipEvent_t ev[2];
     SHIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     SHIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
     int chunks = 0;
     bool stopped_seen = false;
+    const int vtiles = (n_valid + 15) / 16;
+    // the state after epoch `done` epochs: snapshot every CHUNK epochs, looked at one chunk later
+    auto snapshot = [&](int done) -> int {
+        if (done % CHUNK != 0 || done >= max_epochs) return NNEST_OK;
+        SHIP_TRY(hipMemcpyAsync(&snap[chunks & 1], ctl, sizeof(SplTrainCtl), hipMemcpyDeviceToHost, st));
+        SHIP_TRY(hipEventRecord(ev[chunks & 1], st));
+        if (chunks > 0) {
+            SHIP_TRY(hipEventSynchronize(ev[(chunks - 1) & 1]));
+            stopped_seen = snap[(chunks - 1) & 1].stopped != 0;
+        }
+        chunks += 1;
+        return NNEST_OK;
+    };
+    auto valid_args = [&]() {
+        SplGradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = xvalid_dev; a.M = n_valid; a.mtot = n_valid;
+        a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_LOSS; a.stop = stop;
+        a.rows_per_tile = rows_per_tile(n_valid);
+        return a;
+    };
     for (int epoch = 0; epoch < max_epochs && !stopped_seen; ++epoch) {
         for (int mb = 0; mb < n_mb; ++mb) {
             const int M = batch < n_train - mb * batch ? batch : n_train - mb * batch;
@@ -1265,50 +1535,56 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = xtrain_dev; a.perm = perm_dev + (size_t)epoch * n_train + (size_t)mb * batch;
             a.M = M; a.mtot = M; a.noise = noise_dev ? noise_dev + ((size_t)epoch * n_train + (size_t)mb * batch) * D : nullptr;
             a.seed = seed; a.noise_row0 = (long)mb * batch; a.epoch = epoch; a.jitter = jitter;
-            a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_GRAD; a.stop = stop;
+            a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_GRAD; a.stop = stop; a.gbuf = h->gbuf; a.hbuf = h->hbuf;
             a.rows_per_tile = rows_per_tile(M);
-            // (the image of the validation pass that closed the previous epoch is still the current one)
-            if (fused ? (mb == 0 && epoch == 0) : (mb > 0 || epoch == 0)) { if ((rc = build_timage(h, ts, st, stop))) return rc; }
-            SHIP_TRY(launch_grad(a, st));
             const int tiles = grad_tiles(a);
-            hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, h->grad, h->gwsum,
-                               h->losses_dev + mb, -1.0f / (float)M, -1.0f, stop);
-            hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + B * D, h->pi_dev, h->gwsum, h->grad, ts, -1.0f, stop);
             h->adam_step += 1;
             const double bc1 = 1.0 - pow(0.9, (double)h->adam_step), bc2 = 1.0 - pow(0.999, (double)h->adam_step);
-            if (fused)
-                hipLaunchKernelGGL(spl_adam_image_kernel, dim3(B + 80), dim3(1024), head_lds, st, h->w_dev, h->grad, h->adam_m, h->adam_v,
-                                   (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), weight_decay, h->pos_dev, h->pos_dev + np,
-                                   h->pos_dev + 2 * (size_t)np, h->pi_dev, h->wmat, h->timg, ts, stop);
-            else
+            if (fused) {
+                if (mb == 0 && epoch == 0 && (rc = build_timage(h, ts, st, stop))) return rc;
+                const bool ride = mb == 0 && epoch > 0;  // the validation pass of the epoch before
+                if (ride) { a.val_tiles = vtiles; a.xv = xvalid_dev; a.Mv = n_valid; }
+                SHIP_TRY(launch_grad(a, st));
+                if (ride) {
+                    hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch - 1, patience,
+                                       h->epoch_losses_dev, h->partial + (size_t)tiles * ts.gw_floats, ts.gw_floats, vtiles, h->w_dev, h->best_w, np);
+                    if ((rc = snapshot(epoch))) return rc;
+                }
+                SplUpdateArgs u;
+                memset(&u, 0, sizeof(u));
+                u.w = h->w_dev; u.m = h->adam_m; u.v = h->adam_v; u.partial = h->partial; u.tiles = tiles; u.gbuf = h->gbuf; u.hbuf = h->hbuf;
+                u.pos_f = h->pos_dev; u.pos_b = h->pos_dev + np; u.conv_src = h->pos_dev + 2 * (size_t)np; u.pi = h->pi_dev; u.pi_inv = h->pi_dev + B * D;
+                u.wmat = h->wmat; u.timg = h->timg; u.ts = ts;
+                u.step_size = (float)((double)lr / bc1); u.inv_bc2s = (float)(1.0 / sqrt(bc2)); u.wd = weight_decay; u.ldw = -1.0f;
+                u.loss_out = h->losses_dev + mb; u.loss_scale = -1.0f / (float)M; u.stop = stop;
+                const int H = h->s.H, items = 2 * B * ts.SM * SPL_QT;
+                const int trunk = B * (H * h->s.nl + H + H * h->s.nu + H + 4 * (H * H + H));
+                u.n_w3 = (items + 15) / 16;
+                const size_t ldsb = ((size_t)2 * ts.p_f[0] + (size_t)D * D) * sizeof(float) + (size_t)2 * D * sizeof(int);
+                DISPATCH_SPLT(spl_update_kernel, h->s, B + u.n_w3 + (trunk + 1023) / 1024, 1024, ldsb, st, u);
+            } else {
+                if ((mb > 0 || epoch == 0) && (rc = build_timage(h, ts, st, stop))) return rc;
+                SHIP_TRY(launch_grad(a, st));
+                SHIP_TRY(launch_w3(a, h->grad, st));
+                hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, tiles, ts, h->w_dev, h->grad, h->gwsum,
+                                   h->losses_dev + mb, -1.0f / (float)M, -1.0f, stop);
+                hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + B * D, h->pi_dev, h->gwsum, h->grad, ts, -1.0f, stop);
                 hipLaunchKernelGGL(spl_adam_kernel, dim3(256), dim3(256), 0, st, h->w_dev, h->grad, h->adam_m, h->adam_v, np,
                                    (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), weight_decay, stop);
+            }
         }
+        SHIP_TRY(hipGetLastError());
+        if (fused && epoch + 1 < max_epochs) continue;  // this epoch's validation rides with the next epoch's first gradient pass
         // Trainer._validate (trainer.py:405-418): one full batch; mean, then / len(dataset)
         if (!fused && (rc = build_timage(h, ts, st, stop))) return rc;
         {
-            SplGradArgs a;
-            memset(&a, 0, sizeof(a));
-            a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = xvalid_dev; a.M = n_valid; a.mtot = n_valid;
-            a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_LOSS; a.stop = stop;
-            a.rows_per_tile = rows_per_tile(n_valid);
+            const SplGradArgs a = valid_args();
             SHIP_TRY(launch_grad(a, st));
-            hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, grad_tiles(a), ts, h->w_dev, h->grad,
-                               h->gwsum, h->losses_dev + n_mb, -1.0f / (float)n_valid, -1.0f, stop);
         }
-        hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(64), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch, patience,
-                           h->epoch_losses_dev);
-        hipLaunchKernelGGL(spl_keep_best_kernel, dim3(128), dim3(256), 0, st, ctl, h->w_dev, h->best_w, np);
+        hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch, patience,
+                           h->epoch_losses_dev, h->partial, ts.gw_floats, vtiles, h->w_dev, h->best_w, np);
         SHIP_TRY(hipGetLastError());
-        if ((epoch + 1) % CHUNK == 0 && epoch + 1 < max_epochs) {
-            SHIP_TRY(hipMemcpyAsync(&snap[chunks & 1], ctl, sizeof(SplTrainCtl), hipMemcpyDeviceToHost, st));
-            SHIP_TRY(hipEventRecord(ev[chunks & 1], st));
-            if (chunks > 0) {  // the state after the chunk before this one
-                SHIP_TRY(hipEventSynchronize(ev[(chunks - 1) & 1]));
-                stopped_seen = snap[(chunks - 1) & 1].stopped != 0;
-            }
-            chunks += 1;
-        }
+        if ((rc = snapshot(epoch + 1))) return rc;
     }
     SHIP_TRY(hipMemcpyAsync(h->w_dev, h->best_w, nb, hipMemcpyDeviceToDevice, st));  // netG.load_state_dict(best_model)  trainer.py:241
     SHIP_TRY(hipMemcpyAsync(&snap[0], ctl, sizeof(SplTrainCtl), hipMemcpyDeviceToHost, st));

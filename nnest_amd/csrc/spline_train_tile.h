@@ -24,6 +24,7 @@ struct SplTrainShape {
     int cf[2], cb[2];        // conditioner fwd / bwd fragment floats (f1, f2)
     int tblk_floats, timage_floats;
     int p_s, p_t, p_L, p_S, p_U, p_f[2];  // offsets inside a packed block
+    int SM;                  // max(SU, SL): super-tile slots per coupling in the raw-gradient buffer (spl_w3_*)
     int gw_floats;           // workspace per wave: packed gradient slice + B * D * D (dLoss/dW of the convs) + 4 (loss)
 };
 

@@ -341,20 +341,21 @@ def _cpu_fixture(cfg):
         return json.load(f)
 
 
-@pytest.mark.parametrize('cfg', [1, 2])
+@pytest.mark.parametrize('cfg', [1, 2, 3])
 def test_logz_gpu_vs_cpu(tmp_path, cfg):
     """BASELINE's acceptance: log Z of the GPU path against the CPU path (the host driver on the oracle-backed trainer,
     oracle/run_logz_cpu.py -> tests/golden/logz_cpu_cfg<cfg>.json) for the same configuration, the same run() arguments and
     the same list of seeds.  The two paths draw from different noise streams, so a run is an independent estimate with scatter
-    ~ sqrt(H/N) (0.2 at config 1, 0.45 at config 2); the comparison is between the MEANS over the seeds:
+    ~ sqrt(H/N) (0.2 at config 1, 0.45 at config 2, 0.12 at config 3); the comparison is between the MEANS over the seeds:
     |mean_gpu - mean_cpu| <= max(0.1, 2 combined standard errors), standard errors from the samples themselves."""
     ref = _cpu_fixture(cfg)
-    like = Rosenbrock(ref['x_dim'])
+    like = {'Rosenbrock': Rosenbrock, 'GaussianMix': GaussianMix}[ref['likelihood']](ref['x_dim'])
+    scale = {'Rosenbrock': 5.0, 'GaussianMix': 10.0}[ref['likelihood']]
     seeds = ref['seeds']
     cpu = np.array([r['logz'] for r in ref['runs'] if r['seed'] in seeds])
     gpu = []
     for seed in seeds:
-        s = run(tmp_path / str(seed), ref['x_dim'], like, 5.0, ref['num_live_points'], seed, mcmc_num_chains=ref['mcmc_num_chains'])
+        s = run(tmp_path / str(seed), ref['x_dim'], like, scale, ref['num_live_points'], seed, mcmc_num_chains=ref['mcmc_num_chains'])
         gpu.append(s.logz)
     gpu = np.array(gpu)
     se = float(np.hypot(gpu.std(ddof=1) / np.sqrt(len(gpu)), cpu.std(ddof=1) / np.sqrt(len(cpu))))
