@@ -491,7 +491,10 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
 
 // One workgroup of SPL_TEAM waves per 16-row tile.  Every wave carries the tile's rows; the spline work (the bulk of the
 // instruction stream) and the weight-gradient contractions are divided among them (spl_coupling / spl_coupling_bwd).
-enum { SPL_TEAM = 4 };
+#ifndef SPL_TEAM_N
+#define SPL_TEAM_N 4
+#endif
+enum { SPL_TEAM = SPL_TEAM_N };
 
 template <int NTh, int NH>
 __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) {
@@ -982,6 +985,25 @@ struct SplAdamScatter {
     float *w, *m, *v, *timg;
     const int *pos_f, *pos_b;
     float step_size, inv_bc2s, wd;
+    // N parameters of one lane (index < 0: none): every load issued before the first store
+    template <int N>
+    __device__ __forceinline__ void many(const int (&p)[N], const float (&g)[N]) const {
+        float wi[N], mi[N], vi[N];
+        int pf[N], pb[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int q = p[k] >= 0 ? p[k] : 0;
+            wi[k] = w[q]; mi[k] = m[q]; vi[k] = v[q]; pf[k] = pos_f[q]; pb[k] = pos_b[q];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (p[k] < 0) continue;
+            const float wn = spl_adam_one(wi[k], g[k], mi[k], vi[k], step_size, inv_bc2s, wd);
+            m[p[k]] = mi[k]; v[p[k]] = vi[k]; w[p[k]] = wn;
+            if (pf[k] >= 0) timg[pf[k]] = wn;
+            if (pb[k] >= 0) timg[pb[k]] = wn;
+        }
+    }
     __device__ __forceinline__ void operator()(int p, float g) const {
         float mi = m[p], vi = v[p];
         const float wn = spl_adam_one(w[p], g, mi, vi, step_size, inv_bc2s, wd);
@@ -991,6 +1013,10 @@ struct SplAdamScatter {
         if (pb >= 0) timg[pb] = wn;
     }
 };
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding global stores, a
+// round trip to memory at every phase boundary of the head's update
+__device__ __forceinline__ void spl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int NTh, int NH>
 __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
@@ -1003,61 +1029,170 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
         const int b = blockIdx.x, base = b * s.blk_params;
         float *hold = ulds, *hnew = ulds + nhead, *gws = hnew + nhead;  // old head, new head, summed dLoss/dW (later W)
         int *spi = reinterpret_cast<int *>(gws + D * D), *spi_inv = spi + D;
-        for (int i = tid; i < nhead; i += blockDim.x) hold[i] = a.w[base + i];
-        for (int i = tid; i < D; i += blockDim.x) { spi[i] = a.pi[b * D + i]; spi_inv[i] = a.pi_inv[b * D + i]; }
-        // dLoss/dW summed over the tiles, rows permuted as P does: gws[pi(i)][j] = gW[i][j]
-        for (int idx = tid; idx < D * D; idx += blockDim.x)
-            gws[spi_of(a.pi, b, D, idx / D) * D + idx % D] = spl_sum_tiles(a.partial + np + b * D * D + idx, n, a.tiles);
-        __syncthreads();
+#ifdef NNEST_STAMP
+        long long u_t[6]; u_t[0] = wall_clock64();
+#define U_STAMP(i) u_t[i] = wall_clock64();
+#else
+#define U_STAMP(i)
+#endif
+        // Every global load of the head's update is issued up front, in one batch (old parameters, the tiles' partial sums, the Adam
+        // state of the elements this lane will step): taken phase by phase they were three dependent round trips to memory.
+        const int lane = tid & 63, wave = tid >> 6, nwv = (int)(blockDim.x >> 6), nt = (D + 15) >> 4, li = lane & 15, lk = lane >> 4;
+        const bool tiles8 = a.tiles <= 8;
+        auto tile_sum = [&](const float *p) {
+            if (!tiles8) return spl_sum_tiles(p, n, a.tiles);
+            float v[8], acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(u < a.tiles ? u : a.tiles - 1) * n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += u < a.tiles ? v[u] : 0.f;
+            return acc;
+        };
+        // (a) the elements of the two products' output tiles this lane holds: [tile u][4 accumulator registers + S on the diagonal]
+        int hi[2][5];
+        float hm[2][5], hv[2][5];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tile = wave + u * nwv;
+            const bool live = tile < 2 * nt * nt, isU = tile >= nt * nt;
+            const int tt = isU ? tile - nt * nt : tile, ti = tt / nt, tj = tt % nt, col = 16 * tj + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + 4 * lk + r;
+                hi[u][r] = (live && row < D && col < D) ? (isU ? ts.p_U : ts.p_L) + row * D + col : -1;
+            }
+            const int rd = col - 16 * ti - 4 * lk;  // the diagonal element of this lane's column, if this lane holds it
+            hi[u][4] = (live && isU && col < D && rd >= 0 && rd < 4) ? ts.p_S + col : -1;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int ii = hi[u][r] >= 0 ? hi[u][r] : 0;
+                hm[u][r] = a.m[base + ii]; hv[u][r] = a.v[base + ii];
+            }
+        }
+        // (b) ActNorm s, t: one element per thread
+        const bool an = tid < ts.p_L;
+        float an_m = a.m[base + (an ? tid : 0)], an_v = a.v[base + (an ? tid : 0)];
+        float an_g = tile_sum(a.partial + base + (an ? tid : 0));
+        // (c) the old head into LDS, dLoss/dW summed over the tiles and its rows permuted as P does: gws[pi(i)][j] = gW[i][j]
+        {
+            float hw[9];  // x_dim <= 64: the head is at most 8384 floats
+#pragma unroll
+            for (int u = 0; u < 9; ++u) { const int i = tid + u * 1024; hw[u] = a.w[base + (i < nhead ? i : 0)]; }
+            float gs[4];
+            int gd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = tid + u * 1024, ic = idx < D * D ? idx : 0;
+                gd[u] = idx < D * D ? a.pi[b * D + ic / D] * D + ic % D : -1;
+                gs[u] = tile_sum(a.partial + np + b * D * D + ic);
+            }
+#pragma unroll
+            for (int u = 0; u < 9; ++u) { const int i = tid + u * 1024; if (i < nhead) hold[i] = hw[u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (gd[u] >= 0) gws[gd[u]] = gs[u];
+            for (int i = tid; i < D; i += blockDim.x) { spi[i] = a.pi[b * D + i]; spi_inv[i] = a.pi_inv[b * D + i]; }
+        }
+        spl_lds_barrier();
+        U_STAMP(1)
+        // dLoss/dL = tril(G Um^T, -1) and dLoss/d(Um) = triu(Lm^T G) with G = the row-permuted dLoss/dW, Lm = tril(L,-1) + I,
+        // Um = triu(U,1) + diag(S): two D^3 products on the matrix cores, operands straight from LDS, one 16x16 output tile per
+        // wave and round (as scalar loops over LDS they were 9.5 us of this kernel's 21); every output element is one head
+        // parameter and takes its Adam step where it lands.
         const float *Lp = hold + ts.p_L, *Sp = hold + ts.p_S, *Up = hold + ts.p_U;
-        for (int i = tid; i < nhead; i += blockDim.x) {
-            float acc = 0.f;
-            if (i < ts.p_L) {  // ActNorm s, t: the tiles' partials (+ the log-det term of s on every row)
-                acc = spl_sum_tiles(a.partial + base + i, n, a.tiles);
-                if (i < ts.p_t) acc += a.ldw;
-            } else if (i < ts.p_S) {  // dLoss/dL[r][k] = sum_{j >= k} gW[pi^-1(r)][j] Um[k][j]  (k < r), Um[k][k] = S[k]
-                const int o = i - ts.p_L, r = o / D, k = o % D;
-                if (k < r) {
-                    acc = gws[r * D + k] * Sp[k];
-#pragma unroll 4
-                    for (int j = k + 1; j < D; ++j) acc += gws[r * D + j] * Up[k * D + j];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tile = wave + u * nwv;
+            if (tile >= 2 * nt * nt) continue;
+            const bool isU = tile >= nt * nt;
+            const int tt = isU ? tile - nt * nt : tile, ti = tt / nt, tj = tt % nt;
+            const int i = 16 * ti + li, j = 16 * tj + li;  // A row / B column of this lane
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < D; k0 += 4) {
+                const int k = k0 + lk;
+                float av = 0.f, bv = 0.f;
+                if (!isU) {  // C[r][c] = sum_k G[r][k] Um[c][k]
+                    if (i < D && k < D) av = gws[i * D + k];
+                    if (j < D && k < D) bv = j < k ? Up[j * D + k] : (j == k ? Sp[j] : 0.f);
+                } else {     // C[c][j] = sum_k Lm[k][c] G[k][j]
+                    if (i < D && k < D) av = i < k ? Lp[k * D + i] : (i == k ? 1.f : 0.f);
+                    if (j < D && k < D) bv = gws[k * D + j];
                 }
-            } else {  // S[k] (the diagonal, + the conv's log-det term) or Um[k][j], k < j: sum_{r >= k} gW[pi^-1(r)][j] Lm[r][k], Lm[k][k] = 1
-                const bool diag = i < ts.p_U;
-                const int o = i - ts.p_U, k = diag ? i - ts.p_S : o / D, j = diag ? k : o % D;
-                if (diag || k < j) {
-                    acc = gws[k * D + j];
-#pragma unroll 4
-                    for (int r = k + 1; r < D; ++r) acc += gws[r * D + j] * Lp[r * D + k];
-                    if (diag) acc += a.ldw / Sp[k];
+                acc = mfma4(av, bv, acc);
+            }
+            const float cv[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int e = hi[u][r];
+                if (e < 0) continue;
+                float g;
+                if (r < 4) {
+                    const int row = 16 * ti + 4 * lk + r, col = 16 * tj + li;
+                    g = (isU ? row < col : col < row) ? cv[r] : 0.f;
+                } else {
+                    const int col = 16 * tj + li, rd = col - 16 * ti - 4 * lk;
+                    g = (rd == 0 ? cv[0] : rd == 1 ? cv[1] : rd == 2 ? cv[2] : cv[3]) + a.ldw / Sp[col];  // + the conv's log-det term
+                }
+                const float wn = spl_adam_one(hold[e], g, hm[u][r], hv[u][r], a.step_size, a.inv_bc2s, a.wd);
+                a.m[base + e] = hm[u][r]; a.v[base + e] = hv[u][r]; a.w[base + e] = wn;
+                hnew[e] = wn;
+            }
+        }
+        if (an) {  // ActNorm s, t (+ the log-det term of s on every row)
+            if (tid < ts.p_t) an_g += a.ldw;
+            const float wn = spl_adam_one(hold[tid], an_g, an_m, an_v, a.step_size, a.inv_bc2s, a.wd);
+            a.m[base + tid] = an_m; a.v[base + tid] = an_v; a.w[base + tid] = wn;
+            hnew[tid] = wn;
+        }
+        spl_lds_barrier();
+        U_STAMP(2)
+        // W = (P Lm) Um from the new values: a third product of the same form
+        float *Wm = a.wmat + (size_t)b * D * D;
+        {
+            const float *Ln = hnew + ts.p_L, *Sn = hnew + ts.p_S, *Un = hnew + ts.p_U;
+            // (x_dim <= 64: at most 16 output tiles, one per wave of the 1024-thread workgroup)
+            const int tile = wave, ti = tile / nt, tj = tile % nt, i = 16 * ti + li, j = 16 * tj + li;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (tile < nt * nt) {
+                const int pr = i < D ? spi[i] : 0;
+                for (int k0 = 0; k0 < D; k0 += 4) {
+                    const int k = k0 + lk;
+                    float av = 0.f, bv = 0.f;
+                    if (i < D && k < D) av = k < pr ? Ln[pr * D + k] : (k == pr ? 1.f : 0.f);
+                    if (j < D && k < D) bv = k < j ? Un[k * D + j] : (k == j ? Sn[k] : 0.f);
+                    acc = mfma4(av, bv, acc);
                 }
             }
-            float mi = a.m[base + i], vi = a.v[base + i];
-            const float wn = spl_adam_one(hold[i], acc, mi, vi, a.step_size, a.inv_bc2s, a.wd);
-            a.m[base + i] = mi; a.v[base + i] = vi; a.w[base + i] = wn;
-            hnew[i] = wn;
+            spl_lds_barrier();  // every wave is done reading G: its LDS now takes W
+            if (tile < nt * nt) {
+                const float cv[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ti + 4 * lk + r, col = 16 * tj + li;
+                    if (row < D && col < D) { Wm[row * D + col] = cv[r]; gws[row * D + col] = cv[r]; }
+                }
+            }
         }
-        __syncthreads();
-        float *Wm = a.wmat + (size_t)b * D * D;
-        for (int idx = tid; idx < D * D; idx += blockDim.x) {
-            const float wv = spl_w_entry(hnew + ts.p_L, hnew + ts.p_S, hnew + ts.p_U, spi[idx / D], idx % D, D);
-            Wm[idx] = wv;
-            gws[idx] = wv;
-        }
-        __syncthreads();
+        spl_lds_barrier();
+        U_STAMP(3)
         float *blk = a.timg + (size_t)b * ts.tblk_floats;
 #pragma unroll 4
         for (int o = tid; o < 2 * ts.conv_floats; o += blockDim.x) {
             const int src = a.conv_src[o];
             blk[o] = src >= 0 ? gws[src] : 0.f;
         }
+        U_STAMP(4)
         for (int d = tid; d < D; d += blockDim.x) hold[d] = hnew[ts.p_s + d] + logf(fabsf(hnew[ts.p_S + d]));
-        __syncthreads();
+        spl_lds_barrier();
         if (tid == 0) {
             float acc = 0.f;
             for (int d = 0; d < D; ++d) acc += hold[d];
             blk[ts.tblk_floats - 4] = acc;
         }
+        U_STAMP(5)
+#ifdef NNEST_STAMP
+        if (tid == 0 && b == 0) printf("spl_update head: loads+sums %lld | LU grads + Adam %lld | W %lld | conv images %lld | logdet %lld (x10 ns)\n",
+                                       u_t[1] - u_t[0], u_t[2] - u_t[1], u_t[3] - u_t[2], u_t[4] - u_t[3], u_t[5] - u_t[4]);
+#endif
         return;
     }
     const SplAdamScatter step = {a.w, a.m, a.v, a.timg, a.pos_f, a.pos_b, a.step_size, a.inv_bc2s, a.wd};
@@ -1073,19 +1208,24 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
         float db;
         spl_w3_item<NH>(a.gbuf + ((size_t)(cidx * ts.SM + sidx) * SPL_QT + q) * a.tiles * 256, a.hbuf + (size_t)cidx * a.tiles * NH * 256, a.tiles, lane, dW, db);
         const int g = lane >> 4, j = lane & 15;
+        int pi_[4 * NH + 1];
+        float gi_[4 * NH + 1];
 #pragma unroll
         for (int ht = 0; ht < NH; ++ht) {
             const float dv[4] = {dW[ht].x, dW[ht].y, dW[ht].z, dW[ht].w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int jo = 4 * sidx + g, pp = 4 * q + r;
-                if (jo < nout && pp < SPL_P) step(pW3 + (jo * SPL_P + pp) * H + 16 * ht + j, dv[r]);
+                pi_[4 * ht + r] = (jo < nout && pp < SPL_P) ? pW3 + (jo * SPL_P + pp) * H + 16 * ht + j : -1;
+                gi_[4 * ht + r] = dv[r];
             }
         }
-        if (lane < 16) {
+        {
             const int jo = 4 * sidx + (lane >> 2), pp = 4 * q + (lane & 3);
-            if (jo < nout && pp < SPL_P) step(pb3 + jo * SPL_P + pp, db);
+            pi_[4 * NH] = (lane < 16 && jo < nout && pp < SPL_P) ? pb3 + jo * SPL_P + pp : -1;
+            gi_[4 * NH] = db;
         }
+        step.template many<4 * NH + 1>(pi_, gi_);
         return;
     }
     // the trunks: W0, b0, W1, b1, W2, b2 of both conditioners of every block
