@@ -1026,9 +1026,14 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
     const SplineShape &s = ts.s;
     const int D = s.D, B = s.B, np = s.num_params, nhead = ts.p_f[0], n = ts.gw_floats, tid = threadIdx.x;
     if ((int)blockIdx.x < B) {
+        // LDS: the old head, and five 64 x 64 operand matrices at stride 65 (zero-padded; stride 65 keeps a column walk off one
+        // bank): G = the row-permuted dLoss/dW, Um = triu(U,1) + diag(S) and Lm = tril(L,-1) + I of the old values, and of the new
+        // ones (UmN, LmN).  Dense operands make the products' inner loops two unconditional LDS reads per matrix instruction
+        // (fetched through per-lane triangular conditions a 13-step product took 2-3 us).
         const int b = blockIdx.x, base = b * s.blk_params;
-        float *hold = ulds, *hnew = ulds + nhead, *gws = hnew + nhead;  // old head, new head, summed dLoss/dW (later W)
-        int *spi = reinterpret_cast<int *>(gws + D * D), *spi_inv = spi + D;
+        constexpr int DP = 65, MAT = 64 * DP;
+        float *hold = ulds, *G = ulds + nhead, *Um = G + MAT, *Lm = Um + MAT, *UmN = Lm + MAT, *LmN = UmN + MAT, *snew = LmN + MAT;
+        int *spi = reinterpret_cast<int *>(snew + 64);
 #ifdef NNEST_STAMP
         long long u_t[6]; u_t[0] = wall_clock64();
 #define U_STAMP(i) u_t[i] = wall_clock64();
@@ -1073,7 +1078,8 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
         const bool an = tid < ts.p_L;
         float an_m = a.m[base + (an ? tid : 0)], an_v = a.v[base + (an ? tid : 0)];
         float an_g = tile_sum(a.partial + base + (an ? tid : 0));
-        // (c) the old head into LDS, dLoss/dW summed over the tiles and its rows permuted as P does: gws[pi(i)][j] = gW[i][j]
+        // (c) the old head into LDS (plain and as the dense operands), dLoss/dW summed over the tiles with its rows permuted as P
+        // does: G[pi(i)][j] = gW[i][j]
         {
             float hw[9];  // x_dim <= 64: the head is at most 8384 floats
 #pragma unroll
@@ -1083,22 +1089,39 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = tid + u * 1024, ic = idx < D * D ? idx : 0;
-                gd[u] = idx < D * D ? a.pi[b * D + ic / D] * D + ic % D : -1;
+                gd[u] = idx < D * D ? a.pi[b * D + ic / D] * DP + ic % D : -1;
                 gs[u] = tile_sum(a.partial + np + b * D * D + ic);
             }
+            for (int idx = tid; idx < MAT; idx += blockDim.x) {  // the padding of the five matrices
+                const int row = idx / DP, col = idx - row * DP;
+                if (row >= D || col >= D) { G[idx] = 0.f; Um[idx] = 0.f; Lm[idx] = 0.f; UmN[idx] = 0.f; LmN[idx] = 0.f; }
+            }
 #pragma unroll
-            for (int u = 0; u < 9; ++u) { const int i = tid + u * 1024; if (i < nhead) hold[i] = hw[u]; }
+            for (int u = 0; u < 9; ++u) {
+                const int i = tid + u * 1024;
+                if (i >= nhead) continue;
+                hold[i] = hw[u];
+                if (i >= ts.p_U) {         // U[k][j]: the strict upper triangle counts (the diagonal of Um is S's)
+                    const int o = i - ts.p_U, k = o / D, j = o - k * D;
+                    if (k != j) Um[k * DP + j] = k < j ? hw[u] : 0.f;
+                } else if (i >= ts.p_S) {  // S[k]
+                    Um[(i - ts.p_S) * (DP + 1)] = hw[u];
+                } else if (i >= ts.p_L) {  // L[r][k]: the strict lower triangle, 1 on the diagonal
+                    const int o = i - ts.p_L, r = o / D, k = o - r * D;
+                    Lm[r * DP + k] = k < r ? hw[u] : (k == r ? 1.f : 0.f);
+                }
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (gd[u] >= 0) gws[gd[u]] = gs[u];
-            for (int i = tid; i < D; i += blockDim.x) { spi[i] = a.pi[b * D + i]; spi_inv[i] = a.pi_inv[b * D + i]; }
+            for (int u = 0; u < 4; ++u) if (gd[u] >= 0) G[gd[u]] = gs[u];
+            for (int i = tid; i < D; i += blockDim.x) spi[i] = a.pi[b * D + i];
         }
         spl_lds_barrier();
         U_STAMP(1)
-        // dLoss/dL = tril(G Um^T, -1) and dLoss/d(Um) = triu(Lm^T G) with G = the row-permuted dLoss/dW, Lm = tril(L,-1) + I,
-        // Um = triu(U,1) + diag(S): two D^3 products on the matrix cores, operands straight from LDS, one 16x16 output tile per
-        // wave and round (as scalar loops over LDS they were 9.5 us of this kernel's 21); every output element is one head
-        // parameter and takes its Adam step where it lands.
-        const float *Lp = hold + ts.p_L, *Sp = hold + ts.p_S, *Up = hold + ts.p_U;
+        // dLoss/dL = tril(G Um^T, -1) and dLoss/d(Um) = triu(Lm^T G): two D^3 products on the matrix cores, one 16x16 output tile
+        // per wave and round; every output element is one head parameter and takes its Adam step where it lands, the new value
+        // going straight into the new dense operands.
+        const float *Sp = hold + ts.p_S;
+        const int KP = 16 * nt;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int tile = wave + u * nwv;
@@ -1106,70 +1129,54 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
             const bool isU = tile >= nt * nt;
             const int tt = isU ? tile - nt * nt : tile, ti = tt / nt, tj = tt % nt;
             const int i = 16 * ti + li, j = 16 * tj + li;  // A row / B column of this lane
+            // C[r][c] = sum_k G[r][k] Um[c][k]   |   C[c][j] = sum_k Lm[k][c] G[k][j]
+            const float *pa = isU ? Lm + lk * DP + i : G + i * DP + lk, *pb = isU ? G + lk * DP + j : Um + j * DP + lk;
+            const int sa = isU ? 4 * DP : 4, sb = isU ? 4 * DP : 4;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int k0 = 0; k0 < D; k0 += 4) {
-                const int k = k0 + lk;
-                float av = 0.f, bv = 0.f;
-                if (!isU) {  // C[r][c] = sum_k G[r][k] Um[c][k]
-                    if (i < D && k < D) av = gws[i * D + k];
-                    if (j < D && k < D) bv = j < k ? Up[j * D + k] : (j == k ? Sp[j] : 0.f);
-                } else {     // C[c][j] = sum_k Lm[k][c] G[k][j]
-                    if (i < D && k < D) av = i < k ? Lp[k * D + i] : (i == k ? 1.f : 0.f);
-                    if (j < D && k < D) bv = gws[k * D + j];
-                }
-                acc = mfma4(av, bv, acc);
-            }
+#pragma unroll 4
+            for (int k0 = 0; k0 < KP; k0 += 4) acc = mfma4(pa[(k0 >> 2) * sa], pb[(k0 >> 2) * sb], acc);
             const float cv[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const int e = hi[u][r];
                 if (e < 0) continue;
+                const int col = 16 * tj + li, row = r < 4 ? 16 * ti + 4 * lk + r : col;
                 float g;
-                if (r < 4) {
-                    const int row = 16 * ti + 4 * lk + r, col = 16 * tj + li;
-                    g = (isU ? row < col : col < row) ? cv[r] : 0.f;
-                } else {
-                    const int col = 16 * tj + li, rd = col - 16 * ti - 4 * lk;
+                if (r < 4) g = (isU ? row < col : col < row) ? cv[r] : 0.f;
+                else {
+                    const int rd = col - 16 * ti - 4 * lk;
                     g = (rd == 0 ? cv[0] : rd == 1 ? cv[1] : rd == 2 ? cv[2] : cv[3]) + a.ldw / Sp[col];  // + the conv's log-det term
                 }
                 const float wn = spl_adam_one(hold[e], g, hm[u][r], hv[u][r], a.step_size, a.inv_bc2s, a.wd);
                 a.m[base + e] = hm[u][r]; a.v[base + e] = hv[u][r]; a.w[base + e] = wn;
-                hnew[e] = wn;
+                if (!isU) LmN[row * DP + col] = col < row ? wn : (col == row ? 1.f : 0.f);
+                else if (r == 4) { UmN[col * (DP + 1)] = wn; snew[col] = wn; }
+                else if (row != col) UmN[row * DP + col] = row < col ? wn : 0.f;
             }
         }
         if (an) {  // ActNorm s, t (+ the log-det term of s on every row)
             if (tid < ts.p_t) an_g += a.ldw;
             const float wn = spl_adam_one(hold[tid], an_g, an_m, an_v, a.step_size, a.inv_bc2s, a.wd);
             a.m[base + tid] = an_m; a.v[base + tid] = an_v; a.w[base + tid] = wn;
-            hnew[tid] = wn;
+            if (tid < ts.p_t) hold[tid] = wn;  // (the new s, for the log-det constant: nobody reads the old one any more)
         }
         spl_lds_barrier();
         U_STAMP(2)
-        // W = (P Lm) Um from the new values: a third product of the same form
-        float *Wm = a.wmat + (size_t)b * D * D;
-        {
-            const float *Ln = hnew + ts.p_L, *Sn = hnew + ts.p_S, *Un = hnew + ts.p_U;
-            // (x_dim <= 64: at most 16 output tiles, one per wave of the 1024-thread workgroup)
-            const int tile = wave, ti = tile / nt, tj = tile % nt, i = 16 * ti + li, j = 16 * tj + li;
+        // W = (P Lm) Um from the new values: a third product of the same form (x_dim <= 64: at most 16 output tiles, one per wave);
+        // G's LDS takes W (row-major, stride D: the conv images' source table indexes it)
+        float *Wm = a.wmat + (size_t)b * D * D, *Wl = G;
+        if (wave < nt * nt) {
+            const int ti = wave / nt, tj = wave % nt, i = 16 * ti + li, j = 16 * tj + li;
+            const int pr = i < D ? spi[i] : 63;
+            const float *pa = LmN + pr * DP + lk, *pb = UmN + lk * DP + j;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (tile < nt * nt) {
-                const int pr = i < D ? spi[i] : 0;
-                for (int k0 = 0; k0 < D; k0 += 4) {
-                    const int k = k0 + lk;
-                    float av = 0.f, bv = 0.f;
-                    if (i < D && k < D) av = k < pr ? Ln[pr * D + k] : (k == pr ? 1.f : 0.f);
-                    if (j < D && k < D) bv = k < j ? Un[k * D + j] : (k == j ? Sn[k] : 0.f);
-                    acc = mfma4(av, bv, acc);
-                }
-            }
-            spl_lds_barrier();  // every wave is done reading G: its LDS now takes W
-            if (tile < nt * nt) {
-                const float cv[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll 4
+            for (int k0 = 0; k0 < KP; k0 += 4) acc = mfma4(pa[k0], pb[k0 * DP], acc);
+            const float cv[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * ti + 4 * lk + r, col = 16 * tj + li;
-                    if (row < D && col < D) { Wm[row * D + col] = cv[r]; gws[row * D + col] = cv[r]; }
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + 4 * lk + r, col = 16 * tj + li;
+                if (row < D && col < D) { Wm[row * D + col] = cv[r]; Wl[row * D + col] = cv[r]; }
             }
         }
         spl_lds_barrier();
@@ -1178,14 +1185,15 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
 #pragma unroll 4
         for (int o = tid; o < 2 * ts.conv_floats; o += blockDim.x) {
             const int src = a.conv_src[o];
-            blk[o] = src >= 0 ? gws[src] : 0.f;
+            blk[o] = src >= 0 ? Wl[src] : 0.f;
         }
         U_STAMP(4)
-        for (int d = tid; d < D; d += blockDim.x) hold[d] = hnew[ts.p_s + d] + logf(fabsf(hnew[ts.p_S + d]));
+        // log|det| of ActNorm + conv (networks.py:650, :676): the terms in parallel, summed in d order
+        for (int d = tid; d < D; d += blockDim.x) Um[d] = hold[ts.p_s + d] + logf(fabsf(snew[d]));
         spl_lds_barrier();
         if (tid == 0) {
             float acc = 0.f;
-            for (int d = 0; d < D; ++d) acc += hold[d];
+            for (int d = 0; d < D; ++d) acc += Um[d];
             blk[ts.tblk_floats - 4] = acc;
         }
         U_STAMP(5)
@@ -1700,7 +1708,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
                 const int H = h->s.H, items = 2 * B * ts.SM * SPL_QT;
                 const int trunk = B * (H * h->s.nl + H + H * h->s.nu + H + 4 * (H * H + H));
                 u.n_w3 = (items + 15) / 16;
-                const size_t ldsb = ((size_t)2 * ts.p_f[0] + (size_t)D * D) * sizeof(float) + (size_t)2 * D * sizeof(int);
+                const size_t ldsb = ((size_t)ts.p_f[0] + 5 * 64 * 65 + 64) * sizeof(float) + (size_t)D * sizeof(int);
                 DISPATCH_SPLT(spl_update_kernel, h->s, B + u.n_w3 + (trunk + 1023) / 1024, 1024, ldsb, st, u);
             } else {
                 if ((mb > 0 || epoch == 0) && (rc = build_timage(h, ts, st, stop))) return rc;
