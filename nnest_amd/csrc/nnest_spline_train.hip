@@ -379,7 +379,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
         for (int t = 0; t < NTh; ++t) xch[(wv * NTh + t) * 64 + lane] = g_tr[t];
 #pragma unroll
         for (int ht = 0; ht < NH; ++ht) xch[(TEAM * NTh + wv * NH + ht) * 64 + lane] = g_h[ht];
-        __syncthreads();
+        spl_team_barrier();
 #pragma unroll
         for (int t = 0; t < NTh; ++t)
             g_tr[t] = (f32x4){xch[(((4 * t + 0) & (TEAM - 1)) * NTh + t) * 64 + lane].x, xch[(((4 * t + 1) & (TEAM - 1)) * NTh + t) * 64 + lane].y,
@@ -391,7 +391,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
             for (int k = 1; k < TEAM; ++k) acc = acc + xch[(TEAM * NTh + k * NH + ht) * 64 + lane];
             g_h[ht] = acc;
         }
-        __syncthreads();
+        spl_team_barrier();
     }
     CB_STAMP(2)
     // hidden layers 3 and 2 (W2 over h[1], W1 over h[0])
@@ -613,11 +613,11 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     ld = group_sum(ld);
     if (TEAM > 1) {  // the waves hold the log-det of their own super-tiles: add them up
         if (lane < 16) ldred[wv * 16 + lane] = ld;
-        __syncthreads();
+        spl_team_barrier();
         ld = 0.f;
 #pragma unroll
         for (int k = 0; k < TEAM; ++k) ld += ldred[k * 16 + w];
-        __syncthreads();
+        spl_team_barrier();
     }
     float ss = 0.f;
 #pragma unroll

@@ -108,12 +108,12 @@ struct SplineInverseTeam {
         spl_from_parity<NT>(buf, sp.D, sp.nl, lane, xs, t);
         float ld = group_sum(spline_inverse_tile<NT, NH, TEAM>(img, sp, lane, t, wv, xch));
         if (lane < 16) ldred[wv * 16 + lane] = ld;
-        __syncthreads();
+        spl_team_barrier();
         const int w = lane & 15;
         ld = 0.f;
 #pragma unroll
         for (int k = 0; k < TEAM; ++k) ld += ldred[k * 16 + w];
-        __syncthreads();
+        spl_team_barrier();
         spl_to_parity<NT>(buf, sp.D, sp.nl, lane, t, xs);
         return 0.25f * ld;  // the caller sums the four lanes of a walker
     }

@@ -238,6 +238,10 @@ __device__ __forceinline__ float spl_rqs(const f32x4 (&raw)[SPL_QT], float tail,
 // TEAM = 4 or 8: the waves of a workgroup hold the same tile; wave `wv` evaluates the super-tiles s = wv (mod TEAM) and the
 // results are merged through `xch` ([TEAM][NTh][64] f32x4 of LDS).  The trunk is
 // recomputed by every wave (16 MFMAs against 24 per super-tile).
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the wave's outstanding global loads and stores
+// (a round trip to memory per team merge when stash / gradient stores are in flight)
+__device__ __forceinline__ void spl_team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int NTh, int NH, bool INV, int TEAM = 1>
 __device__ __forceinline__ float spl_coupling(const float *__restrict__ net, int S, int n_out, float tail, int lane,
                                               const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv = 0, f32x4 *xch = nullptr) {
@@ -276,12 +280,12 @@ __device__ __forceinline__ float spl_coupling(const float *__restrict__ net, int
     if (TEAM > 1) {  // super-tile s = 4t + r (register r of tile t) comes from wave s mod TEAM
 #pragma unroll
         for (int t = 0; t < NTh; ++t) xch[(wv * NTh + t) * 64 + lane] = tr[t];
-        __syncthreads();
+        spl_team_barrier();
 #pragma unroll
         for (int t = 0; t < NTh; ++t)
             tr[t] = (f32x4){xch[(((4 * t + 0) & (TEAM - 1)) * NTh + t) * 64 + lane].x, xch[(((4 * t + 1) & (TEAM - 1)) * NTh + t) * 64 + lane].y,
                             xch[(((4 * t + 2) & (TEAM - 1)) * NTh + t) * 64 + lane].z, xch[(((4 * t + 3) & (TEAM - 1)) * NTh + t) * 64 + lane].w};
-        __syncthreads();
+        spl_team_barrier();
     }
     return ld;
 }
