@@ -310,7 +310,7 @@ __device__ __forceinline__ f32x4 rows_sum(f32x4 v) {
 // delta propagation through the trunk is repeated by every wave so that all four leave with the same g_tr / g_cond.
 template <int NTh, int NH, int TEAM>
 __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const float *__restrict__ cf, const float *__restrict__ cbw, int pnet,
-                                                 int nin, int nout, int S, int lane, bool row_ok, float gld, float *lds17, float *gp,
+                                                 int nin, int nout, int S, int lane, bool row_ok, bool cmask, float gld, float *lds17, float *gp,
                                                  const f32x4 (&cond)[NTh], const f32x4 (&x_tr)[NTh], f32x4 (&g_tr)[NTh], f32x4 (&g_cond)[NTh],
                                                  int wv, f32x4 *xch, f32x4 *__restrict__ gq, f32x4 *__restrict__ hq, int item_stride
 #ifdef NNEST_STAMP
@@ -361,7 +361,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
             for (int q = 0; q < SPL_QT; ++q) {
                 if (!valid) graw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 // last layer: G to memory (dW3, db3: spl_w3_item), g_h3 += W3^T G
-                gq[(size_t)(s * SPL_QT + q) * item_stride + lane] = graw[q];
+                gq[(size_t)(s * SPL_QT + q) * item_stride + lane] = cmask ? graw[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int hto = 0; hto < NH; ++hto) {
                     const float *a = B4 + (size_t)(((s * SPL_QT + q) * NH + hto) * 4) * 64 + lane;
@@ -406,8 +406,9 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
         for (int ht = 0; ht < NH; ++ht) {
             g_pre[ht] = lrelu_grad4(g_h[ht], h[l][ht]);
             if (mine) {
-                tile_transpose(lds17, lane, g_pre[ht], gT[ht]);
-                const f32x4 db = rows_sum(g_pre[ht]);
+                const f32x4 gc = cmask ? g_pre[ht] : (f32x4){0.f, 0.f, 0.f, 0.f};  // (each row once in the sums over rows)
+                tile_transpose(lds17, lane, gc, gT[ht]);
+                const f32x4 db = rows_sum(gc);
                 if (w == 0) {
                     gp[pb + 16 * ht + 4 * g + 0] = db.x; gp[pb + 16 * ht + 4 * g + 1] = db.y;
                     gp[pb + 16 * ht + 4 * g + 2] = db.z; gp[pb + 16 * ht + 4 * g + 3] = db.w;
@@ -449,8 +450,9 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
         for (int ht = 0; ht < NH; ++ht) {
             g_pre[ht] = lrelu_grad4(g_h[ht], h[0][ht]);
             if (mine) {
-                tile_transpose(lds17, lane, g_pre[ht], gT[ht]);
-                const f32x4 db = rows_sum(g_pre[ht]);
+                const f32x4 gc = cmask ? g_pre[ht] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                tile_transpose(lds17, lane, gc, gT[ht]);
+                const f32x4 db = rows_sum(gc);
                 if (w == 0) {
                     gp[pb0 + 16 * ht + 4 * g + 0] = db.x; gp[pb0 + 16 * ht + 4 * g + 1] = db.y;
                     gp[pb0 + 16 * ht + 4 * g + 2] = db.z; gp[pb0 + 16 * ht + 4 * g + 3] = db.w;
@@ -461,7 +463,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
         for (int t = 0; t < NTh; ++t) {
             if (mine) {
                 f32x4 cin = cond[t];
-                if (!row_ok) cin = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!row_ok) cin = (f32x4){0.f, 0.f, 0.f, 0.f};  // (the delta side carries the each-row-once mask)
                 float cT[4];
                 tile_transpose(lds17, lane, cin, cT);
                 const int j = 16 * t + 4 * (w & 3) + (w >> 2);  // input dim of tile row w
@@ -495,6 +497,9 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
 #define SPL_TEAM_N 4
 #endif
 enum { SPL_TEAM = SPL_TEAM_N };
+#ifndef SPL_ROWS_PER_TILE
+#define SPL_ROWS_PER_TILE 8
+#endif
 
 template <int NTh, int NH>
 __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) {
@@ -513,8 +518,13 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     const int ntl = (int)gridDim.x - a.val_tiles;  // the batch's own tiles
     const bool vtile = tile >= ntl;
     const int mode = vtile ? (int)SPL_MODE_LOSS : a.mode;
-    const int row = (vtile ? tile - ntl : tile) * a.rows_per_tile + w;
-    const bool ok = w < a.rows_per_tile && row < (vtile ? a.Mv : a.M);
+    // rows_per_tile 8: the tile's 8 rows sit in BOTH halves of the 16 matrix-core columns (lanes w and w + 8 carry row w & 7).
+    // The halves run the spline stage on different dimensions (spl_coupling_pair*), everything else is computed twice and the
+    // sums over rows take the low half only (`okc`).
+    const bool dup = a.rows_per_tile == 8;
+    const int row = (vtile ? tile - ntl : tile) * a.rows_per_tile + (dup ? (w & 7) : w);
+    const bool ok = (dup || w < a.rows_per_tile) && row < (vtile ? a.Mv : a.M);
+    const bool cmask = !dup || w < 8, okc = ok && cmask;
     float *gp = a.partial + (size_t)tile * ts.gw_floats;
     f32x4 *stash = reinterpret_cast<f32x4 *>(a.stash) + ((size_t)tile * TEAM + wv) * B * 3 * NTh * 64;  // per block: input halves + upper'
 
@@ -625,7 +635,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #pragma unroll
         for (int t = 0; t < NTh; ++t) ss += base_E4(xs[c][t], s.base_beta);
     ss = group_sum(ss);
-    float lp = (ok && g == 0) ? (-ss + s.base_const * (float)D + ld) : 0.f;
+    float lp = (okc && g == 0) ? (-ss + s.base_const * (float)D + ld) : 0.f;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) lp += __shfl_xor(lp, o);
     if (lane == 0 && wv == 0) gp[ts.gw_floats - 4] = lp;  // sum of log_probs over this tile's rows
@@ -678,14 +688,14 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         f32x4 *gq1 = reinterpret_cast<f32x4 *>(a.gbuf) + ((size_t)(2 * b + 0) * ts.SM * SPL_QT * ntl + tile) * 64;
         f32x4 *hq2 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 1) * ntl + tile) * NH * 64;
         f32x4 *hq1 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 0) * ntl + tile) * NH * 64;
-        spl_coupling_bwd<NTh, NH, TEAM>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch, gq2, hq2, item_stride
+        spl_coupling_bwd<NTh, NH, TEAM>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, cmask, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch, gq2, hq2, item_stride
 #ifdef NNEST_STAMP
             , cb_t
 #endif
             );
         SPL_STAMP(2)
         // first coupling: upper' = RQS(upper; f1(lower))      (networks.py:582-588)
-        spl_coupling_bwd<NTh, NH, TEAM>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch, gq1, hq1, item_stride
+        spl_coupling_bwd<NTh, NH, TEAM>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, cmask, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch, gq1, hq1, item_stride
 #ifdef NNEST_STAMP
             , cb_t
 #endif
@@ -698,7 +708,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
             f32x4 av0[T2], gs0[T2];
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
-                av0[t] = ok ? av[t / NTh][t % NTh] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                av0[t] = okc ? av[t / NTh][t % NTh] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 gs0[t] = gs[t / NTh][t % NTh];
             }
             tile_transpose_batch<T2>(lds17, lane, av0, aT);
@@ -733,8 +743,9 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #pragma unroll
             for (int t = 0; t < NTh; ++t) {
                 const f32x4 gx = ga[hf][t] * es[hf][t];
-                const f32x4 dsum = rows_sum(gx * xin[hf][t]);
-                const f32x4 tsum = rows_sum(ga[hf][t]);
+                const f32x4 gac = cmask ? ga[hf][t] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 dsum = rows_sum(gac * es[hf][t] * xin[hf][t]);
+                const f32x4 tsum = rows_sum(gac);
                 // every lane of every wave holds the sums: lane w < 4 of wave (hf NTh + t) mod TEAM writes register r = w
                 if (w < 4 && (TEAM == 1 || wv == ((hf * NTh + t) & (TEAM - 1)))) {
                     const int d = tslot_dim(s, hf, t, w, g);
@@ -754,7 +765,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     if (mode == SPL_MODE_VJP) {
         f32x4 gp4[2][NTh];
         spl_to_parity<NTh>(buf, D, s.nl, lane, gs, gp4);
-        if (wv == 0) store_tile<NTh>(a.gx, row, ok, D, lane, gp4);
+        if (wv == 0) store_tile<NTh>(a.gx, row, okc, D, lane, gp4);
     }
 }
 
@@ -1043,14 +1054,14 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
         // Every global load of the head's update is issued up front, in one batch (old parameters, the tiles' partial sums, the Adam
         // state of the elements this lane will step): taken phase by phase they were three dependent round trips to memory.
         const int lane = tid & 63, wave = tid >> 6, nwv = (int)(blockDim.x >> 6), nt = (D + 15) >> 4, li = lane & 15, lk = lane >> 4;
-        const bool tiles8 = a.tiles <= 8;
+        const bool tiles16 = a.tiles <= 16;
         auto tile_sum = [&](const float *p) {
-            if (!tiles8) return spl_sum_tiles(p, n, a.tiles);
-            float v[8], acc = 0.f;
+            if (!tiles16) return spl_sum_tiles(p, n, a.tiles);
+            float v[16], acc = 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(u < a.tiles ? u : a.tiles - 1) * n];
+            for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(u < a.tiles ? u : a.tiles - 1) * n];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += u < a.tiles ? v[u] : 0.f;
+            for (int u = 0; u < 16; ++u) acc += u < a.tiles ? v[u] : 0.f;
             return acc;
         };
         // (a) the elements of the two products' output tiles this lane holds: [tile u][4 accumulator registers + S on the diagonal]
@@ -1478,7 +1489,7 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
         h->adam_step = 0;
         h->w_dev_current = false;
     }
-    const int tiles = (max_rows + 15) / 16 > 32 ? (max_rows + 15) / 16 : 32;  // batches of <= 128 rows run 4 rows per tile: 32 tiles
+    const int tiles = (max_rows + 7) / 8 > 40 ? (max_rows + 7) / 8 : 40;
     if (tiles > h->partial_tiles) {
         if (h->partial) { (void)hipFree(h->partial); (void)hipFree(h->stash); (void)hipFree(h->gbuf); (void)hipFree(h->hbuf); }
         SHIP_TRY(hipMalloc((void **)&h->partial, (size_t)tiles * ts.gw_floats * sizeof(float)));
@@ -1501,8 +1512,8 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
     return NNEST_OK;
 }
 
-// the per-wave instruction stream does not shrink with fewer rows per tile (measured: no gain from 4-row tiles), so 16
-static int rows_per_tile(int M) { (void)M; return 16; }
+// 8-row tiles, the rows held in both halves of the 16 columns (spl_grad_kernel): a minibatch of 100 rows is 13 workgroups
+static int rows_per_tile(int M) { (void)M; return SPL_ROWS_PER_TILE; }
 
 static int build_timage(nnest_spline *h, const SplTrainShape &ts, hipStream_t st, const int *stop = nullptr) {
     hipLaunchKernelGGL(spl_assemble_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev, h->wmat, ts, stop);
@@ -1654,7 +1665,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
     SHIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
     int chunks = 0;
     bool stopped_seen = false;
-    const int vtiles = (n_valid + 15) / 16;
+    const int vtiles = (n_valid + rows_per_tile(n_valid) - 1) / rows_per_tile(n_valid);
     // the state after epoch `done` epochs: snapshot every CHUNK epochs, looked at one chunk later
     auto snapshot = [&](int done) -> int {
         if (done % CHUNK != 0 || done >= max_epochs) return NNEST_OK;
