@@ -308,7 +308,7 @@ __device__ __forceinline__ f32x4 rows_sum(f32x4 v) {
 // Team of four waves per tile (TEAM = 4): wave wv owns the super-tiles s = wv (mod 4) -- their spline reverse mode, last-layer
 // weight gradients and share of g_h3 -- and the hidden layers' weight gradients are dealt out one layer per wave; the
 // delta propagation through the trunk is repeated by every wave so that all four leave with the same g_tr / g_cond.
-template <int NTh, int NH, int TEAM>
+template <int NTh, int NH, int TEAM, bool DUP>
 __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const float *__restrict__ cf, const float *__restrict__ cbw, int pnet,
                                                  int nin, int nout, int S, int lane, bool row_ok, bool cmask, float gld, float *lds17, float *gp,
                                                  const f32x4 (&cond)[NTh], const f32x4 (&x_tr)[NTh], f32x4 (&g_tr)[NTh], f32x4 (&g_cond)[NTh],
@@ -346,29 +346,93 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
 #pragma unroll
     for (int ht = 0; ht < NH; ++ht) g_h[ht] = (f32x4){0.f, 0.f, 0.f, 0.f};
     CB_STAMP(0)
+    if constexpr (DUP) {
+        // the wave's super-tiles s = wv + 4k two at a time, (k, k + 1) in the low / high half of the columns (spl_coupling_pair)
+        const bool lo = w < 8;
 #pragma unroll
-    for (int s = 0; s < 4 * NTh; ++s) {
-        if (s < S && (TEAM == 1 || (s & (TEAM - 1)) == wv)) {
-            f32x4 raw[SPL_QT], graw[SPL_QT];
-            spl_raw<NH>(L4, b4, s, lane, h[2], raw);
-            const bool valid = row_ok && (4 * s + g < nout);
-            const float x = reg_of(x_tr[s >> 2], s & 3);
-            const float gy = valid ? reg_of(g_tr[s >> 2], s & 3) : 0.f;
-            float y, lad;
-            const float gx = spl_rqs_fwd_bwd(raw, tail, x, gy, valid ? gld : 0.f, y, lad, graw);
-            set_reg(g_tr[s >> 2], s & 3, valid ? gx : 0.f);
+        for (int r = 0; r < 4; ++r) {
+            if (r != wv) continue;  // uniform over the wave
 #pragma unroll
-            for (int q = 0; q < SPL_QT; ++q) {
-                if (!valid) graw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                // last layer: G to memory (dW3, db3: spl_w3_item), g_h3 += W3^T G
-                gq[(size_t)(s * SPL_QT + q) * item_stride + lane] = cmask ? graw[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < NTh; k += 2) {
+                const int sA = 4 * k + r, sB = 4 * (k + 1) + r;
+                if (sA >= S) continue;
+                const bool hasB = (k + 1 < NTh) && sB < S;
+                const int kb = (k + 1 < NTh) ? k + 1 : k;  // (in range for odd NTh)
+                f32x4 raw[SPL_QT], graw[SPL_QT];
+                spl_raw<NH>(L4, b4, sA, lane, h[2], raw);
+                float x = reg_of(x_tr[k], r), gyr = reg_of(g_tr[k], r);
+                if (k + 1 < NTh) {
+                    if (hasB) {
+                        f32x4 rawB[SPL_QT];
+                        spl_raw<NH>(L4, b4, sB, lane, h[2], rawB);
 #pragma unroll
-                for (int hto = 0; hto < NH; ++hto) {
-                    const float *a = B4 + (size_t)(((s * SPL_QT + q) * NH + hto) * 4) * 64 + lane;
-                    g_h[hto] = mfma4(a[0], graw[q].x, g_h[hto]);
-                    g_h[hto] = mfma4(a[64], graw[q].y, g_h[hto]);
-                    g_h[hto] = mfma4(a[128], graw[q].z, g_h[hto]);
-                    g_h[hto] = mfma4(a[192], graw[q].w, g_h[hto]);
+                        for (int q = 0; q < SPL_QT; ++q) raw[q] = sel4(lo, raw[q], rawB[q]);
+                    }
+                    x = lo ? x : reg_of(x_tr[kb], r);
+                    gyr = lo ? gyr : reg_of(g_tr[kb], r);
+                }
+                const bool valid = row_ok && (lo ? (4 * sA + g < nout) : (hasB && 4 * sB + g < nout));
+                const float gy = valid ? gyr : 0.f;
+                float y, lad;
+                const float gx = spl_rqs_fwd_bwd(raw, tail, x, gy, valid ? gld : 0.f, y, lad, graw);
+                const float gxo = valid ? gx : 0.f, gxp = half_swap(gxo);
+                set_reg(g_tr[k], r, lo ? gxo : gxp);
+                if (k + 1 < NTh && hasB) set_reg(g_tr[kb], r, lo ? gxp : gxo);
+                const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < SPL_QT; ++q) {
+                    if (!valid) graw[q] = zero4;
+                    // last layer: G to memory (dW3, db3: spl_w3_item; each row once: A from the low lanes, B from the high ones),
+                    // g_h3 += W3^T G
+                    const f32x4 gA = lo ? graw[q] : zero4, gB = lo ? zero4 : graw[q];
+                    gq[(size_t)(sA * SPL_QT + q) * item_stride + lane] = gA;
+#pragma unroll
+                    for (int hto = 0; hto < NH; ++hto) {
+                        const float *a = B4 + (size_t)(((sA * SPL_QT + q) * NH + hto) * 4) * 64 + lane;
+                        g_h[hto] = mfma4(a[0], gA.x, g_h[hto]);
+                        g_h[hto] = mfma4(a[64], gA.y, g_h[hto]);
+                        g_h[hto] = mfma4(a[128], gA.z, g_h[hto]);
+                        g_h[hto] = mfma4(a[192], gA.w, g_h[hto]);
+                    }
+                    if (hasB) {
+                        gq[(size_t)(sB * SPL_QT + q) * item_stride + lane] = gB;
+#pragma unroll
+                        for (int hto = 0; hto < NH; ++hto) {
+                            const float *a = B4 + (size_t)(((sB * SPL_QT + q) * NH + hto) * 4) * 64 + lane;
+                            g_h[hto] = mfma4(a[0], gB.x, g_h[hto]);
+                            g_h[hto] = mfma4(a[64], gB.y, g_h[hto]);
+                            g_h[hto] = mfma4(a[128], gB.z, g_h[hto]);
+                            g_h[hto] = mfma4(a[192], gB.w, g_h[hto]);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4 * NTh; ++s) {
+            if (s < S && (TEAM == 1 || (s & (TEAM - 1)) == wv)) {
+                f32x4 raw[SPL_QT], graw[SPL_QT];
+                spl_raw<NH>(L4, b4, s, lane, h[2], raw);
+                const bool valid = row_ok && (4 * s + g < nout);
+                const float x = reg_of(x_tr[s >> 2], s & 3);
+                const float gy = valid ? reg_of(g_tr[s >> 2], s & 3) : 0.f;
+                float y, lad;
+                const float gx = spl_rqs_fwd_bwd(raw, tail, x, gy, valid ? gld : 0.f, y, lad, graw);
+                set_reg(g_tr[s >> 2], s & 3, valid ? gx : 0.f);
+#pragma unroll
+                for (int q = 0; q < SPL_QT; ++q) {
+                    if (!valid) graw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    // last layer: G to memory (dW3, db3: spl_w3_item), g_h3 += W3^T G
+                    gq[(size_t)(s * SPL_QT + q) * item_stride + lane] = cmask ? graw[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int hto = 0; hto < NH; ++hto) {
+                        const float *a = B4 + (size_t)(((s * SPL_QT + q) * NH + hto) * 4) * 64 + lane;
+                        g_h[hto] = mfma4(a[0], graw[q].x, g_h[hto]);
+                        g_h[hto] = mfma4(a[64], graw[q].y, g_h[hto]);
+                        g_h[hto] = mfma4(a[128], graw[q].z, g_h[hto]);
+                        g_h[hto] = mfma4(a[192], graw[q].w, g_h[hto]);
+                    }
                 }
             }
         }
@@ -389,7 +453,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
             f32x4 acc = xch[(TEAM * NTh + 0 * NH + ht) * 64 + lane];
 #pragma unroll
             for (int k = 1; k < TEAM; ++k) acc = acc + xch[(TEAM * NTh + k * NH + ht) * 64 + lane];
-            g_h[ht] = acc;
+            g_h[ht] = DUP ? acc + half_swap4(acc) : acc;  // (DUP: column w has the A share, column w ^ 8 the B share of the row)
         }
         spl_team_barrier();
     }
@@ -497,9 +561,6 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
 #define SPL_TEAM_N 4
 #endif
 enum { SPL_TEAM = SPL_TEAM_N };
-#ifndef SPL_ROWS_PER_TILE
-#define SPL_ROWS_PER_TILE 8
-#endif
 
 template <int NTh, int NH>
 __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) {
@@ -521,7 +582,8 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     // rows_per_tile 8: the tile's 8 rows sit in BOTH halves of the 16 matrix-core columns (lanes w and w + 8 carry row w & 7).
     // The halves run the spline stage on different dimensions (spl_coupling_pair*), everything else is computed twice and the
     // sums over rows take the low half only (`okc`).
-    const bool dup = a.rows_per_tile == 8;
+    constexpr bool DUP = NTh >= 2;  // (one tile per half: every wave has at most one super-tile per coupling, nothing to pair)
+    const bool dup = DUP;
     const int row = (vtile ? tile - ntl : tile) * a.rows_per_tile + (dup ? (w & 7) : w);
     const bool ok = (dup || w < a.rows_per_tile) && row < (vtile ? a.Mv : a.M);
     const bool cmask = !dup || w < 8, okc = ok && cmask;
@@ -608,13 +670,15 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
             for (int t = 0; t < NTh; ++t) av[hf][t] = xs[hf][t] * es[hf][t] + tv[hf][t];
         spl_matmul<NTh>(blk, lane, av, c);
         const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
-        ld += spl_coupling<NTh, NH, false, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch);
+        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch)
+                  : spl_coupling<NTh, NH, false, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch);
         if (mode != SPL_MODE_LOSS) {  // upper' conditions the second coupling: kept for the backward pass
 #pragma unroll
             for (int t = 0; t < NTh; ++t) stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
         }
-        ld += spl_coupling<NTh, NH, false, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch);
-        if (lane < 16 && wv == 0) ld += blk[ts.tblk_floats - 4];
+        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch)
+                  : spl_coupling<NTh, NH, false, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch);
+        if (lane < (DUP ? 8 : 16) && wv == 0) ld += blk[ts.tblk_floats - 4];  // (once per row: DUP adds the halves up below)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -629,6 +693,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         for (int k = 0; k < TEAM; ++k) ld += ldred[k * 16 + w];
         spl_team_barrier();
     }
+    if (DUP) ld += half_swap(ld);  // a row's log|det|: the shares of its two halves
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -688,14 +753,14 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         f32x4 *gq1 = reinterpret_cast<f32x4 *>(a.gbuf) + ((size_t)(2 * b + 0) * ts.SM * SPL_QT * ntl + tile) * 64;
         f32x4 *hq2 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 1) * ntl + tile) * NH * 64;
         f32x4 *hq1 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 0) * ntl + tile) * NH * 64;
-        spl_coupling_bwd<NTh, NH, TEAM>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, cmask, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch, gq2, hq2, item_stride
+        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, cmask, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch, gq2, hq2, item_stride
 #ifdef NNEST_STAMP
             , cb_t
 #endif
             );
         SPL_STAMP(2)
         // first coupling: upper' = RQS(upper; f1(lower))      (networks.py:582-588)
-        spl_coupling_bwd<NTh, NH, TEAM>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, cmask, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch, gq1, hq1, item_stride
+        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, cmask, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch, gq1, hq1, item_stride
 #ifdef NNEST_STAMP
             , cb_t
 #endif
@@ -1512,8 +1577,9 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
     return NNEST_OK;
 }
 
-// 8-row tiles, the rows held in both halves of the 16 columns (spl_grad_kernel): a minibatch of 100 rows is 13 workgroups
-static int rows_per_tile(int M) { (void)M; return SPL_ROWS_PER_TILE; }
+// x_dim > 32: 8-row tiles, the rows held in both halves of the 16 columns (spl_grad_kernel): a minibatch of 100 rows is 13
+// workgroups; up to x_dim 32 (one tile per half) the plain 16-row tiles
+static int rows_per_tile(const nnest::SplineShape &s) { return s.NTh >= 2 ? 8 : 16; }
 
 static int build_timage(nnest_spline *h, const SplTrainShape &ts, hipStream_t st, const int *stop = nullptr) {
     hipLaunchKernelGGL(spl_assemble_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev, h->wmat, ts, stop);
@@ -1567,7 +1633,7 @@ int nnest_spline_loss_grad(nnest_spline_t *h, const float *x_dev, int M, float *
     memset(&a, 0, sizeof(a));
     a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = x_dev; a.M = M; a.mtot = M; a.partial = h->partial; a.stash = h->stash;
     a.mode = SPL_MODE_GRAD; a.gbuf = h->gbuf; a.hbuf = h->hbuf;
-    a.rows_per_tile = rows_per_tile(M);
+    a.rows_per_tile = rows_per_tile(h->s);
     SHIP_TRY(launch_grad(a, st));
     SHIP_TRY(launch_w3(a, grad_dev, st));
     const int tiles = grad_tiles(a);
@@ -1591,7 +1657,7 @@ int nnest_spline_vjp(nnest_spline_t *h, const float *x_dev, const float *gz_dev,
     memset(&a, 0, sizeof(a));
     a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = x_dev; a.M = M; a.mtot = M; a.partial = h->partial; a.stash = h->stash;
     a.mode = SPL_MODE_VJP; a.gz = gz_dev; a.gx = gx_dev; a.gld_in = gld; a.gbuf = h->gbuf; a.hbuf = h->hbuf;
-    a.rows_per_tile = rows_per_tile(M);
+    a.rows_per_tile = rows_per_tile(h->s);
     SHIP_TRY(launch_grad(a, st));
     SHIP_TRY(launch_w3(a, grad_dev, st));
     hipLaunchKernelGGL(spl_reduce_kernel, dim3(256), dim3(256), 0, st, h->partial, grad_tiles(a), ts, h->w_dev, grad_dev, h->gwsum,
@@ -1665,7 +1731,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
     SHIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
     int chunks = 0;
     bool stopped_seen = false;
-    const int vtiles = (n_valid + rows_per_tile(n_valid) - 1) / rows_per_tile(n_valid);
+    const int vtiles = (n_valid + rows_per_tile(h->s) - 1) / rows_per_tile(h->s);
     // the state after epoch `done` epochs: snapshot every CHUNK epochs, looked at one chunk later
     auto snapshot = [&](int done) -> int {
         if (done % CHUNK != 0 || done >= max_epochs) return NNEST_OK;
@@ -1683,7 +1749,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
         memset(&a, 0, sizeof(a));
         a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = xvalid_dev; a.M = n_valid; a.mtot = n_valid;
         a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_LOSS; a.stop = stop;
-        a.rows_per_tile = rows_per_tile(n_valid);
+        a.rows_per_tile = rows_per_tile(h->s);
         return a;
     };
     for (int epoch = 0; epoch < max_epochs && !stopped_seen; ++epoch) {
@@ -1695,7 +1761,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             a.M = M; a.mtot = M; a.noise = noise_dev ? noise_dev + ((size_t)epoch * n_train + (size_t)mb * batch) * D : nullptr;
             a.seed = seed; a.noise_row0 = (long)mb * batch; a.epoch = epoch; a.jitter = jitter;
             a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_GRAD; a.stop = stop; a.gbuf = h->gbuf; a.hbuf = h->hbuf;
-            a.rows_per_tile = rows_per_tile(M);
+            a.rows_per_tile = rows_per_tile(h->s);
             const int tiles = grad_tiles(a);
             h->adam_step += 1;
             const double bc1 = 1.0 - pow(0.9, (double)h->adam_step), bc2 = 1.0 - pow(0.999, (double)h->adam_step);

@@ -137,6 +137,69 @@ __device__ __forceinline__ void spl_raw(const float *__restrict__ L4, const floa
     }
 }
 
+// ---- the two halves of the 16 columns (8-row tiles of the training kernel: lanes w and w ^ 8 carry the same row) ----------------
+// value of the partner lane w ^ 8 (DPP row_ror:8 inside the 16-lane row)
+__device__ __forceinline__ float half_swap(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+}
+__device__ __forceinline__ f32x4 half_swap4(f32x4 v) { return (f32x4){half_swap(v.x), half_swap(v.y), half_swap(v.z), half_swap(v.w)}; }
+__device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return (f32x4){c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w}; }
+
+// Forward coupling of the training kernel.  Wave wv owns the super-tiles s = wv + 4k (register wv of tile k); it takes them two
+// at a time: (k, k + 1) go to the low / high half of the columns, so ONE spline evaluation per lane serves two super-tiles
+// (the matrix work per super-tile is unchanged, the spline arithmetic -- the bulk of the instruction stream -- halves).
+// Both halves leave with the full transformed half again (results swapped across).  Returns this lane's share of log|det|.
+template <int NTh, int NH, int TEAM>
+__device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net, int S, int n_out, float tail, int lane,
+                                                   const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv, f32x4 *xch) {
+    static_assert(TEAM == 4, "one wave per register of a tile");
+    const int g = lane >> 4;
+    const bool lo = (lane & 15) < 8;
+    f32x4 h[NH];
+    spl_hidden<NTh, NH>(net, lane, cond, h);
+    const float *L4 = net + spl_cond_hidden_floats(NTh, NH);
+    const float *b4 = L4 + (size_t)S * SPL_QT * NH * 256;
+    float ld = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r != wv) continue;  // uniform over the wave
+#pragma unroll
+        for (int k = 0; k < NTh; k += 2) {
+            const int sA = 4 * k + r, sB = 4 * (k + 1) + r;
+            if (sA >= S) continue;
+            const bool hasB = (k + 1 < NTh) && sB < S;
+            f32x4 raw[SPL_QT];
+            spl_raw<NH>(L4, b4, sA, lane, h, raw);
+            float x = reg_of(tr[k], r);
+            if (k + 1 < NTh) {
+                if (hasB) {
+                    f32x4 rawB[SPL_QT];
+                    spl_raw<NH>(L4, b4, sB, lane, h, rawB);
+#pragma unroll
+                    for (int q = 0; q < SPL_QT; ++q) raw[q] = sel4(lo, raw[q], rawB[q]);
+                }
+                x = lo ? x : reg_of(tr[(k + 1 < NTh) ? k + 1 : k], r);
+            }
+            const bool valid = lo ? (4 * sA + g < n_out) : (hasB && 4 * sB + g < n_out);
+            float l = 0.f;
+            const float y = spl_rqs<false>(raw, tail, x, l);
+            const float yo = valid ? y : 0.f, yp = half_swap(yo);
+            ld += valid ? l : 0.f;
+            set_reg(tr[k], r, lo ? yo : yp);
+            if (k + 1 < NTh && hasB) set_reg(tr[(k + 1 < NTh) ? k + 1 : k], r, lo ? yp : yo);
+        }
+    }
+    // super-tile s = 4t + r (register r of tile t) comes from wave r
+#pragma unroll
+    for (int t = 0; t < NTh; ++t) xch[(wv * NTh + t) * 64 + lane] = tr[t];
+    spl_team_barrier();
+#pragma unroll
+    for (int t = 0; t < NTh; ++t)
+        tr[t] = (f32x4){xch[(0 * NTh + t) * 64 + lane].x, xch[(1 * NTh + t) * 64 + lane].y, xch[(2 * NTh + t) * 64 + lane].z, xch[(3 * NTh + t) * 64 + lane].w};
+    spl_team_barrier();
+    return ld;
+}
+
 // ---- reverse mode through one axis' knot construction (spl_knots): gradient wrt the 8 logits -----------------------
 // edge_k = -B + 2B sum_{i<k} w_i, size_k = 2B w_k, w = m + (1 - mK) softmax(2B softmax(logits))
 // g_edge = dLoss/d(edge of the selected bin), g_size = dLoss/d(size of the selected bin)
