@@ -234,7 +234,7 @@ int nnest_spline_destroy(nnest_spline_t *h) {
     (void)hipFree(h->img);
     (void)hipFree(h->w_dev); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->best_w); (void)hipFree(h->pi_dev); (void)hipFree(h->pos_dev);
     (void)hipFree(h->wmat); (void)hipFree(h->timg); (void)hipFree(h->partial); (void)hipFree(h->grad); (void)hipFree(h->gwsum);
-    (void)hipFree(h->stash); (void)hipFree(h->gbuf); (void)hipFree(h->hbuf); (void)hipFree(h->losses_dev); (void)hipFree(h->ctl_dev); (void)hipFree(h->epoch_losses_dev);
+    (void)hipFree(h->stash); (void)hipFree(h->gbuf); (void)hipFree(h->hbuf); (void)hipFree(h->keep); (void)hipFree(h->losses_dev); (void)hipFree(h->ctl_dev); (void)hipFree(h->epoch_losses_dev);
     if (h->ctl_host) (void)hipHostFree(h->ctl_host);
     delete h;
     return NNEST_OK;

@@ -240,6 +240,7 @@ struct SplGradArgs {
     float gld_in;       // VJP: dL/d(logdet)
     const int *stop;    // early-stopping flag (see spl_assemble_kernel) or NULL
     float *gbuf;        // [B][2][SM][SPL_QT][tiles][64] f32x4: dLoss/d(raw spline parameters) of every row, per coupling
+    float *keep;        // [tiles][TEAM][B][2][spl_keep_floats4][64] f32x4: activations and spline parameters kept for the backward pass
     float *hbuf;        // [B][2][tiles][NH][64] f32x4: the conditioners' last hidden activations (spl_w3_item contracts the two)
     int val_tiles;      // training loop: workgroups past the batch's own tiles run the forward-only pass over the validation rows
     const float *xv;    //   (the previous epoch's validation loss, trainer.py:405-418, in the shadow of this minibatch's gradient pass)
@@ -312,7 +313,7 @@ template <int NTh, int NH, int TEAM, bool DUP>
 __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const float *__restrict__ cf, const float *__restrict__ cbw, int pnet,
                                                  int nin, int nout, int S, int lane, bool row_ok, bool cmask, float gld, float *lds17, float *gp,
                                                  const f32x4 (&cond)[NTh], const f32x4 (&x_tr)[NTh], f32x4 (&g_tr)[NTh], f32x4 (&g_cond)[NTh],
-                                                 int wv, f32x4 *xch, f32x4 *__restrict__ gq, f32x4 *__restrict__ hq, int item_stride
+                                                 int wv, f32x4 *xch, f32x4 *__restrict__ gq, f32x4 *__restrict__ hq, int item_stride, const f32x4 *__restrict__ keep
 #ifdef NNEST_STAMP
                                                  , long long *cst
 #endif
@@ -326,7 +327,14 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
     const int g = lane >> 4, w = lane & 15, H = ts.s.H;
     const float tail = ts.s.tail;
     f32x4 h[3][NH];
-    spl_hidden_keep<NTh, NH>(cf, lane, cond, h);
+    if constexpr (DUP) {  // kept by the forward pass (spl_coupling_pair)
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int ht = 0; ht < NH; ++ht) h[l][ht] = keep[(l * NH + ht) * 64 + lane];
+    } else {
+        spl_hidden_keep<NTh, NH>(cf, lane, cond, h);
+    }
     const float *L4 = cf + spl_cond_hidden_floats(NTh, NH);
     const float *b4 = L4 + (size_t)S * SPL_QT * NH * 256;
     const float *B1 = cbw, *B2 = cbw + NTh * NH * 256, *B3 = B2 + NH * NH * 256, *B4 = B3 + NH * NH * 256;
@@ -359,15 +367,10 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
                 const bool hasB = (k + 1 < NTh) && sB < S;
                 const int kb = (k + 1 < NTh) ? k + 1 : k;  // (in range for odd NTh)
                 f32x4 raw[SPL_QT], graw[SPL_QT];
-                spl_raw<NH>(L4, b4, sA, lane, h[2], raw);
+#pragma unroll
+                for (int q = 0; q < SPL_QT; ++q) raw[q] = keep[(3 * NH + (k >> 1) * SPL_QT + q) * 64 + lane];  // (each half its own parameters)
                 float x = reg_of(x_tr[k], r), gyr = reg_of(g_tr[k], r);
                 if (k + 1 < NTh) {
-                    if (hasB) {
-                        f32x4 rawB[SPL_QT];
-                        spl_raw<NH>(L4, b4, sB, lane, h[2], rawB);
-#pragma unroll
-                        for (int q = 0; q < SPL_QT; ++q) raw[q] = sel4(lo, raw[q], rawB[q]);
-                    }
                     x = lo ? x : reg_of(x_tr[kb], r);
                     gyr = lo ? gyr : reg_of(g_tr[kb], r);
                 }
@@ -670,13 +673,14 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
             for (int t = 0; t < NTh; ++t) av[hf][t] = xs[hf][t] * es[hf][t] + tv[hf][t];
         spl_matmul<NTh>(blk, lane, av, c);
         const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
-        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch)
+        f32x4 *kpf = mode != SPL_MODE_LOSS ? reinterpret_cast<f32x4 *>(a.keep) + (((size_t)tile * TEAM + wv) * B + b) * 2 * spl_keep_floats4(NTh, NH) * 64 : nullptr;
+        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch, kpf)
                   : spl_coupling<NTh, NH, false, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch);
         if (mode != SPL_MODE_LOSS) {  // upper' conditions the second coupling: kept for the backward pass
 #pragma unroll
             for (int t = 0; t < NTh; ++t) stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
         }
-        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch)
+        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch, kpf ? kpf + spl_keep_floats4(NTh, NH) * 64 : nullptr)
                   : spl_coupling<NTh, NH, false, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch);
         if (lane < (DUP ? 8 : 16) && wv == 0) ld += blk[ts.tblk_floats - 4];  // (once per row: DUP adds the halves up below)
 #pragma unroll
@@ -753,14 +757,15 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         f32x4 *gq1 = reinterpret_cast<f32x4 *>(a.gbuf) + ((size_t)(2 * b + 0) * ts.SM * SPL_QT * ntl + tile) * 64;
         f32x4 *hq2 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 1) * ntl + tile) * NH * 64;
         f32x4 *hq1 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 0) * ntl + tile) * NH * 64;
-        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, cmask, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch, gq2, hq2, item_stride
+        const f32x4 *kp = reinterpret_cast<const f32x4 *>(a.keep) + (((size_t)tile * TEAM + wv) * B + b) * 2 * spl_keep_floats4(NTh, NH) * 64;
+        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, cmask, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch, gq2, hq2, item_stride, kp + spl_keep_floats4(NTh, NH) * 64
 #ifdef NNEST_STAMP
             , cb_t
 #endif
             );
         SPL_STAMP(2)
         // first coupling: upper' = RQS(upper; f1(lower))      (networks.py:582-588)
-        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, cmask, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch, gq1, hq1, item_stride
+        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, cmask, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch, gq1, hq1, item_stride, kp
 #ifdef NNEST_STAMP
             , cb_t
 #endif
@@ -1556,11 +1561,12 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
     }
     const int tiles = (max_rows + 7) / 8 > 40 ? (max_rows + 7) / 8 : 40;
     if (tiles > h->partial_tiles) {
-        if (h->partial) { (void)hipFree(h->partial); (void)hipFree(h->stash); (void)hipFree(h->gbuf); (void)hipFree(h->hbuf); }
+        if (h->partial) { (void)hipFree(h->partial); (void)hipFree(h->stash); (void)hipFree(h->gbuf); (void)hipFree(h->hbuf); (void)hipFree(h->keep); }
         SHIP_TRY(hipMalloc((void **)&h->partial, (size_t)tiles * ts.gw_floats * sizeof(float)));
         SHIP_TRY(hipMalloc((void **)&h->stash, (size_t)tiles * SPL_TEAM * B * 3 * h->s.NTh * 64 * 4 * sizeof(float)));
         SHIP_TRY(hipMalloc((void **)&h->gbuf, (size_t)2 * B * ts.SM * SPL_QT * tiles * 256 * sizeof(float)));
         SHIP_TRY(hipMalloc((void **)&h->hbuf, (size_t)2 * B * tiles * h->s.NH * 256 * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->keep, (size_t)tiles * SPL_TEAM * B * 2 * spl_keep_floats4(h->s.NTh, h->s.NH) * 256 * sizeof(float)));
         h->partial_tiles = tiles;
     }
     if (!h->w_dev_current) {
@@ -1632,7 +1638,7 @@ int nnest_spline_loss_grad(nnest_spline_t *h, const float *x_dev, int M, float *
     SplGradArgs a;
     memset(&a, 0, sizeof(a));
     a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = x_dev; a.M = M; a.mtot = M; a.partial = h->partial; a.stash = h->stash;
-    a.mode = SPL_MODE_GRAD; a.gbuf = h->gbuf; a.hbuf = h->hbuf;
+    a.mode = SPL_MODE_GRAD; a.gbuf = h->gbuf; a.hbuf = h->hbuf; a.keep = h->keep;
     a.rows_per_tile = rows_per_tile(h->s);
     SHIP_TRY(launch_grad(a, st));
     SHIP_TRY(launch_w3(a, grad_dev, st));
@@ -1656,7 +1662,7 @@ int nnest_spline_vjp(nnest_spline_t *h, const float *x_dev, const float *gz_dev,
     SplGradArgs a;
     memset(&a, 0, sizeof(a));
     a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = x_dev; a.M = M; a.mtot = M; a.partial = h->partial; a.stash = h->stash;
-    a.mode = SPL_MODE_VJP; a.gz = gz_dev; a.gx = gx_dev; a.gld_in = gld; a.gbuf = h->gbuf; a.hbuf = h->hbuf;
+    a.mode = SPL_MODE_VJP; a.gz = gz_dev; a.gx = gx_dev; a.gld_in = gld; a.gbuf = h->gbuf; a.hbuf = h->hbuf; a.keep = h->keep;
     a.rows_per_tile = rows_per_tile(h->s);
     SHIP_TRY(launch_grad(a, st));
     SHIP_TRY(launch_w3(a, grad_dev, st));
@@ -1760,7 +1766,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             a.timg = h->timg; a.w = h->w_dev; a.ts = ts; a.x = xtrain_dev; a.perm = perm_dev + (size_t)epoch * n_train + (size_t)mb * batch;
             a.M = M; a.mtot = M; a.noise = noise_dev ? noise_dev + ((size_t)epoch * n_train + (size_t)mb * batch) * D : nullptr;
             a.seed = seed; a.noise_row0 = (long)mb * batch; a.epoch = epoch; a.jitter = jitter;
-            a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_GRAD; a.stop = stop; a.gbuf = h->gbuf; a.hbuf = h->hbuf;
+            a.partial = h->partial; a.stash = h->stash; a.mode = SPL_MODE_GRAD; a.stop = stop; a.gbuf = h->gbuf; a.hbuf = h->hbuf; a.keep = h->keep;
             a.rows_per_tile = rows_per_tile(h->s);
             const int tiles = grad_tiles(a);
             h->adam_step += 1;

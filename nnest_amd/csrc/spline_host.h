@@ -20,6 +20,7 @@ struct nnest_spline {
     float *grad;              // reduced packed gradient
     float *gwsum;             // reduced dLoss/dW of the convs [B][D][D]
     float *stash;             // block inputs of the forward pass
+    float *keep;              // activations and spline parameters the forward pass keeps for the backward pass
     float *gbuf, *hbuf;       // per coupling: dLoss/d(raw spline parameters) and the last hidden activations of every row (spl_w3_*)
     float *losses_dev;        // per-step losses of an epoch + validation
     void *ctl_dev;            // SplTrainCtl: the early-stopping state of a training call (kept on the device)

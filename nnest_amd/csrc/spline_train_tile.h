@@ -145,18 +145,33 @@ __device__ __forceinline__ float half_swap(float v) {
 __device__ __forceinline__ f32x4 half_swap4(f32x4 v) { return (f32x4){half_swap(v.x), half_swap(v.y), half_swap(v.z), half_swap(v.w)}; }
 __device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return (f32x4){c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w}; }
 
+// f32x4 per lane that one wave keeps per coupling (spl_coupling_pair): 3 NH activations + 6 per pair of super-tiles
+__host__ __device__ inline int spl_keep_floats4(int NTh, int NH) { return 3 * NH + ((NTh + 1) / 2) * SPL_QT; }
+
 // Forward coupling of the training kernel.  Wave wv owns the super-tiles s = wv + 4k (register wv of tile k); it takes them two
 // at a time: (k, k + 1) go to the low / high half of the columns, so ONE spline evaluation per lane serves two super-tiles
 // (the matrix work per super-tile is unchanged, the spline arithmetic -- the bulk of the instruction stream -- halves).
 // Both halves leave with the full transformed half again (results swapped across).  Returns this lane's share of log|det|.
 template <int NTh, int NH, int TEAM>
 __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net, int S, int n_out, float tail, int lane,
-                                                   const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv, f32x4 *xch) {
+                                                   const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv, f32x4 *xch,
+                                                   f32x4 *__restrict__ keep = nullptr) {
     static_assert(TEAM == 4, "one wave per register of a tile");
     const int g = lane >> 4;
     const bool lo = (lane & 15) < 8;
+    // `keep` (this wave's slice, spl_keep_floats4): the three hidden activations and the spline parameters of the wave's pairs
+    // stay for the backward pass, which then neither repeats the trunk nor the last layer
+    f32x4 hk[3][NH];
+    spl_hidden_keep<NTh, NH>(net, lane, cond, hk);
     f32x4 h[NH];
-    spl_hidden<NTh, NH>(net, lane, cond, h);
+#pragma unroll
+    for (int ht = 0; ht < NH; ++ht) h[ht] = hk[2][ht];
+    if (keep) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int ht = 0; ht < NH; ++ht) keep[(l * NH + ht) * 64 + lane] = hk[l][ht];
+    }
     const float *L4 = net + spl_cond_hidden_floats(NTh, NH);
     const float *b4 = L4 + (size_t)S * SPL_QT * NH * 256;
     float ld = 0.f;
@@ -179,6 +194,10 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
                     for (int q = 0; q < SPL_QT; ++q) raw[q] = sel4(lo, raw[q], rawB[q]);
                 }
                 x = lo ? x : reg_of(tr[(k + 1 < NTh) ? k + 1 : k], r);
+            }
+            if (keep) {
+#pragma unroll
+                for (int q = 0; q < SPL_QT; ++q) keep[(3 * NH + (k >> 1) * SPL_QT + q) * 64 + lane] = raw[q];
             }
             const bool valid = lo ? (4 * sA + g < n_out) : (hasB && 4 * sB + g < n_out);
             float l = 0.f;
