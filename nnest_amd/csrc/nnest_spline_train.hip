@@ -564,6 +564,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
 #define SPL_TEAM_N 4
 #endif
 enum { SPL_TEAM = SPL_TEAM_N };
+enum { SPL_STASH = 7 };  // tiles of NTh f32x4 per lane the forward pass leaves per block for the backward pass
 
 template <int NTh, int NH>
 __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) {
@@ -591,7 +592,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     const bool ok = (dup || w < a.rows_per_tile) && row < (vtile ? a.Mv : a.M);
     const bool cmask = !dup || w < 8, okc = ok && cmask;
     float *gp = a.partial + (size_t)tile * ts.gw_floats;
-    f32x4 *stash = reinterpret_cast<f32x4 *>(a.stash) + ((size_t)tile * TEAM + wv) * B * 3 * NTh * 64;  // per block: input halves + upper'
+    f32x4 *stash = reinterpret_cast<f32x4 *>(a.stash) + ((size_t)tile * TEAM + wv) * B * SPL_STASH * NTh * 64;  // per block: input halves, upper', ActNorm output, conv output
 
     // The image was written by another kernel, i.e. into other XCDs' L2s: from here every fragment load of the pass would be
     // a cold miss (1.5-2 us each, and the layers consume them in small dependent batches -- by the stamps that was most of the
@@ -663,7 +664,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int t = 0; t < NTh; ++t) stash[((size_t)b * 3 * NTh + c * NTh + t) * 64 + lane] = xs[c][t];
+                for (int t = 0; t < NTh; ++t) stash[((size_t)b * SPL_STASH * NTh + c * NTh + t) * 64 + lane] = xs[c][t];
         }
         f32x4 es[2][NTh], tv[2][NTh], av[2][NTh], c[2][NTh];
         spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);
@@ -672,13 +673,22 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #pragma unroll
             for (int t = 0; t < NTh; ++t) av[hf][t] = xs[hf][t] * es[hf][t] + tv[hf][t];
         spl_matmul<NTh>(blk, lane, av, c);
+        if (mode != SPL_MODE_LOSS) {  // ActNorm and conv outputs: the backward pass does not repeat them
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int t = 0; t < NTh; ++t) {
+                    stash[((size_t)b * SPL_STASH * NTh + (3 + hf) * NTh + t) * 64 + lane] = av[hf][t];
+                    stash[((size_t)b * SPL_STASH * NTh + (5 + hf) * NTh + t) * 64 + lane] = c[hf][t];
+                }
+        }
         const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
         f32x4 *kpf = mode != SPL_MODE_LOSS ? reinterpret_cast<f32x4 *>(a.keep) + (((size_t)tile * TEAM + wv) * B + b) * 2 * spl_keep_floats4(NTh, NH) * 64 : nullptr;
         ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch, kpf)
                   : spl_coupling<NTh, NH, false, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch);
         if (mode != SPL_MODE_LOSS) {  // upper' conditions the second coupling: kept for the backward pass
 #pragma unroll
-            for (int t = 0; t < NTh; ++t) stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
+            for (int t = 0; t < NTh; ++t) stash[((size_t)b * SPL_STASH * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
         }
         ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch, kpf ? kpf + spl_keep_floats4(NTh, NH) * 64 : nullptr)
                   : spl_coupling<NTh, NH, false, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch);
@@ -738,18 +748,20 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-            for (int t = 0; t < NTh; ++t) xin[cc][t] = stash[((size_t)b * 3 * NTh + cc * NTh + t) * 64 + lane];
-        spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);
+            for (int t = 0; t < NTh; ++t) xin[cc][t] = stash[((size_t)b * SPL_STASH * NTh + cc * NTh + t) * 64 + lane];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-            for (int t = 0; t < NTh; ++t) av[hf][t] = xin[hf][t] * es[hf][t] + tv[hf][t];
+            for (int t = 0; t < NTh; ++t) {
+                av[hf][t] = stash[((size_t)b * SPL_STASH * NTh + (3 + hf) * NTh + t) * 64 + lane];
+                c[hf][t] = stash[((size_t)b * SPL_STASH * NTh + (5 + hf) * NTh + t) * 64 + lane];
+            }
+        spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);  // (e^s for the ActNorm gradients at the end of the block)
         SPL_STAMP(5)
-        spl_matmul<NTh>(blk, lane, av, c);
         // upper' = RQS(upper; f1(lower)) is the conditioning input of the second coupling
         f32x4 up2[NTh];
 #pragma unroll
-        for (int t = 0; t < NTh; ++t) up2[t] = stash[((size_t)b * 3 * NTh + 2 * NTh + t) * 64 + lane];
+        for (int t = 0; t < NTh; ++t) up2[t] = stash[((size_t)b * SPL_STASH * NTh + 2 * NTh + t) * 64 + lane];
         // second coupling: lower' = RQS(lower; f2(upper'))   (networks.py:589-598)
         SPL_STAMP(1)
         const int item_stride = ntl * 64;
@@ -1563,7 +1575,7 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
     if (tiles > h->partial_tiles) {
         if (h->partial) { (void)hipFree(h->partial); (void)hipFree(h->stash); (void)hipFree(h->gbuf); (void)hipFree(h->hbuf); (void)hipFree(h->keep); }
         SHIP_TRY(hipMalloc((void **)&h->partial, (size_t)tiles * ts.gw_floats * sizeof(float)));
-        SHIP_TRY(hipMalloc((void **)&h->stash, (size_t)tiles * SPL_TEAM * B * 3 * h->s.NTh * 64 * 4 * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->stash, (size_t)tiles * SPL_TEAM * B * SPL_STASH * h->s.NTh * 64 * 4 * sizeof(float)));
         SHIP_TRY(hipMalloc((void **)&h->gbuf, (size_t)2 * B * ts.SM * SPL_QT * tiles * 256 * sizeof(float)));
         SHIP_TRY(hipMalloc((void **)&h->hbuf, (size_t)2 * B * tiles * h->s.NH * 256 * sizeof(float)));
         SHIP_TRY(hipMalloc((void **)&h->keep, (size_t)tiles * SPL_TEAM * B * 2 * spl_keep_floats4(h->s.NTh, h->s.NH) * 256 * sizeof(float)));
