@@ -273,17 +273,19 @@ __device__ __forceinline__ void spl_actnorm_vecs(const SplTrainShape &ts, const 
 template <int NTh>
 __device__ __forceinline__ void spl_matmul(const float *__restrict__ frag, int lane, const f32x4 (&in)[2][NTh], f32x4 (&out)[2][NTh]) {
     constexpr int T2 = 2 * NTh;
+    float wf[T2 * T2 * 4];
+    load_frags<T2 * T2 * 4>(frag, lane, wf);
 #pragma unroll
     for (int to = 0; to < T2; ++to) {
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ti = 0; ti < T2; ++ti) {
             const f32x4 v = in[ti / NTh][ti % NTh];
-            const float *a = frag + (size_t)((to * T2 + ti) * 4) * 64 + lane;
+            const float *a = wf + (to * T2 + ti) * 4;
             acc0 = mfma4(a[0], v.x, acc0);
-            acc1 = mfma4(a[64], v.y, acc1);
-            acc0 = mfma4(a[128], v.z, acc0);
-            acc1 = mfma4(a[192], v.w, acc1);
+            acc1 = mfma4(a[1], v.y, acc1);
+            acc0 = mfma4(a[2], v.z, acc0);
+            acc1 = mfma4(a[3], v.w, acc1);
         }
         out[to / NTh][to % NTh] = acc0 + acc1;
     }
@@ -374,6 +376,10 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
                     x = lo ? x : reg_of(x_tr[kb], r);
                     gyr = lo ? gyr : reg_of(g_tr[kb], r);
                 }
+                // the transposed last-layer fragments of both super-tiles: requested before the spline arithmetic, used after it
+                float wA[SPL_QT * NH * 4], wB[SPL_QT * NH * 4];
+                load_frags<SPL_QT * NH * 4>(B4 + (size_t)sA * SPL_QT * NH * 256, lane, wA);
+                load_frags<SPL_QT * NH * 4>(B4 + (size_t)(hasB ? sB : sA) * SPL_QT * NH * 256, lane, wB);
                 const bool valid = row_ok && (lo ? (4 * sA + g < nout) : (hasB && 4 * sB + g < nout));
                 const float gy = valid ? gyr : 0.f;
                 float y, lad;
@@ -391,21 +397,21 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
                     gq[(size_t)(sA * SPL_QT + q) * item_stride + lane] = gA;
 #pragma unroll
                     for (int hto = 0; hto < NH; ++hto) {
-                        const float *a = B4 + (size_t)(((sA * SPL_QT + q) * NH + hto) * 4) * 64 + lane;
+                        const float *a = wA + (q * NH + hto) * 4;
                         g_h[hto] = mfma4(a[0], gA.x, g_h[hto]);
-                        g_h[hto] = mfma4(a[64], gA.y, g_h[hto]);
-                        g_h[hto] = mfma4(a[128], gA.z, g_h[hto]);
-                        g_h[hto] = mfma4(a[192], gA.w, g_h[hto]);
+                        g_h[hto] = mfma4(a[1], gA.y, g_h[hto]);
+                        g_h[hto] = mfma4(a[2], gA.z, g_h[hto]);
+                        g_h[hto] = mfma4(a[3], gA.w, g_h[hto]);
                     }
                     if (hasB) {
                         gq[(size_t)(sB * SPL_QT + q) * item_stride + lane] = gB;
 #pragma unroll
                         for (int hto = 0; hto < NH; ++hto) {
-                            const float *a = B4 + (size_t)(((sB * SPL_QT + q) * NH + hto) * 4) * 64 + lane;
+                            const float *a = wB + (q * NH + hto) * 4;
                             g_h[hto] = mfma4(a[0], gB.x, g_h[hto]);
-                            g_h[hto] = mfma4(a[64], gB.y, g_h[hto]);
-                            g_h[hto] = mfma4(a[128], gB.z, g_h[hto]);
-                            g_h[hto] = mfma4(a[192], gB.w, g_h[hto]);
+                            g_h[hto] = mfma4(a[1], gB.y, g_h[hto]);
+                            g_h[hto] = mfma4(a[2], gB.z, g_h[hto]);
+                            g_h[hto] = mfma4(a[3], gB.w, g_h[hto]);
                         }
                     }
                 }

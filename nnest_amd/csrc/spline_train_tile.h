@@ -79,38 +79,50 @@ __device__ __forceinline__ f32x4 lrelu_grad4(f32x4 g, f32x4 post) {  // post-act
     return o;
 }
 
+// N consecutive 64-float fragment rows into registers, ALL loads issued before the first use (the scheduler is held to it):
+// written fragment by fragment next to its matrix instruction, the compiler waits for every group of four loads in turn
+// -- one exposed L2 round trip per group, ~850 s_waitcnt in the gradient kernel, a quarter of its cycles.
+template <int N>
+__device__ __forceinline__ void load_frags(const float *__restrict__ base, int lane, float (&f)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = base[(size_t)i * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // conditioner trunk keeping the three hidden activations
 template <int NTh, int NH>
 __device__ __forceinline__ void spl_hidden_keep(const float *__restrict__ net, int lane, const f32x4 (&in)[NTh], f32x4 (&h)[3][NH]) {
     const int g = lane >> 4;
-    const float *L1 = net, *L2 = net + NH * NTh * 256, *L3 = L2 + NH * NH * 256, *b = L3 + NH * NH * 256;
+    const float *L1 = net, *L2 = net + NH * NTh * 256, *b = L2 + 2 * NH * NH * 256;
+    float w1[NH * NTh * 4], w23[2 * NH * NH * 4];
+    load_frags<NH * NTh * 4>(L1, lane, w1);
+    load_frags<2 * NH * NH * 4>(L2, lane, w23);
 #pragma unroll
     for (int ht = 0; ht < NH; ++ht) {
         f32x4 a0 = *reinterpret_cast<const f32x4 *>(b + 16 * ht + 4 * g), a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NTh; ++t) {
-            const float *a = L1 + (size_t)((ht * NTh + t) * 4) * 64 + lane;
+            const float *a = w1 + (ht * NTh + t) * 4;
             a0 = mfma4(a[0], in[t].x, a0);
-            a1 = mfma4(a[64], in[t].y, a1);
-            a0 = mfma4(a[128], in[t].z, a0);
-            a1 = mfma4(a[192], in[t].w, a1);
+            a1 = mfma4(a[1], in[t].y, a1);
+            a0 = mfma4(a[2], in[t].z, a0);
+            a1 = mfma4(a[3], in[t].w, a1);
         }
         h[0][ht] = lrelu4(a0 + a1);
     }
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-        const float *Lw = l == 0 ? L2 : L3;
         const float *bl = b + 16 * NH * (l + 1);
 #pragma unroll
         for (int hto = 0; hto < NH; ++hto) {
             f32x4 a0 = *reinterpret_cast<const f32x4 *>(bl + 16 * hto + 4 * g), a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hti = 0; hti < NH; ++hti) {
-                const float *a = Lw + (size_t)((hto * NH + hti) * 4) * 64 + lane;
+                const float *a = w23 + ((l * NH + hto) * NH + hti) * 4;
                 a0 = mfma4(a[0], h[l][hti].x, a0);
-                a1 = mfma4(a[64], h[l][hti].y, a1);
-                a0 = mfma4(a[128], h[l][hti].z, a0);
-                a1 = mfma4(a[192], h[l][hti].w, a1);
+                a1 = mfma4(a[1], h[l][hti].y, a1);
+                a0 = mfma4(a[2], h[l][hti].z, a0);
+                a1 = mfma4(a[3], h[l][hti].w, a1);
             }
             h[l + 1][hto] = lrelu4(a0 + a1);
         }
@@ -122,16 +134,18 @@ template <int NH>
 __device__ __forceinline__ void spl_raw(const float *__restrict__ L4, const float *__restrict__ b4, int s, int lane, const f32x4 (&h3)[NH],
                                         f32x4 (&raw)[SPL_QT]) {
     const int g = lane >> 4;
+    float w4[SPL_QT * NH * 4];
+    load_frags<SPL_QT * NH * 4>(L4 + (size_t)s * SPL_QT * NH * 256, lane, w4);
 #pragma unroll
     for (int q = 0; q < SPL_QT; ++q) {
         f32x4 acc = *reinterpret_cast<const f32x4 *>(b4 + ((s * SPL_QT + q) * 4 + g) * 4);
 #pragma unroll
         for (int hti = 0; hti < NH; ++hti) {
-            const float *a = L4 + (size_t)(((s * SPL_QT + q) * NH + hti) * 4) * 64 + lane;
+            const float *a = w4 + (q * NH + hti) * 4;
             acc = mfma4(a[0], h3[hti].x, acc);
-            acc = mfma4(a[64], h3[hti].y, acc);
-            acc = mfma4(a[128], h3[hti].z, acc);
-            acc = mfma4(a[192], h3[hti].w, acc);
+            acc = mfma4(a[1], h3[hti].y, acc);
+            acc = mfma4(a[2], h3[hti].z, acc);
+            acc = mfma4(a[3], h3[hti].w, acc);
         }
         raw[q] = acc;
     }
