@@ -355,6 +355,10 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
     f32x4 g_h[NH];
 #pragma unroll
     for (int ht = 0; ht < NH; ++ht) g_h[ht] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the transposed trunk fragments (B1 | B2 | B3 are contiguous): requested now, used after the spline stage
+    float wb1[NTh * NH * 4], wb23[2 * NH * NH * 4];
+    load_frags<NTh * NH * 4>(B1, lane, wb1);
+    load_frags<2 * NH * NH * 4>(B2, lane, wb23);
     CB_STAMP(0)
     if constexpr (DUP) {
         // the wave's super-tiles s = wv + 4k two at a time, (k, k + 1) in the low / high half of the columns (spl_coupling_pair)
@@ -471,7 +475,6 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
 #pragma unroll
     for (int l = 2; l >= 1; --l) {
         const bool mine = TEAM == 1 || wv == TEAM - 1;  // the trunk's weight gradients: the last wave's (it has the short share of the super-tiles)
-        const float *Bl = l == 2 ? B3 : B2;
         const int pW = l == 2 ? pW2 : pW1, pb = l == 2 ? pb2 : pb1;
         f32x4 g_pre[NH], g_prev[NH];
         float gT[NH][4];
@@ -503,11 +506,11 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hto = 0; hto < NH; ++hto) {
-                const float *a = Bl + (size_t)((hti * NH + hto) * 4) * 64 + lane;
+                const float *a = wb23 + ((l - 1) * NH * NH + hti * NH + hto) * 4;
                 acc = mfma4(a[0], g_pre[hto].x, acc);
-                acc = mfma4(a[64], g_pre[hto].y, acc);
-                acc = mfma4(a[128], g_pre[hto].z, acc);
-                acc = mfma4(a[192], g_pre[hto].w, acc);
+                acc = mfma4(a[1], g_pre[hto].y, acc);
+                acc = mfma4(a[2], g_pre[hto].z, acc);
+                acc = mfma4(a[3], g_pre[hto].w, acc);
             }
             g_prev[hti] = acc;
         }
@@ -552,11 +555,11 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ht = 0; ht < NH; ++ht) {
-                const float *a = B1 + (size_t)((t * NH + ht) * 4) * 64 + lane;
+                const float *a = wb1 + (t * NH + ht) * 4;
                 acc = mfma4(a[0], g_pre[ht].x, acc);
-                acc = mfma4(a[64], g_pre[ht].y, acc);
-                acc = mfma4(a[128], g_pre[ht].z, acc);
-                acc = mfma4(a[192], g_pre[ht].w, acc);
+                acc = mfma4(a[1], g_pre[ht].y, acc);
+                acc = mfma4(a[2], g_pre[ht].z, acc);
+                acc = mfma4(a[3], g_pre[ht].w, acc);
             }
             g_cond[t] = g_cond[t] + acc;
         }

@@ -88,6 +88,13 @@ __device__ __forceinline__ void load_frags(const float *__restrict__ base, int l
     for (int i = 0; i < N; ++i) f[i] = base[(size_t)i * 64 + lane];
     __builtin_amdgcn_sched_barrier(0);
 }
+// N bias quads of this lane group (f32x4 at stride `stride` floats), same discipline
+template <int N>
+__device__ __forceinline__ void load_bias4(const float *__restrict__ base, int stride, f32x4 (&b)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) b[i] = *reinterpret_cast<const f32x4 *>(base + (size_t)i * stride);
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 // conditioner trunk keeping the three hidden activations
 template <int NTh, int NH>
@@ -95,11 +102,13 @@ __device__ __forceinline__ void spl_hidden_keep(const float *__restrict__ net, i
     const int g = lane >> 4;
     const float *L1 = net, *L2 = net + NH * NTh * 256, *b = L2 + 2 * NH * NH * 256;
     float w1[NH * NTh * 4], w23[2 * NH * NH * 4];
+    f32x4 bq[3 * NH];  // b1 | b2 | b3, 16 NH floats each: this lane group's quad of every hidden tile
+    load_bias4<3 * NH>(b + 4 * g, 16, bq);
     load_frags<NH * NTh * 4>(L1, lane, w1);
     load_frags<2 * NH * NH * 4>(L2, lane, w23);
 #pragma unroll
     for (int ht = 0; ht < NH; ++ht) {
-        f32x4 a0 = *reinterpret_cast<const f32x4 *>(b + 16 * ht + 4 * g), a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 a0 = bq[ht], a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NTh; ++t) {
             const float *a = w1 + (ht * NTh + t) * 4;
@@ -112,10 +121,9 @@ __device__ __forceinline__ void spl_hidden_keep(const float *__restrict__ net, i
     }
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-        const float *bl = b + 16 * NH * (l + 1);
 #pragma unroll
         for (int hto = 0; hto < NH; ++hto) {
-            f32x4 a0 = *reinterpret_cast<const f32x4 *>(bl + 16 * hto + 4 * g), a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 a0 = bq[(l + 1) * NH + hto], a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hti = 0; hti < NH; ++hti) {
                 const float *a = w23 + ((l * NH + hto) * NH + hti) * 4;
@@ -135,10 +143,12 @@ __device__ __forceinline__ void spl_raw(const float *__restrict__ L4, const floa
                                         f32x4 (&raw)[SPL_QT]) {
     const int g = lane >> 4;
     float w4[SPL_QT * NH * 4];
+    f32x4 bq[SPL_QT];
+    load_bias4<SPL_QT>(b4 + (s * SPL_QT * 4 + g) * 4, 16, bq);
     load_frags<SPL_QT * NH * 4>(L4 + (size_t)s * SPL_QT * NH * 256, lane, w4);
 #pragma unroll
     for (int q = 0; q < SPL_QT; ++q) {
-        f32x4 acc = *reinterpret_cast<const f32x4 *>(b4 + ((s * SPL_QT + q) * 4 + g) * 4);
+        f32x4 acc = bq[q];
 #pragma unroll
         for (int hti = 0; hti < NH; ++hti) {
             const float *a = w4 + (q * NH + hti) * 4;
