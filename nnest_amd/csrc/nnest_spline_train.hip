@@ -1145,16 +1145,6 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
         // Every global load of the head's update is issued up front, in one batch (old parameters, the tiles' partial sums, the Adam
         // state of the elements this lane will step): taken phase by phase they were three dependent round trips to memory.
         const int lane = tid & 63, wave = tid >> 6, nwv = (int)(blockDim.x >> 6), nt = (D + 15) >> 4, li = lane & 15, lk = lane >> 4;
-        const bool tiles16 = a.tiles <= 16;
-        auto tile_sum = [&](const float *p) {
-            if (!tiles16) return spl_sum_tiles(p, n, a.tiles);
-            float v[16], acc = 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(u < a.tiles ? u : a.tiles - 1) * n];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc += u < a.tiles ? v[u] : 0.f;
-            return acc;
-        };
         // (a) the elements of the two products' output tiles this lane holds: [tile u][4 accumulator registers + S on the diagonal]
         int hi[2][5];
         float hm[2][5], hv[2][5];
@@ -1176,23 +1166,58 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
                 hm[u][r] = a.m[base + ii]; hv[u][r] = a.v[base + ii];
             }
         }
-        // (b) ActNorm s, t: one element per thread
+        // (b) ActNorm s, t: one element per thread; (c) the old head; (d) the tiles' partial sums of dLoss/dW, rows permuted as P
+        // does: G[pi(i)][j] = gW[i][j].  Up to 16 tiles: every load of the phase is in flight before the first one is consumed (the
+        // scheduler is held to it -- as first written the sums came out as one drained batch of 8 loads after another, a dozen
+        // dependent round trips to memory).
         const bool an = tid < ts.p_L;
         float an_m = a.m[base + (an ? tid : 0)], an_v = a.v[base + (an ? tid : 0)];
-        float an_g = tile_sum(a.partial + base + (an ? tid : 0));
-        // (c) the old head into LDS (plain and as the dense operands), dLoss/dW summed over the tiles with its rows permuted as P
-        // does: G[pi(i)][j] = gW[i][j]
+        float an_g = 0.f;
+        float hw[9];  // x_dim <= 64: the head is at most 8384 floats
+        float gs[4];
+        int gd[4];
         {
-            float hw[9];  // x_dim <= 64: the head is at most 8384 floats
 #pragma unroll
             for (int u = 0; u < 9; ++u) { const int i = tid + u * 1024; hw[u] = a.w[base + (i < nhead ? i : 0)]; }
-            float gs[4];
-            int gd[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = tid + u * 1024, ic = idx < D * D ? idx : 0;
                 gd[u] = idx < D * D ? a.pi[b * D + ic / D] * DP + ic % D : -1;
-                gs[u] = tile_sum(a.partial + np + b * D * D + ic);
+            }
+            const float *pan = a.partial + base + (an ? tid : 0);
+            if (a.tiles <= 16) {  // two rounds of 8 tiles x 5 elements in flight (the 1024-thread workgroup has 128 registers per lane)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gs[u] = 0.f;
+#pragma unroll
+                for (int t0 = 0; t0 < 16; t0 += 8) {
+                    float pv[5][8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const size_t off = (size_t)(t0 + t < a.tiles ? t0 + t : a.tiles - 1) * n;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int idx = tid + u * 1024, ic = idx < D * D ? idx : 0;
+                            pv[u][t] = a.partial[off + np + b * D * D + ic];
+                        }
+                        pv[4][t] = pan[off];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const bool live = t0 + t < a.tiles;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) gs[u] += live ? pv[u][t] : 0.f;
+                        an_g += live ? pv[4][t] : 0.f;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = tid + u * 1024, ic = idx < D * D ? idx : 0;
+                    gs[u] = spl_sum_tiles(a.partial + np + b * D * D + ic, n, a.tiles);
+                }
+                an_g = spl_sum_tiles(pan, n, a.tiles);
             }
             for (int idx = tid; idx < MAT; idx += blockDim.x) {  // the padding of the five matrices
                 const int row = idx / DP, col = idx - row * DP;
