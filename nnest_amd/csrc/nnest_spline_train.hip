@@ -606,10 +606,14 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     // The image was written by another kernel, i.e. into other XCDs' L2s: from here every fragment load of the pass would be
     // a cold miss (1.5-2 us each, and the layers consume them in small dependent batches -- by the stamps that was most of the
     // kernel).  One dword per 128-byte line, all in flight at once, brings the image into this XCD's L2 first.
+    // (the row index of this lane first: the rows' loads then queue behind the warm-up instead of behind a second round trip;
+    // the warm-up is waited for only after the rows and their jitter are done -- the noise draws need no memory)
+    long src = 0;
+    if (ok) src = (a.perm && !vtile) ? a.perm[row] : row;
+    float sink = 0.f;
     {
         const char *base = reinterpret_cast<const char *>(a.timg);
         const int n_lines = (int)(((size_t)B * ts.tblk_floats * sizeof(float) + 127) >> 7);
-        float sink = 0.f;
         for (int i = threadIdx.x; i < n_lines; i += 64 * TEAM) {
             const char *p = base + ((size_t)i << 7);
             asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
@@ -620,13 +624,10 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
             const char *p = reinterpret_cast<const char *>(a.w + (size_t)(i / lines_an) * s.blk_params) + ((size_t)(i % lines_an) << 7);
             asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");  // the target register is free again only now
     }
 
     // data = X[perm] + jitter * randn  (trainer.py:392)
     f32x4 xp[2][NTh], xs[2][NTh];
-    long src = 0;
-    if (ok) src = (a.perm && !vtile) ? a.perm[row] : row;
     load_tile<NTh>(vtile ? a.xv : a.x, src, ok, D, lane, xp);
     if (mode == SPL_MODE_GRAD && a.jitter != 0.f) {
         if (a.noise) {
@@ -652,6 +653,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");  // the warm-up's target register is free again only now
     spl_from_parity<NTh>(buf, D, s.nl, lane, xp, xs);
 #ifdef NNEST_STAMP
     long long st_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_0 = wall_clock64(), st_a, cb_t[4] = {0, 0, 0, 0};
