@@ -356,11 +356,14 @@ def main():
                 perms = torch.stack([torch.randperm(C - nv) for _ in range(E)]).int()
                 kw = dict(seed=1, jitter=0.01, batch=100, patience=50)
                 sp.train_epochs(u0[nv:], u0[:nv], perms[:2], None, max_epochs=2, **kw)   # allocations
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                res = sp.train_epochs(u0[nv:], u0[:nv], perms, None, max_epochs=E, **kw)
-                torch.cuda.synchronize(dev)
-                out['spline_flow']['train_ms_per_epoch'] = (time.perf_counter() - t0) / max(1, res['epochs_run']) * 1e3
+                best = float('inf')
+                for _ in range(3):  # (a side number: best of three calls, one hiccup of the box does not stand)
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    res = sp.train_epochs(u0[nv:], u0[:nv], perms, None, max_epochs=E, **kw)
+                    torch.cuda.synchronize(dev)
+                    best = min(best, (time.perf_counter() - t0) / max(1, res['epochs_run']) * 1e3)
+                out['spline_flow']['train_ms_per_epoch'] = best
         if world == 1 and dist is None and args.config == 2 and not args.bare:
             # K5 beside K4: the NVP training epoch at this population
             nv = C // 10
@@ -369,11 +372,14 @@ def main():
             kw = dict(seed=1, jitter=0.01, batch=100, patience=1000)
             tr = flow.HipNVP(D, H, B, L, device=dev, seed=1)
             tr.train_epochs(u0[nv:], u0[:nv], perms[:2], None, max_epochs=2, **kw)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            res = tr.train_epochs(u0[nv:], u0[:nv], perms, None, max_epochs=E, **kw)
-            torch.cuda.synchronize(dev)
-            out['k5_train'] = {'ms_per_epoch': (time.perf_counter() - t0) / max(1, res['epochs_run']) * 1e3,
+            best = float('inf')
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                res = tr.train_epochs(u0[nv:], u0[:nv], perms, None, max_epochs=E, **kw)
+                torch.cuda.synchronize(dev)
+                best = min(best, (time.perf_counter() - t0) / max(1, res['epochs_run']) * 1e3)
+            out['k5_train'] = {'ms_per_epoch': best,
                                'what': 'Trainer.train epoch loop in one launch (nnest_nvp_train), %d live points' % C}
             out['logz'] = logz_report(dev, live_run=not args.no_logz)
         if not args.no_cpu_baseline and world == 1 and dist is None:
