@@ -257,10 +257,12 @@ def test_adam_steps_vs_reference_trajectory(hip, path):
         assert np.sqrt(np.mean((dour - dref) ** 2)) < 0.05 * np.sqrt(np.mean(dref ** 2))
 
 
-@pytest.mark.parametrize('D', [8, 70])
+@pytest.mark.parametrize('D', [8, 33, 50, 64, 70])
 def test_one_training_step_is_gradient_plus_adam(hip, D):
-    """one minibatch of the training loop = loss_grad + one Adam step (torch/optim/adam.py, coupled weight decay), for a shape
-    whose loop keeps the training image current from inside the Adam kernel (x_dim 8) and one that rebuilds it (x_dim 70)"""
+    """one minibatch of the training loop = loss_grad + one Adam step (torch/optim/adam.py, coupled weight decay): for a shape
+    whose loop keeps the training image current from inside the update kernel on 16-row tiles (x_dim 8), the shapes that run
+    8-row tiles with one spline evaluation per pair of super-tiles (x_dim 33, 50, 64: the smallest, BASELINE's and the largest
+    of that form) and one that rebuilds the image per minibatch (x_dim 70)"""
     rng = np.random.RandomState(3)
     sp = hip.HipSpline(D, 16, 2, seed=5)
     X = rng.uniform(-1, 1, size=(140, D))
