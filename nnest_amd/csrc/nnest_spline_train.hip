@@ -341,8 +341,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
     const float *b4 = L4 + (size_t)S * SPL_QT * NH * 256;
     const float *B1 = cbw, *B2 = cbw + NTh * NH * 256, *B3 = B2 + NH * NH * 256, *B4 = B3 + NH * NH * 256;
     // packed offsets of this conditioner's parameters
-    const int pW0 = pnet, pb0 = pW0 + H * nin, pW1 = pb0 + H, pb1 = pW1 + H * H, pW2 = pb1 + H, pb2 = pW2 + H * H, pW3 = pb2 + H,
-              pb3 = pW3 + SPL_P * nout * H;
+    const int pW0 = pnet, pb0 = pW0 + H * nin, pW1 = pb0 + H, pb1 = pW1 + H * H, pW2 = pb1 + H, pb2 = pW2 + H * H;  // (W3, b3: spl_w3_item)
     float hT[2][NH][4];  // activations transposed for the weight-gradient contractions
 #pragma unroll
     for (int l = 0; l < 2; ++l) tile_transpose_batch<NH>(lds17, lane, h[l], hT[l]);
@@ -1262,7 +1261,6 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
             const float *pa = isU ? Lm + lk * DP + i : G + i * DP + lk, *pb = isU ? G + lk * DP + j : Um + j * DP + lk;
             const int sa = isU ? 4 * DP : 4, sb = isU ? 4 * DP : 4;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
             for (int k0 = 0; k0 < KP; k0 += 4) acc = mfma4(pa[(k0 >> 2) * sa], pb[(k0 >> 2) * sb], acc);
             const float cv[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
@@ -1299,7 +1297,6 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
             const int pr = i < D ? spi[i] : 63;
             const float *pa = LmN + pr * DP + lk, *pb = UmN + lk * DP + j;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
             for (int k0 = 0; k0 < KP; k0 += 4) acc = mfma4(pa[k0], pb[k0 * DP], acc);
             const float cv[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
@@ -1311,7 +1308,6 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
         spl_lds_barrier();
         U_STAMP(3)
         float *blk = a.timg + (size_t)b * ts.tblk_floats;
-#pragma unroll 4
         for (int o = tid; o < 2 * ts.conv_floats; o += blockDim.x) {
             const int src = a.conv_src[o];
             blk[o] = src >= 0 ? Wl[src] : 0.f;
