@@ -166,7 +166,6 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
     const int row = tile * 16 + w;
     const bool ok = row < a.C;
     const int D = a.s.D, S = a.steps;
-    const uint64_t walker = a.walker_offset + (uint64_t)row;
     const int nvalid = min(16, a.C - tile * 16);  // walkers in this adaptation group
     const LikeSpec like = a.like;
     const double loglstar = a.loglstar;
