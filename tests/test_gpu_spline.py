@@ -257,14 +257,14 @@ def test_adam_steps_vs_reference_trajectory(hip, path):
         assert np.sqrt(np.mean((dour - dref) ** 2)) < 0.05 * np.sqrt(np.mean(dref ** 2))
 
 
-@pytest.mark.parametrize('D', [8, 33, 50, 64, 70])
-def test_one_training_step_is_gradient_plus_adam(hip, D):
+@pytest.mark.parametrize('D,H', [(8, 16), (33, 16), (50, 16), (64, 16), (70, 16), (40, 32)])
+def test_one_training_step_is_gradient_plus_adam(hip, D, H):
     """one minibatch of the training loop = loss_grad + one Adam step (torch/optim/adam.py, coupled weight decay): for a shape
     whose loop keeps the training image current from inside the update kernel on 16-row tiles (x_dim 8), the shapes that run
     8-row tiles with one spline evaluation per pair of super-tiles (x_dim 33, 50, 64: the smallest, BASELINE's and the largest
-    of that form) and one that rebuilds the image per minibatch (x_dim 70)"""
+    of that form; hidden_dim 32 = two hidden tiles) and one that rebuilds the image per minibatch (x_dim 70)"""
     rng = np.random.RandomState(3)
-    sp = hip.HipSpline(D, 16, 2, seed=5)
+    sp = hip.HipSpline(D, H, 2, seed=5)
     X = rng.uniform(-1, 1, size=(140, D))
     sp.actnorm_init(X[:100])
     sp.data_dep_init_done = True
@@ -285,11 +285,11 @@ def test_one_training_step_is_gradient_plus_adam(hip, D):
     assert big.sum() > 0.5 * big.size
     np.testing.assert_allclose(dour[big], dref[big], rtol=0, atol=2e-5)
     # a second epoch runs from an image that follows the new weights: the loss it reports is the loss at w1
-    sp2 = hip.HipSpline(D, 16, 2, seed=5)
+    sp2 = hip.HipSpline(D, H, 2, seed=5)
     sp2.load_packed(sp.store_packed(), sp.P)
     sp2.data_dep_init_done = True
     loss1, _ = sp2.loss_grad(X[40:])
-    sp3 = hip.HipSpline(D, 16, 2, seed=5)
+    sp3 = hip.HipSpline(D, H, 2, seed=5)
     sp3.load_packed(w0.astype(np.float32), sp.P)
     sp3.data_dep_init_done = True
     res2 = sp3.train_epochs(X[40:], X[:40], perm.repeat(2, 1), None, seed=1, jitter=0.0, batch=100, max_epochs=2, patience=50, lr=lr,
