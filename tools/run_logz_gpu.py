@@ -1,6 +1,6 @@
 """GPU-path log Z of a BASELINE configuration over a list of seeds -> gpurun_out/logz_gpu_cfg<cfg>.json (copied to
 tests/golden/ and read by bench.py's `logz` report; the CPU-path counterpart is oracle/run_logz_cpu.py).
-  python tools/run_logz_gpu.py 2 0,1,2,3,4,5"""
+  python tools/run_logz_gpu.py 2 0,1,2,3,4,5 [lag]      lag: NNEST_MH_LAG of the batch-wide step rule (default: the product's)"""
 import json
 import os
 import sys
@@ -19,6 +19,7 @@ CONFIGS = {1: ('Rosenbrock', 2, 5.0, 100), 2: ('Rosenbrock', 50, 5.0, 1000), 3: 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 seeds = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else '0,1,2,3,4,5').split(',')]
 name, D, scale, N = CONFIGS[cfg]
+lag = int(sys.argv[3]) if len(sys.argv) > 3 else None
 runs = []
 for seed in seeds:
     np.random.seed(seed)
@@ -26,17 +27,17 @@ for seed in seeds:
     s = NestedSampler(D, getattr(likelihoods, name)(D), transform=lambda x: scale * x, log_dir=tempfile.mkdtemp(dir='/tmp'),
                       num_live_points=N, log_level=40, flow='nvp')
     t0 = time.time()
-    s.run(mcmc_num_chains=N)
+    s.run(mcmc_num_chains=N, mcmc_step_lag=lag)
     runs.append(dict(seed=seed, logz=float(s.logz), logzerr=float(s.logzerr), h=float(s.h), niter=int(s.niter), ncall=int(s.ncall),
                      retrains=int(s.num_retrains), batches=int(s.num_batches), train_epochs_total=int(s.trainer.total_iters),
                      wall_s=time.time() - t0))
     print(json.dumps(runs[-1]), flush=True)
 z = np.array([r['logz'] for r in runs])
 doc = dict(what='GPU-path log Z: nnest_amd.NestedSampler on the HIP kernels (tools/run_logz_gpu.py)', config=cfg, likelihood=name, x_dim=D,
-           num_live_points=N, mcmc_num_chains=N, flow='nvp h16 b3 l1', train_iters=500, step_rule='batch-wide, default lag',
+           num_live_points=N, mcmc_num_chains=N, flow='nvp h16 b3 l1', train_iters=500, step_rule='batch-wide, default lag' if lag is None else 'batch-wide, lag %d' % lag,
            seeds=seeds, logz=z.tolist(), mean=float(z.mean()), std=float(z.std(ddof=1)) if len(z) > 1 else None,
            stderr=float(z.std(ddof=1) / np.sqrt(len(z))) if len(z) > 1 else None, runs=runs)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-with open(os.path.join(ROOT, 'gpurun_out', 'logz_gpu_cfg%d.json' % cfg), 'w') as f:
+with open(os.path.join(ROOT, 'gpurun_out', 'logz_gpu_cfg%d%s.json' % (cfg, '' if lag is None else '_lag%d' % lag)), 'w') as f:
     json.dump(doc, f, indent=1)
 print('mean %.3f  std %.3f  stderr %.3f' % (doc['mean'], doc['std'] or 0, doc['stderr'] or 0))
