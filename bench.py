@@ -109,19 +109,22 @@ def committed_traffic(tag='r02'):
 
 def logz_report(dev, live_run):
     """The log-Z half of the metric at config 2: CPU path (oracle-backed host driver, tests/golden/logz_cpu_cfg2.json) against
-    the GPU path on the same number of seeds (tests/golden/logz_gpu_cfg2.json, tools/run_logz_gpu.py), plus one live run."""
+    the GPU path on the same seeds (tests/golden/logz_gpu_cfg2.json, tools/run_logz_gpu.py), plus one live run."""
     out = {}
     cpu_p = os.path.join(ROOT, 'tests', 'golden', 'logz_cpu_cfg2.json')
     gpu_p = os.path.join(ROOT, 'tests', 'golden', 'logz_gpu_cfg2.json')
-    if os.path.exists(cpu_p):
+    if os.path.exists(cpu_p) and os.path.exists(gpu_p):
         with open(cpu_p) as f:
             c = json.load(f)
-        out.update(cpu_mean=c['mean'], cpu_stderr=c['stderr'], cpu_seeds=c['seeds'])
-    if os.path.exists(gpu_p):
         with open(gpu_p) as f:
             g = json.load(f)
-        out.update(gpu_mean=g['mean'], gpu_stderr=g['stderr'], seeds=g['seeds'])
-    if 'cpu_mean' in out and 'gpu_mean' in out:
+        # the two paths share a seed's initial live points: the means are compared over the seeds BOTH fixtures hold
+        cz = dict(zip(c['seeds'], c['logz']))
+        gz = dict(zip(g['seeds'], g['logz']))
+        seeds = sorted(set(cz) & set(gz))
+        cv, gv = np.array([cz[k] for k in seeds]), np.array([gz[k] for k in seeds])
+        se = lambda v: float(v.std(ddof=1) / np.sqrt(len(v))) if len(v) > 1 else None
+        out.update(cpu_mean=float(cv.mean()), cpu_stderr=se(cv), gpu_mean=float(gv.mean()), gpu_stderr=se(gv), seeds=seeds)
         out['delta'] = out['gpu_mean'] - out['cpu_mean']
         out['combined_stderr'] = float(np.hypot(out['gpu_stderr'] or 0.0, out['cpu_stderr'] or 0.0))
     if live_run:

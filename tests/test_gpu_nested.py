@@ -351,7 +351,7 @@ def test_logz_gpu_vs_cpu(tmp_path, cfg):
     ref = _cpu_fixture(cfg)
     like = {'Rosenbrock': Rosenbrock, 'GaussianMix': GaussianMix}[ref['likelihood']](ref['x_dim'])
     scale = {'Rosenbrock': 5.0, 'GaussianMix': 10.0}[ref['likelihood']]
-    seeds = ref['seeds']
+    seeds = ref['seeds'][:12]   # (the fixtures may hold more: twelve runs bound the test's time)
     cpu = np.array([r['logz'] for r in ref['runs'] if r['seed'] in seeds])
     gpu = []
     for seed in seeds:
