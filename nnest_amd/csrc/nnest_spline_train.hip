@@ -291,6 +291,34 @@ __device__ __forceinline__ void spl_matmul(const float *__restrict__ frag, int l
     }
 }
 
+// the same product with its output tiles dealt out over the team's waves (to mod TEAM) and exchanged through LDS: every wave
+// repeated all (2 NTh)^2 x 4 matrix instructions before, 0.85 us per product at x_dim 50
+template <int NTh, int TEAM>
+__device__ __forceinline__ void spl_matmul_team(const float *__restrict__ frag, int lane, int wv, f32x4 *xch, const f32x4 (&in)[2][NTh],
+                                                f32x4 (&out)[2][NTh]) {
+    constexpr int T2 = 2 * NTh;
+#pragma unroll
+    for (int to = 0; to < T2; ++to) {
+        if ((to & (TEAM - 1)) != wv) continue;  // uniform over the wave
+        float wf[T2 * 4];
+        load_frags<T2 * 4>(frag + (size_t)to * T2 * 256, lane, wf);
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ti = 0; ti < T2; ++ti) {
+            const f32x4 v = in[ti / NTh][ti % NTh];
+            acc0 = mfma4(wf[ti * 4 + 0], v.x, acc0);
+            acc1 = mfma4(wf[ti * 4 + 1], v.y, acc1);
+            acc0 = mfma4(wf[ti * 4 + 2], v.z, acc0);
+            acc1 = mfma4(wf[ti * 4 + 3], v.w, acc1);
+        }
+        xch[to * 64 + lane] = acc0 + acc1;
+    }
+    spl_team_barrier();
+#pragma unroll
+    for (int to = 0; to < T2; ++to) out[to / NTh][to % NTh] = xch[to * 64 + lane];
+    spl_team_barrier();
+}
+
 // sum over the 16 rows (lanes w) of a tile; valid in every lane
 // (the 16 lanes of a lane group are one DPP row: quad swaps, then the half-row and row mirrors -- four VALU adds per value
 // instead of four ds_bpermute round trips)
@@ -682,7 +710,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int t = 0; t < NTh; ++t) av[hf][t] = xs[hf][t] * es[hf][t] + tv[hf][t];
-        spl_matmul<NTh>(blk, lane, av, c);
+        spl_matmul_team<NTh, TEAM>(blk, lane, wv, xch, av, c);
         if (mode != SPL_MODE_LOSS) {  // ActNorm and conv outputs: the backward pass does not repeat them
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
@@ -827,7 +855,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #endif
         SPL_STAMP(7)
         f32x4 ga[2][NTh];
-        spl_matmul<NTh>(blk + ts.conv_floats, lane, gs, ga);
+        spl_matmul_team<NTh, TEAM>(blk + ts.conv_floats, lane, wv, xch, gs, ga);
         SPL_STAMP(8)
         // ActNorm a = x e^s + t: g_s = sum_rows g_a x e^s, g_t = sum_rows g_a, g_x = g_a e^s  (the -1 of log|det| is added by the reducer)
 #pragma unroll
