@@ -370,9 +370,15 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
     const float *B1 = cbw, *B2 = cbw + NTh * NH * 256, *B3 = B2 + NH * NH * 256, *B4 = B3 + NH * NH * 256;
     // packed offsets of this conditioner's parameters
     const int pW0 = pnet, pb0 = pW0 + H * nin, pW1 = pb0 + H, pb1 = pW1 + H * H, pW2 = pb1 + H, pb2 = pW2 + H * H;  // (W3, b3: spl_w3_item)
-    float hT[2][NH][4];  // activations transposed for the weight-gradient contractions
+    float hT[2][NH][4];  // activations transposed for the weight-gradient contractions: the wave that has those jobs only
 #pragma unroll
-    for (int l = 0; l < 2; ++l) tile_transpose_batch<NH>(lds17, lane, h[l], hT[l]);
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int ht = 0; ht < NH; ++ht) hT[l][ht][0] = hT[l][ht][1] = hT[l][ht][2] = hT[l][ht][3] = 0.f;
+    if (TEAM == 1 || wv == TEAM - 1) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l) tile_transpose_batch<NH>(lds17, lane, h[l], hT[l]);
+    }
     // The last layer's weight gradients dW3 = G^T h3 are NOT contracted here, tile by tile on the critical path (they were half of
     // this function's time): the rows' G (below) and h3 go to memory and spl_w3_item contracts them over ALL rows of the batch.
     if (TEAM == 1 || wv == TEAM - 1) {
