@@ -137,6 +137,53 @@ __device__ __forceinline__ void spl_hidden_keep(const float *__restrict__ net, i
     }
 }
 
+// the trunk's fragments and biases in registers (spl_hidden_keep's load phase on its own: the training kernel's forward pass
+// requests them one coupling ahead)
+template <int NTh, int NH>
+struct SplTrunkFrags {
+    float w1[NH * NTh * 4], w23[2 * NH * NH * 4];
+    f32x4 bq[3 * NH];
+};
+template <int NTh, int NH>
+__device__ __forceinline__ void spl_trunk_load(const float *__restrict__ net, int lane, SplTrunkFrags<NTh, NH> &f) {
+    const float *L1 = net, *L2 = net + NH * NTh * 256, *b = L2 + 2 * NH * NH * 256;
+    load_bias4<3 * NH>(b + 4 * (lane >> 4), 16, f.bq);
+    load_frags<NH * NTh * 4>(L1, lane, f.w1);
+    load_frags<2 * NH * NH * 4>(L2, lane, f.w23);
+}
+template <int NTh, int NH>
+__device__ __forceinline__ void spl_hidden_keep_pre(const SplTrunkFrags<NTh, NH> &f, const f32x4 (&in)[NTh], f32x4 (&h)[3][NH]) {
+#pragma unroll
+    for (int ht = 0; ht < NH; ++ht) {
+        f32x4 a0 = f.bq[ht], a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NTh; ++t) {
+            const float *a = f.w1 + (ht * NTh + t) * 4;
+            a0 = mfma4(a[0], in[t].x, a0);
+            a1 = mfma4(a[1], in[t].y, a1);
+            a0 = mfma4(a[2], in[t].z, a0);
+            a1 = mfma4(a[3], in[t].w, a1);
+        }
+        h[0][ht] = lrelu4(a0 + a1);
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int hto = 0; hto < NH; ++hto) {
+            f32x4 a0 = f.bq[(l + 1) * NH + hto], a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hti = 0; hti < NH; ++hti) {
+                const float *a = f.w23 + ((l * NH + hto) * NH + hti) * 4;
+                a0 = mfma4(a[0], h[l][hti].x, a0);
+                a1 = mfma4(a[1], h[l][hti].y, a1);
+                a0 = mfma4(a[2], h[l][hti].z, a0);
+                a1 = mfma4(a[3], h[l][hti].w, a1);
+            }
+            h[l + 1][hto] = lrelu4(a0 + a1);
+        }
+    }
+}
+
 // raw spline parameters of super-tile s from the last hidden activation
 template <int NH>
 __device__ __forceinline__ void spl_raw(const float *__restrict__ L4, const float *__restrict__ b4, int s, int lane, const f32x4 (&h3)[NH],
@@ -179,14 +226,17 @@ __host__ __device__ inline int spl_keep_floats4(int NTh, int NH) { return 3 * NH
 template <int NTh, int NH, int TEAM>
 __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net, int S, int n_out, float tail, int lane,
                                                    const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv, f32x4 *xch,
-                                                   f32x4 *__restrict__ keep = nullptr) {
+                                                   f32x4 *__restrict__ keep, SplTrunkFrags<NTh, NH> &tf, const float *__restrict__ next_net) {
     static_assert(TEAM == 4, "one wave per register of a tile");
     const int g = lane >> 4;
     const bool lo = (lane & 15) < 8;
     // `keep` (this wave's slice, spl_keep_floats4): the three hidden activations and the spline parameters of the wave's pairs
     // stay for the backward pass, which then neither repeats the trunk nor the last layer
+    // `tf`: this coupling's trunk fragments, requested a coupling ago; the next coupling's (`next_net`) are requested as soon as
+    // this trunk has consumed them, and arrive behind the spline arithmetic
     f32x4 hk[3][NH];
-    spl_hidden_keep<NTh, NH>(net, lane, cond, hk);
+    spl_hidden_keep_pre<NTh, NH>(tf, cond, hk);
+    if (next_net) spl_trunk_load<NTh, NH>(next_net, lane, tf);
     f32x4 h[NH];
 #pragma unroll
     for (int ht = 0; ht < NH; ++ht) h[ht] = hk[2][ht];
