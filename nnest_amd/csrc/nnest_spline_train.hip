@@ -699,7 +699,11 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     // ---- forward (networks.py:24-32), block inputs stashed -----------------------------------------------------------
     float ld = 0.f;
     SplTrunkFrags<NTh, NH> tfr;  // the trunk fragments of the coupling ahead (spl_coupling_pair)
-    if (DUP) spl_trunk_load<NTh, NH>(a.timg + 2 * ts.conv_floats, lane, tfr);
+    SplRawFrags<NH> rfr;         // and the last-layer fragments of its first pair of super-tiles
+    if (DUP) {
+        spl_trunk_load<NTh, NH>(a.timg + 2 * ts.conv_floats, lane, tfr);
+        spl_rawfrags_load<NTh, NH>(a.timg + 2 * ts.conv_floats, s.SU, wv, lane, rfr);
+    }
     for (int b = 0; b < B; ++b) {
         // (lane- and shape-derived values kept opaque per block: see the backward loop)
         const int lane_o = spl_opaque_v(lane_k), nu_o = spl_opaque_s(s.nu), nl_o = spl_opaque_s(s.nl), SL_o = spl_opaque_s(s.SL), SU_o = spl_opaque_s(s.SU);
@@ -730,14 +734,14 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         }
         const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
         f32x4 *kpf = mode != SPL_MODE_LOSS ? reinterpret_cast<f32x4 *>(a.keep) + (((size_t)tile * TEAM + wv) * B + b) * 2 * spl_keep_floats4(NTh, NH) * 64 : nullptr;
-        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch, kpf, tfr, f2)
+        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch, kpf, tfr, rfr, f2, SL_o)
                   : spl_coupling<NTh, NH, false, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch);
         if (mode != SPL_MODE_LOSS) {  // upper' conditions the second coupling: kept for the backward pass
 #pragma unroll
             for (int t = 0; t < NTh; ++t) stash[((size_t)b * SPL_STASH * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
         }
-        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch, kpf ? kpf + spl_keep_floats4(NTh, NH) * 64 : nullptr, tfr,
-                                                     b + 1 < B ? blk + ts.tblk_floats + 2 * ts.conv_floats : nullptr)
+        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch, kpf ? kpf + spl_keep_floats4(NTh, NH) * 64 : nullptr, tfr, rfr,
+                                                     b + 1 < B ? blk + ts.tblk_floats + 2 * ts.conv_floats : nullptr, SU_o)
                   : spl_coupling<NTh, NH, false, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch);
         if (lane < (DUP ? 8 : 16) && wv == 0) ld += blk[ts.tblk_floats - 4];  // (once per row: DUP adds the halves up below)
 #pragma unroll

@@ -186,13 +186,13 @@ __device__ __forceinline__ void spl_hidden_keep_pre(const SplTrunkFrags<NTh, NH>
 
 // raw spline parameters of super-tile s from the last hidden activation
 template <int NH>
-__device__ __forceinline__ void spl_raw(const float *__restrict__ L4, const float *__restrict__ b4, int s, int lane, const f32x4 (&h3)[NH],
-                                        f32x4 (&raw)[SPL_QT]) {
-    const int g = lane >> 4;
-    float w4[SPL_QT * NH * 4];
-    f32x4 bq[SPL_QT];
-    load_bias4<SPL_QT>(b4 + (s * SPL_QT * 4 + g) * 4, 16, bq);
+__device__ __forceinline__ void spl_raw_load(const float *__restrict__ L4, const float *__restrict__ b4, int s, int lane,
+                                             float (&w4)[SPL_QT * NH * 4], f32x4 (&bq)[SPL_QT]) {
+    load_bias4<SPL_QT>(b4 + (s * SPL_QT * 4 + (lane >> 4)) * 4, 16, bq);
     load_frags<SPL_QT * NH * 4>(L4 + (size_t)s * SPL_QT * NH * 256, lane, w4);
+}
+template <int NH>
+__device__ __forceinline__ void spl_raw_mma(const float (&w4)[SPL_QT * NH * 4], const f32x4 (&bq)[SPL_QT], const f32x4 (&h3)[NH], f32x4 (&raw)[SPL_QT]) {
 #pragma unroll
     for (int q = 0; q < SPL_QT; ++q) {
         f32x4 acc = bq[q];
@@ -206,6 +206,28 @@ __device__ __forceinline__ void spl_raw(const float *__restrict__ L4, const floa
         }
         raw[q] = acc;
     }
+}
+template <int NH>
+__device__ __forceinline__ void spl_raw(const float *__restrict__ L4, const float *__restrict__ b4, int s, int lane, const f32x4 (&h3)[NH],
+                                        f32x4 (&raw)[SPL_QT]) {
+    float w4[SPL_QT * NH * 4];
+    f32x4 bq[SPL_QT];
+    spl_raw_load<NH>(L4, b4, s, lane, w4, bq);
+    spl_raw_mma<NH>(w4, bq, h3, raw);
+}
+// the last-layer fragments of a wave's first pair of super-tiles (s = wv and wv + 4) in registers, requested a coupling ahead
+template <int NH>
+struct SplRawFrags {
+    float wA[SPL_QT * NH * 4], wB[SPL_QT * NH * 4];
+    f32x4 bA[SPL_QT], bB[SPL_QT];
+};
+template <int NTh, int NH>
+__device__ __forceinline__ void spl_rawfrags_load(const float *__restrict__ net, int S, int wv, int lane, SplRawFrags<NH> &f) {
+    const float *L4 = net + spl_cond_hidden_floats(NTh, NH);
+    const float *b4 = L4 + (size_t)S * SPL_QT * NH * 256;
+    const int sA = wv < S ? wv : 0, sB = (NTh >= 2 && wv + 4 < S) ? wv + 4 : sA;
+    spl_raw_load<NH>(L4, b4, sA, lane, f.wA, f.bA);
+    spl_raw_load<NH>(L4, b4, sB, lane, f.wB, f.bB);
 }
 
 // ---- the two halves of the 16 columns (8-row tiles of the training kernel: lanes w and w ^ 8 carry the same row) ----------------
@@ -226,7 +248,8 @@ __host__ __device__ inline int spl_keep_floats4(int NTh, int NH) { return 3 * NH
 template <int NTh, int NH, int TEAM>
 __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net, int S, int n_out, float tail, int lane,
                                                    const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv, f32x4 *xch,
-                                                   f32x4 *__restrict__ keep, SplTrunkFrags<NTh, NH> &tf, const float *__restrict__ next_net) {
+                                                   f32x4 *__restrict__ keep, SplTrunkFrags<NTh, NH> &tf, SplRawFrags<NH> &rf,
+                                                   const float *__restrict__ next_net, int next_S) {
     static_assert(TEAM == 4, "one wave per register of a tile");
     const int g = lane >> 4;
     const bool lo = (lane & 15) < 8;
@@ -258,12 +281,14 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
             if (sA >= S) continue;
             const bool hasB = (k + 1 < NTh) && sB < S;
             f32x4 raw[SPL_QT];
-            spl_raw<NH>(L4, b4, sA, lane, h, raw);
+            if (k == 0) spl_raw_mma<NH>(rf.wA, rf.bA, h, raw);  // (the first pair's fragments came a coupling ahead)
+            else spl_raw<NH>(L4, b4, sA, lane, h, raw);
             float x = reg_of(tr[k], r);
             if (k + 1 < NTh) {
                 if (hasB) {
                     f32x4 rawB[SPL_QT];
-                    spl_raw<NH>(L4, b4, sB, lane, h, rawB);
+                    if (k == 0) spl_raw_mma<NH>(rf.wB, rf.bB, h, rawB);
+                    else spl_raw<NH>(L4, b4, sB, lane, h, rawB);
 #pragma unroll
                     for (int q = 0; q < SPL_QT; ++q) raw[q] = sel4(lo, raw[q], rawB[q]);
                 }
@@ -282,6 +307,7 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
             if (k + 1 < NTh && hasB) set_reg(tr[(k + 1 < NTh) ? k + 1 : k], r, lo ? yp : yo);
         }
     }
+    if (next_net) spl_rawfrags_load<NTh, NH>(next_net, next_S, wv, lane, rf);
     // super-tile s = 4t + r (register r of tile t) comes from wave r
 #pragma unroll
     for (int t = 0; t < NTh; ++t) xch[(wv * NTh + t) * 64 + lane] = tr[t];
