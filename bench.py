@@ -355,7 +355,7 @@ def main():
                                   'note': 'SingleSpeedSpline hidden=%d blocks=%d bins=8; VALU-bound on the spline arithmetic' % (H, B)}
             if C >= 200:  # its training epoch at this population (90 % train / 10 % validation, batch 100: trainer.py:159-176)
                 nv = C // 10
-                E = 20
+                E = 40  # (as the K5 figure below: 40 epochs per call)
                 perms = torch.stack([torch.randperm(C - nv) for _ in range(E)]).int()
                 kw = dict(seed=1, jitter=0.01, batch=100, patience=50)
                 sp.train_epochs(u0[nv:], u0[:nv], perms[:2], None, max_epochs=2, **kw)   # allocations
