@@ -127,6 +127,20 @@ def logz_report(dev, live_run):
         out.update(cpu_mean=float(cv.mean()), cpu_stderr=se(cv), gpu_mean=float(gv.mean()), gpu_stderr=se(gv), seeds=seeds)
         out['delta'] = out['gpu_mean'] - out['cpu_mean']
         out['combined_stderr'] = float(np.hypot(out['gpu_stderr'] or 0.0, out['cpu_stderr'] or 0.0))
+    # config 3 (GaussianMix x_dim 20, 2000 live points): one run scatters by 0.11 only, so there the +-0.1 criterion is resolved
+    c3, g3 = os.path.join(ROOT, 'tests', 'golden', 'logz_cpu_cfg3.json'), os.path.join(ROOT, 'tests', 'golden', 'logz_gpu_cfg3.json')
+    if os.path.exists(c3) and os.path.exists(g3):
+        with open(c3) as f:
+            c = json.load(f)
+        with open(g3) as f:
+            g = json.load(f)
+        cz, gz = dict(zip(c['seeds'], c['logz'])), dict(zip(g['seeds'], g['logz']))
+        seeds = sorted(set(cz) & set(gz))
+        cv, gv = np.array([cz[k] for k in seeds]), np.array([gz[k] for k in seeds])
+        if len(seeds) > 1:
+            out['config3'] = {'cpu_mean': float(cv.mean()), 'gpu_mean': float(gv.mean()), 'delta': float(gv.mean() - cv.mean()),
+                              'combined_stderr': float(np.hypot(cv.std(ddof=1), gv.std(ddof=1)) / np.sqrt(len(seeds))), 'n_seeds': len(seeds),
+                              'analytic': -20.0 * float(np.log(20.0))}
     if live_run:
         import tempfile
         from nnest_amd.likelihoods import Rosenbrock
