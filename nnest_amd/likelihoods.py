@@ -4,6 +4,7 @@ the dtype of the input (it is what the reference's Python row loop computes, use
 points, nested.py:228).  `hip_like_id` tells the sampler that the same function exists inside the fused
 HIP kernels (include/nnest_hip.h NNEST_LIKE_*), which is where the MCMC evaluations happen."""
 import numpy as np
+import scipy.special
 
 from ._lib import LIKE_IDS
 
@@ -38,7 +39,10 @@ class Rosenbrock(Likelihood):
     hip_like_id = LIKE_IDS['rosenbrock']
 
     def loglike_rows(self, x):
-        return -np.sum(100.0 * (x[:, 1:] - x[:, :-1] ** 2.0) ** 2.0 + (1 - x[:, :-1]) ** 2.0, axis=1)
+        # the reference adds the terms with Python's `sum`, i.e. left to right in the dtype of x (likelihoods.py:51); cumsum
+        # is numpy's left-to-right accumulation (np.sum would add pairwise: other bits in float32 from 8 terms on)
+        terms = 100.0 * (x[:, 1:] - x[:, :-1] ** 2.0) ** 2.0 + (1 - x[:, :-1]) ** 2.0
+        return -np.cumsum(terms, axis=1)[:, -1]
 
     @property
     def max_loglike(self):
@@ -79,16 +83,17 @@ class GaussianMix(Likelihood):
         self.positions = [np.asarray(p) for p in pos[:len(weights)]]
 
     def loglike_rows(self, x):
+        # operation for operation what the reference does per row (likelihoods.py:153-162, :182-189): shift the first two
+        # coordinates, square, np.sum over the row in the dtype of x, then float64 constants and scipy's logsumexp
         x = np.asarray(x)
-        rest = np.sum(x[:, 2:] ** 2, axis=1)
         ls = []
         for w, p in zip(self.weights, self.positions):
-            s = rest + (x[:, 0] - p[0]) ** 2 + (x[:, 1] - p[1]) ** 2
-            ls.append(-(s / (2 * self.sigma ** 2)).astype(np.float64) - np.log(2 * np.pi * self.sigma ** 2) * self.x_dim / 2.0
-                      + np.log(w))
-        ls = np.stack(ls, axis=0)
-        mx = np.max(ls, axis=0)
-        return mx + np.log(np.sum(np.exp(ls - mx), axis=0))
+            d = np.array(x, copy=True)
+            d[:, :2] -= p
+            logl = -(np.sum(d ** 2, axis=1) / (2 * self.sigma ** 2))
+            logl = logl - np.log(2 * np.pi * (self.sigma ** 2)) * self.x_dim / 2.0
+            ls.append(logl + np.log(w))
+        return scipy.special.logsumexp(np.stack(ls, axis=0), axis=0)
 
     @property
     def max_loglike(self):

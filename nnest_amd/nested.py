@@ -375,7 +375,8 @@ class NestedSampler(Sampler):
                     if primary:
                         idx = np.random.randint(low=0, high=N, size=C)      # nested.py:405
                         ctl[:-1] = np.resize(idx, per * self.mpi_size)
-                        ctl[-1] = self._next_seed() & 0x7FFFFFFFFFFFFFFF
+                        if self._fused_like_id is not None:   # only the HIP kernel's noise streams consume a seed
+                            ctl[-1] = self._next_seed() & 0x7FFFFFFFFFFFFFFF
                     ctl = self._broadcast(ctl)
                     lo = self.mpi_rank * per
                     my = ctl[lo:lo + per]

@@ -207,8 +207,15 @@ class Sampler(object):
         return like_id
 
     def _next_seed(self):
-        """64-bit seed for the in-kernel Philox streams, from torch's CPU generator (torch.manual_seed)."""
-        return int(torch.empty((), dtype=torch.int64).random_().item())
+        """64-bit seed for the in-kernel Philox streams.  Drawn from a PRIVATE generator seeded once from the seed of torch's
+        CPU generator (torch.manual_seed): the global generator is never advanced by the build's own bookkeeping, so the
+        host protocol consumes torch / numpy randomness draw for draw as the reference's loop does (nested.py:398-456;
+        tests/test_reference_trajectory.py holds the two drivers to the same trajectory)."""
+        gen = getattr(self, '_seed_gen', None)
+        if gen is None:
+            gen = self._seed_gen = torch.Generator(device='cpu')
+            gen.manual_seed(torch.initial_seed())
+        return int(torch.empty((), dtype=torch.int64).random_(generator=gen).item())
 
     # ---- the batched proposal ---------------------------------------------------------------------------
     def _mcmc_sample(self,

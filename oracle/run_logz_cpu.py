@@ -9,6 +9,8 @@ reference's protocol loop (sampler.py:264-463) with its batch-wide dynamic step 
 
   python oracle/run_logz_cpu.py one <cfg> <seed> <out.json>          one run (20-40 CPU-minutes for config 2)
   python oracle/run_logz_cpu.py all <cfg> <seed,seed,...> [jobs]     runs in parallel, writes tests/golden/logz_cpu_cfg<cfg>.json
+  python oracle/run_logz_cpu.py pool <cfg> <lo> <hi> <jobs> <dir>    seeds lo..hi-1, one <dir>/cfg<cfg>_seed<k>.json each (kept; done seeds skipped)
+  python oracle/run_logz_cpu.py merge <cfg> <dir>                    fold every <dir>/cfg<cfg>_seed*.json into the fixture
 """
 import json
 import os
@@ -53,21 +55,29 @@ def one(cfg, seed, out):
     print(json.dumps(res))
 
 
-def all_(cfg, seeds, jobs):
-    import numpy as np
-    tmp = tempfile.mkdtemp(dir='/tmp')
-    pend = list(seeds)
-    running, outs = [], []
+def pool(cfg, seeds, jobs, outdir):
+    """run the seeds `jobs` at a time; every finished seed leaves its own file, so an interrupted pool loses nothing"""
+    os.makedirs(outdir, exist_ok=True)
+    out = lambda sd: os.path.join(outdir, 'cfg%d_seed%d.json' % (cfg, sd))
+    pend = [sd for sd in seeds if not os.path.exists(out(sd))]
+    running = []
     while pend or running:
         while pend and len(running) < jobs:
             sd = pend.pop(0)
-            o = os.path.join(tmp, 'seed%d.json' % sd)
-            outs.append(o)
-            running.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), 'one', str(cfg), str(sd), o],
+            running.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), 'one', str(cfg), str(sd), out(sd)],
                                             stdout=subprocess.DEVNULL))
         time.sleep(5)
         running = [p for p in running if p.poll() is None]
-    runs = [json.load(open(o)) for o in outs if os.path.exists(o)]
+    return [out(sd) for sd in seeds]
+
+
+def all_(cfg, seeds, jobs):
+    outs = pool(cfg, seeds, jobs, tempfile.mkdtemp(dir='/tmp'))
+    merge(cfg, [json.load(open(o)) for o in outs if os.path.exists(o)])
+
+
+def merge(cfg, runs):
+    import numpy as np
     path = os.path.join(ROOT, 'tests', 'golden', 'logz_cpu_cfg%d.json' % cfg)
     if os.path.exists(path):   # add to the seeds already there
         with open(path) as f:
@@ -89,5 +99,10 @@ def all_(cfg, seeds, jobs):
 if __name__ == '__main__':
     if sys.argv[1] == 'one':
         one(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    elif sys.argv[1] == 'pool':
+        pool(int(sys.argv[2]), range(int(sys.argv[3]), int(sys.argv[4])), int(sys.argv[5]), sys.argv[6])
+    elif sys.argv[1] == 'merge':
+        import glob
+        merge(int(sys.argv[2]), [json.load(open(f)) for f in sorted(glob.glob(os.path.join(sys.argv[3], 'cfg%d_seed*.json' % int(sys.argv[2]))))])
     else:
         all_(int(sys.argv[2]), [int(v) for v in sys.argv[3].split(',')], int(sys.argv[4]) if len(sys.argv) > 4 else 4)
