@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 9
+#define NNEST_HIP_ABI_VERSION 10
 
 enum {
     NNEST_OK = 0,
@@ -76,7 +76,9 @@ enum {
 /* flags bits 16..19: pin the kernel form (0 = by population).  A caller that shards ONE batch over ranks pins the form the
  * whole batch would get, so that a shard reproduces the slice of the unsharded run bit for bit. */
 enum { NNEST_MH_FORM_AUTO = 0, NNEST_MH_FORM_IMAGE = 1, NNEST_MH_FORM_REG = 2, NNEST_MH_FORM_TEAM = 3, NNEST_MH_FORM_QUAD = 4,
-       NNEST_MH_FORM_QUAD1 = 5 /* the quad tile with both nets on one wave (same bits as QUAD; A/B diagnostic) */ };
+       NNEST_MH_FORM_QUAD1 = 5, /* the quad tile with both nets on one wave (same bits as QUAD; A/B diagnostic) */
+       NNEST_MH_FORM_SOLO = 6   /* one walker per wave, layers as v_fmac_f32 + DPP row rotations (nnest_solo.hip): <= 4 walkers per CU,
+                                 * x_dim <= 64, fixed step or the batch-wide rule at lag >= 2 */ };
 #define NNEST_MH_FORM(f) (((f) & 15) << 16)
 
 typedef struct nnest_nvp nnest_nvp_t; /* opaque: RealNVP coupling stack + Adam state on one device */
@@ -158,6 +160,12 @@ int nnest_mh_constrained_steps(nnest_nvp_t *nvp, const nnest_like_t *like, float
                                const float *noise_dz_dev, const float *noise_u_dev, uint64_t seed,
                                uint64_t walker_offset, float *hist_x_dev, double *hist_logl_dev, int *n_accept_dev,
                                int *n_call_dev, float *scale_out_dev, void *sync_dev, void *stream);
+/* The kernel form (NNEST_MH_FORM_*, never AUTO) nnest_mh_constrained_steps runs for C walkers under `flags` (in-kernel noise, no
+ * history): the pinned form of flags bits 16..19 if it applies to this flow shape, population and step rule, the form chosen
+ * by population otherwise; -1 if the launch would be refused (NNEST_E_UNSUPPORTED).  A caller that shards one batch of C_total
+ * walkers over ranks asks with C = C_total and pins the answer on every shard (reference: the MPI scatter of one batch,
+ * nnest/nested.py:405-427, has no such choice -- every rank runs the same Python). */
+int nnest_mh_form_for(const nnest_nvp_t *nvp, int C, int flags);
 /* size of sync_dev in 8-byte words for a launch of `steps` steps */
 int nnest_mh_sync_words(int steps);
 /* number of adaptation groups nnest_mh_constrained_steps uses for C walkers (size of scale_out_dev) */

@@ -20,7 +20,8 @@ LIKE_IDS = {'rosenbrock': 0, 'gaussmix': 1, 'himmelblau': 2, 'gaussian': 3, 'egg
 MH_DYNAMIC_STEP = 1      # per 16-walker group
 MH_UNCONSTRAINED = 2
 MH_DYNAMIC_BATCH = 4     # over the whole launch, as the reference (sampler.py:422-431); lag in bits 8..11
-MH_FORMS = {None: 0, 'auto': 0, 'image': 1, 'reg': 2, 'team': 3, 'quad': 4, 'quad1': 5}
+MH_FORMS = {None: 0, 'auto': 0, 'image': 1, 'reg': 2, 'team': 3, 'quad': 4, 'quad1': 5, 'solo': 6}
+MH_FORM_NAMES = {v: k for k, v in MH_FORMS.items() if isinstance(k, str) and v}
 MH_DEFAULT_LAG = 4      # steps between a step and the scale that reflects its batch-wide count
 TRAIN_RESUME = 1
 TRAIN_FINALIZE = 2
@@ -100,6 +101,7 @@ SIGNATURES = {
     'nnest_mh_constrained_steps': [_vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i, _i, _vp, _vp, _u64, _u64,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'nnest_mh_sync_words': [_i],
+    'nnest_mh_form_for': [_vp, _i, _i],
     'nnest_spline_forward': [_vp, _vp, _vp, _vp, _i, _vp],
     'nnest_spline_inverse': [_vp, _vp, _vp, _vp, _i, _vp],
     'nnest_spline_log_probs': [_vp, _vp, _vp, _i, _vp],

@@ -15,7 +15,7 @@ namespace nnest {
 
 // flags word of nnest_mh_constrained_steps: low bits NNEST_MH_*, bits 8..11 the lag of the batch-wide step rule,
 // bits 16..19 the kernel form (0 = chosen by population)
-enum { MH_FORM_AUTO = 0, MH_FORM_IMAGE = 1, MH_FORM_REG = 2, MH_FORM_TEAM = 3, MH_FORM_QUAD = 4, MH_FORM_QUAD1 = 5 };
+enum { MH_FORM_AUTO = 0, MH_FORM_IMAGE = 1, MH_FORM_REG = 2, MH_FORM_TEAM = 3, MH_FORM_QUAD = 4, MH_FORM_QUAD1 = 5, MH_FORM_SOLO = 6 };
 __host__ __device__ inline int mh_flag_lag(int flags) { return (flags >> 8) & 15; }
 __host__ __device__ inline int mh_flag_form(int flags) { return (flags >> 16) & 15; }
 
@@ -104,13 +104,23 @@ __device__ __forceinline__ unsigned long long mh_sync_read(const unsigned long l
         s += __hip_atomic_load(w + k * MH_SYNC_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return s;
 }
+// A wait that runs out (a workgroup of the launch is not resident: the GPU is shared) raises the launch's error word; every
+// later wait of the launch sees it on its first miss and gives up at once, so a failed launch ends after ONE timeout instead
+// of one per remaining step (the host raises from the error word, HipNVP.check_sync).
+__device__ __forceinline__ bool mh_sync_failed(const int *err) {
+    return err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+__device__ __forceinline__ void mh_sync_fail(int *err) {
+    if (err) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // accepted walkers of step `it` over the whole batch; waits (bounded) until all `nwg` workgroups have posted
 __device__ __forceinline__ int mh_sync_total(const unsigned long long *sync, int it, int nwg, unsigned long long first, int *err) {
     unsigned long long s = first;
     int polls = 0;
     while ((int)(s >> 32) != nwg) {
+        if ((polls & 255) == 0 && mh_sync_failed(err)) break;
         if (++polls > MH_SYNC_MAX_POLLS) {
-            if (err) *err = 1;
+            mh_sync_fail(err);
             break;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -144,8 +154,8 @@ __device__ __forceinline__ void mh_sync_publisher(unsigned long long *sync, int 
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         t0 += ndone;
         if (ndone == 0) {
-            if (++polls > MH_SYNC_MAX_POLLS) {
-                if (err) *err = 1;
+            if (++polls > MH_SYNC_MAX_POLLS || ((polls & 255) == 0 && mh_sync_failed(err))) {
+                mh_sync_fail(err);
                 // unblock the readers: publish what there is
                 for (int tt = t0; tt <= last_step; ++tt)
                     if (lane < MH_SYNC_SHARDS)
@@ -165,8 +175,9 @@ __device__ __forceinline__ int mh_result_wait(const unsigned long long *sync, in
     unsigned long long v = first;
     int polls = 0;
     while (!(v >> 63)) {
+        if ((polls & 255) == 0 && mh_sync_failed(err)) break;
         if (++polls > MH_SYNC_MAX_POLLS) {
-            if (err) *err = 1;
+            mh_sync_fail(err);
             break;
         }
         __builtin_amdgcn_s_sleep(1);

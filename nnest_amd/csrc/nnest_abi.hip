@@ -297,6 +297,11 @@ int nnest_mh_constrained_steps(nnest_nvp_t *h, const nnest_like_t *like, float *
     return NNEST_OK;
 }
 
+int nnest_mh_form_for(const nnest_nvp_t *h, int C, int flags) {
+    if (!h || C < 1) return -1;
+    return mh_form_for(h->s, C, flags, h->num_cu);
+}
+
 int nnest_mh_sync_words(int steps) { return steps < 0 ? -1 : (int)mh_sync_words(steps) + 1; }
 
 int nnest_mh_num_groups(const nnest_nvp_t *h, int C) {

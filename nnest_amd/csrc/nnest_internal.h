@@ -24,6 +24,9 @@ hipError_t launch_mh(const float *img, const FlowShape &s, const LikeSpec &like,
 struct MhArgs;
 bool quad_form_eligible(const MhArgs &a, int num_cu);        // nnest_quad.hip
 hipError_t launch_mh_quad(const MhArgs &a, int num_cu, hipStream_t st);  // nnest_quad.hip
+bool solo_form_eligible(const MhArgs &a, int num_cu);        // nnest_solo.hip
+hipError_t launch_mh_solo(const MhArgs &a, hipStream_t st);  // nnest_solo.hip
+int mh_form_for(const FlowShape &s, int C, int flags, int num_cu);
 hipError_t launch_loglike(const LikeSpec &like, const float *x, double *logl, int N, int D, int num_cu, hipStream_t st);
 hipError_t launch_fill_noise(float *dz, float *u, int steps, int C, int D, uint64_t seed, uint64_t walker_offset,
                              hipStream_t st);

@@ -668,16 +668,48 @@ static hipError_t launch_pass_t(const PassArgs &a_in, int num_cu, hipStream_t st
 // image by population; flags bits 16..19 pin a form (a caller that shards one batch over ranks pins the form the whole
 // batch would get, so a shard reproduces the slice of the unsharded run bit for bit).  The batch-wide step rule needs every
 // workgroup resident: it is refused where the grid could exceed the chip.
+// The form a launch runs, decided in ONE place (also behind nnest_mh_form_for): the pinned form if it applies to this shape /
+// population / rule, the first eligible one otherwise; -1 = none (pinned form not applicable, or the batch-wide rule on a grid
+// that may not be resident).
 template <int NT, int NH, int LT>
-static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
+static int pick_mh_form(const MhArgs &a, int num_cu) {
     const int ntiles = (a.C + 15) / 16;
     const int form = mh_flag_form(a.flags);
     const bool batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;
+    if ((form == MH_FORM_AUTO || form == MH_FORM_SOLO) && solo_form_eligible(a, num_cu)) return MH_FORM_SOLO;
+    if (form == MH_FORM_SOLO) return -1;
+    if ((form == MH_FORM_AUTO || form == MH_FORM_QUAD || form == MH_FORM_QUAD1) && quad_form_eligible(a, num_cu))
+        return form == MH_FORM_QUAD1 ? MH_FORM_QUAD1 : MH_FORM_QUAD;
+    if (form == MH_FORM_QUAD || form == MH_FORM_QUAD1) return -1;
+    if constexpr (LT == 1 && NH == 1) {  // fewer tiles than CUs: three waves per tile (team form)
+        if ((form == MH_FORM_AUTO || form == MH_FORM_TEAM) && a.s.B == 3 && ntiles <= num_cu && !a.noise_dz && a.s.scale_mode != 2) return MH_FORM_TEAM;
+    }
+    if (form == MH_FORM_TEAM) return -1;
+    if constexpr (LT == 1 && NH == 1 && NT <= 2) {  // register form: NT >= 3 would spill.  One wave per SIMD available; SingleSpeedNVP defaults: hidden_dim 16, num_blocks 3, num_layers 1 (nnest/sampler.py:37-43)
+        if ((form == MH_FORM_AUTO || form == MH_FORM_REG) && a.s.B == 3 && ntiles <= 4 * num_cu && a.s.scale_mode != 2) return MH_FORM_REG;
+    }
+    if (form == MH_FORM_REG) return -1;
+    int block, grid;
+    pick_geometry(ntiles, num_cu, 8, &block, &grid);  // mh_kernel: __launch_bounds__(512, 3)
+    if (batch && grid > num_cu) return -1;  // one workgroup per CU is what is certainly resident
+    return MH_FORM_IMAGE;
+}
+
+// Which form runs (DESIGN.md "K4"): solo (1 walker per wave, nnest_solo.hip) / quad (4 walkers per tile, nnest_quad.hip) while their
+// tiles fit the CUs, then team, register, image by population; flags bits 16..19 pin a form (a caller that shards one batch over ranks
+// pins the form the whole batch would get, so a shard reproduces the slice of the unsharded run bit for bit).  The batch-wide
+// step rule needs every workgroup resident: it is refused where the grid could exceed the chip.
+template <int NT, int NH, int LT>
+static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
+    const int ntiles = (a.C + 15) / 16;
+    const bool batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;
     if (batch && !a.sync) return hipErrorInvalidValue;
-    if ((form == MH_FORM_AUTO || form == MH_FORM_QUAD || form == MH_FORM_QUAD1) && quad_form_eligible(a, num_cu)) return launch_mh_quad(a, num_cu, st);
-    if (form == MH_FORM_QUAD || form == MH_FORM_QUAD1) return hipErrorInvalidConfiguration;
+    const int form = pick_mh_form<NT, NH, LT>(a, num_cu);
+    if (form < 0) return hipErrorInvalidConfiguration;
+    if (form == MH_FORM_SOLO) return launch_mh_solo(a, st);
+    if (form == MH_FORM_QUAD || form == MH_FORM_QUAD1) return launch_mh_quad(a, num_cu, st);
     if constexpr (LT == 1 && NH == 1) {
-        if ((form == MH_FORM_AUTO || form == MH_FORM_TEAM) && a.s.B == 3 && ntiles <= num_cu && !a.noise_dz && a.s.scale_mode != 2) {  // fewer tiles than CUs: three waves per tile (team form)
+        if (form == MH_FORM_TEAM) {
             const size_t timg = NT <= 2 ? 0 : (size_t)a.s.image_floats * 4;  // 3-4 tiles per class: fragments from an LDS image
             const int grid = ntiles + ((batch && mh_flag_lag(a.flags) >= 2) ? 1 : 0);  // + the workgroup that publishes the batch totals
             if (a.hist_x || a.hist_logl) {
@@ -692,9 +724,8 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
             return hipGetLastError();
         }
     }
-    if (form == MH_FORM_TEAM) return hipErrorInvalidConfiguration;
-    if constexpr (LT == 1 && NH == 1 && NT <= 2) {  // register form: NT >= 3 would spill
-        if ((form == MH_FORM_AUTO || form == MH_FORM_REG) && a.s.B == 3 && ntiles <= 4 * num_cu && a.s.scale_mode != 2) {  // one wave per SIMD available; SingleSpeedNVP defaults: hidden_dim 16, num_blocks 3, num_layers 1 (nnest/sampler.py:37-43)
+    if constexpr (LT == 1 && NH == 1 && NT <= 2) {
+        if (form == MH_FORM_REG) {
             if (a.noise_dz || a.hist_x || a.hist_logl)
                 hipLaunchKernelGGL((mh_kernel_reg<NT, 1, 1, 3, true>), dim3(ntiles), dim3(64), 0, st, a);
             else
@@ -702,10 +733,8 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
             return hipGetLastError();
         }
     }
-    if (form == MH_FORM_REG) return hipErrorInvalidConfiguration;
     int block, grid;
-    pick_geometry(ntiles, num_cu, 8, &block, &grid);  // mh_kernel: __launch_bounds__(512, 3)
-    if (batch && grid > num_cu) return hipErrorInvalidConfiguration;  // one workgroup per CU is what is certainly resident
+    pick_geometry(ntiles, num_cu, 8, &block, &grid);
     const size_t img_bytes = (size_t)a.s.image_floats * 4;
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
     if (img_bytes <= (size_t)LDS_IMAGE_LIMIT) {
@@ -724,6 +753,9 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
     }
     return hipGetLastError();
 }
+
+template <int NT, int NH, int LT>
+static int mh_form_t(const MhArgs &a, int num_cu) { return pick_mh_form<NT, NH, LT>(a, num_cu); }
 
 // L = 1 (the reference default, nnest/sampler.py:43) gets the compile-time interleaved form; other depths run
 // the generic runtime-L form (LT = -1)
@@ -826,6 +858,13 @@ hipError_t launch_fill_noise(float *dz, float *u, int steps, int C, int D, uint6
 }
 
 int mh_num_groups(int C) { return (C + 15) / 16; }
+
+// the form nnest_mh_constrained_steps would run for C walkers with these flags (in-kernel noise, no history): MH_FORM_* or -1
+int mh_form_for(const FlowShape &s, int C, int flags, int num_cu) {
+    MhArgs a = MhArgs();
+    a.s = s; a.C = C; a.flags = flags;
+    DISPATCH_SHAPE(mh_form_t, s, a, num_cu);
+}
 
 #include "spline_kernels.h"
 

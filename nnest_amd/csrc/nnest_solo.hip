@@ -1,0 +1,556 @@
+// nnest_solo.hip -- K4, "solo" form (round 3): the persistent constrained-Metropolis kernel (Sampler._mcmc_sample,
+// sampler.py:229-463) with ONE walker per wave, for populations of at most four walkers per compute unit -- BASELINE config 2
+// (1000 walkers) is 1000 net waves on the chip's 1024 SIMDs.
+//
+// Why.  The quad form (nnest_quad.hip) spends a step in a chain of nine small layers, each [3 DPP moves -> 4 dependent
+// v_mfma_f32_4x4x1 -> reduce-scatter over the four 16-lane rows (3 permlane swaps + adds + hazard nops) -> activation]:
+// 232 cycles per layer of which the matrix pipe is 54, plus three LDS exchanges + barriers per step between the scale-net
+// and the translate-net wave (730 cycles).  On gfx950 the f32 MFMA has NO rate advantage over the f32 VALU (both
+// 64 FLOP/clk/SIMD, MI355X_MICROARCH.md), so at this population -- latency-bound, one wave per SIMD -- the matrix pipe buys
+// nothing and its operand layouts cost the cross-lane traffic.  Here a layer is a chain of v_fmac_f32 with a DPP row
+// rotation on the activation operand: 16 lanes of a row hold the 16 features of a layer, lane p accumulates
+// out[p] = sum_t W[p][(p - t) & 15] * in[(p - t) & 15] with the weights W[p][(p - t) & 15] in its own registers -- no
+// operand movement at all, output feature p lands in lane p, which is the next layer's input layout.
+//
+// Lane layout.  lane = 32 n + 16 h + p:  n = net (0 scale_net / tanh, 1 translate_net / relu), h = K-half, p = position.
+// Every lane holds the walker's state at position p: xs[c][u] = dim 2U p + 2u + c (U = FlowShape::NT; parity class c), i.e.
+// 2U consecutive floats of the row; the four (n, h) rows hold bit-identical copies.  Rows h = 0 / 1 accumulate the rotations
+// t = 0..7 / 8..15 of every dot product (the input of the h = 1 rows is pre-rotated by 8 with a row-masked DPP move, so all
+// rows issue the same row_ror:0..7), one v_permlane16_swap + add joins the halves, one v_permlane32_swap hands log_s to the
+// translate half and t to the scale half: both nets of a coupling block run concurrently in ONE wave, with no LDS exchange
+// and no workgroup barrier inside the flow.  Per block and U = 2: 40 v_fmac (against 12 MFMA + 9 DPP + 9 permlane + ...),
+// 4 half-joins, 2 net swaps; 44 weight registers per lane and block.
+//
+// One workgroup = four net waves (walkers 4 tile .. 4 tile + 3) + one noise wave that draws the next step's proposal noise
+// (the xoshiro streams of every other form: nnest_mh_fill_noise replays them) and relays the batch-wide step rule
+// (mh_common.h) so that a step of the net waves holds no global-memory operation; ONE workgroup barrier per step.
+// Summation order differs from the other forms (K split in two halves, left to right), so results agree with them and
+// with the oracle to rounding, not bitwise; decisions on the same noise are the same except at rounding-borderline ratios.
+#include "mh_common.h"
+#include "nnest_internal.h"
+
+namespace nnest {
+
+static __device__ __forceinline__ void solo_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int N>  // lane p of every 16-lane row <- lane (p - N) & 15 of the same row
+static __device__ __forceinline__ float solo_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true));
+}
+// acc += w * x[(p - N) & 15]: one v_fmac_f32 with the rotation folded in (hipcc 7.2 does not combine update_dpp + fma by
+// itself: it emits v_mov_b32_dpp + v_pk_fma_f32).  The caller guards x (solo_dpp_guard) -- a DPP read needs two wait states
+// after the VALU write of its source, and the hazard recognizer does not look inside inline asm.
+template <int N>
+static __device__ __forceinline__ void solo_fmac(float &acc, float x, float w) {
+    if constexpr (N == 0) acc = __builtin_fmaf(w, x, acc);
+    else asm("v_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(N));
+}
+static __device__ __forceinline__ void solo_dpp_guard(float &x) { asm("s_nop 1" : "+v"(x)); }
+// the input of a layer as the h = 1 rows (rows 1 and 3 of the wave) need it: rotated by 8; rows 0 and 2 keep it
+static __device__ __forceinline__ float solo_prerotate(float v) {
+    float r = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x128, 0xa, 0xf, false));
+    solo_dpp_guard(r);
+    return r;
+}
+// sum of the two K-halves: rows (n, 0) and (n, 1) both end with row(n,0) + row(n,1) -- the same addition in both, so the
+// copies stay bit-identical.  (v_permlane16_swap with both operands the same value: hipcc 7.2 folds the two results of the
+// builtin, hence the asm; s_nop 1: the swap reads VGPRs a VALU instruction may just have written.)
+static __device__ __forceinline__ float solo_join(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// (value held by the scale half, value held by the translate half), in every lane
+static __device__ __forceinline__ void solo_nets(float v, float &from_scale, float &from_translate) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    from_scale = a;
+    from_translate = b;
+}
+// sum over the 16 positions of a row, bit-identical in its 16 lanes (each stage adds a pair that both partners see)
+static __device__ __forceinline__ float solo_row_sum(float v) {
+    v = v + solo_ror<8>(v);
+    v = v + solo_ror<4>(v);
+    v = v + solo_ror<2>(v);
+    v = v + solo_ror<1>(v);
+    return v;
+}
+
+static __device__ __forceinline__ float solo_lane0(float v) {  // position 0's value (every row holds the same copy)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+}
+
+template <int U>
+struct SoloNet {  // this lane's share of one coupling block (its net n, its K-half h), num_layers = 1, hidden 16
+    float w1[U][8], w2[8], w3[U][8];
+    float b1, b2, b3[U];  // biases ride in the h = 0 half; 0 in the h = 1 half
+};
+
+// gather from the packed (block, net) region (LDS copy), state_dict layout W0[H][D] b0[H] W1[H][H] b1[H] Wo[D][H] bo[D]
+// (nnest/networks.py:271-282).  cc / ct: conditioning / transformed parity class of the block.
+template <int U>
+static __device__ __forceinline__ void solo_gather(SoloNet<U> &n, const float *p, int D, int cc, int ct, int lane) {
+    const int H = 16;
+    const int pos = lane & 15, h = (lane >> 4) & 1;
+    const int pb0 = H * D, pW1 = pb0 + H, pb1 = pW1 + H * H, pWo = pb1 + H, pbo = pWo + D * H;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int q = (pos - t - 8 * h) & 15;  // position whose value this lane consumes at rotation t
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int d = 2 * U * q + 2 * u + cc;
+            n.w1[u][t] = d < D ? p[pos * D + d] : 0.f;
+            const int dO = 2 * U * pos + 2 * u + ct;  // dim of this lane's transformed slot u
+            n.w3[u][t] = dO < D ? p[pWo + dO * H + q] : 0.f;
+        }
+        n.w2[t] = p[pW1 + pos * H + q];
+    }
+    n.b1 = h == 0 ? p[pb0 + pos] : 0.f;
+    n.b2 = h == 0 ? p[pb1 + pos] : 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int dO = 2 * U * pos + 2 * u + ct;
+        n.b3[u] = (h == 0 && dO < D) ? p[pbo + dO] : 0.f;
+    }
+}
+
+#define SOLO_ROT8(STMT) { constexpr int t = 0; STMT } { constexpr int t = 1; STMT } { constexpr int t = 2; STMT } { constexpr int t = 3; STMT } \
+                        { constexpr int t = 4; STMT } { constexpr int t = 5; STMT } { constexpr int t = 6; STMT } { constexpr int t = 7; STMT }
+
+// CouplingLayer.inverse (networks.py:300-309), both nets at once (the wave's two halves); returns the lane's log-det partial
+template <int U>
+static __device__ __forceinline__ float solo_coupling_inverse(const SoloNet<U> &w, bool translate_half, const float (&cond)[U],
+                                                              float (&trans)[U]) {
+    float xin[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) xin[u] = solo_prerotate(cond[u]);
+    float a0 = w.b1, a1 = 0.f;  // two accumulators: a dependent v_fmac issues every ~4-5 cycles, an independent one every 4
+    SOLO_ROT8(
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {
+            if ((t + u) & 1) solo_fmac<t>(a1, xin[u], w.w1[u][t]);
+            else solo_fmac<t>(a0, xin[u], w.w1[u][t]);
+        })
+    float hid = solo_join(a0 + a1);
+    hid = translate_half ? fmaxf(hid, 0.f) : fast_tanh(hid);
+    {
+        float hin = solo_prerotate(hid);
+        a0 = w.b2; a1 = 0.f;
+        SOLO_ROT8(if (t & 1) solo_fmac<t>(a1, hin, w.w2[t]); else solo_fmac<t>(a0, hin, w.w2[t]);)
+        hid = solo_join(a0 + a1);
+        hid = translate_half ? fmaxf(hid, 0.f) : fast_tanh(hid);
+    }
+    const float hin = solo_prerotate(hid);
+    float o[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) o[u] = w.b3[u];
+    SOLO_ROT8(_Pragma("unroll") for (int u = 0; u < U; ++u) solo_fmac<t>(o[u], hin, w.w3[u][t]);)
+    float ld = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float ls, tt;
+        solo_nets(solo_join(o[u]), ls, tt);
+        trans[u] = (trans[u] - tt) * __expf(-ls);  // (inputs - t) * exp(-log_s)   networks.py:307-309
+        ld -= ls;
+    }
+    return ld;
+}
+
+// ---- likelihoods on a solo wave (the per-term arithmetic of loglike_tile, flow_tile.h; sums over the 16 positions) ----
+#pragma clang fp contract(off)
+template <int U>
+static __device__ __forceinline__ double solo_loglike(const LikeSpec &lk, int D, int lane, const float (&xs)[2][U]) {
+    const int m = lane & 15;
+    const float scale = lk.scale;
+    float th[2 * U + 1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { th[2 * u] = scale * xs[0][u]; th[2 * u + 1] = scale * xs[1][u]; }
+    double acc;
+    if (lk.id == 0) {
+        // Rosenbrock (likelihoods.py:51): -sum_i 100 (x[i+1] - x[i]^2)^2 + (1 - x[i])^2, i = 0..D-2
+        th[2 * U] = solo_ror<15>(th[0]);  // first dim of position m + 1
+        float facc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * U; ++k) {
+            const int i = 2 * U * m + k;
+            float a = th[k] * th[k];
+            float b = th[k + 1] - a;
+            float c = b * b;
+            float e = 100.0f * c;
+            float f = 1.0f - th[k];
+            float q = f * f;
+            float term = e + q;
+            facc = facc + ((i + 1 < D) ? term : 0.f);
+        }
+        acc = -(double)solo_row_sum(facc);
+    } else if (lk.id == 1) {
+        // GaussianMix (likelihoods.py:165-189): logsumexp_k[ log w_k - |theta - mu_k|^2/2 - (D/2) log 2pi ]
+        float facc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * U; ++k) {
+            const int d = 2 * U * m + k;
+            float sq = th[k] * th[k];
+            facc = facc + ((d >= 2 && d < D) ? sq : 0.f);
+        }
+        const double base = (double)solo_row_sum(facc);
+        const float t0 = solo_lane0(th[0]), t1 = solo_lane0(th[1]);  // theta[0], theta[1]: position 0
+        const float mu0[4] = {0.f, 0.f, 4.f, -4.f}, mu1[4] = {4.f, -4.f, 0.f, 0.f};
+        const double lw[4] = {-0.916290731874155, -1.203972804325936, -1.6094379124341003, -2.302585092994046};
+        double l[4], mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a = t0 - mu0[k], b = t1 - mu1[k];
+            double s = base + (double)(a * a) + (D > 1 ? (double)(b * b) : 0.0);
+            l[k] = -(s * 0.5) - 0.9189385332046727 * (double)D + lw[k];
+            mx = l[k] > mx ? l[k] : mx;
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) se += __expf((float)(l[k] - mx));
+        acc = mx + (double)__logf(se);
+    } else if (lk.id == 2) {
+        // Himmelblau (likelihoods.py:70) summed over consecutive pairs (x[2i], x[2i+1])
+        float facc = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int d1 = 2 * U * m + 2 * u + 1;
+            float x0 = th[2 * u], x1 = th[2 * u + 1];
+            float a = x0 * x0 + x1 - 11.f;
+            float b = x0 + x1 * x1 - 7.f;
+            float v = -(a * a) - b * b;
+            facc = facc + ((d1 < D) ? v : 0.f);
+        }
+        acc = (double)solo_row_sum(facc);
+    } else if (lk.id == 4) {
+        // Eggbox (likelihoods.py:104-106), x_dim = 2
+        const float t0 = solo_lane0(th[0]), t1 = solo_lane0(th[1]);
+        float chi = cosf(t0 / 2.f) * cosf(t1 / 2.f);
+        float b = 2.f + chi;
+        float b2 = b * b;
+        acc = (double)(b2 * b2 * b);
+    } else {
+        // float64 moments of theta (Gaussian, GaussianShell, DoubleGaussianShell: loglike_tile, flow_tile.h)
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2 * U; ++k) {
+            const bool valid = 2 * U * m + k < D;
+            const double t = valid ? (double)th[k] : 0.0;
+            s1 += t;
+            s2 += t * t;
+        }
+#pragma unroll
+        for (int o = 1; o <= 8; o <<= 1) {  // totals over the 16 positions, identical in every lane of a row
+            s1 = s1 + __shfl_xor(s1, o);
+            s2 = s2 + __shfl_xor(s2, o);
+        }
+        const double Dd = (double)D;
+        if (lk.id == 3) {
+            const double c = (double)lk.p[0];
+            const double quad = (s2 - c * s1 * s1 / (1.0 + (Dd - 1.0) * c)) / (1.0 - c);
+            const double logdet = (Dd - 1.0) * log(1.0 - c) + log(1.0 + (Dd - 1.0) * c);
+            acc = -0.5 * quad - 0.5 * logdet - 0.9189385332046727 * Dd;
+        } else {
+            double sh[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double sig = (double)lk.p[3 * k], rs = (double)lk.p[3 * k + 1], cen = (double)lk.p[3 * k + 2];
+                double r2 = s2 - 2.0 * cen * s1 + Dd * cen * cen;
+                double rad = sqrt(r2 > 0.0 ? r2 : 0.0);
+                sh[k] = -((rad - rs) * (rad - rs)) / (2.0 * sig * sig);
+            }
+            if (lk.id == 5) acc = sh[0];
+            else {
+                const double mx = sh[0] > sh[1] ? sh[0] : sh[1], mn = sh[0] > sh[1] ? sh[1] : sh[0];
+                acc = mx + log1p(exp(mn - mx));
+            }
+        }
+    }
+    if (!(fabs(acc) <= 1.79769313486231570e308)) acc = -1e100;  // logl[~isfinite] = -1e100   sampler.py:128
+    return acc;
+}
+#pragma clang fp contract(fast)
+
+static constexpr int SOLO_ETAB = 1024;   // steps + 2 <= SOLO_ETAB: exp(1 / (1 + k)) from a table
+static constexpr int SOLO_AHEAD = 3;     // the noise wave requests a batch total this many steps before the net waves apply it
+
+template <int U, bool DBG>
+__global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];  // the packed weights
+    __shared__ __attribute__((aligned(16))) float nbuf[2][4][16][2 * U];
+    __shared__ float ubuf[2][4];
+    __shared__ int acc_lds[2][4], res_lds[2];  // batch rule relayed by the noise wave: the walkers' accepts / the batch total
+    __shared__ double etab[SOLO_ETAB];
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x;
+    const int D = a.s.D, S = a.steps, C = a.C;
+    const bool recorded = DBG && a.noise_dz;
+    const bool dynamic = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;  // the per-16-walker rule belongs to the 16-walker forms
+    const bool use_tab = S + 2 <= SOLO_ETAB;
+    const int lag = mh_flag_lag(a.flags);                          // >= 2 (solo_form_eligible): the rule is always relayed
+    const int ntiles = (C + 3) >> 2;
+    if (tile >= ntiles) {
+        // batch-wide step rule (mh_common.h): the one workgroup behind the tiles sums every step's counters as soon as they
+        // are complete and publishes the total; its other waves leave at once
+        if (dynamic && wave == 0) mh_sync_publisher(a.sync, S, S - lag, ntiles, lane, a.sync_err);
+        return;
+    }
+    {
+        const int n = a.s.nets_params();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) wlds[i] = a.packed[i];
+        if (dynamic && use_tab)
+            for (int k = threadIdx.x; k < S + 2; k += blockDim.x) etab[k] = exp(1.0 / (double)(1 + k));
+    }
+    __syncthreads();
+
+    if (wave == 4) {
+        // proposal noise: the streams of the 16-walker forms -- per (walker, lane group g) 8 normals for dims
+        // 32 t + 8 g + [0, 8), t < U -- generated by 16 lanes (4 walkers x 4 groups) and written where the net waves read them.
+        const int j = lane & 3, g = (lane >> 2) & 3;
+        const bool gen = lane < 16;
+        XoshiroNoise<U> rng;
+        rng.init(a.seed, a.walker_offset + (uint64_t)(tile * 4 + j), g, D);
+        // batch totals in flight: requested SOLO_AHEAD iterations before they are handed to the net waves (a request is a
+        // round trip to the memory side, ~1.5 us: about two steps of this form)
+        unsigned long long q[SOLO_AHEAD];
+#pragma unroll
+        for (int r = 0; r < SOLO_AHEAD; ++r) q[r] = 0;
+        const int last = S - lag;  // last step whose total is ever applied
+        for (int k = 0; k <= S; ++k) {
+            // between the barriers k - 1 and k the net waves run step k - 1: the accepts of step k - 2 are in LDS, and the total
+            // they will apply at the end of step k (that of step k - lag) has to be in LDS by barrier k
+            const int want = k - lag;
+            unsigned long long cur = 0;
+            if (dynamic) {
+                if (k >= 2 && lane == 0) {
+                    const int *ac = acc_lds[k & 1];
+                    mh_sync_post(a.sync, k - 2, tile, (ac[0] + ac[1]) + (ac[2] + ac[3]));
+                }
+                cur = q[0];
+#pragma unroll
+                for (int r = 0; r + 1 < SOLO_AHEAD; ++r) q[r] = q[r + 1];
+                const int ahead = want + SOLO_AHEAD;
+                q[SOLO_AHEAD - 1] = (ahead >= 1 && ahead <= last) ? mh_result_load(a.sync, S, ahead, tile) : 0ull;
+            }
+            if (gen && !recorded) {
+                float nz[U][8], u;
+                rng.next(nz, u);
+#pragma unroll
+                for (int t = 0; t < U; ++t)
+#pragma unroll
+                    for (int qq = 0; qq < 8; ++qq) {
+                        const int d = 32 * t + 8 * g + qq;        // padded dims (d >= D) carry 0
+                        nbuf[k & 1][j][d / (2 * U)][d % (2 * U)] = nz[t][qq];
+                    }
+                if (g == 0) ubuf[k & 1][j] = u;
+            }
+            if (dynamic && want >= 1) {
+                const int total = mh_result_wait(a.sync, S, want, tile, cur, a.sync_err);
+                if (lane == 0) res_lds[k & 1] = total;
+            }
+            solo_barrier();  // publish buffer k
+        }
+        return;
+    }
+
+    // ---- one walker per wave ----
+    const int j = wave;
+    const int pos = lane & 15;
+    const bool translate_half = lane >= 32;
+    const bool writer_lane = lane < 16;  // row (n = 0, h = 0) does the stores
+    const int row = tile * 4 + j;
+    const bool ok = row < C;
+    const LikeSpec like = a.like;
+    const double loglstar = a.loglstar;
+    const bool free_mode = (a.flags & NNEST_MH_UNCONSTRAINED) != 0;
+
+    SoloNet<U> net[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+        solo_gather<U>(net[b], wlds + (size_t)(b * 2 + (translate_half ? 1 : 0)) * a.s.net_params, D, (b + 1) & 1, b & 1, lane);
+    // NormalizingFlow.inverse (networks.py:34-42), num_blocks = 3: blocks 2, 1, 0; block b conditions on class (b+1)&1 and
+    // transforms class b&1
+    auto inverse = [&](float (&xs)[2][U]) {
+        float ld = solo_coupling_inverse<U>(net[2], translate_half, xs[1], xs[0]);
+        ld += solo_coupling_inverse<U>(net[1], translate_half, xs[0], xs[1]);
+        ld += solo_coupling_inverse<U>(net[0], translate_half, xs[1], xs[0]);
+        return ld;
+    };
+
+    float z[2][U], x[2][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int d = 2 * U * pos + 2 * u + c;
+            z[c][u] = (ok && d < D) ? a.z[(size_t)row * D + d] : 0.f;
+            x[c][u] = z[c][u];
+        }
+    float ld = solo_row_sum(inverse(x));  // x = f^-1(z), log_det_J  (sampler.py:266, :295)
+    double logl = ok ? a.logl[row] : 0.0;
+    double scale = (double)a.step_size;
+    int accept = 0, reject = 0, n_acc = 0, n_call = 0;
+
+    auto store_row = [&](float *base, size_t r, const float (&v)[2][U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int d = 2 * U * pos + 2 * u + c;
+                if (d < D) base[r * D + d] = v[c][u];
+            }
+    };
+    if (DBG && writer_lane && ok) {
+        if (a.hist_x) store_row(a.hist_x, (size_t)row * (S + 1), x);
+        if (a.hist_logl && pos == 0) a.hist_logl[(size_t)row * (S + 1)] = logl;
+    }
+
+    float nz[2 * U], u_next = 0.f;
+    int kbuf = 0, relayed_total = 0;
+    auto fetch_noise = [&]() {
+        solo_barrier();  // the noise wave has published buffer kbuf (and the batch total to apply in step kbuf)
+        if (!recorded) {
+#pragma unroll
+            for (int k = 0; k < 2 * U; ++k) nz[k] = nbuf[kbuf & 1][j][pos][k];
+            u_next = ubuf[kbuf & 1][j];
+        }
+        if (dynamic) relayed_total = res_lds[kbuf & 1];
+        ++kbuf;
+    };
+    fetch_noise();
+
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, a_prop = 0, a_inv = 0, a_post = 0, a_tot = 0;
+    (void)st0; (void)st1; (void)st2; (void)st3; (void)a_prop; (void)a_inv; (void)a_post; (void)a_tot;
+    for (int it = 1; it <= S; ++it) {
+        STAMP(st0);
+        // proposal z' = z + randn * scale  (sampler.py:310, :316); float32 like torch
+        const float fs = (float)scale;
+        float zp[2][U], xp[2][U];
+        float u;
+        if (recorded) {
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int d = 2 * U * pos + 2 * uu + c;
+                    const float dz = (ok && d < D) ? a.noise_dz[((size_t)(it - 1) * C + row) * D + d] : 0.f;
+                    zp[c][uu] = z[c][uu] + dz * fs;
+                }
+            u = ok ? a.noise_u[(size_t)(it - 1) * C + row] : 1.f;
+        } else {
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+                zp[0][uu] = z[0][uu] + nz[2 * uu] * fs;
+                zp[1][uu] = z[1][uu] + nz[2 * uu + 1] * fs;
+            }
+            u = u_next;
+        }
+        const bool have_total = dynamic && it - lag >= 1;
+        fetch_noise();
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) xp[c][uu] = zp[c][uu];
+        STAMP(st1);
+        const float ldp = solo_row_sum(inverse(xp));  // sampler.py:321
+        STAMP(st2);
+
+        // log_ratio = log_det_J' - log_det_J, -inf outside the prior box  (sampler.py:326-331); UniformPrior(D,-1,1)
+        // (priors.py:39-43): NaN compares false, i.e. counts as inside; padded dims hold 0
+        int okl = 1;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) okl &= !(xp[c][uu] < -1.f || xp[c][uu] > 1.f);
+        const bool inb = __ballot(okl != 0) == ~0ull;
+        float log_ratio = inb ? (ldp - ld) : -INFINITY;
+        float ratio = fminf(__expf(log_ratio), 1.0f);  // exp().clamp(max=1)  :335
+        if (log_ratio != log_ratio) ratio = log_ratio;  // NaN stays NaN (u < NaN is false, as in torch)
+        const bool pre = ok && (u < ratio);             // :336
+        const double lp = solo_loglike<U>(like, D, lane, xp);
+        bool acc = pre && (lp > loglstar);  // :361
+        if (free_mode) {  // sampler.py:396-410
+            const double lr = inb ? (double)(ldp - ld) + (lp - logl) : -INFINITY;
+            const double rt = fmin(exp(lr), 1.0);
+            acc = ok && ((double)u < rt);
+        }
+        n_call += (free_mode ? ok : pre) ? 1 : 0;
+        n_acc += acc ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+                z[c][uu] = acc ? zp[c][uu] : z[c][uu];
+                x[c][uu] = acc ? xp[c][uu] : x[c][uu];
+            }
+        ld = acc ? ldp : ld;
+        logl = acc ? lp : logl;
+        if (dynamic) {  // sampler.py:422-431 over the whole batch, `lag` steps behind (mh_common.h)
+            if (lane == 0) acc_lds[it & 1][j] = acc ? 1 : 0;  // posted by the noise wave after the next barrier
+            if (have_total) {
+                if (2 * relayed_total > C) accept += 1; else reject += 1;
+                if (accept > reject) scale *= use_tab ? etab[accept] : exp(1.0 / (1 + accept));
+                if (accept < reject) scale /= use_tab ? etab[reject] : exp(1.0 / (1 + reject));
+            }
+        }
+        STAMP(st3);
+#ifdef NNEST_STAMP
+        a_prop += st1 - st0; a_inv += st2 - st1; a_post += st3 - st2; a_tot += st3 - st0;
+#endif
+        if (DBG && writer_lane && ok) {
+            if (a.hist_x) store_row(a.hist_x, (size_t)row * (S + 1) + it, x);
+            if (a.hist_logl && pos == 0) a.hist_logl[(size_t)row * (S + 1) + it] = logl;
+        }
+    }
+#ifdef NNEST_STAMP
+    if (a.scale_out && lane == 0 && tile == 0 && j == 0) {
+        float *o = a.scale_out;
+        o[0] = (float)a_tot; o[1] = (float)a_prop; o[2] = (float)a_inv; o[3] = (float)a_post;
+    }
+#endif
+    if (writer_lane && ok) {
+        store_row(a.z, (size_t)row, z);
+        if (a.x) store_row(a.x, (size_t)row, x);
+        if (pos == 0) {
+            a.logl[row] = logl;
+            if (a.n_accept) a.n_accept[row] = n_acc;
+            if (a.n_call) a.n_call[row] = n_call;
+        }
+    }
+#ifndef NNEST_STAMP
+    // scale_out has one entry per 16 walkers (nnest_mh_num_groups): the first walker of each group reports
+    if (a.scale_out && lane == 0 && j == 0 && (tile & 3) == 0) a.scale_out[tile >> 2] = (float)scale;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+bool solo_form_eligible(const MhArgs &a, int num_cu) {
+    const FlowShape &s = a.s;
+    if (s.H != 16 || s.B != 3 || s.L != 1 || s.scale_mode != 0 || s.NT < 1 || s.NT > 2) return false;  // 132 weight registers at NT = 2
+    if (a.flags & NNEST_MH_DYNAMIC_STEP) return false;  // the per-16-walker rule belongs to the 16-walker forms
+    if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && mh_flag_lag(a.flags) < 2) return false;  // lag 0 / 1 leave no time for the relay: quad form
+    // one workgroup (4 walkers, 5 waves) per CU, every one resident, + the workgroup that publishes the batch totals
+    return (a.C + 3) / 4 + 1 <= num_cu;
+}
+
+template <int U, bool DBG>
+static hipError_t launch_solo_k(const MhArgs &a, hipStream_t st) {
+    const int batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) ? 1 : 0;
+    const int grid = (a.C + 3) / 4 + batch;  // + the workgroup that publishes the batch-wide counts
+    const size_t lds = (size_t)a.s.nets_params() * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mh_kernel_solo<U, DBG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((mh_kernel_solo<U, DBG>), dim3(grid), dim3(320), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mh_solo(const MhArgs &a, hipStream_t st) {
+    const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
+    switch (a.s.NT) {
+        case 1: return dbg ? launch_solo_k<1, true>(a, st) : launch_solo_k<1, false>(a, st);
+        case 2: return dbg ? launch_solo_k<2, true>(a, st) : launch_solo_k<2, false>(a, st);
+    }
+    return hipErrorInvalidConfiguration;
+}
+
+}  // namespace nnest

@@ -155,7 +155,7 @@ class _HipFlow(object):
         loglstar None / NaN = the unconstrained branch (sampler.py:371-410): likelihood and box prior in the ratio.
         dynamic: False | True or 'batch' (sampler.py:422-431 over all C walkers; `lag` steps between a step and the
         scale that reflects its count, 0 = the reference exactly) | 'group' (per 16 walkers, shard-invariant).
-        form: None (by population) | 'quad' | 'team' | 'reg' | 'image' (include/nnest_hip.h NNEST_MH_FORM_*)."""
+        form: None (by population) | 'solo' | 'quad' | 'team' | 'reg' | 'image' (include/nnest_hip.h NNEST_MH_FORM_*)."""
         free = loglstar is None or loglstar != loglstar
         loglstar = 0.0 if free else loglstar
         assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()
@@ -186,6 +186,16 @@ class _HipFlow(object):
                 int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), _lib.ptr(hx), _lib.ptr(hl), _lib.ptr(n_acc),
                 _lib.ptr(n_call), _lib.ptr(scale_out), _lib.ptr(sync), _lib.current_stream(dev)))
         return dict(x=x, n_accept=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl, sync=sync)
+
+    def mh_form_for(self, C, dynamic=False, lag=None, free=False, form=None):
+        """the K4 form (name) `mh_steps` runs for C walkers under this step rule -- asked of the library
+        (nnest_mh_form_for), which knows the shapes each form is built for; None if the launch would be refused.  A caller
+        that shards one batch over ranks asks for the WHOLE batch and pins the answer on every shard."""
+        fn = getattr(self._lib, 'nnest_mh_form_for', None) if self._sym.get('mh') is getattr(self._lib, 'nnest_mh_constrained_steps', None) else None
+        if fn is None:
+            return None
+        f = fn(self._h, int(C), _lib.mh_flags(dynamic, free, lag, form))
+        return _lib.MH_FORM_NAMES.get(f)
 
     @staticmethod
     def check_sync(res):

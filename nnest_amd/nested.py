@@ -151,20 +151,18 @@ class NestedSampler(Sampler):
         elif self.mpi_rank != 0:
             netG.load_packed(w)
 
-    def _pinned_form(self, C):
-        """the K4 form the WHOLE batch of C chains would run (nnest_kernels.hip launch_mh_t), pinned on every rank's shard so
-        that the sharded batch reproduces the unsharded one bit for bit"""
+    def _pinned_form(self, C, dynamic=False):
+        """the K4 form the WHOLE batch of C chains would run, pinned on every rank's shard so that the sharded batch
+        reproduces the unsharded one bit for bit.  The library is asked (nnest_mh_form_for): which form applies depends on
+        the flow's shape (x_dim, hidden_dim, num_blocks, num_layers, scale) and on the step rule as well as on the population."""
         if self.mpi_size == 1 or self._fused_like_id is None:
             return None
-        from . import _lib
-        cu = getattr(self, '_num_cu', None) or _lib.device_info()['num_cu']
-        self._num_cu = cu
-        netG = self.trainer.netG
-        two = 2 * (4 * getattr(netG, 'num_params', 1 << 30) + 16384) <= 160 * 1024   # two quad workgroups per CU (nnest_quad.hip)
-        for form, tile, lim in (('quad', 4, (2 if two else 1) * cu - 1), ('team', 16, cu), ('reg', 16, 4 * cu)):
-            if -(-C // tile) <= lim:
-                return form
-        return 'image'
+        ask = getattr(self.trainer.netG, 'mh_form_for', None)
+        if ask is None:
+            return None
+        mode = 'batch' if dynamic and getattr(self, '_batch_rule_ok', True) else ('group' if dynamic else False)
+        lag = self.mcmc_step_lag
+        return ask(C, dynamic=mode, lag=lag) or ask(C, dynamic='group' if dynamic else False)
 
     def _checkpoint(self, it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt, state):
         cp = self.logs['checkpoint']
@@ -233,6 +231,11 @@ class NestedSampler(Sampler):
             it = int(self._broadcast(np.array([it], dtype=np.int64))[0])
         total_calls = 0
         if it >= 0:
+            # nested.py:166-195.  The reference has every MPI rank read the checkpoint files; here rank 0 reads them and
+            # broadcasts the state (ranks need no shared file system), each rank taking ncall / size as its own call count
+            # (nested.py:183)
+            STRATS = ('rejection_prior', 'rejection_flow', 'density_flow', 'mcmc')
+            nd = self.num_derived
             if primary:
                 self.logger.info('Using checkpoint [%d]' % it)
                 cp = self.logs['checkpoint']
@@ -241,12 +244,32 @@ class NestedSampler(Sampler):
                 active_u = np.load(os.path.join(cp, 'active_u_%s.npy' % it))
                 active_logl = np.load(os.path.join(cp, 'active_logl_%s.npy' % it))
                 active_derived = np.load(os.path.join(cp, 'active_derived_%s.npy' % it))
-                saved_v = list(np.load(os.path.join(cp, 'saved_v.npy')))
-                saved_logl = np.load(os.path.join(cp, 'saved_logl.npy')).tolist()
-                saved_logwt = np.load(os.path.join(cp, 'saved_logwt.npy')).tolist()
+                saved_arr = np.load(os.path.join(cp, 'saved_v.npy')).reshape(-1, self.x_dim + nd)
+                saved_logl = np.load(os.path.join(cp, 'saved_logl.npy'))
+                saved_logwt = np.load(os.path.join(cp, 'saved_logwt.npy'))
                 assert it == len(saved_logl)
+                head = np.array([data['logz'], data['h'], data['logvol'], data['ncall'], data['fraction_remain'],
+                                 len(data['strategy']), len(data['expired_strategies'])]
+                                + [STRATS.index(m) for m in data['strategy']] + [-1] * (4 - len(data['strategy']))
+                                + [STRATS.index(m) for m in data['expired_strategies']] + [-1] * (4 - len(data['expired_strategies'])),
+                                dtype=np.float64)
+            else:
+                head = np.empty(15)
+                active_u, active_logl = np.empty((N, self.x_dim)), np.empty(N)
+                active_derived = np.empty((N, nd))
+                saved_arr, saved_logl, saved_logwt = np.empty((it, self.x_dim + nd)), np.empty(it), np.empty(it)
             if self.use_mpi:
-                raise NotImplementedError('resume from checkpoint with more than one rank')
+                head = self._broadcast(head)
+                active_u, active_logl = self._broadcast(active_u), self._broadcast(active_logl)
+                if nd > 0:
+                    active_derived = self._broadcast(active_derived)
+                if it > 0:
+                    saved_arr, saved_logl, saved_logwt = (self._broadcast(np.ascontiguousarray(a, dtype=np.float64))
+                                                          for a in (saved_arr, saved_logl, saved_logwt))
+            data = dict(logz=float(head[0]), h=float(head[1]), logvol=float(head[2]), ncall=int(head[3]), fraction_remain=float(head[4]),
+                        strategy=[STRATS[int(k)] for k in head[7:7 + int(head[5])]],
+                        expired_strategies=[STRATS[int(k)] for k in head[11:11 + int(head[6])]])
+            saved_v, saved_logl, saved_logwt = list(saved_arr), list(saved_logl), list(saved_logwt)
             ev, logvol = _Evidence(data['logz'], data['h']), data['logvol']
             self.total_calls = int(data['ncall'] / self.mpi_size)
             total_calls = data['ncall']
@@ -381,7 +404,7 @@ class NestedSampler(Sampler):
                     lo = self.mpi_rank * per
                     my = ctl[lo:lo + per]
                     kw = dict(init_samples=active_u[my, :], init_loglikes=active_logl[my], loglstar=loglstar,
-                              walker_offset=lo, seed=int(ctl[-1]), form=self._pinned_form(C))
+                              walker_offset=lo, seed=int(ctl[-1]), form=self._pinned_form(C, mcmc_dynamic_step_size))
                     # what the loop below consumes of a chain is its first x, its last x and the last logL (+ derived): one
                     # row [x_0 | x_S | logL_S | derived_S] per chain, all-gathered over the ranks (C2) -- on device memory when
                     # the whole batch ran inside the HIP kernel

@@ -100,7 +100,9 @@ class Sampler(object):
             self.use_mpi = True
         self.single_or_primary_process = (not self.use_mpi) or self.mpi_rank == 0
 
-        if self.single_or_primary_process or (log_dir is not None and os.path.isdir(os.path.join(log_dir, 'info'))):
+        # only the primary process owns a run directory: the others neither write it nor read checkpoints from it (the
+        # reference lets every MPI rank read the checkpoint files, sampler.py:179-185; here rank 0 broadcasts the resumed state)
+        if self.single_or_primary_process:
             self.logs = get_or_create_run_dir(log_dir, append_run_num=append_run_num)
             self.log_dir = self.logs['run_dir']
         else:
@@ -121,7 +123,8 @@ class Sampler(object):
             from .trainer import Trainer
             self.trainer = Trainer(x_dim, hidden_dim=hidden_dim, num_slow=num_slow, batch_size=batch_size, flow=flow,
                                    num_blocks=num_blocks, num_layers=num_layers, learning_rate=learning_rate,
-                                   log_dir=self.log_dir, log=self.single_or_primary_process, use_gpu=use_gpu,
+                                   log_dir=self.log_dir if self.single_or_primary_process else None,
+                                   log=self.single_or_primary_process, use_gpu=use_gpu,
                                    base_dist=base_dist, scale=scale, log_level=log_level)
         else:
             self.trainer = trainer
@@ -179,11 +182,12 @@ class Sampler(object):
         prior = self._user_prior
         if prior is None:
             return np.zeros(x.shape[0])
-        pts = self.transform(x) if self._transform_prior else x
         rows = getattr(prior, 'log_prob_rows', None)   # whole-batch form of the same rule, when the prior has one
         if callable(rows):
-            return rows(pts)
-        return np.array([prior(r) for r in pts])
+            return rows(self.transform(x) if self._transform_prior else x)
+        if self._transform_prior:   # one row at a time through the transform, as the reference calls it (sampler.py:159)
+            return np.array([prior(self.transform(r)) for r in x])
+        return np.array([prior(r) for r in x])
 
     # ---- fused-path eligibility -----------------------------------------------------------------------
     def _fused_eligibility(self):
@@ -270,11 +274,16 @@ class Sampler(object):
         try:
             res = netG.mh_steps(*args, dynamic=mode, lag=lag, **kw)
         except _lib.NnestHipError as e:
-            if mode != 'batch' or e.code != _lib.NNEST_E_UNSUPPORTED:
+            if e.code != _lib.NNEST_E_UNSUPPORTED or (mode != 'batch' and form is None):
                 raise
-            self.logger.warning('batch-wide step rule not available for %d walkers (%s); using the per-group rule' % (z.shape[0], e))
-            self._batch_rule_ok = False
-            res = netG.mh_steps(*args, dynamic='group', **kw)
+            # refused: the batch-wide rule on a grid that may not be resident, or a pinned form that does not apply to this
+            # shape / rule.  Next: the per-group rule, with the form the library picks for it.
+            if mode == 'batch':
+                self.logger.warning('batch-wide step rule not available for %d walkers (%s); using the per-group rule' % (z.shape[0], e))
+                self._batch_rule_ok = False
+                mode = 'group'
+            kw['form'] = None
+            res = netG.mh_steps(*args, dynamic=mode, lag=lag, **kw)
         return res, z0, z, logl
 
     def _mcmc_sample_fused(self, mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar, walker_offset,

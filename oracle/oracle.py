@@ -318,11 +318,13 @@ def prior_inbox(x):
     return np.where(np.array(flag) == 1, 0.0, -np.inf)
 
 
-def mcmc_sample(nvp, like, like_scale, init, init_logl, loglstar, step, dynamic, dz, u, lag=0):
+def mcmc_sample(nvp, like, like_scale, init, init_logl, loglstar, step, dynamic, dz, u, lag=0, margins=None):
     """Sampler._mcmc_sample hard-constraint branch (nnest/sampler.py:229-463) with recorded noise.
     Returns the reference's tuple pieces: samples, latent, loglikes, scale, ncall, (acc, rej).
     lag > 0: build-defined variant of the step-size rule -- the update after step `it` uses the accepted count of step
-    it - lag (what the GPU's batch-wide mode does to keep the grid-wide wait off the step; 0 = the reference)."""
+    it - lag (what the GPU's batch-wide mode does to keep the grid-wide wait off the step; 0 = the reference).
+    margins: optional float64 [S, C] array that receives, per step and walker, how far the step's decision was from its
+    thresholds (orc_set_margin_out, nnest_oracle.c) -- for asserting that a kernel's differing decisions were borderline."""
     S, C, D = dz.shape
     init = _f64(init); init_logl = _f64(init_logl); dz = _f32(dz); u = _f32(u)
     samples = np.empty((C, S + 1, D), np.float32)
@@ -332,12 +334,16 @@ def mcmc_sample(nvp, like, like_scale, init, init_logl, loglstar, step, dynamic,
     acc = ctypes.c_long(0); rej = ctypes.c_long(0)
     lib().orc_set_scale_mode(SCALE_MODES[nvp.scale])
     lib().orc_set_step_lag(int(lag))
+    if margins is not None:
+        assert margins.shape == (S, C) and margins.dtype == np.float64 and margins.flags['C_CONTIGUOUS']
+        lib().orc_set_margin_out(_p(margins, _dp))
     ncall = lib().orc_mcmc_sample(_p(nvp.w, _fp), nvp.D, nvp.H, nvp.B, nvp.L, LIKE_IDS[like.lower()],
                                   ctypes.c_float(like_scale), _p(init, _dp), _p(init_logl, _dp), C, S,
                                   ctypes.c_double(loglstar), ctypes.byref(scale), int(bool(dynamic)), _p(dz, _fp),
                                   _p(u, _fp), _p(samples, _fp), _p(latent, _fp), _p(loglikes, _dp),
                                   ctypes.byref(acc), ctypes.byref(rej))
     lib().orc_set_step_lag(0)
+    lib().orc_set_margin_out(None)
     return samples, latent, loglikes, scale.value, ncall, (acc.value, rej.value)
 
 

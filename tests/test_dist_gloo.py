@@ -76,3 +76,99 @@ def test_two_rank_nested_run_is_replicated(tmp_path):
     assert abs(logz0 + 5.80) <= 0.45   # 200 live points: sqrt(h/N) ~ 0.16
     assert nt0 >= 1 and nt1 == 0       # only rank 0 trains; the weights reach rank 1 by broadcast
     assert has_logs0 and not has_logs1  # only the primary process writes the run directory
+
+
+def _resume_worker(rank, world, port, tmp, phase, out):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from nnest_amd.nested import NestedSampler
+        from nnest_amd.likelihoods import Rosenbrock
+        from tests.oracle_trainer import OracleTrainer
+        np.random.seed(3 + rank + 10 * phase)
+        torch.manual_seed(3 + rank + 10 * phase)
+        tr = OracleTrainer(2, seed=7)
+        s = NestedSampler(2, Rosenbrock(2), transform=lambda x: 5 * x, log_dir=tmp, append_run_num=False, resume=True,
+                          num_live_points=120, trainer=tr, log_level=40, checkpoint_min_seconds=0)
+        if phase == 0:      # the run that is "killed": it stops at max_iters with checkpoints on disk
+            s.run(train_iters=40, mcmc_num_chains=6, max_iters=260, log_interval=20)
+        else:               # the resumed run: both ranks continue from rank 0's newest checkpoint
+            s.run(train_iters=40, mcmc_num_chains=6, log_interval=20)
+        out.put((rank, float(s.logz), int(s.niter), int(s.ncall), float(np.sum(s.samples)), int(s.total_calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(target, world, args):
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (out,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_run_resumes_from_checkpoint(tmp_path):
+    """nested.py:166-195 under more than one rank: a run stopped at iteration 261 leaves checkpoint_260; a second two-rank
+    run on the same directory resumes from it (rank 0 reads, every rank receives the state), splits the recorded call count
+    over the ranks (nested.py:183) and converges; the ranks stay replicas of each other."""
+    import glob
+    first = _spawn(_resume_worker, 2, (str(tmp_path), 0))
+    assert first[0][1:5] == first[1][1:5] and first[0][2] == 262    # max_iters = 260 -> niter 262
+    cps = sorted(int(f.split('checkpoint_')[-1].split('.txt')[0]) for f in glob.glob(str(tmp_path / 'checkpoint' / 'checkpoint_*.txt')))
+    assert cps[-1] == 260
+    import json
+    with open(str(tmp_path / 'checkpoint' / 'checkpoint_260.txt')) as f:
+        ncall_cp = json.load(f)['ncall']
+    second = _spawn(_resume_worker, 2, (str(tmp_path), 1))
+    a, b = second
+    assert a[1:5] == b[1:5]                         # replicated after the resume too
+    assert a[2] > 400 and a[3] > ncall_cp           # it went on from iteration 260, counting on top of the checkpoint's calls
+    assert abs(a[1] + 5.80) <= 0.6, a[1]            # 120 live points: sqrt(h/N) ~ 0.2
+
+
+def _rule_worker(rank, world, port, tmp, out):
+    sys.path.insert(0, ROOT)
+    if world > 1:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from nnest_amd.nested import NestedSampler
+        from nnest_amd.likelihoods import Rosenbrock
+        from tests.oracle_trainer import OracleTrainer
+        zs = []
+        for seed in (11, 12, 13):
+            np.random.seed(seed)
+            torch.manual_seed(seed)
+            tr = OracleTrainer(2, seed=seed)
+            s = NestedSampler(2, Rosenbrock(2), transform=lambda x: 5 * x, log_dir=os.path.join(tmp, 'w%d_s%d' % (world, seed)),
+                              num_live_points=150, trainer=tr, log_level=40)
+            s.run(train_iters=60, mcmc_num_chains=16, mcmc_dynamic_step_size=True)
+            zs.append(float(s.logz))
+        out.put((rank, zs))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_per_rank_step_rule_against_whole_batch_rule(tmp_path):
+    """The step-size rule (sampler.py:422-431) counts the accepted chains of ONE process's shard: with N ranks it is a
+    per-shard controller (8 chains each here) where one rank applies it to all 16 (stated deviation of the
+    multi-rank run).  Same seeds, dynamic step, 1 rank against 2: the evidence agrees within the runs' own scatter --
+    150 live points: sqrt(h/N) ~ 0.18 per run, three seeds."""
+    one = _spawn(_rule_worker, 1, (str(tmp_path),))[0][1]
+    two = _spawn(_rule_worker, 2, (str(tmp_path),))
+    assert two[0][1] == two[1][1]
+    d = np.mean(two[0][1]) - np.mean(one)
+    assert abs(d) <= 3 * 0.18 * np.sqrt(2.0 / 3.0), (one, two[0][1])
+    assert abs(np.mean(one) + 5.80) <= 0.35 and abs(np.mean(two[0][1]) + 5.80) <= 0.35

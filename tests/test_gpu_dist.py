@@ -68,6 +68,49 @@ def test_two_ranks_one_gpu(tmp_path, flow):
     assert abs(a[1] + 5.80) <= 0.45, a[1]       # 300 live points: sqrt(h/N) ~ 0.13
 
 
+def _shape_worker(rank, world, port, tmp, D, H, N, out):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from nnest_amd.nested import NestedSampler
+        from nnest_amd.likelihoods import Rosenbrock
+        np.random.seed(100 + rank)
+        torch.manual_seed(100 + rank)
+        s = NestedSampler(D, Rosenbrock(D), transform=lambda x: 5 * x, log_dir=tmp, num_live_points=N, log_level=40, flow='nvp',
+                          hidden_dim=H)
+        form = s._pinned_form(N, True)
+        s.run(strategy=['mcmc'], train_iters=3, mcmc_num_chains=N, mcmc_steps=12, max_iters=N // 4)
+        out.put((rank, float(s.logz), int(s.niter), int(s.ncall), float(np.sum(s.samples)), form, int(s.num_batches)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('D,H,N', [(100, 16, 8000), (20, 32, 2000), (50, 16, 1000)])
+def test_two_ranks_shapes_whose_forms_differ(tmp_path, D, H, N):
+    """round-2 advice: the pinned form of a sharded batch has to be one the flow's SHAPE admits, not only its population --
+    BASELINE config 5's shape (x_dim 100, 8000 chains: no register form at 4 tiles per class), a hidden_dim 32 flow (no
+    quad / team / register form) and config 2's shape (solo form).  The library is asked (nnest_mh_form_for); the run goes
+    through and the ranks stay replicas."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shape_worker, args=(r, world, port, str(tmp_path), D, H, N, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = res
+    assert a[1:] == b[1:] and np.isfinite(a[1]) and a[6] >= 1
+    assert a[5] == {(100, 16, 8000): 'image', (20, 32, 2000): 'image', (50, 16, 1000): 'solo'}[(D, H, N)]
+
+
 def _nccl_single(port, tmp, out):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'

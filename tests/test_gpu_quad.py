@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import oracle as orc  # checker only
+from tests.mh_checks import assert_borderline
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -55,10 +56,12 @@ def test_quad_inkernel_noise_vs_oracle_per_walker(hip, C, S):
     logl = torch.from_numpy(init_logl).cuda()
     res = nvp.mh_steps(0, 5.0, z, logl, loglstar, step, S, seed=seed, walker_offset=off, history=True, form='quad')
     hx, hl = cpu(res['hist_x']), cpu(res['hist_logl'])
-    so, _, lo, _, _, _ = orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, loglstar, step, False, dzc, uc)
+    margins = np.empty((S, C))
+    so, _, lo, _, _, _ = orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, loglstar, step, False, dzc, uc, margins=margins)
     moved_o = np.sum(np.any(so[:, 1:] != so[:, :-1], axis=2), axis=1)
     same = cpu(res['n_accept']) == moved_o
     assert np.sum(~same) <= max(1, C // 200)
+    assert_borderline(hx, so, margins, np.flatnonzero(~same))
     assert rel(hx[same], so[same]) < 5e-5
     assert rel(hl[same], lo[same]) < 5e-5
     assert int(res['n_accept'].sum()) > 0
@@ -117,8 +120,9 @@ def test_batch_wide_step_rule_vs_oracle(hip, C, form, lag):
     logl = torch.from_numpy(init_logl).cuda()
     res = nvp.mh_steps(0, 5.0, z, logl, loglstar, step, S, dynamic='batch', lag=lag, seed=seed, history=True, form=form)
     hip.HipNVP.check_sync(res)
+    margins = np.empty((S, C))
     so, _, lo, sc, ncall, (acc, rej) = orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, loglstar, step, True, cpu(dz),
-                                                       cpu(u), lag=lag)
+                                                       cpu(u), lag=lag, margins=margins)
     scales = cpu(res['scale'])
     assert np.all(scales == scales[0])                       # one rule for the whole batch
     assert abs(float(scales[0]) - sc) < 1e-6 * max(1.0, sc)  # same sequence of majority decisions
@@ -126,6 +130,7 @@ def test_batch_wide_step_rule_vs_oracle(hip, C, form, lag):
     moved_o = np.sum(np.any(so[:, 1:] != so[:, :-1], axis=2), axis=1)
     same = cpu(res['n_accept']) == moved_o
     assert np.sum(~same) <= max(1, C // 200)
+    assert_borderline(cpu(res['hist_x']), so, margins, np.flatnonzero(~same))
     assert rel(cpu(res['hist_x'])[same], so[same]) < 5e-5
     assert rel(cpu(res['hist_logl'])[same], lo[same]) < 5e-5
 

@@ -1,0 +1,216 @@
+"""GPU parity of the "solo" form of the persistent Metropolis kernel (ONE walker per wave; layers as v_fmac_f32 with DPP row
+rotations, both nets of a coupling block in the two halves of the wave: nnest_amd/csrc/nnest_solo.hip) against the oracle
+on the same noise -- Sampler._mcmc_sample (nnest/sampler.py:229-463), hard-constraint and unconstrained branch, fixed step
+and the batch-wide step rule (sampler.py:422-431) relayed by the noise wave.  The form is what BASELINE config 2's 1000
+walkers run by default."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc  # checker only
+from tests.mh_checks import assert_borderline
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from nnest_amd import flow
+    if not torch.cuda.is_available():
+        pytest.fail('no GPU visible: the -m gpu tests must run on an MI355X')
+    return flow
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / (1.0 + np.abs(b))))
+
+
+def trained(hip):
+    g = np.load(os.path.join(G, 'mcmc_rosen_d50.npz'))
+    nvp = hip.HipNVP(50, 16, 3, 1)
+    nvp.load_packed(g['w'])
+    return nvp, orc.NVP(50, 16, 3, 1, g['w']), g
+
+
+def test_solo_is_what_config_2_runs(hip):
+    """the library's own answer (nnest_mh_form_for): 1000 walkers at x_dim 50 run the solo form under a fixed step and under
+    the batch-wide rule at the default lag; lag 0 / 1 (no time for the relay), the per-group rule, x_dim > 64 and
+    populations beyond four walkers per CU go to the other forms"""
+    nvp, _, _ = trained(hip)
+    assert nvp.mh_form_for(1000) == 'solo' and nvp.mh_form_for(1000, dynamic='batch') == 'solo'
+    assert nvp.mh_form_for(1000, dynamic='batch', lag=0) == 'quad' and nvp.mh_form_for(1000, dynamic='group') in ('team', 'reg', 'image')
+    assert nvp.mh_form_for(2000) == 'quad' and nvp.mh_form_for(4000) == 'team' and nvp.mh_form_for(100000) == 'image'
+    assert nvp.mh_form_for(100000, dynamic='batch') is None                    # grid may not be resident: refused
+    assert nvp.mh_form_for(1000, form='team') == 'team' and nvp.mh_form_for(5000, form='solo') is None
+    big = hip.HipNVP(100, 16, 3, 1, seed=0)
+    assert big.mh_form_for(1000) == 'quad' and big.mh_form_for(8000) == 'image' and big.mh_form_for(8000, form='reg') is None
+    wide = hip.HipNVP(20, 32, 3, 1, seed=0)
+    assert wide.mh_form_for(500) == 'image' and wide.mh_form_for(500, form='quad') is None
+
+
+@pytest.mark.parametrize('C,S', [(1000, 30), (37, 25), (3, 40), (1020, 4), (1, 50)])
+def test_solo_inkernel_noise_vs_oracle_per_walker(hip, C, S):
+    """Fixed step size: walkers are independent, so every walker's chain is replayed through the oracle on the kernel's own
+    noise (nnest_mh_fill_noise).  A walker whose accept count differs took a borderline decision the other way (float32
+    rounding of a different summation order): asserted to be borderline, then left out; there may be very few."""
+    nvp, o, g = trained(hip)
+    rng = np.random.RandomState(C)
+    init = g['init'][rng.randint(0, g['init'].shape[0], size=C)]
+    init_logl = orc.loglike('rosenbrock', init, 5.0)
+    loglstar = float(np.min(init_logl)) - 1e3
+    step, seed, off = 0.05, 424242, 77
+    dz, u = nvp.fill_noise(S, C, seed=seed, walker_offset=off)
+    z, _ = nvp.forward(init)
+    logl = torch.from_numpy(init_logl).cuda()
+    res = nvp.mh_steps(0, 5.0, z, logl, loglstar, step, S, seed=seed, walker_offset=off, history=True, form='solo')
+    hx, hl = cpu(res['hist_x']), cpu(res['hist_logl'])
+    margins = np.empty((S, C))
+    so, _, lo, _, ncall, _ = orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, loglstar, step, False, cpu(dz), cpu(u),
+                                             margins=margins)
+    moved_o = np.sum(np.any(so[:, 1:] != so[:, :-1], axis=2), axis=1)
+    same = cpu(res['n_accept']) == moved_o
+    assert np.sum(~same) <= max(1, C // 200)
+    assert_borderline(hx, so, margins, np.flatnonzero(~same))
+    assert rel(hx[same], so[same]) < 5e-5
+    assert rel(hl[same], lo[same]) < 5e-5
+    assert int(res['n_accept'].sum()) > 0
+    if same.all():
+        assert int(res['n_call'].sum()) == ncall
+    # production instantiation (no history): same final state, bit for bit; and the default form IS this one
+    for form in ('solo', None):
+        z2, _ = nvp.forward(init)
+        logl2 = torch.from_numpy(init_logl).cuda()
+        res2 = nvp.mh_steps(0, 5.0, z2, logl2, loglstar, step, S, seed=seed, walker_offset=off, form=form)
+        assert torch.equal(z2, z) and torch.equal(logl2, logl) and torch.equal(res2['x'], res['x'])
+        assert torch.equal(res2['n_accept'], res['n_accept']) and torch.equal(res2['n_call'], res['n_call'])
+    assert rel(cpu(res['x']), hx[:, -1]) == 0.0
+
+
+@pytest.mark.parametrize('D,like,scale', [(2, 'rosenbrock', 5.0), (3, 'rosenbrock', 5.0), (20, 'gaussmix', 10.0), (32, 'himmelblau', 5.0),
+                                          (33, 'rosenbrock', 5.0), (50, 'rosenbrock', 5.0), (64, 'rosenbrock', 5.0),
+                                          (7, 'gaussian', 3.0), (5, 'shell', 6.0), (5, 'double_shell', 6.0), (2, 'eggbox', 15.0)])
+def test_solo_shapes_and_likelihoods_vs_oracle(hip, D, like, scale):
+    """x_dim 2..64 (one and two register groups per class, odd sizes, full tiles) and every fused likelihood, fixed step,
+    per walker against the oracle's chain."""
+    nvp = hip.HipNVP(D, 16, 3, 1, seed=D)
+    o = orc.NVP(D, 16, 3, 1, nvp.store_packed())
+    params = {'gaussian': (0.5,), 'shell': (0.1, 2.0, 0.0), 'double_shell': (0.1, 2.0, -1.0, 0.2, 1.5, 1.0)}.get(like)
+    C, S = 70, 15
+    rng = np.random.RandomState(D)
+    init = rng.uniform(-0.5, 0.5, size=(C, D))
+    init_logl = orc.loglike(like, init, scale, params)
+    z, _ = nvp.forward(init)
+    logl = torch.from_numpy(init_logl).cuda()
+    lid = hip._lib.LIKE_IDS[like]
+    res = nvp.mh_steps(lid, scale, z, logl, -1e300, 0.05, S, seed=9, history=True, form='solo', like_params=params)
+    hx = cpu(res['hist_x'])
+    lo = orc.loglike(like, hx.reshape(-1, D), scale, params).reshape(C, S + 1)   # every stored logL belongs to its stored x
+    hl = cpu(res['hist_logl'])
+    assert np.max(np.abs(hl - lo) / (1.0 + np.abs(lo))) < 5e-5
+    xo, _ = o.inverse(cpu(z))                                                    # the final x is f^-1 of the final latent
+    assert rel(cpu(res['x']), xo) < 1e-4
+    assert float(res['x'].abs().max()) <= 1.0 and int(res['n_accept'].sum()) > 0
+    assert torch.equal(res['n_call'], res['n_accept'])   # threshold -1e300: every pre-accepted proposal is accepted
+    if like == 'rosenbrock':   # and the whole chain against the oracle's on the same noise
+        dz, u = nvp.fill_noise(S, C, seed=9)
+        margins = np.empty((S, C))
+        so, _, _, _, _, _ = orc.mcmc_sample(o, like, scale, init, init_logl, -1e300, 0.05, False, cpu(dz), cpu(u), margins=margins)
+        moved_o = np.sum(np.any(so[:, 1:] != so[:, :-1], axis=2), axis=1)
+        same = cpu(res['n_accept']) == moved_o
+        assert np.sum(~same) <= 1
+        assert_borderline(hx, so, margins, np.flatnonzero(~same))
+        assert rel(hx[same], so[same]) < 5e-5
+
+
+@pytest.mark.parametrize('C,lag', [(1000, 2), (1000, 4), (333, 3), (1017, 8), (64, 15)])
+def test_solo_batch_wide_step_rule_vs_oracle(hip, C, lag):
+    """NNEST_MH_DYNAMIC_BATCH relayed by the noise wave: the accept count is taken over the WHOLE launch, `lag` steps behind.
+    The oracle runs the whole batch with the same lag: same scale sequence, same chains."""
+    nvp, o, g = trained(hip)
+    rng = np.random.RandomState(C + lag)
+    init = g['init'][rng.randint(0, g['init'].shape[0], size=C)]
+    init_logl = orc.loglike('rosenbrock', init, 5.0)
+    loglstar = float(np.min(init_logl)) - 1e3
+    S, step, seed = 40, 0.3, 99
+    dz, u = nvp.fill_noise(S, C, seed=seed)
+    z, _ = nvp.forward(init)
+    logl = torch.from_numpy(init_logl).cuda()
+    res = nvp.mh_steps(0, 5.0, z, logl, loglstar, step, S, dynamic='batch', lag=lag, seed=seed, history=True, form='solo')
+    hip.HipNVP.check_sync(res)
+    margins = np.empty((S, C))
+    so, _, lo, sc, ncall, (acc, rej) = orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, loglstar, step, True, cpu(dz),
+                                                       cpu(u), lag=lag, margins=margins)
+    scales = cpu(res['scale'])
+    assert np.all(scales == scales[0])                       # one rule for the whole batch
+    assert abs(float(scales[0]) - sc) < 1e-6 * max(1.0, sc)  # same sequence of majority decisions
+    assert sc != step                                        # the rule did act
+    moved_o = np.sum(np.any(so[:, 1:] != so[:, :-1], axis=2), axis=1)
+    same = cpu(res['n_accept']) == moved_o
+    assert np.sum(~same) <= max(1, C // 200)
+    assert_borderline(cpu(res['hist_x']), so, margins, np.flatnonzero(~same))
+    assert rel(cpu(res['hist_x'])[same], so[same]) < 5e-5
+    assert rel(cpu(res['hist_logl'])[same], lo[same]) < 5e-5
+
+
+def test_solo_agrees_with_the_quad_form_and_shards(hip):
+    """the same launch in the solo and the quad form: the same chains to rounding; a shard with walker_offset reproduces the
+    slice of the full solo launch bit for bit (a walker's chain depends on its own noise stream only)"""
+    nvp, o, g = trained(hip)
+    C = 600
+    init = g['init'][np.arange(C) % g['init'].shape[0]]
+    init_logl = orc.loglike('rosenbrock', init, 5.0)
+
+    def run(lo, hi, form, **kw):
+        z, _ = nvp.forward(init[lo:hi])
+        logl = torch.from_numpy(init_logl[lo:hi]).cuda()
+        res = nvp.mh_steps(0, 5.0, z, logl, -1e9, 0.03, 25, seed=31, walker_offset=lo, form=form, **kw)
+        return cpu(z), cpu(logl), cpu(res['n_accept'])
+
+    zs, ls, ns = run(0, C, 'solo')
+    zq, lq, nq = run(0, C, 'quad')
+    same = ns == nq
+    assert np.sum(~same) <= 3
+    assert rel(zs[same], zq[same]) < 2e-5 and rel(ls[same], lq[same]) < 2e-5
+    zp, lp, _ = run(201, 333, 'solo')
+    assert np.array_equal(zp, zs[201:333]) and np.array_equal(lp, ls[201:333])
+
+
+def test_solo_unconstrained_branch_vs_oracle(hip):
+    """loglstar = None (sampler.py:371-410): likelihood and box prior in the Metropolis ratio"""
+    nvp, o, g = trained(hip)
+    C, S = 200, 20
+    init = g['init'][np.arange(C) % g['init'].shape[0]]
+    init_logl = orc.loglike('rosenbrock', init, 5.0)
+    dz, u = nvp.fill_noise(S, C, seed=3)
+    z, _ = nvp.forward(init)
+    logl = torch.from_numpy(init_logl).cuda()
+    res = nvp.mh_steps(0, 5.0, z, logl, None, 0.01, S, seed=3, history=True, form='solo')
+    so, _, lo, _, ncall, (acc, _) = orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, float('nan'), 0.01, False, cpu(dz), cpu(u))
+    moved_o = np.sum(np.any(so[:, 1:] != so[:, :-1], axis=2), axis=1)
+    same = cpu(res['n_accept']) == moved_o
+    assert np.sum(~same) <= 3 and int(res['n_call'].sum()) == C * S == ncall
+    assert rel(cpu(res['hist_x'])[same], so[same]) < 5e-5
+    assert rel(cpu(res['hist_logl'])[same], lo[same]) < 2e-4
+
+
+def test_solo_golden_trace_recorded_noise(hip):
+    """the reference's own recorded torch noise (tests/golden/mcmc_rosen_d50.npz, fixed step): every decision and state"""
+    g = np.load(os.path.join(G, 'mcmc_rosen_d50.npz'))
+    assert not bool(g['dynamic'])
+    nvp = hip.HipNVP(50, 16, 3, 1)
+    nvp.load_packed(g['w'])
+    S, C, _ = g['dz'].shape
+    z, _ = nvp.forward(g['init'])
+    logl = torch.from_numpy(g['init_logl']).cuda().contiguous()
+    res = nvp.mh_steps(0, float(g['scale']), z, logl, float(g['loglstar']), float(g['step']), S,
+                       noise=(torch.from_numpy(g['dz']), torch.from_numpy(g['u'])), history=True, form='solo')
+    assert int(res['n_call'].sum()) == int(g['ncall']) and int(res['n_accept'].sum()) == int(g['total_accepted'])
+    assert rel(cpu(res['hist_x']), g['samples']) < 3e-5 and rel(cpu(res['hist_logl']), g['loglikes']) < 3e-5
+    assert rel(cpu(z), g['latent'][:, -1]) < 3e-5
