@@ -24,8 +24,8 @@
 // One workgroup = four net waves (walkers 4 tile .. 4 tile + 3) + one noise wave that draws the next step's proposal noise
 // (the xoshiro streams of every other form: nnest_mh_fill_noise replays them) and relays the batch-wide step rule
 // (mh_common.h) so that a step of the net waves holds no global-memory operation; ONE workgroup barrier per step.
-// Summation order differs from the other forms (K split in two halves, left to right), so results agree with them and
-// with the oracle to rounding, not bitwise; decisions on the same noise are the same except at rounding-borderline ratios.
+// Summation order differs from the other forms (K split in two halves, left to right), so results agree with them (and with a
+// CPU restatement) to rounding, not bitwise; decisions on the same noise are the same except at rounding-borderline ratios.
 #include "mh_common.h"
 #include "nnest_internal.h"
 
