@@ -96,14 +96,16 @@ def cpu_baseline(D, w, like, scale, walkers, target_seconds=10.0):
                           walkers, steps_all, threads, cores)}
 
 
-def committed_traffic(tag='r02'):
+def committed_traffic(kernel, tag='r03'):
     """HBM bytes per K4 launch from this round's committed rocprofv3 PMC passes of THIS command (scripts/profile_bench.sh ->
-    profiles/<tag>/bench_pmc.json); None when the profile is absent"""
+    profiles/<tag>/bench_pmc.json); None when the profile is absent or was taken on another kernel than the one that just ran"""
     path = os.path.join(ROOT, 'profiles', tag, 'bench_pmc.json')
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
         d = json.load(f)
+    if d.get('kernel') != kernel:
+        return None, None
     return d.get('traffic_bytes_per_launch'), os.path.relpath(path, ROOT)
 
 
@@ -209,8 +211,7 @@ def main():
     else:
         C_total = args.walkers or N_cfg
         C = -(-C_total // world)
-        cu = _lib.device_info()['num_cu']
-        form = next((f for f, t, lim in (('quad', 4, (2 if D <= 64 else 1) * cu - 1), ('team', 16, cu), ('reg', 16, 4 * cu)) if -(-C_total // t) <= lim), 'image')
+        form = 'whole batch'   # resolved below: the form the WHOLE batch would run, pinned on every shard
     S = args.mcmc_steps if args.mcmc_steps > 0 else 5 * D
     nvp = flow.HipNVP(D, H, B, L, device=dev, seed=0)
     rng = np.random.RandomState(1234 + rank)
@@ -222,6 +223,11 @@ def main():
     step_size = 1.0 / np.sqrt(D)
     dynamic = False if args.fixed_step else 'batch'
     lag = None if args.lag < 0 else args.lag
+    if form == 'whole batch':   # the library's own answer (nnest_mh_form_for); a population too large for the batch rule's
+        form = nvp.mh_form_for(C_total, dynamic=dynamic, lag=lag)   # resident grid runs the per-16-walker rule
+        if form is None and dynamic:
+            dynamic = 'group'
+            form = nvp.mh_form_for(C_total, dynamic=dynamic)
 
     # state buffers are re-seeded outside the timed launches (clone is not part of the hot path)
     zs = [z0.clone() for _ in range(args.steps + args.warmup)]
@@ -272,10 +278,10 @@ def main():
         achieved_tflops = evals_per_launch * fl / (kern_ms * 1e-3) / 1e12
         info = _lib.device_info()
         cu = info['num_cu']
-        kform = form or next((f for f, t, lim in (('quad', 4, (2 if D <= 64 else 1) * cu - 1), ('team', 16, cu), ('reg', 16, 4 * cu)) if -(-C // t) <= lim), 'image')
-        tiles = -(-C // (4 if kform == 'quad' else 16))
+        kform = form or nvp.mh_form_for(C, dynamic=dynamic, lag=lag)
+        tiles = -(-C // (4 if kform in ('quad', 'solo') else 16))
         default_workload = (args.config, C, S, world, dynamic) == (2, 1000, 250, 1, 'batch') and lag is None
-        traffic, traffic_src = committed_traffic() if default_workload else (None, None)
+        traffic, traffic_src = committed_traffic('mh_kernel_%s' % kform) if default_workload else (None, None)
         out = {
             'metric': METRIC % D,
             'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -295,8 +301,11 @@ def main():
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'mh_kernel_%s' % kform, 'kernel_ms': kern_ms, 'flops_per_eval': fl,
                          'hbm_frac_if_streamed': evals_per_launch * alg_bytes_per_eval(D) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         'note': 'f32-input MFMA peak (= f32 vector peak); %d walker tiles on %d CUs: latency-bound at this '
-                                 'population (a step is a serial chain of 9 small layers), see `saturated`' % (tiles, cu)},
+                         'step_rule_lag': (lag if lag is not None else nvp.default_lag(C, form)) if dynamic == 'batch' else None,
+                         'note': 'f32 peak: the f32-input MFMA rate and the f32 vector (v_fma) rate are the same 157.3 TFLOP/s on '
+                                 'gfx950; the solo form runs its layers on the vector unit (v_fmac_f32 + DPP), the other forms on '
+                                 'MFMA.  %d walker tiles on %d CUs: latency-bound at this population (a step is a serial chain of '
+                                 '9 small layers), see `saturated`' % (tiles, cu)},
             'device': info['name'],
         }
         if world == 1 and dist is None and not args.bare:

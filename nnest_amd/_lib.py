@@ -23,6 +23,7 @@ MH_DYNAMIC_BATCH = 4     # over the whole launch, as the reference (sampler.py:4
 MH_FORMS = {None: 0, 'auto': 0, 'image': 1, 'reg': 2, 'team': 3, 'quad': 4, 'quad1': 5, 'solo': 6}
 MH_FORM_NAMES = {v: k for k, v in MH_FORMS.items() if isinstance(k, str) and v}
 MH_DEFAULT_LAG = 4      # steps between a step and the scale that reflects its batch-wide count
+MH_SOLO_LAG = 8         # ... where the solo form runs (its steps are shorter: the same ~10 us of latency)
 TRAIN_RESUME = 1
 TRAIN_FINALIZE = 2
 TRAIN_ONE_CU = 4

@@ -29,7 +29,11 @@ __host__ __device__ inline int mh_flag_form(int flags) { return (flags >> 16) & 
 // workgroup then reads one word per step.  Layout: counters [steps + 2][8][8], results [steps + 2][8][8], error word.
 enum { MH_SYNC_SHARDS = 8, MH_SYNC_STRIDE = 8 /* uint64 per shard slot */, MH_SYNC_MAX_POLLS = 1 << 20 };
 __host__ __device__ inline size_t mh_sync_counter_words(int steps) { return (size_t)(steps + 2) * MH_SYNC_SHARDS * MH_SYNC_STRIDE; }
-__host__ __device__ inline size_t mh_sync_words(int steps) { return 2 * mh_sync_counter_words(steps); }
+// behind the counters and the per-step results: one "window" word per 32 steps (8 replicas): high half = P, the number of steps
+// published so far (all steps <= P), low half = the up/down votes (2 * total > walkers) of the window's steps.  ONE fresh load
+// of the current window tells a reader every decision taken so far, however early or late it asks (solo form).
+__host__ __device__ inline size_t mh_sync_window_words(int steps) { return (size_t)((steps + 2) / 32 + 1) * MH_SYNC_SHARDS * MH_SYNC_STRIDE; }
+__host__ __device__ inline size_t mh_sync_words(int steps) { return 2 * mh_sync_counter_words(steps) + mh_sync_window_words(steps); }
 
 struct MhArgs {
     const float *img;
@@ -133,9 +137,11 @@ __device__ __forceinline__ int mh_sync_total(const unsigned long long *sync, int
 // The publishing wave keeps EIGHT steps in flight (lane group g = lane >> 3 polls step t0 + g, one shard per lane): a poll is a
 // round trip to the memory side (~1.5 us, about one step), so a wave that handled one step per round trip would throttle the
 // whole grid to its own pace (measured: +0.08 ms per 250 steps at any lag).  Steps are published in order.
-__device__ __forceinline__ void mh_sync_publisher(unsigned long long *sync, int steps, int last_step, int nwg, int lane, int *err) {
+__device__ __forceinline__ void mh_sync_publisher(unsigned long long *sync, int steps, int last_step, int nwg, int nwalkers, int lane, int *err) {
     const int g = lane >> 3, sh = lane & 7;
     unsigned long long *results = sync + mh_sync_counter_words(steps);
+    unsigned long long *windows = sync + 2 * mh_sync_counter_words(steps);
+    unsigned int wbits = 0;   // votes of the window being filled
     int t0 = 1, polls = 0;
     while (t0 <= last_step) {
         const int t = t0 + g;
@@ -152,15 +158,31 @@ __device__ __forceinline__ void mh_sync_publisher(unsigned long long *sync, int 
         if (g < ndone)
             __hip_atomic_store(results + ((size_t)t * MH_SYNC_SHARDS + sh) * MH_SYNC_STRIDE, (1ull << 63) | (v & 0xffffffffull),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ndone > 0) {   // the window words: steps t0 .. t0 + ndone - 1 (step s is bit (s - 1) & 31 of window (s - 1) >> 5)
+            const unsigned long long up = __ballot(done && 2 * (int)(v & 0xffffffffull) > nwalkers);   // lanes 8 j: step t0 + j
+            for (int j = 0; j < ndone; ++j) {
+                const int s_ = t0 + j, wi = (s_ - 1) >> 5, bi = (s_ - 1) & 31;
+                wbits |= (unsigned int)((up >> (8 * j)) & 1ull) << bi;
+                if (bi == 31 || j == ndone - 1) {   // window complete, or the last step published this round
+                    if (lane < MH_SYNC_SHARDS)
+                        __hip_atomic_store(windows + ((size_t)wi * MH_SYNC_SHARDS + lane) * MH_SYNC_STRIDE,
+                                           ((unsigned long long)(unsigned int)s_ << 32) | wbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (bi == 31) wbits = 0;
+                }
+            }
+        }
         t0 += ndone;
         if (ndone == 0) {
             if (++polls > MH_SYNC_MAX_POLLS || ((polls & 255) == 0 && mh_sync_failed(err))) {
                 mh_sync_fail(err);
                 // unblock the readers: publish what there is
                 for (int tt = t0; tt <= last_step; ++tt)
-                    if (lane < MH_SYNC_SHARDS)
+                    if (lane < MH_SYNC_SHARDS) {
                         __hip_atomic_store(results + ((size_t)tt * MH_SYNC_SHARDS + lane) * MH_SYNC_STRIDE, 1ull << 63, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(windows + ((size_t)((tt - 1) >> 5) * MH_SYNC_SHARDS + lane) * MH_SYNC_STRIDE,
+                                           (unsigned long long)(unsigned int)last_step << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 return;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -184,6 +206,27 @@ __device__ __forceinline__ int mh_result_wait(const unsigned long long *sync, in
         v = mh_result_load(sync, steps, it, wg);
     }
     return (int)(v & 0xffffffffull);
+}
+
+// the window word that holds step `it` (this workgroup's replica)
+__device__ __forceinline__ unsigned long long mh_window_load(const unsigned long long *sync, int steps, int it, int wg) {
+    const unsigned long long *w = sync + 2 * mh_sync_counter_words(steps) + ((size_t)((it - 1) >> 5) * MH_SYNC_SHARDS + (wg & (MH_SYNC_SHARDS - 1))) * MH_SYNC_STRIDE;
+    return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// did step `it` vote up?  `first`: a window word loaded earlier; polls (bounded) until the word covers the step
+__device__ __forceinline__ bool mh_window_vote(const unsigned long long *sync, int steps, int it, int wg, unsigned long long first, int *err) {
+    unsigned long long v = first;
+    int polls = 0;
+    while ((int)(v >> 32) < it) {
+        if ((polls & 255) == 0 && mh_sync_failed(err)) break;
+        if (++polls > MH_SYNC_MAX_POLLS) {
+            mh_sync_fail(err);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        v = mh_window_load(sync, steps, it, wg);
+    }
+    return ((v >> ((it - 1) & 31)) & 1ull) != 0;
 }
 
 }  // namespace nnest

@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(192, 2) mh_kernel_team(MhArgs a) {  // min 2 w
     const int lag_rule = mh_flag_lag(a.flags);
     const bool relay = batch_rule && lag_rule >= 2;
     if (tile >= ntiles) {   // the workgroup behind the tiles publishes the batch-wide accept counts (mh_common.h)
-        if (relay && role == 0) mh_sync_publisher(a.sync, S, S - lag_rule, ntiles, lane, a.sync_err);
+        if (relay && role == 0) mh_sync_publisher(a.sync, S, S - lag_rule, ntiles, a.C, lane, a.sync_err);
         return;
     }
     for (int i = threadIdx.x; i < B * 2 * TI::NBIAS; i += blockDim.x) {

@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(TEAM ? 192 : 128, 1) mh_kernel_quad(MhArgs a) 
     if (tile >= ntiles) {
         // batch-wide step rule (mh_common.h): the one workgroup behind the tiles sums every step's counters as soon as they
         // are complete and publishes the total; its other waves leave at once
-        if (batch_rule && wave == 0) mh_sync_publisher(a.sync, S, S - lag_rule, ntiles, lane, a.sync_err);
+        if (batch_rule && wave == 0) mh_sync_publisher(a.sync, S, S - lag_rule, ntiles, C, lane, a.sync_err);
         return;
     }
     {

@@ -37,21 +37,6 @@ template <int N>  // lane p of every 16-lane row <- lane (p - N) & 15 of the sam
 static __device__ __forceinline__ float solo_ror(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true));
 }
-// acc += w * x[(p - N) & 15]: one v_fmac_f32 with the rotation folded in (hipcc 7.2 does not combine update_dpp + fma by
-// itself: it emits v_mov_b32_dpp + v_pk_fma_f32).  The caller guards x (solo_dpp_guard) -- a DPP read needs two wait states
-// after the VALU write of its source, and the hazard recognizer does not look inside inline asm.
-template <int N>
-static __device__ __forceinline__ void solo_fmac(float &acc, float x, float w) {
-    if constexpr (N == 0) acc = __builtin_fmaf(w, x, acc);
-    else asm("v_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(w), "n"(N));
-}
-static __device__ __forceinline__ void solo_dpp_guard(float &x) { asm("s_nop 1" : "+v"(x)); }
-// the input of a layer as the h = 1 rows (rows 1 and 3 of the wave) need it: rotated by 8; rows 0 and 2 keep it
-static __device__ __forceinline__ float solo_prerotate(float v) {
-    float r = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x128, 0xa, 0xf, false));
-    solo_dpp_guard(r);
-    return r;
-}
 // sum of the two K-halves: rows (n, 0) and (n, 1) both end with row(n,0) + row(n,1) -- the same addition in both, so the
 // copies stay bit-identical.  (v_permlane16_swap with both operands the same value: hipcc 7.2 folds the two results of the
 // builtin, hence the asm; s_nop 1: the swap reads VGPRs a VALU instruction may just have written.)
@@ -114,51 +99,113 @@ static __device__ __forceinline__ void solo_gather(SoloNet<U> &n, const float *p
     }
 }
 
-#define SOLO_ROT8(STMT) { constexpr int t = 0; STMT } { constexpr int t = 1; STMT } { constexpr int t = 2; STMT } { constexpr int t = 3; STMT } \
-                        { constexpr int t = 4; STMT } { constexpr int t = 5; STMT } { constexpr int t = 6; STMT } { constexpr int t = 7; STMT }
+// ---- a layer's chain of multiply-adds as ONE asm statement ----------------------------------------------------------------
+// hipcc 7.2 does not fold update_dpp into a multiply-add (it emits v_mov_b32_dpp + v_pk_fma_f32), so the v_fmac_f32_dpp are
+// inline asm; written statement by statement, hipcc puts an s_nop between every two of them -- it has to assume that an
+// inline asm reading a VGPR the previous instruction wrote might be a DPP read of it (two wait states) -- which at the one
+// instruction per 4 cycles a lone wave issues is a fifth of the layer.  Inside one statement the hazards are ours: the only DPP
+// source is the layer's input, written before the statement (s_nop 1 at its head covers the row-masked pre-rotation right in
+// front of it); the accumulators are plain VOP2 operands, which need no wait states.
+#define SOLO_D(acc, x, w, t) "v_fmac_f32_dpp %" #acc ", %" #x ", %" #w " row_ror:" #t " row_mask:0xf bank_mask:0xf\n\t"
+#define SOLO_F(acc, x, w) "v_fmac_f32 %" #acc ", %" #x ", %" #w "\n\t"
 
-// CouplingLayer.inverse (networks.py:300-309), both nets at once (the wave's two halves); returns the lane's log-det partial
-template <int U>
-static __device__ __forceinline__ float solo_coupling_inverse(const SoloNet<U> &w, bool translate_half, const float (&cond)[U],
-                                                              float (&trans)[U]) {
-    float xin[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) xin[u] = solo_prerotate(cond[u]);
-    float a0 = w.b1, a1 = 0.f;  // two accumulators: a dependent v_fmac issues every ~4-5 cycles, an independent one every 4
-    SOLO_ROT8(
-        _Pragma("unroll") for (int u = 0; u < U; ++u) {
-            if ((t + u) & 1) solo_fmac<t>(a1, xin[u], w.w1[u][t]);
-            else solo_fmac<t>(a0, xin[u], w.w1[u][t]);
-        })
-    float hid = solo_join(a0 + a1);
-    hid = translate_half ? fmaxf(hid, 0.f) : fast_tanh(hid);
-    {
-        float hin = solo_prerotate(hid);
-        a0 = w.b2; a1 = 0.f;
-        SOLO_ROT8(if (t & 1) solo_fmac<t>(a1, hin, w.w2[t]); else solo_fmac<t>(a0, hin, w.w2[t]);)
-        hid = solo_join(a0 + a1);
-        hid = translate_half ? fmaxf(hid, 0.f) : fast_tanh(hid);
-    }
-    const float hin = solo_prerotate(hid);
-    float o[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) o[u] = w.b3[u];
-    SOLO_ROT8(_Pragma("unroll") for (int u = 0; u < U; ++u) solo_fmac<t>(o[u], hin, w.w3[u][t]);)
-    float ld = 0.f;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        float ls, tt;
-        solo_nets(solo_join(o[u]), ls, tt);
-        trans[u] = (trans[u] - tt) * __expf(-ls);  // (inputs - t) * exp(-log_s)   networks.py:307-309
-        ld -= ls;
-    }
-    return ld;
+// a0 += sum_t w0[t] x0[(p - t) & 15],  a1 += sum_t w1[t] x1[(p - t) & 15]   (t = 0..7)
+static __device__ __forceinline__ void solo_chain_2in(float &a0, float &a1, float x0, float x1, const float (&w0)[8], const float (&w1)[8]) {
+    asm("s_nop 1\n\t"
+        SOLO_F(0, 2, 4) SOLO_F(1, 3, 12)
+        SOLO_D(0, 2, 5, 1) SOLO_D(1, 3, 13, 1) SOLO_D(0, 2, 6, 2) SOLO_D(1, 3, 14, 2) SOLO_D(0, 2, 7, 3) SOLO_D(1, 3, 15, 3)
+        SOLO_D(0, 2, 8, 4) SOLO_D(1, 3, 16, 4) SOLO_D(0, 2, 9, 5) SOLO_D(1, 3, 17, 5) SOLO_D(0, 2, 10, 6) SOLO_D(1, 3, 18, 6)
+        SOLO_D(0, 2, 11, 7) SOLO_D(1, 3, 19, 7)
+        : "+v"(a0), "+v"(a1)
+        : "v"(x0), "v"(x1), "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]), "v"(w0[4]), "v"(w0[5]), "v"(w0[6]), "v"(w0[7]),
+          "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w1[4]), "v"(w1[5]), "v"(w1[6]), "v"(w1[7]));
 }
+// a0 += sum_t w0[t] x[(p - t) & 15],  a1 += sum_t w1[t] x[(p - t) & 15]   (one input, two outputs)
+static __device__ __forceinline__ void solo_chain_2out(float &a0, float &a1, float x, const float (&w0)[8], const float (&w1)[8]) {
+    asm("s_nop 1\n\t"
+        SOLO_F(0, 2, 3) SOLO_F(1, 2, 11)
+        SOLO_D(0, 2, 4, 1) SOLO_D(1, 2, 12, 1) SOLO_D(0, 2, 5, 2) SOLO_D(1, 2, 13, 2) SOLO_D(0, 2, 6, 3) SOLO_D(1, 2, 14, 3)
+        SOLO_D(0, 2, 7, 4) SOLO_D(1, 2, 15, 4) SOLO_D(0, 2, 8, 5) SOLO_D(1, 2, 16, 5) SOLO_D(0, 2, 9, 6) SOLO_D(1, 2, 17, 6)
+        SOLO_D(0, 2, 10, 7) SOLO_D(1, 2, 18, 7)
+        : "+v"(a0), "+v"(a1)
+        : "v"(x), "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]), "v"(w0[4]), "v"(w0[5]), "v"(w0[6]), "v"(w0[7]),
+          "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w1[4]), "v"(w1[5]), "v"(w1[6]), "v"(w1[7]));
+}
+// a0 += sum_{t even} w[t] x[(p - t) & 15],  a1 += sum_{t odd} ...   (one input, one output over two accumulators)
+static __device__ __forceinline__ void solo_chain_1(float &a0, float &a1, float x, const float (&w)[8]) {
+    asm("s_nop 1\n\t"
+        SOLO_F(0, 2, 3) SOLO_D(1, 2, 4, 1) SOLO_D(0, 2, 5, 2) SOLO_D(1, 2, 6, 3) SOLO_D(0, 2, 7, 4) SOLO_D(1, 2, 8, 5) SOLO_D(0, 2, 9, 6)
+        SOLO_D(1, 2, 10, 7)
+        : "+v"(a0), "+v"(a1)
+        : "v"(x), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+}
+// the h = 1 rows' view of a layer input: rotated by 8 in rows 1 and 3, unchanged in rows 0 and 2 (the s_nop 1 at the head of
+// the chain that consumes it is the DPP read's wait)
+static __device__ __forceinline__ float solo_rot8_h1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x128, 0xa, 0xf, false));
+}
+// tanh in the scale half, relu in the translate half, without a branch (hipcc turns the plain conditional into a divergent
+// branch: both sides then run one after the other under exec masks, plus the mask bookkeeping): `sel` is all ones in the
+// translate half; v_bfi_b32 picks the bits
+static __device__ __forceinline__ float solo_activate(float v, unsigned sel) {
+    const float th = fast_tanh(v), rl = fmaxf(v, 0.f);
+    unsigned out;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(out) : "v"(sel), "v"(__float_as_uint(rl)), "v"(__float_as_uint(th)));
+    return __uint_as_float(out);
+}
+// v_permlane16_swap of two DIFFERENT registers: rows (n, 1) of `a` trade places with rows (n, 0) of `b`
+static __device__ __forceinline__ void solo_swap16(float &a, float &b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+}
+
+// CouplingLayer.inverse (networks.py:300-309), both nets at once (the wave's two halves); returns the lane's log-det partial.
+// U = 2: the last layer's two outputs are reduce-SCATTERED over the K-halves (one swap: row h ends with output u = h), so the
+// affine update runs once per lane on the slot its row owns and one more swap hands both results to both rows; the log-det
+// partial is then per row (the caller sums rows h = 0 and 1, solo_logdet_total).
+template <int U>
+static __device__ __forceinline__ float solo_coupling_inverse(const SoloNet<U> &w, unsigned sel, bool h1, const float (&cond)[U],
+                                                              float (&trans)[U]) {
+    float a0 = w.b1, a1 = 0.f;
+    if constexpr (U == 2) {
+        solo_chain_2in(a0, a1, solo_rot8_h1(cond[0]), solo_rot8_h1(cond[1]), w.w1[0], w.w1[1]);
+    } else {
+        solo_chain_1(a0, a1, solo_rot8_h1(cond[0]), w.w1[0]);
+    }
+    float hid = solo_activate(solo_join(a0 + a1), sel);
+    a0 = w.b2; a1 = 0.f;
+    solo_chain_1(a0, a1, solo_rot8_h1(hid), w.w2);
+    hid = solo_activate(solo_join(a0 + a1), sel);
+    const float hin = solo_rot8_h1(hid);
+    if constexpr (U == 2) {
+        float o0 = w.b3[0], o1 = w.b3[1];
+        solo_chain_2out(o0, o1, hin, w.w3[0], w.w3[1]);
+        solo_swap16(o0, o1);               // rows h = 0: both halves of output 0; rows h = 1: both halves of output 1
+        float ls, tt;
+        solo_nets(o0 + o1, ls, tt);
+        const float cur = h1 ? trans[1] : trans[0];
+        float nw = (cur - tt) * __expf(-ls);  // (inputs - t) * exp(-log_s)   networks.py:307-309
+        float nb = nw;
+        solo_swap16(nw, nb);               // every row: nw = slot 0's new value, nb = slot 1's
+        trans[0] = nw;
+        trans[1] = nb;
+        return -ls;
+    } else {
+        float o0 = w.b3[0], o1 = 0.f;
+        solo_chain_1(o0, o1, hin, w.w3[0]);
+        float ls, tt;
+        solo_nets(solo_join(o0 + o1), ls, tt);
+        trans[0] = (trans[0] - tt) * __expf(-ls);
+        return h1 ? 0.f : -ls;             // the same value in both rows: counted once
+    }
+}
+// log-det of the walker from the lanes' partials: over the 16 positions of a row, then over the two K-halves
+static __device__ __forceinline__ float solo_logdet_total(float ld) { return solo_join(solo_row_sum(ld)); }
 
 // ---- likelihoods on a solo wave (the per-term arithmetic of loglike_tile, flow_tile.h; sums over the 16 positions) ----
 #pragma clang fp contract(off)
-template <int U>
-static __device__ __forceinline__ double solo_loglike(const LikeSpec &lk, int D, int lane, const float (&xs)[2][U]) {
+template <int U, int LK>   // LK >= 0: the likelihood id is known at compile time (the other branches are not instantiated)
+static __device__ __forceinline__ double solo_loglike(const LikeSpec &lk_in, int D, int lane, const float (&xs)[2][U]) {
+    struct { int id; float scale; const float *p; } lk = {LK >= 0 ? LK : lk_in.id, lk_in.scale, lk_in.p};
     const int m = lane & 15;
     const float scale = lk.scale;
     float th[2 * U + 1];
@@ -270,14 +317,14 @@ static __device__ __forceinline__ double solo_loglike(const LikeSpec &lk, int D,
 #pragma clang fp contract(fast)
 
 static constexpr int SOLO_ETAB = 1024;   // steps + 2 <= SOLO_ETAB: exp(1 / (1 + k)) from a table
-static constexpr int SOLO_AHEAD = 3;     // the noise wave requests a batch total this many steps before the net waves apply it
 
-template <int U, bool DBG>
+template <int U, bool DBG, int LK>
 __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];  // the packed weights
     __shared__ __attribute__((aligned(16))) float nbuf[2][4][16][2 * U];
     __shared__ float ubuf[2][4];
-    __shared__ int acc_lds[2][4], res_lds[2];  // batch rule relayed by the noise wave: the walkers' accepts / the batch total
+    __shared__ int acc_lds[2][4];   // batch rule: the four walkers' accepts of a step, posted by the noise wave
+    __shared__ float fsbuf[2];      // the proposal scale that goes with a noise buffer
     __shared__ double etab[SOLO_ETAB];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -286,12 +333,12 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     const bool recorded = DBG && a.noise_dz;
     const bool dynamic = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;  // the per-16-walker rule belongs to the 16-walker forms
     const bool use_tab = S + 2 <= SOLO_ETAB;
-    const int lag = mh_flag_lag(a.flags);                          // >= 2 (solo_form_eligible): the rule is always relayed
+    const int lag = mh_flag_lag(a.flags);                          // >= 3 (solo_form_eligible): the rule is always relayed
     const int ntiles = (C + 3) >> 2;
     if (tile >= ntiles) {
         // batch-wide step rule (mh_common.h): the one workgroup behind the tiles sums every step's counters as soon as they
         // are complete and publishes the total; its other waves leave at once
-        if (dynamic && wave == 0) mh_sync_publisher(a.sync, S, S - lag, ntiles, lane, a.sync_err);
+        if (dynamic && wave == 0) mh_sync_publisher(a.sync, S, S - lag, ntiles, C, lane, a.sync_err);
         return;
     }
     {
@@ -305,50 +352,72 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     if (wave == 4) {
         // proposal noise: the streams of the 16-walker forms -- per (walker, lane group g) 8 normals for dims
         // 32 t + 8 g + [0, 8), t < U -- generated by 16 lanes (4 walkers x 4 groups) and written where the net waves read them.
+        // The batch-wide step rule (sampler.py:422-431, `lag` steps behind; mh_common.h) lives here entirely: this wave posts the
+        // tile's accepted count, learns the batch's votes, keeps (accept, reject, scale) in the reference's float64 arithmetic and
+        // hands the net waves the float32 scale of their next proposal with the noise -- a step of the net waves holds neither a
+        // global-memory operation nor the rule's arithmetic.
         const int j = lane & 3, g = (lane >> 2) & 3;
         const bool gen = lane < 16;
         XoshiroNoise<U> rng;
         rng.init(a.seed, a.walker_offset + (uint64_t)(tile * 4 + j), g, D);
-        // batch totals in flight: requested SOLO_AHEAD iterations before they are handed to the net waves (a request is a
-        // round trip to the memory side, ~1.5 us: about two steps of this form)
-        unsigned long long q[SOLO_AHEAD];
-#pragma unroll
-        for (int r = 0; r < SOLO_AHEAD; ++r) q[r] = 0;
-        const int last = S - lag;  // last step whose total is ever applied
-        for (int k = 0; k <= S; ++k) {
-            // between the barriers k - 1 and k the net waves run step k - 1: the accepts of step k - 2 are in LDS, and the total
-            // they will apply at the end of step k (that of step k - lag) has to be in LDS by barrier k
-            const int want = k - lag;
-            unsigned long long cur = 0;
-            if (dynamic) {
-                if (k >= 2 && lane == 0) {
-                    const int *ac = acc_lds[k & 1];
-                    mh_sync_post(a.sync, k - 2, tile, (ac[0] + ac[1]) + (ac[2] + ac[3]));
-                }
-                cur = q[0];
-#pragma unroll
-                for (int r = 0; r + 1 < SOLO_AHEAD; ++r) q[r] = q[r + 1];
-                const int ahead = want + SOLO_AHEAD;
-                q[SOLO_AHEAD - 1] = (ahead >= 1 && ahead <= last) ? mh_result_load(a.sync, S, ahead, tile) : 0ull;
-            }
-            if (gen && !recorded) {
-                float nz[U][8], u;
-                rng.next(nz, u);
-#pragma unroll
-                for (int t = 0; t < U; ++t)
-#pragma unroll
-                    for (int qq = 0; qq < 8; ++qq) {
-                        const int d = 32 * t + 8 * g + qq;        // padded dims (d >= D) carry 0
-                        nbuf[k & 1][j][d / (2 * U)][d % (2 * U)] = nz[t][qq];
-                    }
-                if (g == 0) ubuf[k & 1][j] = u;
-            }
-            if (dynamic && want >= 1) {
-                const int total = mh_result_wait(a.sync, S, want, tile, cur, a.sync_err);
-                if (lane == 0) res_lds[k & 1] = total;
-            }
-            solo_barrier();  // publish buffer k
+        double scale = (double)a.step_size;   // python float in the reference (sampler.py:255, :428-431)
+        int accept = 0, reject = 0;
+        const int last = S - lag;  // last step whose vote is ever applied
+        // The votes arrive as "window" words (every decision published so far in one 64-bit word, mh_common.h), requested TWO
+        // iterations before they are needed: a round trip to the memory side (~1.5 us) is longer than an iteration (~1.2 us).
+        // hipcc waits for a load right where it is issued as soon as its destination is a loop-carried variable, so the requests
+        // are inline asm (sc1: served by the memory side, as the relaxed agent-scope loads elsewhere) and the wait is explicit.
+        // Every iteration issues exactly ONE atomic and ONE request, in that order and after its own consumption, so
+        // "vmcnt(2)" -- everything but the two youngest operations has completed -- is exactly "the request made two
+        // iterations ago has landed" (vector-memory operations complete in order, MI355X_MICROARCH.md).  The loop runs two
+        // iterations per trip: each request has a register pair of its own (qa / qb) and is never moved.
+        const unsigned long long *wbase = a.sync + 2 * mh_sync_counter_words(S) + (size_t)(tile & (MH_SYNC_SHARDS - 1)) * MH_SYNC_STRIDE;
+#define SOLO_NOISE_ITERATION(k_, q_)                                                                                        \
+        {                                                                                                                   \
+            const int k = (k_), want = k - lag;                                                                             \
+            if (dynamic) {                                                                                                  \
+                if (want >= 1) {                                                                                            \
+                    asm volatile("s_waitcnt vmcnt(2)" : "+v"(q_) : : "memory");                                             \
+                    const bool up = mh_window_vote(a.sync, S, want, tile, q_, a.sync_err);                                  \
+                    if (up) accept += 1; else reject += 1;                                                                  \
+                    if (accept > reject) scale *= use_tab ? etab[accept] : exp(1.0 / (1 + accept));                         \
+                    if (accept < reject) scale /= use_tab ? etab[reject] : exp(1.0 / (1 + reject));                         \
+                }                                                                                                           \
+                /* between the barriers k - 1 and k the net waves run step k - 1: the accepts of step k - 2 are in LDS */   \
+                /* (k < 2: a zero to the unused slot of step 0, so that every iteration issues the same operations) */      \
+                if (lane == 0) {                                                                                            \
+                    const int *ac = acc_lds[k & 1];                                                                         \
+                    mh_sync_post(a.sync, k >= 2 ? k - 2 : 0, tile, k >= 2 ? (ac[0] + ac[1]) + (ac[2] + ac[3]) : 0);         \
+                }                                                                                                           \
+                const int ask = min(max(want + 2, 1), max(last, 1));   /* the window of the step needed two iterations on */  \
+                const unsigned long long *wp = wbase + (size_t)((ask - 1) >> 5) * MH_SYNC_SHARDS * MH_SYNC_STRIDE;          \
+                asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(q_) : "v"(wp) : "memory");                        \
+            }                                                                                                               \
+            /* buffer k carries the noise of step k + 1 and its scale: the scale after the votes of the steps <= k - lag */  \
+            if (lane == 0) fsbuf[k & 1] = (float)scale;                                                                     \
+            if (gen && !recorded) {                                                                                         \
+                float nz[U][8], u;                                                                                          \
+                rng.next(nz, u);                                                                                            \
+                _Pragma("unroll") for (int t = 0; t < U; ++t)                                                               \
+                    _Pragma("unroll") for (int qq = 0; qq < 8; ++qq) {                                                      \
+                        const int d = 32 * t + 8 * g + qq; /* padded dims (d >= D) carry 0 */                               \
+                        nbuf[k & 1][j][d / (2 * U)][d % (2 * U)] = nz[t][qq];                                               \
+                    }                                                                                                       \
+                if (g == 0) ubuf[k & 1][j] = u;                                                                             \
+            }                                                                                                               \
+            solo_barrier(); /* publish buffer k */                                                                          \
         }
+        unsigned long long qa = 0, qb = 0;
+        for (int k2 = 0; k2 <= S; k2 += 2) {
+            SOLO_NOISE_ITERATION(k2, qa)
+            if (k2 + 1 <= S) SOLO_NOISE_ITERATION(k2 + 1, qb)
+        }
+#undef SOLO_NOISE_ITERATION
+        if (dynamic) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa), "+v"(qb) : : "memory");   // no request outlives its registers
+#ifndef NNEST_STAMP
+        // scale_out has one entry per 16 walkers (nnest_mh_num_groups): the first tile of each group reports
+        if (a.scale_out && lane == 0 && (tile & 3) == 0) a.scale_out[tile >> 2] = (float)scale;
+#endif
         return;
     }
 
@@ -369,10 +438,12 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
         solo_gather<U>(net[b], wlds + (size_t)(b * 2 + (translate_half ? 1 : 0)) * a.s.net_params, D, (b + 1) & 1, b & 1, lane);
     // NormalizingFlow.inverse (networks.py:34-42), num_blocks = 3: blocks 2, 1, 0; block b conditions on class (b+1)&1 and
     // transforms class b&1
+    const unsigned sel = translate_half ? 0xffffffffu : 0u;
+    const bool h1 = (lane & 16) != 0;
     auto inverse = [&](float (&xs)[2][U]) {
-        float ld = solo_coupling_inverse<U>(net[2], translate_half, xs[1], xs[0]);
-        ld += solo_coupling_inverse<U>(net[1], translate_half, xs[0], xs[1]);
-        ld += solo_coupling_inverse<U>(net[0], translate_half, xs[1], xs[0]);
+        float ld = solo_coupling_inverse<U>(net[2], sel, h1, xs[1], xs[0]);
+        ld += solo_coupling_inverse<U>(net[1], sel, h1, xs[0], xs[1]);
+        ld += solo_coupling_inverse<U>(net[0], sel, h1, xs[1], xs[0]);
         return ld;
     };
 
@@ -385,10 +456,9 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
             z[c][u] = (ok && d < D) ? a.z[(size_t)row * D + d] : 0.f;
             x[c][u] = z[c][u];
         }
-    float ld = solo_row_sum(inverse(x));  // x = f^-1(z), log_det_J  (sampler.py:266, :295)
+    float ld = solo_logdet_total(inverse(x));  // x = f^-1(z), log_det_J  (sampler.py:266, :295)
     double logl = ok ? a.logl[row] : 0.0;
-    double scale = (double)a.step_size;
-    int accept = 0, reject = 0, n_acc = 0, n_call = 0;
+    int n_acc = 0, n_call = 0;
 
     auto store_row = [&](float *base, size_t r, const float (&v)[2][U]) {
 #pragma unroll
@@ -404,16 +474,16 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
         if (a.hist_logl && pos == 0) a.hist_logl[(size_t)row * (S + 1)] = logl;
     }
 
-    float nz[2 * U], u_next = 0.f;
-    int kbuf = 0, relayed_total = 0;
+    float nz[2 * U], u_next = 0.f, fs_next = a.step_size;
+    int kbuf = 0;
     auto fetch_noise = [&]() {
-        solo_barrier();  // the noise wave has published buffer kbuf (and the batch total to apply in step kbuf)
+        solo_barrier();  // the noise wave has published buffer kbuf: noise, accept uniform and scale of the next step
         if (!recorded) {
 #pragma unroll
             for (int k = 0; k < 2 * U; ++k) nz[k] = nbuf[kbuf & 1][j][pos][k];
             u_next = ubuf[kbuf & 1][j];
         }
-        if (dynamic) relayed_total = res_lds[kbuf & 1];
+        fs_next = fsbuf[kbuf & 1];
         ++kbuf;
     };
     fetch_noise();
@@ -423,7 +493,7 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     for (int it = 1; it <= S; ++it) {
         STAMP(st0);
         // proposal z' = z + randn * scale  (sampler.py:310, :316); float32 like torch
-        const float fs = (float)scale;
+        const float fs = fs_next;
         float zp[2][U], xp[2][U];
         float u;
         if (recorded) {
@@ -444,14 +514,13 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
             }
             u = u_next;
         }
-        const bool have_total = dynamic && it - lag >= 1;
         fetch_noise();
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int uu = 0; uu < U; ++uu) xp[c][uu] = zp[c][uu];
         STAMP(st1);
-        const float ldp = solo_row_sum(inverse(xp));  // sampler.py:321
+        const float ldp = solo_logdet_total(inverse(xp));  // sampler.py:321
         STAMP(st2);
 
         // log_ratio = log_det_J' - log_det_J, -inf outside the prior box  (sampler.py:326-331); UniformPrior(D,-1,1)
@@ -466,7 +535,7 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
         float ratio = fminf(__expf(log_ratio), 1.0f);  // exp().clamp(max=1)  :335
         if (log_ratio != log_ratio) ratio = log_ratio;  // NaN stays NaN (u < NaN is false, as in torch)
         const bool pre = ok && (u < ratio);             // :336
-        const double lp = solo_loglike<U>(like, D, lane, xp);
+        const double lp = solo_loglike<U, LK>(like, D, lane, xp);
         bool acc = pre && (lp > loglstar);  // :361
         if (free_mode) {  // sampler.py:396-410
             const double lr = inb ? (double)(ldp - ld) + (lp - logl) : -INFINITY;
@@ -484,14 +553,7 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
             }
         ld = acc ? ldp : ld;
         logl = acc ? lp : logl;
-        if (dynamic) {  // sampler.py:422-431 over the whole batch, `lag` steps behind (mh_common.h)
-            if (lane == 0) acc_lds[it & 1][j] = acc ? 1 : 0;  // posted by the noise wave after the next barrier
-            if (have_total) {
-                if (2 * relayed_total > C) accept += 1; else reject += 1;
-                if (accept > reject) scale *= use_tab ? etab[accept] : exp(1.0 / (1 + accept));
-                if (accept < reject) scale /= use_tab ? etab[reject] : exp(1.0 / (1 + reject));
-            }
-        }
+        if (dynamic && lane == 0) acc_lds[it & 1][j] = acc ? 1 : 0;  // sampler.py:422-431: counted by the noise wave after the next barrier
         STAMP(st3);
 #ifdef NNEST_STAMP
         a_prop += st1 - st0; a_inv += st2 - st1; a_post += st3 - st2; a_tot += st3 - st0;
@@ -516,10 +578,6 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
             if (a.n_call) a.n_call[row] = n_call;
         }
     }
-#ifndef NNEST_STAMP
-    // scale_out has one entry per 16 walkers (nnest_mh_num_groups): the first walker of each group reports
-    if (a.scale_out && lane == 0 && j == 0 && (tile & 3) == 0) a.scale_out[tile >> 2] = (float)scale;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,28 +585,34 @@ bool solo_form_eligible(const MhArgs &a, int num_cu) {
     const FlowShape &s = a.s;
     if (s.H != 16 || s.B != 3 || s.L != 1 || s.scale_mode != 0 || s.NT < 1 || s.NT > 2) return false;  // 132 weight registers at NT = 2
     if (a.flags & NNEST_MH_DYNAMIC_STEP) return false;  // the per-16-walker rule belongs to the 16-walker forms
-    if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && mh_flag_lag(a.flags) < 2) return false;  // lag 0 / 1 leave no time for the relay: quad form
+    if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && mh_flag_lag(a.flags) < 3) return false;  // the relay posts step k - 2 in iteration k and asks for step k - lag before that: lag < 3 runs the quad form
     // one workgroup (4 walkers, 5 waves) per CU, every one resident, + the workgroup that publishes the batch totals
     return (a.C + 3) / 4 + 1 <= num_cu;
 }
 
-template <int U, bool DBG>
+template <int U, bool DBG, int LK>
 static hipError_t launch_solo_k(const MhArgs &a, hipStream_t st) {
     const int batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) ? 1 : 0;
     const int grid = (a.C + 3) / 4 + batch;  // + the workgroup that publishes the batch-wide counts
     const size_t lds = (size_t)a.s.nets_params() * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mh_kernel_solo<U, DBG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mh_kernel_solo<U, DBG, LK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mh_kernel_solo<U, DBG>), dim3(grid), dim3(320), lds, st, a);
+    hipLaunchKernelGGL((mh_kernel_solo<U, DBG, LK>), dim3(grid), dim3(320), lds, st, a);
     return hipGetLastError();
 }
 
 hipError_t launch_mh_solo(const MhArgs &a, hipStream_t st) {
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
+    // the production kernel of the BASELINE likelihood (Rosenbrock) is compiled with the likelihood fixed: the step loop then
+    // carries no other likelihood's code (the float64 paths cost 14 spilled registers and a chain of scalar branches per step)
+    if (!dbg && a.like.id == NNEST_LIKE_ROSENBROCK) {
+        if (a.s.NT == 1) return launch_solo_k<1, false, NNEST_LIKE_ROSENBROCK>(a, st);
+        if (a.s.NT == 2) return launch_solo_k<2, false, NNEST_LIKE_ROSENBROCK>(a, st);
+    }
     switch (a.s.NT) {
-        case 1: return dbg ? launch_solo_k<1, true>(a, st) : launch_solo_k<1, false>(a, st);
-        case 2: return dbg ? launch_solo_k<2, true>(a, st) : launch_solo_k<2, false>(a, st);
+        case 1: return dbg ? launch_solo_k<1, true, -1>(a, st) : launch_solo_k<1, false, -1>(a, st);
+        case 2: return dbg ? launch_solo_k<2, true, -1>(a, st) : launch_solo_k<2, false, -1>(a, st);
     }
     return hipErrorInvalidConfiguration;
 }

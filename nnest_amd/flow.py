@@ -174,6 +174,8 @@ class _HipFlow(object):
             dz = _as_dev_f32(noise[0].reshape(-1, self.D), dev)
             u = noise[1].to(device=dev, dtype=torch.float32).contiguous()
             assert dz.shape[0] == steps * C and u.numel() == steps * C
+        if lag is None and dynamic in (True, 'batch'):
+            lag = self.default_lag(C, form)
         flags = _lib.mh_flags(dynamic, free, lag, form)
         sync = None
         if flags & _lib.MH_DYNAMIC_BATCH:   # per-step batch counters, zeroed for every launch; last word = error flag
@@ -196,6 +198,15 @@ class _HipFlow(object):
             return None
         f = fn(self._h, int(C), _lib.mh_flags(dynamic, free, lag, form))
         return _lib.MH_FORM_NAMES.get(f)
+
+    def default_lag(self, C, form=None):
+        """steps between an MCMC step and the proposal scale that reflects its batch-wide accept count when the caller names
+        none.  The count of a step reaches every compute unit about 4.5 us after the step ended (atomics -> publishing wave ->
+        one fetch); the lag is what keeps that off the step's critical path: 4 steps of the 2 us forms, 8 steps of the solo
+        form's 1.2 us.  0 is the reference's rule exactly."""
+        if form == 'solo' or (form is None and self.mh_form_for(C, dynamic='batch', lag=_lib.MH_SOLO_LAG) == 'solo'):
+            return _lib.MH_SOLO_LAG
+        return _lib.MH_DEFAULT_LAG
 
     @staticmethod
     def check_sync(res):

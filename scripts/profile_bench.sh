@@ -6,7 +6,8 @@
 #   bench_pmc.json           {"traffic_bytes_per_launch": ...} read back by bench.py (roofline.traffic)
 #   bench_under_rocprof.json the bench line printed under the profiler
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
+KERN=${2:-mh_kernel_solo<2, false, 0>}   # the kernel the default bench command runs (roofline.kernel)
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -19,29 +20,29 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU 
 cd "$OUT"
 f=$(find trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -12 "$f" > bench_kernel_stats.csv
-python3 - "$TAG" <<'PY'
+python3 - "$TAG" "$KERN" <<'PY'
 import csv, glob, collections, json, sys
-tag = sys.argv[1]
+tag, kern = sys.argv[1], sys.argv[2]
 vals = {}
 n = 0
 for d in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
     for f in glob.glob('%s/**/*counter_collection.csv' % d, recursive=True):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if 'mh_kernel_quad<2, false, true>' in r['Kernel_Name']:
+            if kern in r['Kernel_Name']:
                 agg[r['Counter_Name']].append(float(r['Counter_Value']))
         for c, v in agg.items():
             vals[c] = sum(v) / len(v)
             n = len(v)
 with open('bench_pmc_summary.txt', 'w') as o:
     o.write('# rocprofv3 PMC passes of `python bench.py --steps 20 --warmup 3 --bare` '
-            '(scripts/profile_bench.sh %s);\n# mean per dispatch of mh_kernel_quad<2, false, true> (%d dispatches); '
+            '(scripts/profile_bench.sh %s);\n# mean per dispatch of ' + kern + ' (%d dispatches); '
             'FETCH_SIZE / WRITE_SIZE raw counter units are KiB; SQ cycle counters count 4 clocks\n' % (tag, n))
     for c in sorted(vals):
         o.write('%-18s %14.2f\n' % (c, vals[c]))
 if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
     json.dump({'traffic_bytes_per_launch': int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), 'fetch_kib': vals['FETCH_SIZE'],
-               'write_kib': vals['WRITE_SIZE'], 'kernel': 'mh_kernel_quad', 'source': 'scripts/profile_bench.sh ' + tag,
+               'write_kib': vals['WRITE_SIZE'], 'kernel': kern.split('<')[0], 'source': 'scripts/profile_bench.sh ' + tag,
                'note': 'raw FETCH_SIZE + WRITE_SIZE (one dword per lane accesses: reads ~0.8x, writes exact, DESIGN.md 3)'},
               open('bench_pmc.json', 'w'))
 print(open('bench_pmc_summary.txt').read())

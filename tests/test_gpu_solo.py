@@ -45,7 +45,7 @@ def test_solo_is_what_config_2_runs(hip):
     populations beyond four walkers per CU go to the other forms"""
     nvp, _, _ = trained(hip)
     assert nvp.mh_form_for(1000) == 'solo' and nvp.mh_form_for(1000, dynamic='batch') == 'solo'
-    assert nvp.mh_form_for(1000, dynamic='batch', lag=0) == 'quad' and nvp.mh_form_for(1000, dynamic='group') in ('team', 'reg', 'image')
+    assert nvp.mh_form_for(1000, dynamic='batch', lag=0) == 'quad' and nvp.mh_form_for(1000, dynamic='batch', lag=2) == 'quad' and nvp.mh_form_for(1000, dynamic='group') in ('team', 'reg', 'image')
     assert nvp.mh_form_for(2000) == 'quad' and nvp.mh_form_for(4000) == 'team' and nvp.mh_form_for(100000) == 'image'
     assert nvp.mh_form_for(100000, dynamic='batch') is None                    # grid may not be resident: refused
     assert nvp.mh_form_for(1000, form='team') == 'team' and nvp.mh_form_for(5000, form='solo') is None
@@ -129,7 +129,7 @@ def test_solo_shapes_and_likelihoods_vs_oracle(hip, D, like, scale):
         assert rel(hx[same], so[same]) < 5e-5
 
 
-@pytest.mark.parametrize('C,lag', [(1000, 2), (1000, 4), (333, 3), (1017, 8), (64, 15)])
+@pytest.mark.parametrize('C,lag', [(1000, 3), (1000, 4), (333, 5), (1017, 8), (64, 15)])
 def test_solo_batch_wide_step_rule_vs_oracle(hip, C, lag):
     """NNEST_MH_DYNAMIC_BATCH relayed by the noise wave: the accept count is taken over the WHOLE launch, `lag` steps behind.
     The oracle runs the whole batch with the same lag: same scale sequence, same chains."""

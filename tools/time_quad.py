@@ -48,7 +48,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'stamp':
         print('%-18s %.3f ms; cycles per step: total %d  propose+noise %d  inverse %d  post %d  [tail %d | result wait %d | post atomic %d | '
               'scale update %d]' % (name, ms, o[0] / S, o[1] / S, o[2] / S, o[3] / S, o[4] / S, o[5] / S, o[6] / S, o[7] / S))
 else:
-    for name, kw in (('solo fixed', dict(form='solo')), ('solo batch lag 2', dict(form='solo', dynamic='batch', lag=2)),
+    for name, kw in (('solo fixed', dict(form='solo')),
                      ('solo batch lag 3', dict(form='solo', dynamic='batch', lag=3)), ('solo batch lag 4', dict(form='solo', dynamic='batch', lag=4)),
                      ('solo batch lag 6', dict(form='solo', dynamic='batch', lag=6)), ('solo batch lag 8', dict(form='solo', dynamic='batch', lag=8)),
                      ('solo batch lag 12', dict(form='solo', dynamic='batch', lag=12)),
