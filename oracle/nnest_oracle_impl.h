@@ -34,6 +34,13 @@
 /* per-net parameter count */
 static int FN(net_size)(int D, int H, int L) { return H * D + H + L * (H * H + H) + D * H + D; }
 
+/* orc_flow_kind = 1: the masked autoregressive flow of maf_oracle_impl.h (same parameter layout); the four entry points
+ * below hand over to it, so everything built on them (training steps, the Metropolis loop) runs either flow */
+void FN(maf_forward)(const float *w, int D, int H, int B, int L, const REAL *x, int N, REAL *z, REAL *logdet);
+void FN(maf_inverse)(const float *w, int D, int H, int B, int L, const REAL *z, int N, REAL *x, REAL *logdet);
+void FN(maf_log_probs)(const float *w, int D, int H, int B, int L, const REAL *x, int N, REAL *lp);
+double FN(maf_loss_grad)(const float *w, int D, int H, int B, int L, const REAL *X, int M, REAL *grad);
+
 /* y[out] = W[out,in] x[in] + b   (nn.Linear, networks.py:271-282) */
 static void FN(linear)(const float *W, const float *b, int out, int in, const REAL *x, REAL *y) {
     for (int o = 0; o < out; ++o) {
@@ -122,6 +129,7 @@ static REAL FN(scale_inv_row)(const float *w, int D, int B, int bs, int b, REAL 
 
 /* NormalizingFlow.forward (networks.py:24-32): blocks 0..B-1, log_det accumulated */
 void FN(nvp_forward)(const float *w, int D, int H, int B, int L, const REAL *x, int N, REAL *z, REAL *logdet) {
+    if (orc_flow_kind == 1) { FN(maf_forward)(w, D, H, B, L, x, N, z, logdet); return; }
     int bs = 2 * FN(net_size)(D, H, L);
     for (int n = 0; n < N; ++n) {
         REAL r[512];
@@ -138,6 +146,7 @@ void FN(nvp_forward)(const float *w, int D, int H, int B, int L, const REAL *x, 
 
 /* NormalizingFlow.inverse (networks.py:34-42): blocks reversed */
 void FN(nvp_inverse)(const float *w, int D, int H, int B, int L, const REAL *z, int N, REAL *x, REAL *logdet) {
+    if (orc_flow_kind == 1) { FN(maf_inverse)(w, D, H, B, L, z, N, x, logdet); return; }
     int bs = 2 * FN(net_size)(D, H, L);
     for (int n = 0; n < N; ++n) {
         REAL r[512];
@@ -176,6 +185,7 @@ static REAL FN(base_logp)(const REAL *u, int D, REAL *gneg) {
 /* NormalizingFlowModel.log_probs (networks.py:71-76) with the N(0,I) base (networks.py:51-57):
  * MVN(0,I).log_prob(u) = -0.5*|u|^2 - (D/2) log(2 pi) */
 void FN(nvp_log_probs)(const float *w, int D, int H, int B, int L, const REAL *x, int N, REAL *lp) {
+    if (orc_flow_kind == 1) { FN(maf_log_probs)(w, D, H, B, L, x, N, lp); return; }
     int bs = 2 * FN(net_size)(D, H, L);
     for (int n = 0; n < N; ++n) {
         REAL r[512];
@@ -249,6 +259,7 @@ static void FN(mlp_bwd)(const float *p, float *gp_unused, REAL *gp, int D, int H
 
 /* loss and dloss/dw for a minibatch X[M,D].  grad has num_params entries (zeroed here). Returns loss. */
 double FN(nvp_loss_grad)(const float *w, int D, int H, int B, int L, const REAL *X, int M, REAL *grad) {
+    if (orc_flow_kind == 1) return FN(maf_loss_grad)(w, D, H, B, L, X, M, grad);
     int ns = FN(net_size)(D, H, L), bs = 2 * ns, np_ = B * bs + (orc_scale_mode == 2 ? B : 0);
     for (int i = 0; i < np_; ++i) grad[i] = 0;
     REAL *xin = (REAL *)malloc(sizeof(REAL) * (size_t)B * D);
@@ -303,3 +314,5 @@ double FN(nvp_loss_grad)(const float *w, int D, int H, int B, int L, const REAL 
     free(xin); free(lss); free(as); free(at);
     return loss;
 }
+
+#include "maf_oracle_impl.h"

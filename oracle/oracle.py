@@ -89,9 +89,11 @@ class NVP(object):
 
     Restates SingleSpeedNVP / NormalizingFlowModel (nnest/networks.py:17-84, :248-347)."""
 
-    def __init__(self, D, H=16, B=3, L=1, weights=None, scale='', base_beta=0.0):
+    def __init__(self, D, H=16, B=3, L=1, weights=None, scale='', base_beta=0.0, kind='nvp'):
         self.D, self.H, self.B, self.L = int(D), int(H), int(B), int(L)
         self.scale = scale
+        assert kind in ('nvp', 'maf') and (kind == 'nvp' or scale == '')
+        self.kind = kind   # 'maf': the build-defined masked autoregressive flow (maf_oracle_impl.h; UNPINNED), same parameter layout
         self.base_beta = float(base_beta)   # 0: N(0,I); > 0: GeneralisedNormal(0, 1, beta) (distributions/generalised_normal.py)
         self.n = num_params(D, H, B, L, scale)
         self.w = np.zeros(self.n, np.float32) if weights is None else _f32(weights).copy()
@@ -102,6 +104,7 @@ class NVP(object):
 
     def _cfg(self):
         lib().orc_set_scale_mode(SCALE_MODES[self.scale])
+        lib().orc_set_flow_kind(1 if self.kind == 'maf' else 0)
         lib().orc_set_base_beta(ctypes.c_double(self.base_beta))
         return (_p(self.w, _fp), self.D, self.H, self.B, self.L)
 
@@ -165,8 +168,7 @@ class NVP(object):
         nz = None if noise is None else _f32(noise)
         g = np.empty(self.n, np.float32)
         self.t += 1
-        lib().orc_set_scale_mode(SCALE_MODES[self.scale])
-        lib().orc_set_base_beta(ctypes.c_double(self.base_beta))
+        self._cfg()
         loss = lib().orc_train_step(_p(self.w, _fp), _p(self.m, _fp), _p(self.v, _fp), self.D, self.H, self.B,
                                     self.L, _p(X, _fp), _p(idx, _ip), None if nz is None else _p(nz, _fp), M,
                                     ctypes.c_float(jitter), self.t, ctypes.c_float(lr), ctypes.c_float(wd),
@@ -333,6 +335,7 @@ def mcmc_sample(nvp, like, like_scale, init, init_logl, loglstar, step, dynamic,
     scale = ctypes.c_double(step)
     acc = ctypes.c_long(0); rej = ctypes.c_long(0)
     lib().orc_set_scale_mode(SCALE_MODES[nvp.scale])
+    lib().orc_set_flow_kind(1 if getattr(nvp, 'kind', 'nvp') == 'maf' else 0)
     lib().orc_set_step_lag(int(lag))
     if margins is not None:
         assert margins.shape == (S, C) and margins.dtype == np.float64 and margins.flags['C_CONTIGUOUS']
