@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 10
+#define NNEST_HIP_ABI_VERSION 11
 
 enum {
     NNEST_OK = 0,
@@ -99,6 +99,16 @@ int nnest_nvp_create(int D, int H, int B, int L, nnest_nvp_t **out);
  * 'constant' the B ScaleLayer scalars follow the blocks (nnest_nvp_num_params counts them). */
 enum { NNEST_SCALE_AFFINE = 0, NNEST_SCALE_TRANSLATE = 1, NNEST_SCALE_CONSTANT = 2 };
 int nnest_nvp_create_scaled(int D, int H, int B, int L, int scale_mode, nnest_nvp_t **out);
+/* Masked autoregressive flow (named by BASELINE config 5).  ABSENT FROM THE REFERENCE (nnest/trainer.py:83-100
+ * dispatches 'choleksy' / 'nvp' / 'spline' only): build-defined, DESIGN.md 3c -- B blocks of two MADE-masked nets with the
+ * shapes of the coupling nets (so the packed vector has the SingleSpeedNVP layout and size), dimension order reversed between
+ * blocks; forward (x -> z, the density / training direction) is one pass, inverse (z -> x, sampling and the Metropolis
+ * proposals) runs group by group (nnest_maf_num_groups passes per block, at most hidden_dim + 1).  The handle is an
+ * nnest_nvp_t: every nnest_nvp_* entry point (weights, Adam state, forward / inverse / log_probs / inverse_loglike, loss_grad,
+ * adam_step) and nnest_mh_constrained_steps accept it; nnest_nvp_train and nnest_nvp_vjp return NNEST_E_UNSUPPORTED (the epoch
+ * loop of this flow is driven from the host).  hidden_dim 16, x_dim 2..128. */
+int nnest_maf_create(int D, int H, int B, int L, nnest_nvp_t **out);
+int nnest_maf_num_groups(const nnest_nvp_t *maf);
 int nnest_nvp_destroy(nnest_nvp_t *nvp);
 int nnest_nvp_num_params(const nnest_nvp_t *nvp);
 /* Base distribution of the flow (NormalizingFlowModel(prior=...), networks.py:47-59; Trainer(base_dist=...), trainer.py:41):

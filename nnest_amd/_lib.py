@@ -82,6 +82,8 @@ SIGNATURES = {
     'nnest_spline_load_weights': [_vp, _vp, _vp, _vp],
     'nnest_spline_store_weights': [_vp, _vp, _vp, _vp],
     'nnest_nvp_create_scaled': [_i, _i, _i, _i, _i, ctypes.POINTER(_vp)],
+    'nnest_maf_create': [_i, _i, _i, _i, ctypes.POINTER(_vp)],
+    'nnest_maf_num_groups': [_vp],
     'nnest_nvp_destroy': [_vp],
     'nnest_nvp_num_params': [_vp],
     'nnest_nvp_set_base': [_vp, _f],

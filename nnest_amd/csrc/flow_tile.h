@@ -26,6 +26,7 @@
 namespace nnest {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+enum { FLOW_KIND_NVP = 0, FLOW_KIND_MAF = 1 };
 
 struct FlowShape {
     int D, H, B, L;
@@ -43,6 +44,10 @@ struct FlowShape {
     // reference's GeneralisedNormal(0, 1, beta) (nnest/distributions/generalised_normal.py:66-71).  base_const = the
     // per-dimension constant of its log density.
     float base_beta, base_const;
+    // which flow the handle is: FLOW_KIND_NVP the reference's SingleSpeedNVP; FLOW_KIND_MAF the build-defined masked autoregressive
+    // flow (maf_tile.h: same parameter layout; NT stays the tiles per parity class, the fragment image is laid out for 2 NT
+    // tiles; G = groups of the sequential inverse)
+    int kind, G;
     __host__ __device__ int nets_params() const { return B * 2 * net_params; }
     __host__ __device__ int num_params() const { return B * 2 * net_params + (scale_mode == 2 ? B : 0); }
     __host__ __device__ int image_total() const { return image_floats + (scale_mode == 2 ? B : 0); }

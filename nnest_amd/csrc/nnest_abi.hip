@@ -25,6 +25,8 @@ struct nnest_nvp {
     int *fwd_pos;    // packed parameter -> element of the forward fragment image (-1: absent)
     int *bwd_pos;    // packed parameter -> element of the backward fragment image
     size_t train_ws_floats;
+    float *img_bwd;  // MAF: the transposed fragment image (the RealNVP training kernels keep theirs in the workspace / LDS)
+    int *gpos;       // MAF: packed parameter -> slot of a tile's weight-gradient buffer
 };
 
 static thread_local char g_err[512] = "";
@@ -46,6 +48,16 @@ void set_last_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg)
         hipError_t e__ = (expr);                                                                        \
         if (e__ != hipSuccess) return fail(NNEST_E_HIP, "%s: %s", #expr, hipGetErrorString(e__));       \
     } while (0)
+
+// the fragment image(s) of the handle's flow from its packed weights
+static hipError_t refresh_images(nnest_nvp *h, hipStream_t st) {
+    if (h->s.kind == FLOW_KIND_MAF) return launch_maf_repack(h->w, h->img, h->img_bwd, h->s, st);
+    if (h->s.scale_mode != NNEST_SCALE_AFFINE) {
+        hipError_t e = launch_zero_scale_nets(h->w, h->s, st);  // unused slots stay 0
+        if (e != hipSuccess) return e;
+    }
+    return launch_repack(h->w, h->img, h->s, st);
+}
 
 extern "C" {
 
@@ -88,6 +100,8 @@ int nnest_nvp_create_scaled(int D, int H, int B, int L, int scale_mode, nnest_nv
     s.image_floats = B * 2 * s.net_floats;
     s.net_params = H * D + H + L * (H * H + H) + D * H + D;
     s.scale_mode = scale_mode;
+    s.kind = FLOW_KIND_NVP;
+    s.G = 0;
     s.base_beta = 0.f;
     s.base_const = -0.91893853320467274f;  // -log(2 pi) / 2
     if (!shape_supported(s))
@@ -127,10 +141,67 @@ int nnest_nvp_create_scaled(int D, int H, int B, int L, int scale_mode, nnest_nv
     return NNEST_OK;
 }
 
+int nnest_maf_create(int D, int H, int B, int L, nnest_nvp_t **out) {
+    if (!out) return fail(NNEST_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (D < 2 || H < 1 || B < 1 || L < 0) return fail(NNEST_E_ARG, "bad shape D=%d H=%d B=%d L=%d (a MAF needs x_dim >= 2)", D, H, B, L);
+    if (H != 16) return fail(NNEST_E_UNSUPPORTED, "maf: hidden_dim=%d, the kernels are instantiated for 16", H);
+    FlowShape s;
+    s.D = D; s.H = H; s.B = B; s.L = L;
+    s.NT = ((D + 1) / 2 + 15) / 16;
+    s.NH = H / 16;
+    s.net_floats = frag_net_floats(2 * s.NT, s.NH, L);                 // fragments over both parity classes: 2 NT tiles
+    s.image_floats = B * 2 * s.net_floats + B * 16 * 2 * s.NT;         // + the group of every slot, per block
+    s.net_params = H * D + H + L * (H * H + H) + D * H + D;
+    s.scale_mode = NNEST_SCALE_AFFINE;
+    s.kind = FLOW_KIND_MAF;
+    s.G = maf_num_groups(D, H);
+    s.base_beta = 0.f;
+    s.base_const = -0.91893853320467274f;
+    if (s.NT > 4 || !maf_shape_supported(s))
+        return fail(NNEST_E_UNSUPPORTED, "maf: x_dim=%d num_blocks=%d num_layers=%d: the fragment image (%d floats) has to fit one CU's LDS and x_dim <= 128", D, B, L, s.image_floats);
+    nnest_nvp *h = new nnest_nvp();
+    memset(h, 0, sizeof(*h));
+    h->s = s;
+    h->num_params = s.num_params();
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(NNEST_E_HIP, "hipGetDevice failed (no GPU?)"); }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, h->device) != hipSuccess) { delete h; return fail(NNEST_E_HIP, "hipGetDeviceProperties failed"); }
+    h->num_cu = p.multiProcessorCount;
+    const size_t nb = (size_t)h->num_params * sizeof(float), ib = (size_t)s.image_floats * sizeof(float);
+    h->train_ws_floats = maf_workspace_floats(s);
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc((void **)&h->w, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->adam_m, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->adam_v, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->best_w, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->img, ib);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->img_bwd, ib);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->adam_step, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->train_ws, h->train_ws_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->gpos, nb);
+    if (e == hipSuccess) e = launch_maf_build_gpos(h->gpos, s, 0);
+    if (e == hipSuccess) e = hipMemset(h->w, 0, nb);
+    if (e == hipSuccess) e = hipMemset(h->adam_m, 0, nb);
+    if (e == hipSuccess) e = hipMemset(h->adam_v, 0, nb);
+    if (e == hipSuccess) e = hipMemset(h->adam_step, 0, sizeof(int));
+    if (e == hipSuccess) e = refresh_images(h, 0);
+    if (e == hipSuccess) e = hipStreamSynchronize(0);
+    if (e != hipSuccess) {
+        nnest_nvp_destroy(h);
+        return fail(NNEST_E_HIP, "device allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return NNEST_OK;
+}
+
+int nnest_maf_num_groups(const nnest_nvp_t *h) { return (h && h->s.kind == FLOW_KIND_MAF) ? h->s.G : -1; }
+
 int nnest_nvp_destroy(nnest_nvp_t *h) {
     if (!h) return NNEST_OK;
     (void)hipFree(h->w); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->best_w); (void)hipFree(h->img);
     (void)hipFree(h->adam_step); (void)hipFree(h->train_ws); (void)hipFree(h->fwd_pos); (void)hipFree(h->bwd_pos);
+    (void)hipFree(h->img_bwd); (void)hipFree(h->gpos);
     delete h;
     return NNEST_OK;
 }
@@ -149,8 +220,7 @@ int nnest_nvp_load_weights(nnest_nvp_t *h, const float *packed_host, void *strea
     if (!h || !packed_host) return fail(NNEST_E_ARG, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(h->w, packed_host, (size_t)h->num_params * sizeof(float), hipMemcpyHostToDevice, st));
-    if (h->s.scale_mode != NNEST_SCALE_AFFINE) HIP_TRY(launch_zero_scale_nets(h->w, h->s, st));  // unused slots stay 0
-    HIP_TRY(launch_repack(h->w, h->img, h->s, st));
+    HIP_TRY(refresh_images(h, st));
     HIP_TRY(hipStreamSynchronize(st));
     return NNEST_OK;
 }
@@ -325,6 +395,8 @@ int nnest_nvp_train(nnest_nvp_t *h, const float *xtrain_dev, int n_train, const 
     if (n_train < 1 || n_valid < 1 || batch < 1 || max_epochs < 0)
         return fail(NNEST_E_ARG, "bad sizes n_train=%d n_valid=%d batch=%d max_epochs=%d", n_train, n_valid, batch, max_epochs);
     if (batch > 128) return fail(NNEST_E_UNSUPPORTED, "batch_size=%d > 128 (one workgroup holds a minibatch)", batch);
+    if (h->s.kind == FLOW_KIND_MAF)
+        return fail(NNEST_E_UNSUPPORTED, "maf: the epoch loop is driven from the host (nnest_nvp_loss_grad + nnest_nvp_adam_step per minibatch)");
     HIP_TRY(launch_train(h->w, h->adam_m, h->adam_v, h->best_w, h->img, h->adam_step, h->s, xtrain_dev, n_train, xvalid_dev,
                          n_valid, perm_dev, noise_dev, seed, jitter, batch, max_epochs, patience, lr, weight_decay,
                          epoch_offset, flags, losses_dev, result_dev, h->train_ws, h->fwd_pos, h->bwd_pos, (hipStream_t)stream));
@@ -334,6 +406,11 @@ int nnest_nvp_train(nnest_nvp_t *h, const float *xtrain_dev, int n_train, const 
 int nnest_nvp_loss_grad(nnest_nvp_t *h, const float *x_dev, int M, float *grad_dev, float *loss_dev, void *stream) {
     if (!h || !x_dev || !grad_dev || !loss_dev) return fail(NNEST_E_ARG, "NULL argument");
     if (M < 1 || M > 128) return fail(NNEST_E_UNSUPPORTED, "M=%d outside [1,128]", M);
+    if (h->s.kind == FLOW_KIND_MAF) {
+        if (h->s.L > 2) return fail(NNEST_E_UNSUPPORTED, "maf: num_layers=%d > 2 has no training kernel", h->s.L);
+        HIP_TRY(launch_maf_loss_grad(h->s, h->img, h->img_bwd, h->gpos, x_dev, M, grad_dev, loss_dev, h->train_ws, (hipStream_t)stream));
+        return NNEST_OK;
+    }
     HIP_TRY(launch_loss_grad(h->w, h->s, x_dev, M, grad_dev, loss_dev, h->train_ws, h->img, h->fwd_pos, h->bwd_pos,
                              (hipStream_t)stream));
     return NNEST_OK;
@@ -342,6 +419,7 @@ int nnest_nvp_loss_grad(nnest_nvp_t *h, const float *x_dev, int M, float *grad_d
 int nnest_nvp_vjp(nnest_nvp_t *h, const float *x_dev, const float *gz_dev, float gld, int M, float *grad_dev, float *gx_dev, void *stream) {
     if (!h || !x_dev || !gz_dev || !grad_dev || !gx_dev) return fail(NNEST_E_ARG, "NULL argument");
     if (M < 1 || M > 128) return fail(NNEST_E_UNSUPPORTED, "M=%d outside [1,128]", M);
+    if (h->s.kind == FLOW_KIND_MAF) return fail(NNEST_E_UNSUPPORTED, "maf: no vector-Jacobian product (it is not a stage of a fast/slow hierarchy)");
     HIP_TRY(launch_vjp(h->w, h->s, x_dev, gz_dev, gld, M, grad_dev, gx_dev, h->train_ws, h->img, h->fwd_pos, h->bwd_pos, (hipStream_t)stream));
     return NNEST_OK;
 }
@@ -355,8 +433,7 @@ int nnest_nvp_adam_step(nnest_nvp_t *h, const float *grad_dev, float lr, float w
     step += 1;
     HIP_TRY(launch_adam_packed(h->w, grad_dev, h->adam_m, h->adam_v, h->num_params, step, lr, weight_decay, st));
     HIP_TRY(hipMemcpyAsync(h->adam_step, &step, sizeof(int), hipMemcpyHostToDevice, st));
-    if (h->s.scale_mode != NNEST_SCALE_AFFINE) HIP_TRY(launch_zero_scale_nets(h->w, h->s, st));
-    HIP_TRY(launch_repack(h->w, h->img, h->s, st));
+    HIP_TRY(refresh_images(h, st));
     HIP_TRY(hipStreamSynchronize(st));
     return NNEST_OK;
 }

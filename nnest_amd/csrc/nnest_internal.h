@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "flow_tile.h"
+#include "maf_tile.h"
 #include "spline_tile.h"
 #include "../../include/nnest_hip.h"
 
@@ -27,6 +28,8 @@ hipError_t launch_mh_quad(const MhArgs &a, int num_cu, hipStream_t st);  // nnes
 bool solo_form_eligible(const MhArgs &a, int num_cu);        // nnest_solo.hip
 hipError_t launch_mh_solo(const MhArgs &a, hipStream_t st);  // nnest_solo.hip
 int mh_form_for(const FlowShape &s, int C, int flags, int num_cu);
+bool maf_shape_supported(const FlowShape &s);   // maf_kernels.h (nnest_kernels.hip)
+hipError_t launch_maf_repack(const float *packed, float *imgf, float *imgb, const FlowShape &s, hipStream_t st);
 hipError_t launch_loglike(const LikeSpec &like, const float *x, double *logl, int N, int D, int num_cu, hipStream_t st);
 hipError_t launch_fill_noise(float *dz, float *u, int steps, int C, int D, uint64_t seed, uint64_t walker_offset,
                              hipStream_t st);
@@ -56,6 +59,11 @@ hipError_t launch_train(float *packed, float *adam_m, float *adam_v, float *best
                         float *workspace, const int *fwd_pos, const int *bwd_pos,
                         hipStream_t st);
 hipError_t launch_build_pos(int *fwd_pos, int *bwd_pos, const FlowShape &s, hipStream_t st);
+// masked autoregressive flow (maf_train.h inside nnest_train.hip)
+size_t maf_workspace_floats(const FlowShape &s);
+hipError_t launch_maf_build_gpos(int *gpos, const FlowShape &s, hipStream_t st);
+hipError_t launch_maf_loss_grad(const FlowShape &s, const float *imgf, const float *imgb, const int *gpos, const float *x, int M,
+                                float *grad, float *loss, float *workspace, hipStream_t st);
 hipError_t launch_training_jitter(const double *samples, int N, int D, double *out, hipStream_t st);
 
 }  // namespace nnest

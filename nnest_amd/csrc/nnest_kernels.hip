@@ -6,6 +6,7 @@
 //   fill_noise_kernel         the in-kernel proposal noise as arrays (tests)
 // Launch wrappers (C++, used by nnest_abi.hip) are at the bottom.  See flow_tile.h for the data layout.
 #include "flow_tile.h"
+#include "maf_tile.h"
 #include "mh_common.h"
 #include "nnest_internal.h"
 
@@ -806,12 +807,16 @@ hipError_t launch_repack(const float *packed, float *img, const FlowShape &s, hi
     return hipGetLastError();
 }
 
+static hipError_t launch_maf_pass(const PassArgs &a, int num_cu, hipStream_t st);   // maf_kernels.h
+static hipError_t launch_maf_mh(const MhArgs &a, int num_cu, hipStream_t st);
+
 hipError_t launch_pass(const float *img, const FlowShape &s, int mode, const float *in, float *out, float *logdet,
                        double *logl, int *inbox, int N, const LikeSpec &like, int num_cu, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     PassArgs a;
     a.img = img; a.s = s; a.mode = mode; a.in = in; a.out = out; a.logdet = logdet; a.logl = logl; a.inbox = inbox;
     a.N = N; a.like = like;
+    if (s.kind == FLOW_KIND_MAF) return launch_maf_pass(a, num_cu, st);
     DISPATCH_SHAPE(launch_pass_t, s, a, num_cu, st);
 }
 
@@ -829,6 +834,7 @@ hipError_t launch_mh(const float *img, const FlowShape &s, const LikeSpec &like,
     a.steps = steps; a.C = C; a.flags = flags; a.like = like;
     a.noise_dz = noise_dz; a.noise_u = noise_u; a.seed = seed; a.walker_offset = walker_offset;
     a.hist_x = hist_x; a.hist_logl = hist_logl; a.n_accept = n_accept; a.n_call = n_call; a.scale_out = scale_out;
+    if (s.kind == FLOW_KIND_MAF) return launch_maf_mh(a, num_cu, st);
     DISPATCH_SHAPE(launch_mh_t, s, a, num_cu, st);
 }
 
@@ -863,9 +869,17 @@ int mh_num_groups(int C) { return (C + 15) / 16; }
 int mh_form_for(const FlowShape &s, int C, int flags, int num_cu) {
     MhArgs a = MhArgs();
     a.s = s; a.C = C; a.flags = flags;
+    if (s.kind == FLOW_KIND_MAF) {   // the image form only (maf_kernels.h)
+        const int form = mh_flag_form(flags);
+        if (form != MH_FORM_AUTO && form != MH_FORM_IMAGE) return -1;
+        int block, grid;
+        pick_geometry((C + 15) / 16, num_cu, 4, &block, &grid);
+        return ((flags & NNEST_MH_DYNAMIC_BATCH) && grid > num_cu) ? -1 : MH_FORM_IMAGE;
+    }
     DISPATCH_SHAPE(mh_form_t, s, a, num_cu);
 }
 
+#include "maf_kernels.h"
 #include "spline_kernels.h"
 
 }  // namespace nnest

@@ -987,6 +987,7 @@ static hipError_t dispatch_train(const TrainArgs &a, hipStream_t st) {
 }
 
 #include "nnest_train_grid.h"
+#include "maf_train.h"
 
 hipError_t launch_loss_grad(const float *packed, const FlowShape &s, const float *x, int M, float *grad, float *loss,
                             float *workspace, float *img_fwd, const int *fwd_pos, const int *bwd_pos, hipStream_t st) {

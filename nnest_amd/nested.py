@@ -161,7 +161,7 @@ class NestedSampler(Sampler):
         if ask is None:
             return None
         mode = 'batch' if dynamic and getattr(self, '_batch_rule_ok', True) else ('group' if dynamic else False)
-        lag = self.mcmc_step_lag
+        lag = getattr(self, 'mcmc_step_lag', None)
         return ask(C, dynamic=mode, lag=lag) or ask(C, dynamic='group' if dynamic else False)
 
     def _checkpoint(self, it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt, state):

@@ -48,8 +48,9 @@ class Trainer(object):
         if not torch.cuda.is_available():
             raise _lib.NnestHipError('nnest_amd.Trainer needs an MI355X (torch.cuda.is_available() is False); '
                                      'there is no CPU fallback')
-        if flow.lower() not in ('nvp', 'spline', 'choleksy'):
-            raise NotImplementedError('flow=%r (trainer.py:83-100 knows choleksy, nvp, spline)' % flow)
+        # 'maf' is not in the reference (trainer.py:83-100 knows choleksy, nvp, spline): build-defined, nnest_amd/maf.py
+        if flow.lower() not in ('nvp', 'spline', 'choleksy', 'maf'):
+            raise NotImplementedError('flow=%r (trainer.py:83-100 knows choleksy, nvp, spline; this build adds maf)' % flow)
         self.flow = flow.lower()
         if num_slow != 0:
             assert x_dim > num_slow                      # trainer.py:79
@@ -86,7 +87,12 @@ class Trainer(object):
         self.num_slow = num_slow
         self.learning_rate = learning_rate
         self.weight_decay = weight_decay
-        if self.flow == 'choleksy':  # SingleSpeedCholeksy(x_dim)  (trainer.py:83-84; the reference ignores num_slow here too)
+        if self.flow == 'maf':
+            if num_slow > 0 or scale != '':
+                raise NotImplementedError("flow='maf' with num_slow > 0 or a scale variant")
+            from .maf import HipMAF
+            self.netG = HipMAF(x_dim, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed)
+        elif self.flow == 'choleksy':  # SingleSpeedCholeksy(x_dim)  (trainer.py:83-84; the reference ignores num_slow here too)
             from .cholesky import HipCholesky
             self.netG = HipCholesky(x_dim, device=self.gpu, seed=seed)
         elif self.flow == 'spline' and num_slow > 0:   # FastSlowSpline(num_fast, num_slow, hidden_dim, num_blocks)  (trainer.py:93-95)
