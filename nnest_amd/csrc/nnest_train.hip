@@ -65,7 +65,11 @@ struct TrainArgs {
     // barrier counter, error word
     float *gstage, *gtile;
     int *gpos;
-    float *gpart, *grep;
+    float *gpart;
+    float *gimgf, *gimgb;          // grid kernel: the published forward / backward fragment images (the owners' new weights)
+    float *gdst;                   // grid kernel: (w, exp_avg, exp_avg_sq) of the parameters no job reaches, compact [3][ndead_pad]
+    float *gown;                   // grid kernel, > 2 tiles per class: the job owners' parameter records [64 waves][64 lanes][32]
+    int *gdead, *gndead;           // grid kernel: the parameters no job reaches (+ their count)
     unsigned int *gsync;
     int *gerr;
     const float *gz;  // VJP: upstream gradient [M, D]

@@ -8,11 +8,14 @@
 //        per-row gradients G and activations go to a GLOBAL staging area, one region per (block, net), instead of one LDS
 //        region reused under workgroup barriers);
 //   grid barrier;
-//   W    the 30 weight-gradient jobs, one per wave across the 64 waves of the grid, each contracting over all rows exactly
-//        as the single-workgroup kernel does (same operand order: the same bits), result tile to a job-private slot;
+//   W+A  the 30 weight-gradient jobs, one per wave across the 64 waves of the grid (job J on wave J / 8 of workgroup J % 8), each contracting over all rows exactly
+//        as the single-workgroup kernel does (same operand order: the same bits) -- and the wave that produced a gradient tile
+//        OWNS that tile's parameters: their weights and Adam moments live in its registers for the whole launch (the job ->
+//        wave map is static), it applies Adam right there and publishes the NEW WEIGHTS (round 3; round 2 published the
+//        gradients and had every workgroup step a private replica of the whole vector: 17.7 k of a minibatch's 57 k cycles).
+//        The waves without a job step the parameters no job reaches (zero gradient: weight decay only) in global memory;
 //   grid barrier;
-//   A    EVERY workgroup applies Adam to the whole parameter vector (identical values; no third barrier) and refreshes its
-//        own LDS copies of the fragment images.
+//   R    every workgroup scatters the published weights into its LDS copies of the two fragment images.
 // Validation: tile-sets per workgroup as the single-workgroup kernel gives them to its waves, partial sums exchanged at one
 // more grid barrier per epoch; summation orders are those of train_kernel, so the two kernels agree to the last bit or two
 // (hipcc fuses a few multiply-adds differently in the two bodies) and each is bitwise reproducible run to run
@@ -24,7 +27,7 @@
 // vmcnt(0) -> workgroup barrier -> one lane's agent-scope atomic add on a counter -> sc1 poll of the counter by one lane
 // -> workgroup barrier -> loads.  Polls are bounded (a counter that never fills sets the error word and the kernel ends).
 
-enum { GRID_WG = 8, GRID_MAX_POLLS = 1 << 22, NNEST_TRAIN_POS_LDS = 1 << 20 /* internal flag bit, never part of the ABI */ };
+enum { GRID_WG = 8, GRID_MAX_POLLS = 1 << 22 };
 
 // (the s_nop: a VMEM store of more than 8 bytes reads its data registers for up to two cycles after issue, and the compiler's
 // hazard recognizer cannot see inside the asm -- without it the next VALU write corrupted some lanes of some stores)
@@ -32,6 +35,13 @@ __device__ __forceinline__ void st_sc1_f32x4(float *p, f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ float ld_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a 16-byte sc1 load, ISSUED only: hipcc does not know it is a load, the caller drains (ld_drain) before using the value
+__device__ __forceinline__ f32x4 ld_sc1_x4_issue(const float *p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // all G workgroups have finished what precedes; `phase` counts barriers (same value in every thread of the grid)
 __device__ __forceinline__ bool grid_barrier(unsigned int *ctr, int &phase, int G, int *err) {
@@ -106,6 +116,43 @@ __global__ void grid_gpos_kernel(int *__restrict__ gpos, FlowShape s) {
         if (wt >= 0) gpos[wt] = i;
         if (bt >= 0) gpos[bt] = NJ * 256 + i;
     }
+}
+
+// Where job J's result tile sits in the two fragment images.  The tile a job produces -- lane (gq, j) register r = element (row
+// 4 gq + r, column j) of a 16 x 16 block of a weight matrix -- IS the A-fragment of the BACKWARD image for that block (same lane /
+// register mapping: bwd_image_src), and its transpose is the A-fragment of the FORWARD image (fwd_image_src).  So an owner
+// publishes its new weights straight into two global images laid out like the LDS ones, and the refresh phase is a copy.
+// Offsets in floats of the tile's [64 lanes][4]; bias: offset of the 16 floats its bias vector fills in the forward image, or -1.
+template <int NT, int NH, int L>
+__host__ __device__ inline void grid_job_image_offsets(const FlowShape &s, int J, int *off_f, int *off_b, int *off_bias) {
+    constexpr int J_W3 = NT * NH, J_W2 = L * NH * NH, NJOBS = J_W3 + J_W2 + NH * NT;
+    const int bn = J / NJOBS, base = bn * s.net_floats;
+    int q = J % NJOBS;
+    if (q < J_W3) {          // Wout block (tau, ht)
+        const int tau = q / NH, ht = q % NH;
+        *off_b = base + frag_off_L1() + (ht * NT + tau) * 256;
+        *off_f = base + frag_off_L3(NT, NH, L) + (tau * NH + ht) * 256;
+        *off_bias = ht == 0 ? base + frag_off_b3(NT, NH, L) + 16 * tau : -1;
+        return;
+    }
+    q -= J_W3;
+    if (q < J_W2) {          // hidden layer l, block (hto, hti)
+        const int l = q / (NH * NH), hto = (q / NH) % NH, hti = q % NH;
+        *off_b = base + frag_off_L2(NT, NH) + ((l * NH + hti) * NH + hto) * 256;
+        *off_f = base + frag_off_L2(NT, NH) + ((l * NH + hto) * NH + hti) * 256;
+        *off_bias = hti == 0 ? base + frag_off_b2(NT, NH, L) + l * 16 * NH + 16 * hto : -1;
+        return;
+    }
+    q -= J_W2;               // W0 block (ht, tau)
+    const int ht = q / NT, tau = q % NT;
+    *off_b = base + frag_off_L3(NT, NH, L) + (tau * NH + ht) * 256;
+    *off_f = base + frag_off_L1() + (ht * NT + tau) * 256;
+    *off_bias = tau == 0 ? base + frag_off_b1(NT, NH, L) + 16 * ht : -1;
+}
+// the parameters no job produces a gradient for (the ones the alternating mask never reaches): a list, any order
+__global__ void grid_dead_kernel(const int *__restrict__ gpos, int np, int *__restrict__ dead, int *__restrict__ count) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < np; p += gridDim.x * blockDim.x)
+        if (gpos[p] < 0) dead[atomicAdd(count, 1)] = p;
 }
 
 // contract_rows over the global staging area (row stride 128, sc1 loads): the same operand order as contract_rows
@@ -378,62 +425,101 @@ __device__ __forceinline__ void team_block_backward(const TrainArgs &a, int b, i
     }
 }
 
-// Adam over the whole packed vector (as adam_sweep: float4 groups, U groups in flight per thread) with the gradient gathered
-// from the job results through gpos (sc1 loads: other workgroups wrote them).  Every workgroup steps its OWN replica of
-// (w, exp_avg, exp_avg_sq): a shared copy would be read-modify-written by eight workgroups at different times (a slow one
-// would step values a fast one had already stepped).
-__device__ __forceinline__ void adam_sweep_grid(const TrainArgs &a, const AdamStep &ad, int np, float *imgf, float *imgb, float *rw,
-                                                float *rm, float *rv, const int *fpos, const int *bpos) {
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    constexpr int U = 6;  // 6 x 512 float4 groups cover the default flow's 11 628 parameters in one pass
-    const int n4 = np >> 2;
-    for (int i0 = threadIdx.x; i0 < n4; i0 += U * blockDim.x) {
-        f32x4 w4[U], m4[U], v4[U];
-        float g[U][4];
-        i32x4 gp[U];
+// What a job's wave owns: the weight, exp_avg and exp_avg_sq of its result tile (lane (gq, j) register r) and of its bias vector,
+// and their indices in the packed vector.  OREG (<= 2 tiles per class): in registers for the whole launch.  Otherwise (3-4 tiles per
+// class: the row tile's forward / backward state alone takes the register file) in a private 128-byte record per lane in global
+// memory, read at the head of the W phase beside the contraction's operands and written back behind it.
+struct OwnState {
+    float tw[4], tm[4], tv[4], bw[4], bm[4], bv[4];
+    int wt[4], bt[4];
+};
+__device__ __forceinline__ void own_load(OwnState &o, const float *rec) {
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(rec);
+    const f32x4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5], a6 = q[6], a7 = q[7];
+    o.tw[0] = a0.x; o.tw[1] = a0.y; o.tw[2] = a0.z; o.tw[3] = a0.w;
+    o.tm[0] = a1.x; o.tm[1] = a1.y; o.tm[2] = a1.z; o.tm[3] = a1.w;
+    o.tv[0] = a2.x; o.tv[1] = a2.y; o.tv[2] = a2.z; o.tv[3] = a2.w;
+    o.bw[0] = a3.x; o.bw[1] = a3.y; o.bw[2] = a3.z; o.bw[3] = a3.w;
+    o.bm[0] = a4.x; o.bm[1] = a4.y; o.bm[2] = a4.z; o.bm[3] = a4.w;
+    o.bv[0] = a5.x; o.bv[1] = a5.y; o.bv[2] = a5.z; o.bv[3] = a5.w;
+    o.wt[0] = __float_as_int(a6.x); o.wt[1] = __float_as_int(a6.y); o.wt[2] = __float_as_int(a6.z); o.wt[3] = __float_as_int(a6.w);
+    o.bt[0] = __float_as_int(a7.x); o.bt[1] = __float_as_int(a7.y); o.bt[2] = __float_as_int(a7.z); o.bt[3] = __float_as_int(a7.w);
+}
+__device__ __forceinline__ void own_store(const OwnState &o, float *rec, bool with_targets) {
+    f32x4 *q = reinterpret_cast<f32x4 *>(rec);
+    q[0] = (f32x4){o.tw[0], o.tw[1], o.tw[2], o.tw[3]};
+    q[1] = (f32x4){o.tm[0], o.tm[1], o.tm[2], o.tm[3]};
+    q[2] = (f32x4){o.tv[0], o.tv[1], o.tv[2], o.tv[3]};
+    q[3] = (f32x4){o.bw[0], o.bw[1], o.bw[2], o.bw[3]};
+    q[4] = (f32x4){o.bm[0], o.bm[1], o.bm[2], o.bm[3]};
+    q[5] = (f32x4){o.bv[0], o.bv[1], o.bv[2], o.bv[3]};
+    if (with_targets) {
+        q[6] = (f32x4){__int_as_float(o.wt[0]), __int_as_float(o.wt[1]), __int_as_float(o.wt[2]), __int_as_float(o.wt[3])};
+        q[7] = (f32x4){__int_as_float(o.bt[0]), __int_as_float(o.bt[1]), __int_as_float(o.bt[2]), __int_as_float(o.bt[3])};
+    }
+}
+
+// data = X[perm] + jitter * randn (trainer.py:392) for the 16-row tile `wg` of minibatch (epoch, mb), in PIECES of four dimensions
+// per lane -- piece q = (tile q / 2, half q % 2) is dims 32 t + 8 g + 4 hf + [0, 4) of the lane's row: one row load and one
+// Philox block -- so that the free waves of a workgroup can prepare a minibatch's rows side by side.  out[c][k] (c = parity
+// class, k = 0, 1) are components 2 hf + k of xs[c][t].  Padded rows / dims hold 0.
+__device__ __forceinline__ void grid_rows_piece(const TrainArgs &a, int epoch, int mb, int wg, int lane, int q, float (&out)[2][2]) {
+    const int w = lane & 15, g = lane >> 4, D = a.s.D, t = q >> 1, hf = q & 1;
+    const int M = min(a.batch, a.n_train - mb * a.batch);
+    const int row = wg * 16 + w;
+    const bool row_ok = wg < ((M + 15) >> 4) && row < M;
+    long src = 0;
+    if (row_ok) src = a.perm[(size_t)epoch * a.n_train + mb * a.batch + row];
+    const int d0 = 32 * t + 8 * g + 4 * hf;
+    float v[4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {   // the job slots first (the gathers below depend on them) ...
-            const int i = i0 + u * blockDim.x;
-            gp[u] = i < n4 ? reinterpret_cast<const i32x4 *>(a.gpos)[i] : (i32x4){-1, -1, -1, -1};
+    for (int j = 0; j < 4; ++j) v[j] = (row_ok && d0 + j < D) ? a.xtrain[(size_t)src * D + d0 + j] : 0.f;
+    if (a.jitter != 0.f && row_ok) {
+        const long p = (long)mb * a.batch + row;
+        float n[4];
+        if (a.noise) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) n[j] = d0 + j < D ? a.noise[((size_t)epoch * a.n_train + p) * D + d0 + j] : 0.f;
+        } else {
+            const f32x4 nn = noise_normal4(a.seed, (uint64_t)p, (uint32_t)(a.epoch_offset + epoch), (uint32_t)(8 * t + 2 * g + hf), NOISE_STREAM_JITTER);
+            n[0] = nn.x; n[1] = nn.y; n[2] = nn.z; n[3] = nn.w;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {   // ... then every other operand, all in flight together
-            const int i = i0 + u * blockDim.x;
-            if (i < n4) {
-                g[u][0] = ld_sc1(a.gtile + max(gp[u].x, 0));   // unconditional (no divergent branch per element);
-                g[u][1] = ld_sc1(a.gtile + max(gp[u].y, 0));
-                g[u][2] = ld_sc1(a.gtile + max(gp[u].z, 0));
-                g[u][3] = ld_sc1(a.gtile + max(gp[u].w, 0));
-                w4[u] = reinterpret_cast<const f32x4 *>(rw)[i];
-                m4[u] = reinterpret_cast<const f32x4 *>(rm)[i];
-                v4[u] = reinterpret_cast<const f32x4 *>(rv)[i];
-            }
-        }
+        for (int j = 0; j < 4; ++j)
+            if (d0 + j < D) v[j] += n[j] * a.jitter;
+    }
+    out[0][0] = v[0]; out[1][0] = v[1]; out[0][1] = v[2]; out[1][1] = v[3];
+}
+// all pieces of a tile's rows, into registers (the workgroups whose waves all carry jobs)
+template <int NT>
+__device__ __forceinline__ void grid_rows(const TrainArgs &a, int epoch, int mb, int wg, int lane, f32x4 (&xs)[2][NT]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * blockDim.x;
-            if (i < n4) {
-                float w[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
-                float m[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w}, v[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
-                // where the stepped weight sits in the two fragment images: read here (from the LDS copy of the maps when it
-                // fits), not held across the long-latency loads above
-                const i32x4 fp = reinterpret_cast<const i32x4 *>(fpos)[i], bp = reinterpret_cast<const i32x4 *>(bpos)[i];
-                const int f[4] = {fp.x, fp.y, fp.z, fp.w}, bq[4] = {bp.x, bp.y, bp.z, bp.w};
-                const int gq[4] = {gp[u].x, gp[u].y, gp[u].z, gp[u].w};   // < 0: no job produces this gradient: exactly zero
+    for (int q = 0; q < 2 * NT; ++q) {
+        float o[2][2];
+        grid_rows_piece(a, epoch, mb, wg, lane, q, o);
+        const int t = q >> 1;
+        if (q & 1) { xs[0][t].z = o[0][0]; xs[0][t].w = o[0][1]; xs[1][t].z = o[1][0]; xs[1][t].w = o[1][1]; }
+        else       { xs[0][t].x = o[0][0]; xs[0][t].y = o[0][1]; xs[1][t].x = o[1][0]; xs[1][t].y = o[1][1]; }
+    }
+}
+// the pieces q = k, k + nfree, ... of minibatch (epoch, mb) into the LDS buffer [c][t][lane] of f32x4 (free wave k of nfree)
+template <int NT>
+__device__ __forceinline__ void grid_rows_to_lds(const TrainArgs &a, int epoch, int mb, int wg, int lane, int k, int nfree, f32x4 *buf) {
+    for (int q = k; q < 2 * NT; q += nfree) {
+        float o[2][2];
+        grid_rows_piece(a, epoch, mb, wg, lane, q, o);
+        const int t = q >> 1, hf = q & 1;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) adam_one(a, ad, w[k], gq[k] >= 0 ? g[u][k] : 0.f, m[k], v[k], f[k], bq[k], imgf, imgb);
-                reinterpret_cast<f32x4 *>(rw)[i] = (f32x4){w[0], w[1], w[2], w[3]};
-                reinterpret_cast<f32x4 *>(rm)[i] = (f32x4){m[0], m[1], m[2], m[3]};
-                reinterpret_cast<f32x4 *>(rv)[i] = (f32x4){v[0], v[1], v[2], v[3]};
-            }
+        for (int c = 0; c < 2; ++c) {
+            float *dst = reinterpret_cast<float *>(buf + (c * NT + t) * 64 + lane) + 2 * hf;
+            dst[0] = o[c][0]; dst[1] = o[c][1];
         }
     }
-    for (int p = 4 * n4 + threadIdx.x; p < np; p += blockDim.x) {  // tail (np not a multiple of 4)
-        const int gp = a.gpos[p];
-        float w = rw[p], m = rm[p], v = rv[p];
-        adam_one(a, ad, w, gp >= 0 ? ld_sc1(a.gtile + gp) : 0.f, m, v, fpos[p], bpos[p], imgf, imgb);
-        rw[p] = w; rm[p] = m; rv[p] = v;
-    }
+}
+
+// adam_one without the scatter into the images (the refresh phase does that from the published weights)
+__device__ __forceinline__ void adam_reg(const TrainArgs &a, const AdamStep &ad, float &w, float g, float &m, float &v) {
+    adam_one(a, ad, w, g, m, v, -1, -1, nullptr, nullptr);
 }
 
 template <int NT, int NH, int L>
@@ -442,29 +528,59 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *imgf = smem;
     float *imgb = smem + a.s.image_floats;
-    // parameter -> image element maps: LDS copies behind the images when they fit (a.flags bit NNEST_TRAIN_POS_LDS, set by the launcher)
-    const bool pos_lds = (a.flags & NNEST_TRAIN_POS_LDS) != 0;
-    int *lfp = reinterpret_cast<int *>(smem + 2 * a.s.image_floats), *lbp = lfp + ((a.s.num_params() + 3) & ~3);
-    const int *fpos = pos_lds ? lfp : a.fwd_pos, *bpos = pos_lds ? lbp : a.bwd_pos;
     __shared__ f32x4 xch[2 * NT * 64];   // the two net waves' exchange buffer
+    // the next minibatch's rows (permutation gather + Philox jitter: 6 k cycles of a 13 k forward pass when the net waves did it
+    // themselves) are prepared by this workgroup's eight waves behind their W-phase work, a piece (four dimensions per lane) each
+    __shared__ f32x4 xpre[2][2 * NT * 64];
     __shared__ int ctl[4];      // [0] stop flag, [1] counter, [2] best epoch
     __shared__ float ctlf[2];   // [0] best validation loss
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int w = lane & 15, g = lane >> 4;
     const int wg = blockIdx.x, G = gridDim.x;
     const int D = a.s.D, B = a.s.B;
-    const int np = a.s.num_params();
     constexpr int NJOBS = NT * NH + L * NH * NH + NH * NT;
     const int NJ = B * 2 * NJOBS;
     f32x4 *stash_w = reinterpret_cast<f32x4 *>(a.stash) + (size_t)wg * B * 2 * (L + 1) * NH * 64;
-    const int npad = (np + 3) & ~3;
-    float *rw = a.grep + (size_t)wg * 3 * npad, *rm = rw + npad, *rv = rm + npad;  // this workgroup's replica of w, exp_avg, exp_avg_sq
     int phase = 0;
 
     rebuild_images_to(a, imgf, imgb);
-    for (int i = threadIdx.x; i < np; i += blockDim.x) {
-        rw[i] = a.w[i]; rm[i] = a.m[i]; rv[i] = a.v[i];
-        if (pos_lds) { lfp[i] = a.fwd_pos[i]; lbp[i] = a.bwd_pos[i]; }
+    // ---- who owns what.  Wave (wg, wave) runs job Jmine = 8 wg + wave of every minibatch (NJ <= 64 jobs: grid_eligible) and keeps
+    // that tile's parameters -- weight, exp_avg, exp_avg_sq of lane (gq, j) register r, and of the bias vector -- in registers
+    // from here to the end of the launch.  The waves beyond the jobs share the parameters no job reaches.
+    const int Jmine = wave * G + wg;   // jobs fill the low waves of EVERY workgroup: the high waves stay free (dead parameters, row prefetch)
+    const bool owner = Jmine < NJ;
+    constexpr bool OREG = NT <= 2;
+    float *own_rec = a.gown + ((size_t)Jmine * 64 + lane) * 32;
+    int off_f = 0, off_b = 0, off_bias = -1;
+    if (owner) grid_job_image_offsets<NT, NH, L>(a.s, Jmine, &off_f, &off_b, &off_bias);
+    __shared__ __attribute__((aligned(16))) float trs[TRAIN_WAVES][16 * 20];   // per wave: a 16 x 16 tile, rows 80 bytes apart
+    OwnState os;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        os.wt[r] = os.bt[r] = -1;
+        os.tw[r] = os.tm[r] = os.tv[r] = os.bw[r] = os.bm[r] = os.bv[r] = 0.f;
+    }
+    if (owner) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            grid_job_targets<NT, NH, L>(a.s, Jmine, lane, r, &os.wt[r], &os.bt[r]);
+            if (os.wt[r] >= 0) { os.tw[r] = a.w[os.wt[r]]; os.tm[r] = a.m[os.wt[r]]; os.tv[r] = a.v[os.wt[r]]; }
+            if (os.bt[r] >= 0) { os.bw[r] = a.w[os.bt[r]]; os.bm[r] = a.m[os.bt[r]]; os.bv[r] = a.v[os.bt[r]]; }
+        }
+        if (!OREG) own_store(os, own_rec, true);
+    }
+    // The parameters no job reaches, shared out over ALL waves of the grid (behind their job) in chunks of whole 256-byte rows of a COMPACT private
+    // array (gdst: [w | exp_avg | exp_avg_sq][ndead_pad], indexed by position in the list): a wave's entries share no cache line
+    // with another workgroup's -- the XCDs' L2s are not coherent with each other, and packed neighbours a.w[p], a.w[p + 1] may
+    // belong to waves on different XCDs.  The packed vectors are written once, at the end, with write-through stores.
+    const int n_waves = G * TRAIN_WAVES, ndead = *a.gndead;
+    const int ndead_pad = (ndead + 63) & ~63;
+    const int dead_per = ((ndead + n_waves - 1) / n_waves + 63) & ~63;
+    const int dead0 = min(ndead, Jmine * dead_per), dead1 = min(ndead, dead0 + dead_per);
+    float *dw = a.gdst, *dm = a.gdst + ndead_pad, *dv = a.gdst + 2 * ndead_pad;
+    for (int k = dead0 + lane; k < dead1; k += 64) {
+        const int pidx = a.gdead[k];
+        dw[k] = a.w[pidx]; dm[k] = a.m[pidx]; dv[k] = a.v[pidx];
     }
     const bool resume = (a.flags & NNEST_TRAIN_RESUME) != 0;
     if (threadIdx.x == 0) {
@@ -473,11 +589,21 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
         ctl[2] = resume ? a.result->best_epoch : 0;
         ctlf[0] = resume ? a.result->best_validation_loss : INFINITY;
     }
-    if (wg == 0 && !resume)
-        for (int i = threadIdx.x; i < np; i += blockDim.x) a.best_w[i] = a.w[i];  // best_model = deepcopy(netG)  trainer.py:194
+    if (!resume) {   // best_model = deepcopy(netG)  (trainer.py:194): every wave snapshots what it owns (one writer per entry)
+        if (owner) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (os.wt[r] >= 0) st_sc1(a.best_w + os.wt[r], os.tw[r]);
+                if (os.bt[r] >= 0) st_sc1(a.best_w + os.bt[r], os.bw[r]);
+            }
+        }
+        for (int k = dead0 + lane; k < dead1; k += 64) st_sc1(a.best_w + a.gdead[k], dw[k]);
+    }
     __syncthreads();
 
     const int n_mb = (a.n_train + a.batch - 1) / a.batch;
+    if (a.max_epochs > 0) grid_rows_to_lds<NT>(a, 0, 0, wg, lane, TRAIN_WAVES - 1 - wave, TRAIN_WAVES, xpre[0]);   // the first minibatch's rows
+    __syncthreads();
     int adam_t = a.adam_step ? *a.adam_step : 0;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0;
     (void)ph; (void)q0; (void)q1; (void)q2; (void)q3; (void)q4; (void)q5; (void)q6;
@@ -511,34 +637,11 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
                 float lp = 0.f;
                 if (wg_active) {
                     f32x4 xs[2][NT], gs[2][NT];
-                    // data = X[perm] + jitter * randn  (trainer.py:392)
-                    long src = 0;
-                    if (row_ok) src = a.perm[(size_t)epoch * a.n_train + mb * a.batch + row];
-                    load_tile<NT>(a.xtrain, src, row_ok, D, lane, xs);
-                    if (a.jitter != 0.f) {
-                        const long p = (long)mb * a.batch + row;
-                        if (a.noise) {
-                            f32x4 nz[2][NT];
-                            load_tile<NT>(a.noise + (size_t)epoch * a.n_train * D, p, row_ok, D, lane, nz);
+                    // data = X[perm] + jitter * randn  (trainer.py:392): prepared a phase ahead by the last wave, or here
 #pragma unroll
-                            for (int c = 0; c < 2; ++c)
+                    for (int c = 0; c < 2; ++c)
 #pragma unroll
-                                for (int t = 0; t < NT; ++t) xs[c][t] = xs[c][t] + nz[c][t] * a.jitter;
-                        } else {
-#pragma unroll
-                            for (int t = 0; t < NT; ++t) {
-                                f32x4 n0 = noise_normal4(a.seed, (uint64_t)p, (uint32_t)(a.epoch_offset + epoch), (uint32_t)(8 * t + 2 * g), NOISE_STREAM_JITTER);
-                                f32x4 n1 = noise_normal4(a.seed, (uint64_t)p, (uint32_t)(a.epoch_offset + epoch), (uint32_t)(8 * t + 2 * g + 1), NOISE_STREAM_JITTER);
-                                const int d0 = 32 * t + 8 * g;
-                                if (row_ok) {
-                                    if (d0 + 0 < D) xs[0][t].x += n0.x * a.jitter; if (d0 + 1 < D) xs[1][t].x += n0.y * a.jitter;
-                                    if (d0 + 2 < D) xs[0][t].y += n0.z * a.jitter; if (d0 + 3 < D) xs[1][t].y += n0.w * a.jitter;
-                                    if (d0 + 4 < D) xs[0][t].z += n1.x * a.jitter; if (d0 + 5 < D) xs[1][t].z += n1.y * a.jitter;
-                                    if (d0 + 6 < D) xs[0][t].w += n1.z * a.jitter; if (d0 + 7 < D) xs[1][t].w += n1.w * a.jitter;
-                                }
-                            }
-                        }
-                    }
+                        for (int t = 0; t < NT; ++t) xs[c][t] = xpre[mbcount & 1][(c * NT + t) * 64 + lane];
                     float ldp = 0.f;
                     for (int b = 0; b < B; ++b) {
                         const float *wf = imgf + (size_t)b * 2 * a.s.net_floats;
@@ -575,8 +678,10 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
             alive = grid_barrier(a.gsync, phase, G, a.gerr);
             if (!alive) break;
             TSTAMP(q3);
-            // ---- W: one weight-gradient job per wave of the grid ----
-            for (int J = wg * TRAIN_WAVES + wave; J < NJ; J += G * TRAIN_WAVES) {
+            // ---- W + A: one weight-gradient job per wave of the grid; Adam on the tile's parameters in this wave's registers ----
+            if (owner) {
+                const int J = Jmine;
+                if (!OREG) own_load(os, own_rec);   // (requested beside the contraction's operands)
                 const int bn = J / NJOBS;
                 int q = J % NJOBS;
                 const float *stg = a.gstage + (size_t)bn * SM::count * TRAIN_MAX_ROWS * 16;
@@ -597,8 +702,39 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
                     t = tau == 0 ? contract_rows_grid<true>(stg, rows_pad, SM::gpre(0, ht), SM::m(tau), lane, bt)
                                  : contract_rows_grid<false>(stg, rows_pad, SM::gpre(0, ht), SM::m(tau), lane, bt);
                 }
-                st_sc1_f32x4(a.gtile + ((size_t)J * 64 + lane) * 4, t);
-                st_sc1_f32x4(a.gtile + ((size_t)NJ * 64 + (size_t)J * 64 + lane) * 4, bt);
+                const float gt[4] = {t.x, t.y, t.z, t.w}, gb[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (os.wt[r] >= 0) adam_reg(a, ad, os.tw[r], gt[r], os.tm[r], os.tv[r]);
+                    if (os.bt[r] >= 0) adam_reg(a, ad, os.bw[r], gb[r], os.bm[r], os.bv[r]);
+                }
+                // the NEW weights, one whole 1-KB fragment tile per store instruction (sc1: the other workgroups read them): as they
+                // stand into the published backward image, transposed (through this wave's LDS scratch) into the forward image
+                st_sc1_f32x4(a.gimgb + off_b + lane * 4, (f32x4){os.tw[0], os.tw[1], os.tw[2], os.tw[3]});
+                {
+                    float *tr = trs[wave];
+                    const int gq = lane >> 4, j = lane & 15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tr[(4 * gq + r) * 20 + j] = os.tw[r];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its own LDS traffic, in order)
+                    const f32x4 tt = *reinterpret_cast<const f32x4 *>(tr + j * 20 + 4 * gq);   // lane (g, i): T[i][4 g .. 4 g + 3]
+                    st_sc1_f32x4(a.gimgf + off_f + lane * 4, tt);
+                }
+                if (off_bias >= 0 && (lane & 15) == 0)
+                    st_sc1_f32x4(a.gimgf + off_bias + (lane >> 4) * 4, (f32x4){os.bw[0], os.bw[1], os.bw[2], os.bw[3]});
+                if (!OREG) own_store(os, own_rec, false);
+            }
+            // every wave: its share of the parameters no job reaches -- zero gradient, weight decay only (they take their Adam step
+            // too, as in torch) -- ...
+            for (int k = dead0 + lane; k < dead1; k += 64) {
+                float w_ = dw[k], m_ = dm[k], v_ = dv[k];
+                adam_reg(a, ad, w_, 0.f, m_, v_);
+                dw[k] = w_; dm[k] = m_; dv[k] = v_;
+            }
+            {   // ... and its pieces of the NEXT minibatch's rows (the job-less high waves first)
+                int e2 = epoch, m2 = mb + 1;
+                if (m2 == n_mb) { m2 = 0; e2 = epoch + 1; }
+                if (e2 < a.max_epochs) grid_rows_to_lds<NT>(a, e2, m2, wg, lane, TRAIN_WAVES - 1 - wave, TRAIN_WAVES, xpre[(mbcount + 1) & 1]);
             }
             TSTAMP(q4);
             alive = grid_barrier(a.gsync, phase, G, a.gerr);
@@ -609,7 +745,32 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
             float lpart[GRID_WG];
 #pragma unroll
             for (int k = 0; k < GRID_WG; ++k) lpart[k] = ld_sc1(part + k);
-            adam_sweep_grid(a, ad, np, imgf, imgb, rw, rm, rv, fpos, bpos);
+            // ---- R: the published weights into this workgroup's LDS images.  Every load -- the tile values (sc1) and the slot maps
+            // -- is requested before the first LDS write: one round trip to the memory side for the whole phase
+            {
+                // both published images are laid out like the LDS ones: a straight copy, 16 bytes per lane and load, every load
+                // requested before the first LDS write (one round trip to the memory side for the whole phase)
+                constexpr int RU = 4;
+                const int n4 = a.s.image_floats >> 2;
+                for (int i0 = threadIdx.x; i0 < n4; i0 += RU * blockDim.x) {
+                    f32x4 vf[RU], vb[RU];
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) {
+                        const int i = min(i0 + u * (int)blockDim.x, n4 - 1);
+                        vf[u] = ld_sc1_x4_issue(a.gimgf + 4 * (size_t)i);
+                        vb[u] = ld_sc1_x4_issue(a.gimgb + 4 * (size_t)i);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]) : : "memory");
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) {
+                        const int i = i0 + u * blockDim.x;
+                        if (i < n4) {
+                            reinterpret_cast<f32x4 *>(imgf)[i] = vf[u];
+                            reinterpret_cast<f32x4 *>(imgb)[i] = vb[u];
+                        }
+                    }
+                }
+            }
             float loss = 0.f;
 #pragma unroll
             for (int k = 0; k < GRID_WG; ++k) loss += k < G ? lpart[k] : 0.f;
@@ -659,9 +820,16 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
         // early stopping bookkeeping (trainer.py:205-209, :223-232); every thread of the grid evaluates the same values
         const bool improved = valid_loss < ctlf[0];
         __syncthreads();
-        if (improved) {
-            if (wg == 0)
-                for (int i = threadIdx.x; i < np; i += blockDim.x) a.best_w[i] = rw[i];
+        if (improved) {   // best_model = deepcopy(netG)  (trainer.py:208): every wave snapshots what it owns
+            if (owner) {
+                if (!OREG) own_load(os, own_rec);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (os.wt[r] >= 0) st_sc1(a.best_w + os.wt[r], os.tw[r]);
+                    if (os.bt[r] >= 0) st_sc1(a.best_w + os.bt[r], os.bw[r]);
+                }
+            }
+            for (int k = dead0 + lane; k < dead1; k += 64) st_sc1(a.best_w + a.gdead[k], dw[k]);
             if (threadIdx.x == 0) { ctlf[0] = valid_loss; ctl[2] = a.epoch_offset + epoch + 1; ctl[1] = 0; }
         }
         __syncthreads();
@@ -672,18 +840,31 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_grid(TrainArgs a) 
         __syncthreads();
         if (ctl[0]) break;
     }
-    // workgroup 0 writes its replica back (nobody reads a.w / a.m / a.v after the start of the launch)
-    if (wg != 0) return;
+    // every wave writes what it owns back -- write-through stores, one writer per entry (nobody reads the packed vectors between
+    // the start of the launch and the kernel that follows: launch_repack rebuilds the forward image from a.w)
     __syncthreads();
     const bool stopped = ctl[0] != 0;
     const bool restore = stopped || (a.flags & NNEST_TRAIN_FINALIZE);   // netG.load_state_dict(best_model)  (trainer.py:241)
-    for (int i = threadIdx.x; i < np; i += blockDim.x) {
-        a.w[i] = restore ? a.best_w[i] : rw[i];
-        a.m[i] = rm[i];
-        a.v[i] = rv[i];
+    if (owner) {
+        if (!OREG) own_load(os, own_rec);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (os.wt[r] >= 0) {
+                st_sc1(a.w + os.wt[r], restore ? ld_sc1(a.best_w + os.wt[r]) : os.tw[r]);
+                st_sc1(a.m + os.wt[r], os.tm[r]); st_sc1(a.v + os.wt[r], os.tv[r]);
+            }
+            if (os.bt[r] >= 0) {
+                st_sc1(a.w + os.bt[r], restore ? ld_sc1(a.best_w + os.bt[r]) : os.bw[r]);
+                st_sc1(a.m + os.bt[r], os.bm[r]); st_sc1(a.v + os.bt[r], os.bv[r]);
+            }
+        }
     }
-    __syncthreads();
-    rebuild_images(a);
+    for (int k = dead0 + lane; k < dead1; k += 64) {
+        const int pidx = a.gdead[k];
+        st_sc1(a.w + pidx, restore ? ld_sc1(a.best_w + pidx) : dw[k]);
+        st_sc1(a.m + pidx, dm[k]); st_sc1(a.v + pidx, dv[k]);
+    }
+    if (wg != 0) return;
 #ifdef NNEST_STAMP
     if (threadIdx.x == 0 && a.losses)   // diagnostic build: cycles per phase, summed over the minibatches (workgroup 0, wave 0)
         for (int i = 0; i < 8; ++i) a.losses[i] = (float)ph[i];
@@ -715,36 +896,46 @@ static hipError_t launch_train_grid_t(TrainArgs a, float *gridws, hipStream_t st
     a.gpart = reinterpret_cast<float *>(a.gpos + a.s.num_params());
     a.gsync = reinterpret_cast<unsigned int *>(a.gpart + 64);
     a.gerr = reinterpret_cast<int *>(a.gsync + 8);
-    a.grep = a.gpart + 64 + 16 + ((4 - ((a.s.num_params() + 64 + 16) & 3)) & 3);   // 16-byte aligned behind the small words
+    a.gndead = reinterpret_cast<int *>(a.gsync + 12);
+    a.gdead = reinterpret_cast<int *>(a.gpart + 64 + 16);
+    a.gown = reinterpret_cast<float *>(a.gdead + a.s.num_params());
+    a.gown += (64 - ((size_t)(a.gown - gridws) & 63)) & 63;   // 256-byte aligned records
+    a.gdst = a.gown + (size_t)GRID_WG * TRAIN_WAVES * 64 * 32;
+    a.gimgf = a.gdst + (size_t)3 * ((a.s.num_params() + 63) & ~63) + 64;
+    a.gimgf += (64 - ((size_t)(a.gimgf - gridws) & 63)) & 63;
+    a.gimgb = a.gimgf + ((a.s.image_floats + 63) & ~63);
     hipError_t e = hipMemsetAsync(a.gpos, 0xFF, (size_t)a.s.num_params() * sizeof(int), st);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(a.gpart, 0, (64 + 16) * sizeof(float), st);  // partial sums, the barrier counter, the error word
+    e = hipMemsetAsync(a.gimgf, 0, (size_t)2 * ((a.s.image_floats + 63) & ~63) * sizeof(float), st);   // (the backward image's unused bias area)
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.gpart, 0, (64 + 16) * sizeof(float), st);  // partial sums, the barrier counter, the error word, the dead count
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((grid_gpos_kernel<NT, NH, L>), dim3(32), dim3(256), 0, st, a.gpos, a.s);
+    hipLaunchKernelGGL(grid_dead_kernel, dim3(32), dim3(256), 0, st, a.gpos, a.s.num_params(), a.gdead, a.gndead);
     size_t lds = 2 * (size_t)a.s.image_floats * sizeof(float);
-    const size_t pos = 2 * (size_t)((a.s.num_params() + 3) & ~3) * sizeof(int);
-    if (lds + pos + 2 * NT * 1024 <= 160 * 1024 - 512) {   // the two position maps beside the images (and the exchange buffer)
-        lds += pos;
-        a.flags |= NNEST_TRAIN_POS_LDS;
-    }
     if (lds > 64 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(train_kernel_grid<NT, NH, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((train_kernel_grid<NT, NH, L>), dim3(GRID_WG), dim3(TRAIN_THREADS), lds, st, a);
-    return hipGetLastError();
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_repack(a.w, a.img_fwd, a.s, st);   // the inference kernels' forward image from the weights the launch leaves
 }
 
 // grid form: the epoch loop of an affine flow whose two fragment images fit one CU's LDS; everything else runs train_kernel
 static bool grid_eligible(const TrainArgs &a) {
     return a.mode == TRAIN_MODE_EPOCHS && a.s.scale_mode == 0 && !(a.flags & NNEST_TRAIN_ONE_CU) &&
-           2 * (size_t)a.s.image_floats * sizeof(float) <= 160 * 1024 - 1024 && a.s.NH == 1 && a.s.L <= 2;
+           2 * (size_t)a.s.image_floats * sizeof(float) <= 160 * 1024 - 1024 && a.s.NH == 1 && a.s.L <= 2 &&
+           a.s.B * 2 * (2 * a.s.NT + a.s.L) <= GRID_WG * TRAIN_WAVES;   // one job per wave: the owner of its parameters
 }
 
 static size_t grid_workspace_floats(const FlowShape &s) {
     const int CT = 2 * s.NT + 2 * (s.L + 1) * s.NH, NJOBS = 2 * s.NT * s.NH + s.L * s.NH * s.NH;
     return (size_t)s.B * 2 * CT * TRAIN_MAX_ROWS * 16 + (size_t)2 * s.B * 2 * NJOBS * 256 + (size_t)s.num_params() + 64 + 16 + 64 +
-           (size_t)GRID_WG * 3 * ((s.num_params() + 3) & ~3);
+           (size_t)s.num_params() /* dead list */ +
+           (size_t)GRID_WG * TRAIN_WAVES * 64 * 32 + 64 /* owners' records */ + (size_t)3 * (s.num_params() + 64) + 128 /* dead state */ +
+           (size_t)2 * (s.image_floats + 64) + 64 /* the published images */;
 }
 
 static hipError_t dispatch_train_grid(const TrainArgs &a, float *gridws, hipStream_t st) {
