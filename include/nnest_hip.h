@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 11
+#define NNEST_HIP_ABI_VERSION 12
 
 enum {
     NNEST_OK = 0,
@@ -307,6 +307,12 @@ int nnest_chol_inverse(nnest_chol_t *chol, const float *z_dev, float *x_dev, flo
 int nnest_chol_log_probs(nnest_chol_t *chol, const float *x_dev, float *logp_dev, int N, void *stream);
 int nnest_chol_loss_grad(nnest_chol_t *chol, const float *x_dev, int M, float *grad_dev, float *loss_dev, void *stream);
 int nnest_chol_adam_step(nnest_chol_t *chol, const float *grad_dev, float lr, float weight_decay, void *stream);
+
+/* Host-side (no GPU involved): the rows of a chain file in the reference's text format -- Sampler._save_samples,
+ * nnest/sampler.py:494-511: np.savetxt(fmt='%.5E'): '%.5E' numbers separated by one space, '\n' after every row -- into out_host
+ * (capacity >= 14 * n_rows * n_cols + 1 bytes); formatted on `threads` host threads.  Returns the number of bytes written, -1 on
+ * a bad argument. */
+long nnest_format_rows_e5(const double *rows_host, long n_rows, int n_cols, char *out_host, long out_cap, int threads);
 
 #ifdef __cplusplus
 }

@@ -132,6 +132,7 @@ SIGNATURES = {
     'nnest_nvp_train': [_vp, _vp, _i, _vp, _i, _vp, _vp, _u64, _f, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp],
     'nnest_nvp_loss_grad': [_vp, _vp, _i, _vp, _vp, _vp],
     'nnest_training_jitter': [_vp, _i, _i, _vp, _vp],
+    'nnest_format_rows_e5': [_vp, ctypes.c_long, _i, _vp, ctypes.c_long, _i],
 }
 
 _lib = None
@@ -148,7 +149,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_char_p if name == 'nnest_hip_last_error' else ctypes.c_int
+            fn.restype = ctypes.c_char_p if name == 'nnest_hip_last_error' else (ctypes.c_long if name == 'nnest_format_rows_e5' else ctypes.c_int)
         _lib = lib
     return _lib
 

@@ -14,9 +14,11 @@ and its endpoints are all-gathered on device memory (RCCL); every rank retrains 
 one broadcast seed -- the training kernels are bitwise reproducible, so the replicas stay identical with no weight
 broadcast (a trainer that cannot promise that is trained on rank 0 and its weights are broadcast).
 
-Deviation from the reference's checkpoint cadence (nested.py:473-485 dumps every dead point and rewrites chain.txt as
-text every `log_interval` accepted points, O(n^2) over a run -- 995 s of a 15 s GPU run): full dumps are limited to one
-per `checkpoint_min_seconds` (default 30; 0 restores the reference's cadence), so a crash loses at most that much work.
+Checkpoints (nested.py:473-485: every `log_interval` accepted points the reference rewrites every dead point and chain.txt as
+text -- O(n^2) over a run, 995 s of a 15 s GPU run).  Here a checkpoint writes the live set and APPENDS the new dead points to
+saved_*.npy (GrowingNpy: the same files, valid .npy at any time), so it costs ~1 ms; it is taken at the reference's cadence but
+at most once per `checkpoint_min_seconds` (default 2; 0 = exactly the reference's cadence and file set), and chain.txt -- a
+derived product -- is rewritten at most once per `chain_min_seconds` (default 30) and at the end.
 """
 import csv
 import glob
@@ -30,6 +32,7 @@ import torch
 
 from .priors import UniformPrior
 from .sampler import Sampler
+from .utils import GrowingNpy
 
 
 class _Evidence(object):
@@ -77,7 +80,8 @@ class NestedSampler(Sampler):
                  num_live_points=1000,
                  fused=True,
                  mcmc_history=False,
-                 checkpoint_min_seconds=30.0):
+                 checkpoint_min_seconds=2.0,
+                 chain_min_seconds=30.0):
         prior = UniformPrior(x_dim, -1, 1)  # nested.py:76
         super(NestedSampler, self).__init__(x_dim, loglike, transform=transform, append_run_num=append_run_num,
                                             hidden_dim=hidden_dim, num_slow=num_slow, num_derived=num_derived,
@@ -89,6 +93,8 @@ class NestedSampler(Sampler):
                                             mcmc_history=mcmc_history)
         self.num_live_points = num_live_points
         self.checkpoint_min_seconds = checkpoint_min_seconds
+        self.chain_min_seconds = chain_min_seconds
+        self._grow = None
         self.sampler = 'nested'
         if self.single_or_primary_process:
             self.logger.info('Num live points [%d]' % self.num_live_points)
@@ -170,9 +176,14 @@ class NestedSampler(Sampler):
         np.save(os.path.join(cp, 'active_v_%s.npy' % it), active_v)
         np.save(os.path.join(cp, 'active_logl_%s.npy' % it), active_logl)
         np.save(os.path.join(cp, 'active_derived_%s.npy' % it), active_derived)
-        np.save(os.path.join(cp, 'saved_v.npy'), np.array(saved_v))
-        np.save(os.path.join(cp, 'saved_logl.npy'), np.array(saved_logl))
-        np.save(os.path.join(cp, 'saved_logwt.npy'), np.array(saved_logwt))
+        # the dead points so far: the same three files as the reference (nested.py:479-481), grown by the new rows only
+        if getattr(self, '_grow', None) is None:
+            self._grow = {'saved_v': GrowingNpy(os.path.join(cp, 'saved_v.npy'), (self.x_dim + self.num_derived,)),
+                          'saved_logl': GrowingNpy(os.path.join(cp, 'saved_logl.npy'), ()),
+                          'saved_logwt': GrowingNpy(os.path.join(cp, 'saved_logwt.npy'), ())}
+        self._grow['saved_v'].sync(saved_v)
+        self._grow['saved_logl'].sync(saved_logl)
+        self._grow['saved_logwt'].sync(saved_logwt)
         with open(os.path.join(cp, 'checkpoint_%s.txt' % it), 'w') as f:
             json.dump(state, f)
 
@@ -295,7 +306,9 @@ class NestedSampler(Sampler):
                                   'fraction_remain': fraction_remain, 'strategy': strategy,
                                   'expired_strategies': expired_strategies})
 
-        last_checkpoint = time.time()
+        last_checkpoint = last_chain = time.time()
+        if self.chain_min_seconds <= 0:
+            last_chain = -1e300
         first_time = True
         get_samples = True
         nb = 0
@@ -455,14 +468,16 @@ class NestedSampler(Sampler):
                 if (it > 0 and it % log_interval == 0 and primary
                         and time.time() - last_checkpoint >= self.checkpoint_min_seconds):
                     last_checkpoint = time.time()
-                    self.samples = np.array(saved_v)
-                    self.weights = np.exp(np.array(saved_logwt) - ev.logz)
-                    self.loglikes = np.array(saved_logl)
                     self._checkpoint(it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt,
                                      {'logz': ev.logz, 'h': ev.h, 'logvol': logvol, 'ncall': total_calls,
                                       'fraction_remain': fraction_remain, 'strategy': strategy,
                                       'expired_strategies': expired_strategies})
-                    self._save_samples(self.samples, self.loglikes, weights=self.weights)
+                    if last_checkpoint - last_chain >= self.chain_min_seconds:
+                        last_chain = last_checkpoint
+                        self.samples = np.array(saved_v)
+                        self.weights = np.exp(np.array(saved_logwt) - ev.logz)
+                        self.loglikes = np.array(saved_logl)
+                        self._save_samples(self.samples, self.loglikes, weights=self.weights)
 
         # the remaining live points share the last volume shell equally (nested.py:487-495)
         logvol = -len(saved_v) / N - np.log(N)

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .utils import create_logger, get_or_create_run_dir
+from .utils import create_logger, get_or_create_run_dir, write_rows_e5
 
 
 def detect_linear_scale(transform, x_dim):
@@ -603,8 +603,7 @@ class Sampler(object):
         header = ''
         if self.param_names is not None:
             header = 'weight minusloglike ' + ' '.join(self.param_names)
-        np.savetxt(os.path.join(self.logs['chains'], outfile + '.txt'), np.concatenate(cols, axis=1), fmt='%.5E',
-                   header=header, comments='#')
+        write_rows_e5(os.path.join(self.logs['chains'], outfile + '.txt'), np.concatenate(cols, axis=1), header=header)
 
     # ---- collectives -------------------------------------------------------------------------------------------------
     # One process per GPU, torch.distributed ('nccl' = RCCL over xGMI; 'gloo' on CPU for the tests).  A tensor argument stays

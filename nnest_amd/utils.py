@@ -1,5 +1,6 @@
 """Host plumbing shared by the sampler front-ends: logger factory and the numbered run-directory tree
 (same layout as the reference's nnest/utils/logger.py:9-22, :38-75 so its analysis scripts find the files)."""
+import numpy as np
 import errno
 import logging
 import os
@@ -71,3 +72,58 @@ class ScalarWriter(object):
             self.flush()
         except Exception:
             pass
+
+
+class GrowingNpy(object):
+    """An .npy file (format 1.0, float64, C order) that grows by appended rows: the header is written once with room for the
+    row count and patched in place, so that a dump costs the new rows only -- the reference rewrites every dead point at every
+    checkpoint (nested.py:473-485: np.save of the whole list), which is quadratic over a run.  np.load reads the file like
+    any other .npy at any time between two `sync` calls."""
+    HEADER_BYTES = 128
+
+    def __init__(self, path, row_shape):
+        self.path, self.row_shape, self.rows = path, tuple(int(v) for v in row_shape), 0
+        with open(path, 'wb') as f:
+            f.write(self._header(0))
+
+    def _header(self, n):
+        d = "{'descr': '<f8', 'fortran_order': False, 'shape': %s, }" % (repr((n,) + self.row_shape),)
+        body = self.HEADER_BYTES - 10
+        assert len(d) < body
+        return b'\x93NUMPY\x01\x00' + np.uint16(body).tobytes() + (d + ' ' * (body - 1 - len(d)) + '\n').encode('latin1')
+
+    def sync(self, rows):
+        """`rows`: the complete sequence so far (list of rows or array); rows beyond those already on disk are appended"""
+        n = len(rows)
+        if n > self.rows:
+            new = np.ascontiguousarray(np.asarray(rows[self.rows:n], dtype=np.float64)).reshape((n - self.rows,) + self.row_shape)
+            with open(self.path, 'r+b') as f:
+                f.seek(0, 2)
+                f.write(new.tobytes())
+                f.seek(0)
+                f.write(self._header(n))
+            self.rows = n
+
+
+def write_rows_e5(path, rows, header=''):
+    """np.savetxt(path, rows, fmt='%.5E', header=header, comments='#') -- the chain-file format of Sampler._save_samples
+    (sampler.py:494-511) -- with the rows formatted by the native library (nnest_format_rows_e5: snprintf on a few host threads;
+    np.savetxt formats row by row in Python, 1.8 s for a 2e5 x 52 chain)."""
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    if rows.ndim == 1:
+        rows = rows[:, None]
+    try:
+        from . import _lib
+        import ctypes
+        lib = _lib.load()
+        cap = 14 * rows.size + 1
+        buf = ctypes.create_string_buffer(cap)
+        n = lib.nnest_format_rows_e5(rows.ctypes.data_as(ctypes.c_void_p), rows.shape[0], rows.shape[1], buf, cap, 8)
+        if n < 0:
+            raise ValueError('nnest_format_rows_e5')
+        with open(path, 'wb') as f:
+            if header:
+                f.write(('#' + header + '\n').encode())
+            f.write(memoryview(buf)[:n])
+    except (OSError, AttributeError, ValueError, RuntimeError):   # no native library at hand (a pure-host use of the driver)
+        np.savetxt(path, rows, fmt='%.5E', header=header, comments='#')

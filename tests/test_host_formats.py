@@ -105,3 +105,35 @@ def test_resume_from_a_reference_written_checkpoint(tmp_path):
     assert len(s.loglikes) == s.niter - 1 + 100 and np.array_equal(s.loglikes[:it], cps['saved_logl'])
     # 11 more iterations of 691 happen here; the evidence is essentially the reference's (-6.0258)
     assert abs(s.logz - meta['final_logz']) < 0.05, (s.logz, meta['final_logz'])
+
+
+def test_chain_text_writer_is_savetxt_byte_for_byte(tmp_path):
+    """Sampler._save_samples (sampler.py:494-511) writes np.savetxt(fmt='%.5E'); the native formatter behind it
+    (nnest_format_rows_e5, nnest_amd/utils.write_rows_e5) has to produce the same bytes: magnitudes across the float64 range,
+    negative zero, infinities, NaN, values that round up a decade, a header line."""
+    from nnest_amd.utils import write_rows_e5
+    rng = np.random.RandomState(3)
+    a = rng.standard_normal((6000, 7)) * np.exp(rng.uniform(-300, 300, size=(6000, 7)))
+    a[5, 3] = np.nan; a[6, 2] = np.inf; a[7, 1] = -np.inf; a[8, 0] = 0.0; a[9, 0] = -0.0; a[10, 0] = 1e-300
+    a[11, 1] = 9.999995e5; a[12, 2] = 9.9999949e5; a[13, 3] = 1e-30; a[14, 4] = 5e-324
+    for header in ('', 'weight minusloglike a b c d e'):
+        write_rows_e5(str(tmp_path / 'n.txt'), a, header=header)
+        np.savetxt(str(tmp_path / 's.txt'), a, fmt='%.5E', header=header, comments='#')
+        assert open(str(tmp_path / 'n.txt'), 'rb').read() == open(str(tmp_path / 's.txt'), 'rb').read()
+
+
+def test_growing_npy_is_a_valid_npy_after_every_sync(tmp_path):
+    """the checkpoint's saved_v / saved_logl / saved_logwt (nested.py:479-481) grow by appended rows; np.load -- what the
+    reference's resume does (nested.py:191-193) -- reads them at any point"""
+    from nnest_amd.utils import GrowingNpy
+    g = GrowingNpy(str(tmp_path / 'v.npy'), (3,))
+    s = GrowingNpy(str(tmp_path / 'l.npy'), ())
+    rows, vals = [], []
+    assert np.load(str(tmp_path / 'v.npy')).shape == (0, 3) and np.load(str(tmp_path / 'l.npy')).shape == (0,)
+    for k in range(1, 40):
+        rows += [np.arange(3) + 10.0 * k + j for j in range(k % 5)]
+        vals += [float(k)] * (k % 3)
+        g.sync(rows)
+        s.sync(vals)
+        assert np.array_equal(np.load(str(tmp_path / 'v.npy')), np.array(rows).reshape(-1, 3))
+        assert np.array_equal(np.load(str(tmp_path / 'l.npy')), np.array(vals))
