@@ -128,6 +128,15 @@ def logz_report(dev, live_run):
                    gpu_seeds=len(gv))
         out['delta'] = out['gpu_mean'] - out['cpu_mean']
         out['combined_stderr'] = float(np.hypot(out['gpu_stderr'] or 0.0, out['cpu_stderr'] or 0.0))
+        # "resolved": the ensembles can tell a difference of 0.2 from 0 at three standard errors, and they agree within 0.1
+        out['resolved'] = bool(out['combined_stderr'] <= 0.07 and abs(out['delta']) <= 0.1)
+        out['step_rule'] = g.get('step_rule')
+        lag0_p = os.path.join(ROOT, 'tests', 'golden', 'logz_gpu_cfg2_lag0.json')
+        if os.path.exists(lag0_p):   # the reference's exact step rule (lag 0) on the GPU path
+            with open(lag0_p) as f:
+                g0 = np.array(json.load(f)['logz'])
+            out['gpu_lag0'] = {'mean': float(g0.mean()), 'stderr': se(g0), 'seeds': len(g0), 'delta_vs_cpu': float(g0.mean() - out['cpu_mean']),
+                               'combined_stderr': float(np.hypot(se(g0) or 0.0, out['cpu_stderr'] or 0.0))}
     # config 3 (GaussianMix x_dim 20, 2000 live points): one run scatters by 0.11 only, so there the +-0.1 criterion is resolved
     c3, g3 = os.path.join(ROOT, 'tests', 'golden', 'logz_cpu_cfg3.json'), os.path.join(ROOT, 'tests', 'golden', 'logz_gpu_cfg3.json')
     if os.path.exists(c3) and os.path.exists(g3):
@@ -155,7 +164,7 @@ def logz_report(dev, live_run):
         out['live_run'] = {'logz': float(s.logz), 'logzerr': float(s.logzerr), 'wall_s': time.time() - t0, 'ncall': int(s.ncall),
                            'seed': 0, 'delta_vs_cpu_mean': (float(s.logz) - out['cpu_mean']) if 'cpu_mean' in out else None}
     out['note'] = ('independent noise streams: one run scatters by logzerr ~ sqrt(H/N) ~ 0.43 around the ensemble mean; the '
-                   '+-0.1 statement is on the means (tests/test_gpu_nested.py::test_logz_cfg2_gpu_vs_cpu)')
+                   '+-0.1 statement is on the means (tests/test_gpu_nested.py::test_committed_logz_fixtures_resolve_the_acceptance)')
     return out
 
 
@@ -389,6 +398,37 @@ def main():
                     torch.cuda.synchronize(dev)
                     best = min(best, (time.perf_counter() - t0) / max(1, res['epochs_run']) * 1e3)
                 out['spline_flow']['train_ms_per_epoch'] = best
+        if world == 1 and dist is None and not args.bare and args.config in (2, 5):
+            # the same workload on the build-defined MAF (BASELINE config 5 names it): reported beside, never
+            # as `value`.  Its inverse -- the direction the proposals need -- is `num_groups` passes of the nets per block
+            # (DESIGN.md 3c), so its evals/s sit that factor below the RealNVP's in the same (image) kernel form.
+            from nnest_amd.maf import HipMAF
+            mf = HipMAF(D, H, B, L, device=dev, seed=0)
+            zmf, _ = mf.forward(u0)
+            Sm = min(S, 50)   # (a bounded sample of the S-step launch: the kernel is a loop of identical steps)
+            t_ms = []
+            for k in range(3):
+                zz, ll = zmf.clone(), logl0.clone()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                mf.mh_steps(LIKE_ID[like], scale, zz, ll, loglstar, step_size, Sm, dynamic='group', seed=7 + k)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                t_ms.append(e0.elapsed_time(e1))
+            ms = float(np.median(t_ms[1:]))
+            nvm = min(C, 1000) // 10
+            Xm = u0[:min(C, 1000)]
+            perms = torch.stack([torch.randperm(Xm.shape[0] - nvm) for _ in range(3)])
+            t0 = time.perf_counter()
+            resm = mf.train_epochs(Xm[nvm:], Xm[:nvm], perms, None, seed=1, jitter=0.01, batch=100, max_epochs=3, patience=50)
+            torch.cuda.synchronize(dev)
+            out['maf_flow'] = {'kernel': 'maf_mh_kernel (image form, grouped sequential inverse)', 'num_groups': mf.num_groups,
+                               'walkers': C, 'mcmc_steps_timed': Sm, 'kernel_ms': ms, 'evals_per_s': C * Sm / (ms * 1e-3),
+                               'train_ms_per_epoch': (time.perf_counter() - t0) / max(1, resm['epochs_run']) * 1e3,
+                               'train_what': 'host-driven epoch loop (loss_grad + adam_step per minibatch), %d points' % Xm.shape[0],
+                               'note': 'UNPINNED: the reference has no MAF (nnest/trainer.py:83-100); parity is against the oracle '
+                                       'restatement of the build-defined flow (tests/test_gpu_maf.py)'}
         if world == 1 and dist is None and args.config == 2 and not args.bare:
             # K5 beside K4: the NVP training epoch at this population
             nv = C // 10

@@ -347,8 +347,12 @@ struct ImageInverse {
     }
 };
 
-template <int NT, int NH, int LT, bool WLDS, bool DBG>
-__global__ void __launch_bounds__(512, 3) mh_kernel(MhArgs a) {  // >= 3 waves/SIMD: the chains of one wave hide behind the others
+// WIDE: up to eight waves per workgroup, >= 3 waves per SIMD (the chains of one wave hide behind the others; <= 170 registers).
+// !WIDE: at most two waves per workgroup, one wave per SIMD and the whole register file -- populations of a few tiles per CU at
+// 3-4 tiles per class (x_dim > 64), where the proposal state alone is ~160 registers and the 170-register budget spilled
+// 400-540 of them (BASELINE config 5 on ONE GPU: 500 tiles on 256 CUs).
+template <int NT, int NH, int LT, bool WLDS, bool DBG, bool WIDE = true>
+__global__ void __launch_bounds__(WIDE ? 512 : 128, WIDE ? 3 : 1) mh_kernel(MhArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_img[];
     const float *img = a.img;
     if (WLDS) {
@@ -738,6 +742,14 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
     pick_geometry(ntiles, num_cu, 8, &block, &grid);
     const size_t img_bytes = (size_t)a.s.image_floats * 4;
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
+    if constexpr (NT >= 3) {
+        if (block <= 128 && img_bytes <= (size_t)LDS_IMAGE_LIMIT && !dbg) {   // few tiles per CU: the one-wave-per-SIMD build
+            hipError_t e = allow_lds(mh_kernel<NT, NH, LT, true, false, false>, img_bytes);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((mh_kernel<NT, NH, LT, true, false, false>), dim3(grid), dim3(block), img_bytes, st, a);
+            return hipGetLastError();
+        }
+    }
     if (img_bytes <= (size_t)LDS_IMAGE_LIMIT) {
         if (dbg) {
             hipError_t e = allow_lds(mh_kernel<NT, NH, LT, true, true>, img_bytes);

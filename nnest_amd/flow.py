@@ -163,8 +163,8 @@ class _HipFlow(object):
         C = z.shape[0]
         dev = self.device
         x = torch.empty_like(z)
-        n_acc = torch.zeros(C, dtype=torch.int32, device=dev)
-        n_call = torch.zeros(C, dtype=torch.int32, device=dev)
+        n_acc = torch.empty(C, dtype=torch.int32, device=dev)    # (every form writes both counters of every walker: no fill launches
+        n_call = torch.empty(C, dtype=torch.int32, device=dev)   # in front of the kernel)
         ngroups = (C + 15) // 16
         scale_out = torch.empty(max(ngroups, 1), dtype=torch.float32, device=dev)
         hx = torch.empty(C, steps + 1, self.D, dtype=torch.float32, device=dev) if history else None

@@ -341,27 +341,49 @@ def _cpu_fixture(cfg):
         return json.load(f)
 
 
+def _fixture(kind, cfg):
+    with open(os.path.join(G, 'logz_%s_cfg%d.json' % (kind, cfg))) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('cfg', [1, 2, 3])
+def test_committed_logz_fixtures_resolve_the_acceptance(cfg):
+    """BASELINE's acceptance "log Z within +-0.1 of the CPU reference" on the committed ensembles (CPU path:
+    oracle/run_logz_cpu.py; GPU path: tools/run_logz_gpu.py; unpaired means over every seed each fixture holds): the means
+    agree within 0.1 AND the comparison has the resolution to say so -- combined standard error <= 0.07, i.e. a true
+    difference of 0.2 would stand out by three standard errors."""
+    c, g = np.array(_fixture('cpu', cfg)['logz']), np.array(_fixture('gpu', cfg)['logz'])
+    se = float(np.hypot(c.std(ddof=1) / np.sqrt(len(c)), g.std(ddof=1) / np.sqrt(len(g))))
+    delta = float(g.mean() - c.mean())
+    print('config %d: cpu %.3f (%d seeds), gpu %.3f (%d seeds), delta %.3f +- %.3f' % (cfg, c.mean(), len(c), g.mean(), len(g), delta, se))
+    assert se <= 0.07, se
+    assert abs(delta) <= 0.1, delta
+
+
 @pytest.mark.parametrize('cfg', [1, 2, 3])
 def test_logz_gpu_vs_cpu(tmp_path, cfg):
-    """BASELINE's acceptance: log Z of the GPU path against the CPU path (the host driver on the oracle-backed trainer,
-    oracle/run_logz_cpu.py -> tests/golden/logz_cpu_cfg<cfg>.json) for the same configuration, the same run() arguments and
-    the same list of seeds.  The two paths draw from different noise streams, so a run is an independent estimate with scatter
-    ~ sqrt(H/N) (0.2 at config 1, 0.45 at config 2, 0.12 at config 3); the comparison is between the MEANS over the seeds:
-    |mean_gpu - mean_cpu| <= max(0.1, 2 combined standard errors), standard errors from the samples themselves."""
-    ref = _cpu_fixture(cfg)
+    """The GPU path re-run live (twelve seeds) against the FULL CPU-path fixture (the host driver on the oracle-backed trainer,
+    oracle/run_logz_cpu.py -> tests/golden/logz_cpu_cfg<cfg>.json; same configuration and run() arguments).  The two paths
+    draw from different noise streams, so a run is an independent estimate with scatter ~ sqrt(H/N) (0.2 at config 1, 0.45 at
+    config 2, 0.12 at config 3).  Twelve live runs cannot resolve +-0.1 at config 2 by themselves (their mean scatters by
+    0.18) -- that is the committed fixtures' job, test above; this test holds the live code to the fixtures: the live mean
+    within three standard errors of its own sample from the CPU ensemble's mean, and from the committed GPU ensemble's."""
+    ref, gfix = _fixture('cpu', cfg), _fixture('gpu', cfg)
     like = {'Rosenbrock': Rosenbrock, 'GaussianMix': GaussianMix}[ref['likelihood']](ref['x_dim'])
     scale = {'Rosenbrock': 5.0, 'GaussianMix': 10.0}[ref['likelihood']]
-    seeds = ref['seeds'][:12]   # (the fixtures may hold more: twelve runs bound the test's time)
-    cpu = np.array([r['logz'] for r in ref['runs'] if r['seed'] in seeds])
+    seeds = ref['seeds'][:12]
+    cpu, gcommitted = np.array(ref['logz']), np.array(gfix['logz'])
     gpu = []
     for seed in seeds:
         s = run(tmp_path / str(seed), ref['x_dim'], like, scale, ref['num_live_points'], seed, mcmc_num_chains=ref['mcmc_num_chains'])
         gpu.append(s.logz)
     gpu = np.array(gpu)
-    se = float(np.hypot(gpu.std(ddof=1) / np.sqrt(len(gpu)), cpu.std(ddof=1) / np.sqrt(len(cpu))))
+    se_live = float(gpu.std(ddof=1) / np.sqrt(len(gpu)))
+    se = float(np.hypot(se_live, cpu.std(ddof=1) / np.sqrt(len(cpu))))
     delta = float(gpu.mean() - cpu.mean())
-    print('config %d: gpu %.3f +- %.3f, cpu %.3f +- %.3f, delta %.3f, combined standard error %.3f (%d seeds)' % (
-        cfg, gpu.mean(), gpu.std(ddof=1) / np.sqrt(len(gpu)), cpu.mean(), cpu.std(ddof=1) / np.sqrt(len(cpu)), delta, se, len(seeds)))
-    assert abs(delta) <= max(0.1, 2 * se), (delta, se)
-    # and the run-to-run scatter is the same on both sides (within a factor: 6-16 samples)
+    print('config %d: live gpu %.3f +- %.3f (%d seeds), cpu fixture %.3f (%d seeds), delta %.3f +- %.3f; committed gpu %.3f' % (
+        cfg, gpu.mean(), se_live, len(seeds), cpu.mean(), len(cpu), delta, se, gcommitted.mean()))
+    assert abs(delta) <= 3 * se, (delta, se)
+    assert abs(float(gpu.mean() - gcommitted.mean())) <= 3 * float(np.hypot(se_live, gcommitted.std(ddof=1) / np.sqrt(len(gcommitted))))
+    # and the run-to-run scatter is the same on both sides (within a factor: 12 samples)
     assert 0.4 < gpu.std(ddof=1) / cpu.std(ddof=1) < 2.5

@@ -1,6 +1,7 @@
 """GPU-path log Z of a BASELINE configuration over a list of seeds -> gpurun_out/logz_gpu_cfg<cfg>.json (copied to
 tests/golden/ and read by bench.py's `logz` report; the CPU-path counterpart is oracle/run_logz_cpu.py).
-  python tools/run_logz_gpu.py 2 0,1,2,3,4,5 [lag]      lag: NNEST_MH_LAG of the batch-wide step rule (default: the product's)"""
+  python tools/run_logz_gpu.py 2 0,1,2,3,4,5 [lag] [tag]      lag: NNEST_MH_LAG of the batch-wide step rule ('-' or absent: the product's
+                                                               default); tag: suffix of the output file; seeds may be a range a:b"""
 import json
 import os
 import sys
@@ -17,9 +18,11 @@ from nnest_amd.nested import NestedSampler  # noqa: E402
 
 CONFIGS = {1: ('Rosenbrock', 2, 5.0, 100), 2: ('Rosenbrock', 50, 5.0, 1000), 3: ('GaussianMix', 20, 10.0, 2000)}
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-seeds = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else '0,1,2,3,4,5').split(',')]
+_sd = sys.argv[2] if len(sys.argv) > 2 else '0,1,2,3,4,5'
+seeds = list(range(*[int(v) for v in _sd.split(':')])) if ':' in _sd else [int(v) for v in _sd.split(',')]
 name, D, scale, N = CONFIGS[cfg]
-lag = int(sys.argv[3]) if len(sys.argv) > 3 else None
+lag = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != '-' else None
+tag = sys.argv[4] if len(sys.argv) > 4 else ''
 runs = []
 for seed in seeds:
     np.random.seed(seed)
@@ -38,6 +41,6 @@ doc = dict(what='GPU-path log Z: nnest_amd.NestedSampler on the HIP kernels (too
            seeds=seeds, logz=z.tolist(), mean=float(z.mean()), std=float(z.std(ddof=1)) if len(z) > 1 else None,
            stderr=float(z.std(ddof=1) / np.sqrt(len(z))) if len(z) > 1 else None, runs=runs)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-with open(os.path.join(ROOT, 'gpurun_out', 'logz_gpu_cfg%d%s.json' % (cfg, '' if lag is None else '_lag%d' % lag)), 'w') as f:
+with open(os.path.join(ROOT, 'gpurun_out', 'logz_gpu_cfg%d%s%s.json' % (cfg, '' if lag is None else '_lag%d' % lag, tag)), 'w') as f:
     json.dump(doc, f, indent=1)
 print('mean %.3f  std %.3f  stderr %.3f' % (doc['mean'], doc['std'] or 0, doc['stderr'] or 0))
