@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 12
+#define NNEST_HIP_ABI_VERSION 13
 
 enum {
     NNEST_OK = 0,
@@ -73,6 +73,12 @@ enum {
                                  * Needs every workgroup resident: NNEST_E_UNSUPPORTED beyond ~16 walkers x 8 x CUs */
 };
 #define NNEST_MH_LAG(n) (((n) & 15) << 8)
+/* flags bits 20..27, with NNEST_MH_DYNAMIC_BATCH and lag >= 1: the first n steps of the launch apply the rule EXACTLY (lag 0, a
+ * grid-wide wait on each of them) and only the steps after them run `lag` behind: votes 1..n are applied as the reference
+ * applies them, the votes of the steps s > n from step s + 1 + lag on.  The rule's gain is 1 / (1 + votes) and every launch
+ * starts from the caller's step_size, so the early votes are the ones that move the scale.  Kernel forms that do not implement
+ * it return NNEST_E_UNSUPPORTED (nnest_mh_form_for tells). */
+#define NNEST_MH_WARM(n) (((n) & 255) << 20)
 /* flags bits 16..19: pin the kernel form (0 = by population).  A caller that shards ONE batch over ranks pins the form the
  * whole batch would get, so that a shard reproduces the slice of the unsharded run bit for bit. */
 enum { NNEST_MH_FORM_AUTO = 0, NNEST_MH_FORM_IMAGE = 1, NNEST_MH_FORM_REG = 2, NNEST_MH_FORM_TEAM = 3, NNEST_MH_FORM_QUAD = 4,
@@ -235,7 +241,7 @@ int nnest_nvp_loss_grad(nnest_nvp_t *nvp, const float *x_dev, int M, float *grad
 int nnest_nvp_vjp(nnest_nvp_t *nvp, const float *x_dev, const float *gz_dev, float gld, int M, float *grad_dev, float *gx_dev,
                   void *stream);
 /* one torch.optim.Adam step (coupled weight decay, trainer.py:121-122) from a gradient computed outside nnest_nvp_train;
- * uses and advances the handle's Adam state; synchronises `stream` */
+ * uses and advances the handle's Adam state (the step counter lives on the device: asynchronous on `stream`, like the passes) */
 int nnest_nvp_adam_step(nnest_nvp_t *nvp, const float *grad_dev, float lr, float weight_decay, void *stream);
 
 /* training jitter when jitter < 0 (trainer.py:168-171): 0.2 * mean of the 2-nearest-neighbour distance

@@ -23,20 +23,22 @@ MH_DYNAMIC_BATCH = 4     # over the whole launch, as the reference (sampler.py:4
 MH_FORMS = {None: 0, 'auto': 0, 'image': 1, 'reg': 2, 'team': 3, 'quad': 4, 'quad1': 5, 'solo': 6}
 MH_FORM_NAMES = {v: k for k, v in MH_FORMS.items() if isinstance(k, str) and v}
 MH_DEFAULT_LAG = 4      # steps between a step and the scale that reflects its batch-wide count
+MH_WARM_STEPS = 16      # exact steps in front of the lagged rule where the form implements them (NNEST_MH_WARM)
 MH_SOLO_LAG = 8         # ... where the solo form runs (its steps are shorter: the same ~10 us of latency)
 TRAIN_RESUME = 1
 TRAIN_FINALIZE = 2
 TRAIN_ONE_CU = 4
 
 
-def mh_flags(dynamic=False, free=False, lag=None, form=None):
+def mh_flags(dynamic=False, free=False, lag=None, form=None, warm=0):
     """flags word of nnest_mh_constrained_steps.  dynamic: False | True / 'batch' (the reference's batch-wide rule) |
-    'group' (per 16 walkers)"""
+    'group' (per 16 walkers); warm: NNEST_MH_WARM, exact steps in front of a lagged batch rule"""
     fl = MH_UNCONSTRAINED if free else 0
     if dynamic == 'group':
         fl |= MH_DYNAMIC_STEP
     elif dynamic:
         fl |= MH_DYNAMIC_BATCH | ((MH_DEFAULT_LAG if lag is None else int(lag)) & 15) << 8
+        fl |= (min(int(warm or 0), 255) & 255) << 20
     return fl | (MH_FORMS[form] << 16)
 
 

@@ -18,6 +18,7 @@ namespace nnest {
 enum { MH_FORM_AUTO = 0, MH_FORM_IMAGE = 1, MH_FORM_REG = 2, MH_FORM_TEAM = 3, MH_FORM_QUAD = 4, MH_FORM_QUAD1 = 5, MH_FORM_SOLO = 6 };
 __host__ __device__ inline int mh_flag_lag(int flags) { return (flags >> 8) & 15; }
 __host__ __device__ inline int mh_flag_form(int flags) { return (flags >> 16) & 15; }
+__host__ __device__ inline int mh_flag_warm(int flags) { return (flags >> 20) & 255; }   // NNEST_MH_WARM
 
 // Batch-wide step-size adaptation (sampler.py:422-431 over ALL walkers of the launch).  One 64-bit word per (step, shard):
 // every workgroup adds (1 << 32 | accepted walkers of its tile) once per step; a step's total is complete when the

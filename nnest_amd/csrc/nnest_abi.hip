@@ -427,14 +427,8 @@ int nnest_nvp_vjp(nnest_nvp_t *h, const float *x_dev, const float *gz_dev, float
 int nnest_nvp_adam_step(nnest_nvp_t *h, const float *grad_dev, float lr, float weight_decay, void *stream) {
     if (!h || !grad_dev) return fail(NNEST_E_ARG, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    int step = 0;
-    HIP_TRY(hipMemcpyAsync(&step, h->adam_step, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    step += 1;
-    HIP_TRY(launch_adam_packed(h->w, grad_dev, h->adam_m, h->adam_v, h->num_params, step, lr, weight_decay, st));
-    HIP_TRY(hipMemcpyAsync(h->adam_step, &step, sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(launch_adam_packed_dev(h->w, grad_dev, h->adam_m, h->adam_v, h->num_params, h->adam_step, lr, weight_decay, st));
     HIP_TRY(refresh_images(h, st));
-    HIP_TRY(hipStreamSynchronize(st));
     return NNEST_OK;
 }
 

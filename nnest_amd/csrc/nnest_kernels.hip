@@ -347,12 +347,15 @@ struct ImageInverse {
     }
 };
 
-// WIDE: up to eight waves per workgroup, >= 3 waves per SIMD (the chains of one wave hide behind the others; <= 170 registers).
-// !WIDE: at most two waves per workgroup, one wave per SIMD and the whole register file -- populations of a few tiles per CU at
-// 3-4 tiles per class (x_dim > 64), where the proposal state alone is ~160 registers and the 170-register budget spilled
-// 400-540 of them (BASELINE config 5 on ONE GPU: 500 tiles on 256 CUs).
-template <int NT, int NH, int LT, bool WLDS, bool DBG, bool WIDE = true>
-__global__ void __launch_bounds__(WIDE ? 512 : 128, WIDE ? 3 : 1) mh_kernel(MhArgs a) {
+// OCC = waves per SIMD the build is compiled for (its register budget): 3 -- up to eight waves per workgroup, <= 168 registers,
+// the chains of one wave hide behind the others (chip-filling populations at <= 2 tiles per class; 61-118 spilled registers
+// there, and still 5 % faster at 131 072 walkers than the spill-free OCC 2 build); 2 -- <= 256 registers, no spills at <= 2 tiles
+// per class; 1 -- at most two waves per workgroup and the whole register file: 3-4 tiles per class (x_dim > 64), where the
+// proposal state alone is ~160 registers (BASELINE config 5 on ONE GPU: 500 tiles on 256 CUs; 0 spills against 396).
+// Measured (profiles/r03/k4_image_occupancy_d{50,100}.txt): x_dim 100 -- OCC 1 9.1 us per step at 8000 walkers (OCC 3: 13.2),
+// OCC 2 best from 32 768 walkers on (1.98e9 evals/s at 131 072 against 1.70e9 / 1.31e9); x_dim 50 -- OCC 2 and 3 within 5 %.
+template <int NT, int NH, int LT, bool WLDS, bool DBG, int OCC = 3>
+__global__ void __launch_bounds__(OCC == 1 ? 128 : 512, OCC) mh_kernel(MhArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_img[];
     const float *img = a.img;
     if (WLDS) {
@@ -683,6 +686,7 @@ static int pick_mh_form(const MhArgs &a, int num_cu) {
     const bool batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;
     if ((form == MH_FORM_AUTO || form == MH_FORM_SOLO) && solo_form_eligible(a, num_cu)) return MH_FORM_SOLO;
     if (form == MH_FORM_SOLO) return -1;
+    if (batch && mh_flag_lag(a.flags) > 0 && mh_flag_warm(a.flags) > 0) return -1;   // exact warm-up steps in front of a lagged rule: the solo form only
     if ((form == MH_FORM_AUTO || form == MH_FORM_QUAD || form == MH_FORM_QUAD1) && quad_form_eligible(a, num_cu))
         return form == MH_FORM_QUAD1 ? MH_FORM_QUAD1 : MH_FORM_QUAD;
     if (form == MH_FORM_QUAD || form == MH_FORM_QUAD1) return -1;
@@ -742,13 +746,24 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
     pick_geometry(ntiles, num_cu, 8, &block, &grid);
     const size_t img_bytes = (size_t)a.s.image_floats * 4;
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
+    static const int occ_env = [] { const char *e = getenv("NNEST_MH_OCC"); return e ? atoi(e) : 0; }();   // diagnostic: pin the build
     if constexpr (NT >= 3) {
-        if (block <= 128 && img_bytes <= (size_t)LDS_IMAGE_LIMIT && !dbg) {   // few tiles per CU: the one-wave-per-SIMD build
-            hipError_t e = allow_lds(mh_kernel<NT, NH, LT, true, false, false>, img_bytes);
+        // (under the batch-wide rule every workgroup has to be resident: two 2-wave workgroups per CU need two LDS images)
+        const bool fits = block <= 128 || !batch || 2 * img_bytes + 8192 <= (size_t)160 * 1024;
+        if (((ntiles <= 4 * num_cu && occ_env == 0 && fits) || occ_env == 1) && img_bytes <= (size_t)LDS_IMAGE_LIMIT && !dbg) {   // <= one tile per SIMD: the one-wave-per-SIMD build
+            hipError_t e = allow_lds(mh_kernel<NT, NH, LT, true, false, 1>, img_bytes);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((mh_kernel<NT, NH, LT, true, false, false>), dim3(grid), dim3(block), img_bytes, st, a);
+            if (block > 128) { block = 128; grid = (ntiles + 1) / 2; }
+            hipLaunchKernelGGL((mh_kernel<NT, NH, LT, true, false, 1>), dim3(grid), dim3(block), img_bytes, st, a);
             return hipGetLastError();
         }
+    }
+    // two waves per SIMD: everything else at 3-4 tiles per class; at <= 2 tiles per class up to 16 tiles per CU
+    if ((occ_env == 2 || (occ_env == 0 && (NT >= 3 || ntiles <= 16 * num_cu))) && img_bytes <= (size_t)LDS_IMAGE_LIMIT && !dbg) {
+        hipError_t e = allow_lds(mh_kernel<NT, NH, LT, true, false, 2>, img_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((mh_kernel<NT, NH, LT, true, false, 2>), dim3(grid), dim3(block), img_bytes, st, a);
+        return hipGetLastError();
     }
     if (img_bytes <= (size_t)LDS_IMAGE_LIMIT) {
         if (dbg) {

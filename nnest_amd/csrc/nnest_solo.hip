@@ -325,6 +325,7 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     __shared__ float ubuf[2][4];
     __shared__ int acc_lds[2][4];   // batch rule: the four walkers' accepts of a step, posted by the noise wave
     __shared__ float fsbuf[2];      // the proposal scale that goes with a noise buffer
+    __shared__ float fs_exact;      // warm-up steps of the batch rule: the scale of the next step, known only after this step's votes
     __shared__ double etab[SOLO_ETAB];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -334,11 +335,14 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     const bool dynamic = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;  // the per-16-walker rule belongs to the 16-walker forms
     const bool use_tab = S + 2 <= SOLO_ETAB;
     const int lag = mh_flag_lag(a.flags);                          // >= 3 (solo_form_eligible): the rule is always relayed
+    // the first `warm` steps apply the rule exactly (lag 0: a grid-wide wait per step) -- where its gain 1 / (1 + n) is large and
+    // the scale still far from where it settles -- the rest `lag` steps behind (mh_common.h); at most S - 1
+    const int warm = dynamic ? min(mh_flag_warm(a.flags), S - 1) : 0;
     const int ntiles = (C + 3) >> 2;
     if (tile >= ntiles) {
         // batch-wide step rule (mh_common.h): the one workgroup behind the tiles sums every step's counters as soon as they
         // are complete and publishes the total; its other waves leave at once
-        if (dynamic && wave == 0) mh_sync_publisher(a.sync, S, S - lag, ntiles, C, lane, a.sync_err);
+        if (dynamic && wave == 0) mh_sync_publisher(a.sync, S, max(S - lag, warm), ntiles, C, lane, a.sync_err);
         return;
     }
     {
@@ -376,7 +380,7 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
         {                                                                                                                   \
             const int k = (k_), want = k - lag;                                                                             \
             if (dynamic) {                                                                                                  \
-                if (want >= 1) {                                                                                            \
+                if (want > warm) {                                                                                          \
                     asm volatile("s_waitcnt vmcnt(2)" : "+v"(q_) : : "memory");                                             \
                     const bool up = mh_window_vote(a.sync, S, want, tile, q_, a.sync_err);                                  \
                     if (up) accept += 1; else reject += 1;                                                                  \
@@ -384,10 +388,11 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
                     if (accept < reject) scale /= use_tab ? etab[reject] : exp(1.0 / (1 + reject));                         \
                 }                                                                                                           \
                 /* between the barriers k - 1 and k the net waves run step k - 1: the accepts of step k - 2 are in LDS */   \
-                /* (k < 2: a zero to the unused slot of step 0, so that every iteration issues the same operations) */      \
+                /* (no step of its own to post: a zero to the unused slot of step 0 -- every iteration issues the same operations) */ \
                 if (lane == 0) {                                                                                            \
                     const int *ac = acc_lds[k & 1];                                                                         \
-                    mh_sync_post(a.sync, k >= 2 ? k - 2 : 0, tile, k >= 2 ? (ac[0] + ac[1]) + (ac[2] + ac[3]) : 0);         \
+                    const bool mine = k - 2 > warm; /* (the warm-up posted its steps itself) */                            \
+                    mh_sync_post(a.sync, mine ? k - 2 : 0, tile, mine ? (ac[0] + ac[1]) + (ac[2] + ac[3]) : 0);             \
                 }                                                                                                           \
                 const int ask = min(max(want + 2, 1), max(last, 1));   /* the window of the step needed two iterations on */  \
                 const unsigned long long *wp = wbase + (size_t)((ask - 1) >> 5) * MH_SYNC_SHARDS * MH_SYNC_STRIDE;          \
@@ -408,7 +413,42 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
             solo_barrier(); /* publish buffer k */                                                                          \
         }
         unsigned long long qa = 0, qb = 0;
-        for (int k2 = 0; k2 <= S; k2 += 2) {
+        int k0 = 0;
+        if (warm > 0) {
+            // warm-up: iteration k draws the noise of step k + 1 as always, then -- behind the net waves' step k - 1 (barrier A) --
+            // posts that step's accepts, waits for the batch's vote, applies it and hands over the scale of step k (barrier B)
+            for (int k = 0; k <= warm + 1; ++k) {
+                if (gen && !recorded) {
+                    float nz[U][8], u;
+                    rng.next(nz, u);
+#pragma unroll
+                    for (int t = 0; t < U; ++t)
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq) {
+                            const int d = 32 * t + 8 * g + qq;
+                            nbuf[k & 1][j][d / (2 * U)][d % (2 * U)] = nz[t][qq];
+                        }
+                    if (g == 0) ubuf[k & 1][j] = u;
+                }
+                if (k >= 2) {
+                    solo_barrier();   // A: the net waves have decided step k - 1
+                    if (lane == 0) {
+                        const int *ac = acc_lds[(k - 1) & 1];
+                        mh_sync_post(a.sync, k - 1, tile, (ac[0] + ac[1]) + (ac[2] + ac[3]));
+                    }
+                    const bool up = mh_window_vote(a.sync, S, k - 1, tile, 0ull, a.sync_err);
+                    if (up) accept += 1; else reject += 1;
+                    if (accept > reject) scale *= use_tab ? etab[accept] : exp(1.0 / (1 + accept));
+                    if (accept < reject) scale /= use_tab ? etab[reject] : exp(1.0 / (1 + reject));
+                    if (lane == 0) fs_exact = (float)scale;
+                }
+                if (lane == 0) fsbuf[k & 1] = (float)scale;
+                if (k >= 2) solo_barrier();   // B: the scale of step k
+                solo_barrier();               // publish buffer k
+            }
+            k0 = warm + 2;
+        }
+        for (int k2 = k0; k2 <= S; k2 += 2) {
             SOLO_NOISE_ITERATION(k2, qa)
             if (k2 + 1 <= S) SOLO_NOISE_ITERATION(k2 + 1, qb)
         }
@@ -554,6 +594,11 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
         ld = acc ? ldp : ld;
         logl = acc ? lp : logl;
         if (dynamic && lane == 0) acc_lds[it & 1][j] = acc ? 1 : 0;  // sampler.py:422-431: counted by the noise wave after the next barrier
+        if (it <= warm) {   // warm-up: the next step's scale exists only after this step's votes (noise wave, between A and B)
+            solo_barrier();
+            solo_barrier();
+            fs_next = fs_exact;
+        }
         STAMP(st3);
 #ifdef NNEST_STAMP
         a_prop += st1 - st0; a_inv += st2 - st1; a_post += st3 - st2; a_tot += st3 - st0;

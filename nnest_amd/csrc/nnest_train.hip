@@ -1047,6 +1047,30 @@ __global__ void adam_packed_kernel(float *__restrict__ w, const float *__restric
     }
 }
 
+// the same step with the step count on the DEVICE (the handle's counter, which the training kernels advance too): no read-back,
+// no stream synchronisation between the minibatches of a host-driven epoch loop.  Bias corrections as on the host (float64 pow).
+__global__ void adam_packed_dev_kernel(float *__restrict__ w, const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v, int n,
+                                       const int *__restrict__ step_dev, float lr, float wd) {
+    const int step = *step_dev + 1;
+    const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
+    const float step_size = (float)((double)lr / bc1), inv_bc2s = (float)(1.0 / sqrt(bc2));
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float gi = grad[i] + wd * w[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        w[i] = w[i] - step_size * (mi / (sqrtf(vi) * inv_bc2s + eps));
+    }
+}
+__global__ void adam_step_advance_kernel(int *step_dev) { *step_dev += 1; }
+
+hipError_t launch_adam_packed_dev(float *w, const float *grad, float *m, float *v, int n, int *step_dev, float lr, float wd, hipStream_t st) {
+    hipLaunchKernelGGL(adam_packed_dev_kernel, dim3(64), dim3(256), 0, st, w, grad, m, v, n, step_dev, lr, wd);
+    hipLaunchKernelGGL(adam_step_advance_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    return hipGetLastError();
+}
+
 hipError_t launch_adam_packed(float *w, const float *grad, float *m, float *v, int n, int step, float lr, float wd, hipStream_t st) {
     const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
     hipLaunchKernelGGL(adam_packed_kernel, dim3(64), dim3(256), 0, st, w, grad, m, v, n, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), wd);

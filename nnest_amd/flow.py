@@ -148,13 +148,14 @@ class _HipFlow(object):
         return x, ld, logl, inbox
 
     def mh_steps(self, like_id, like_scale, z, logl, loglstar, step_size, steps, dynamic=False, noise=None, seed=0,
-                 walker_offset=0, history=False, like_params=None, lag=None, form=None):
+                 walker_offset=0, history=False, like_params=None, lag=None, form=None, warm=None):
         """K4: `steps` constrained Metropolis steps for all walkers in one launch (Sampler._mcmc_sample,
         sampler.py:229-463).  z [C,D] float32 and logl [C] float64 are updated in place.
         noise = (dz [steps,C,D], u [steps,C]) replays recorded draws; None = in-kernel Philox.
         loglstar None / NaN = the unconstrained branch (sampler.py:371-410): likelihood and box prior in the ratio.
         dynamic: False | True or 'batch' (sampler.py:422-431 over all C walkers; `lag` steps between a step and the
         scale that reflects its count, 0 = the reference exactly) | 'group' (per 16 walkers, shard-invariant).
+        warm: with a lagged batch rule, the first `warm` steps apply it exactly (NNEST_MH_WARM); None = default_warm().
         form: None (by population) | 'solo' | 'quad' | 'team' | 'reg' | 'image' (include/nnest_hip.h NNEST_MH_FORM_*)."""
         free = loglstar is None or loglstar != loglstar
         loglstar = 0.0 if free else loglstar
@@ -176,7 +177,9 @@ class _HipFlow(object):
             assert dz.shape[0] == steps * C and u.numel() == steps * C
         if lag is None and dynamic in (True, 'batch'):
             lag = self.default_lag(C, form)
-        flags = _lib.mh_flags(dynamic, free, lag, form)
+        if warm is None:
+            warm = self.default_warm(C, dynamic, lag, form)
+        flags = _lib.mh_flags(dynamic, free, lag, form, warm)
         sync = None
         if flags & _lib.MH_DYNAMIC_BATCH:   # per-step batch counters, zeroed for every launch; last word = error flag
             sync = torch.zeros(self._lib.nnest_mh_sync_words(int(steps)), dtype=torch.int64, device=dev)
@@ -189,14 +192,14 @@ class _HipFlow(object):
                 _lib.ptr(n_call), _lib.ptr(scale_out), _lib.ptr(sync), _lib.current_stream(dev)))
         return dict(x=x, n_accept=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl, sync=sync)
 
-    def mh_form_for(self, C, dynamic=False, lag=None, free=False, form=None):
+    def mh_form_for(self, C, dynamic=False, lag=None, free=False, form=None, warm=0):
         """the K4 form (name) `mh_steps` runs for C walkers under this step rule -- asked of the library
         (nnest_mh_form_for), which knows the shapes each form is built for; None if the launch would be refused.  A caller
         that shards one batch over ranks asks for the WHOLE batch and pins the answer on every shard."""
         fn = getattr(self._lib, 'nnest_mh_form_for', None) if self._sym.get('mh') is getattr(self._lib, 'nnest_mh_constrained_steps', None) else None
         if fn is None:
             return None
-        f = fn(self._h, int(C), _lib.mh_flags(dynamic, free, lag, form))
+        f = fn(self._h, int(C), _lib.mh_flags(dynamic, free, lag, form, warm))
         return _lib.MH_FORM_NAMES.get(f)
 
     def default_lag(self, C, form=None):
@@ -207,6 +210,16 @@ class _HipFlow(object):
         if form == 'solo' or (form is None and self.mh_form_for(C, dynamic='batch', lag=_lib.MH_SOLO_LAG) == 'solo'):
             return _lib.MH_SOLO_LAG
         return _lib.MH_DEFAULT_LAG
+
+    def default_warm(self, C, dynamic, lag, form=None):
+        """exact steps in front of a lagged batch rule when the caller names none: MH_WARM_STEPS where the form that runs
+        implements them (the solo form), 0 elsewhere.  Every launch restarts the rule from the caller's step_size with gain
+        1 / (1 + votes): its first votes move the scale by e-folds, and a lag there is so many steps spent at the initial
+        scale."""
+        if dynamic not in (True, 'batch') or not lag:
+            return 0
+        w = _lib.MH_WARM_STEPS
+        return w if self.mh_form_for(C, dynamic='batch', lag=lag, form=form, warm=w) == 'solo' else 0
 
     @staticmethod
     def check_sync(res):

@@ -204,11 +204,15 @@ class NestedSampler(Sampler):
             rejection_cache_interval=10,
             rejection_enlargement_factor=1.1,
             rejection_trials=None,
-            mcmc_step_lag=None):
+            mcmc_step_lag=None,
+            mcmc_step_warm=None):
         # mcmc_step_lag (not in the reference): steps between an MCMC step and the proposal scale that reflects its batch-wide
         # accept count inside the HIP kernel; 0 = the reference's rule exactly (one grid-wide wait per step), None = the
         # default that keeps the wait off the step (include/nnest_hip.h NNEST_MH_LAG)
         self.mcmc_step_lag = mcmc_step_lag
+        # mcmc_step_warm (not in the reference): with a lagged rule, the first so many steps of every launch apply it exactly
+        # (NNEST_MH_WARM); None = the kernel form's default
+        self.mcmc_step_warm = mcmc_step_warm
         if strategy is None or len(strategy) == 0:
             strategy = ['rejection_prior', 'mcmc']
         for s in strategy:

@@ -271,6 +271,8 @@ class Sampler(object):
         lag = getattr(self, 'mcmc_step_lag', None)
         if lag is None and int(mcmc_steps) < 100:
             lag = 0   # short chains: the lag would be a sizeable part of the launch, and the exact rule costs microseconds here
+        if getattr(self, 'mcmc_step_warm', None) is not None:
+            kw['warm'] = int(self.mcmc_step_warm)
         try:
             res = netG.mh_steps(*args, dynamic=mode, lag=lag, **kw)
         except _lib.NnestHipError as e:

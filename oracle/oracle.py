@@ -320,7 +320,7 @@ def prior_inbox(x):
     return np.where(np.array(flag) == 1, 0.0, -np.inf)
 
 
-def mcmc_sample(nvp, like, like_scale, init, init_logl, loglstar, step, dynamic, dz, u, lag=0, margins=None):
+def mcmc_sample(nvp, like, like_scale, init, init_logl, loglstar, step, dynamic, dz, u, lag=0, margins=None, warm=0):
     """Sampler._mcmc_sample hard-constraint branch (nnest/sampler.py:229-463) with recorded noise.
     Returns the reference's tuple pieces: samples, latent, loglikes, scale, ncall, (acc, rej).
     lag > 0: build-defined variant of the step-size rule -- the update after step `it` uses the accepted count of step
@@ -337,6 +337,7 @@ def mcmc_sample(nvp, like, like_scale, init, init_logl, loglstar, step, dynamic,
     lib().orc_set_scale_mode(SCALE_MODES[nvp.scale])
     lib().orc_set_flow_kind(1 if getattr(nvp, 'kind', 'nvp') == 'maf' else 0)
     lib().orc_set_step_lag(int(lag))
+    lib().orc_set_step_warm(int(warm))   # first `warm` steps exact in front of the lagged ones (NNEST_MH_WARM)
     if margins is not None:
         assert margins.shape == (S, C) and margins.dtype == np.float64 and margins.flags['C_CONTIGUOUS']
         lib().orc_set_margin_out(_p(margins, _dp))
@@ -346,6 +347,7 @@ def mcmc_sample(nvp, like, like_scale, init, init_logl, loglstar, step, dynamic,
                                   _p(u, _fp), _p(samples, _fp), _p(latent, _fp), _p(loglikes, _dp),
                                   ctypes.byref(acc), ctypes.byref(rej))
     lib().orc_set_step_lag(0)
+    lib().orc_set_step_warm(0)
     lib().orc_set_margin_out(None)
     return samples, latent, loglikes, scale.value, ncall, (acc.value, rej.value)
 

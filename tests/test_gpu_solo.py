@@ -129,10 +129,12 @@ def test_solo_shapes_and_likelihoods_vs_oracle(hip, D, like, scale):
         assert rel(hx[same], so[same]) < 5e-5
 
 
-@pytest.mark.parametrize('C,lag', [(1000, 3), (1000, 4), (333, 5), (1017, 8), (64, 15)])
-def test_solo_batch_wide_step_rule_vs_oracle(hip, C, lag):
-    """NNEST_MH_DYNAMIC_BATCH relayed by the noise wave: the accept count is taken over the WHOLE launch, `lag` steps behind.
-    The oracle runs the whole batch with the same lag: same scale sequence, same chains."""
+@pytest.mark.parametrize('C,lag,warm', [(1000, 3, 0), (1000, 4, 0), (333, 5, 0), (1017, 8, 0), (64, 15, 0), (1000, 8, 16), (333, 3, 1),
+                                        (1017, 8, 39), (500, 5, 200), (64, 15, 7)])
+def test_solo_batch_wide_step_rule_vs_oracle(hip, C, lag, warm):
+    """NNEST_MH_DYNAMIC_BATCH relayed by the noise wave: the accept count is taken over the WHOLE launch, `lag` steps behind --
+    after `warm` steps under the exact rule (NNEST_MH_WARM; the product's default is 16 in front of lag 8).
+    The oracle runs the whole batch with the same schedule: same scale sequence, same chains."""
     nvp, o, g = trained(hip)
     rng = np.random.RandomState(C + lag)
     init = g['init'][rng.randint(0, g['init'].shape[0], size=C)]
@@ -142,11 +144,11 @@ def test_solo_batch_wide_step_rule_vs_oracle(hip, C, lag):
     dz, u = nvp.fill_noise(S, C, seed=seed)
     z, _ = nvp.forward(init)
     logl = torch.from_numpy(init_logl).cuda()
-    res = nvp.mh_steps(0, 5.0, z, logl, loglstar, step, S, dynamic='batch', lag=lag, seed=seed, history=True, form='solo')
+    res = nvp.mh_steps(0, 5.0, z, logl, loglstar, step, S, dynamic='batch', lag=lag, seed=seed, history=True, form='solo', warm=warm)
     hip.HipNVP.check_sync(res)
     margins = np.empty((S, C))
     so, _, lo, sc, ncall, (acc, rej) = orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, loglstar, step, True, cpu(dz),
-                                                       cpu(u), lag=lag, margins=margins)
+                                                       cpu(u), lag=lag, margins=margins, warm=warm)
     scales = cpu(res['scale'])
     assert np.all(scales == scales[0])                       # one rule for the whole batch
     assert abs(float(scales[0]) - sc) < 1e-6 * max(1.0, sc)  # same sequence of majority decisions

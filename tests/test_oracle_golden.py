@@ -176,6 +176,48 @@ def test_mcmc_sample_trace(path):
     assert rel(loglikes, g['loglikes']) < (1e-4 if np.isnan(float(g['loglstar'])) else 2e-5)
 
 
+def test_lagged_step_rule_schedules_against_the_reference_rule():
+    """the build-defined schedules of the step rule (orc_set_step_lag / orc_set_step_warm: what the GPU's batch-wide mode runs)
+    against the reference's rule (lag 0, pinned by the golden traces above) on one set of noise: a lag L leaves the first L + 1
+    steps at the initial scale; `warm` exact steps in front of it reproduce the reference's chain through step warm + 1 and,
+    from there, apply no vote for L steps; warm >= steps - 1 is the reference's chain throughout."""
+    g = np.load(os.path.join(G, 'mcmc_rosen_d50_dyn.npz'))
+    nvp = orc.NVP(int(g['D']), int(g['H']), int(g['B']), int(g['L']), g['w'])
+    S, C, D = 30, 16, int(g['D'])
+    rng = np.random.RandomState(3)
+    dz = rng.standard_normal((S, C, D)).astype(np.float32)
+    u = rng.uniform(size=(S, C)).astype(np.float32)
+    init = g['init'][:C]
+    init_logl = orc.loglike('rosenbrock', init, float(g['scale']))
+    star = float(np.min(init_logl)) - 1e3
+
+    def run(**kw):
+        smp, lat, ll, sc, ncall, _ = orc.mcmc_sample(nvp, 'rosenbrock', float(g['scale']), init, init_logl, star, 0.3, True, dz, u, **kw)
+        return lat, sc
+
+    exact, sc0 = run()
+    lag5, sc5 = run(lag=5)
+    assert not np.array_equal(exact, lag5) and sc5 != sc0
+    prop = lag5[:, 1:] - lag5[:, :-1]                   # accepted moves are scale * dz: the first 6 steps run at the initial scale
+    for it in range(6):
+        mv = np.any(prop[:, it] != 0, axis=1)
+        assert np.allclose(prop[mv, it], np.float32(0.3) * dz[it][mv], rtol=0, atol=2e-6)
+    w8, scw = run(lag=5, warm=8)
+    assert np.array_equal(w8[:, :10], exact[:, :10])    # steps 1..9: the scale of step 9 reflects the votes of steps 1..8 in both
+    assert not np.array_equal(w8, exact)
+    prop = w8[:, 1:] - w8[:, :-1]
+    ratio = []
+    for it in range(8, 14):                             # steps 9..14 share one scale: no vote is applied after steps 9..13
+        mv = np.any(prop[:, it] != 0, axis=1)
+        if mv.any():
+            k = np.argmax(np.abs(dz[it][mv][0]))
+            ratio.append(float(prop[mv, it][0][k] / dz[it][mv][0][k]))
+    assert len(ratio) >= 2 and np.ptp(ratio) < 1e-3 * abs(ratio[0])
+    full, scf = run(lag=5, warm=S - 1)
+    assert np.array_equal(full, exact)                  # (the kernel and the oracle clamp warm to steps - 1)
+    assert np.array_equal(run(lag=0, warm=8)[0], exact)  # without a lag there is nothing to warm up
+
+
 def test_nested_cfg1_fixture_matches_survey_probe():
     with open(os.path.join(G, 'nested_cfg1.json')) as f:
         r = json.load(f)

@@ -34,8 +34,8 @@ def timed(**kw):
 
 
 if len(sys.argv) > 1 and sys.argv[1] == 'stamp':
-    for name, kw in (('solo fixed', dict(form='solo')), ('solo batch lag 4', dict(form='solo', dynamic='batch', lag=4)),
-                     ('solo batch lag 8', dict(form='solo', dynamic='batch', lag=8))):
+    for name, kw in (('solo fixed', dict(form='solo')), ('solo batch lag 4', dict(form='solo', warm=0, dynamic='batch', lag=4)),
+                     ('solo batch lag 8', dict(form='solo', warm=0, dynamic='batch', lag=8))):
         ms, res = timed(**kw)
         o = res['scale'].cpu().numpy()
         print('%-18s %.3f ms; cycles per step: total %d  propose+noise %d  inverse %d  post %d' % (name, ms, o[0] / S, o[1] / S, o[2] / S, o[3] / S))
@@ -49,9 +49,14 @@ if len(sys.argv) > 1 and sys.argv[1] == 'stamp':
               'scale update %d]' % (name, ms, o[0] / S, o[1] / S, o[2] / S, o[3] / S, o[4] / S, o[5] / S, o[6] / S, o[7] / S))
 else:
     for name, kw in (('solo fixed', dict(form='solo')),
-                     ('solo batch lag 3', dict(form='solo', dynamic='batch', lag=3)), ('solo batch lag 4', dict(form='solo', dynamic='batch', lag=4)),
-                     ('solo batch lag 6', dict(form='solo', dynamic='batch', lag=6)), ('solo batch lag 8', dict(form='solo', dynamic='batch', lag=8)),
-                     ('solo batch lag 12', dict(form='solo', dynamic='batch', lag=12)),
+                     ('solo batch lag 3', dict(form='solo', warm=0, dynamic='batch', lag=3)), ('solo batch lag 4', dict(form='solo', warm=0, dynamic='batch', lag=4)),
+                     ('solo batch lag 6', dict(form='solo', warm=0, dynamic='batch', lag=6)), ('solo batch lag 8', dict(form='solo', warm=0, dynamic='batch', lag=8)),
+                     ('solo batch lag 12', dict(form='solo', warm=0, dynamic='batch', lag=12)),
+                     ('solo batch lag 8 after 8 exact steps', dict(form='solo', warm=8, dynamic='batch', lag=8)),
+                     ('solo batch lag 8 after 16 exact steps', dict(form='solo', warm=16, dynamic='batch', lag=8)),
+                     ('solo batch lag 8 after 32 exact steps', dict(form='solo', warm=32, dynamic='batch', lag=8)),
+                     ('solo batch lag 8 after 249 exact steps', dict(form='solo', warm=249, dynamic='batch', lag=8)),
+                     ('default (as the sampler launches it)', dict(dynamic='batch')),
                      ('quad fixed', dict(form='quad')), ('quad1 fixed (both nets on one wave)', dict(form='quad1')),
                      ('quad1 batch lag 2', dict(form='quad1', dynamic='batch', lag=2)), ('quad batch lag 0', dict(form='quad', dynamic='batch', lag=0)),
                      ('quad batch lag 1', dict(form='quad', dynamic='batch', lag=1)),

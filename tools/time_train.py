@@ -35,5 +35,5 @@ if os.environ.get('NNEST_HIP_LIB', '').endswith('STAMP.so'):   # NNEST_STAMP bui
     nvp = flow.HipNVP(D, 16, 3, 1, seed=1)
     res = nvp.train_epochs(live[nv:], live[:nv], perms, None, max_epochs=E, seed=1, jitter=0.01, batch=100, patience=1000)
     ph = res['losses'].cpu().numpy().ravel()[:8] / (E * ((N - nv + 99) // 100))
-    print('grid kernel, cycles per minibatch: forward %d  backward+staging %d  barrier %d  weight-gradient jobs %d  barrier %d  '
-          'loss + Adam %d' % tuple(ph[:6]))
+    print('grid kernel, cycles per minibatch: forward %d  backward+staging %d  barrier %d  weight-gradient jobs + Adam + publish %d  '
+          'barrier %d  loss + image refresh %d' % tuple(ph[:6]))
