@@ -298,7 +298,8 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s x_dim=%d, %d live points (walkers) per GPU, %d MH steps per launch, NVP hidden=%d '
                                    'blocks=%d layers=%d, %s' % (like, D, C, S, H, B, L,
-                                                                'fixed step' if not dynamic else 'batch-wide dynamic step rule'),
+                                                                'fixed step' if not dynamic else
+                                                                'batch-wide dynamic step rule (product default: exact steps, then lagged)'),
                        'baseline_config': args.config, 'walkers_per_gpu': C, 'walkers_total': C_total, 'mcmc_steps': S,
                        'evals_per_step': evals_per_launch,
                        'parallelism': ('single GPU' if world == 1 and dist is None else
@@ -311,6 +312,8 @@ def main():
                          'kernel': 'mh_kernel_%s' % kform, 'kernel_ms': kern_ms, 'flops_per_eval': fl,
                          'hbm_frac_if_streamed': evals_per_launch * alg_bytes_per_eval(D) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          'step_rule_lag': (lag if lag is not None else nvp.default_lag(C, form)) if dynamic == 'batch' else None,
+                         'step_rule_exact_steps': (nvp.default_warm(C, dynamic, lag if lag is not None else nvp.default_lag(C, form), form)
+                                                   if dynamic == 'batch' else None),
                          'note': 'f32 peak: the f32-input MFMA rate and the f32 vector (v_fma) rate are the same 157.3 TFLOP/s on '
                                  'gfx950; the solo form runs its layers on the vector unit (v_fmac_f32 + DPP), the other forms on '
                                  'MFMA.  %d walker tiles on %d CUs: latency-bound at this population (a step is a serial chain of '

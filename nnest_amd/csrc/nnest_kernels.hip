@@ -672,6 +672,41 @@ static hipError_t launch_pass_t(const PassArgs &a_in, int num_cu, hipStream_t st
     return hipGetLastError();
 }
 
+// The image form's launch shape, decided in ONE place (the launcher uses it; pick_mh_form asks it whether the batch-wide rule's
+// grid is resident).  occ: the build (waves per SIMD it is compiled for, see mh_kernel); capacity: workgroups of this shape the
+// chip holds at once -- by wave slots (4 SIMDs x occ per CU) and by LDS (one copy of the fragment image per workgroup).  Under
+// the batch-wide rule every workgroup waits on every other one, so the grid must not exceed the capacity: the workgroups are made
+// as large as that takes (the fewest waves per workgroup that fit: small populations still spread over the CUs).
+struct ImageGeom { int occ, block, grid, capacity; };
+template <int NT>
+static ImageGeom image_geometry(int ntiles, int num_cu, size_t img_bytes, bool batch, bool dbg) {
+    static const int occ_env = [] { const char *e = getenv("NNEST_MH_OCC"); return e ? atoi(e) : 0; }();   // diagnostic: pin the build
+    const bool in_lds = img_bytes <= (size_t)LDS_IMAGE_LIMIT;
+    ImageGeom g;
+    pick_geometry(ntiles, num_cu, 8, &g.block, &g.grid);
+    g.occ = 3;
+    if (in_lds && !dbg) {   // (the builds that record history / replay noise exist at 3 waves per SIMD only)
+        if (NT >= 3 && ((occ_env == 0 && ntiles <= 4 * num_cu) || occ_env == 1)) g.occ = 1;        // <= one tile per SIMD
+        else if (occ_env == 2 || (occ_env == 0 && (NT >= 3 || ntiles <= 16 * num_cu))) g.occ = 2;
+    }
+    const int max_wpb = g.occ == 1 ? 2 : 8;
+    int wpb = g.block / 64 < max_wpb ? g.block / 64 : max_wpb;
+    auto capacity = [&](int w) {
+        int per_cu = (4 * g.occ) / w;
+        if (in_lds) {
+            const int by_lds = (int)(((size_t)160 * 1024 - 4096) / (img_bytes > 0 ? img_bytes : 1));
+            per_cu = per_cu < by_lds ? per_cu : by_lds;
+        }
+        return num_cu * (per_cu > 0 ? per_cu : 0);
+    };
+    if (batch)
+        while (wpb < max_wpb && (ntiles + wpb - 1) / wpb > capacity(wpb)) wpb *= 2;
+    g.block = 64 * wpb;
+    g.grid = (ntiles + wpb - 1) / wpb;
+    g.capacity = capacity(wpb);
+    return g;
+}
+
 // Which form runs (DESIGN.md "K4"): quad (4 walkers per tile, nnest_quad.hip) while its tiles fit the CUs, then team, register,
 // image by population; flags bits 16..19 pin a form (a caller that shards one batch over ranks pins the form the whole
 // batch would get, so a shard reproduces the slice of the unsharded run bit for bit).  The batch-wide step rule needs every
@@ -698,9 +733,8 @@ static int pick_mh_form(const MhArgs &a, int num_cu) {
         if ((form == MH_FORM_AUTO || form == MH_FORM_REG) && a.s.B == 3 && ntiles <= 4 * num_cu && a.s.scale_mode != 2) return MH_FORM_REG;
     }
     if (form == MH_FORM_REG) return -1;
-    int block, grid;
-    pick_geometry(ntiles, num_cu, 8, &block, &grid);  // mh_kernel: __launch_bounds__(512, 3)
-    if (batch && grid > num_cu) return -1;  // one workgroup per CU is what is certainly resident
+    const ImageGeom g = image_geometry<NT>(ntiles, num_cu, (size_t)a.s.image_floats * 4, batch, a.noise_dz || a.hist_x || a.hist_logl);
+    if (batch && g.grid > g.capacity) return -1;  // the batch-wide rule needs every workgroup resident
     return MH_FORM_IMAGE;
 }
 
@@ -742,24 +776,19 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
             return hipGetLastError();
         }
     }
-    int block, grid;
-    pick_geometry(ntiles, num_cu, 8, &block, &grid);
     const size_t img_bytes = (size_t)a.s.image_floats * 4;
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
-    static const int occ_env = [] { const char *e = getenv("NNEST_MH_OCC"); return e ? atoi(e) : 0; }();   // diagnostic: pin the build
+    const ImageGeom geo = image_geometry<NT>(ntiles, num_cu, img_bytes, batch, dbg);
+    const int block = geo.block, grid = geo.grid;
     if constexpr (NT >= 3) {
-        // (under the batch-wide rule every workgroup has to be resident: two 2-wave workgroups per CU need two LDS images)
-        const bool fits = block <= 128 || !batch || 2 * img_bytes + 8192 <= (size_t)160 * 1024;
-        if (((ntiles <= 4 * num_cu && occ_env == 0 && fits) || occ_env == 1) && img_bytes <= (size_t)LDS_IMAGE_LIMIT && !dbg) {   // <= one tile per SIMD: the one-wave-per-SIMD build
+        if (geo.occ == 1) {   // one wave per SIMD, the whole register file
             hipError_t e = allow_lds(mh_kernel<NT, NH, LT, true, false, 1>, img_bytes);
             if (e != hipSuccess) return e;
-            if (block > 128) { block = 128; grid = (ntiles + 1) / 2; }
             hipLaunchKernelGGL((mh_kernel<NT, NH, LT, true, false, 1>), dim3(grid), dim3(block), img_bytes, st, a);
             return hipGetLastError();
         }
     }
-    // two waves per SIMD: everything else at 3-4 tiles per class; at <= 2 tiles per class up to 16 tiles per CU
-    if ((occ_env == 2 || (occ_env == 0 && (NT >= 3 || ntiles <= 16 * num_cu))) && img_bytes <= (size_t)LDS_IMAGE_LIMIT && !dbg) {
+    if (geo.occ == 2) {
         hipError_t e = allow_lds(mh_kernel<NT, NH, LT, true, false, 2>, img_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((mh_kernel<NT, NH, LT, true, false, 2>), dim3(grid), dim3(block), img_bytes, st, a);

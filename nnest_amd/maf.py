@@ -70,12 +70,14 @@ class HipMAF(HipNVP):
         best_w = self.store_packed()
         for epoch in range(max_epochs):
             tot = torch.zeros((), dtype=torch.float32, device=dev)
+            # the epoch's rows in minibatch order, jitter applied (data + jitter * randn, trainer.py:392): one gather and one
+            # draw per epoch; a minibatch is a slice (nothing is queued between its two library calls but the loss add)
+            rows_all = xtrain[perm[epoch]]
+            if jitter != 0.0:
+                nz = noise[epoch] if noise is not None else torch.randn(rows_all.shape, device=dev, generator=gen)
+                rows_all = rows_all + float(jitter) * nz
             for b0 in range(0, n_train, batch):
-                rows = xtrain[perm[epoch, b0:b0 + batch]]
-                if jitter != 0.0:   # data + jitter * randn (trainer.py:392)
-                    nz = noise[epoch, b0:b0 + batch] if noise is not None else torch.randn(rows.shape, device=dev, generator=gen)
-                    rows = rows + float(jitter) * nz
-                loss, grad = self.loss_grad(rows.contiguous())
+                loss, grad = self.loss_grad(rows_all[b0:b0 + batch])
                 self.adam_step(grad, lr, weight_decay)
                 tot += loss[0]
             train_loss = float(tot) / n_train                               # trainer.py:403

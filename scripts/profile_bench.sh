@@ -35,9 +35,9 @@ for d in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
             vals[c] = sum(v) / len(v)
             n = len(v)
 with open('bench_pmc_summary.txt', 'w') as o:
-    o.write('# rocprofv3 PMC passes of `python bench.py --steps 20 --warmup 3 --bare` '
-            '(scripts/profile_bench.sh %s);\n# mean per dispatch of ' + kern + ' (%d dispatches); '
-            'FETCH_SIZE / WRITE_SIZE raw counter units are KiB; SQ cycle counters count 4 clocks\n' % (tag, n))
+    o.write('# rocprofv3 PMC passes of `python bench.py --steps 20 --warmup 3 --bare` (scripts/profile_bench.sh %s);\n'
+            '# mean per dispatch of %s (%d dispatches); FETCH_SIZE / WRITE_SIZE raw counter units are KiB; SQ cycle counters count '
+            '4 clocks\n' % (tag, kern, n))
     for c in sorted(vals):
         o.write('%-18s %14.2f\n' % (c, vals[c]))
 if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:

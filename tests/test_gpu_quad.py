@@ -105,7 +105,7 @@ def test_quad_shapes_and_likelihoods_vs_oracle(hip, D, like, scale):
 
 
 @pytest.mark.parametrize('C,form,lag', [(1000, 'quad', 0), (1000, 'quad', 2), (333, 'quad', 1), (2000, 'quad', 4), (2000, 'team', 2),
-                                        (2000, 'team', 0), (4800, 'reg', 3)])
+                                        (2000, 'team', 0), (4800, 'reg', 3), (6000, 'image', 2), (20000, 'image', 4)])
 def test_batch_wide_step_rule_vs_oracle(hip, C, form, lag):
     """NNEST_MH_DYNAMIC_BATCH: the accept count is taken over the WHOLE launch (the reference's rule at lag 0; with lag L
     the update after step s uses the count of step s - L).  The oracle runs the whole batch with the same lag."""
@@ -133,6 +133,42 @@ def test_batch_wide_step_rule_vs_oracle(hip, C, form, lag):
     assert_borderline(cpu(res['hist_x']), so, margins, np.flatnonzero(~same))
     assert rel(cpu(res['hist_x'])[same], so[same]) < 5e-5
     assert rel(cpu(res['hist_logl'])[same], lo[same]) < 5e-5
+
+
+def test_batch_rule_at_the_config5_population_on_one_gpu(hip):
+    """BASELINE config 5's shape on ONE GPU -- x_dim 100, 8000 walkers: 500 tiles of 16 on 256 CUs, image form, one wave per SIMD
+    -- under the reference's batch-wide rule (round 2 refused it there: more workgroups than CUs; the launch shape now
+    guarantees residency, two 2-wave workgroups per CU).  Scale sequence and chains against the oracle."""
+    D, C, S, lag = 100, 8000, 10, 4
+    nvp = hip.HipNVP(D, 16, 3, 1, seed=3)
+    o = orc.NVP(D, 16, 3, 1, nvp.store_packed())
+    assert nvp.mh_form_for(C, dynamic='batch', lag=lag) == 'image'
+    rng = np.random.RandomState(5)
+    init = rng.uniform(-0.5, 0.5, size=(C, D))
+    init_logl = orc.loglike('rosenbrock', init, 5.0)
+    loglstar = float(np.min(init_logl)) - 1e3
+    step, seed = 0.05, 123
+    dz, u = nvp.fill_noise(S, C, seed=seed)
+    z, _ = nvp.forward(init)
+    logl = torch.from_numpy(init_logl).cuda()
+    res = nvp.mh_steps(0, 5.0, z, logl, loglstar, step, S, dynamic='batch', lag=lag, seed=seed, history=True)
+    hip.HipNVP.check_sync(res)
+    margins = np.empty((S, C))
+    so, _, lo, sc, ncall, _ = orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, loglstar, step, True, cpu(dz), cpu(u), lag=lag,
+                                              margins=margins)
+    scales = cpu(res['scale'])
+    assert np.all(scales == scales[0]) and abs(float(scales[0]) - sc) < 1e-6 * max(1.0, sc) and sc != step
+    moved_o = np.sum(np.any(so[:, 1:] != so[:, :-1], axis=2), axis=1)
+    same = cpu(res['n_accept']) == moved_o
+    assert np.sum(~same) <= C // 200
+    assert_borderline(cpu(res['hist_x']), so, margins, np.flatnonzero(~same))
+    assert rel(cpu(res['hist_x'])[same], so[same]) < 5e-5
+    # the production build (no history; one wave per SIMD): the same final state bit for bit
+    z2, _ = nvp.forward(init)
+    logl2 = torch.from_numpy(init_logl).cuda()
+    res2 = nvp.mh_steps(0, 5.0, z2, logl2, loglstar, step, S, dynamic='batch', lag=lag, seed=seed)
+    hip.HipNVP.check_sync(res2)
+    assert torch.equal(z2, z) and torch.equal(res2['n_accept'], res['n_accept']) and torch.equal(res2['scale'], res['scale'])
 
 
 def test_batch_rule_differs_from_group_rule_and_lag_matters(hip):
