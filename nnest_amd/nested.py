@@ -324,11 +324,13 @@ class NestedSampler(Sampler):
         self.num_retrains = 0
         self.num_batches = 0
 
+        # (the largest live likelihood, kept up to date: the point that is replaced is the smallest one, so the maximum only grows;
+        # the reference takes np.max over the live points at every iteration, nested.py:461 -- the same value)
+        max_logl = np.max(active_logl)
         while fraction_remain > dlogz and it <= max_iters:
             worst = int(np.argmin(active_logl))              # nested.py:272
             logwt = logvol + active_logl[worst]
             loglstar = active_logl[worst]
-            expected_vol = np.exp(-it / N)
             if accept_point:
                 # the worst live point dies: it joins the evidence and the chain (nested.py:280-293)
                 ev.add(logwt, loglstar)
@@ -378,7 +380,7 @@ class NestedSampler(Sampler):
                     mean_calls = np.mean(ncs[-20:]) if len(ncs) > 20 else 0
                     mcmc_valid = 'mcmc' in strategy and 'mcmc' not in expired_strategies
                     if current_method == 'rejection_prior':
-                        expire = expected_vol < volume_switch >= 0 or (volume_switch < 0 and mean_calls > mcmc_steps
+                        expire = np.exp(-it / N) < volume_switch >= 0 or (volume_switch < 0 and mean_calls > mcmc_steps
                                                                        and mcmc_valid)
                     else:                                            # nested.py:344-347, :355-358
                         expire = mean_calls > mcmc_steps and mcmc_valid
@@ -396,6 +398,7 @@ class NestedSampler(Sampler):
                         active_u[worst] = samples[cand]
                         active_v[worst] = self.transform(active_u[worst])
                         active_logl[worst] = loglikes[cand]
+                        max_logl = max(max_logl, active_logl[worst])
                         if self.num_derived > 0:
                             active_derived[worst] = derived_samples[cand]
                         accept_point = True
@@ -403,7 +406,7 @@ class NestedSampler(Sampler):
                 total_calls = int(self._all_sum(self.total_calls))
                 if accept_point and it > 0 and (it + 1) % log_interval == 0 and primary:
                     self.logger.info('Step [%d] loglstar [%5.4e] max logl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
-                                     'mean calls [%5.4f]' % (it + 1, loglstar, np.max(active_logl), ev.logz, expected_vol,
+                                     'mean calls [%5.4f]' % (it + 1, loglstar, max_logl, ev.logz, np.exp(-it / N),
                                                              total_calls, mean_calls))
 
             elif current_method == 'mcmc':                   # nested.py:398-456
@@ -447,6 +450,7 @@ class NestedSampler(Sampler):
                         active_u[worst] = end_u[cand]
                         active_v[worst] = end_v[cand]
                         active_logl[worst] = end_logl[cand]
+                        max_logl = max(max_logl, active_logl[worst])
                         if nd > 0:
                             active_derived[worst] = end_derived[cand]
                         accept_point = True
@@ -455,14 +459,14 @@ class NestedSampler(Sampler):
                 if accept_point and it > 0 and it % log_interval == 0 and primary:
                     acc = self.total_accepted / max(1, self.total_accepted + self.total_rejected)
                     self.logger.info('Step [%d] loglstar [%5.4e] maxlogl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
-                                     'scale [%5.4f]' % (it, loglstar, np.max(active_logl), ev.logz, expected_vol, total_calls, scale))
+                                     'scale [%5.4f]' % (it, loglstar, max_logl, ev.logz, np.exp(-it / N), total_calls, scale))
                     with open(os.path.join(self.logs['results'], 'results.csv'), 'a') as f:
                         csv.writer(f).writerow([it, acc, float('nan'), float('nan'), float('nan'), scale, loglstar, ev.logz,
                                                 fraction_remain, total_calls])
 
             if accept_point:                                 # nested.py:458-485
                 logvol -= 1.0 / N
-                logz_remain = np.max(active_logl) - it / N
+                logz_remain = max_logl - it / N
                 fraction_remain = np.logaddexp(ev.logz, logz_remain) - ev.logz
                 it += 1
                 if primary:
