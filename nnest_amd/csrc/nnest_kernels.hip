@@ -523,7 +523,13 @@ struct LdsNoise {
 };
 
 template <int NT, int L, int B, bool DBG>
-__global__ void __launch_bounds__(192, 2) mh_kernel_team(MhArgs a) {  // min 2 waves/SIMD: <= 256 VGPRs, MFMA results stay in VGPRs
+// min 2 waves/SIMD, i.e. <= 256 VGPRs: MFMA results stay in VGPRs.  The build with the whole register file (-DNNEST_TEAM_FULL_FROM=<tiles
+// per class>; 0 spilled registers against 41 at 2 tiles per class and 105 at 4) measured SLOWER, round 3: 4.34 against 4.12 us per
+// step at x_dim 50 / 4000 walkers, 6.76 against 6.50-6.68 at x_dim 100 / 2000-4000 (profiles/r03/k4_team_register_budget.txt).
+#ifndef NNEST_TEAM_FULL_FROM
+#define NNEST_TEAM_FULL_FROM 99
+#endif
+__global__ void __launch_bounds__(192, NT >= NNEST_TEAM_FULL_FROM ? 1 : 2) mh_kernel_team(MhArgs a) {
     typedef TeamInverse<NT, L, B> TI;
     constexpr bool WREG = NT <= 2;
     extern __shared__ __attribute__((aligned(16))) float team_img[];  // !WREG: the fragment image
