@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 13
+#define NNEST_HIP_ABI_VERSION 14
 
 enum {
     NNEST_OK = 0,
@@ -243,6 +243,12 @@ int nnest_nvp_vjp(nnest_nvp_t *nvp, const float *x_dev, const float *gz_dev, flo
 /* one torch.optim.Adam step (coupled weight decay, trainer.py:121-122) from a gradient computed outside nnest_nvp_train;
  * uses and advances the handle's Adam state (the step counter lives on the device: asynchronous on `stream`, like the passes) */
 int nnest_nvp_adam_step(nnest_nvp_t *nvp, const float *grad_dev, float lr, float weight_decay, void *stream);
+/* MAF handles (nnest_maf_create): one epoch of Trainer._train (trainer.py:384-403) queued by ONE call -- per minibatch of `batch`
+ * (<= 128) consecutive rows of rows_dev [n_train, D] (the caller has applied the epoch's permutation and jitter): loss + gradient,
+ * one Adam step (coupled weight decay), image rebuild; *loss_sum_dev += the minibatch's loss (the reference's running sum of
+ * loss.item(), trainer.py:402).  Asynchronous on `stream`; nothing is read back. */
+int nnest_maf_train_epoch(nnest_nvp_t *nvp, const float *rows_dev, int n_train, int batch, float lr, float weight_decay,
+                          float *loss_sum_dev, void *stream);
 
 /* training jitter when jitter < 0 (trainer.py:168-171): 0.2 * mean of the 2-nearest-neighbour distance
  * table (self distance 0 included) of samples_dev [N,D] float64; result to out_dev float64[1]. */

@@ -86,6 +86,7 @@ SIGNATURES = {
     'nnest_nvp_create_scaled': [_i, _i, _i, _i, _i, ctypes.POINTER(_vp)],
     'nnest_maf_create': [_i, _i, _i, _i, ctypes.POINTER(_vp)],
     'nnest_maf_num_groups': [_vp],
+    'nnest_maf_train_epoch': [_vp, _vp, _i, _i, _f, _f, _vp, _vp],
     'nnest_nvp_destroy': [_vp],
     'nnest_nvp_num_params': [_vp],
     'nnest_nvp_set_base': [_vp, _f],

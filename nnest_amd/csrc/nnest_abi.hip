@@ -27,6 +27,7 @@ struct nnest_nvp {
     size_t train_ws_floats;
     float *img_bwd;  // MAF: the transposed fragment image (the RealNVP training kernels keep theirs in the workspace / LDS)
     int *gpos;       // MAF: packed parameter -> slot of a tile's weight-gradient buffer
+    float *grad_buf; // MAF: gradient + loss of the minibatch in flight (nnest_maf_train_epoch), num_params + 1 floats
 };
 
 static thread_local char g_err[512] = "";
@@ -201,7 +202,7 @@ int nnest_nvp_destroy(nnest_nvp_t *h) {
     if (!h) return NNEST_OK;
     (void)hipFree(h->w); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->best_w); (void)hipFree(h->img);
     (void)hipFree(h->adam_step); (void)hipFree(h->train_ws); (void)hipFree(h->fwd_pos); (void)hipFree(h->bwd_pos);
-    (void)hipFree(h->img_bwd); (void)hipFree(h->gpos);
+    (void)hipFree(h->img_bwd); (void)hipFree(h->gpos); (void)hipFree(h->grad_buf);
     delete h;
     return NNEST_OK;
 }
@@ -429,6 +430,24 @@ int nnest_nvp_adam_step(nnest_nvp_t *h, const float *grad_dev, float lr, float w
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(launch_adam_packed_dev(h->w, grad_dev, h->adam_m, h->adam_v, h->num_params, h->adam_step, lr, weight_decay, st));
     HIP_TRY(refresh_images(h, st));
+    return NNEST_OK;
+}
+
+int nnest_maf_train_epoch(nnest_nvp_t *h, const float *rows_dev, int n_train, int batch, float lr, float weight_decay, float *loss_sum_dev,
+                          void *stream) {
+    if (!h || !rows_dev || !loss_sum_dev) return fail(NNEST_E_ARG, "NULL argument");
+    if (h->s.kind != FLOW_KIND_MAF) return fail(NNEST_E_ARG, "not a MAF handle (nnest_maf_create)");
+    if (n_train < 1 || batch < 1 || batch > 128) return fail(NNEST_E_UNSUPPORTED, "batch=%d outside [1,128]", batch);
+    if (h->s.L > 2) return fail(NNEST_E_UNSUPPORTED, "maf: num_layers=%d > 2 has no training kernel", h->s.L);
+    hipStream_t st = (hipStream_t)stream;
+    if (!h->grad_buf) HIP_TRY(hipMalloc(&h->grad_buf, ((size_t)h->num_params + 1) * sizeof(float)));
+    float *grad = h->grad_buf, *loss = h->grad_buf + h->num_params;
+    for (int b0 = 0; b0 < n_train; b0 += batch) {   // Trainer._train's loop over the loader (trainer.py:387-403), queued back to back
+        const int M = n_train - b0 < batch ? n_train - b0 : batch;
+        HIP_TRY(launch_maf_loss_grad(h->s, h->img, h->img_bwd, h->gpos, rows_dev + (size_t)b0 * h->s.D, M, grad, loss, h->train_ws, st));
+        HIP_TRY(launch_adam_packed_dev(h->w, grad, h->adam_m, h->adam_v, h->num_params, h->adam_step, lr, weight_decay, st, loss, loss_sum_dev));
+        HIP_TRY(refresh_images(h, st));
+    }
     return NNEST_OK;
 }
 

@@ -54,7 +54,8 @@ class HipMAF(HipNVP):
     def train_epochs(self, xtrain, xvalid, perm, noise=None, seed=0, jitter=0.0, batch=100, max_epochs=1, patience=50,
                      lr=1e-3, weight_decay=1e-6, epoch_offset=0, resume=False, finalize=True, result=None, one_cu=False):
         """Trainer.train's epoch loop (trainer.py:198-241) driven from the host: per minibatch one gradient (nnest_nvp_loss_grad:
-        two launches) and one Adam step + image rebuild (nnest_nvp_adam_step); arguments and return value as HipNVP.train_epochs"""
+        two launches) and one Adam step + image rebuild, an epoch's minibatches queued by one call (nnest_maf_train_epoch);
+        arguments and return value as HipNVP.train_epochs"""
         assert not resume and epoch_offset == 0
         dev = self.device
         xtrain = _as_dev_f32(xtrain, dev)
@@ -76,10 +77,10 @@ class HipMAF(HipNVP):
             if jitter != 0.0:
                 nz = noise[epoch] if noise is not None else torch.randn(rows_all.shape, device=dev, generator=gen)
                 rows_all = rows_all + float(jitter) * nz
-            for b0 in range(0, n_train, batch):
-                loss, grad = self.loss_grad(rows_all[b0:b0 + batch])
-                self.adam_step(grad, lr, weight_decay)
-                tot += loss[0]
+            rows_all = rows_all.contiguous()
+            with torch.cuda.device(dev):   # every minibatch of the epoch queued by one library call (nothing read back)
+                _lib.check(self._lib.nnest_maf_train_epoch(self._h, _lib.ptr(rows_all), n_train, int(batch), ctypes.c_float(lr),
+                                                           ctypes.c_float(weight_decay), _lib.ptr(tot), _lib.current_stream(dev)))
             train_loss = float(tot) / n_train                               # trainer.py:403
             valid_loss = float(-self.log_probs(xvalid).mean()) / n_valid    # trainer.py:405-418
             losses[epoch] = (train_loss, valid_loss)
