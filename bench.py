@@ -241,13 +241,14 @@ def main():
     # state buffers are re-seeded outside the timed launches (clone is not part of the hot path)
     zs = [z0.clone() for _ in range(args.steps + args.warmup)]
     ls = [logl0.clone() for _ in range(args.steps + args.warmup)]
-    gathered = torch.empty(world * C, 2 * D + 1, dtype=torch.float64, device=dev) if dist is not None else None
+    gathered = torch.empty(world * C, D + 2, dtype=torch.float64, device=dev) if dist is not None else None
 
     def launch(i):
         res = nvp.mh_steps(LIKE_ID[like], scale, zs[i], ls[i], loglstar, step_size, S, dynamic=dynamic, lag=lag, seed=42 + i,
                            walker_offset=rank * C, form=form)
         if dist is not None:   # C2: what the nested-sampling loop consumes of a batch, gathered on every rank (device memory)
-            ends = torch.cat([x_start.double(), res['x'].double(), ls[i][:, None]], dim=1)
+            moved = (x_start != res['x']).all(dim=1)
+            ends = torch.cat([res['x'].double(), ls[i][:, None], moved[:, None].double()], dim=1)
             dist.all_gather_into_tensor(gathered, ends)
         return res
 
@@ -305,7 +306,7 @@ def main():
                        'parallelism': ('single GPU' if world == 1 and dist is None else
                                        'walkers sharded x%d (%s scaling), one RCCL all-gather of the chain endpoints '
                                        '[%d, %d] f64 per batch; flow replicas trained per rank (no weight broadcast)'
-                                       % (world, args.scaling, C, 2 * D + 1))},
+                                       % (world, args.scaling, C, D + 2))},
             'roofline': {'bound': 'mfma', 'achieved': achieved_tflops, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved_tflops / FP32_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_source': traffic_src,

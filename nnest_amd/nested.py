@@ -425,22 +425,22 @@ class NestedSampler(Sampler):
                     my = ctl[lo:lo + per]
                     kw = dict(init_samples=active_u[my, :], init_loglikes=active_logl[my], loglstar=loglstar,
                               walker_offset=lo, seed=int(ctl[-1]), form=self._pinned_form(C, mcmc_dynamic_step_size))
-                    # what the loop below consumes of a chain is its first x, its last x and the last logL (+ derived): one
-                    # row [x_0 | x_S | logL_S | derived_S] per chain, all-gathered over the ranks (C2) -- on device memory when
-                    # the whole batch ran inside the HIP kernel
+                    # what the loop below consumes of a chain is its last x, the last logL and whether every coordinate moved
+                    # (+ derived): one row [x_S | logL_S | moved | derived_S] per chain, all-gathered over the ranks (C2) -- on
+                    # device memory when the whole batch ran inside the HIP kernel
                     if self._fused_like_id is not None and nd == 0:
                         ends, scale, nc = self._mcmc_endpoints_fused(mcmc_steps, step_size, mcmc_dynamic_step_size, **kw)
                     else:
                         s_x, _lat, s_d, s_l, scale, nc = self._mcmc_sample(
                             mcmc_steps, step_size=step_size, dynamic_step_size=mcmc_dynamic_step_size,
                             init_derived=active_derived[my, :] if nd > 0 else np.empty((per, 0)), **kw)
-                        ends = np.concatenate([s_x[:, 0, :], s_x[:, -1, :], s_l[:, -1:], s_d[:, -1, :]], axis=1).astype(np.float64)
+                        mv = np.all(s_x[:, 0, :] != s_x[:, -1, :], axis=1)   # a chain is usable if every coordinate moved (nested.py:432)
+                        ends = np.concatenate([s_x[:, -1, :], s_l[:, -1:], mv[:, None], s_d[:, -1, :]], axis=1).astype(np.float64)
                     ends = self._all_gather_rows(ends)[:C]
                     ends = ends.cpu().numpy() if torch.is_tensor(ends) else ends
-                    start_u, end_u, end_logl, end_derived = ends[:, :D], ends[:, D:2 * D], ends[:, 2 * D], ends[:, 2 * D + 1:]
+                    end_u, end_logl, moved, end_derived = ends[:, :D], ends[:, D], ends[:, D + 1] != 0, ends[:, D + 2:]
                     self.num_batches += 1
-                    # a chain is usable if every coordinate moved (nested.py:432); its transform once per batch
-                    moved = np.all(start_u != end_u, axis=1)
+                    # (its transform once per batch)
                     end_v = self.transform(end_u)
                 while nb < C:
                     cand = nb

@@ -315,14 +315,17 @@ class Sampler(object):
 
     def _mcmc_endpoints_fused(self, mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar, walker_offset, seed,
                               form=None):
-        """What the nested-sampling loop consumes of a batch (nested.py:432-437) -- start x, end x, end logL per chain -- as ONE
-        device tensor [C, 2 D + 1] float64, so that the per-batch all-gather (C2) runs on device memory."""
+        """What the nested-sampling loop consumes of a batch (nested.py:432-437) -- per chain its end x, its end logL and whether
+        every coordinate moved (the reference's test of a usable chain, evaluated here, where the start x exists) -- as ONE
+        device tensor [C, D + 2] float64, so that the per-batch all-gather (C2) runs on device memory and carries no start
+        points (round 2 gathered [C, 2 D + 1])."""
         netG = self.trainer.netG
         C = init_samples.shape[0]
         res, z0, z, logl = self._fused_launch(mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar,
                                               walker_offset, seed, form)
         x0, _ = netG.inverse(z0)
-        ends = torch.cat([x0.double(), res['x'].double(), logl[:, None]], dim=1)
+        moved = (x0 != res['x']).all(dim=1)
+        ends = torch.cat([res['x'].double(), logl[:, None], moved[:, None].double()], dim=1)
         counts = torch.stack([res['n_call'].sum(), res['n_accept'].sum()]).cpu()   # one small copy; orders the stream too
         netG.check_sync(res)
         ncall, nacc = int(counts[0]), int(counts[1])
