@@ -315,10 +315,11 @@ def main():
                          'step_rule_lag': (lag if lag is not None else nvp.default_lag(C, form)) if dynamic == 'batch' else None,
                          'step_rule_exact_steps': (nvp.default_warm(C, dynamic, lag if lag is not None else nvp.default_lag(C, form), form)
                                                    if dynamic == 'batch' else None),
-                         'note': 'f32 peak: the f32-input MFMA rate and the f32 vector (v_fma) rate are the same 157.3 TFLOP/s on '
-                                 'gfx950; the solo form runs its layers on the vector unit (v_fmac_f32 + DPP), the other forms on '
-                                 'MFMA.  %d walker tiles on %d CUs: latency-bound at this population (a step is a serial chain of '
-                                 '9 small layers), see `saturated`' % (tiles, cu)},
+                         'note': 'f32 peak: the f32-input MFMA peak and the f32 vector peak (packed v_pk_fma_f32) are the same 157.3 '
+                                 'TFLOP/s on gfx950; the solo form runs its layers on the vector unit (plain v_fmac_f32 + DPP: half '
+                                 'that peak at most, priced against the full figure), the other forms on MFMA.  %d walker tiles on '
+                                 '%d CUs: latency-bound at this population (a step is a serial chain of 9 small layers), see '
+                                 '`saturated`' % (tiles, cu)},
             'device': info['name'],
         }
         if world == 1 and dist is None and not args.bare:

@@ -27,7 +27,7 @@ struct nnest_nvp {
     size_t train_ws_floats;
     float *img_bwd;  // MAF: the transposed fragment image (the RealNVP training kernels keep theirs in the workspace / LDS)
     int *gpos;       // MAF: packed parameter -> slot of a tile's weight-gradient buffer
-    float *grad_buf; // MAF: gradient + loss of the minibatch in flight (nnest_maf_train_epoch), num_params + 1 floats
+    unsigned int *ticket; // MAF: block counter of the fused update kernel (nnest_maf_train_epoch)
 };
 
 static thread_local char g_err[512] = "";
@@ -182,6 +182,11 @@ int nnest_maf_create(int D, int H, int B, int L, nnest_nvp_t **out) {
     if (e == hipSuccess) e = hipMalloc((void **)&h->train_ws, h->train_ws_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->gpos, nb);
     if (e == hipSuccess) e = launch_maf_build_gpos(h->gpos, s, 0);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->fwd_pos, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->bwd_pos, nb);
+    if (e == hipSuccess) e = launch_maf_build_pos(h->fwd_pos, h->bwd_pos, s, 0);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->ticket, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(h->ticket, 0, sizeof(unsigned int));
     if (e == hipSuccess) e = hipMemset(h->w, 0, nb);
     if (e == hipSuccess) e = hipMemset(h->adam_m, 0, nb);
     if (e == hipSuccess) e = hipMemset(h->adam_v, 0, nb);
@@ -202,7 +207,7 @@ int nnest_nvp_destroy(nnest_nvp_t *h) {
     if (!h) return NNEST_OK;
     (void)hipFree(h->w); (void)hipFree(h->adam_m); (void)hipFree(h->adam_v); (void)hipFree(h->best_w); (void)hipFree(h->img);
     (void)hipFree(h->adam_step); (void)hipFree(h->train_ws); (void)hipFree(h->fwd_pos); (void)hipFree(h->bwd_pos);
-    (void)hipFree(h->img_bwd); (void)hipFree(h->gpos); (void)hipFree(h->grad_buf);
+    (void)hipFree(h->img_bwd); (void)hipFree(h->gpos); (void)hipFree(h->ticket);
     delete h;
     return NNEST_OK;
 }
@@ -440,13 +445,10 @@ int nnest_maf_train_epoch(nnest_nvp_t *h, const float *rows_dev, int n_train, in
     if (n_train < 1 || batch < 1 || batch > 128) return fail(NNEST_E_UNSUPPORTED, "batch=%d outside [1,128]", batch);
     if (h->s.L > 2) return fail(NNEST_E_UNSUPPORTED, "maf: num_layers=%d > 2 has no training kernel", h->s.L);
     hipStream_t st = (hipStream_t)stream;
-    if (!h->grad_buf) HIP_TRY(hipMalloc(&h->grad_buf, ((size_t)h->num_params + 1) * sizeof(float)));
-    float *grad = h->grad_buf, *loss = h->grad_buf + h->num_params;
-    for (int b0 = 0; b0 < n_train; b0 += batch) {   // Trainer._train's loop over the loader (trainer.py:387-403), queued back to back
-        const int M = n_train - b0 < batch ? n_train - b0 : batch;
-        HIP_TRY(launch_maf_loss_grad(h->s, h->img, h->img_bwd, h->gpos, rows_dev + (size_t)b0 * h->s.D, M, grad, loss, h->train_ws, st));
-        HIP_TRY(launch_adam_packed_dev(h->w, grad, h->adam_m, h->adam_v, h->num_params, h->adam_step, lr, weight_decay, st, loss, loss_sum_dev));
-        HIP_TRY(refresh_images(h, st));
+    for (int b0 = 0; b0 < n_train; b0 += batch) {   // Trainer._train's loop over the loader (trainer.py:387-403), queued back to back:
+        const int M = n_train - b0 < batch ? n_train - b0 : batch;   // two launches per minibatch (gradient; reduce + Adam + images)
+        HIP_TRY(launch_maf_train_minibatch(h->s, h->img, h->img_bwd, h->gpos, h->fwd_pos, h->bwd_pos, rows_dev + (size_t)b0 * h->s.D, M, h->w,
+                                           h->adam_m, h->adam_v, h->adam_step, lr, weight_decay, loss_sum_dev, h->ticket, h->train_ws, st));
     }
     return NNEST_OK;
 }

@@ -64,6 +64,10 @@ hipError_t launch_build_pos(int *fwd_pos, int *bwd_pos, const FlowShape &s, hipS
 // masked autoregressive flow (maf_train.h inside nnest_train.hip)
 size_t maf_workspace_floats(const FlowShape &s);
 hipError_t launch_maf_build_gpos(int *gpos, const FlowShape &s, hipStream_t st);
+hipError_t launch_maf_build_pos(int *fwd_pos, int *bwd_pos, const FlowShape &s, hipStream_t st);
+hipError_t launch_maf_train_minibatch(const FlowShape &s, float *imgf, float *imgb, const int *gpos, const int *fwd_pos, const int *bwd_pos,
+                                      const float *x, int M, float *w, float *m, float *v, int *step_dev, float lr, float wd,
+                                      float *loss_acc, unsigned int *ticket, float *workspace, hipStream_t st);
 hipError_t launch_maf_loss_grad(const FlowShape &s, const float *imgf, const float *imgb, const int *gpos, const float *x, int M,
                                 float *grad, float *loss, float *workspace, hipStream_t st);
 hipError_t launch_training_jitter(const double *samples, int N, int D, double *out, hipStream_t st);

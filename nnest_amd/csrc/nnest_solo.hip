@@ -5,8 +5,8 @@
 // Why.  The quad form (nnest_quad.hip) spends a step in a chain of nine small layers, each [3 DPP moves -> 4 dependent
 // v_mfma_f32_4x4x1 -> reduce-scatter over the four 16-lane rows (3 permlane swaps + adds + hazard nops) -> activation]:
 // 232 cycles per layer of which the matrix pipe is 54, plus three LDS exchanges + barriers per step between the scale-net
-// and the translate-net wave (730 cycles).  On gfx950 the f32 MFMA has NO rate advantage over the f32 VALU (both
-// 64 FLOP/clk/SIMD, MI355X_MICROARCH.md), so at this population -- latency-bound, one wave per SIMD -- the matrix pipe buys
+// and the translate-net wave (730 cycles).  On gfx950 the f32 MFMA has no peak advantage over the f32 VALU (both
+// 64 FLOP/clk/SIMD, the vector figure with packed FMAs; MI355X_MICROARCH.md), so at this population -- latency-bound, one wave per SIMD -- the matrix pipe buys
 // nothing and its operand layouts cost the cross-lane traffic.  Here a layer is a chain of v_fmac_f32 with a DPP row
 // rotation on the activation operand: 16 lanes of a row hold the 16 features of a layer, lane p accumulates
 // out[p] = sum_t W[p][(p - t) & 15] * in[(p - t) & 15] with the weights W[p][(p - t) & 15] in its own registers -- no

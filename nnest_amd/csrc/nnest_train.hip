@@ -991,6 +991,20 @@ static hipError_t dispatch_train(const TrainArgs &a, hipStream_t st) {
 }
 
 #include "nnest_train_grid.h"
+// torch.optim.Adam (coupled weight decay), one element of the step, every operation rounded by itself (no multiply-add contraction: the choice of which product a compiler
+// fuses differs from kernel to kernel, and the kernels that share this function must agree bit for bit -- maf_update_kernel steps
+// the same parameters inside another loop)
+#pragma clang fp contract(off)
+__device__ __forceinline__ float adam_elem(float wi, float g, float &mref, float &vref, float step_size, float inv_bc2s, float wd) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const float gi = g + wd * wi;
+    const float mi = mref + (gi - mref) * (1.0f - b1);
+    const float vi = vref * b2 + ((1.0f - b2) * gi) * gi;
+    mref = mi; vref = vi;
+    return wi - step_size * (mi / (sqrtf(vi) * inv_bc2s + eps));
+}
+#pragma clang fp contract(fast)
+
 #include "maf_train.h"
 
 hipError_t launch_loss_grad(const float *packed, const FlowShape &s, const float *x, int M, float *grad, float *loss,
@@ -1054,13 +1068,10 @@ __global__ void adam_packed_dev_kernel(float *__restrict__ w, const float *__res
     const int step = *step_dev + 1;
     const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
     const float step_size = (float)((double)lr / bc1), inv_bc2s = (float)(1.0 / sqrt(bc2));
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float gi = grad[i] + wd * w[i];
-        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
-        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        float mi = m[i], vi = v[i];
+        w[i] = adam_elem(w[i], grad[i], mi, vi, step_size, inv_bc2s, wd);
         m[i] = mi; v[i] = vi;
-        w[i] = w[i] - step_size * (mi / (sqrtf(vi) * inv_bc2s + eps));
     }
 }
 __global__ void adam_step_advance_kernel(int *step_dev) { *step_dev += 1; }

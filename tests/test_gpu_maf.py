@@ -124,6 +124,43 @@ def test_maf_adam_steps_follow_the_oracle(hip):
     assert rel(cpu(z), zo) < 2e-5
 
 
+@pytest.mark.parametrize('D,L', [(7, 1), (50, 1), (100, 2)])
+def test_maf_epoch_call_equals_the_stepwise_loop(hip, D, L):
+    """[UNPINNED]  nnest_maf_train_epoch (gradient kernel + ONE kernel that reduces, steps Adam and rewrites both fragment images
+    through position maps) against the same minibatches driven step by step (nnest_nvp_loss_grad + nnest_nvp_adam_step, whose
+    images are rebuilt by the gather kernel): the same weights, moments and step count bit for bit, the same running loss, and
+    passes that follow the new weights."""
+    import ctypes
+    from nnest_amd import _lib
+    a, _ = pair(hip, D, 3, L, seed=4, scale=0.5)
+    b = hip.HipMAF(D, 16, 3, L, seed=4)
+    b.load_packed(a.store_packed())
+    rng = np.random.RandomState(D)
+    X = torch.from_numpy((rng.standard_normal((230, D)) * 0.3).astype(np.float32)).cuda()
+    tot = torch.zeros((), dtype=torch.float32, device='cuda')
+    _lib.check(a._lib.nnest_maf_train_epoch(a._h, _lib.ptr(X), 230, 100, ctypes.c_float(1e-3), ctypes.c_float(1e-6), _lib.ptr(tot),
+                                            _lib.current_stream(a.device)))
+    ref = 0.0
+    for b0 in range(0, 230, 100):
+        loss, grad = b.loss_grad(X[b0:b0 + 100])
+        b.adam_step(grad, 1e-3, 1e-6)
+        ref += float(loss[0])
+    assert np.array_equal(a.store_packed(), b.store_packed())
+    ma, va = a.adam_moments()
+    mb, vb = b.adam_moments()
+    assert np.array_equal(ma, mb) and np.array_equal(va, vb) and a.adam_step_count() == b.adam_step_count() == 3
+    assert abs(float(tot) - ref) <= 1e-6 * max(1.0, abs(ref))
+    za, lda = a.forward(X[:64])      # the images written by the update kernel == the images rebuilt from the weights
+    zb, ldb = b.forward(X[:64])
+    assert torch.equal(za, zb) and torch.equal(lda, ldb)
+    xa, _ = a.inverse(za)
+    xb, _ = b.inverse(zb)
+    assert torch.equal(xa, xb)
+    la, ga = a.loss_grad(X[:100])    # ... the transposed image too (the backward pass reads it)
+    lb, gb = b.loss_grad(X[:100])
+    assert torch.equal(ga, gb) and torch.equal(la, lb)
+
+
 @pytest.mark.parametrize('D,C,S,dyn', [(50, 200, 12, False), (100, 64, 6, False), (5, 37, 30, True), (20, 1000, 8, True)])
 def test_maf_metropolis_kernel_vs_oracle(hip, D, C, S, dyn):
     """[UNPINNED]  K4 (Sampler._mcmc_sample, sampler.py:229-463) with the MAF's grouped inverse inside the persistent kernel:

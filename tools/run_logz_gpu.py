@@ -1,7 +1,8 @@
 """GPU-path log Z of a BASELINE configuration over a list of seeds -> gpurun_out/logz_gpu_cfg<cfg>.json (copied to
 tests/golden/ and read by bench.py's `logz` report; the CPU-path counterpart is oracle/run_logz_cpu.py).
   python tools/run_logz_gpu.py 2 0,1,2,3,4,5 [lag] [tag]      lag: NNEST_MH_LAG of the batch-wide step rule ('-' or absent: the product's
-                                                               default); tag: suffix of the output file; seeds may be a range a:b"""
+                                                               default); tag: suffix of the output file; seeds may be a range a:b
+  python tools/run_logz_gpu.py 2 0:48 - _maf maf              fifth argument: the flow ('nvp' | 'spline' | 'maf')"""
 import json
 import os
 import sys
@@ -23,12 +24,13 @@ seeds = list(range(*[int(v) for v in _sd.split(':')])) if ':' in _sd else [int(v
 name, D, scale, N = CONFIGS[cfg]
 lag = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != '-' else None
 tag = sys.argv[4] if len(sys.argv) > 4 else ''
+flow = sys.argv[5] if len(sys.argv) > 5 else 'nvp'
 runs = []
 for seed in seeds:
     np.random.seed(seed)
     torch.manual_seed(seed)
     s = NestedSampler(D, getattr(likelihoods, name)(D), transform=lambda x: scale * x, log_dir=tempfile.mkdtemp(dir='/tmp'),
-                      num_live_points=N, log_level=40, flow='nvp')
+                      num_live_points=N, log_level=40, flow=flow)
     t0 = time.time()
     s.run(mcmc_num_chains=N, mcmc_step_lag=lag)
     runs.append(dict(seed=seed, logz=float(s.logz), logzerr=float(s.logzerr), h=float(s.h), niter=int(s.niter), ncall=int(s.ncall),
@@ -37,7 +39,7 @@ for seed in seeds:
     print(json.dumps(runs[-1]), flush=True)
 z = np.array([r['logz'] for r in runs])
 doc = dict(what='GPU-path log Z: nnest_amd.NestedSampler on the HIP kernels (tools/run_logz_gpu.py)', config=cfg, likelihood=name, x_dim=D,
-           num_live_points=N, mcmc_num_chains=N, flow='nvp h16 b3 l1', train_iters=500, step_rule='batch-wide, default lag' if lag is None else 'batch-wide, lag %d' % lag,
+           num_live_points=N, mcmc_num_chains=N, flow=flow + ' h16 b3 l1', train_iters=500, step_rule='batch-wide, default lag' if lag is None else 'batch-wide, lag %d' % lag,
            seeds=seeds, logz=z.tolist(), mean=float(z.mean()), std=float(z.std(ddof=1)) if len(z) > 1 else None,
            stderr=float(z.std(ddof=1) / np.sqrt(len(z))) if len(z) > 1 else None, runs=runs)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
