@@ -201,6 +201,69 @@ static __device__ __forceinline__ float solo_coupling_inverse(const SoloNet<U> &
 // log-det of the walker from the lanes' partials: over the 16 positions of a row, then over the two K-halves
 static __device__ __forceinline__ float solo_logdet_total(float ld) { return solo_join(solo_row_sum(ld)); }
 
+// ---- x_dim 97..128 (U = 4): a lane's share of a block is 78 weights, 234 for the three blocks -- more than the register file
+// leaves beside the state.  They live in LDS instead, field-major ([block][field / 4][lane][4]: one conflict-free ds_read_b128
+// per four fields; the four net waves of a workgroup hold identical copies, so ONE copy per workgroup, 60 KB), and a layer's
+// weights are read into registers right before the layer's chain.  Fields: w1[u][t] at 8 u + t, w2[t] at 32 + t, w3[u][t] at
+// 40 + 8 u + t, b1 72, b2 73, b3[u] 74 + u.
+constexpr int SOLO4_NF = 80;
+static __device__ __forceinline__ void solo4_store(float *base, int b, const SoloNet<4> &n, int lane) {
+    float *q = base + (size_t)b * SOLO4_NF * 64;
+    auto put = [&](int f, float v) { q[((size_t)(f >> 2) * 64 + lane) * 4 + (f & 3)] = v; };
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { put(8 * u + t, n.w1[u][t]); put(40 + 8 * u + t, n.w3[u][t]); }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) put(32 + t, n.w2[t]);
+    put(72, n.b1); put(73, n.b2);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) put(74 + u, n.b3[u]);
+    put(78, 0.f); put(79, 0.f);
+}
+static __device__ __forceinline__ void solo4_load8(float (&w)[8], const float *blk, int f0, int lane) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(blk + ((size_t)(f0 >> 2) * 64 + lane) * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(blk + ((size_t)((f0 >> 2) + 1) * 64 + lane) * 4);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+// CouplingLayer.inverse as solo_coupling_inverse<2>, four slots per class: the first layer takes its four inputs as two pairs
+// on the same two accumulators, the last layer's four outputs are two reduce-scattered pairs (row h ends with outputs h and 2 + h)
+static __device__ __forceinline__ float solo_coupling_inverse4(const float *blk, int lane, unsigned sel, bool h1, const float (&cond)[4],
+                                                               float (&trans)[4]) {
+    const f32x4 bA = *reinterpret_cast<const f32x4 *>(blk + ((size_t)18 * 64 + lane) * 4);   // b1 b2 b3[0] b3[1]
+    const f32x4 bB = *reinterpret_cast<const f32x4 *>(blk + ((size_t)19 * 64 + lane) * 4);   // b3[2] b3[3] - -
+    float wa[8], wb[8];
+    float a0 = bA.x, a1 = 0.f;
+    solo4_load8(wa, blk, 0, lane); solo4_load8(wb, blk, 8, lane);
+    solo_chain_2in(a0, a1, solo_rot8_h1(cond[0]), solo_rot8_h1(cond[1]), wa, wb);
+    solo4_load8(wa, blk, 16, lane); solo4_load8(wb, blk, 24, lane);
+    solo_chain_2in(a0, a1, solo_rot8_h1(cond[2]), solo_rot8_h1(cond[3]), wa, wb);
+    float hid = solo_activate(solo_join(a0 + a1), sel);
+    a0 = bA.y; a1 = 0.f;
+    solo4_load8(wa, blk, 32, lane);
+    solo_chain_1(a0, a1, solo_rot8_h1(hid), wa);
+    hid = solo_activate(solo_join(a0 + a1), sel);
+    const float hin = solo_rot8_h1(hid);
+    float ld = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float o0 = k == 0 ? bA.z : bB.x, o1 = k == 0 ? bA.w : bB.y;
+        solo4_load8(wa, blk, 40 + 16 * k, lane); solo4_load8(wb, blk, 48 + 16 * k, lane);
+        solo_chain_2out(o0, o1, hin, wa, wb);
+        solo_swap16(o0, o1);               // rows h = 0: both halves of output 2 k; rows h = 1: both halves of output 2 k + 1
+        float ls, tt;
+        solo_nets(o0 + o1, ls, tt);
+        const float cur = h1 ? trans[2 * k + 1] : trans[2 * k];
+        float nw = (cur - tt) * __expf(-ls);  // (inputs - t) * exp(-log_s)   networks.py:307-309
+        float nb = nw;
+        solo_swap16(nw, nb);
+        trans[2 * k] = nw;
+        trans[2 * k + 1] = nb;
+        ld -= ls;
+    }
+    return ld;
+}
+
 // ---- likelihoods on a solo wave (the per-term arithmetic of loglike_tile, flow_tile.h; sums over the 16 positions) ----
 #pragma clang fp contract(off)
 template <int U, int LK>   // LK >= 0: the likelihood id is known at compile time (the other branches are not instantiated)
@@ -346,8 +409,16 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
         return;
     }
     {
-        const int n = a.s.nets_params();
-        for (int i = threadIdx.x; i < n; i += blockDim.x) wlds[i] = a.packed[i];
+        if constexpr (U != 4) {
+            const int n = a.s.nets_params();
+            for (int i = threadIdx.x; i < n; i += blockDim.x) wlds[i] = a.packed[i];
+        } else {   // U = 4: net wave b (of waves 0..2) gathers block b's lane shares from the packed vector into the field-major LDS copy
+            if (wave < 3) {
+                SoloNet<4> nb;
+                solo_gather<4>(nb, a.packed + (size_t)(wave * 2 + (lane >= 32 ? 1 : 0)) * a.s.net_params, D, (wave + 1) & 1, wave & 1, lane);
+                solo4_store(wlds, wave, nb, lane);
+            }
+        }
         if (dynamic && use_tab)
             for (int k = threadIdx.x; k < S + 2; k += blockDim.x) etab[k] = exp(1.0 / (double)(1 + k));
     }
@@ -472,19 +543,28 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     const double loglstar = a.loglstar;
     const bool free_mode = (a.flags & NNEST_MH_UNCONSTRAINED) != 0;
 
-    SoloNet<U> net[3];
+    SoloNet<U != 4 ? U : 1> net[U != 4 ? 3 : 1];   // (U = 4: the weights stay in LDS, solo_coupling_inverse4)
+    if constexpr (U != 4) {
 #pragma unroll
-    for (int b = 0; b < 3; ++b)
-        solo_gather<U>(net[b], wlds + (size_t)(b * 2 + (translate_half ? 1 : 0)) * a.s.net_params, D, (b + 1) & 1, b & 1, lane);
+        for (int b = 0; b < 3; ++b)
+            solo_gather<U>(net[b], wlds + (size_t)(b * 2 + (translate_half ? 1 : 0)) * a.s.net_params, D, (b + 1) & 1, b & 1, lane);
+    }
     // NormalizingFlow.inverse (networks.py:34-42), num_blocks = 3: blocks 2, 1, 0; block b conditions on class (b+1)&1 and
     // transforms class b&1
     const unsigned sel = translate_half ? 0xffffffffu : 0u;
     const bool h1 = (lane & 16) != 0;
     auto inverse = [&](float (&xs)[2][U]) {
-        float ld = solo_coupling_inverse<U>(net[2], sel, h1, xs[1], xs[0]);
-        ld += solo_coupling_inverse<U>(net[1], sel, h1, xs[0], xs[1]);
-        ld += solo_coupling_inverse<U>(net[0], sel, h1, xs[1], xs[0]);
-        return ld;
+        if constexpr (U == 4) {
+            float ld = solo_coupling_inverse4(wlds + (size_t)2 * SOLO4_NF * 64, lane, sel, h1, xs[1], xs[0]);
+            ld += solo_coupling_inverse4(wlds + (size_t)1 * SOLO4_NF * 64, lane, sel, h1, xs[0], xs[1]);
+            ld += solo_coupling_inverse4(wlds, lane, sel, h1, xs[1], xs[0]);
+            return ld;
+        } else {
+            float ld = solo_coupling_inverse<U>(net[2], sel, h1, xs[1], xs[0]);
+            ld += solo_coupling_inverse<U>(net[1], sel, h1, xs[0], xs[1]);
+            ld += solo_coupling_inverse<U>(net[0], sel, h1, xs[1], xs[0]);
+            return ld;
+        }
     };
 
     float z[2][U], x[2][U];
@@ -628,7 +708,8 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
 // ------------------------------------------------------------------------------------------------
 bool solo_form_eligible(const MhArgs &a, int num_cu) {
     const FlowShape &s = a.s;
-    if (s.H != 16 || s.B != 3 || s.L != 1 || s.scale_mode != 0 || s.NT < 1 || s.NT > 2) return false;  // 132 weight registers at NT = 2
+    // 132 weight registers at NT = 2; NT = 4 (x_dim 97..128) keeps the weights in LDS; NT = 3 is not instantiated (the quad form runs it)
+    if (s.H != 16 || s.B != 3 || s.L != 1 || s.scale_mode != 0 || !(s.NT == 1 || s.NT == 2 || s.NT == 4)) return false;
     if (a.flags & NNEST_MH_DYNAMIC_STEP) return false;  // the per-16-walker rule belongs to the 16-walker forms
     if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && mh_flag_lag(a.flags) < 3) return false;  // the relay posts step k - 2 in iteration k and asks for step k - lag before that: lag < 3 runs the quad form
     // one workgroup (4 walkers, 5 waves) per CU, every one resident, + the workgroup that publishes the batch totals
@@ -639,7 +720,7 @@ template <int U, bool DBG, int LK>
 static hipError_t launch_solo_k(const MhArgs &a, hipStream_t st) {
     const int batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) ? 1 : 0;
     const int grid = (a.C + 3) / 4 + batch;  // + the workgroup that publishes the batch-wide counts
-    const size_t lds = (size_t)a.s.nets_params() * sizeof(float);
+    const size_t lds = U == 4 ? (size_t)3 * SOLO4_NF * 64 * sizeof(float) : (size_t)a.s.nets_params() * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mh_kernel_solo<U, DBG, LK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -654,10 +735,12 @@ hipError_t launch_mh_solo(const MhArgs &a, hipStream_t st) {
     if (!dbg && a.like.id == NNEST_LIKE_ROSENBROCK) {
         if (a.s.NT == 1) return launch_solo_k<1, false, NNEST_LIKE_ROSENBROCK>(a, st);
         if (a.s.NT == 2) return launch_solo_k<2, false, NNEST_LIKE_ROSENBROCK>(a, st);
+        if (a.s.NT == 4) return launch_solo_k<4, false, NNEST_LIKE_ROSENBROCK>(a, st);
     }
     switch (a.s.NT) {
         case 1: return dbg ? launch_solo_k<1, true, -1>(a, st) : launch_solo_k<1, false, -1>(a, st);
         case 2: return dbg ? launch_solo_k<2, true, -1>(a, st) : launch_solo_k<2, false, -1>(a, st);
+        case 4: return dbg ? launch_solo_k<4, true, -1>(a, st) : launch_solo_k<4, false, -1>(a, st);
     }
     return hipErrorInvalidConfiguration;
 }

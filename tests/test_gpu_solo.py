@@ -41,7 +41,7 @@ def trained(hip):
 
 def test_solo_is_what_config_2_runs(hip):
     """the library's own answer (nnest_mh_form_for): 1000 walkers at x_dim 50 run the solo form under a fixed step and under
-    the batch-wide rule at the default lag; lag 0 / 1 (no time for the relay), the per-group rule, x_dim > 64 and
+    the batch-wide rule at the default lag; lag 0 / 1 (no time for the relay), the per-group rule, x_dim 65..96 and
     populations beyond four walkers per CU go to the other forms"""
     nvp, _, _ = trained(hip)
     assert nvp.mh_form_for(1000) == 'solo' and nvp.mh_form_for(1000, dynamic='batch') == 'solo'
@@ -50,7 +50,9 @@ def test_solo_is_what_config_2_runs(hip):
     assert nvp.mh_form_for(100000, dynamic='batch') is None                    # grid may not be resident: refused
     assert nvp.mh_form_for(1000, form='team') == 'team' and nvp.mh_form_for(5000, form='solo') is None
     big = hip.HipNVP(100, 16, 3, 1, seed=0)
-    assert big.mh_form_for(1000) == 'quad' and big.mh_form_for(8000) == 'image' and big.mh_form_for(8000, form='reg') is None
+    assert big.mh_form_for(1000) == 'solo' and big.mh_form_for(8000) == 'image' and big.mh_form_for(8000, form='reg') is None   # x_dim 97..128: weights in LDS
+    mid = hip.HipNVP(80, 16, 3, 1, seed=0)
+    assert mid.mh_form_for(1000) == 'quad'   # three tiles per class: no solo instantiation
     wide = hip.HipNVP(20, 32, 3, 1, seed=0)
     assert wide.mh_form_for(500) == 'image' and wide.mh_form_for(500, form='quad') is None
 
@@ -95,6 +97,7 @@ def test_solo_inkernel_noise_vs_oracle_per_walker(hip, C, S):
 
 @pytest.mark.parametrize('D,like,scale', [(2, 'rosenbrock', 5.0), (3, 'rosenbrock', 5.0), (20, 'gaussmix', 10.0), (32, 'himmelblau', 5.0),
                                           (33, 'rosenbrock', 5.0), (50, 'rosenbrock', 5.0), (64, 'rosenbrock', 5.0),
+                                          (97, 'rosenbrock', 5.0), (100, 'rosenbrock', 5.0), (128, 'rosenbrock', 5.0), (100, 'gaussmix', 10.0),
                                           (7, 'gaussian', 3.0), (5, 'shell', 6.0), (5, 'double_shell', 6.0), (2, 'eggbox', 15.0)])
 def test_solo_shapes_and_likelihoods_vs_oracle(hip, D, like, scale):
     """x_dim 2..64 (one and two register groups per class, odd sizes, full tiles) and every fused likelihood, fixed step,
@@ -159,6 +162,40 @@ def test_solo_batch_wide_step_rule_vs_oracle(hip, C, lag, warm):
     assert_borderline(cpu(res['hist_x']), so, margins, np.flatnonzero(~same))
     assert rel(cpu(res['hist_x'])[same], so[same]) < 5e-5
     assert rel(cpu(res['hist_logl'])[same], lo[same]) < 5e-5
+
+
+@pytest.mark.parametrize('D,C,lag,warm', [(100, 500, 8, 16), (128, 1000, 4, 0)])
+def test_solo_lds_weights_batch_rule_vs_oracle(hip, D, C, lag, warm):
+    """x_dim 97..128 (the lane's weights in LDS, four slots per class): BASELINE config 5's per-GPU population under the product's
+    step rule, scale sequence and chains against the oracle"""
+    nvp = hip.HipNVP(D, 16, 3, 1, seed=D)
+    o = orc.NVP(D, 16, 3, 1, nvp.store_packed())
+    assert nvp.mh_form_for(C, dynamic='batch', lag=lag, warm=warm) == 'solo'
+    rng = np.random.RandomState(C)
+    init = rng.uniform(-0.5, 0.5, size=(C, D))
+    init_logl = orc.loglike('rosenbrock', init, 5.0)
+    loglstar = float(np.min(init_logl)) - 1e3
+    S, step, seed = 40, 0.05, 7
+    dz, u = nvp.fill_noise(S, C, seed=seed)
+    z, _ = nvp.forward(init)
+    logl = torch.from_numpy(init_logl).cuda()
+    res = nvp.mh_steps(0, 5.0, z, logl, loglstar, step, S, dynamic='batch', lag=lag, warm=warm, seed=seed, history=True)
+    hip.HipNVP.check_sync(res)
+    margins = np.empty((S, C))
+    so, _, lo, sc, ncall, _ = orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, loglstar, step, True, cpu(dz), cpu(u), lag=lag,
+                                              margins=margins, warm=warm)
+    scales = cpu(res['scale'])
+    assert np.all(scales == scales[0]) and abs(float(scales[0]) - sc) < 1e-6 * max(1.0, sc) and sc != step
+    moved_o = np.sum(np.any(so[:, 1:] != so[:, :-1], axis=2), axis=1)
+    same = cpu(res['n_accept']) == moved_o
+    assert np.sum(~same) <= max(1, C // 200)
+    assert_borderline(cpu(res['hist_x']), so, margins, np.flatnonzero(~same))
+    assert rel(cpu(res['hist_x'])[same], so[same]) < 5e-5
+    assert rel(cpu(res['hist_logl'])[same], lo[same]) < 5e-5
+    z2, _ = nvp.forward(init)          # production instantiation (no history): the same final state bit for bit
+    logl2 = torch.from_numpy(init_logl).cuda()
+    res2 = nvp.mh_steps(0, 5.0, z2, logl2, loglstar, step, S, dynamic='batch', lag=lag, warm=warm, seed=seed)
+    assert torch.equal(z2, z) and torch.equal(res2['n_accept'], res['n_accept']) and torch.equal(res2['scale'], res['scale'])
 
 
 def test_solo_agrees_with_the_quad_form_and_shards(hip):

@@ -14,7 +14,7 @@ FORM = sys.argv[2] if len(sys.argv) > 2 else None
 nvp = flow.HipNVP(D, 16, 3, 1, seed=0)
 rng = np.random.RandomState(0)
 for C in (1000, 2000, 4000, 6000, 8000, 12000, 16000, 32768, 131072):
-    S = 50 if C <= 16000 else 20
+    S = int(os.environ.get('K4_STEPS', 50 if C <= 16000 else 20))
     u0 = rng.uniform(-1, 1, size=(C, D))
     z0, _ = nvp.forward(u0)
     l0 = flow.loglike(0, u0, 5.0)
