@@ -228,19 +228,32 @@ static __device__ __forceinline__ void solo4_load8(float (&w)[8], const float *b
 }
 // CouplingLayer.inverse as solo_coupling_inverse<2>, four slots per class: the first layer takes its four inputs as two pairs
 // on the same two accumulators, the last layer's four outputs are two reduce-scattered pairs (row h ends with outputs h and 2 + h)
-static __device__ __forceinline__ float solo_coupling_inverse4(const float *blk, int lane, unsigned sel, bool h1, const float (&cond)[4],
-                                                               float (&trans)[4]) {
-    const f32x4 bA = *reinterpret_cast<const f32x4 *>(blk + ((size_t)18 * 64 + lane) * 4);   // b1 b2 b3[0] b3[1]
-    const f32x4 bB = *reinterpret_cast<const f32x4 *>(blk + ((size_t)19 * 64 + lane) * 4);   // b3[2] b3[3] - -
+struct Solo4Lds {   // a block's weights where they live: the workgroup's LDS copy ...
+    const float *blk; int lane;
+    __device__ __forceinline__ void load8(float (&w)[8], int f0) const { solo4_load8(w, blk, f0, lane); }
+    __device__ __forceinline__ f32x4 bias(int c) const { return *reinterpret_cast<const f32x4 *>(blk + ((size_t)(18 + c) * 64 + lane) * 4); }
+};
+struct Solo4Reg {   // ... or this lane's registers (ONE of the three blocks: a third of the LDS traffic of a step)
+    const SoloNet<4> &n;
+    __device__ __forceinline__ void load8(float (&w)[8], int f0) const {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) w[t] = f0 < 32 ? n.w1[f0 >> 3][t] : (f0 < 40 ? n.w2[t] : n.w3[(f0 - 40) >> 3][t]);
+    }
+    __device__ __forceinline__ f32x4 bias(int c) const { return c == 0 ? (f32x4){n.b1, n.b2, n.b3[0], n.b3[1]} : (f32x4){n.b3[2], n.b3[3], 0.f, 0.f}; }
+};
+template <class W>
+static __device__ __forceinline__ float solo_coupling_inverse4(const W &wsrc, unsigned sel, bool h1, const float (&cond)[4], float (&trans)[4]) {
+    const f32x4 bA = wsrc.bias(0);   // b1 b2 b3[0] b3[1]
+    const f32x4 bB = wsrc.bias(1);   // b3[2] b3[3] - -
     float wa[8], wb[8];
     float a0 = bA.x, a1 = 0.f;
-    solo4_load8(wa, blk, 0, lane); solo4_load8(wb, blk, 8, lane);
+    wsrc.load8(wa, 0); wsrc.load8(wb, 8);
     solo_chain_2in(a0, a1, solo_rot8_h1(cond[0]), solo_rot8_h1(cond[1]), wa, wb);
-    solo4_load8(wa, blk, 16, lane); solo4_load8(wb, blk, 24, lane);
+    wsrc.load8(wa, 16); wsrc.load8(wb, 24);
     solo_chain_2in(a0, a1, solo_rot8_h1(cond[2]), solo_rot8_h1(cond[3]), wa, wb);
     float hid = solo_activate(solo_join(a0 + a1), sel);
     a0 = bA.y; a1 = 0.f;
-    solo4_load8(wa, blk, 32, lane);
+    wsrc.load8(wa, 32);
     solo_chain_1(a0, a1, solo_rot8_h1(hid), wa);
     hid = solo_activate(solo_join(a0 + a1), sel);
     const float hin = solo_rot8_h1(hid);
@@ -248,7 +261,7 @@ static __device__ __forceinline__ float solo_coupling_inverse4(const float *blk,
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         float o0 = k == 0 ? bA.z : bB.x, o1 = k == 0 ? bA.w : bB.y;
-        solo4_load8(wa, blk, 40 + 16 * k, lane); solo4_load8(wb, blk, 48 + 16 * k, lane);
+        wsrc.load8(wa, 40 + 16 * k); wsrc.load8(wb, 48 + 16 * k);
         solo_chain_2out(o0, o1, hin, wa, wb);
         solo_swap16(o0, o1);               // rows h = 0: both halves of output 2 k; rows h = 1: both halves of output 2 k + 1
         float ls, tt;
@@ -543,8 +556,10 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     const double loglstar = a.loglstar;
     const bool free_mode = (a.flags & NNEST_MH_UNCONSTRAINED) != 0;
 
-    SoloNet<U != 4 ? U : 1> net[U != 4 ? 3 : 1];   // (U = 4: the weights stay in LDS, solo_coupling_inverse4)
-    if constexpr (U != 4) {
+    SoloNet<U> net[U != 4 ? 3 : 1];   // (U = 4: blocks 0 and 2 stay in LDS, block 1 in registers, solo_coupling_inverse4)
+    if constexpr (U == 4) {
+        solo_gather<4>(net[0], a.packed + (size_t)(1 * 2 + (translate_half ? 1 : 0)) * a.s.net_params, D, (1 + 1) & 1, 1 & 1, lane);
+    } else {
 #pragma unroll
         for (int b = 0; b < 3; ++b)
             solo_gather<U>(net[b], wlds + (size_t)(b * 2 + (translate_half ? 1 : 0)) * a.s.net_params, D, (b + 1) & 1, b & 1, lane);
@@ -555,9 +570,9 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     const bool h1 = (lane & 16) != 0;
     auto inverse = [&](float (&xs)[2][U]) {
         if constexpr (U == 4) {
-            float ld = solo_coupling_inverse4(wlds + (size_t)2 * SOLO4_NF * 64, lane, sel, h1, xs[1], xs[0]);
-            ld += solo_coupling_inverse4(wlds + (size_t)1 * SOLO4_NF * 64, lane, sel, h1, xs[0], xs[1]);
-            ld += solo_coupling_inverse4(wlds, lane, sel, h1, xs[1], xs[0]);
+            float ld = solo_coupling_inverse4(Solo4Lds{wlds + (size_t)2 * SOLO4_NF * 64, lane}, sel, h1, xs[1], xs[0]);
+            ld += solo_coupling_inverse4(Solo4Reg{net[0]}, sel, h1, xs[0], xs[1]);
+            ld += solo_coupling_inverse4(Solo4Lds{wlds, lane}, sel, h1, xs[1], xs[0]);
             return ld;
         } else {
             float ld = solo_coupling_inverse<U>(net[2], sel, h1, xs[1], xs[0]);
