@@ -84,7 +84,7 @@ enum {
 enum { NNEST_MH_FORM_AUTO = 0, NNEST_MH_FORM_IMAGE = 1, NNEST_MH_FORM_REG = 2, NNEST_MH_FORM_TEAM = 3, NNEST_MH_FORM_QUAD = 4,
        NNEST_MH_FORM_QUAD1 = 5, /* the quad tile with both nets on one wave (same bits as QUAD; A/B diagnostic) */
        NNEST_MH_FORM_SOLO = 6   /* one walker per wave, layers as v_fmac_f32 + DPP row rotations (nnest_solo.hip): <= 4 walkers per CU,
-                                 * x_dim <= 64 or 97..128 (there with the weights in LDS), fixed step or the batch-wide rule at lag >= 3 */ };
+                                 * x_dim <= 128 (beyond 64 with the weights in LDS), fixed step or the batch-wide rule at lag >= 3 */ };
 #define NNEST_MH_FORM(f) (((f) & 15) << 16)
 
 typedef struct nnest_nvp nnest_nvp_t; /* opaque: RealNVP coupling stack + Adam state on one device */

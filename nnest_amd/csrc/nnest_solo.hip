@@ -207,18 +207,19 @@ static __device__ __forceinline__ float solo_logdet_total(float ld) { return sol
 // weights are read into registers right before the layer's chain.  Fields: w1[u][t] at 8 u + t, w2[t] at 32 + t, w3[u][t] at
 // 40 + 8 u + t, b1 72, b2 73, b3[u] 74 + u.
 constexpr int SOLO4_NF = 80;
-static __device__ __forceinline__ void solo4_store(float *base, int b, const SoloNet<4> &n, int lane) {
+template <int U>   // U = 3 or 4: the fields of an absent fourth slot stay unwritten (never read)
+static __device__ __forceinline__ void solo4_store(float *base, int b, const SoloNet<U> &n, int lane) {
     float *q = base + (size_t)b * SOLO4_NF * 64;
     auto put = [&](int f, float v) { q[((size_t)(f >> 2) * 64 + lane) * 4 + (f & 3)] = v; };
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int t = 0; t < 8; ++t) { put(8 * u + t, n.w1[u][t]); put(40 + 8 * u + t, n.w3[u][t]); }
 #pragma unroll
     for (int t = 0; t < 8; ++t) put(32 + t, n.w2[t]);
     put(72, n.b1); put(73, n.b2);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) put(74 + u, n.b3[u]);
+    for (int u = 0; u < 4; ++u) put(74 + u, u < U ? n.b3[u < U ? u : 0] : 0.f);
     put(78, 0.f); put(79, 0.f);
 }
 static __device__ __forceinline__ void solo4_load8(float (&w)[8], const float *blk, int f0, int lane) {
@@ -233,24 +234,35 @@ struct Solo4Lds {   // a block's weights where they live: the workgroup's LDS co
     __device__ __forceinline__ void load8(float (&w)[8], int f0) const { solo4_load8(w, blk, f0, lane); }
     __device__ __forceinline__ f32x4 bias(int c) const { return *reinterpret_cast<const f32x4 *>(blk + ((size_t)(18 + c) * 64 + lane) * 4); }
 };
+template <int U>
 struct Solo4Reg {   // ... or this lane's registers (ONE of the three blocks: a third of the LDS traffic of a step)
-    const SoloNet<4> &n;
+    const SoloNet<U> &n;
     __device__ __forceinline__ void load8(float (&w)[8], int f0) const {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) w[t] = f0 < 32 ? n.w1[f0 >> 3][t] : (f0 < 40 ? n.w2[t] : n.w3[(f0 - 40) >> 3][t]);
+        for (int t = 0; t < 8; ++t) w[t] = f0 < 32 ? n.w1[(f0 >> 3) < U ? (f0 >> 3) : 0][t] : (f0 < 40 ? n.w2[t] : n.w3[((f0 - 40) >> 3) < U ? ((f0 - 40) >> 3) : 0][t]);
     }
-    __device__ __forceinline__ f32x4 bias(int c) const { return c == 0 ? (f32x4){n.b1, n.b2, n.b3[0], n.b3[1]} : (f32x4){n.b3[2], n.b3[3], 0.f, 0.f}; }
+    __device__ __forceinline__ f32x4 bias(int c) const {
+        return c == 0 ? (f32x4){n.b1, n.b2, n.b3[0], n.b3[1]} : (f32x4){n.b3[2], U > 3 ? n.b3[U > 3 ? 3 : 0] : 0.f, 0.f, 0.f};
+    }
 };
-template <class W>
-static __device__ __forceinline__ float solo_coupling_inverse4(const W &wsrc, unsigned sel, bool h1, const float (&cond)[4], float (&trans)[4]) {
+// U = 4: the first layer takes its four inputs as two pairs on the same two accumulators, the last layer's four outputs are two
+// reduce-scattered pairs (row h ends with outputs h and 2 + h).  U = 3 (x_dim 65..96): the third slot goes through the one-slot
+// chains of solo_coupling_inverse<1> -- its output whole in both rows, its log-det counted in the h = 0 rows.
+template <int U, class W>
+static __device__ __forceinline__ float solo_coupling_inverse4(const W &wsrc, unsigned sel, bool h1, const float (&cond)[U], float (&trans)[U]) {
     const f32x4 bA = wsrc.bias(0);   // b1 b2 b3[0] b3[1]
     const f32x4 bB = wsrc.bias(1);   // b3[2] b3[3] - -
     float wa[8], wb[8];
     float a0 = bA.x, a1 = 0.f;
     wsrc.load8(wa, 0); wsrc.load8(wb, 8);
     solo_chain_2in(a0, a1, solo_rot8_h1(cond[0]), solo_rot8_h1(cond[1]), wa, wb);
-    wsrc.load8(wa, 16); wsrc.load8(wb, 24);
-    solo_chain_2in(a0, a1, solo_rot8_h1(cond[2]), solo_rot8_h1(cond[3]), wa, wb);
+    if constexpr (U == 4) {
+        wsrc.load8(wa, 16); wsrc.load8(wb, 24);
+        solo_chain_2in(a0, a1, solo_rot8_h1(cond[2]), solo_rot8_h1(cond[3]), wa, wb);
+    } else {
+        wsrc.load8(wa, 16);
+        solo_chain_1(a0, a1, solo_rot8_h1(cond[2]), wa);
+    }
     float hid = solo_activate(solo_join(a0 + a1), sel);
     a0 = bA.y; a1 = 0.f;
     wsrc.load8(wa, 32);
@@ -259,7 +271,7 @@ static __device__ __forceinline__ float solo_coupling_inverse4(const W &wsrc, un
     const float hin = solo_rot8_h1(hid);
     float ld = 0.f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < U / 2; ++k) {
         float o0 = k == 0 ? bA.z : bB.x, o1 = k == 0 ? bA.w : bB.y;
         wsrc.load8(wa, 40 + 16 * k); wsrc.load8(wb, 48 + 16 * k);
         solo_chain_2out(o0, o1, hin, wa, wb);
@@ -273,6 +285,15 @@ static __device__ __forceinline__ float solo_coupling_inverse4(const W &wsrc, un
         trans[2 * k] = nw;
         trans[2 * k + 1] = nb;
         ld -= ls;
+    }
+    if constexpr (U == 3) {
+        float o0 = bB.x, o1 = 0.f;
+        wsrc.load8(wa, 56);
+        solo_chain_1(o0, o1, hin, wa);
+        float ls, tt;
+        solo_nets(solo_join(o0 + o1), ls, tt);
+        trans[2] = (trans[2] - tt) * __expf(-ls);
+        ld -= h1 ? 0.f : ls;               // the same value in both rows: counted once
     }
     return ld;
 }
@@ -422,14 +443,14 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
         return;
     }
     {
-        if constexpr (U != 4) {
+        if constexpr (U < 3) {
             const int n = a.s.nets_params();
             for (int i = threadIdx.x; i < n; i += blockDim.x) wlds[i] = a.packed[i];
-        } else {   // U = 4: net wave b (of waves 0..2) gathers block b's lane shares from the packed vector into the field-major LDS copy
+        } else {   // U = 3, 4: net wave b (of waves 0..2) gathers block b's lane shares from the packed vector into the field-major LDS copy
             if (wave < 3) {
-                SoloNet<4> nb;
-                solo_gather<4>(nb, a.packed + (size_t)(wave * 2 + (lane >= 32 ? 1 : 0)) * a.s.net_params, D, (wave + 1) & 1, wave & 1, lane);
-                solo4_store(wlds, wave, nb, lane);
+                SoloNet<U> nb;
+                solo_gather<U>(nb, a.packed + (size_t)(wave * 2 + (lane >= 32 ? 1 : 0)) * a.s.net_params, D, (wave + 1) & 1, wave & 1, lane);
+                solo4_store<U>(wlds, wave, nb, lane);
             }
         }
         if (dynamic && use_tab)
@@ -556,9 +577,9 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     const double loglstar = a.loglstar;
     const bool free_mode = (a.flags & NNEST_MH_UNCONSTRAINED) != 0;
 
-    SoloNet<U> net[U != 4 ? 3 : 1];   // (U = 4: blocks 0 and 2 stay in LDS, block 1 in registers, solo_coupling_inverse4)
-    if constexpr (U == 4) {
-        solo_gather<4>(net[0], a.packed + (size_t)(1 * 2 + (translate_half ? 1 : 0)) * a.s.net_params, D, (1 + 1) & 1, 1 & 1, lane);
+    SoloNet<U> net[U < 3 ? 3 : 1];   // (U = 3, 4: blocks 0 and 2 stay in LDS, block 1 in registers, solo_coupling_inverse4)
+    if constexpr (U >= 3) {
+        solo_gather<U>(net[0], a.packed + (size_t)(1 * 2 + (translate_half ? 1 : 0)) * a.s.net_params, D, (1 + 1) & 1, 1 & 1, lane);
     } else {
 #pragma unroll
         for (int b = 0; b < 3; ++b)
@@ -569,10 +590,10 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     const unsigned sel = translate_half ? 0xffffffffu : 0u;
     const bool h1 = (lane & 16) != 0;
     auto inverse = [&](float (&xs)[2][U]) {
-        if constexpr (U == 4) {
-            float ld = solo_coupling_inverse4(Solo4Lds{wlds + (size_t)2 * SOLO4_NF * 64, lane}, sel, h1, xs[1], xs[0]);
-            ld += solo_coupling_inverse4(Solo4Reg{net[0]}, sel, h1, xs[0], xs[1]);
-            ld += solo_coupling_inverse4(Solo4Lds{wlds, lane}, sel, h1, xs[1], xs[0]);
+        if constexpr (U >= 3) {
+            float ld = solo_coupling_inverse4<U>(Solo4Lds{wlds + (size_t)2 * SOLO4_NF * 64, lane}, sel, h1, xs[1], xs[0]);
+            ld += solo_coupling_inverse4<U>(Solo4Reg<U>{net[0]}, sel, h1, xs[0], xs[1]);
+            ld += solo_coupling_inverse4<U>(Solo4Lds{wlds, lane}, sel, h1, xs[1], xs[0]);
             return ld;
         } else {
             float ld = solo_coupling_inverse<U>(net[2], sel, h1, xs[1], xs[0]);
@@ -723,8 +744,8 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
 // ------------------------------------------------------------------------------------------------
 bool solo_form_eligible(const MhArgs &a, int num_cu) {
     const FlowShape &s = a.s;
-    // 132 weight registers at NT = 2; NT = 4 (x_dim 97..128) keeps the weights in LDS; NT = 3 is not instantiated (the quad form runs it)
-    if (s.H != 16 || s.B != 3 || s.L != 1 || s.scale_mode != 0 || !(s.NT == 1 || s.NT == 2 || s.NT == 4)) return false;
+    // 132 weight registers at NT = 2; NT = 3, 4 (x_dim 65..128) keep the weights of two blocks in LDS
+    if (s.H != 16 || s.B != 3 || s.L != 1 || s.scale_mode != 0 || s.NT < 1 || s.NT > 4) return false;
     if (a.flags & NNEST_MH_DYNAMIC_STEP) return false;  // the per-16-walker rule belongs to the 16-walker forms
     if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && mh_flag_lag(a.flags) < 3) return false;  // the relay posts step k - 2 in iteration k and asks for step k - lag before that: lag < 3 runs the quad form
     // one workgroup (4 walkers, 5 waves) per CU, every one resident, + the workgroup that publishes the batch totals
@@ -735,7 +756,7 @@ template <int U, bool DBG, int LK>
 static hipError_t launch_solo_k(const MhArgs &a, hipStream_t st) {
     const int batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) ? 1 : 0;
     const int grid = (a.C + 3) / 4 + batch;  // + the workgroup that publishes the batch-wide counts
-    const size_t lds = U == 4 ? (size_t)3 * SOLO4_NF * 64 * sizeof(float) : (size_t)a.s.nets_params() * sizeof(float);
+    const size_t lds = U >= 3 ? (size_t)3 * SOLO4_NF * 64 * sizeof(float) : (size_t)a.s.nets_params() * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mh_kernel_solo<U, DBG, LK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -750,11 +771,13 @@ hipError_t launch_mh_solo(const MhArgs &a, hipStream_t st) {
     if (!dbg && a.like.id == NNEST_LIKE_ROSENBROCK) {
         if (a.s.NT == 1) return launch_solo_k<1, false, NNEST_LIKE_ROSENBROCK>(a, st);
         if (a.s.NT == 2) return launch_solo_k<2, false, NNEST_LIKE_ROSENBROCK>(a, st);
+        if (a.s.NT == 3) return launch_solo_k<3, false, NNEST_LIKE_ROSENBROCK>(a, st);
         if (a.s.NT == 4) return launch_solo_k<4, false, NNEST_LIKE_ROSENBROCK>(a, st);
     }
     switch (a.s.NT) {
         case 1: return dbg ? launch_solo_k<1, true, -1>(a, st) : launch_solo_k<1, false, -1>(a, st);
         case 2: return dbg ? launch_solo_k<2, true, -1>(a, st) : launch_solo_k<2, false, -1>(a, st);
+        case 3: return dbg ? launch_solo_k<3, true, -1>(a, st) : launch_solo_k<3, false, -1>(a, st);
         case 4: return dbg ? launch_solo_k<4, true, -1>(a, st) : launch_solo_k<4, false, -1>(a, st);
     }
     return hipErrorInvalidConfiguration;

@@ -41,7 +41,7 @@ def trained(hip):
 
 def test_solo_is_what_config_2_runs(hip):
     """the library's own answer (nnest_mh_form_for): 1000 walkers at x_dim 50 run the solo form under a fixed step and under
-    the batch-wide rule at the default lag; lag 0 / 1 (no time for the relay), the per-group rule, x_dim 65..96 and
+    the batch-wide rule at the default lag; lag 0 / 1 (no time for the relay), the per-group rule and
     populations beyond four walkers per CU go to the other forms"""
     nvp, _, _ = trained(hip)
     assert nvp.mh_form_for(1000) == 'solo' and nvp.mh_form_for(1000, dynamic='batch') == 'solo'
@@ -52,7 +52,7 @@ def test_solo_is_what_config_2_runs(hip):
     big = hip.HipNVP(100, 16, 3, 1, seed=0)
     assert big.mh_form_for(1000) == 'solo' and big.mh_form_for(8000) == 'image' and big.mh_form_for(8000, form='reg') is None   # x_dim 97..128: weights in LDS
     mid = hip.HipNVP(80, 16, 3, 1, seed=0)
-    assert mid.mh_form_for(1000) == 'quad'   # three tiles per class: no solo instantiation
+    assert mid.mh_form_for(1000) == 'solo' and mid.mh_form_for(1000, dynamic='batch', lag=0) == 'quad'   # x_dim 65..96: three slots per class
     wide = hip.HipNVP(20, 32, 3, 1, seed=0)
     assert wide.mh_form_for(500) == 'image' and wide.mh_form_for(500, form='quad') is None
 
@@ -97,6 +97,7 @@ def test_solo_inkernel_noise_vs_oracle_per_walker(hip, C, S):
 
 @pytest.mark.parametrize('D,like,scale', [(2, 'rosenbrock', 5.0), (3, 'rosenbrock', 5.0), (20, 'gaussmix', 10.0), (32, 'himmelblau', 5.0),
                                           (33, 'rosenbrock', 5.0), (50, 'rosenbrock', 5.0), (64, 'rosenbrock', 5.0),
+                                          (65, 'rosenbrock', 5.0), (80, 'rosenbrock', 5.0), (96, 'rosenbrock', 5.0), (81, 'gaussmix', 10.0),
                                           (97, 'rosenbrock', 5.0), (100, 'rosenbrock', 5.0), (128, 'rosenbrock', 5.0), (100, 'gaussmix', 10.0),
                                           (7, 'gaussian', 3.0), (5, 'shell', 6.0), (5, 'double_shell', 6.0), (2, 'eggbox', 15.0)])
 def test_solo_shapes_and_likelihoods_vs_oracle(hip, D, like, scale):
@@ -164,9 +165,9 @@ def test_solo_batch_wide_step_rule_vs_oracle(hip, C, lag, warm):
     assert rel(cpu(res['hist_logl'])[same], lo[same]) < 5e-5
 
 
-@pytest.mark.parametrize('D,C,lag,warm', [(100, 500, 8, 16), (128, 1000, 4, 0)])
+@pytest.mark.parametrize('D,C,lag,warm', [(100, 500, 8, 16), (128, 1000, 4, 0), (80, 333, 8, 16)])
 def test_solo_lds_weights_batch_rule_vs_oracle(hip, D, C, lag, warm):
-    """x_dim 97..128 (the lane's weights in LDS, four slots per class): BASELINE config 5's per-GPU population under the product's
+    """x_dim 65..128 (the lane's weights in LDS, three or four slots per class): BASELINE config 5's per-GPU population under the product's
     step rule, scale sequence and chains against the oracle"""
     nvp = hip.HipNVP(D, 16, 3, 1, seed=D)
     o = orc.NVP(D, 16, 3, 1, nvp.store_packed())
