@@ -247,7 +247,7 @@ def main():
         res = nvp.mh_steps(LIKE_ID[like], scale, zs[i], ls[i], loglstar, step_size, S, dynamic=dynamic, lag=lag, seed=42 + i,
                            walker_offset=rank * C, form=form)
         if dist is not None:   # C2: what the nested-sampling loop consumes of a batch, gathered on every rank (device memory)
-            moved = (x_start != res['x']).all(dim=1)
+            moved = res['n_accept'] > 0   # (as nnest_amd/sampler.py::_mcmc_endpoints_fused)
             ends = torch.cat([res['x'].double(), ls[i][:, None], moved[:, None].double()], dim=1)
             dist.all_gather_into_tensor(gathered, ends)
         return res
