@@ -51,8 +51,7 @@ hipError_t launch_loss_grad(const float *packed, const FlowShape &s, const float
 hipError_t launch_vjp(const float *packed, const FlowShape &s, const float *x, const float *gz, float gld, int M, float *grad, float *gx,
                       float *workspace, float *img_fwd, const int *fwd_pos, const int *bwd_pos, hipStream_t st);
 hipError_t launch_adam_packed(float *w, const float *grad, float *m, float *v, int n, int step, float lr, float wd, hipStream_t st);
-hipError_t launch_adam_packed_dev(float *w, const float *grad, float *m, float *v, int n, int *step_dev, float lr, float wd, hipStream_t st,
-                                  const float *loss = nullptr, float *loss_acc = nullptr);
+hipError_t launch_adam_packed_dev(float *w, const float *grad, float *m, float *v, int n, int *step_dev, float lr, float wd, hipStream_t st);
 size_t train_workspace_floats(const FlowShape &s, int batch);
 hipError_t launch_train(float *packed, float *adam_m, float *adam_v, float *best_w, float *img, int *adam_step_dev,
                         const FlowShape &s, const float *xtrain, int n_train, const float *xvalid, int n_valid,

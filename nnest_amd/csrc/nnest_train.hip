@@ -1075,14 +1075,10 @@ __global__ void adam_packed_dev_kernel(float *__restrict__ w, const float *__res
     }
 }
 __global__ void adam_step_advance_kernel(int *step_dev) { *step_dev += 1; }
-// ... and, for an epoch loop queued in one call, the epoch's running loss: acc += the minibatch loss just written
-__global__ void adam_step_advance_acc_kernel(int *step_dev, const float *loss, float *acc) { *step_dev += 1; *acc += *loss; }
 
-hipError_t launch_adam_packed_dev(float *w, const float *grad, float *m, float *v, int n, int *step_dev, float lr, float wd, hipStream_t st,
-                                  const float *loss, float *loss_acc) {
+hipError_t launch_adam_packed_dev(float *w, const float *grad, float *m, float *v, int n, int *step_dev, float lr, float wd, hipStream_t st) {
     hipLaunchKernelGGL(adam_packed_dev_kernel, dim3(64), dim3(256), 0, st, w, grad, m, v, n, step_dev, lr, wd);
-    if (loss && loss_acc) hipLaunchKernelGGL(adam_step_advance_acc_kernel, dim3(1), dim3(1), 0, st, step_dev, loss, loss_acc);
-    else hipLaunchKernelGGL(adam_step_advance_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    hipLaunchKernelGGL(adam_step_advance_kernel, dim3(1), dim3(1), 0, st, step_dev);
     return hipGetLastError();
 }
 
