@@ -11,10 +11,11 @@ mcmc_steps = 5*x_dim = 250 (nnest/nested.py:155-156), NVP hidden 16 / 3 blocks /
 before the timed region.  Synthetic data: u ~ U(-1,1), seeded default-init weights.
 
 N > 1 (one process per GPU, torchrun): the real per-batch data path of a sharded run -- K4 on this rank's shard of the
-walkers, then ONE RCCL all-gather of the chain endpoints [C/N, 2D+1] float64 (C2) -- inside the timed
+walkers, then ONE RCCL all-gather of the chains' ends [C/N, D+2] float64 (C2) -- inside the timed
 region.  --scaling weak (default): 1000 walkers per GPU; --scaling strong: the configuration's population split over
-the ranks (--config 4: Himmelblau x_dim=32, 4000 live points; --config 5: Rosenbrock x_dim=100, 8000 live points), with
-the kernel form of the whole batch pinned on every shard.
+the ranks (--config 4: Himmelblau x_dim=32, 4000 live points; --config 5: Rosenbrock x_dim=100, 8000 live points); as in
+the product, the kernel form of the whole batch is pinned on the shards only under a fixed step (where it makes the
+sharded batch the unsharded one bit for bit) -- under the step rule every rank runs the fastest form of its shard.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
 """
@@ -220,7 +221,7 @@ def main():
     else:
         C_total = args.walkers or N_cfg
         C = -(-C_total // world)
-        form = 'whole batch'   # resolved below: the form the WHOLE batch would run, pinned on every shard
+        form = 'whole batch' if args.fixed_step else None   # resolved below: the form the WHOLE batch would run, pinned on every shard
     S = args.mcmc_steps if args.mcmc_steps > 0 else 5 * D
     nvp = flow.HipNVP(D, H, B, L, device=dev, seed=0)
     rng = np.random.RandomState(1234 + rank)

@@ -159,7 +159,7 @@ class NestedSampler(Sampler):
 
     def _pinned_form(self, C, dynamic=False):
         """the K4 form the WHOLE batch of C chains would run, pinned on every rank's shard so that the sharded batch
-        reproduces the unsharded one bit for bit.  The library is asked (nnest_mh_form_for): which form applies depends on
+        reproduces the unsharded one bit for bit -- under a fixed step or the per-16-walker rule, which are shard-invariant.  The library is asked (nnest_mh_form_for): which form applies depends on
         the flow's shape (x_dim, hidden_dim, num_blocks, num_layers, scale) and on the step rule as well as on the population."""
         if self.mpi_size == 1 or self._fused_like_id is None:
             return None
@@ -167,6 +167,11 @@ class NestedSampler(Sampler):
         if ask is None:
             return None
         mode = 'batch' if dynamic and getattr(self, '_batch_rule_ok', True) else ('group' if dynamic else False)
+        if mode == 'batch':
+            # the batch-wide rule counts per rank: a sharded batch is not the unsharded one whatever the form,
+            # so nothing is pinned and every rank runs the fastest form of its own shard (config 5 on 8 GPUs: the solo form
+            # at 1000 walkers per rank instead of the 8000-walker batch's image form, 4x the step rate)
+            return None
         lag = getattr(self, 'mcmc_step_lag', None)
         return ask(C, dynamic=mode, lag=lag) or ask(C, dynamic='group' if dynamic else False)
 

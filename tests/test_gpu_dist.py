@@ -81,7 +81,8 @@ def _shape_worker(rank, world, port, tmp, D, H, N, out):
         torch.manual_seed(100 + rank)
         s = NestedSampler(D, Rosenbrock(D), transform=lambda x: 5 * x, log_dir=tmp, num_live_points=N, log_level=40, flow='nvp',
                           hidden_dim=H)
-        form = s._pinned_form(N, True)
+        form = s._pinned_form(N, False)   # (what a fixed-step run would pin; under the batch-wide rule nothing is pinned)
+        assert s._pinned_form(N, True) is None or not getattr(s, '_batch_rule_ok', True)
         s.run(strategy=['mcmc'], train_iters=3, mcmc_num_chains=N, mcmc_steps=12, max_iters=N // 4)
         out.put((rank, float(s.logz), int(s.niter), int(s.ncall), float(np.sum(s.samples)), form, int(s.num_batches)))
     finally:
