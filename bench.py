@@ -227,7 +227,6 @@ def main():
     rng = np.random.RandomState(1234 + rank)
     u0 = rng.uniform(-1, 1, size=(C, D))
     z0, _ = nvp.forward(u0)
-    x_start, _ = nvp.inverse(z0)
     logl0 = flow.loglike(LIKE_ID[like], u0, scale, device=dev)
     loglstar = float(logl0.min())
     step_size = 1.0 / np.sqrt(D)
