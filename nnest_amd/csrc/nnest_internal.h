@@ -26,7 +26,7 @@ struct MhArgs;
 bool quad_form_eligible(const MhArgs &a, int num_cu);        // nnest_quad.hip
 hipError_t launch_mh_quad(const MhArgs &a, int num_cu, hipStream_t st);  // nnest_quad.hip
 bool solo_form_eligible(const MhArgs &a, int num_cu);        // nnest_solo.hip
-hipError_t launch_mh_solo(const MhArgs &a, hipStream_t st);  // nnest_solo.hip
+hipError_t launch_mh_solo(const MhArgs &a, int num_cu, hipStream_t st);  // nnest_solo.hip
 int mh_form_for(const FlowShape &s, int C, int flags, int num_cu);
 bool maf_shape_supported(const FlowShape &s);   // maf_kernels.h (nnest_kernels.hip)
 hipError_t launch_maf_repack(const float *packed, float *imgf, float *imgb, const FlowShape &s, hipStream_t st);

@@ -755,7 +755,7 @@ static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
     if (batch && !a.sync) return hipErrorInvalidValue;
     const int form = pick_mh_form<NT, NH, LT>(a, num_cu);
     if (form < 0) return hipErrorInvalidConfiguration;
-    if (form == MH_FORM_SOLO) return launch_mh_solo(a, st);
+    if (form == MH_FORM_SOLO) return launch_mh_solo(a, num_cu, st);
     if (form == MH_FORM_QUAD || form == MH_FORM_QUAD1) return launch_mh_quad(a, num_cu, st);
     if constexpr (LT == 1 && NH == 1) {
         if (form == MH_FORM_TEAM) {

@@ -21,9 +21,10 @@
 // and no workgroup barrier inside the flow.  Per block and U = 2: 40 v_fmac (against 12 MFMA + 9 DPP + 9 permlane + ...),
 // 4 half-joins, 2 net swaps; 44 weight registers per lane and block.
 //
-// One workgroup = four net waves (walkers 4 tile .. 4 tile + 3) + one noise wave that draws the next step's proposal noise
-// (the xoshiro streams of every other form: nnest_mh_fill_noise replays them) and relays the batch-wide step rule
-// (mh_common.h) so that a step of the net waves holds no global-memory operation; ONE workgroup barrier per step.
+// One workgroup = WPG net waves (walkers WPG tile .. WPG tile + WPG - 1; WPG = 4, or 8 / 12 beyond one walker per SIMD: round 4)
+// + one noise wave that draws the next step's proposal noise (the xoshiro streams of every other form: nnest_mh_fill_noise
+// replays them) + one relay wave for the batch-wide step rule (mh_common.h), so that a step of the net waves holds no
+// global-memory operation; ONE workgroup barrier per step.
 // Summation order differs from the other forms (K split in two halves, left to right), so results agree with them (and with a
 // CPU restatement) to rounding, not bitwise; decisions on the same noise are the same except at rounding-borderline ratios.
 #include "mh_common.h"
@@ -43,6 +44,15 @@ static __device__ __forceinline__ float solo_ror(float v) {
 static __device__ __forceinline__ float solo_join(float v) {
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// The same join for a hidden layer's pre-activation, with the NEXT layer's view of it built in: the h = 1 rows consume their
+// layer input rotated by 8 (solo_rot8_h1), and the copy the swap needs anyway can be that rotation -- rows (n, 1) then end with
+// ror8(row(n,0)) + ror8(row(n,1)), bit for bit ror8 of what rows (n, 0) hold.  Saves the row-masked move and its two wait states
+// per hidden layer (activations are elementwise, so they commute with the rotation).
+static __device__ __forceinline__ float solo_join_rot(float v) {
+    float a = v, b;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %1, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
     return a + b;
 }
 // (value held by the scale half, value held by the translate half), in every lane
@@ -73,10 +83,15 @@ struct SoloNet {  // this lane's share of one coupling block (its net n, its K-h
 
 // gather from the packed (block, net) region (LDS copy), state_dict layout W0[H][D] b0[H] W1[H][H] b1[H] Wo[D][H] bo[D]
 // (nnest/networks.py:271-282).  cc / ct: conditioning / transformed parity class of the block.
+// The scale net's hidden layers (the lanes below 32) are stored times 2 log2(e): their sums then are the argument of v_exp_f32
+// itself -- tanh(a) = 1 - 2 / (2^{a 2 log2 e} + 1), solo_activate -- one multiply less per activation on the step's serial chain
+// (the translate half's relu lanes keep their weights as they are).
+constexpr float SOLO_TANH_PRESCALE = 2.8853900817779268f;
 template <int U>
 static __device__ __forceinline__ void solo_gather(SoloNet<U> &n, const float *p, int D, int cc, int ct, int lane) {
     const int H = 16;
     const int pos = lane & 15, h = (lane >> 4) & 1;
+    const float cs = lane < 32 ? SOLO_TANH_PRESCALE : 1.0f;
     const int pb0 = H * D, pW1 = pb0 + H, pb1 = pW1 + H * H, pWo = pb1 + H, pbo = pWo + D * H;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -84,14 +99,14 @@ static __device__ __forceinline__ void solo_gather(SoloNet<U> &n, const float *p
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int d = 2 * U * q + 2 * u + cc;
-            n.w1[u][t] = d < D ? p[pos * D + d] : 0.f;
+            n.w1[u][t] = d < D ? cs * p[pos * D + d] : 0.f;
             const int dO = 2 * U * pos + 2 * u + ct;  // dim of this lane's transformed slot u
             n.w3[u][t] = dO < D ? p[pWo + dO * H + q] : 0.f;
         }
-        n.w2[t] = p[pW1 + pos * H + q];
+        n.w2[t] = cs * p[pW1 + pos * H + q];
     }
-    n.b1 = h == 0 ? p[pb0 + pos] : 0.f;
-    n.b2 = h == 0 ? p[pb1 + pos] : 0.f;
+    n.b1 = h == 0 ? cs * p[pb0 + pos] : 0.f;
+    n.b2 = h == 0 ? cs * p[pb1 + pos] : 0.f;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int dO = 2 * U * pos + 2 * u + ct;
@@ -104,14 +119,30 @@ static __device__ __forceinline__ void solo_gather(SoloNet<U> &n, const float *p
 // inline asm; written statement by statement, hipcc puts an s_nop between every two of them -- it has to assume that an
 // inline asm reading a VGPR the previous instruction wrote might be a DPP read of it (two wait states) -- which at the one
 // instruction per 4 cycles a lone wave issues is a fifth of the layer.  Inside one statement the hazards are ours: the only DPP
-// source is the layer's input, written before the statement (s_nop 1 at its head covers the row-masked pre-rotation right in
-// front of it); the accumulators are plain VOP2 operands, which need no wait states.
+// source is the layer's input, written before the statement; the accumulators are plain VOP2 operands, which need no wait states.
 #define SOLO_D(acc, x, w, t) "v_fmac_f32_dpp %" #acc ", %" #x ", %" #w " row_ror:" #t " row_mask:0xf bank_mask:0xf\n\t"
 #define SOLO_F(acc, x, w) "v_fmac_f32 %" #acc ", %" #x ", %" #w "\n\t"
 
-// a0 += sum_t w0[t] x0[(p - t) & 15],  a1 += sum_t w1[t] x1[(p - t) & 15]   (t = 0..7)
-static __device__ __forceinline__ void solo_chain_2in(float &a0, float &a1, float x0, float x1, const float (&w0)[8], const float (&w1)[8]) {
-    asm("s_nop 1\n\t"
+#define SOLO_M(acc, x, w, t) "v_mul_f32_dpp %" #acc ", %" #x ", %" #w " row_ror:" #t " row_mask:0xf bank_mask:0xf\n\t"
+// Hazards inside a statement are ours: a DPP read needs two wait states behind the VALU write of its source (the layer input,
+// written right in front of the statement).  The two-accumulator chains open with two plain (non-DPP) multiply-adds, which ARE
+// those wait states; the one-input chains open with one, so they carry an s_nop 0.
+// The chains START their accumulators -- a0 = bias + w[0] x (v_fma_f32), a1 = the first product (v_mul_f32) -- instead of
+// adding to registers the caller initialised: a layer's bias is loop-invariant, so a "+v" accumulator cost a v_mov_b32 per
+// accumulator and layer (18 per step) on a wave that issues one instruction per 4 cycles.  The *_acc forms add to what is there.
+// a0 = b0 + sum_t w0[t] x0[(p - t) & 15],  a1 = sum_t w1[t] x1[(p - t) & 15]   (t = 0..7)
+static __device__ __forceinline__ void solo_chain_2in(float &a0, float &a1, float b0, float x0, float x1, const float (&w0)[8], const float (&w1)[8]) {
+    asm(
+        "v_fma_f32 %0, %2, %4, %20\n\t" "v_mul_f32 %1, %3, %12\n\t"
+        SOLO_D(0, 2, 5, 1) SOLO_D(1, 3, 13, 1) SOLO_D(0, 2, 6, 2) SOLO_D(1, 3, 14, 2) SOLO_D(0, 2, 7, 3) SOLO_D(1, 3, 15, 3)
+        SOLO_D(0, 2, 8, 4) SOLO_D(1, 3, 16, 4) SOLO_D(0, 2, 9, 5) SOLO_D(1, 3, 17, 5) SOLO_D(0, 2, 10, 6) SOLO_D(1, 3, 18, 6)
+        SOLO_D(0, 2, 11, 7) SOLO_D(1, 3, 19, 7)
+        : "=&v"(a0), "=&v"(a1)
+        : "v"(x0), "v"(x1), "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]), "v"(w0[4]), "v"(w0[5]), "v"(w0[6]), "v"(w0[7]),
+          "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w1[4]), "v"(w1[5]), "v"(w1[6]), "v"(w1[7]), "v"(b0));
+}
+static __device__ __forceinline__ void solo_chain_2in_acc(float &a0, float &a1, float x0, float x1, const float (&w0)[8], const float (&w1)[8]) {
+    asm(
         SOLO_F(0, 2, 4) SOLO_F(1, 3, 12)
         SOLO_D(0, 2, 5, 1) SOLO_D(1, 3, 13, 1) SOLO_D(0, 2, 6, 2) SOLO_D(1, 3, 14, 2) SOLO_D(0, 2, 7, 3) SOLO_D(1, 3, 15, 3)
         SOLO_D(0, 2, 8, 4) SOLO_D(1, 3, 16, 4) SOLO_D(0, 2, 9, 5) SOLO_D(1, 3, 17, 5) SOLO_D(0, 2, 10, 6) SOLO_D(1, 3, 18, 6)
@@ -120,20 +151,27 @@ static __device__ __forceinline__ void solo_chain_2in(float &a0, float &a1, floa
         : "v"(x0), "v"(x1), "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]), "v"(w0[4]), "v"(w0[5]), "v"(w0[6]), "v"(w0[7]),
           "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w1[4]), "v"(w1[5]), "v"(w1[6]), "v"(w1[7]));
 }
-// a0 += sum_t w0[t] x[(p - t) & 15],  a1 += sum_t w1[t] x[(p - t) & 15]   (one input, two outputs)
-static __device__ __forceinline__ void solo_chain_2out(float &a0, float &a1, float x, const float (&w0)[8], const float (&w1)[8]) {
-    asm("s_nop 1\n\t"
-        SOLO_F(0, 2, 3) SOLO_F(1, 2, 11)
+// a0 = b0 + sum_t w0[t] x[(p - t) & 15],  a1 = b1 + sum_t w1[t] x[(p - t) & 15]   (one input, two outputs)
+static __device__ __forceinline__ void solo_chain_2out(float &a0, float &a1, float b0, float b1, float x, const float (&w0)[8], const float (&w1)[8]) {
+    asm(
+        "v_fma_f32 %0, %2, %3, %19\n\t" "v_fma_f32 %1, %2, %11, %20\n\t"
         SOLO_D(0, 2, 4, 1) SOLO_D(1, 2, 12, 1) SOLO_D(0, 2, 5, 2) SOLO_D(1, 2, 13, 2) SOLO_D(0, 2, 6, 3) SOLO_D(1, 2, 14, 3)
         SOLO_D(0, 2, 7, 4) SOLO_D(1, 2, 15, 4) SOLO_D(0, 2, 8, 5) SOLO_D(1, 2, 16, 5) SOLO_D(0, 2, 9, 6) SOLO_D(1, 2, 17, 6)
         SOLO_D(0, 2, 10, 7) SOLO_D(1, 2, 18, 7)
-        : "+v"(a0), "+v"(a1)
+        : "=&v"(a0), "=&v"(a1)
         : "v"(x), "v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w0[3]), "v"(w0[4]), "v"(w0[5]), "v"(w0[6]), "v"(w0[7]),
-          "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w1[4]), "v"(w1[5]), "v"(w1[6]), "v"(w1[7]));
+          "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(w1[3]), "v"(w1[4]), "v"(w1[5]), "v"(w1[6]), "v"(w1[7]), "v"(b0), "v"(b1));
 }
-// a0 += sum_{t even} w[t] x[(p - t) & 15],  a1 += sum_{t odd} ...   (one input, one output over two accumulators)
-static __device__ __forceinline__ void solo_chain_1(float &a0, float &a1, float x, const float (&w)[8]) {
-    asm("s_nop 1\n\t"
+// a0 = b0 + sum_{t even} w[t] x[(p - t) & 15],  a1 = sum_{t odd} ...   (one input, one output over two accumulators)
+static __device__ __forceinline__ void solo_chain_1(float &a0, float &a1, float b0, float x, const float (&w)[8]) {
+    asm("s_nop 0\n\t"
+        "v_fma_f32 %0, %2, %3, %11\n\t" SOLO_M(1, 2, 4, 1) SOLO_D(0, 2, 5, 2) SOLO_D(1, 2, 6, 3) SOLO_D(0, 2, 7, 4) SOLO_D(1, 2, 8, 5) SOLO_D(0, 2, 9, 6)
+        SOLO_D(1, 2, 10, 7)
+        : "=&v"(a0), "=&v"(a1)
+        : "v"(x), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(b0));
+}
+static __device__ __forceinline__ void solo_chain_1_acc(float &a0, float &a1, float x, const float (&w)[8]) {
+    asm("s_nop 0\n\t"
         SOLO_F(0, 2, 3) SOLO_D(1, 2, 4, 1) SOLO_D(0, 2, 5, 2) SOLO_D(1, 2, 6, 3) SOLO_D(0, 2, 7, 4) SOLO_D(1, 2, 8, 5) SOLO_D(0, 2, 9, 6)
         SOLO_D(1, 2, 10, 7)
         : "+v"(a0), "+v"(a1)
@@ -148,7 +186,8 @@ static __device__ __forceinline__ float solo_rot8_h1(float v) {
 // branch: both sides then run one after the other under exec masks, plus the mask bookkeeping): `sel` is all ones in the
 // translate half; v_bfi_b32 picks the bits
 static __device__ __forceinline__ float solo_activate(float v, unsigned sel) {
-    const float th = fast_tanh(v), rl = fmaxf(v, 0.f);
+    // (scale half: v arrives times 2 log2(e), solo_gather)
+    const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v) + 1.0f), rl = fmaxf(v, 0.f);
     unsigned out;
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(out) : "v"(sel), "v"(__float_as_uint(rl)), "v"(__float_as_uint(th)));
     return __uint_as_float(out);
@@ -165,20 +204,18 @@ static __device__ __forceinline__ void solo_swap16(float &a, float &b) {
 template <int U>
 static __device__ __forceinline__ float solo_coupling_inverse(const SoloNet<U> &w, unsigned sel, bool h1, const float (&cond)[U],
                                                               float (&trans)[U]) {
-    float a0 = w.b1, a1 = 0.f;
+    float a0, a1;
     if constexpr (U == 2) {
-        solo_chain_2in(a0, a1, solo_rot8_h1(cond[0]), solo_rot8_h1(cond[1]), w.w1[0], w.w1[1]);
+        solo_chain_2in(a0, a1, w.b1, solo_rot8_h1(cond[0]), solo_rot8_h1(cond[1]), w.w1[0], w.w1[1]);
     } else {
-        solo_chain_1(a0, a1, solo_rot8_h1(cond[0]), w.w1[0]);
+        solo_chain_1(a0, a1, w.b1, solo_rot8_h1(cond[0]), w.w1[0]);
     }
-    float hid = solo_activate(solo_join(a0 + a1), sel);
-    a0 = w.b2; a1 = 0.f;
-    solo_chain_1(a0, a1, solo_rot8_h1(hid), w.w2);
-    hid = solo_activate(solo_join(a0 + a1), sel);
-    const float hin = solo_rot8_h1(hid);
+    float hid = solo_activate(solo_join_rot(a0 + a1), sel);   // (h = 1 rows: rotated by 8, as the next chain reads it)
+    solo_chain_1(a0, a1, w.b2, hid, w.w2);
+    const float hin = solo_activate(solo_join_rot(a0 + a1), sel);
     if constexpr (U == 2) {
-        float o0 = w.b3[0], o1 = w.b3[1];
-        solo_chain_2out(o0, o1, hin, w.w3[0], w.w3[1]);
+        float o0, o1;
+        solo_chain_2out(o0, o1, w.b3[0], w.b3[1], hin, w.w3[0], w.w3[1]);
         solo_swap16(o0, o1);               // rows h = 0: both halves of output 0; rows h = 1: both halves of output 1
         float ls, tt;
         solo_nets(o0 + o1, ls, tt);
@@ -190,8 +227,8 @@ static __device__ __forceinline__ float solo_coupling_inverse(const SoloNet<U> &
         trans[1] = nb;
         return -ls;
     } else {
-        float o0 = w.b3[0], o1 = 0.f;
-        solo_chain_1(o0, o1, hin, w.w3[0]);
+        float o0, o1;
+        solo_chain_1(o0, o1, w.b3[0], hin, w.w3[0]);
         float ls, tt;
         solo_nets(solo_join(o0 + o1), ls, tt);
         trans[0] = (trans[0] - tt) * __expf(-ls);
@@ -207,7 +244,7 @@ static __device__ __forceinline__ float solo_logdet_total(float ld) { return sol
 // weights are read into registers right before the layer's chain.  Fields: w1[u][t] at 8 u + t, w2[t] at 32 + t, w3[u][t] at
 // 40 + 8 u + t, b1 72, b2 73, b3[u] 74 + u.
 constexpr int SOLO4_NF = 80;
-template <int U>   // U = 3 or 4: the fields of an absent fourth slot stay unwritten (never read)
+template <int U>   // the fields of absent slots stay unwritten (never read)
 static __device__ __forceinline__ void solo4_store(float *base, int b, const SoloNet<U> &n, int lane) {
     float *q = base + (size_t)b * SOLO4_NF * 64;
     auto put = [&](int f, float v) { q[((size_t)(f >> 2) * 64 + lane) * 4 + (f & 3)] = v; };
@@ -242,39 +279,47 @@ struct Solo4Reg {   // ... or this lane's registers (ONE of the three blocks: a 
         for (int t = 0; t < 8; ++t) w[t] = f0 < 32 ? n.w1[(f0 >> 3) < U ? (f0 >> 3) : 0][t] : (f0 < 40 ? n.w2[t] : n.w3[((f0 - 40) >> 3) < U ? ((f0 - 40) >> 3) : 0][t]);
     }
     __device__ __forceinline__ f32x4 bias(int c) const {
-        return c == 0 ? (f32x4){n.b1, n.b2, n.b3[0], n.b3[1]} : (f32x4){n.b3[2], U > 3 ? n.b3[U > 3 ? 3 : 0] : 0.f, 0.f, 0.f};
+        return c == 0 ? (f32x4){n.b1, n.b2, n.b3[0], U > 1 ? n.b3[U > 1 ? 1 : 0] : 0.f}
+                      : (f32x4){U > 2 ? n.b3[U > 2 ? 2 : 0] : 0.f, U > 3 ? n.b3[U > 3 ? 3 : 0] : 0.f, 0.f, 0.f};
     }
 };
-// U = 4: the first layer takes its four inputs as two pairs on the same two accumulators, the last layer's four outputs are two
-// reduce-scattered pairs (row h ends with outputs h and 2 + h).  U = 3 (x_dim 65..96): the third slot goes through the one-slot
-// chains of solo_coupling_inverse<1> -- its output whole in both rows, its log-det counted in the h = 0 rows.
+// The coupling with its weights fetched through a source W (Solo4Lds / Solo4Reg), U = 1..4 -- the arithmetic, operation for
+// operation, of solo_coupling_inverse<U> (U <= 2), so a launch whose weights live in LDS reproduces the register-resident one bit
+// for bit.  U = 4: the first layer takes its four inputs as two pairs on the same two accumulators, the last layer's four outputs
+// are two reduce-scattered pairs (row h ends with outputs h and 2 + h).  Odd U (x_dim 65..96, x_dim <= 32): the last slot goes
+// through the one-slot chains -- its output whole in both rows, its log-det counted in the h = 0 rows.
 template <int U, class W>
 static __device__ __forceinline__ float solo_coupling_inverse4(const W &wsrc, unsigned sel, bool h1, const float (&cond)[U], float (&trans)[U]) {
     const f32x4 bA = wsrc.bias(0);   // b1 b2 b3[0] b3[1]
     const f32x4 bB = wsrc.bias(1);   // b3[2] b3[3] - -
     float wa[8], wb[8];
-    float a0 = bA.x, a1 = 0.f;
-    wsrc.load8(wa, 0); wsrc.load8(wb, 8);
-    solo_chain_2in(a0, a1, solo_rot8_h1(cond[0]), solo_rot8_h1(cond[1]), wa, wb);
+    float a0, a1;
+    if constexpr (U >= 2) {
+        wsrc.load8(wa, 0); wsrc.load8(wb, 8);
+        solo_chain_2in(a0, a1, bA.x, solo_rot8_h1(cond[0]), solo_rot8_h1(cond[U >= 2 ? 1 : 0]), wa, wb);
+    }
     if constexpr (U == 4) {
         wsrc.load8(wa, 16); wsrc.load8(wb, 24);
-        solo_chain_2in(a0, a1, solo_rot8_h1(cond[2]), solo_rot8_h1(cond[3]), wa, wb);
-    } else {
-        wsrc.load8(wa, 16);
-        solo_chain_1(a0, a1, solo_rot8_h1(cond[2]), wa);
+        solo_chain_2in_acc(a0, a1, solo_rot8_h1(cond[U == 4 ? 2 : 0]), solo_rot8_h1(cond[U == 4 ? 3 : 0]), wa, wb);
     }
-    float hid = solo_activate(solo_join(a0 + a1), sel);
-    a0 = bA.y; a1 = 0.f;
+    if constexpr (U == 1) {
+        wsrc.load8(wa, 0);
+        solo_chain_1(a0, a1, bA.x, solo_rot8_h1(cond[0]), wa);
+    }
+    if constexpr (U == 3) {
+        wsrc.load8(wa, 16);
+        solo_chain_1_acc(a0, a1, solo_rot8_h1(cond[U - 1]), wa);
+    }
+    float hid = solo_activate(solo_join_rot(a0 + a1), sel);   // (h = 1 rows: rotated by 8, as the next chain reads it)
     wsrc.load8(wa, 32);
-    solo_chain_1(a0, a1, solo_rot8_h1(hid), wa);
-    hid = solo_activate(solo_join(a0 + a1), sel);
-    const float hin = solo_rot8_h1(hid);
+    solo_chain_1(a0, a1, bA.y, hid, wa);
+    const float hin = solo_activate(solo_join_rot(a0 + a1), sel);
     float ld = 0.f;
 #pragma unroll
     for (int k = 0; k < U / 2; ++k) {
-        float o0 = k == 0 ? bA.z : bB.x, o1 = k == 0 ? bA.w : bB.y;
+        float o0, o1;
         wsrc.load8(wa, 40 + 16 * k); wsrc.load8(wb, 48 + 16 * k);
-        solo_chain_2out(o0, o1, hin, wa, wb);
+        solo_chain_2out(o0, o1, k == 0 ? bA.z : bB.x, k == 0 ? bA.w : bB.y, hin, wa, wb);
         solo_swap16(o0, o1);               // rows h = 0: both halves of output 2 k; rows h = 1: both halves of output 2 k + 1
         float ls, tt;
         solo_nets(o0 + o1, ls, tt);
@@ -286,13 +331,13 @@ static __device__ __forceinline__ float solo_coupling_inverse4(const W &wsrc, un
         trans[2 * k + 1] = nb;
         ld -= ls;
     }
-    if constexpr (U == 3) {
-        float o0 = bB.x, o1 = 0.f;
-        wsrc.load8(wa, 56);
-        solo_chain_1(o0, o1, hin, wa);
+    if constexpr (U & 1) {
+        float o0, o1;
+        wsrc.load8(wa, 40 + 8 * (U - 1));
+        solo_chain_1(o0, o1, U == 1 ? bA.z : bB.x, hin, wa);
         float ls, tt;
         solo_nets(solo_join(o0 + o1), ls, tt);
-        trans[2] = (trans[2] - tt) * __expf(-ls);
+        trans[U - 1] = (trans[U - 1] - tt) * __expf(-ls);
         ld -= h1 ? 0.f : ls;               // the same value in both rows: counted once
     }
     return ld;
@@ -415,12 +460,19 @@ static __device__ __forceinline__ double solo_loglike(const LikeSpec &lk_in, int
 
 static constexpr int SOLO_ETAB = 1024;   // steps + 2 <= SOLO_ETAB: exp(1 / (1 + k)) from a table
 
-template <int U, bool DBG, int LK>
-__global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
+// WPG = walkers (= net waves) per workgroup: 4 (one per SIMD: populations up to 4 x CUs), 8 or 12 (two / three per SIMD; round 4).
+// Beyond one wave per SIMD the register file no longer holds a lane's 132 weights beside the state (9 waves -> 168 registers, 13
+// waves -> 128), so they are read from the workgroup's field-major LDS copy as at x_dim > 64.
+template <int U, int WPG> constexpr bool solo_lds_weights() { return U >= 3 || WPG > 4; }
+template <int U, int WPG> constexpr int solo_reg_blocks() { return !solo_lds_weights<U, WPG>() ? 3 : (WPG == 4 ? 1 : (U <= 2 && WPG == 8 ? 1 : 0)); }
+
+template <int U, bool DBG, int LK, int WPG>
+__global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];  // the packed weights
-    __shared__ __attribute__((aligned(16))) float nbuf[2][4][16][2 * U];
-    __shared__ float ubuf[2][4];
-    __shared__ int acc_lds[2][4];   // batch rule: the four walkers' accepts of a step, posted by the noise wave
+    __shared__ __attribute__((aligned(16))) float nbuf[2][WPG][16][2 * U];
+    __shared__ float ubuf[2][WPG];
+    __shared__ __attribute__((aligned(16))) uint32_t rawbuf[4 * WPG * 8 * U];   // the noise wave's raw draws of a step, stream-major
+    __shared__ int acc_lds[2][WPG];   // batch rule: the walkers' accepts of a step, posted by the noise wave
     __shared__ float fsbuf[2];      // the proposal scale that goes with a noise buffer
     __shared__ float fs_exact;      // warm-up steps of the batch rule: the scale of the next step, known only after this step's votes
     __shared__ double etab[SOLO_ETAB];
@@ -435,7 +487,9 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     // the first `warm` steps apply the rule exactly (lag 0: a grid-wide wait per step) -- where its gain 1 / (1 + n) is large and
     // the scale still far from where it settles -- the rest `lag` steps behind (mh_common.h); at most S - 1
     const int warm = dynamic ? min(mh_flag_warm(a.flags), S - 1) : 0;
-    const int ntiles = (C + 3) >> 2;
+    constexpr bool LDSW = solo_lds_weights<U, WPG>();
+    constexpr int RB = solo_reg_blocks<U, WPG>();
+    const int ntiles = (C + WPG - 1) / WPG;
     if (tile >= ntiles) {
         // batch-wide step rule (mh_common.h): the one workgroup behind the tiles sums every step's counters as soon as they
         // are complete and publishes the total; its other waves leave at once
@@ -443,10 +497,10 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
         return;
     }
     {
-        if constexpr (U < 3) {
+        if constexpr (!LDSW) {
             const int n = a.s.nets_params();
             for (int i = threadIdx.x; i < n; i += blockDim.x) wlds[i] = a.packed[i];
-        } else {   // U = 3, 4: net wave b (of waves 0..2) gathers block b's lane shares from the packed vector into the field-major LDS copy
+        } else {   // net wave b (of waves 0..2) gathers block b's lane shares from the packed vector into the field-major LDS copy
             if (wave < 3) {
                 SoloNet<U> nb;
                 solo_gather<U>(nb, a.packed + (size_t)(wave * 2 + (lane >= 32 ? 1 : 0)) * a.s.net_params, D, (wave + 1) & 1, wave & 1, lane);
@@ -458,17 +512,80 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     }
     __syncthreads();
 
-    if (wave == 4) {
+    if (wave == WPG) {
         // proposal noise: the streams of the 16-walker forms -- per (walker, lane group g) 8 normals for dims
-        // 32 t + 8 g + [0, 8), t < U -- generated by 16 lanes (4 walkers x 4 groups) and written where the net waves read them.
-        // The batch-wide step rule (sampler.py:422-431, `lag` steps behind; mh_common.h) lives here entirely: this wave posts the
+        // 32 t + 8 g + [0, 8), t < U -- generated by 4 WPG lanes (walkers x 4 groups) and written where the net waves read them.
+        // Buffer k carries the noise of step k + 1; its scale (fsbuf) comes from the relay wave under the batch rule.
+        // Round 4: the draws of a stream are sequential, so only 4 WPG lanes can advance the generators -- but the Box-Muller
+        // transform of a draw pair (v_log / v_sqrt / v_sin / v_cos, half of the wave's cycles when 16 lanes did 8 pairs each) is
+        // not: the raw 32-bit draws go through an LDS staging row and all 64 lanes transform WPG U / 8 quads (4 draws -> 4
+        // normals) each, with the arithmetic of box_muller() -- the normals are bit for bit those of XoshiroNoise::next.
+        const int g = lane & 3, j = min(lane >> 2, WPG - 1);
+        const bool gen = lane < 4 * WPG;
+        Xoshiro128 rn = xoshiro_seed(a.seed, a.walker_offset + (uint64_t)(tile * WPG + j), (uint32_t)g, NOISE_STREAM_DZ);
+        Xoshiro128 ru = xoshiro_seed(a.seed, a.walker_offset + (uint64_t)(tile * WPG + j), 0xffffffffu, NOISE_STREAM_U);
+        constexpr int NQ = 8 * WPG * U;   // quads per step: (4 WPG streams) x (2 U quads each)
+        unsigned long long n0 = 0, n1 = 0, n2 = 0, n_gen = 0, n_all = 0;
+        (void)n0; (void)n1; (void)n2; (void)n_gen; (void)n_all;
+        for (int k = 0; k <= S; ++k) {
+            STAMP(n0);
+            if (!recorded) {
+                if (gen) {
+#pragma unroll
+                    for (int t = 0; t < 2 * U; ++t) {   // stream order: tile t / 2, draws 4 (t & 1) .. + 3 of its eight
+                        u32x4 r;
+                        r.x = xoshiro_next(rn); r.y = xoshiro_next(rn); r.z = xoshiro_next(rn); r.w = xoshiro_next(rn);
+                        *reinterpret_cast<u32x4 *>(&rawbuf[lane * 8 * U + 4 * t]) = r;
+                    }
+                    const float u = xoshiro_uniform(ru);
+                    if (g == 0) ubuf[k & 1][j] = u;
+                }
+                float *nb = &nbuf[k & 1][0][0][0];
+#pragma unroll
+                for (int i = 0; i < (NQ + 63) / 64; ++i) {
+                    const int q = lane + 64 * i;
+                    if (NQ % 64 == 0 || q < NQ) {
+                        const u32x4 r = *reinterpret_cast<const u32x4 *>(&rawbuf[4 * q]);
+                        const int sl = q / (2 * U), qq = q % (2 * U);          // stream (walker sl >> 2, lane group sl & 3), quad of the stream
+                        const int d0 = 32 * (qq >> 1) + 8 * (sl & 3) + 4 * (qq & 1);  // first of the quad's four dims (padded dims, d >= D, carry 0)
+                        float o0, o1, o2, o3;
+                        box_muller(r.x, r.y, o0, o1);
+                        box_muller(r.z, r.w, o2, o3);
+                        const f32x4 o = {d0 < D ? o0 : 0.f, d0 + 1 < D ? o1 : 0.f, d0 + 2 < D ? o2 : 0.f, d0 + 3 < D ? o3 : 0.f};
+                        *reinterpret_cast<f32x4 *>(nb + (sl >> 2) * 32 * U + d0) = o;
+                    }
+                }
+            }
+            if (!dynamic && lane == 0) fsbuf[k & 1] = a.step_size;
+            STAMP(n1);
+            if (k >= 2 && k <= warm + 1) {   // warm-up: the relay wave's exchange with the batch sits between A and B
+                solo_barrier();   // A
+                solo_barrier();   // B
+            }
+            solo_barrier();   // publish buffer k
+            STAMP(n2);
+#ifdef NNEST_STAMP
+            n_gen += n1 - n0; n_all += n2 - n0;
+#endif
+        }
+#ifdef NNEST_STAMP
+        if (a.scale_out && lane == 0 && tile == 0) { a.scale_out[4] = (float)n_gen; a.scale_out[5] = (float)n_all; }
+#endif
+#ifndef NNEST_STAMP
+        if (!dynamic && a.scale_out && lane == 0) {   // scale_out has one entry per 16 walkers (nnest_mh_num_groups): the tile that holds a group's first walker reports
+            const int g0 = (tile * WPG + 15) >> 4;
+            if (16 * g0 < (tile + 1) * WPG && 16 * g0 < C) a.scale_out[g0] = a.step_size;
+        }
+#endif
+        return;
+    }
+    if (wave == WPG + 1) {
+        // The batch-wide step rule (sampler.py:422-431, `lag` steps behind; mh_common.h) lives in this wave entirely: it posts the
         // tile's accepted count, learns the batch's votes, keeps (accept, reject, scale) in the reference's float64 arithmetic and
-        // hands the net waves the float32 scale of their next proposal with the noise -- a step of the net waves holds neither a
-        // global-memory operation nor the rule's arithmetic.
-        const int j = lane & 3, g = (lane >> 2) & 3;
-        const bool gen = lane < 16;
-        XoshiroNoise<U> rng;
-        rng.init(a.seed, a.walker_offset + (uint64_t)(tile * 4 + j), g, D);
+        // hands the net waves the float32 scale of their next proposal -- a step of the net waves holds neither a global-memory
+        // operation nor the rule's arithmetic.  (Round 3 had the noise wave do this too: its draws and the rule's round trips
+        // then added up to more than a step of the net waves, who waited ~210 cycles per step at the barrier; as two waves they overlap.)
+        if (!dynamic) return;   // a wave that has ended no longer counts at s_barrier
         double scale = (double)a.step_size;   // python float in the reference (sampler.py:255, :428-431)
         int accept = 0, reject = 0;
         const int last = S - lag;  // last step whose vote is ever applied
@@ -481,65 +598,46 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
         // iterations ago has landed" (vector-memory operations complete in order, MI355X_MICROARCH.md).  The loop runs two
         // iterations per trip: each request has a register pair of its own (qa / qb) and is never moved.
         const unsigned long long *wbase = a.sync + 2 * mh_sync_counter_words(S) + (size_t)(tile & (MH_SYNC_SHARDS - 1)) * MH_SYNC_STRIDE;
-#define SOLO_NOISE_ITERATION(k_, q_)                                                                                        \
+#define SOLO_RELAY_ITERATION(k_, q_)                                                                                        \
         {                                                                                                                   \
             const int k = (k_), want = k - lag;                                                                             \
-            if (dynamic) {                                                                                                  \
-                if (want > warm) {                                                                                          \
-                    asm volatile("s_waitcnt vmcnt(2)" : "+v"(q_) : : "memory");                                             \
-                    const bool up = mh_window_vote(a.sync, S, want, tile, q_, a.sync_err);                                  \
-                    if (up) accept += 1; else reject += 1;                                                                  \
-                    if (accept > reject) scale *= use_tab ? etab[accept] : exp(1.0 / (1 + accept));                         \
-                    if (accept < reject) scale /= use_tab ? etab[reject] : exp(1.0 / (1 + reject));                         \
-                }                                                                                                           \
-                /* between the barriers k - 1 and k the net waves run step k - 1: the accepts of step k - 2 are in LDS */   \
-                /* (no step of its own to post: a zero to the unused slot of step 0 -- every iteration issues the same operations) */ \
-                if (lane == 0) {                                                                                            \
-                    const int *ac = acc_lds[k & 1];                                                                         \
-                    const bool mine = k - 2 > warm; /* (the warm-up posted its steps itself) */                            \
-                    mh_sync_post(a.sync, mine ? k - 2 : 0, tile, mine ? (ac[0] + ac[1]) + (ac[2] + ac[3]) : 0);             \
-                }                                                                                                           \
-                const int ask = min(max(want + 2, 1), max(last, 1));   /* the window of the step needed two iterations on */  \
-                const unsigned long long *wp = wbase + (size_t)((ask - 1) >> 5) * MH_SYNC_SHARDS * MH_SYNC_STRIDE;          \
-                asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(q_) : "v"(wp) : "memory");                        \
+            if (want > warm) {                                                                                              \
+                asm volatile("s_waitcnt vmcnt(2)" : "+v"(q_) : : "memory");                                                 \
+                const bool up = mh_window_vote(a.sync, S, want, tile, q_, a.sync_err);                                      \
+                if (up) accept += 1; else reject += 1;                                                                      \
+                if (accept > reject) scale *= use_tab ? etab[accept] : exp(1.0 / (1 + accept));                             \
+                if (accept < reject) scale /= use_tab ? etab[reject] : exp(1.0 / (1 + reject));                             \
             }                                                                                                               \
+            /* between the barriers k - 1 and k the net waves run step k - 1: the accepts of step k - 2 are in LDS */       \
+            /* (no step of its own to post: a zero to the unused slot of step 0 -- every iteration issues the same operations) */ \
+            if (lane == 0) {                                                                                                \
+                const int *ac = acc_lds[k & 1];                                                                             \
+                const bool mine = k - 2 > warm; /* (the warm-up posted its steps itself) */                                \
+                int acs = 0;                                                                                                \
+                _Pragma("unroll") for (int w_ = 0; w_ < WPG; ++w_) acs += ac[w_];                                           \
+                mh_sync_post(a.sync, mine ? k - 2 : 0, tile, mine ? acs : 0);                                               \
+            }                                                                                                               \
+            const int ask = min(max(want + 2, 1), max(last, 1));   /* the window of the step needed two iterations on */      \
+            const unsigned long long *wp = wbase + (size_t)((ask - 1) >> 5) * MH_SYNC_SHARDS * MH_SYNC_STRIDE;              \
+            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(q_) : "v"(wp) : "memory");                            \
             /* buffer k carries the noise of step k + 1 and its scale: the scale after the votes of the steps <= k - lag */  \
             if (lane == 0) fsbuf[k & 1] = (float)scale;                                                                     \
-            if (gen && !recorded) {                                                                                         \
-                float nz[U][8], u;                                                                                          \
-                rng.next(nz, u);                                                                                            \
-                _Pragma("unroll") for (int t = 0; t < U; ++t)                                                               \
-                    _Pragma("unroll") for (int qq = 0; qq < 8; ++qq) {                                                      \
-                        const int d = 32 * t + 8 * g + qq; /* padded dims (d >= D) carry 0 */                               \
-                        nbuf[k & 1][j][d / (2 * U)][d % (2 * U)] = nz[t][qq];                                               \
-                    }                                                                                                       \
-                if (g == 0) ubuf[k & 1][j] = u;                                                                             \
-            }                                                                                                               \
             solo_barrier(); /* publish buffer k */                                                                          \
         }
         unsigned long long qa = 0, qb = 0;
         int k0 = 0;
         if (warm > 0) {
-            // warm-up: iteration k draws the noise of step k + 1 as always, then -- behind the net waves' step k - 1 (barrier A) --
-            // posts that step's accepts, waits for the batch's vote, applies it and hands over the scale of step k (barrier B)
+            // warm-up: behind the net waves' step k - 1 (barrier A) post that step's accepts, wait for the batch's vote, apply it
+            // and hand over the scale of step k (barrier B)
             for (int k = 0; k <= warm + 1; ++k) {
-                if (gen && !recorded) {
-                    float nz[U][8], u;
-                    rng.next(nz, u);
-#pragma unroll
-                    for (int t = 0; t < U; ++t)
-#pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) {
-                            const int d = 32 * t + 8 * g + qq;
-                            nbuf[k & 1][j][d / (2 * U)][d % (2 * U)] = nz[t][qq];
-                        }
-                    if (g == 0) ubuf[k & 1][j] = u;
-                }
                 if (k >= 2) {
                     solo_barrier();   // A: the net waves have decided step k - 1
                     if (lane == 0) {
                         const int *ac = acc_lds[(k - 1) & 1];
-                        mh_sync_post(a.sync, k - 1, tile, (ac[0] + ac[1]) + (ac[2] + ac[3]));
+                        int acs = 0;
+#pragma unroll
+                        for (int w_ = 0; w_ < WPG; ++w_) acs += ac[w_];
+                        mh_sync_post(a.sync, k - 1, tile, acs);
                     }
                     const bool up = mh_window_vote(a.sync, S, k - 1, tile, 0ull, a.sync_err);
                     if (up) accept += 1; else reject += 1;
@@ -554,14 +652,17 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
             k0 = warm + 2;
         }
         for (int k2 = k0; k2 <= S; k2 += 2) {
-            SOLO_NOISE_ITERATION(k2, qa)
-            if (k2 + 1 <= S) SOLO_NOISE_ITERATION(k2 + 1, qb)
+            SOLO_RELAY_ITERATION(k2, qa)
+            if (k2 + 1 <= S) SOLO_RELAY_ITERATION(k2 + 1, qb)
         }
-#undef SOLO_NOISE_ITERATION
-        if (dynamic) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa), "+v"(qb) : : "memory");   // no request outlives its registers
+#undef SOLO_RELAY_ITERATION
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa), "+v"(qb) : : "memory");   // no request outlives its registers
 #ifndef NNEST_STAMP
-        // scale_out has one entry per 16 walkers (nnest_mh_num_groups): the first tile of each group reports
-        if (a.scale_out && lane == 0 && (tile & 3) == 0) a.scale_out[tile >> 2] = (float)scale;
+        // scale_out has one entry per 16 walkers (nnest_mh_num_groups): the tile that holds a group's first walker reports
+        if (a.scale_out && lane == 0) {
+            const int g0 = (tile * WPG + 15) >> 4;
+            if (16 * g0 < (tile + 1) * WPG && 16 * g0 < C) a.scale_out[g0] = (float)scale;
+        }
 #endif
         return;
     }
@@ -571,15 +672,16 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     const int pos = lane & 15;
     const bool translate_half = lane >= 32;
     const bool writer_lane = lane < 16;  // row (n = 0, h = 0) does the stores
-    const int row = tile * 4 + j;
+    const int row = tile * WPG + j;
     const bool ok = row < C;
     const LikeSpec like = a.like;
     const double loglstar = a.loglstar;
     const bool free_mode = (a.flags & NNEST_MH_UNCONSTRAINED) != 0;
 
-    SoloNet<U> net[U < 3 ? 3 : 1];   // (U = 3, 4: blocks 0 and 2 stay in LDS, block 1 in registers, solo_coupling_inverse4)
-    if constexpr (U >= 3) {
-        solo_gather<U>(net[0], a.packed + (size_t)(1 * 2 + (translate_half ? 1 : 0)) * a.s.net_params, D, (1 + 1) & 1, 1 & 1, lane);
+    SoloNet<U> net[RB > 0 ? RB : 1];   // (weights in LDS: blocks 0 and 2 stay there, block 1 in registers where they fit, solo_coupling_inverse4)
+    if constexpr (LDSW) {
+        if constexpr (RB == 1)
+            solo_gather<U>(net[0], a.packed + (size_t)(1 * 2 + (translate_half ? 1 : 0)) * a.s.net_params, D, (1 + 1) & 1, 1 & 1, lane);
     } else {
 #pragma unroll
         for (int b = 0; b < 3; ++b)
@@ -590,9 +692,10 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
     const unsigned sel = translate_half ? 0xffffffffu : 0u;
     const bool h1 = (lane & 16) != 0;
     auto inverse = [&](float (&xs)[2][U]) {
-        if constexpr (U >= 3) {
+        if constexpr (LDSW) {
             float ld = solo_coupling_inverse4<U>(Solo4Lds{wlds + (size_t)2 * SOLO4_NF * 64, lane}, sel, h1, xs[1], xs[0]);
-            ld += solo_coupling_inverse4<U>(Solo4Reg<U>{net[0]}, sel, h1, xs[0], xs[1]);
+            if constexpr (RB == 1) ld += solo_coupling_inverse4<U>(Solo4Reg<U>{net[0]}, sel, h1, xs[0], xs[1]);
+            else ld += solo_coupling_inverse4<U>(Solo4Lds{wlds + (size_t)1 * SOLO4_NF * 64, lane}, sel, h1, xs[0], xs[1]);
             ld += solo_coupling_inverse4<U>(Solo4Lds{wlds, lane}, sel, h1, xs[1], xs[0]);
             return ld;
         } else {
@@ -725,9 +828,10 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
         }
     }
 #ifdef NNEST_STAMP
-    if (a.scale_out && lane == 0 && tile == 0 && j == 0) {
+    if (a.scale_out && lane == 0 && tile == 0) {
         float *o = a.scale_out;
-        o[0] = (float)a_tot; o[1] = (float)a_prop; o[2] = (float)a_inv; o[3] = (float)a_post;
+        if (j == 0) { o[0] = (float)a_tot; o[1] = (float)a_prop; o[2] = (float)a_inv; o[3] = (float)a_post; }
+        if (j < 4) { o[8 + 2 * j] = (float)a_inv; o[9 + 2 * j] = (float)a_post; }   // the four net waves: which one shares its SIMD with the noise wave
     }
 #endif
     if (writer_lane && ok) {
@@ -742,43 +846,67 @@ __global__ void __launch_bounds__(320) mh_kernel_solo(MhArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// walkers (net waves) per workgroup for a population: 4 while one walker per SIMD covers it, then 8 and 12 (two / three walkers
+// per SIMD: the SIMD issues one vector instruction per 2 cycles, a lone wave one per 4 -- MI355X_MICROARCH.md).  0 = the
+// population does not fit the form (every workgroup must be resident: the batch rule's waits span the grid).
+// NNEST_SOLO_WPG in the environment pins the value (diagnostic: tools/time_k4.py).
+int solo_walkers_per_group(int C, int num_cu) {
+    static const int pinned = [] { const char *e = getenv("NNEST_SOLO_WPG"); return e ? atoi(e) : 0; }();
+    for (int wpg = 4; wpg <= 12; wpg += 4) {
+        if (pinned && wpg != pinned) continue;
+        if ((C + wpg - 1) / wpg + 1 <= num_cu) return wpg;   // + the workgroup that publishes the batch totals
+    }
+    return 0;
+}
+
 bool solo_form_eligible(const MhArgs &a, int num_cu) {
     const FlowShape &s = a.s;
-    // 132 weight registers at NT = 2; NT = 3, 4 (x_dim 65..128) keep the weights of two blocks in LDS
+    // 132 weight registers at NT = 2; NT = 3, 4 (x_dim 65..128) and more than one walker per SIMD keep the weights in LDS
     if (s.H != 16 || s.B != 3 || s.L != 1 || s.scale_mode != 0 || s.NT < 1 || s.NT > 4) return false;
     if (a.flags & NNEST_MH_DYNAMIC_STEP) return false;  // the per-16-walker rule belongs to the 16-walker forms
     if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && mh_flag_lag(a.flags) < 3) return false;  // the relay posts step k - 2 in iteration k and asks for step k - lag before that: lag < 3 runs the quad form
-    // one workgroup (4 walkers, 5 waves) per CU, every one resident, + the workgroup that publishes the batch totals
-    return (a.C + 3) / 4 + 1 <= num_cu;
+    const int wpg = solo_walkers_per_group(a.C, num_cu);
+    if (wpg != 4 && (a.noise_dz || a.hist_x || a.hist_logl)) return false;   // history / recorded noise: the one-walker-per-SIMD build only
+    return wpg != 0;
 }
 
-template <int U, bool DBG, int LK>
+template <int U, bool DBG, int LK, int WPG>
 static hipError_t launch_solo_k(const MhArgs &a, hipStream_t st) {
     const int batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) ? 1 : 0;
-    const int grid = (a.C + 3) / 4 + batch;  // + the workgroup that publishes the batch-wide counts
-    const size_t lds = U >= 3 ? (size_t)3 * SOLO4_NF * 64 * sizeof(float) : (size_t)a.s.nets_params() * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mh_kernel_solo<U, DBG, LK>),
+    const int grid = (a.C + WPG - 1) / WPG + batch;  // + the workgroup that publishes the batch-wide counts
+    const size_t lds = solo_lds_weights<U, WPG>() ? (size_t)3 * SOLO4_NF * 64 * sizeof(float) : (size_t)a.s.nets_params() * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mh_kernel_solo<U, DBG, LK, WPG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mh_kernel_solo<U, DBG, LK>), dim3(grid), dim3(320), lds, st, a);
+    hipLaunchKernelGGL((mh_kernel_solo<U, DBG, LK, WPG>), dim3(grid), dim3(64 * (WPG + 2)), lds, st, a);
     return hipGetLastError();
 }
+template <int U, bool DBG, int LK>
+static hipError_t launch_solo_w(const MhArgs &a, int wpg, hipStream_t st) {
+    if (wpg == 4) return launch_solo_k<U, DBG, LK, 4>(a, st);
+    if constexpr (!DBG) {   // (history / recorded noise: the one-walker-per-SIMD build only)
+        if (wpg == 8) return launch_solo_k<U, DBG, LK, 8>(a, st);
+        if (wpg == 12) return launch_solo_k<U, DBG, LK, 12>(a, st);
+    }
+    return hipErrorInvalidConfiguration;
+}
 
-hipError_t launch_mh_solo(const MhArgs &a, hipStream_t st) {
+hipError_t launch_mh_solo(const MhArgs &a, int num_cu, hipStream_t st) {
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
+    const int wpg = solo_walkers_per_group(a.C, num_cu);
     // the production kernel of the BASELINE likelihood (Rosenbrock) is compiled with the likelihood fixed: the step loop then
     // carries no other likelihood's code (the float64 paths cost 14 spilled registers and a chain of scalar branches per step)
     if (!dbg && a.like.id == NNEST_LIKE_ROSENBROCK) {
-        if (a.s.NT == 1) return launch_solo_k<1, false, NNEST_LIKE_ROSENBROCK>(a, st);
-        if (a.s.NT == 2) return launch_solo_k<2, false, NNEST_LIKE_ROSENBROCK>(a, st);
-        if (a.s.NT == 3) return launch_solo_k<3, false, NNEST_LIKE_ROSENBROCK>(a, st);
-        if (a.s.NT == 4) return launch_solo_k<4, false, NNEST_LIKE_ROSENBROCK>(a, st);
+        if (a.s.NT == 1) return launch_solo_w<1, false, NNEST_LIKE_ROSENBROCK>(a, wpg, st);
+        if (a.s.NT == 2) return launch_solo_w<2, false, NNEST_LIKE_ROSENBROCK>(a, wpg, st);
+        if (a.s.NT == 3) return launch_solo_w<3, false, NNEST_LIKE_ROSENBROCK>(a, wpg, st);
+        if (a.s.NT == 4) return launch_solo_w<4, false, NNEST_LIKE_ROSENBROCK>(a, wpg, st);
     }
     switch (a.s.NT) {
-        case 1: return dbg ? launch_solo_k<1, true, -1>(a, st) : launch_solo_k<1, false, -1>(a, st);
-        case 2: return dbg ? launch_solo_k<2, true, -1>(a, st) : launch_solo_k<2, false, -1>(a, st);
-        case 3: return dbg ? launch_solo_k<3, true, -1>(a, st) : launch_solo_k<3, false, -1>(a, st);
-        case 4: return dbg ? launch_solo_k<4, true, -1>(a, st) : launch_solo_k<4, false, -1>(a, st);
+        case 1: return dbg ? launch_solo_w<1, true, -1>(a, wpg, st) : launch_solo_w<1, false, -1>(a, wpg, st);
+        case 2: return dbg ? launch_solo_w<2, true, -1>(a, wpg, st) : launch_solo_w<2, false, -1>(a, wpg, st);
+        case 3: return dbg ? launch_solo_w<3, true, -1>(a, wpg, st) : launch_solo_w<3, false, -1>(a, wpg, st);
+        case 4: return dbg ? launch_solo_w<4, true, -1>(a, wpg, st) : launch_solo_w<4, false, -1>(a, wpg, st);
     }
     return hipErrorInvalidConfiguration;
 }

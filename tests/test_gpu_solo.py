@@ -46,7 +46,9 @@ def test_solo_is_what_config_2_runs(hip):
     nvp, _, _ = trained(hip)
     assert nvp.mh_form_for(1000) == 'solo' and nvp.mh_form_for(1000, dynamic='batch') == 'solo'
     assert nvp.mh_form_for(1000, dynamic='batch', lag=0) == 'quad' and nvp.mh_form_for(1000, dynamic='batch', lag=2) == 'quad' and nvp.mh_form_for(1000, dynamic='group') in ('team', 'reg', 'image')
-    assert nvp.mh_form_for(2000) == 'quad' and nvp.mh_form_for(4000) == 'team' and nvp.mh_form_for(100000) == 'image'
+    # round 4: two / three walkers per SIMD (8 / 12 net waves per workgroup, weights in LDS) carry the form to 3060 walkers
+    assert nvp.mh_form_for(2000) == 'solo' and nvp.mh_form_for(3000) == 'solo' and nvp.mh_form_for(3061) != 'solo'
+    assert nvp.mh_form_for(4000) == 'team' and nvp.mh_form_for(100000) == 'image'
     assert nvp.mh_form_for(100000, dynamic='batch') is None                    # grid may not be resident: refused
     assert nvp.mh_form_for(1000, form='team') == 'team' and nvp.mh_form_for(5000, form='solo') is None
     big = hip.HipNVP(100, 16, 3, 1, seed=0)

@@ -35,10 +35,12 @@ def timed(**kw):
 
 if len(sys.argv) > 1 and sys.argv[1] == 'stamp':
     for name, kw in (('solo fixed', dict(form='solo')), ('solo batch lag 4', dict(form='solo', warm=0, dynamic='batch', lag=4)),
-                     ('solo batch lag 8', dict(form='solo', warm=0, dynamic='batch', lag=8))):
+                     ('solo batch lag 8', dict(form='solo', warm=0, dynamic='batch', lag=8)), ('solo product rule', dict(form='solo', dynamic='batch'))):
         ms, res = timed(**kw)
         o = res['scale'].cpu().numpy()
-        print('%-18s %.3f ms; cycles per step: total %d  propose+noise %d  inverse %d  post %d' % (name, ms, o[0] / S, o[1] / S, o[2] / S, o[3] / S))
+        print('%-18s %.3f ms; cycles per step: total %d  propose+noise %d  inverse %d  post %d | noise wave: draws %d of %d per iteration | '
+              'inverse / post of the four net waves: %s' % (name, ms, o[0] / S, o[1] / S, o[2] / S, o[3] / S, o[4] / (S + 1), o[5] / (S + 1),
+                                                           ' '.join('%d/%d' % (o[8 + 2 * j] / S, o[9 + 2 * j] / S) for j in range(4))))
     for name, kw in (('quad fixed', dict(form='quad')), ('quad1 fixed', dict(form='quad1')),
                      ('quad batch lag 2', dict(form='quad', dynamic='batch', lag=2)),
                      ('quad batch lag 4', dict(form='quad', dynamic='batch', lag=4)),
