@@ -43,8 +43,12 @@ __device__ __forceinline__ f32x4 ld_sc1_x4_issue(const float *p) {
 }
 __device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// all G workgroups have finished what precedes; `phase` counts barriers (same value in every thread of the grid)
-__device__ __forceinline__ bool grid_barrier(unsigned int *ctr, int &phase, int G, int *err) {
+// all G workgroups have finished what precedes; `phase` counts barriers (same value in every thread of the grid).
+// first_poll_sleep (units of 64 cycles): a poll is a round trip to the memory side (~3 k cycles, measured), and one issued right
+// behind the arrival sees only the workgroups that arrived before it -- behind a phase whose workgroups finish ~1 k cycles apart
+// the early ones miss and pay a second round trip (rows kernel: 2.0 polls per barrier); holding the first poll back by the
+// expected spread makes it the only one.
+__device__ __forceinline__ bool grid_barrier(unsigned int *ctr, int &phase, int G, int *err, int first_poll_sleep = 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores (incl. the asm ones the compiler does not count)
 #ifdef GRID_FENCE
     __threadfence();
@@ -56,6 +60,8 @@ __device__ __forceinline__ bool grid_barrier(unsigned int *ctr, int &phase, int 
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int want = (unsigned int)G * (unsigned int)phase;
         int polls = 0, good = 1;
+        if (first_poll_sleep > 8) __builtin_amdgcn_s_sleep(16);   // (the instruction takes an immediate)
+        else if (first_poll_sleep > 0) __builtin_amdgcn_s_sleep(8);
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             if (++polls > GRID_MAX_POLLS) { good = 0; *err = 1; break; }
             __builtin_amdgcn_s_sleep(1);

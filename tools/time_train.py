@@ -36,4 +36,8 @@ if os.environ.get('NNEST_HIP_LIB', '').endswith('STAMP.so'):   # NNEST_STAMP bui
     res = nvp.train_epochs(live[nv:], live[:nv], perms, None, max_epochs=E, seed=1, jitter=0.01, batch=100, patience=1000)
     ph = res['losses'].cpu().numpy().ravel()[:8] / (E * ((N - nv + 99) // 100))
     print('grid kernel, cycles per minibatch: forward %d  backward+staging %d  barrier %d  weight-gradient jobs + Adam + publish %d  '
-          'barrier %d  loss + image refresh %d' % tuple(ph[:6]))
+          'barrier %d  loss + image refresh %d  [first barrier: drain + workgroup barrier %d cycles, %.2f missed polls]' % tuple(ph[:8]))
+    raw = res['losses'].cpu().numpy().ravel()
+    arr, st = raw[20:20 + 25], raw[50:50 + 25]
+    print('rows kernel, minibatch 20: start of the minibatch per workgroup (10 ns ticks, relative):', (st - st.min()).astype(int).tolist())
+    print('rows kernel, minibatch 20: arrival at the first grid barrier per workgroup (relative to the earliest start):', (arr - st.min()).astype(int).tolist())
