@@ -326,6 +326,42 @@ int nnest_chol_adam_step(nnest_chol_t *chol, const float *grad_dev, float lr, fl
  * a bad argument. */
 long nnest_format_rows_e5(const double *rows_host, long n_rows, int n_cols, char *out_host, long out_cap, int threads);
 
+/* Host-side (no GPU involved): the per-iteration body of the nested-sampling loop while the MCMC strategy is in force --
+ * NestedSampler.run, nnest/nested.py:269-293 (worst live point, evidence update, dead-point append), :429-437 (consume the next
+ * usable chain of the batch), :458-471 (volume shell, remaining-evidence test) -- as ONE call per event instead of ~7 us of
+ * interpreter per iteration (2e5 iterations in a BASELINE config-2 run).  The loop returns to the caller whenever the reference
+ * does something that is not this arithmetic, with the reason:
+ *   NNEST_HOST_FINISHED      fraction_remain <= dlogz or it > max_iters (nested.py:269)
+ *   NNEST_HOST_RETRAIN       first pass, or it % update_interval == 0 at the top of a pass (nested.py:311-314): train, then call
+ *                            again with resume = NNEST_HOST_AFTER_TRAIN
+ *   NNEST_HOST_NEED_SAMPLES  the batch is used up (nested.py:399): run the chains from loglstar (state.loglstar), hand over the new
+ *                            endpoints, nb = 0, resume = NNEST_HOST_AFTER_SAMPLES
+ *   NNEST_HOST_LOG           a point was accepted at it > 0, it % log_interval == 0 (nested.py:439-456, before `it` advances):
+ *                            log, then resume = NNEST_HOST_AFTER_LOG
+ *   NNEST_HOST_CHECKPOINT    `it` has just advanced to a multiple of log_interval (nested.py:473-485); resume = NNEST_HOST_TOP
+ *   NNEST_HOST_DEAD_FULL     the dead-point buffers are full: grow them, resume = NNEST_HOST_TOP (nothing was changed)
+ * Arithmetic: float64, the reference's operations in the reference's order; log Z by logaddexp as numpy computes it (libm exp /
+ * log1p).  The information H is NOT updated here (numpy's vectorised exp is not libm's): per dead point the loop records log Z
+ * before the update (dead_logz_prev), the caller forms the two exponentials with numpy and nnest_host_h_update runs the recurrence.
+ * Dead point k: row dead_v[k] = [v (D) | derived (nd)], dead_logl[k], dead_logwt[k], dead_logz_prev[k]. */
+enum { NNEST_HOST_FINISHED = 0, NNEST_HOST_RETRAIN = 1, NNEST_HOST_NEED_SAMPLES = 2, NNEST_HOST_LOG = 3, NNEST_HOST_CHECKPOINT = 4,
+       NNEST_HOST_DEAD_FULL = 5 };
+enum { NNEST_HOST_TOP = 0, NNEST_HOST_AFTER_TRAIN = 1, NNEST_HOST_AFTER_SAMPLES = 2, NNEST_HOST_AFTER_LOG = 3 };
+typedef struct {
+    double logz, logvol, fraction_remain, max_logl, loglstar;
+    long long it, n_dead;
+    int accept_point, nb, first_time, resume, worst, pad_;
+} nnest_host_state_t;
+int nnest_host_mcmc_consume(nnest_host_state_t *state, int N, int D, int nd, double *active_u, double *active_v, double *active_logl,
+                            double *active_derived, const double *end_u, const double *end_v, const double *end_logl,
+                            const unsigned char *moved, const double *end_derived, int C, double *dead_v, double *dead_logl,
+                            double *dead_logwt, double *dead_logz_prev, long long dead_cap, double dlogz, long long max_iters,
+                            long long update_interval, long long log_interval);
+/* h <- exp(logwt - total) * logl + exp(logz_prev - total) * (h + logz_prev) - total  over n dead points (nested.py:281-283), the two
+ * exponentials supplied by the caller (e1, e2); every operation rounded by itself.  Returns the new h. */
+double nnest_host_h_update(double h, const double *e1, const double *e2, const double *logl, const double *logz_prev,
+                           const double *total, long long n);
+
 #ifdef __cplusplus
 }
 #endif

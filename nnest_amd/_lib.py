@@ -136,7 +136,18 @@ SIGNATURES = {
     'nnest_nvp_loss_grad': [_vp, _vp, _i, _vp, _vp, _vp],
     'nnest_training_jitter': [_vp, _i, _i, _vp, _vp],
     'nnest_format_rows_e5': [_vp, ctypes.c_long, _i, _vp, ctypes.c_long, _i],
+    'nnest_host_mcmc_consume': [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong,
+                                _d, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong],
+    'nnest_host_h_update': [_d, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong],
 }
+HOST_FINISHED, HOST_RETRAIN, HOST_NEED_SAMPLES, HOST_LOG, HOST_CHECKPOINT, HOST_DEAD_FULL = range(6)   # include/nnest_hip.h NNEST_HOST_*
+HOST_TOP, HOST_AFTER_TRAIN, HOST_AFTER_SAMPLES, HOST_AFTER_LOG = range(4)
+
+
+class HostState(ctypes.Structure):   # nnest_host_state_t
+    _fields_ = [('logz', _d), ('logvol', _d), ('fraction_remain', _d), ('max_logl', _d), ('loglstar', _d),
+                ('it', ctypes.c_longlong), ('n_dead', ctypes.c_longlong),
+                ('accept_point', _i), ('nb', _i), ('first_time', _i), ('resume', _i), ('worst', _i), ('pad_', _i)]
 
 _lib = None
 
@@ -152,7 +163,8 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_char_p if name == 'nnest_hip_last_error' else (ctypes.c_long if name == 'nnest_format_rows_e5' else ctypes.c_int)
+            fn.restype = (ctypes.c_char_p if name == 'nnest_hip_last_error' else ctypes.c_long if name == 'nnest_format_rows_e5'
+                          else ctypes.c_double if name == 'nnest_host_h_update' else ctypes.c_int)
         _lib = lib
     return _lib
 

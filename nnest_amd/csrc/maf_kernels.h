@@ -111,6 +111,7 @@ static hipError_t launch_maf_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
     if (form != MH_FORM_AUTO && form != MH_FORM_IMAGE) return hipErrorInvalidConfiguration;
     const bool batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;
     if (batch && !a.sync) return hipErrorInvalidValue;
+    if (batch && mh_flag_lag(a.flags) > 0 && mh_flag_warm(a.flags) > 0) return hipErrorInvalidConfiguration;   // exact warm-up steps: the solo form only (nnest_hip.h)
     int block, grid;
     pick_geometry(ntiles, num_cu, 4, &block, &grid);
     if (batch && grid > num_cu) return hipErrorInvalidConfiguration;  // one workgroup per CU is what is certainly resident

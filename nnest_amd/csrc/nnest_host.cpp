@@ -5,6 +5,7 @@
 // '\n' after every row).  np.savetxt formats row by row in Python (9 us per 52-column row: 1.8 s for a config-2 chain of 2e5
 // rows, 15 % of the run); here blocks of rows are formatted with snprintf("%.5E") -- the C library's correctly rounded
 // conversion, the same digits Python's '%' produces -- on a few threads.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -43,4 +44,87 @@ extern "C" long nnest_format_rows_e5(const double *rows, long n_rows, int n_cols
         total += used[t];
     }
     return total;
+}
+
+// ---- the nested-sampling loop's per-iteration body (include/nnest_hip.h; nnest/nested.py:269-293, :429-437, :458-471) ----
+// numpy's logaddexp (npy_logaddexp): x == y: x + log 2; else the larger + log1p(exp(-|x - y|)); libm exp / log1p
+static inline double host_logaddexp(double x, double y) {
+    if (x == y) return x + 0.693147180559945309417232121458176568;
+    const double t = x - y;
+    if (t > 0) return x + log1p(exp(-t));
+    if (t <= 0) return y + log1p(exp(t));
+    return t;   // NaN
+}
+
+extern "C" int nnest_host_mcmc_consume(nnest_host_state_t *st, int N, int D, int nd, double *active_u, double *active_v,
+                                       double *active_logl, double *active_derived, const double *end_u, const double *end_v,
+                                       const double *end_logl, const unsigned char *moved, const double *end_derived, int C,
+                                       double *dead_v, double *dead_logl, double *dead_logwt, double *dead_logz_prev,
+                                       long long dead_cap, double dlogz, long long max_iters, long long update_interval,
+                                       long long log_interval) {
+    const int W = D + nd;
+    int resume = st->resume;
+    st->resume = NNEST_HOST_TOP;
+    for (;;) {
+        if (resume == NNEST_HOST_TOP) {
+            if (!(st->fraction_remain > dlogz && st->it <= max_iters)) return NNEST_HOST_FINISHED;   // nested.py:269
+            if (st->accept_point && st->n_dead >= dead_cap) return NNEST_HOST_DEAD_FULL;
+            int worst = 0;                                           // np.argmin: the first smallest (nested.py:272)
+            for (int i = 1; i < N; ++i)
+                if (active_logl[i] < active_logl[worst]) worst = i;
+            st->worst = worst;
+            st->loglstar = active_logl[worst];
+            if (st->accept_point) {                                  // nested.py:280-293
+                const double logwt = st->logvol + active_logl[worst];
+                const long long k = st->n_dead;
+                dead_logz_prev[k] = st->logz;
+                st->logz = host_logaddexp(st->logz, logwt);
+                memcpy(dead_v + k * W, active_v + (size_t)worst * D, sizeof(double) * D);
+                if (nd > 0) memcpy(dead_v + k * W + D, active_derived + (size_t)worst * nd, sizeof(double) * nd);
+                dead_logwt[k] = logwt;
+                dead_logl[k] = st->loglstar;
+                st->n_dead = k + 1;
+                st->accept_point = 0;
+            }
+            if (st->first_time || st->it % update_interval == 0) return NNEST_HOST_RETRAIN;   // nested.py:311-314
+        }
+        if (resume == NNEST_HOST_TOP || resume == NNEST_HOST_AFTER_TRAIN) {
+            if (st->nb >= C) return NNEST_HOST_NEED_SAMPLES;         // nested.py:399
+        }
+        if (resume != NNEST_HOST_AFTER_LOG) {
+            const double loglstar = st->loglstar;
+            const int worst = st->worst;
+            while (st->nb < C) {                                     // nested.py:429-437
+                const int cand = st->nb++;
+                if (moved[cand] && end_logl[cand] > loglstar) {
+                    memcpy(active_u + (size_t)worst * D, end_u + (size_t)cand * D, sizeof(double) * D);
+                    memcpy(active_v + (size_t)worst * D, end_v + (size_t)cand * D, sizeof(double) * D);
+                    active_logl[worst] = end_logl[cand];
+                    if (end_logl[cand] > st->max_logl) st->max_logl = end_logl[cand];
+                    if (nd > 0) memcpy(active_derived + (size_t)worst * nd, end_derived + (size_t)cand * nd, sizeof(double) * nd);
+                    st->accept_point = 1;
+                    break;
+                }
+            }
+            if (st->accept_point && st->it > 0 && st->it % log_interval == 0) return NNEST_HOST_LOG;   // nested.py:439-456
+        }
+        resume = NNEST_HOST_TOP;
+        if (st->accept_point) {                                      // nested.py:458-471
+            st->logvol -= 1.0 / (double)N;
+            const double logz_remain = st->max_logl - (double)st->it / (double)N;
+            st->fraction_remain = host_logaddexp(st->logz, logz_remain) - st->logz;
+            st->it += 1;
+            if (st->it > 0 && st->it % log_interval == 0) return NNEST_HOST_CHECKPOINT;   // nested.py:473-485
+        }
+    }
+}
+
+extern "C" double nnest_host_h_update(double h, const double *e1, const double *e2, const double *logl, const double *logz_prev,
+                                      const double *total, long long n) {
+    for (long long k = 0; k < n; ++k) {
+        const double a = e1[k] * logl[k];
+        const double b = e2[k] * (h + logz_prev[k]);
+        h = (a + b) - total[k];
+    }
+    return h;
 }

@@ -934,6 +934,7 @@ int mh_form_for(const FlowShape &s, int C, int flags, int num_cu) {
     if (s.kind == FLOW_KIND_MAF) {   // the image form only (maf_kernels.h)
         const int form = mh_flag_form(flags);
         if (form != MH_FORM_AUTO && form != MH_FORM_IMAGE) return -1;
+        if ((flags & NNEST_MH_DYNAMIC_BATCH) && mh_flag_lag(flags) > 0 && mh_flag_warm(flags) > 0) return -1;
         int block, grid;
         pick_geometry((C + 15) / 16, num_cu, 4, &block, &grid);
         return ((flags & NNEST_MH_DYNAMIC_BATCH) && grid > num_cu) ? -1 : MH_FORM_IMAGE;

@@ -81,8 +81,13 @@ class HipMAF(HipNVP):
             with torch.cuda.device(dev):   # every minibatch of the epoch queued by one library call (nothing read back)
                 _lib.check(self._lib.nnest_maf_train_epoch(self._h, _lib.ptr(rows_all), n_train, int(batch), ctypes.c_float(lr),
                                                            ctypes.c_float(weight_decay), _lib.ptr(tot), _lib.current_stream(dev)))
-            train_loss = float(tot) / n_train                               # trainer.py:403
-            valid_loss = float(-self.log_probs(xvalid).mean()) / n_valid    # trainer.py:405-418
+            # Trainer._validate (trainer.py:405-418): the SUM over minibatches of each minibatch's mean, / len(dataset) -- not the
+            # mean over the whole set (they differ by the number of minibatches, and in detail when the last one is ragged)
+            lp = self.log_probs(xvalid)
+            vsum = torch.stack([-c.mean() for c in lp.split(int(batch))]).sum()
+            both = torch.stack([tot, vsum.to(tot.dtype)]).cpu()             # one read-back per epoch
+            train_loss = float(both[0]) / n_train                           # trainer.py:403
+            valid_loss = float(both[1]) / n_valid
             losses[epoch] = (train_loss, valid_loss)
             epochs_run = epoch + 1
             if valid_loss < best:                                           # trainer.py:205-209

@@ -30,6 +30,9 @@ import time
 import numpy as np
 import torch
 
+import ctypes
+
+from . import _lib
 from .priors import UniformPrior
 from .sampler import Sampler
 from .utils import GrowingNpy
@@ -81,7 +84,8 @@ class NestedSampler(Sampler):
                  fused=True,
                  mcmc_history=False,
                  checkpoint_min_seconds=2.0,
-                 chain_min_seconds=30.0):
+                 chain_min_seconds=30.0,
+                 native_loop=True):
         prior = UniformPrior(x_dim, -1, 1)  # nested.py:76
         super(NestedSampler, self).__init__(x_dim, loglike, transform=transform, append_run_num=append_run_num,
                                             hidden_dim=hidden_dim, num_slow=num_slow, num_derived=num_derived,
@@ -94,6 +98,10 @@ class NestedSampler(Sampler):
         self.num_live_points = num_live_points
         self.checkpoint_min_seconds = checkpoint_min_seconds
         self.chain_min_seconds = chain_min_seconds
+        # native_loop (not in the reference): the per-iteration body of run() under the 'mcmc' strategy in the native library
+        # (nnest_host_mcmc_consume); False = the Python restatement of the same loop below (kept as the readable form and the
+        # cross-check: tests/test_host_nested.py runs both and requires equal trajectories)
+        self.native_loop = native_loop
         self._grow = None
         self.sampler = 'nested'
         if self.single_or_primary_process:
@@ -183,14 +191,164 @@ class NestedSampler(Sampler):
         np.save(os.path.join(cp, 'active_derived_%s.npy' % it), active_derived)
         # the dead points so far: the same three files as the reference (nested.py:479-481), grown by the new rows only
         if getattr(self, '_grow', None) is None:
-            self._grow = {'saved_v': GrowingNpy(os.path.join(cp, 'saved_v.npy'), (self.x_dim + self.num_derived,)),
-                          'saved_logl': GrowingNpy(os.path.join(cp, 'saved_logl.npy'), ()),
-                          'saved_logwt': GrowingNpy(os.path.join(cp, 'saved_logwt.npy'), ())}
+            # (created with the rows there are -- a resumed run's dead points included -- through a temporary file that replaces
+            # the old one: the rows on disk are never gone; run() drops the writers, so every run starts its own files)
+            self._grow = {'saved_v': GrowingNpy(os.path.join(cp, 'saved_v.npy'), (self.x_dim + self.num_derived,), initial=saved_v),
+                          'saved_logl': GrowingNpy(os.path.join(cp, 'saved_logl.npy'), (), initial=saved_logl),
+                          'saved_logwt': GrowingNpy(os.path.join(cp, 'saved_logwt.npy'), (), initial=saved_logwt)}
         self._grow['saved_v'].sync(saved_v)
         self._grow['saved_logl'].sync(saved_logl)
         self._grow['saved_logwt'].sync(saved_logwt)
         with open(os.path.join(cp, 'checkpoint_%s.txt' % it), 'w') as f:
             json.dump(state, f)
+
+    def _mcmc_loop_native(self, loc, strategy, expired_strategies, mcmc_steps, C, dynamic, step_size, train_iters, jitter,
+                          update_interval, log_interval, dlogz, max_iters, primary):
+        """The rest of run()'s while loop once 'mcmc' is the strategy in force: nnest_host_mcmc_consume does the per-iteration
+        body (nested.py:269-293, :429-437, :458-471); this method does what it returns for -- retrain (nested.py:311-314), a new
+        batch of chains (nested.py:399-427), the log line + results.csv row (nested.py:439-456), the checkpoint
+        (nested.py:473-485).  `loc`: run()'s locals at the hand-over.  The trajectory is the Python loop's, value for value
+        (tests/test_reference_trajectory.py runs both)."""
+        lib = _lib.load()
+        N, D, nd = self.num_live_points, self.x_dim, self.num_derived
+        W = D + nd
+        f64 = lambda a, shape: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(shape))
+        active_u, active_v = f64(loc['active_u'], (N, D)), f64(loc['active_v'], (N, D))
+        active_logl, active_derived = f64(loc['active_logl'], (N,)), f64(loc['active_derived'], (N, nd))
+        ev = loc['ev']
+        n0 = len(loc['saved_logl'])
+        cap = max(2 * n0 + 4096, 1 << 16)
+        dead = {'v': np.empty((cap, W)), 'logl': np.empty(cap), 'logwt': np.empty(cap), 'zprev': np.empty(cap)}
+        if n0:
+            dead['v'][:n0] = np.asarray(loc['saved_v'], dtype=np.float64).reshape(n0, W)
+            dead['logl'][:n0], dead['logwt'][:n0] = loc['saved_logl'], loc['saved_logwt']
+        h_upto = n0                       # ev.h covers the dead points [0, h_upto)
+        st = _lib.HostState(logz=ev.logz, logvol=loc['logvol'], fraction_remain=loc['fraction_remain'], max_logl=float(loc['max_logl']),
+                            loglstar=0.0, it=int(loc['it']), n_dead=n0, accept_point=int(loc['accept_point']), nb=C,
+                            first_time=int(loc['first_time']), resume=_lib.HOST_TOP, worst=0, pad_=0)
+        end_u, end_v, end_logl = np.zeros((C, D)), np.zeros((C, D)), np.zeros(C)
+        moved, end_derived = np.zeros(C, dtype=np.uint8), np.zeros((C, nd))
+        total_calls, scale = loc['total_calls'], loc['scale']
+        last_checkpoint = last_chain = time.time()
+        if self.chain_min_seconds <= 0:
+            last_chain = -1e300
+        scalars_upto = st.it
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+        def catch_up():
+            """the information H (nested.py:281-283) over the dead points added since the last call -- the exponentials by numpy,
+            as the reference forms them -- and log Z"""
+            nonlocal h_upto
+            n = st.n_dead
+            if n > h_upto:
+                zprev = dead['zprev'][h_upto:n]
+                total = np.append(zprev[1:], st.logz)   # log Z after the update = log Z before the next one
+                e1, e2 = np.exp(dead['logwt'][h_upto:n] - total), np.exp(zprev - total)
+                logl = np.ascontiguousarray(dead['logl'][h_upto:n])
+                ev.h = float(lib.nnest_host_h_update(ev.h, P(e1), P(e2), P(logl), P(np.ascontiguousarray(zprev)), P(total), n - h_upto))
+                h_upto = n
+            ev.logz = st.logz
+
+        def scalars():
+            """trainer.writer.add_scalar('logz', ev.logz, it) of every accepted point (nested.py:467), in bulk: at step k log Z
+            holds k dead points"""
+            nonlocal scalars_upto
+            if primary and st.it > scalars_upto:
+                ks = np.arange(scalars_upto + 1, st.it + 1)
+                z = np.where(ks < st.n_dead, dead['zprev'][np.minimum(ks, st.n_dead - 1)], st.logz)
+                if hasattr(self.trainer.writer, 'add_scalars'):
+                    self.trainer.writer.add_scalars('logz', ks, z)
+                else:
+                    for k, v in zip(ks, z):
+                        self.trainer.writer.add_scalar('logz', float(v), int(k))
+            scalars_upto = st.it
+
+        while True:
+            reason = lib.nnest_host_mcmc_consume(
+                ctypes.byref(st), N, D, nd, P(active_u), P(active_v), P(active_logl), P(active_derived), P(end_u), P(end_v), P(end_logl),
+                P(moved), P(end_derived), C, P(dead['v']), P(dead['logl']), P(dead['logwt']), P(dead['zprev']), cap, float(dlogz),
+                int(max_iters), int(update_interval), int(log_interval))
+            if reason == _lib.HOST_FINISHED:
+                break
+            if reason == _lib.HOST_DEAD_FULL:
+                cap *= 2
+                for k, a in dead.items():
+                    b = np.empty((cap,) + a.shape[1:])
+                    b[:a.shape[0]] = a
+                    dead[k] = b
+                st.resume = _lib.HOST_TOP
+            elif reason == _lib.HOST_RETRAIN:
+                self._train(active_u, train_iters, jitter)   # nested.py:311-314
+                self.num_retrains += 1
+                st.first_time = 0
+                st.resume = _lib.HOST_AFTER_TRAIN
+            elif reason == _lib.HOST_NEED_SAMPLES:           # nested.py:399-427
+                per = -(-C // self.mpi_size)
+                ctl = np.zeros(per * self.mpi_size + 1, dtype=np.int64)
+                if primary:
+                    idx = np.random.randint(low=0, high=N, size=C)      # nested.py:405
+                    ctl[:-1] = np.resize(idx, per * self.mpi_size)
+                    if self._fused_like_id is not None:   # only the HIP kernel's noise streams consume a seed
+                        ctl[-1] = self._next_seed() & 0x7FFFFFFFFFFFFFFF
+                ctl = self._broadcast(ctl)
+                lo = self.mpi_rank * per
+                my = ctl[lo:lo + per]
+                kw = dict(init_samples=active_u[my, :], init_loglikes=active_logl[my], loglstar=st.loglstar,
+                          walker_offset=lo, seed=int(ctl[-1]), form=self._pinned_form(C, dynamic))
+                if self._fused_like_id is not None and nd == 0:
+                    ends, scale, nc = self._mcmc_endpoints_fused(mcmc_steps, step_size, dynamic, **kw)
+                else:
+                    s_x, _lat, s_d, s_l, scale, nc = self._mcmc_sample(
+                        mcmc_steps, step_size=step_size, dynamic_step_size=dynamic,
+                        init_derived=active_derived[my, :] if nd > 0 else np.empty((per, 0)), **kw)
+                    mv = np.all(s_x[:, 0, :] != s_x[:, -1, :], axis=1)   # a chain is usable if every coordinate moved (nested.py:432)
+                    ends = np.concatenate([s_x[:, -1, :], s_l[:, -1:], mv[:, None], s_d[:, -1, :]], axis=1).astype(np.float64)
+                ends = self._all_gather_rows(ends)[:C]
+                ends = ends.cpu().numpy() if torch.is_tensor(ends) else ends
+                end_u[:] = ends[:, :D]
+                end_logl[:] = ends[:, D]
+                moved[:] = ends[:, D + 1] != 0
+                if nd > 0:
+                    end_derived[:] = ends[:, D + 2:]
+                end_v[:] = self.transform(end_u)
+                self.num_batches += 1
+                total_calls = int(self._all_sum(self.total_calls))
+                st.nb = 0
+                st.resume = _lib.HOST_AFTER_SAMPLES
+            elif reason == _lib.HOST_LOG:                    # nested.py:439-456 (before `it` advances)
+                if primary:
+                    acc = self.total_accepted / max(1, self.total_accepted + self.total_rejected)
+                    self.logger.info('Step [%d] loglstar [%5.4e] maxlogl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
+                                     'scale [%5.4f]' % (st.it, st.loglstar, st.max_logl, st.logz, np.exp(-st.it / N), total_calls, scale))
+                    with open(os.path.join(self.logs['results'], 'results.csv'), 'a') as f:
+                        csv.writer(f).writerow([st.it, acc, float('nan'), float('nan'), float('nan'), scale, np.float64(st.loglstar),
+                                                np.float64(st.logz), np.float64(st.fraction_remain), total_calls])
+                st.resume = _lib.HOST_AFTER_LOG
+            elif reason == _lib.HOST_CHECKPOINT:             # nested.py:473-485
+                scalars()
+                if primary and time.time() - last_checkpoint >= self.checkpoint_min_seconds:
+                    last_checkpoint = time.time()
+                    catch_up()
+                    n = st.n_dead
+                    self._checkpoint(st.it, active_u, active_v, active_logl, active_derived, dead['v'][:n], dead['logl'][:n],
+                                     dead['logwt'][:n],
+                                     {'logz': ev.logz, 'h': ev.h, 'logvol': st.logvol, 'ncall': total_calls,
+                                      'fraction_remain': st.fraction_remain, 'strategy': strategy,
+                                      'expired_strategies': expired_strategies})
+                    if last_checkpoint - last_chain >= self.chain_min_seconds:
+                        last_chain = last_checkpoint
+                        self.samples = np.array(dead['v'][:n])
+                        self.weights = np.exp(dead['logwt'][:n] - ev.logz)
+                        self.loglikes = np.array(dead['logl'][:n])
+                        self._save_samples(self.samples, self.loglikes, weights=self.weights)
+                st.resume = _lib.HOST_TOP
+            else:
+                raise RuntimeError('nnest_host_mcmc_consume returned %d' % reason)
+        scalars()
+        catch_up()
+        n = st.n_dead
+        return (active_u, active_v, active_logl, active_derived, list(dead['v'][:n]), list(dead['logl'][:n]), list(dead['logwt'][:n]),
+                ev, st.logvol, st.fraction_remain, int(st.it), total_calls, scale)
 
     # ---- the run ----------------------------------------------------------------------------------------------
     def run(self,
@@ -218,6 +376,8 @@ class NestedSampler(Sampler):
         # mcmc_step_warm (not in the reference): with a lagged rule, the first so many steps of every launch apply it exactly
         # (NNEST_MH_WARM); None = the kernel form's default
         self.mcmc_step_warm = mcmc_step_warm
+        self._grow = None   # the dead-point files of a previous run() on this object are not this run's
+        self._prior_cache = None   # (nor are the prior candidates it left unexamined: a reseeded run must not depend on them)
         if strategy is None or len(strategy) == 0:
             strategy = ['rejection_prior', 'mcmc']
         for s in strategy:
@@ -333,6 +493,16 @@ class NestedSampler(Sampler):
         # the reference takes np.max over the live points at every iteration, nested.py:461 -- the same value)
         max_logl = np.max(active_logl)
         while fraction_remain > dlogz and it <= max_iters:
+            if self.native_loop and _first_live(strategy, expired_strategies) == 'mcmc':
+                # From here on the strategy in force is 'mcmc' for good (strategies only expire, nested.py:300-306, and 'mcmc'
+                # never does): the per-iteration body runs in the native library, which returns for everything that is not
+                # that arithmetic (nnest_host_mcmc_consume, include/nnest_hip.h)
+                native = self._mcmc_loop_native(
+                    locals(), strategy, expired_strategies, mcmc_steps, mcmc_num_chains, mcmc_dynamic_step_size, step_size, train_iters,
+                    jitter, update_interval, log_interval, dlogz, max_iters, primary)
+                (active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt, ev, logvol, fraction_remain, it,
+                 total_calls, scale) = native
+                break
             worst = int(np.argmin(active_logl))              # nested.py:272
             logwt = logvol + active_logl[worst]
             loglstar = active_logl[worst]

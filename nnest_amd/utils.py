@@ -58,6 +58,14 @@ class ScalarWriter(object):
         if len(self._buf) >= 256:
             self.flush()
 
+    def add_scalars(self, tag, steps, values):
+        """add_scalar for a run of steps at once (the native nested-sampling loop reports log Z per accepted point in bulk)"""
+        if self.path is None:
+            return
+        self._buf.extend('%s,%s,%r\n' % (tag, int(k), float(v)) for k, v in zip(steps, values))
+        if len(self._buf) >= 256:
+            self.flush()
+
     def add_figure(self, *a, **k):
         pass
 
@@ -81,10 +89,11 @@ class GrowingNpy(object):
     any other .npy at any time between two `sync` calls."""
     HEADER_BYTES = 128
 
-    def __init__(self, path, row_shape):
-        self.path, self.row_shape, self.rows = path, tuple(int(v) for v in row_shape), 0
-        with open(path, 'wb') as f:
-            f.write(self._header(0))
+    def __init__(self, path, row_shape, initial=None):
+        """initial: rows the file starts with (a run resumed from a checkpoint: the dead points read back) -- written to a
+        temporary file that then REPLACES `path`, so the rows on disk are never gone, whoever wrote `path` before"""
+        self.path, self.row_shape = path, tuple(int(v) for v in row_shape)
+        self._rewrite(initial)
 
     def _header(self, n):
         d = "{'descr': '<f8', 'fortran_order': False, 'shape': %s, }" % (repr((n,) + self.row_shape),)
@@ -92,10 +101,23 @@ class GrowingNpy(object):
         assert len(d) < body
         return b'\x93NUMPY\x01\x00' + np.uint16(body).tobytes() + (d + ' ' * (body - 1 - len(d)) + '\n').encode('latin1')
 
+    def _rewrite(self, rows):
+        n = 0 if rows is None else len(rows)
+        tmp = self.path + '.tmp'
+        with open(tmp, 'wb') as f:
+            f.write(self._header(n))
+            if n:
+                f.write(np.ascontiguousarray(np.asarray(rows, dtype=np.float64)).reshape((n,) + self.row_shape).tobytes())
+        os.replace(tmp, self.path)
+        self.rows = n
+
     def sync(self, rows):
-        """`rows`: the complete sequence so far (list of rows or array); rows beyond those already on disk are appended"""
+        """`rows`: the complete sequence so far (list of rows or array); rows beyond those already on disk are appended.  A
+        sequence SHORTER than the file (a new run on the same object) rewrites the file."""
         n = len(rows)
-        if n > self.rows:
+        if n < self.rows:
+            self._rewrite(rows)
+        elif n > self.rows:
             new = np.ascontiguousarray(np.asarray(rows[self.rows:n], dtype=np.float64)).reshape((n - self.rows,) + self.row_shape)
             with open(self.path, 'r+b') as f:
                 f.seek(0, 2)

@@ -256,3 +256,63 @@ def test_solo_golden_trace_recorded_noise(hip):
     assert int(res['n_call'].sum()) == int(g['ncall']) and int(res['n_accept'].sum()) == int(g['total_accepted'])
     assert rel(cpu(res['hist_x']), g['samples']) < 3e-5 and rel(cpu(res['hist_logl']), g['loglikes']) < 3e-5
     assert rel(cpu(z), g['latent'][:, -1]) < 3e-5
+
+
+@pytest.mark.parametrize('C', [1000, 2000, 3000])
+def test_eight_and_twelve_walkers_per_workgroup_run_the_same_chains(hip, C):
+    """Round 4: beyond 4 walkers per compute unit the solo form puts 8 / 12 net waves in a workgroup and reads its weights from
+    LDS (nnest_solo.hip: solo_walkers_per_group).  A walker's chain must not depend on how many walkers share its workgroup:
+    the first 1000 walkers of a 2000- / 3000-walker launch under a fixed step are, bit for bit, the 1000-walker launch (4 per
+    workgroup, weights in registers), and every walker is replayed through the oracle on the kernel's own noise."""
+    nvp, o, g = trained(hip)
+    assert nvp.mh_form_for(C) == 'solo'
+    rng = np.random.RandomState(5)
+    init = g['init'][rng.randint(0, g['init'].shape[0], size=C)]
+    z0, _ = nvp.forward(init)
+    l0 = hip.loglike(0, init, 5.0)
+    star, S = float(np.median(cpu(l0))) - 50.0, 40
+    out = {}
+    for n in (1000, C):
+        z, l = z0[:n].clone(), l0[:n].clone()
+        res = nvp.mh_steps(0, 5.0, z, l, star, 0.05, S, seed=11)
+        out[n] = (cpu(z), cpu(l), cpu(res['n_accept']), cpu(res['n_call']), cpu(res['x']))
+    for a, b in zip(out[1000], out[C]):
+        assert np.array_equal(a, b[:1000])
+    # and under the batch-wide rule (exact steps, then lagged) the larger launch follows the oracle's replay of its own noise
+    init_logl = orc.loglike('rosenbrock', init, 5.0)
+    z = z0.clone()
+    l = torch.from_numpy(init_logl).cuda()
+    res = nvp.mh_steps(0, 5.0, z, l, star, 0.3, S, seed=12, dynamic='batch', lag=3, warm=4)
+    nvp.check_sync(res)
+    dz, u = nvp.fill_noise(S, C, seed=12)
+    margins = np.empty((S, C))
+    so, _, lo, sc, ncall, _ = orc.mcmc_sample(o, 'rosenbrock', 5.0, init, init_logl, star, 0.3, True, cpu(dz), cpu(u), lag=3, margins=margins, warm=4)
+    scales = cpu(res['scale'])
+    assert np.all(scales == scales[0]) and abs(float(scales[0]) - sc) < 1e-6 * max(1.0, sc) and sc != 0.3
+    moved_o = np.sum(np.any(so[:, 1:] != so[:, :-1], axis=2), axis=1)
+    same = cpu(res['n_accept']) == moved_o
+    assert np.sum(~same) <= max(1, C // 200)
+    assert rel(cpu(res['x'])[same], so[same, -1]) < 5e-5
+
+
+def test_usable_chain_flag_from_the_accept_count(hip):
+    """ADVICE r03 / stated deviation: the driver marks a chain usable when the kernel's accept count is non-zero, where the
+    reference tests that every coordinate of x moved (nested.py:432: samples[:, 0] != samples[:, -1]).  The two agree whenever an
+    accepted latent move displaces every float32 coordinate -- checked here over a launch at a late-run proposal scale, and at a
+    scale a hundred times below anything the step rule reaches -- and every form writes both counters of every walker (the driver
+    allocates them uninitialised)."""
+    nvp, o, g = trained(hip)
+    for C, step in ((1000, 0.05), (1000, 5e-4), (2000, 0.02), (4000, 0.02)):
+        rng = np.random.RandomState(C)
+        init = g['init'][rng.randint(0, g['init'].shape[0], size=C)]
+        z0, _ = nvp.forward(init)
+        x0, _ = nvp.inverse(z0)
+        l0 = hip.loglike(0, init, 5.0)
+        z, l = z0.clone(), l0.clone()
+        star = float(np.median(cpu(l0)))
+        res = nvp.mh_steps(0, 5.0, z, l, star, step, 60, seed=3, dynamic='batch')
+        nvp.check_sync(res)
+        na, nc = cpu(res['n_accept']), cpu(res['n_call'])
+        assert np.all((na >= 0) & (na <= 60) & (nc >= na) & (nc <= 60))      # written for every walker, by every form
+        moved_ref = np.all(cpu(x0) != cpu(res['x']), axis=1)
+        assert np.array_equal(moved_ref, na > 0), (C, step, int(np.sum(moved_ref != (na > 0))))
