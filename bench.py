@@ -97,7 +97,7 @@ def cpu_baseline(D, w, like, scale, walkers, target_seconds=10.0):
                           walkers, steps_all, threads, cores)}
 
 
-def committed_traffic(kernel, tag='r03'):
+def committed_traffic(kernel, tag='r04'):
     """HBM bytes per K4 launch from this round's committed rocprofv3 PMC passes of THIS command (scripts/profile_bench.sh ->
     profiles/<tag>/bench_pmc.json); None when the profile is absent or was taken on another kernel than the one that just ran"""
     path = os.path.join(ROOT, 'profiles', tag, 'bench_pmc.json')
@@ -160,10 +160,40 @@ def logz_report(dev, live_run):
         torch.manual_seed(0)
         s = NestedSampler(50, Rosenbrock(50), transform=lambda x: 5.0 * x, log_dir=tempfile.mkdtemp(dir='/tmp'),
                           num_live_points=1000, log_level=40, flow='nvp')
+        # where the wall time of the run goes: both wrapped calls end in a read-back (the training result / the batch's counts), so
+        # the wall time around them is the kernel's time plus its launch and read-back
+        from nnest_amd import flow as _flow
+        split = {'k5_s': 0.0, 'k4_s': 0.0, 'k5_calls': 0, 'k4_calls': 0, 'epochs': 0}
+        _te, _ef = _flow.HipNVP.train_epochs, type(s)._mcmc_endpoints_fused
+
+        def te(self, *a, **k):
+            t = time.perf_counter()
+            r = _te(self, *a, **k)
+            torch.cuda.synchronize()
+            split['k5_s'] += time.perf_counter() - t
+            split['k5_calls'] += 1
+            split['epochs'] += int(r['epochs_run']) - int(k.get('epoch_offset', 0))
+            return r
+
+        def ef(self, *a, **k):
+            t = time.perf_counter()
+            r = _ef(self, *a, **k)
+            split['k4_s'] += time.perf_counter() - t
+            split['k4_calls'] += 1
+            return r
+        _flow.HipNVP.train_epochs, type(s)._mcmc_endpoints_fused = te, ef
         t0 = time.time()
-        s.run(mcmc_num_chains=1000)
-        out['live_run'] = {'logz': float(s.logz), 'logzerr': float(s.logzerr), 'wall_s': time.time() - t0, 'ncall': int(s.ncall),
+        try:
+            s.run(mcmc_num_chains=1000)
+        finally:
+            _flow.HipNVP.train_epochs, type(s)._mcmc_endpoints_fused = _te, _ef
+        wall = time.time() - t0
+        out['live_run'] = {'logz': float(s.logz), 'logzerr': float(s.logzerr), 'wall_s': wall, 'ncall': int(s.ncall),
                            'seed': 0, 'delta_vs_cpu_mean': (float(s.logz) - out['cpu_mean']) if 'cpu_mean' in out else None}
+        out['e2e'] = {'what': 'BASELINE config 2 end to end (NestedSampler.run, 1000 walkers per batch, seed 0), wall seconds',
+                      'wall_s': wall, 'k5_s': split['k5_s'], 'k4_s': split['k4_s'], 'host_s': wall - split['k5_s'] - split['k4_s'],
+                      'k5_calls': split['k5_calls'], 'k5_epochs': split['epochs'], 'k4_launches': split['k4_calls'],
+                      'niter': int(s.niter), 'retrains': int(s.num_retrains)}
     out['note'] = ('independent noise streams: one run scatters by logzerr ~ sqrt(H/N) ~ 0.43 around the ensemble mean; the '
                    '+-0.1 statement is on the means (tests/test_gpu_nested.py::test_committed_logz_fixtures_resolve_the_acceptance)')
     return out
@@ -283,6 +313,40 @@ def main():
     total_evals = evals_per_launch * args.steps * world
     value = total_evals / dt
 
+    # north_star's own multi-GPU statement -- config 2's 1000 walkers SPLIT over the ranks (strong) -- measured in the same
+    # invocation, beside the weak line above (every rank takes part: the all-gather is a collective)
+    strong = None
+    if dist is not None and args.scaling == 'weak' and args.config == 2:
+        Cr = -(-N_cfg // world)
+        us = np.random.RandomState(4321 + rank).uniform(-1, 1, size=(Cr, D))
+        zz0, _ = nvp.forward(us)
+        ll0 = flow.loglike(LIKE_ID[like], us, scale, device=dev)
+        zs2 = [zz0.clone() for _ in range(args.steps + args.warmup)]
+        ls2 = [ll0.clone() for _ in range(args.steps + args.warmup)]
+        g2 = torch.empty(world * Cr, D + 2, dtype=torch.float64, device=dev)
+        star2 = float(ll0.min())
+
+        def launch2(i):
+            r = nvp.mh_steps(LIKE_ID[like], scale, zs2[i], ls2[i], star2, step_size, S, dynamic=dynamic, lag=lag, seed=142 + i,
+                             walker_offset=rank * Cr)
+            dist.all_gather_into_tensor(g2, torch.cat([r['x'].double(), ls2[i][:, None], (r['n_accept'] > 0)[:, None].double()], dim=1))
+            return r
+        for i in range(args.warmup):
+            launch2(i)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            r2 = launch2(args.warmup + k)
+        barrier()
+        t2 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        nvp.check_sync(r2)
+        strong = {'what': 'BASELINE config 2 as north_star states it: %d walkers split over the %d ranks (%d each), K4 + one RCCL '
+                          'all-gather of the endpoints per batch' % (N_cfg, world, Cr),
+                  'walkers_total': Cr * world, 'walkers_per_gpu': Cr, 'ms_per_step': float(t2.item()) / args.steps * 1e3,
+                  'value': Cr * world * S * args.steps / float(t2.item()), 'unit': 'evals/s', 'scaling': 'strong',
+                  'kernel': 'mh_kernel_%s' % nvp.mh_form_for(Cr, dynamic=dynamic, lag=lag)}
+
     if rank == 0:
         fl = useful_flops_per_eval(D, H, B, L)
         achieved_tflops = evals_per_launch * fl / (kern_ms * 1e-3) / 1e12
@@ -290,6 +354,8 @@ def main():
         cu = info['num_cu']
         kform = form or nvp.mh_form_for(C, dynamic=dynamic, lag=lag)
         tiles = -(-C // (4 if kform in ('quad', 'solo') else 16))
+        solo = kform == 'solo'
+
         default_workload = (args.config, C, S, world, dynamic) == (2, 1000, 250, 1, 'batch') and lag is None
         traffic, traffic_src = committed_traffic('mh_kernel_%s' % kform) if default_workload else (None, None)
         out = {
@@ -307,7 +373,7 @@ def main():
                                        'walkers sharded x%d (%s scaling), one RCCL all-gather of the chain endpoints '
                                        '[%d, %d] f64 per batch; flow replicas trained per rank (no weight broadcast)'
                                        % (world, args.scaling, C, D + 2))},
-            'roofline': {'bound': 'mfma', 'achieved': achieved_tflops, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'roofline': {'bound': 'valu' if solo else 'mfma', 'achieved': achieved_tflops, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved_tflops / FP32_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'mh_kernel_%s' % kform, 'kernel_ms': kern_ms, 'flops_per_eval': fl,
@@ -315,13 +381,18 @@ def main():
                          'step_rule_lag': (lag if lag is not None else nvp.default_lag(C, form)) if dynamic == 'batch' else None,
                          'step_rule_exact_steps': (nvp.default_warm(C, dynamic, lag if lag is not None else nvp.default_lag(C, form), form)
                                                    if dynamic == 'batch' else None),
-                         'note': 'f32 peak: the f32-input MFMA peak and the f32 vector peak (packed v_pk_fma_f32) are the same 157.3 '
-                                 'TFLOP/s on gfx950; the solo form runs its layers on the vector unit (plain v_fmac_f32 + DPP: half '
-                                 'that peak at most, priced against the full figure), the other forms on MFMA.  %d walker tiles on '
-                                 '%d CUs: latency-bound at this population (a step is a serial chain of 9 small layers), see '
-                                 '`saturated`' % (tiles, cu)},
+                         'note': 'bound "valu": the solo form issues no MFMA (one walker per wave, layers as v_fmac_f32 + DPP) -- the f32 '
+                                 'vector peak and the f32-input MFMA peak are the same 157.3 TFLOP/s on gfx950 (64 FLOP/clk/SIMD), and a '
+                                 'lone wave issues one vector instruction per 4 cycles, half the SIMD rate.  %d walker tiles on %d CUs: '
+                                 'latency-bound at this population (a step is a serial chain of 9 small layers), see `saturated`'
+                                 % (tiles, cu)},
             'device': info['name'],
         }
+        if dist is not None:
+            out['rccl_ranks'] = dist.get_world_size()
+            out['collective_backend'] = dist.get_backend()
+        if strong is not None:
+            out['strong_config2'] = strong
         if world == 1 and dist is None and not args.bare:
             # K3: the single batched pass over all live points (inverse + box prior + likelihood), SURVEY.md 8d
             for _ in range(3):
@@ -386,8 +457,13 @@ def main():
                 torch.cuda.synchronize(dev)
                 t_ms.append(e0.elapsed_time(e1))
             ms = float(np.median(t_ms[1:]))
+            sp_flops = 136000   # per eval: 2 x 68 k multiply-adds on the matrix cores; the ~150 spline evaluations on top are not counted
             out['spline_flow'] = {'kernel': 'spline_mh_kernel_team' if (C + 15) // 16 <= 2 * cu else 'spline_mh_kernel',
                                   'kernel_ms': ms, 'evals_per_s': C * S / (ms * 1e-3),
+                                  'roofline': {'bound': 'mfma', 'flops_per_unit': sp_flops, 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
+                                               'achieved': C * S * sp_flops / (ms * 1e-3) / 1e12,
+                                               'frac': C * S * sp_flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                               'kernel': 'spline_mh_kernel_team', 'profile': 'profiles/r04/spline_kernel_stats.csv'},
                                   'note': 'SingleSpeedSpline hidden=%d blocks=%d bins=8; VALU-bound on the spline arithmetic' % (H, B)}
             if C >= 200:  # its training epoch at this population (90 % train / 10 % validation, batch 100: trainer.py:159-176)
                 nv = C // 10
@@ -403,6 +479,11 @@ def main():
                     torch.cuda.synchronize(dev)
                     best = min(best, (time.perf_counter() - t0) / max(1, res['epochs_run']) * 1e3)
                 out['spline_flow']['train_ms_per_epoch'] = best
+                tf = ((C - nv) * 3 + nv) * sp_flops   # forward + backward (2 x) over the training rows, forward over the validation rows
+                out['spline_flow']['train_roofline'] = {'bound': 'mfma', 'flops_per_unit': tf, 'unit_is': 'epoch', 'unit': 'TFLOP/s',
+                                                        'peak': FP32_PEAK_TFLOPS, 'achieved': tf / (best * 1e-3) / 1e12,
+                                                        'frac': tf / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 'kernel': 'spl_grad_kernel + spl_update_kernel',
+                                                        'profile': 'profiles/r04/spline_train_kernel_stats.csv'}
         if world == 1 and dist is None and not args.bare and args.config in (2, 5):
             # the same workload on the build-defined MAF (BASELINE config 5 names it): reported beside, never
             # as `value`.  Its inverse -- the direction the proposals need -- is `num_groups` passes of the nets per block
@@ -430,9 +511,18 @@ def main():
             t0 = time.perf_counter()
             resm = mf.train_epochs(Xm[nvm:], Xm[:nvm], perms, None, seed=1, jitter=0.01, batch=100, max_epochs=6, patience=50)
             torch.cuda.synchronize(dev)
+            mfl = useful_flops_per_eval(D, H, B, L)   # one mask-pruned pass of the nets: what an incremental inverse would need
+            tfm = ((Xm.shape[0] - nvm) * 3 + nvm) * mfl
+            t_ep = (time.perf_counter() - t0) / max(1, resm['epochs_run']) * 1e3
             out['maf_flow'] = {'kernel': 'maf_mh_kernel (image form, grouped sequential inverse)', 'num_groups': mf.num_groups,
+                               'roofline': {'bound': 'mfma', 'flops_per_unit': mfl, 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
+                                            'achieved': C * Sm * mfl / (ms * 1e-3) / 1e12, 'frac': C * Sm * mfl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                            'executed_over_algorithmic': mf.num_groups, 'kernel': 'maf_mh_kernel', 'profile': None},
+                               'train_roofline': {'bound': 'mfma', 'flops_per_unit': tfm, 'unit_is': 'epoch', 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
+                                                  'achieved': tfm / (t_ep * 1e-3) / 1e12, 'frac': tfm / (t_ep * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                                  'kernel': 'maf_grad_kernel + maf_update_kernel', 'profile': None},
                                'walkers': C, 'mcmc_steps_timed': Sm, 'kernel_ms': ms, 'evals_per_s': C * Sm / (ms * 1e-3),
-                               'train_ms_per_epoch': (time.perf_counter() - t0) / max(1, resm['epochs_run']) * 1e3,
+                               'train_ms_per_epoch': t_ep,
                                'train_what': 'host-driven epoch loop (loss_grad + adam_step per minibatch), %d points' % Xm.shape[0],
                                'note': 'UNPINNED: the reference has no MAF (nnest/trainer.py:83-100); parity is against the oracle '
                                        'restatement of the build-defined flow (tests/test_gpu_maf.py)'}
@@ -451,8 +541,15 @@ def main():
                 res = tr.train_epochs(u0[nv:], u0[:nv], perms, None, max_epochs=E, **kw)
                 torch.cuda.synchronize(dev)
                 best = min(best, (time.perf_counter() - t0) / max(1, res['epochs_run']) * 1e3)
+            kfl = ((C - nv) * 3 + nv) * fl   # forward + backward (2 x) over the training rows, forward over the validation rows
             out['k5_train'] = {'ms_per_epoch': best,
-                               'what': 'Trainer.train epoch loop in one launch (nnest_nvp_train), %d live points' % C}
+                               'what': 'Trainer.train epoch loop in one launch (nnest_nvp_train), %d live points' % C,
+                               'roofline': {'bound': 'valu', 'flops_per_unit': kfl, 'unit_is': 'epoch', 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
+                                            'achieved': kfl / (best * 1e-3) / 1e12, 'frac': kfl / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                            'kernel': 'train_kernel_rows<2>', 'profile': 'profiles/r04/train_kernel_stats.csv',
+                                            'note': 'latency-bound: per minibatch one forward + backward chain per row (100 waves on 25 '
+                                                    'CUs) and four cross-CU round trips (two grid barriers, the operand loads of the '
+                                                    'weight-gradient jobs, the image refresh)'}}
             out['logz'] = logz_report(dev, live_run=not args.no_logz)
         if not args.no_cpu_baseline and world == 1 and dist is None:
             out['cpu_baseline'] = cpu_baseline(D, nvp.store_packed(), like, scale, C)
