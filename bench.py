@@ -551,6 +551,8 @@ def main():
                                                     'CUs) and four cross-CU round trips (two grid barriers, the operand loads of the '
                                                     'weight-gradient jobs, the image refresh)'}}
             out['logz'] = logz_report(dev, live_run=not args.no_logz)
+            if 'e2e' in out['logz']:
+                out['e2e'] = out['logz'].pop('e2e')   # (the wall-time split of the live run: a top-level object)
         if not args.no_cpu_baseline and world == 1 and dist is None:
             out['cpu_baseline'] = cpu_baseline(D, nvp.store_packed(), like, scale, C)
         print(json.dumps(out))
