@@ -115,8 +115,9 @@ __device__ __forceinline__ unsigned long long mh_sync_read(const unsigned long l
 __device__ __forceinline__ bool mh_sync_failed(const int *err) {
     return err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
-__device__ __forceinline__ void mh_sync_fail(int *err) {
-    if (err) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// (the value says which wait it was: 1 counter total, 2 publisher, 3 published result, 4 window vote -- HipNVP.check_sync reports it)
+__device__ __forceinline__ void mh_sync_fail(int *err, int which = 1) {
+    if (err) __hip_atomic_store(err, which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // accepted walkers of step `it` over the whole batch; waits (bounded) until all `nwg` workgroups have posted
 __device__ __forceinline__ int mh_sync_total(const unsigned long long *sync, int it, int nwg, unsigned long long first, int *err) {
@@ -175,7 +176,7 @@ __device__ __forceinline__ void mh_sync_publisher(unsigned long long *sync, int 
         t0 += ndone;
         if (ndone == 0) {
             if (++polls > MH_SYNC_MAX_POLLS || ((polls & 255) == 0 && mh_sync_failed(err))) {
-                mh_sync_fail(err);
+                if (polls > MH_SYNC_MAX_POLLS) mh_sync_fail(err, 2);
                 // unblock the readers: publish what there is
                 for (int tt = t0; tt <= last_step; ++tt)
                     if (lane < MH_SYNC_SHARDS) {
@@ -200,7 +201,7 @@ __device__ __forceinline__ int mh_result_wait(const unsigned long long *sync, in
     while (!(v >> 63)) {
         if ((polls & 255) == 0 && mh_sync_failed(err)) break;
         if (++polls > MH_SYNC_MAX_POLLS) {
-            mh_sync_fail(err);
+            mh_sync_fail(err, 3);
             break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -221,7 +222,7 @@ __device__ __forceinline__ bool mh_window_vote(const unsigned long long *sync, i
     while ((int)(v >> 32) < it) {
         if ((polls & 255) == 0 && mh_sync_failed(err)) break;
         if (++polls > MH_SYNC_MAX_POLLS) {
-            mh_sync_fail(err);
+            mh_sync_fail(err, 4 | (it << 8) | ((wg & 1023) << 20));   /* (+ the step and the workgroup of the wait that ran out) */
             break;
         }
         __builtin_amdgcn_s_sleep(1);

@@ -166,6 +166,8 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
     __shared__ int acc_lds[2][WPG];   // batch rule: the walkers' accepts of a step, posted by the noise wave
     __shared__ float fsbuf[2];      // the proposal scale that goes with a noise buffer
     __shared__ float fs_exact;      // warm-up steps of the batch rule: the scale of the next step, known only after this step's votes
+    __shared__ float fs_cand[2];    // ... and the two values it can take: the batch votes up / down
+    __shared__ int vote_sel;        // which of the two it was
     __shared__ double etab[SOLO_ETAB];
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -218,7 +220,10 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
         constexpr int NQ = 8 * WPG * U;   // quads per step: (4 WPG streams) x (2 U quads each)
         unsigned long long n0 = 0, n1 = 0, n2 = 0, n_gen = 0, n_all = 0;
         (void)n0; (void)n1; (void)n2; (void)n_gen; (void)n_all;
-        for (int k = 0; k <= S; ++k) {
+        // Buffer k (the noise of step k + 1) is generated ONE barrier ahead of the barrier that publishes it, so that under the
+        // warm-up's order of barriers (P0, P1, then A_k, P_{k+1}, B_k per exact step: the net waves' loop) no barrier waits for a draw.
+        auto draw = [&](int k) {
+            if (k > S) return;
             STAMP(n0);
             if (!recorded) {
                 if (gen) {
@@ -249,16 +254,31 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
             }
             if (!dynamic && lane == 0) fsbuf[k & 1] = a.step_size;
             STAMP(n1);
-            if (k >= 2 && k <= warm + 1) {   // warm-up: the relay wave's exchange with the batch sits between A and B
-                solo_barrier();   // A
-                solo_barrier();   // B
-            }
-            solo_barrier();   // publish buffer k
-            STAMP(n2);
 #ifdef NNEST_STAMP
-            n_gen += n1 - n0; n_all += n2 - n0;
+            n_gen += n1 - n0;
 #endif
+        };
+        STAMP(n2);
+        draw(0);
+        solo_barrier();                    // P0
+        if (S >= 1) {
+            draw(1);
+            solo_barrier();                // P1
+            draw(2);
+            for (int k = 1; k <= warm; ++k) {
+                solo_barrier();            // A_k
+                solo_barrier();            // P_{k+1}
+                draw(k + 2);
+                solo_barrier();            // B_k
+            }
+            for (int k = warm > 0 ? warm + 2 : 2; k <= S; ++k) {
+                solo_barrier();            // P_k
+                draw(k + 1);
+            }
         }
+#ifdef NNEST_STAMP
+        { unsigned long long n3 = 0; STAMP(n3); n_all = n3 - n2; }
+#endif
 #ifdef NNEST_STAMP
         if (a.scale_out && lane == 0 && tile == 0) { a.scale_out[4] = (float)n_gen; a.scale_out[5] = (float)n_all; }
 #endif
@@ -292,8 +312,13 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
 #define SOLO_RELAY_ITERATION(k_, q_)                                                                                        \
         {                                                                                                                   \
             const int k = (k_), want = k - lag;                                                                             \
+            /* the wait is UNCONDITIONAL: it is also what tells the compiler that q_ is read in every iteration.  Where the */  \
+            /* compiler can see that the first iterations never consume (want <= warm) it treats the request's destination  */  \
+            /* registers as free, hands them to another value, and the load lands on top of it (round 4: the accept count   */  \
+            /* posted for step warm + 2 came out as a window word in ~4 % of the launches -- a batch total that never       */  \
+            /* completes, 126 ms until the bounded wait gives up).                                                          */  \
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(q_) : : "memory");                                                     \
             if (want > warm) {                                                                                              \
-                asm volatile("s_waitcnt vmcnt(2)" : "+v"(q_) : : "memory");                                                 \
                 const bool up = mh_window_vote(a.sync, S, want, tile, q_, a.sync_err);                                      \
                 if (up) accept += 1; else reject += 1;                                                                      \
                 if (accept > reject) scale *= use_tab ? etab[accept] : exp(1.0 / (1 + accept));                             \
@@ -318,27 +343,45 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
         unsigned long long qa = 0, qb = 0;
         int k0 = 0;
         if (warm > 0) {
-            // warm-up: behind the net waves' step k - 1 (barrier A) post that step's accepts, wait for the batch's vote, apply it
-            // and hand over the scale of step k (barrier B)
-            for (int k = 0; k <= warm + 1; ++k) {
-                if (k >= 2) {
-                    solo_barrier();   // A: the net waves have decided step k - 1
-                    if (lane == 0) {
-                        const int *ac = acc_lds[(k - 1) & 1];
-                        int acs = 0;
+            // Warm-up: behind the net waves' step k (barrier A) post that step's accepts and wait for the batch's vote while the
+            // net waves evaluate step k + 1 for BOTH scales it can lead to (fs_cand, written one vote ahead); at barrier B name
+            // the one it was (vote_sel) and the scale itself (fs_exact).  Barriers in the net waves' order: P0, P1, then
+            // A_k, P_{k+1}, B_k per exact step.
+            auto E = [&](int n) { return use_tab ? etab[n] : exp(1.0 / (1 + n)); };
+            auto next_scale = [&](int acc, int rej, double sc) {   // sampler.py:428-431
+                if (acc > rej) sc *= E(acc);
+                if (acc < rej) sc /= E(rej);
+                return sc;
+            };
+            if (lane == 0) {
+                fsbuf[0] = (float)scale;
+                fs_cand[0] = (float)next_scale(accept + 1, reject, scale);
+                fs_cand[1] = (float)next_scale(accept, reject + 1, scale);
+            }
+            solo_barrier();                   // P0
+            if (lane == 0) fsbuf[1] = (float)scale;
+            solo_barrier();                   // P1
+            for (int k = 1; k <= warm; ++k) {
+                solo_barrier();               // A_k: the net waves have decided step k
+                if (lane == 0) {
+                    const int *ac = acc_lds[k & 1];
+                    int acs = 0;
 #pragma unroll
-                        for (int w_ = 0; w_ < WPG; ++w_) acs += ac[w_];
-                        mh_sync_post(a.sync, k - 1, tile, acs);
-                    }
-                    const bool up = mh_window_vote(a.sync, S, k - 1, tile, 0ull, a.sync_err);
-                    if (up) accept += 1; else reject += 1;
-                    if (accept > reject) scale *= use_tab ? etab[accept] : exp(1.0 / (1 + accept));
-                    if (accept < reject) scale /= use_tab ? etab[reject] : exp(1.0 / (1 + reject));
-                    if (lane == 0) fs_exact = (float)scale;
+                    for (int w_ = 0; w_ < WPG; ++w_) acs += ac[w_];
+                    mh_sync_post(a.sync, k, tile, acs);
+                    fsbuf[(k + 1) & 1] = (float)scale;   // (buffer k + 1's scale is not used: step k + 2 takes fs_exact or a candidate)
                 }
-                if (lane == 0) fsbuf[k & 1] = (float)scale;
-                if (k >= 2) solo_barrier();   // B: the scale of step k
-                solo_barrier();               // publish buffer k
+                solo_barrier();               // P_{k+1}
+                const bool up = mh_window_vote(a.sync, S, k, tile, 0ull, a.sync_err);
+                if (up) accept += 1; else reject += 1;
+                scale = next_scale(accept, reject, scale);
+                if (lane == 0) {
+                    vote_sel = up ? 0 : 1;
+                    fs_exact = (float)scale;
+                    fs_cand[0] = (float)next_scale(accept + 1, reject, scale);
+                    fs_cand[1] = (float)next_scale(accept, reject + 1, scale);
+                }
+                solo_barrier();               // B_k
             }
             k0 = warm + 2;
         }
@@ -440,12 +483,12 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, a_prop = 0, a_inv = 0, a_post = 0, a_tot = 0;
     (void)st0; (void)st1; (void)st2; (void)st3; (void)a_prop; (void)a_inv; (void)a_post; (void)a_tot;
-    for (int it = 1; it <= S; ++it) {
-        STAMP(st0);
-        // proposal z' = z + randn * scale  (sampler.py:310, :316); float32 like torch
-        const float fs = fs_next;
-        float zp[2][U], xp[2][U];
-        float u;
+    // One Metropolis step in three parts, so that the warm-up below can evaluate a step for TWO candidate scales:
+    //   propose   z' = z + randn * scale  (sampler.py:310, :316), float32 like torch -- from the noise held in registers;
+    //   finish    x' = f^-1(z'), box prior, Jacobian ratio, likelihood, the decision (sampler.py:321-361 / :396-410);
+    //   apply     counters, z / x / log-det / logL of the accepted proposal (sampler.py:342-365), the accept flag for the rule.
+    struct Prop { float zp[2][U], xp[2][U]; float ldp; double lp; bool pre, acc; };
+    auto propose = [&](int it, float fs, float (&zp)[2][U], float &u) {
         if (recorded) {
 #pragma unroll
             for (int uu = 0; uu < U; ++uu)
@@ -453,70 +496,99 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
                 for (int c = 0; c < 2; ++c) {
                     const int d = 2 * U * pos + 2 * uu + c;
                     const float dz = (ok && d < D) ? a.noise_dz[((size_t)(it - 1) * C + row) * D + d] : 0.f;
-                    zp[c][uu] = z[c][uu] + dz * fs;
+                    zp[c][uu] = __builtin_fmaf(dz, fs, z[c][uu]);
                 }
             u = ok ? a.noise_u[(size_t)(it - 1) * C + row] : 1.f;
         } else {
 #pragma unroll
             for (int uu = 0; uu < U; ++uu) {
-                zp[0][uu] = z[0][uu] + nz[2 * uu] * fs;
-                zp[1][uu] = z[1][uu] + nz[2 * uu + 1] * fs;
+                zp[0][uu] = __builtin_fmaf(nz[2 * uu], fs, z[0][uu]);       // (one fused multiply-add, spelled out: the step is compiled
+                zp[1][uu] = __builtin_fmaf(nz[2 * uu + 1], fs, z[1][uu]);   // in three places and all of them must round alike)
             }
             u = u_next;
         }
-        fetch_noise();
+    };
+    auto finish = [&](Prop &r, float u) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int uu = 0; uu < U; ++uu) xp[c][uu] = zp[c][uu];
+            for (int uu = 0; uu < U; ++uu) r.xp[c][uu] = r.zp[c][uu];
         STAMP(st1);
-        const float ldp = solo_logdet_total(inverse(xp));  // sampler.py:321
+        r.ldp = solo_logdet_total(inverse(r.xp));  // sampler.py:321
         STAMP(st2);
-
         // log_ratio = log_det_J' - log_det_J, -inf outside the prior box  (sampler.py:326-331); UniformPrior(D,-1,1)
         // (priors.py:39-43): NaN compares false, i.e. counts as inside; padded dims hold 0
         int okl = 1;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int uu = 0; uu < U; ++uu) okl &= !(xp[c][uu] < -1.f || xp[c][uu] > 1.f);
+            for (int uu = 0; uu < U; ++uu) okl &= !(r.xp[c][uu] < -1.f || r.xp[c][uu] > 1.f);
         const bool inb = __ballot(okl != 0) == ~0ull;
-        float log_ratio = inb ? (ldp - ld) : -INFINITY;
+        float log_ratio = inb ? (r.ldp - ld) : -INFINITY;
         float ratio = fminf(__expf(log_ratio), 1.0f);  // exp().clamp(max=1)  :335
         if (log_ratio != log_ratio) ratio = log_ratio;  // NaN stays NaN (u < NaN is false, as in torch)
-        const bool pre = ok && (u < ratio);             // :336
-        const double lp = solo_loglike<U, LK>(like, D, lane, xp);
-        bool acc = pre && (lp > loglstar);  // :361
+        r.pre = ok && (u < ratio);                      // :336
+        r.lp = solo_loglike<U, LK>(like, D, lane, r.xp);
+        r.acc = r.pre && (r.lp > loglstar);  // :361
         if (free_mode) {  // sampler.py:396-410
-            const double lr = inb ? (double)(ldp - ld) + (lp - logl) : -INFINITY;
+            const double lr = inb ? (double)(r.ldp - ld) + (r.lp - logl) : -INFINITY;
             const double rt = fmin(exp(lr), 1.0);
-            acc = ok && ((double)u < rt);
+            r.acc = ok && ((double)u < rt);
         }
-        n_call += (free_mode ? ok : pre) ? 1 : 0;
-        n_acc += acc ? 1 : 0;
+    };
+    auto apply = [&](int it, const Prop &r) {
+        n_call += (free_mode ? ok : r.pre) ? 1 : 0;
+        n_acc += r.acc ? 1 : 0;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int uu = 0; uu < U; ++uu) {
-                z[c][uu] = acc ? zp[c][uu] : z[c][uu];
-                x[c][uu] = acc ? xp[c][uu] : x[c][uu];
+                z[c][uu] = r.acc ? r.zp[c][uu] : z[c][uu];
+                x[c][uu] = r.acc ? r.xp[c][uu] : x[c][uu];
             }
-        ld = acc ? ldp : ld;
-        logl = acc ? lp : logl;
-        if (dynamic && lane == 0) acc_lds[it & 1][j] = acc ? 1 : 0;  // sampler.py:422-431: counted by the noise wave after the next barrier
-        if (it <= warm) {   // warm-up: the next step's scale exists only after this step's votes (noise wave, between A and B)
-            solo_barrier();
-            solo_barrier();
-            fs_next = fs_exact;
+        ld = r.acc ? r.ldp : ld;
+        logl = r.acc ? r.lp : logl;
+        if (dynamic && lane == 0) acc_lds[it & 1][j] = r.acc ? 1 : 0;  // sampler.py:422-431: counted by the relay wave after the next barrier
+        if (DBG && writer_lane && ok) {
+            if (a.hist_x) store_row(a.hist_x, (size_t)row * (S + 1) + it, x);
+            if (a.hist_logl && pos == 0) a.hist_logl[(size_t)row * (S + 1) + it] = logl;
+        }
+    };
+    Prop cur;
+    bool have = false;   // `cur` already holds this step's evaluated proposal (warm-up: chosen among the two candidates)
+    for (int it = 1; it <= S; ++it) {
+        STAMP(st0);
+        if (!have) {
+            float u;
+            propose(it, fs_next, cur.zp, u);
+            fetch_noise();
+            finish(cur, u);
+        }
+        apply(it, cur);
+        have = false;
+        if (it <= warm) {
+            // Warm-up (round 4).  The scale of step it + 1 exists only after the whole batch's vote on step it -- a grid-wide
+            // round trip (~2.5 us) that round 3 spent waiting.  There are only TWO scales it can be (the vote is up or down;
+            // the relay wave works both out beforehand, in the rule's own float64 arithmetic), so step it + 1 is evaluated for
+            // both while the vote travels, and the one the vote names is kept: the chain is, bit for bit, the one that waits.
+            solo_barrier();                    // A: the relay posts this step's accepts and starts waiting for the vote
+            const float f0 = fs_cand[0], f1 = fs_cand[1];
+            Prop c1;
+            float u;
+            propose(it + 1, f0, cur.zp, u);
+            propose(it + 1, f1, c1.zp, u);
+            fetch_noise();                     // (the noise of step it + 2)
+            finish(cur, u);
+            finish(c1, u);
+            solo_barrier();                    // B: the vote is in
+            if (vote_sel != 0) cur = c1;
+            have = true;
+            fs_next = fs_exact;                // (step warm + 2 runs at the scale the exact steps end with: no lagged vote is due yet)
         }
         STAMP(st3);
 #ifdef NNEST_STAMP
         a_prop += st1 - st0; a_inv += st2 - st1; a_post += st3 - st2; a_tot += st3 - st0;
 #endif
-        if (DBG && writer_lane && ok) {
-            if (a.hist_x) store_row(a.hist_x, (size_t)row * (S + 1) + it, x);
-            if (a.hist_logl && pos == 0) a.hist_logl[(size_t)row * (S + 1) + it] = logl;
-        }
     }
 #ifdef NNEST_STAMP
     if (a.scale_out && lane == 0 && tile == 0) {
