@@ -15,9 +15,9 @@
 //   grid barrier;
 //   W+A   the weight-gradient jobs, one per wave of the grid in train_kernel_grid's static order (job J on wave J / G of workgroup
 //         J % G), the owner applies Adam in registers and publishes its new tile into the backward fragment image (+ biases);
-//   grid barrier;
 //   R     every workgroup re-lays the published image into its two LDS "solo" images (forward and transposed: lane (net, K-half,
-//         position) x field, solo_tile.h) through per-thread destination maps built once per launch.
+//         position) x field, solo_tile.h) through a destination map built once per launch.  The tiles are published as
+//         {weight, tag} granules, so this phase polls the DATA (no second grid barrier in front of it: one cross-CU round trip less).
 // Summation inside a layer is the solo order (K in two halves, left to right), not the MFMA order of train_kernel, so the two
 // agree to rounding (tests/test_gpu_train.py::test_grid_training_vs_single_workgroup: 1e-4 of the largest element after 12 epochs);
 // every reduction has a fixed order and every gradient element one producer: the kernel reproduces itself bit for bit, which
@@ -396,6 +396,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_rows(TrainArgs a) 
     if (a.max_epochs > 0) rows_prepare<U>(a, 0, 0, wg, xpre[0]);
     __syncthreads();
 
+    float *pub = a.gimgf;         // the published weights: {weight, tag} pairs, 2 x image_floats floats (the two image areas of train_kernel_grid)
     float *part_base = a.gtile;   // [2][128] log p of a minibatch's rows, [2][128] validation sums of the row waves (sc1 words, one writer each)
     // the sum of the 4 G row waves' words in a fixed order: lane l takes words l and l + 64, then a butterfly over the lanes
     auto sum_rows = [&](const float *words) {
@@ -533,10 +534,17 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_rows(TrainArgs a) 
                     if (os.wt[r] >= 0) adam_reg(a, ad, os.tw[r], gt[r], os.tm[r], os.tv[r]);
                     if (os.bt[r] >= 0) adam_reg(a, ad, os.bw[r], gb[r], os.bm[r], os.bv[r]);
                 }
-                // the NEW weights as they stand: one whole 1-KB tile of the published backward fragment image per store instruction
-                st_sc1_f32x4(a.gimgb + off_b + lane * 4, (f32x4){os.tw[0], os.tw[1], os.tw[2], os.tw[3]});
-                if (off_bias >= 0 && (lane & 15) == 0)
-                    st_sc1_f32x4(a.gimgb + off_bias + (lane >> 4) * 4, (f32x4){os.bw[0], os.bw[1], os.bw[2], os.bw[3]});
+                // the NEW weights as they stand, every one with the minibatch's TAG beside it ({w, tag} granules of 8 bytes inside
+                // 16-byte stores: element i of the backward fragment image at pub[2 i], its tag at pub[2 i + 1]).  A reader that finds
+                // the tag of this minibatch has this minibatch's weight, whatever the order its loads were served in -- which is what
+                // lets the refresh below poll the data itself instead of waiting at a second grid barrier and THEN loading.
+                const float tg = __int_as_float(mbcount + 1);
+                st_sc1_f32x4(pub + 2 * (off_b + lane * 4), (f32x4){os.tw[0], tg, os.tw[1], tg});
+                st_sc1_f32x4(pub + 2 * (off_b + lane * 4) + 4, (f32x4){os.tw[2], tg, os.tw[3], tg});
+                if (off_bias >= 0 && (lane & 15) == 0) {
+                    st_sc1_f32x4(pub + 2 * (off_bias + (lane >> 4) * 4), (f32x4){os.bw[0], tg, os.bw[1], tg});
+                    st_sc1_f32x4(pub + 2 * (off_bias + (lane >> 4) * 4) + 4, (f32x4){os.bw[2], tg, os.bw[3], tg});
+                }
             }
             for (int k = dead0 + lane; k < dead1; k += 64) {   // the parameters no job reaches: zero gradient, weight decay only
                 float w_ = dw[k], m_ = dm[k], v_ = dv[k];
@@ -544,41 +552,62 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_rows(TrainArgs a) 
                 dw[k] = w_; dm[k] = m_; dv[k] = v_;
             }
             TSTAMP(q4);
-            alive = grid_barrier(a.gsync, phase, G, a.gerr);
-            if (!alive) break;
+            // (no second grid barrier: what it ordered -- every job has read the staging area, every tile is published -- is exactly
+            // "all tiles carry this minibatch's tag", which the refresh establishes by itself; a workgroup enters the next pass only
+            // behind that, and the owners publish the next tiles only behind the next FIRST barrier, i.e. behind every refresh)
+            __syncthreads();
             TSTAMP(q5);
-            // loss = -mean(log_probs)  (trainer.py:394) over the rows' words (requested in front of the refresh's loads: one round trip);
-            // only the thread that reports the epoch losses needs it
+            // loss = -mean(log_probs)  (trainer.py:394) over the rows' words (written before the first barrier); only the thread that
+            // reports the epoch losses needs it
             float lsum = 0.f;
             if (wave == 0) lsum = sum_rows(part);
-            // ---- R: the published tiles into this workgroup's two solo images; every load requested before the first LDS write
+            // ---- R: the published tiles into this workgroup's two solo images.  All loads of a thread are requested at once; a
+            // granule whose tag is not this minibatch's yet sends the thread round again (bounded).
             {
-                f32x4 vb[RU];
-                i32x4 mp[RU];
+                constexpr int CH = RU > 4 ? 4 : RU;   // loads in flight per thread and round (x_dim > 64: two rounds, the second finds its data there)
+                const int want = mbcount + 1;
+                __builtin_amdgcn_s_sleep(16);   // (the owners' stores are ~1.5 k cycles from being visible: a poll issued at once would miss and cost a whole round trip)
 #pragma unroll
-                for (int u = 0; u < RU; ++u) {
-                    const int i = min((int)threadIdx.x + u * TRAIN_THREADS, IMGF / 4 - 1);
-                    vb[u] = ld_sc1_x4_issue(a.gimgb + 4 * (size_t)i);
-                    mp[u] = gmap[i];
-                }
+                for (int c0 = 0; c0 < RU; c0 += CH) {
+                    f32x4 va[CH], vc[CH];
+                    i32x4 mp[CH];
 #pragma unroll
-                for (int u = 0; u < RU; ++u) asm volatile("s_waitcnt vmcnt(0)" : "+v"(vb[u]) : : "memory");
+                    for (int u = 0; u < CH; ++u) mp[u] = gmap[min((int)threadIdx.x + (c0 + u) * TRAIN_THREADS, IMGF / 4 - 1)];
+                    bool fresh = false;
+                    for (int polls = 0; !fresh; ++polls) {
+                        if (polls > GRID_MAX_POLLS / 64) { *a.gerr = 1; break; }
 #pragma unroll
-                for (int u = 0; u < RU; ++u) {
-                    if ((int)threadIdx.x + u * TRAIN_THREADS < IMGF / 4) {
-                        const float e4[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
-                        const int m4[4] = {mp[u].x, mp[u].y, mp[u].z, mp[u].w};
+                        for (int u = 0; u < CH; ++u) {
+                            const int i = min((int)threadIdx.x + (c0 + u) * TRAIN_THREADS, IMGF / 4 - 1);
+                            va[u] = ld_sc1_x4_issue(pub + 8 * (size_t)i);
+                            vc[u] = ld_sc1_x4_issue(pub + 8 * (size_t)i + 4);
+                        }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int f = m4[e] & 0xffff, k = (m4[e] >> 16) & 0xffff;
-                            if (f != 0xffff) smem[f & 0x3fff] = (f >> 14) ? SOLO_TANH_PRESCALE * e4[e] : e4[e];
-                            if (k != 0xffff) smem[k] = e4[e];
+                        for (int u = 0; u < CH; ++u) asm volatile("s_waitcnt vmcnt(0)" : "+v"(va[u]), "+v"(vc[u]) : : "memory");
+                        fresh = true;
+#pragma unroll
+                        for (int u = 0; u < CH; ++u)
+                            fresh = fresh && __float_as_int(va[u].y) == want && __float_as_int(va[u].w) == want && __float_as_int(vc[u].y) == want &&
+                                    __float_as_int(vc[u].w) == want;
+                    }
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+                        if (c0 + u < RU && (int)threadIdx.x + (c0 + u) * TRAIN_THREADS < IMGF / 4) {
+                            const float e4[4] = {va[u].x, va[u].z, vc[u].x, vc[u].z};
+                            const int m4[4] = {mp[u].x, mp[u].y, mp[u].z, mp[u].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int f = m4[e] & 0xffff, k = (m4[e] >> 16) & 0xffff;
+                                if (f != 0xffff) smem[f & 0x3fff] = (f >> 14) ? SOLO_TANH_PRESCALE * e4[e] : e4[e];
+                                if (k != 0xffff) smem[k] = e4[e];
+                            }
                         }
                     }
                 }
             }
             epoch_loss += -lsum / (float)M;
-            __syncthreads();
+            alive = __syncthreads_and(*a.gerr == 0 ? 1 : 0) != 0;   // (a refresh that ran out ends the launch: result.stopped = 2)
+            if (!alive) break;
             TSTAMP(q6);
             if (wave == 0 && q1 > q0) { TACC(ph[0], q1, q0); TACC(ph[1], q2, q1); }
             TACC(ph[2], q3, q2); TACC(ph[3], q4, q3); TACC(ph[4], q5, q4); TACC(ph[5], q6, q5);
