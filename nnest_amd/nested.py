@@ -376,6 +376,8 @@ class NestedSampler(Sampler):
         # mcmc_step_warm (not in the reference): with a lagged rule, the first so many steps of every launch apply it exactly
         # (NNEST_MH_WARM); None = the kernel form's default
         self.mcmc_step_warm = mcmc_step_warm
+        if hasattr(self.trainer, 'wait_for_saves'):
+            self.trainer.async_save = True   # models/netG.pt written beside the GPU work; run() waits for the last one below
         self._grow = None   # the dead-point files of a previous run() on this object are not this run's
         self._prior_cache = None   # (nor are the prior candidates it left unexamined: a reseeded run must not depend on them)
         if strategy is None or len(strategy) == 0:
@@ -671,6 +673,9 @@ class NestedSampler(Sampler):
             saved_logwt.append(logvol + active_logl[i])
             saved_logl.append(active_logl[i])
 
+        if hasattr(self.trainer, 'wait_for_saves'):
+            self.trainer.wait_for_saves()
+            self.trainer.async_save = False
         logz, h = ev.logz, ev.h
         self.logz = logz
         self.h = h
