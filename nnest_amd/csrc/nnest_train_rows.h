@@ -171,83 +171,9 @@ static __device__ __forceinline__ float rows_act_grad(float g, float a, unsigned
     return __uint_as_float(out);
 }
 
-// ---- {value, tag} granules: what crosses workgroups without a grid barrier ----
-// An 8-byte aligned pair written by ONE sc1 store is never seen torn (MI355X_MICROARCH.md "Valid forms": R2's granule), so a
-// reader that finds the tag of the current minibatch beside a value has that minibatch's value -- whatever order its loads
-// were served in.  The staged rows, the rows' log p and the published weights all travel this way; tags count minibatches from 1
-// within a launch, and the launcher zeroes the three areas (a previous launch's tags must not be mistaken for this one's).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void st_sc1_f32x2(float *p, float v, float tag) {
-    const f32x2 d = {v, tag};
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(d) : "memory");
-}
-__device__ __forceinline__ f32x2 ld_sc1_x2_issue(const float *p) {   // ISSUED only: the caller drains before using the value
-    f32x2 v;
-    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-enum { ROWS_MAX_RETRIES = 1 << 15 };
-
 // one 16-float row of a staged tensor: lanes of the h = 0 rows (one per net) write position `col` of row `row` of column tile ct
-static __device__ __forceinline__ void rows_stage(float *stg_net, int ct, int row, int col, float v, float tag, bool stager) {
-    if (stager) st_sc1_f32x2(stg_net + (((size_t)ct * TRAIN_MAX_ROWS + row) * 16 + col) * 2, v, tag);
-}
-
-// contract_rows_grid over the TAGGED staging area: the same operands in the same order (the same bits), each load a {value, tag}
-// pair; the job polls its operands until every one carries this minibatch's tag -- which is all the first grid barrier was for.
-// Two halves of the rows, each consumed into the accumulators before the next is requested (64 registers in flight, not 128).
-template <bool WITH_BIAS>
-__device__ __forceinline__ f32x4 contract_rows_tagged(const float *stg2, int rows_pad, int ct_g, int ct_a, int lane, f32x4 &bias, int want, int *err) {
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
-    float bs = 0.f;
-    const float *G = stg2 + (((size_t)ct_g * TRAIN_MAX_ROWS + (lane >> 4)) * 16 + (lane & 15)) * 2;
-    const float *A = stg2 + (((size_t)ct_a * TRAIN_MAX_ROWS + (lane >> 4)) * 16 + (lane & 15)) * 2;
-    constexpr int NIT = TRAIN_MAX_ROWS / 16, HALF = NIT / 2;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        if (hf * HALF * 16 >= rows_pad) break;
-        f32x2 gv[HALF][4], ev[HALF][4];
-        bool fresh = false;
-        for (int polls = 0; !fresh; ++polls) {
-            if (polls > ROWS_MAX_RETRIES) { *err = 1; break; }
-#pragma unroll
-            for (int i = 0; i < HALF; ++i) {
-                const int it = hf * HALF + i, r = it * 16 < rows_pad ? it * 16 : 0;   // (rows beyond rows_pad: redirected to tile 0, products skipped)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    gv[i][k] = ld_sc1_x2_issue(G + (size_t)(r + 4 * k) * 32);
-                    ev[i][k] = ld_sc1_x2_issue(A + (size_t)(r + 4 * k) * 32);
-                }
-            }
-            bool ok = true;
-#pragma unroll
-            for (int i = 0; i < HALF; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(gv[i][k]), "+v"(ev[i][k]) : : "memory");
-                    ok = ok && __float_as_int(gv[i][k].y) == want && __float_as_int(ev[i][k].y) == want;
-                }
-            fresh = __all(ok ? 1 : 0) != 0;
-        }
-#pragma unroll
-        for (int i = 0; i < HALF; ++i) {
-            if ((hf * HALF + i) * 16 < rows_pad) {
-                a0 = mfma4(gv[i][0].x, ev[i][0].x, a0);
-                a1 = mfma4(gv[i][1].x, ev[i][1].x, a1);
-                a2 = mfma4(gv[i][2].x, ev[i][2].x, a2);
-                a3 = mfma4(gv[i][3].x, ev[i][3].x, a3);
-                if (WITH_BIAS) bs += (gv[i][0].x + gv[i][1].x) + (gv[i][2].x + gv[i][3].x);
-            }
-        }
-    }
-    if (WITH_BIAS) {
-        bs += __shfl_xor(bs, 16);
-        bs += __shfl_xor(bs, 32);
-        const int q4 = (lane >> 4) * 4;
-        bias = (f32x4){__shfl(bs, q4 + 0), __shfl(bs, q4 + 1), __shfl(bs, q4 + 2), __shfl(bs, q4 + 3)};
-    }
-    return (a0 + a1) + (a2 + a3);
+static __device__ __forceinline__ void rows_stage(float *stg_net, int ct, int row, int col, float v, bool stager) {
+    if (stager) st_sc1(stg_net + ((size_t)ct * TRAIN_MAX_ROWS + row) * 16 + col, v);
 }
 
 // ---- reverse mode through one coupling block (block_backward_grid's arithmetic on one row) ----
@@ -256,7 +182,7 @@ __device__ __forceinline__ f32x4 contract_rows_tagged(const float *stg2, int row
 template <int U>
 static __device__ __forceinline__ void rows_block_backward(const Solo4Lds &wb_, unsigned sel, bool h1, bool translate_half, int pos, int D, int ct,
                                                            bool row_ok, float gld, const float (&cond)[U], float (&ytrans)[U], float (&gcond)[U],
-                                                           float (&gtrans)[U], const RowsKeep<U> &kp, float *stg_net, int row, bool stager, float tag) {
+                                                           float (&gtrans)[U], const RowsKeep<U> &kp, float *stg_net, int row, bool stager) {
     typedef StageMap<U, 1, 1> SM;
     float go[U];
 #pragma unroll
@@ -286,7 +212,7 @@ static __device__ __forceinline__ void rows_block_backward(const Solo4Lds &wb_, 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int s = U * pos + u;
-        rows_stage(stg_net, SM::gout(s >> 4), row, s & 15, go[u], tag, stager);
+        rows_stage(stg_net, SM::gout(s >> 4), row, s & 15, go[u], stager);
     }
     // g_h2 = Wo^T g_out   (the transposed image's first U field groups)
     float wa[8], wb[8], a0, a1;
@@ -309,18 +235,18 @@ static __device__ __forceinline__ void rows_block_backward(const Solo4Lds &wb_, 
     float w2[8], w3a[8], w3b[8];
     wb_.load8(w2, 32);   // (requested ahead of the activation gradient, as in the forward pass)
     const float g_a2 = rows_act_grad(solo_join_rot(a0 + a1), kp.h2, sel);   // (h = 1 rows: rotated by 8, like kp.h2)
-    rows_stage(stg_net, SM::gpre(1, 0), row, pos, g_a2, tag, stager);
-    rows_stage(stg_net, SM::act(1, 0), row, pos, kp.h2, tag, stager);
+    rows_stage(stg_net, SM::gpre(1, 0), row, pos, g_a2, stager);
+    rows_stage(stg_net, SM::act(1, 0), row, pos, kp.h2, stager);
     // g_h1 = W1^T g_a2
     if constexpr (U >= 2) { wb_.load8(w3a, 40); wb_.load8(w3b, 48); }
     solo_chain_1(a0, a1, 0.f, g_a2, w2);
     const float g_a1 = rows_act_grad(solo_join_rot(a0 + a1), kp.h1, sel);
-    rows_stage(stg_net, SM::gpre(0, 0), row, pos, g_a1, tag, stager);
-    rows_stage(stg_net, SM::act(0, 0), row, pos, kp.h1, tag, stager);
+    rows_stage(stg_net, SM::gpre(0, 0), row, pos, g_a1, stager);
+    rows_stage(stg_net, SM::act(0, 0), row, pos, kp.h1, stager);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int s = U * pos + u;
-        rows_stage(stg_net, SM::m(s >> 4), row, s & 15, row_ok ? cond[u] : 0.f, tag, stager);
+        rows_stage(stg_net, SM::m(s >> 4), row, s & 15, row_ok ? cond[u] : 0.f, stager);
     }
     // d loss / d (conditioning input) += W0^T g_a1 of both nets
 #pragma unroll
