@@ -152,6 +152,16 @@ def logz_report(dev, live_run):
             out['config3'] = {'cpu_mean': float(cv.mean()), 'gpu_mean': float(gv.mean()), 'delta': float(gv.mean() - cv.mean()),
                               'combined_stderr': float(np.hypot(cv.std(ddof=1), gv.std(ddof=1)) / np.sqrt(len(seeds))), 'n_seeds': len(seeds),
                               'analytic': -20.0 * float(np.log(20.0))}
+    # config 1 at the reference's default mcmc_num_chains = 10 (nested.py:185) instead of one chain per live point (fixtures *_cfg11)
+    c11, g11 = os.path.join(ROOT, 'tests', 'golden', 'logz_cpu_cfg11.json'), os.path.join(ROOT, 'tests', 'golden', 'logz_gpu_cfg11.json')
+    if os.path.exists(c11) and os.path.exists(g11):
+        with open(c11) as f:
+            cv = np.array(json.load(f)['logz'])
+        with open(g11) as f:
+            gv = np.array(json.load(f)['logz'])
+        out['config1_ten_chains'] = {'cpu_mean': float(cv.mean()), 'gpu_mean': float(gv.mean()), 'delta': float(gv.mean() - cv.mean()),
+                                     'combined_stderr': float(np.hypot(cv.std(ddof=1) / np.sqrt(len(cv)), gv.std(ddof=1) / np.sqrt(len(gv)))),
+                                     'cpu_seeds': len(cv), 'gpu_seeds': len(gv)}
     if live_run:
         import tempfile
         from nnest_amd.likelihoods import Rosenbrock

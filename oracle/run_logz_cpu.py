@@ -22,7 +22,15 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-CONFIGS = {1: ('Rosenbrock', 2, 5.0, 100), 2: ('Rosenbrock', 50, 5.0, 1000), 3: ('GaussianMix', 20, 10.0, 2000)}
+# (likelihood, x_dim, prior scale, live points[, mcmc_num_chains: the live-point count when absent])
+# 11 = config 1 at the reference's DEFAULT mcmc_num_chains = 10 (nested.py:185) instead of one chain per live point
+CONFIGS = {1: ('Rosenbrock', 2, 5.0, 100), 2: ('Rosenbrock', 50, 5.0, 1000), 3: ('GaussianMix', 20, 10.0, 2000),
+           11: ('Rosenbrock', 2, 5.0, 100, 10)}
+
+
+def config(cfg):
+    c = CONFIGS[cfg]
+    return c[0], c[1], c[2], c[3], (c[4] if len(c) > 4 else c[3])
 
 
 def one(cfg, seed, out):
@@ -38,7 +46,7 @@ def one(cfg, seed, out):
     from nnest_amd import likelihoods
     from nnest_amd.nested import NestedSampler
     from tests.oracle_trainer import OracleTrainer
-    name, D, scale, N = CONFIGS[cfg]
+    name, D, scale, N, chains = config(cfg)
     like = getattr(likelihoods, name)(D)
     np.random.seed(seed)
     torch.manual_seed(seed)
@@ -46,8 +54,8 @@ def one(cfg, seed, out):
     s = NestedSampler(D, like, transform=lambda x: scale * x, log_dir=tempfile.mkdtemp(dir='/tmp'), num_live_points=N,
                       trainer=tr, log_level=30, fused=False, flow='nvp')
     t0 = time.time()
-    s.run(mcmc_num_chains=N)     # the same call as the GPU runs it is compared with (tools/run_config.py)
-    res = dict(config=cfg, seed=seed, likelihood=name, x_dim=D, num_live_points=N, mcmc_num_chains=N, logz=float(s.logz),
+    s.run(mcmc_num_chains=chains)     # the same call as the GPU runs it is compared with (tools/run_config.py)
+    res = dict(config=cfg, seed=seed, likelihood=name, x_dim=D, num_live_points=N, mcmc_num_chains=chains, logz=float(s.logz),
                logzerr=float(s.logzerr), h=float(s.h), niter=int(s.niter), ncall=int(s.ncall), retrains=int(s.num_retrains),
                batches=int(s.num_batches), train_epochs_total=int(tr.total_iters), wall_s=time.time() - t0)
     with open(out, 'w') as f:
@@ -85,9 +93,9 @@ def merge(cfg, runs):
         runs = [r for r in old if r['seed'] not in [q['seed'] for q in runs]] + runs
         runs.sort(key=lambda r: r['seed'])
     z = np.array([r['logz'] for r in runs])
-    name, D, scale, N = CONFIGS[cfg]
+    name, D, scale, N, chains = config(cfg)
     doc = dict(what='CPU-path log Z: host driver + oracle-backed trainer (oracle/run_logz_cpu.py)', config=cfg,
-               likelihood=name, x_dim=D, num_live_points=N, mcmc_num_chains=N, flow='nvp h16 b3 l1', train_iters=500,
+               likelihood=name, x_dim=D, num_live_points=N, mcmc_num_chains=chains, flow='nvp h16 b3 l1', train_iters=500,
                seeds=[r['seed'] for r in runs], logz=[r['logz'] for r in runs], mean=float(z.mean()),
                std=float(z.std(ddof=1)) if len(z) > 1 else None,
                stderr=float(z.std(ddof=1) / np.sqrt(len(z))) if len(z) > 1 else None, runs=runs)

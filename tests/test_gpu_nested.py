@@ -346,9 +346,10 @@ def _fixture(kind, cfg):
         return json.load(f)
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 3])
+@pytest.mark.parametrize('cfg', [1, 2, 3, 11])
 def test_committed_logz_fixtures_resolve_the_acceptance(cfg):
-    """BASELINE's acceptance "log Z within +-0.1 of the CPU reference" on the committed ensembles (CPU path:
+    """(cfg 11 = configuration 1 at the reference's default mcmc_num_chains = 10, nested.py:185, instead of one chain per live point.)
+    BASELINE's acceptance "log Z within +-0.1 of the CPU reference" on the committed ensembles (CPU path:
     oracle/run_logz_cpu.py; GPU path: tools/run_logz_gpu.py; unpaired means over every seed each fixture holds): the means
     agree within 0.1 AND the comparison has the resolution to say so -- combined standard error <= 0.07, i.e. a true
     difference of 0.2 would stand out by three standard errors."""
@@ -372,7 +373,7 @@ def test_committed_logz_fixtures_resolve_the_acceptance(cfg):
     assert b['train_form'] == 'rows'
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 3])
+@pytest.mark.parametrize('cfg', [1, 2, 3, 11])
 def test_logz_gpu_vs_cpu(tmp_path, cfg):
     """The GPU path re-run live (twelve seeds) against the FULL CPU-path fixture (the host driver on the oracle-backed trainer,
     oracle/run_logz_cpu.py -> tests/golden/logz_cpu_cfg<cfg>.json; same configuration and run() arguments).  The two paths

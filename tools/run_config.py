@@ -1,5 +1,5 @@
 """Run one BASELINE.json configuration end to end on this GPU and print a JSON summary (developer / evidence tool).
-  python tools/run_config.py 3 [flow]      configs: 2 Rosenbrock-50/1000, 3 GaussianMix-20/2000, 4 Himmelblau-32/4000, 5 Rosenbrock-100/8000"""
+  python tools/run_config.py 3 [flow] [seed]      configs: 2 Rosenbrock-50/1000, 3 GaussianMix-20/2000, 4 Himmelblau-32/4000, 5 Rosenbrock-100/8000"""
 import json
 import os
 import sys
@@ -15,15 +15,16 @@ from nnest_amd.nested import NestedSampler  # noqa: E402
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 flow = sys.argv[2] if len(sys.argv) > 2 else 'nvp'
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 like, scale, N = {2: (Rosenbrock(50), 5.0, 1000), 3: (GaussianMix(20), 10.0, 2000), 4: (Himmelblau(32), 5.0, 4000),
                   5: (Rosenbrock(100), 5.0, 8000)}[cfg]
-np.random.seed(0)
-torch.manual_seed(0)
+np.random.seed(seed)
+torch.manual_seed(seed)
 s = NestedSampler(like.x_dim, like, transform=lambda x: scale * x, log_dir=tempfile.mkdtemp(dir='/tmp'), num_live_points=N,
                   log_level=30, flow=flow)
 t0 = time.time()
 s.run(mcmc_num_chains=N)
-out = dict(config=cfg, flow=flow, likelihood=type(like).__name__, x_dim=like.x_dim, num_live_points=N, mcmc_num_chains=N,
+out = dict(config=cfg, flow=flow, seed=seed, likelihood=type(like).__name__, x_dim=like.x_dim, num_live_points=N, mcmc_num_chains=N,
            wall_s=time.time() - t0, logz=s.logz, logzerr=s.logzerr, h=s.h, niter=s.niter, ncall=s.ncall, retrains=s.num_retrains,
            batches=s.num_batches, train_epochs_total=int(s.trainer.total_iters))
 if cfg == 3:

@@ -17,11 +17,13 @@ sys.path.insert(0, ROOT)
 from nnest_amd import likelihoods  # noqa: E402
 from nnest_amd.nested import NestedSampler  # noqa: E402
 
-CONFIGS = {1: ('Rosenbrock', 2, 5.0, 100), 2: ('Rosenbrock', 50, 5.0, 1000), 3: ('GaussianMix', 20, 10.0, 2000)}
+# 11 = config 1 at the reference's DEFAULT mcmc_num_chains = 10 (nested.py:185) instead of one chain per live point
+CONFIGS = {1: ('Rosenbrock', 2, 5.0, 100, 100), 2: ('Rosenbrock', 50, 5.0, 1000, 1000), 3: ('GaussianMix', 20, 10.0, 2000, 2000),
+           11: ('Rosenbrock', 2, 5.0, 100, 10)}
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 _sd = sys.argv[2] if len(sys.argv) > 2 else '0,1,2,3,4,5'
 seeds = list(range(*[int(v) for v in _sd.split(':')])) if ':' in _sd else [int(v) for v in _sd.split(',')]
-name, D, scale, N = CONFIGS[cfg]
+name, D, scale, N, chains = CONFIGS[cfg]
 lag = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != '-' else None
 tag = sys.argv[4] if len(sys.argv) > 4 else ''
 flow = sys.argv[5] if len(sys.argv) > 5 else 'nvp'
@@ -52,18 +54,18 @@ for seed in seeds:
     s = NestedSampler(D, getattr(likelihoods, name)(D), transform=lambda x: scale * x, log_dir=tempfile.mkdtemp(dir='/tmp'),
                       num_live_points=N, log_level=40, flow=flow)
     if stamp is None:
-        stamp = build_stamp(s, N, 5 * D)
+        stamp = build_stamp(s, chains, 5 * D)
         if lag is not None:
             stamp['step_lag'] = lag
     t0 = time.time()
-    s.run(mcmc_num_chains=N, mcmc_step_lag=lag)
+    s.run(mcmc_num_chains=chains, mcmc_step_lag=lag)
     runs.append(dict(seed=seed, logz=float(s.logz), logzerr=float(s.logzerr), h=float(s.h), niter=int(s.niter), ncall=int(s.ncall),
                      retrains=int(s.num_retrains), batches=int(s.num_batches), train_epochs_total=int(s.trainer.total_iters),
                      wall_s=time.time() - t0))
     print(json.dumps(runs[-1]), flush=True)
 z = np.array([r['logz'] for r in runs])
 doc = dict(what='GPU-path log Z: nnest_amd.NestedSampler on the HIP kernels (tools/run_logz_gpu.py)', config=cfg, likelihood=name, x_dim=D,
-           num_live_points=N, mcmc_num_chains=N, flow=flow + ' h16 b3 l1', train_iters=500, step_rule='batch-wide, default lag' if lag is None else 'batch-wide, lag %d' % lag,
+           num_live_points=N, mcmc_num_chains=chains, flow=flow + ' h16 b3 l1', train_iters=500, step_rule='batch-wide, default lag' if lag is None else 'batch-wide, lag %d' % lag,
            seeds=seeds, logz=z.tolist(), mean=float(z.mean()), std=float(z.std(ddof=1)) if len(z) > 1 else None,
            stderr=float(z.std(ddof=1) / np.sqrt(len(z))) if len(z) > 1 else None, build=stamp, runs=runs)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
