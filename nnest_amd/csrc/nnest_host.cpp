@@ -65,13 +65,30 @@ extern "C" int nnest_host_mcmc_consume(nnest_host_state_t *st, int N, int D, int
     const int W = D + nd;
     int resume = st->resume;
     st->resume = NNEST_HOST_TOP;
+    // np.argmin(active_logl) (nested.py:272: the FIRST smallest) per iteration is a scan of N values -- 2.7 s of a config-5 run
+    // (8000 live points, 10^6 iterations).  One value changes per iteration, so the minimum is kept in a tournament tree over the
+    // indices: node = the better of its children, the left (lower indices) on a tie; rebuilt at every entry (the caller owns the
+    // array between calls), one leaf-to-root path per replaced point.
+    int P2 = 1;
+    while (P2 < N) P2 <<= 1;
+    static thread_local std::vector<int> tree;
+    tree.assign(2 * (size_t)P2, -1);
+    auto better = [&](int a, int b) { return b < 0 ? a : a < 0 ? b : (active_logl[b] < active_logl[a] ? b : a); };
+    if (N > 64) {
+        for (int i = 0; i < N; ++i) tree[P2 + i] = i;
+        for (int k = P2 - 1; k >= 1; --k) tree[k] = better(tree[2 * k], tree[2 * k + 1]);
+    }
     for (;;) {
         if (resume == NNEST_HOST_TOP) {
             if (!(st->fraction_remain > dlogz && st->it <= max_iters)) return NNEST_HOST_FINISHED;   // nested.py:269
             if (st->accept_point && st->n_dead >= dead_cap) return NNEST_HOST_DEAD_FULL;
-            int worst = 0;                                           // np.argmin: the first smallest (nested.py:272)
-            for (int i = 1; i < N; ++i)
-                if (active_logl[i] < active_logl[worst]) worst = i;
+            int worst = 0;
+            if (N > 64) {
+                worst = tree[1];
+            } else {
+                for (int i = 1; i < N; ++i)
+                    if (active_logl[i] < active_logl[worst]) worst = i;
+            }
             st->worst = worst;
             st->loglstar = active_logl[worst];
             if (st->accept_point) {                                  // nested.py:280-293
@@ -100,6 +117,8 @@ extern "C" int nnest_host_mcmc_consume(nnest_host_state_t *st, int N, int D, int
                     memcpy(active_u + (size_t)worst * D, end_u + (size_t)cand * D, sizeof(double) * D);
                     memcpy(active_v + (size_t)worst * D, end_v + (size_t)cand * D, sizeof(double) * D);
                     active_logl[worst] = end_logl[cand];
+                    if (N > 64)
+                        for (int k = (P2 + worst) >> 1; k >= 1; k >>= 1) tree[k] = better(tree[2 * k], tree[2 * k + 1]);
                     if (end_logl[cand] > st->max_logl) st->max_logl = end_logl[cand];
                     if (nd > 0) memcpy(active_derived + (size_t)worst * nd, end_derived + (size_t)cand * nd, sizeof(double) * nd);
                     st->accept_point = 1;

@@ -185,3 +185,62 @@ def test_growing_npy_restarts_and_initial_rows(tmp_path):
     g2 = GrowingNpy(str(tmp_path / 'v.npy'), (2,), initial=np.ones((3, 2)))
     g2.sync(np.ones((4, 2)))
     assert np.load(str(tmp_path / 'v.npy')).shape == (4, 2)
+
+
+def test_native_loop_takes_the_first_smallest_live_point():
+    """nnest_host_mcmc_consume keeps np.argmin(active_logl) (nested.py:272) in a tournament tree; with MANY tied likelihood values
+    the order of the dead points must still be numpy's (the first smallest), through several batches of replacements."""
+    import ctypes
+    from nnest_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    N, D, C = 300, 2, 64
+    logl = rng.integers(0, 12, N).astype(np.float64)
+    u = np.ascontiguousarray(rng.random((N, D)))
+    v = u.copy()
+    derived = np.zeros((N, 0))
+    m_logl, m_v = logl.copy(), v.copy()            # the mirror: the same loop with np.argmin
+    cap = 4096
+    dead_v, dead_logl, dead_logwt, dead_zprev = np.zeros((cap, D)), np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    st = _lib.HostState(logz=-1e300, logvol=0.0, fraction_remain=1.0, max_logl=float(logl.max()), loglstar=0.0, it=1, n_dead=0,
+                        accept_point=0, nb=C, first_time=0, resume=_lib.HOST_TOP, worst=0, pad_=0)
+    end_u, end_v, end_logl = np.zeros((C, D)), np.zeros((C, D)), np.zeros(C)
+    moved, end_d = np.ones(C, dtype=np.uint8), np.zeros((C, 0))
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    expect_v, expect_l = [], []
+    m_accept, batches = False, 0
+    while True:
+        reason = lib.nnest_host_mcmc_consume(ctypes.byref(st), N, D, 0, P(u), P(v), P(logl), P(derived), P(end_u), P(end_v), P(end_logl), P(moved),
+                                             P(end_d), C, P(dead_v), P(dead_logl), P(dead_logwt), P(dead_zprev), cap, -1.0, 10 ** 9, 10 ** 9,
+                                             10 ** 9)
+        assert reason == _lib.HOST_NEED_SAMPLES, reason
+        if batches == 12:
+            break
+        batches += 1
+        end_logl[:] = rng.integers(0, 16, C)           # ties among the candidates and with the live points
+        end_u[:] = rng.random((C, D))
+        end_v[:] = end_u
+        moved[:] = rng.random(C) < 0.9
+        nb = 0                                         # the mirror consumes the batch
+        while True:
+            worst = int(np.argmin(m_logl))
+            if m_accept:
+                expect_v.append(m_v[worst].copy())
+                expect_l.append(m_logl[worst])
+                m_accept = False
+            if nb >= C:
+                break
+            while nb < C:
+                c = nb
+                nb += 1
+                if moved[c] and end_logl[c] > m_logl[worst]:
+                    m_logl[worst], m_v[worst] = end_logl[c], end_v[c]
+                    m_accept = True
+                    break
+        st.nb = 0
+        st.resume = _lib.HOST_AFTER_SAMPLES
+    n = int(st.n_dead)
+    assert n == len(expect_l) and n > 300
+    assert np.array_equal(dead_logl[:n], np.array(expect_l))
+    assert np.array_equal(dead_v[:n], np.array(expect_v))
+    assert np.array_equal(logl, m_logl) and np.array_equal(v, m_v)

@@ -1,12 +1,12 @@
-"""Developer diagnostic: wall-time split of a full config-2 run (low-overhead timers around the main segments).
-   python tools/run_timing.py [flow]"""
+"""Developer diagnostic: wall-time split of a full run of a BASELINE configuration (low-overhead timers around the main segments).
+   python tools/run_timing.py [flow] [config: 2 (default) | 3 | 4 | 5]"""
 import os, sys, time, tempfile, json
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nnest_amd.flow as nflow
 import nnest_amd.trainer as tmod
 import nnest_amd.sampler as smod
-from nnest_amd.likelihoods import Rosenbrock
+from nnest_amd.likelihoods import GaussianMix, Himmelblau, Rosenbrock
 from nnest_amd.nested import NestedSampler
 T = {}
 def wrap(obj, name, key, sync=False):
@@ -70,11 +70,20 @@ def _argsort_timed(self, *a, **k):
     t0 = time.perf_counter(); r = _argsort(self, *a, **k); e = T.setdefault('  argsort (perm table)', [0.0, 0]); e[0] += time.perf_counter() - t0; e[1] += 1; return r
 torch.Tensor.argsort = _argsort_timed
 flow = sys.argv[1] if len(sys.argv) > 1 else 'nvp'
-like = Rosenbrock(50)
+cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+like, scale, N = {2: (Rosenbrock(50), 5.0, 1000), 3: (GaussianMix(20), 10.0, 2000), 4: (Himmelblau(32), 5.0, 4000),
+                  5: (Rosenbrock(100), 5.0, 8000)}[cfg]
+_L = L.load()
+_consume = _L.nnest_host_mcmc_consume
+def _consume_timed(*a):
+    t0 = time.perf_counter(); r = _consume(*a); e = T.setdefault('nnest_host_mcmc_consume (evidence loop)', [0.0, 0]); e[0] += time.perf_counter() - t0; e[1] += 1; return r
+_L.nnest_host_mcmc_consume = _consume_timed
+wrap(NestedSampler, '_mcmc_endpoints_fused', 'K4 batch (launch + read-back)')
+wrap(NestedSampler, '_checkpoint', 'checkpoint')
 np.random.seed(0); torch.manual_seed(0)
-s = NestedSampler(50, like, transform=lambda x: 5.0 * x, log_dir=tempfile.mkdtemp(dir='/tmp'), num_live_points=1000, log_level=30, flow=flow)
+s = NestedSampler(like.x_dim, like, transform=lambda x: scale * x, log_dir=tempfile.mkdtemp(dir='/tmp'), num_live_points=N, log_level=30, flow=flow)
 t0 = time.time()
-s.run(mcmc_num_chains=1000)
+s.run(mcmc_num_chains=N)
 print('wall %.1f s logz %.3f' % (time.time() - t0, s.logz))
 for k, (t, n) in sorted(T.items(), key=lambda kv: -kv[1][0]):
     print('  %-32s %8.2f s  %7d calls  %8.3f ms each' % (k, t, n, t / n * 1e3))
