@@ -17,7 +17,7 @@ live = rng.uniform(-1, 1, size=(N, D))
 nv = N // 10
 E = 40
 perms = torch.stack([torch.randperm(N - nv) for _ in range(E)]).int()
-for name, one_cu in (('eight CUs (train_kernel_grid)', False), ('one CU   (train_kernel)', True)):
+for name, one_cu in (('multi-CU (train_kernel_rows)', False), ('one CU   (train_kernel)', True)):
     nvp = flow.HipNVP(D, 16, 3, 1, seed=1)
     kw = dict(seed=1, jitter=0.01, batch=100, patience=1000, one_cu=one_cu)
     nvp.train_epochs(live[nv:], live[:nv], perms[:2], None, max_epochs=2, **kw)
