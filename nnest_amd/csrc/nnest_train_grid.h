@@ -60,7 +60,9 @@ __device__ __forceinline__ bool grid_barrier(unsigned int *ctr, int &phase, int 
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int want = (unsigned int)G * (unsigned int)phase;
         int polls = 0, good = 1;
-        if (first_poll_sleep > 8) __builtin_amdgcn_s_sleep(16);   // (the instruction takes an immediate)
+        if (first_poll_sleep >= 256) {   // 256 + n: n units of 256 cycles (the instruction takes an immediate)
+            for (int i = 256; i < first_poll_sleep; ++i) __builtin_amdgcn_s_sleep(4);
+        } else if (first_poll_sleep > 8) __builtin_amdgcn_s_sleep(16);
         else if (first_poll_sleep > 0) __builtin_amdgcn_s_sleep(8);
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             if (++polls > GRID_MAX_POLLS) { good = 0; *err = 1; break; }

@@ -175,6 +175,22 @@ static __device__ __forceinline__ float rows_act_grad(float g, float a, unsigned
 static __device__ __forceinline__ void rows_stage(float *stg_net, int ct, int row, int col, float v, bool stager) {
     if (stager) st_sc1(stg_net + ((size_t)ct * TRAIN_MAX_ROWS + row) * 16 + col, v);
 }
+// a value per slot: the lane at position pos holds slots U pos .. U pos + U - 1 (column tile ct0 + slot / 16, column slot % 16).
+// U = 4: the lane's four slots are one aligned 16-byte store.  (U = 1, 2 collecting the neighbours' values by DPP into 16-byte stores
+// was measured SLOWER, 11.8 against 11.3 us per minibatch at x_dim 50: the drain in front of the barrier is not what the barrier waits for.)
+template <int U>
+static __device__ __forceinline__ void rows_stage_slots(float *stg_net, int ct0, int row, int pos, const float (&v)[U], bool stager) {
+    if constexpr (U == 4) {
+        const int s = 4 * pos;
+        if (stager) st_sc1_f32x4(stg_net + ((size_t)(ct0 + (s >> 4)) * TRAIN_MAX_ROWS + row) * 16 + (s & 15), (f32x4){v[0], v[1], v[2], v[3]});
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = U * pos + u;
+            rows_stage(stg_net, ct0 + (s >> 4), row, s & 15, v[u], stager);
+        }
+    }
+}
 
 // ---- reverse mode through one coupling block (block_backward_grid's arithmetic on one row) ----
 // in: ytrans = the block's OUTPUT on the transformed side, gtrans / gcond = d loss / d (block outputs);
@@ -209,11 +225,7 @@ static __device__ __forceinline__ void rows_block_backward(const Solo4Lds &wb_, 
         gtrans[U - 1] = gv * __expf(kp.ls[U / 2]);
         go[U - 1] = translate_half ? g_t : g_ls;
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int s = U * pos + u;
-        rows_stage(stg_net, SM::gout(s >> 4), row, s & 15, go[u], stager);
-    }
+    rows_stage_slots<U>(stg_net, SM::gout(0), row, pos, go, stager);
     // g_h2 = Wo^T g_out   (the transposed image's first U field groups)
     float wa[8], wb[8], a0, a1;
     if constexpr (U >= 2) {
@@ -243,10 +255,11 @@ static __device__ __forceinline__ void rows_block_backward(const Solo4Lds &wb_, 
     const float g_a1 = rows_act_grad(solo_join_rot(a0 + a1), kp.h1, sel);
     rows_stage(stg_net, SM::gpre(0, 0), row, pos, g_a1, stager);
     rows_stage(stg_net, SM::act(0, 0), row, pos, kp.h1, stager);
+    {
+        float cm[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int s = U * pos + u;
-        rows_stage(stg_net, SM::m(s >> 4), row, s & 15, row_ok ? cond[u] : 0.f, stager);
+        for (int u = 0; u < U; ++u) cm[u] = row_ok ? cond[u] : 0.f;
+        rows_stage_slots<U>(stg_net, SM::m(0), row, pos, cm, stager);
     }
     // d loss / d (conditioning input) += W0^T g_a1 of both nets
 #pragma unroll
@@ -319,6 +332,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_rows(TrainArgs a) 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pos = lane & 15;
     const bool h1 = (lane & 16) != 0, translate_half = lane >= 32, stager = (lane & 16) == 0;
+    const int sl_r = (int)a.gld_in & 255, sl_b = ((int)a.gld_in >> 8) & 255;   // hold-backs of the two polls, units of 256 cycles (launch_train_rows_t)
     const unsigned sel = translate_half ? 0xffffffffu : 0u;
     const int wg = blockIdx.x, G = gridDim.x;
     const int D = a.s.D;
@@ -507,7 +521,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_rows(TrainArgs a) 
                 alive = okd != 0;
             }
 #else
-            alive = grid_barrier(a.gsync, phase, G, a.gerr, 16);   // (the workgroups leave the pass ~1 k cycles apart)
+            alive = grid_barrier(a.gsync, phase, G, a.gerr, 256 + sl_b);   // (the workgroups leave the pass ~1 k cycles apart)
 #endif
             if (!alive) break;
             TSTAMP(q3);
@@ -566,7 +580,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_rows(TrainArgs a) 
             {
                 constexpr int CH = RU > 4 ? 4 : RU;   // loads in flight per thread and round (x_dim > 64: two rounds, the second finds its data there)
                 const int want = mbcount + 1;
-                __builtin_amdgcn_s_sleep(16);   // (the owners' stores are ~1.5 k cycles from being visible: a poll issued at once would miss and cost a whole round trip)
+                for (int i = 0; i < sl_r; ++i) __builtin_amdgcn_s_sleep(4);   // (the owners' stores are ~1.5 k cycles from being visible: a poll issued at once would miss and cost a whole round trip)
 #pragma unroll
                 for (int c0 = 0; c0 < RU; c0 += CH) {
                     f32x4 va[CH], vc[CH];
@@ -749,6 +763,11 @@ static hipError_t launch_train_rows_t(TrainArgs a, float *gridws, hipStream_t st
     hipLaunchKernelGGL((grid_gpos_kernel<U, 1, 1>), dim3(32), dim3(256), 0, st, a.gpos, a.s);
     hipLaunchKernelGGL(grid_dead_kernel, dim3(32), dim3(256), 0, st, a.gpos, a.s.num_params(), a.gdead, a.gndead);
     hipLaunchKernelGGL((rows_maps_kernel<U>), dim3(32), dim3(256), 0, st, reinterpret_cast<int *>(a.gown), a.s);   // (the owners' record area of train_kernel_grid: unused here)
+    {   // how long the first poll of the grid barrier / of the refresh is held back (units of 256 cycles; NNEST_K5_SLEEP=r,b overrides)
+        int r = 4, b = 4;
+        if (const char *e = getenv("NNEST_K5_SLEEP")) sscanf(e, "%d,%d", &r, &b);
+        a.gld_in = (float)((r & 255) + 256 * (b & 255));   // (the VJP's scalar: unused by the training loop)
+    }
     const int NJ = ROWS_B * 2 * (2 * U + 1);
     const int G = max((a.batch + ROWS_PER_WG - 1) / ROWS_PER_WG, (NJ + TRAIN_WAVES - 1) / TRAIN_WAVES);
     const size_t lds = (size_t)2 * ROWS_B * SOLO4_NF * 64 * sizeof(float);
