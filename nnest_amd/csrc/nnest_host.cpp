@@ -18,8 +18,9 @@ extern "C" long nnest_format_rows_e5(const double *rows, long n_rows, int n_cols
     const long per_row = (long)n_cols * 14;   // "-1.23457E+123 " is 14 characters
     if (out_cap < n_rows * per_row + 1) return -1;
     if (threads < 1) threads = 1;
-    if (threads > 16) threads = 16;
+    if (threads > 64) threads = 64;
     if (n_rows < 4096) threads = 1;
+    else if ((long)threads * 2048 > n_rows) threads = (int)(n_rows / 2048);   // (a thread is worth starting for a few thousand rows)
     std::vector<long> used(threads, 0);
     const long chunk = (n_rows + threads - 1) / threads;
     auto work = [&](int t) {

@@ -316,3 +316,40 @@ def test_usable_chain_flag_from_the_accept_count(hip):
         assert np.all((na >= 0) & (na <= 60) & (nc >= na) & (nc <= 60))      # written for every walker, by every form
         moved_ref = np.all(cpu(x0) != cpu(res['x']), axis=1)
         assert np.array_equal(moved_ref, na > 0), (C, step, int(np.sum(moved_ref != (na > 0))))
+
+
+@pytest.mark.gpu
+def test_every_form_writes_both_counters_of_every_walker(hip, monkeypatch):
+    """The driver allocates n_accept / n_call uninitialised (flow.py: no fill launches in front of the kernel), so a form that
+    left a walker's counters unwritten would feed garbage into the usable-chain flag and the call accounting.  Here
+    every int32 allocation is poisoned first, at ragged populations that leave every form's last tile / workgroup partly empty."""
+    import torch
+    nvp, o, g = trained(hip)
+    orig = torch.empty
+
+    def poisoned(*a, **k):
+        t = orig(*a, **k)
+        if t.dtype == torch.int32:
+            t.fill_(0x7fffffff)
+        return t
+
+    forms = set()
+    for C, dyn in ((1, False), (37, False), (37, 'batch'), (131, True), (1001, 'batch'), (1021, False), (2003, 'batch'), (3059, 'batch'),
+                   (4001, 'batch'), (4001, True), (9001, False)):
+        rng = np.random.RandomState(C)
+        init = g['init'][rng.randint(0, g['init'].shape[0], size=C)]
+        z0, _ = nvp.forward(init)
+        l0 = hip.loglike(0, init, 5.0)
+        star = float(np.median(cpu(l0))) if C > 1 else float(cpu(l0)[0]) - 1.0
+        monkeypatch.setattr(torch, 'empty', poisoned)
+        try:
+            res = nvp.mh_steps(0, 5.0, z0.clone(), l0.clone(), star, 0.02, 120, seed=C, dynamic=dyn)
+        finally:
+            monkeypatch.setattr(torch, 'empty', orig)
+        if dyn == 'batch':
+            nvp.check_sync(res)
+        na, nc = cpu(res['n_accept']), cpu(res['n_call'])
+        assert np.all((na >= 0) & (na <= 120) & (nc >= na) & (nc <= 120)), (C, dyn, int(na.max()), int(nc.max()))
+        lag = nvp.default_lag(C) if dyn == 'batch' else 0
+        forms.add(nvp.mh_form_for(C, dynamic=dyn, lag=lag, warm=nvp.default_warm(C, dyn, lag) if lag else 0))
+    assert len(forms) >= 3, forms     # solo, quad / team / image ... all went through it
