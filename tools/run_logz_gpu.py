@@ -57,6 +57,8 @@ for seed in seeds:
         stamp = build_stamp(s, chains, 5 * D)
         if lag is not None:
             stamp['step_lag'] = lag
+            if lag == 0:
+                stamp['step_warm'] = 0    # (every step exact: no warm-up in front of anything)
     t0 = time.time()
     s.run(mcmc_num_chains=chains, mcmc_step_lag=lag)
     runs.append(dict(seed=seed, logz=float(s.logz), logzerr=float(s.logzerr), h=float(s.h), niter=int(s.niter), ncall=int(s.ncall),
