@@ -56,7 +56,7 @@ def test_passes_vs_reference_fixture(hip, path):
         assert np.array_equal(sp.store_packed(), g['w_' + tag]) and np.array_equal(sp.P, g['P'])
         x = g['x']
         # measured against the float64 oracle the kernels sit at 1e-6..2e-6, the level of the reference's own float32
-        # (tools/spline_err.py); against the reference's float32 outputs: 1e-5 relative-to-(1+|v|)
+        # (tests/diag_spline_err.py); against the reference's float32 outputs: 1e-5 relative-to-(1+|v|)
         z, ld = sp.forward(x)
         assert rel(cpu(z), g['z_' + tag]) < 1e-5
         assert rel(cpu(ld), g['ldf_' + tag]) < 1e-5
