@@ -132,7 +132,7 @@ __device__ __forceinline__ void spl_hidden(const float *__restrict__ net, int la
 // v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32 (1 ulp each; quarter rate) instead of the correctly-rounded library
 // sequences: the spline evaluation is VALU-bound (about 40 exponentials per dimension and direction), and with the
 // library calls it cost ~6x more than the matrix work around it.  Measured in float64 arithmetic the passes stay at
-// the 1e-6 level of the reference's own float32 (tools/spline_err.py).
+// the 1e-6 level of the reference's own float32 (tests/diag_spline_err.py).
 __device__ __forceinline__ float spl_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
 __device__ __forceinline__ float spl_log(float v) { return __builtin_amdgcn_logf(v) * 0.6931471805599453f; }
 __device__ __forceinline__ float spl_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
