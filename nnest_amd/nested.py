@@ -378,6 +378,8 @@ class NestedSampler(Sampler):
         self.mcmc_step_warm = mcmc_step_warm
         if hasattr(self.trainer, 'wait_for_saves'):
             self.trainer.async_save = True   # models/netG.pt written beside the GPU work; run() waits for the last one below
+            if hasattr(self.trainer, 'background_jobs') and hasattr(self.trainer.writer, 'jobs'):
+                self.trainer.writer.jobs = self.trainer.background_jobs()   # ... and the bulk log-Z scalars
         self._grow = None   # the dead-point files of a previous run() on this object are not this run's
         self._prior_cache = None   # (nor are the prior candidates it left unexamined: a reseeded run must not depend on them)
         if strategy is None or len(strategy) == 0:
@@ -676,6 +678,8 @@ class NestedSampler(Sampler):
         if hasattr(self.trainer, 'wait_for_saves'):
             self.trainer.wait_for_saves()
             self.trainer.async_save = False
+            if getattr(self.trainer.writer, 'jobs', None) is not None:
+                self.trainer.writer.jobs = None
         logz, h = ev.logz, ev.h
         self.logz = logz
         self.h = h

@@ -236,22 +236,23 @@ class Trainer(object):
                          % (self.best_validation_epoch, self.best_validation_loss, time.time() - start_time))
 
     def _save_async(self, state, path):
-        import threading
-        self.wait_for_saves()
-
         def work():
             tmp = path + '.tmp'
             torch.save(state, tmp)
             os.replace(tmp, path)
-        self._saver = threading.Thread(target=work)   # (not a daemon: the interpreter waits for it at exit)
-        self._saver.start()
+        self.background_jobs().submit(work)
+
+    def background_jobs(self):
+        """the worker that writes files the run does not wait for (utils.BackgroundJobs), created at first use"""
+        if getattr(self, '_jobs', None) is None:
+            from .utils import BackgroundJobs
+            self._jobs = BackgroundJobs()
+        return self._jobs
 
     def wait_for_saves(self):
-        """block until models/netG.pt holds the last trained weights"""
-        t = getattr(self, '_saver', None)
-        if t is not None:
-            t.join()
-            self._saver = None
+        """block until models/netG.pt holds the last trained weights (and everything else handed to background_jobs() is done)"""
+        if getattr(self, '_jobs', None) is not None:
+            self._jobs.wait()
 
     # ------------------------------------------------------------------------------------------------
     def forward(self, x, to_numpy=False):

@@ -244,3 +244,39 @@ def test_native_loop_takes_the_first_smallest_live_point():
     assert np.array_equal(dead_logl[:n], np.array(expect_l))
     assert np.array_equal(dead_v[:n], np.array(expect_v))
     assert np.array_equal(logl, m_logl) and np.array_equal(v, m_v)
+
+
+def test_background_jobs_keep_the_order_of_the_scalar_rows(tmp_path):
+    """round 4: models/netG.pt and the bulk log-Z scalars are written by one worker thread (utils.BackgroundJobs) beside the GPU work.
+    scalars.csv must hold the rows in the order of the calls, whichever path a row took, and a job's exception surfaces at wait()."""
+    from nnest_amd.utils import BackgroundJobs, ScalarWriter
+    jobs = BackgroundJobs()
+    w = ScalarWriter(str(tmp_path))
+    w.jobs = jobs
+    w.add_scalar('logz', -3.0, 1)
+    w.add_scalar('logz', -2.5, 2)
+    w.add_scalars('logz', np.arange(3, 2003), np.linspace(-2.0, 0.0, 2000))
+    w.add_scalar('logz', 0.25, 2003)
+    w.add_scalars('logz', [2004, 2005], [0.5, 0.75])
+    w.flush()
+    rows = open(os.path.join(str(tmp_path), 'scalars.csv')).read().splitlines()
+    assert len(rows) == 2005
+    assert [int(r.split(',')[1]) for r in rows] == list(range(1, 2006))
+    assert rows[0] == 'logz,1,-3.0' and rows[-1] == 'logz,2005,0.75' and rows[2] == 'logz,3,-2.0'
+    # the same rows without a worker
+    w2 = ScalarWriter(str(tmp_path / 'b'))
+    os.makedirs(str(tmp_path / 'b'))
+    w2.add_scalar('logz', -3.0, 1)
+    w2.add_scalar('logz', -2.5, 2)
+    w2.add_scalars('logz', np.arange(3, 2003), np.linspace(-2.0, 0.0, 2000))
+    w2.add_scalar('logz', 0.25, 2003)
+    w2.add_scalars('logz', [2004, 2005], [0.5, 0.75])
+    w2.flush()
+    assert open(os.path.join(str(tmp_path / 'b'), 'scalars.csv')).read().splitlines() == rows
+
+    def boom():
+        raise OSError('disk full')
+    jobs.submit(boom)
+    with pytest.raises(OSError):
+        jobs.wait()
+    jobs.wait()   # reported once
