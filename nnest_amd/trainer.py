@@ -164,7 +164,10 @@ class Trainer(object):
         start_time = time.time()
         samples = np.asarray(samples)
         if self.path:
-            np.save(os.path.join(self.path, 'data', 'originals.npy'), samples)
+            if getattr(self, 'async_save', False):   # (a copy: the caller's live points move on while the worker writes)
+                self.background_jobs().submit(lambda a=np.array(samples), p=os.path.join(self.path, 'data', 'originals.npy'): np.save(p, a))
+            else:
+                np.save(os.path.join(self.path, 'data', 'originals.npy'), samples)
         training_jitter = self.training_jitter(samples) if jitter < 0 else jitter
         if self.log:
             self.logger.info('Number of training samples [%d]' % samples.shape[0])
