@@ -84,6 +84,14 @@ def cpu_baseline(D, w, like, scale, walkers, target_seconds=10.0):
         return walkers * steps / (time.perf_counter() - t0)
 
     cores = os.cpu_count() or 1
+    try:   # what this process may actually use: the affinity mask and the container's CPU quota (cgroup v2 cpu.max: "quota period")
+        cores = min(cores, len(os.sched_getaffinity(0)))
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, per = f.read().split()[:2]
+        if q != 'max':
+            cores = max(1, min(cores, int(np.ceil(float(q) / float(per)))))
+    except (OSError, ValueError, AttributeError):
+        pass
     r1 = run(2, 1)
     one = run(int(max(2, min(2000, target_seconds * r1 / walkers))), 1)
     threads = min(cores, walkers)
@@ -93,7 +101,7 @@ def cpu_baseline(D, w, like, scale, walkers, target_seconds=10.0):
     return {'value': allc, 'unit': 'evals/s', 'cores': threads, 'kind': 'port',
             'one_thread': one,
             'sample': '%d walkers x %d MH steps of the same workload (dynamic step rule), oracle/nnest_oracle.c, walkers '
-                      'split over %d threads of the %d host cores; one_thread = the same code on one core' % (
+                      'split over %d threads (the %d CPUs this container may use: affinity mask and cgroup quota); one_thread = the same code on one core' % (
                           walkers, steps_all, threads, cores)}
 
 
