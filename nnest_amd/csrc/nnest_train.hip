@@ -993,6 +993,7 @@ static hipError_t dispatch_train(const TrainArgs &a, hipStream_t st) {
 
 #include "nnest_train_grid.h"
 #include "nnest_train_rows.h"
+#include "nnest_train_pipe.h"
 // torch.optim.Adam (coupled weight decay), one element of the step, every operation rounded by itself (no multiply-add contraction: the choice of which product a compiler
 // fuses differs from kernel to kernel, and the kernels that share this function must agree bit for bit -- maf_update_kernel steps
 // the same parameters inside another loop)
@@ -1112,6 +1113,7 @@ hipError_t launch_train(float *packed, float *adam_m, float *adam_v, float *best
     a.losses = losses; a.result = result;
     a.epoch_offset = epoch_offset; a.flags = flags;
     a.mode = TRAIN_MODE_EPOCHS;
+    if (grid_eligible(a) && pipe_eligible(a)) return dispatch_train_pipe(a, workspace + ((single_workspace_floats(s) + 63) & ~(size_t)63), st);
     if (grid_eligible(a) && rows_eligible(a)) return dispatch_train_rows(a, workspace + ((single_workspace_floats(s) + 63) & ~(size_t)63), st);
     if (grid_eligible(a)) return dispatch_train_grid(a, workspace + ((single_workspace_floats(s) + 63) & ~(size_t)63), st);
     return dispatch_train(a, st);

@@ -1,0 +1,597 @@
+// nnest_train_pipe.h -- K5, the rows form PIPELINED PER COUPLING BLOCK (round 5; included behind nnest_train_rows.h, inside
+// namespace nnest).
+//
+// train_kernel_rows runs a minibatch as  F+B (all row waves) -> grid barrier -> weight-gradient jobs + Adam + publish -> refresh
+// of the two LDS images:  5.7 k cycles of arithmetic and 19.9 k cycles of cross-CU hand-offs, all of them exposed, because the one
+// barrier sits behind the WHOLE backward pass and every wave of the grid takes part in every phase (profiles/r04/k5_stamps.txt).
+// But the backward pass leaves block 2 first, then 1, then 0, and a block's weights depend on that block's gradients only
+// (trainer.py:396-398: one optimizer step over independent tensors).  Here a workgroup's waves have fixed roles and nothing in the
+// minibatch loop is a workgroup barrier or a grid barrier:
+//   row waves (0..3)      forward and backward of one row each (rows_block_forward / rows_block_backward, unchanged arithmetic);
+//                         behind a block's backward stores they ARRIVE on that block's counter (the wave's counted s_waitcnt, an
+//                         LDS count of the workgroup's four waves, the last one adds to the grid's counter) and go on;
+//   service waves (4..7)  prepare the next minibatch's rows; the owner of a weight-gradient job waits for ITS block's counter,
+//                         contracts, applies Adam in its registers and publishes the new tile as {weight, tag} granules; then
+//                         every service wave re-lays the published tiles into the workgroup's two solo images BLOCK BY BLOCK
+//                         (2, 1, 0 -- the order the backward pass frees them) and counts the block refreshed in LDS;
+//   the next forward pass waits, block by block, for that LDS count.
+// So blocks 2 and 1 are contracted, stepped, published and refreshed while the row waves are still in blocks 1 and 0; only block 0's
+// chain -- a third of the bytes -- stays on the critical path.  The forward-pass quantities a job needs (activations, the
+// conditioning input) are staged by the FORWARD pass, which halves the stores in front of the last arrival.
+// Same jobs, same operand order, same Adam, same publish format as train_kernel_rows; the one difference in value is that the staged
+// conditioning input is the forward pass's own (train_kernel_rows stages the one its backward pass recovered by inverting the
+// blocks above: equal to rounding).  Every reduction keeps a fixed order: bitwise reproducible run to run.
+//
+// Cross-CU visibility (MI355X_MICROARCH.md, "Valid forms"): all handed-off bytes are sc1 stores and sc1 loads to registers; a
+// counter add comes after the s_waitcnt of every wave it signals for (a wave's stores complete in order: only stores are in flight
+// in a row wave); the wave that polled a counter loads only after its poll matched; published weights are tagged granules (R2).
+// Every wait is bounded; one that runs out sets the error word and the launch ends with result.stopped = 2.
+
+enum { PIPE_SVC = 4, SF_REF = 0, SF_X = 3, SF_ARR = 4, SF_ABORT = 7, SF_N = 8 };
+
+static __device__ __forceinline__ int pipe_lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// spin on a word of the workgroup's LDS until it reaches `want`; false: aborted or ran out
+static __device__ __forceinline__ bool pipe_wait_lds(const int *flag, int want, const int *abort_w) {
+    bool ok = true;
+    for (int polls = 0; pipe_lds_ld(flag) < want; ++polls) {
+        if (polls > GRID_MAX_POLLS || pipe_lds_ld(abort_w)) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    return ok;
+}
+// spin on a counter of the grid (sc1 loads)
+static __device__ __forceinline__ bool pipe_wait_ctr(const unsigned int *ctr, unsigned int want, const int *abort_w, const int *gerr) {
+    bool ok = true;
+    for (int polls = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++polls) {
+        if (polls > GRID_MAX_POLLS || ((polls & 255) == 255 && (pipe_lds_ld(abort_w) || __hip_atomic_load(gerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))) {
+            ok = false;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    return ok;
+}
+
+// what the forward pass stages for the block's weight-gradient jobs: the two hidden activations and the conditioning input
+template <int U>
+static __device__ __forceinline__ void rows_stage_forward(float *stg_net, int row, int pos, bool row_ok, const float (&cond)[U],
+                                                          const RowsKeep<U> &kp, bool stager) {
+    typedef StageMap<U, 1, 1> SM;
+    rows_stage(stg_net, SM::act(1, 0), row, pos, kp.h2, stager);
+    rows_stage(stg_net, SM::act(0, 0), row, pos, kp.h1, stager);
+    float cm[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cm[u] = row_ok ? cond[u] : 0.f;
+    rows_stage_slots<U>(stg_net, SM::m(0), row, pos, cm, stager);
+}
+
+template <int U>
+__global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) {
+    typedef StageMap<U, 1, 1> SM;
+    constexpr int B = ROWS_B, IMG = ROWS_B * SOLO4_NF * 64;
+    constexpr int NBS = 2 + (U == 4 ? 1 : U);   // vector-memory stores of one block's backward pass (gout, g_pre of the two hidden layers)
+    constexpr int NPW = (ROWS_PER_WG * 8 * U + 63) / 64;   // service waves that prepare rows
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *imgf = smem;          // forward solo image  [B][SOLO4_NF / 4][64][4]
+    float *imgb = smem + IMG;    // transposed solo image
+    __shared__ __attribute__((aligned(16))) float xpre[2][ROWS_PER_WG * 32 * U];   // the minibatch's rows, flat, a minibatch ahead
+    __shared__ int ctl[4];      // [0] stop flag, [1] counter, [2] best epoch
+    __shared__ float ctlf[2];   // [0] best validation loss, [1] the epoch's training loss (workgroup 0)
+    __shared__ int sflag[SF_N]; // [SF_REF + b] service waves that have refreshed block b (monotonic), [SF_X] row preparations done,
+                                // [SF_ARR + b] row waves arrived behind block b's backward stores, [SF_ABORT]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wg = blockIdx.x, G = gridDim.x;
+    const int D = a.s.D;
+    constexpr int NJOBS = 2 * U + 1;
+    const bool row_wave = wave < ROWS_PER_WG;
+    int phase = 0;
+
+    // ---- the two solo images from the packed weights ----
+    for (int i = threadIdx.x; i < 2 * IMG; i += blockDim.x) smem[i] = 0.f;
+    if (threadIdx.x < SF_N) sflag[threadIdx.x] = threadIdx.x == SF_X ? NPW : 0;
+    __syncthreads();
+    for (int p = threadIdx.x; p < a.s.nets_params(); p += blockDim.x) {
+        const int bn = p / a.s.net_params, o = p - bn * a.s.net_params;
+        int df, db; bool sc;
+        rows_param_dest<U>(D, bn >> 1, bn & 1, o, df, db, sc);
+        const float v = a.w[p];
+        if (df >= 0) imgf[df] = sc ? SOLO_TANH_PRESCALE * v : v;
+        if (db >= 0) imgb[db] = v;
+    }
+    const bool resume = (a.flags & NNEST_TRAIN_RESUME) != 0;
+    if (threadIdx.x == 0) {
+        ctl[0] = 0;
+        ctl[1] = resume ? a.result->counter : 0;
+        ctl[2] = resume ? a.result->best_epoch : 0;
+        ctlf[0] = resume ? a.result->best_validation_loss : INFINITY;
+        ctlf[1] = 0.f;
+    }
+    const int n_mb = (a.n_train + a.batch - 1) / a.batch;
+    if (a.max_epochs > 0) rows_prepare<U>(a, 0, 0, wg, xpre[0]);
+    __syncthreads();
+
+    float *part_base = a.gtile;   // [3][128] log p of a minibatch's rows, [2][128] validation sums of the row waves (sc1 words, one writer each)
+    unsigned int *arrival = reinterpret_cast<unsigned int *>(a.gtile + 1024);   // [b] at + 32 b: workgroups whose rows are behind block b's backward stores
+    const int *abort_w = &sflag[SF_ABORT];
+    // the sum of the 4 G row waves' words in a fixed order: lane l takes words l and l + 64, then a butterfly over the lanes
+    auto sum_rows = [&](const float *words) {
+        float v = (lane < ROWS_PER_WG * G ? ld_sc1(words + lane) : 0.f) + (lane + 64 < ROWS_PER_WG * G ? ld_sc1(words + lane + 64) : 0.f);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    unsigned long long ph[4] = {0, 0, 0, 0}, q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0;
+    (void)ph; (void)q0; (void)q1; (void)q2; (void)q3; (void)q4;
+    int epochs_run = 0, mbcount = 0;
+    float last_train_loss = 0.f;
+    bool alive = true;
+    auto fail = [&]() {   // a wait ran out (or another wave's did): every wave of the workgroup leaves its loops, the launch ends
+        alive = false;
+        if (lane == 0) { sflag[SF_ABORT] = 1; *a.gerr = 1; }
+    };
+    // What both kinds of wave do at the end of an epoch, barrier for barrier (the two kinds run different code: a workgroup barrier
+    // counts waves, not program counters).  validate(): the role's share of Trainer._validate; snapshot(): the role's share of
+    // best_model = deepcopy(netG).  Returns false when the epoch loop ends.
+    auto epoch_end = [&](int epoch, auto &&validate, auto &&snapshot) -> bool {
+        __syncthreads();
+        alive = alive && pipe_lds_ld(abort_w) == 0;
+        if (alive) validate();
+        __syncthreads();
+        alive = alive && pipe_lds_ld(abort_w) == 0;
+        if (!alive) return false;
+        alive = grid_barrier(a.gsync, phase, G, a.gerr);
+        if (!alive) return false;
+        const float vtot = sum_rows(part_base + (3 + (epoch & 1)) * TRAIN_MAX_ROWS);
+        const float valid_loss = (-vtot / (float)a.n_valid) / (float)a.n_valid;  // mean, then / len(dataset)  :418
+        const float train_loss = ctlf[1];
+        last_train_loss = train_loss;
+        epochs_run = epoch + 1;
+#ifndef NNEST_STAMP
+        if (a.losses && wg == 0 && threadIdx.x == 0) {
+            a.losses[2 * epoch] = train_loss;
+            a.losses[2 * epoch + 1] = valid_loss;
+        }
+#endif
+        // early stopping bookkeeping (trainer.py:205-209, :223-232); every thread of the grid evaluates the same values
+        const bool improved = valid_loss < ctlf[0];
+        __syncthreads();
+        if (improved) {
+            snapshot();
+            if (threadIdx.x == 0) { ctlf[0] = valid_loss; ctl[2] = a.epoch_offset + epoch + 1; ctl[1] = 0; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ctl[1] += 1;
+            if (ctl[1] > a.patience) ctl[0] = 1;
+        }
+        __syncthreads();
+        return ctl[0] == 0;
+    };
+
+    if (row_wave) {
+        // =====================================================================================================================
+        // a row of every minibatch: forward, backward, arrivals
+        // =====================================================================================================================
+        const int pos = lane & 15;
+        const bool h1 = (lane & 16) != 0, translate_half = lane >= 32, stager = (lane & 16) == 0;
+        const unsigned sel = translate_half ? 0xffffffffu : 0u;
+        const int row = wg * ROWS_PER_WG + wave;
+        float *stg_net0 = a.gstage + (size_t)(translate_half ? 1 : 0) * SM::count * TRAIN_MAX_ROWS * 16;   // + 2 b regions per block
+        constexpr size_t RS = (size_t)2 * SM::count * TRAIN_MAX_ROWS * 16;   // a block's two staging regions
+        // the stores of block b's backward pass (and everything before them) have completed -> count the wave in; the workgroup's
+        // last wave counts the workgroup in
+        auto arrive = [&](int b) {
+            if (lane == 0) {
+                const int old = __hip_atomic_fetch_add(&sflag[SF_ARR + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((old & (ROWS_PER_WG - 1)) == ROWS_PER_WG - 1) __hip_atomic_fetch_add(arrival + 32 * b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+        // log p(row) = -sum E(z) + D base_const + log|det|   (networks.py:71-76), the same value in every lane
+        auto log_prob = [&](const float (&xs)[2][U], float ld_lane) {
+            float ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int u = 0; u < U; ++u) ss += base_E(xs[c][u], a.s.base_beta);
+            return -solo_row_sum(ss) + a.s.base_const * (float)D + solo_logdet_total(ld_lane);
+        };
+        for (int epoch = 0; epoch < a.max_epochs; ++epoch) {
+            for (int mb = 0; mb < n_mb && alive; ++mb, ++mbcount) {
+                const int M = min(a.batch, a.n_train - mb * a.batch);
+                const int rows_pad = ((M + 15) >> 4) * 16;
+                float *part = part_base + (mbcount % 3) * TRAIN_MAX_ROWS;
+                const bool row_ok = row < M;
+                TSTAMP(q0);
+                if (!pipe_wait_lds(&sflag[SF_X], NPW * (mbcount + 1), abort_w)) { fail(); break; }
+                if (row < rows_pad) {   // (rows M .. rows_pad - 1 run on zeros with row_ok = false: their staged gradients must read 0)
+                    float xs[2][U], gs[2][U];
+                    const float *xr = xpre[mbcount & 1] + wave * 32 * U + 2 * U * pos;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { xs[0][u] = xr[2 * u]; xs[1][u] = xr[2 * u + 1]; }
+                    RowsKeep<U> kp[B];
+                    // NormalizingFlow.forward (networks.py:24-32); a block's images must be the ones the last minibatch's weights were re-laid into
+                    bool okw = pipe_wait_lds(&sflag[SF_REF + 0], PIPE_SVC * mbcount, abort_w);
+                    TSTAMP(q1);
+                    float ld_lane = rows_block_forward<U>(Solo4Lds{imgf, lane}, sel, h1, xs[1], xs[0], kp[0]);
+                    rows_stage_forward<U>(stg_net0, row, pos, row_ok, xs[1], kp[0], stager);
+                    okw = okw && pipe_wait_lds(&sflag[SF_REF + 1], PIPE_SVC * mbcount, abort_w);
+                    ld_lane += rows_block_forward<U>(Solo4Lds{imgf + SOLO4_NF * 64, lane}, sel, h1, xs[0], xs[1], kp[1]);
+                    rows_stage_forward<U>(stg_net0 + RS, row, pos, row_ok, xs[0], kp[1], stager);
+                    okw = okw && pipe_wait_lds(&sflag[SF_REF + 2], PIPE_SVC * mbcount, abort_w);
+                    ld_lane += rows_block_forward<U>(Solo4Lds{imgf + 2 * SOLO4_NF * 64, lane}, sel, h1, xs[1], xs[0], kp[2]);
+                    rows_stage_forward<U>(stg_net0 + 2 * RS, row, pos, row_ok, xs[1], kp[2], stager);
+                    if (!okw) { fail(); break; }
+                    const float lp = row_ok ? log_prob(xs, ld_lane) : 0.f;
+                    if (lane == 0) st_sc1(part + row, lp);
+                    TSTAMP(q2);
+                    // d(loss)/du = dE/du / M ; d(loss)/d(logdet) = -1/M
+                    const float invM = 1.0f / (float)M, gld = -invM;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) gs[c][u] = row_ok ? base_dE(xs[c][u], a.s.base_beta) * invM : 0.f;
+                    rows_block_backward<U, false>(Solo4Lds{imgb + 2 * SOLO4_NF * 64, lane}, sel, h1, translate_half, pos, D, 0, row_ok, gld, xs[1], xs[0], gs[1], gs[0], kp[2], stg_net0 + 2 * RS, row, stager);
+                    rows_block_backward<U, false>(Solo4Lds{imgb + SOLO4_NF * 64, lane}, sel, h1, translate_half, pos, D, 1, row_ok, gld, xs[0], xs[1], gs[0], gs[1], kp[1], stg_net0 + RS, row, stager);
+                    // block 2's stores (and everything before them) are complete once at most block 1's NBS are outstanding
+                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NBS) : "memory");
+                    arrive(2);
+                    rows_block_backward<U, false>(Solo4Lds{imgb, lane}, sel, h1, translate_half, pos, D, 0, row_ok, gld, xs[1], xs[0], gs[1], gs[0], kp[0], stg_net0, row, stager);
+                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NBS) : "memory");
+                    arrive(1);
+                    TSTAMP(q3);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    arrive(0);
+                    TSTAMP(q4);
+                    if (wave == 0) { TACC(ph[0], q1, q0); TACC(ph[1], q2, q1); TACC(ph[2], q3, q2); TACC(ph[3], q4, q3); }
+                } else {
+                    if (lane == 0) st_sc1(part + row, 0.f);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    arrive(2); arrive(1); arrive(0);
+                }
+            }
+            // ---- Trainer._validate (trainer.py:405-418): validation row r on wave r % 4 of workgroup (r / 4) % G ----
+            const bool go_on = epoch_end(epoch, [&]() {
+                float vsum = 0.f;
+                bool okw = true;
+#pragma unroll
+                for (int b = 0; b < B; ++b) okw = okw && pipe_wait_lds(&sflag[SF_REF + b], PIPE_SVC * mbcount, abort_w);
+                if (!okw) { fail(); return; }
+                for (int r = row; r < a.n_valid; r += ROWS_PER_WG * G) {
+                    float xs[2][U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const int d = 2 * U * pos + 2 * u + c;
+                            xs[c][u] = d < D ? a.xvalid[(size_t)r * D + d] : 0.f;
+                        }
+                    RowsKeep<U> kp[B];
+                    float ld_lane = rows_block_forward<U>(Solo4Lds{imgf, lane}, sel, h1, xs[1], xs[0], kp[0]);
+                    ld_lane += rows_block_forward<U>(Solo4Lds{imgf + SOLO4_NF * 64, lane}, sel, h1, xs[0], xs[1], kp[1]);
+                    ld_lane += rows_block_forward<U>(Solo4Lds{imgf + 2 * SOLO4_NF * 64, lane}, sel, h1, xs[1], xs[0], kp[2]);
+                    vsum += log_prob(xs, ld_lane);
+                }
+                if (lane == 0) st_sc1(part_base + (3 + (epoch & 1)) * TRAIN_MAX_ROWS + row, vsum);
+            }, [&]() {});
+            if (!go_on) break;
+        }
+        __syncthreads();
+#ifdef NNEST_STAMP
+        // diagnostic build, cycles summed over the minibatches (workgroup 0, row wave 0): wait for the rows and block 0's images,
+        // forward, backward up to the last store, drain in front of the last arrival
+        if (a.losses && wg == 0 && threadIdx.x == 0) for (int i = 0; i < 4; ++i) a.losses[i] = (float)ph[i];
+#endif
+    } else {
+        // =====================================================================================================================
+        // service wave: the next minibatch's rows, this wave's weight-gradient job, the refresh block by block
+        // =====================================================================================================================
+        const int svc = wave - ROWS_PER_WG;                      // 0..3
+        const int sidx = (int)threadIdx.x - 64 * ROWS_PER_WG;   // 0..255
+        const int sl_r = (int)a.gld_in & 255;   // hold-back of the first data poll behind a block's arrivals, units of 64 cycles (launch_train_pipe_t)
+        const int NJ = B * 2 * NJOBS;
+        float *pub = a.gimgf;         // the published weights: {weight, tag} pairs, 2 x image_floats floats
+        // The owners publish their new weights as tiles of the backward FRAGMENT image (+ the biases in its forward-image bias
+        // area): element i of that image is parameter src(i), whose places in the two solo images rows_maps_kernel has packed into
+        // one word.  Block b's part of the image is elements [2 b net_floats, 2 (b + 1) net_floats): QB quads of four; service
+        // thread sidx re-lays quads sidx + 256 u of every block.
+        constexpr int NETF = 2 * U * 256 + 256 + 16 + 16 + 16 * U;   // net_floats of the shape (flow_tile.h frag_net_floats)
+        constexpr int QB = NETF / 2;
+        constexpr int RUB = (QB + 64 * PIPE_SVC - 1) / (64 * PIPE_SVC);
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        static_assert(2 * IMG < 0xffff && IMG < (1 << 14), "refresh map packing");
+        i32x4 mp[B][RUB];
+        {
+            const i32x4 *gmap = reinterpret_cast<const i32x4 *>(a.gown);
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int u = 0; u < RUB; ++u) mp[b][u] = gmap[b * QB + min(sidx + 64 * PIPE_SVC * u, QB - 1)];
+        }
+        // ---- who owns what: service wave (wg, svc) runs job Jmine of every minibatch and keeps that tile's parameters and moments
+        const int Jmine = svc * G + wg;
+        const bool owner = Jmine < NJ;
+        const int jblock = owner ? Jmine / (2 * NJOBS) : 0;
+        int off_f = 0, off_b = 0, off_bias = -1;
+        if (owner) grid_job_image_offsets<U, 1, 1>(a.s, Jmine, &off_f, &off_b, &off_bias);
+        OwnState os;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            os.wt[r] = os.bt[r] = -1;
+            os.tw[r] = os.tm[r] = os.tv[r] = os.bw[r] = os.bm[r] = os.bv[r] = 0.f;
+        }
+        if (owner) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                grid_job_targets<U, 1, 1>(a.s, Jmine, lane, r, &os.wt[r], &os.bt[r]);
+                if (os.wt[r] >= 0) { os.tw[r] = a.w[os.wt[r]]; os.tm[r] = a.m[os.wt[r]]; os.tv[r] = a.v[os.wt[r]]; }
+                if (os.bt[r] >= 0) { os.bw[r] = a.w[os.bt[r]]; os.bm[r] = a.m[os.bt[r]]; os.bv[r] = a.v[os.bt[r]]; }
+            }
+        }
+        // the parameters no job reaches, shared out over the service waves of the grid in whole 256-byte rows of a compact private array
+        const int n_svc = G * PIPE_SVC, ndead = *a.gndead;
+        const int ndead_pad = (ndead + 63) & ~63;
+        const int dead_per = ((ndead + n_svc - 1) / n_svc + 63) & ~63;
+        const int dead0 = min(ndead, Jmine * dead_per), dead1 = min(ndead, dead0 + dead_per);
+        float *dw = a.gdst, *dm = a.gdst + ndead_pad, *dv = a.gdst + 2 * ndead_pad;
+        for (int k = dead0 + lane; k < dead1; k += 64) {
+            const int pidx = a.gdead[k];
+            dw[k] = a.w[pidx]; dm[k] = a.m[pidx]; dv[k] = a.v[pidx];
+        }
+        auto snapshot = [&]() {   // best_model = deepcopy(netG)  (trainer.py:194, :208): every owner snapshots what it owns (one writer per entry)
+            if (owner) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (os.wt[r] >= 0) st_sc1(a.best_w + os.wt[r], os.tw[r]);
+                    if (os.bt[r] >= 0) st_sc1(a.best_w + os.bt[r], os.bw[r]);
+                }
+            }
+            for (int k = dead0 + lane; k < dead1; k += 64) st_sc1(a.best_w + a.gdead[k], dw[k]);
+        };
+        if (!resume) snapshot();
+        // re-lay the blocks of `mask` whose published tiles all carry tag `want`; returns the blocks still missing.  All loads of
+        // the wave are requested at once; a block is taken when every lane of the wave found its granules fresh.
+        auto refresh_try = [&](int mask, int want) {
+            f32x4 va[B][RUB], vc[B][RUB];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                if (!((mask >> b) & 1)) continue;
+#pragma unroll
+                for (int u = 0; u < RUB; ++u) {
+                    const size_t qd = (size_t)b * QB + min(sidx + 64 * PIPE_SVC * u, QB - 1);
+                    va[b][u] = ld_sc1_x4_issue(pub + 8 * qd);
+                    vc[b][u] = ld_sc1_x4_issue(pub + 8 * qd + 4);
+                }
+            }
+#pragma unroll
+            for (int b = B - 1; b >= 0; --b) {
+                if (!((mask >> b) & 1)) continue;
+#pragma unroll
+                for (int u = 0; u < RUB; ++u) asm volatile("s_waitcnt vmcnt(0)" : "+v"(va[b][u]), "+v"(vc[b][u]) : : "memory");
+                bool fresh = true;
+#pragma unroll
+                for (int u = 0; u < RUB; ++u)
+                    fresh = fresh && __float_as_int(va[b][u].y) == want && __float_as_int(va[b][u].w) == want && __float_as_int(vc[b][u].y) == want &&
+                            __float_as_int(vc[b][u].w) == want;
+                if (!__all(fresh)) continue;
+#pragma unroll
+                for (int u = 0; u < RUB; ++u) {
+                    if (sidx + 64 * PIPE_SVC * u < QB) {
+                        const float e4[4] = {va[b][u].x, va[b][u].z, vc[b][u].x, vc[b][u].z};
+                        const int m4[4] = {mp[b][u].x, mp[b][u].y, mp[b][u].z, mp[b][u].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int f = m4[e] & 0xffff, k = (m4[e] >> 16) & 0xffff;
+                            if (f != 0xffff) smem[f & 0x3fff] = (f >> 14) ? SOLO_TANH_PRESCALE * e4[e] : e4[e];
+                            if (k != 0xffff) smem[k] = e4[e];
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&sflag[SF_REF + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                mask &= ~(1 << b);
+            }
+            return mask;
+        };
+        auto refresh = [&](int mask, int want) {
+            for (int polls = 0; mask; ++polls) {
+                if (polls > GRID_MAX_POLLS / 64 || pipe_lds_ld(abort_w)) { fail(); break; }
+                mask = refresh_try(mask, want);
+            }
+        };
+        int adam_t = a.adam_step ? *a.adam_step : 0;
+        for (int epoch = 0; epoch < a.max_epochs; ++epoch) {
+            float epoch_loss = 0.f;
+            for (int mb = 0; mb < n_mb && alive; ++mb, ++mbcount) {
+                const int M = min(a.batch, a.n_train - mb * a.batch);
+                const int rows_pad = ((M + 15) >> 4) * 16;
+                const float *part = part_base + (mbcount % 3) * TRAIN_MAX_ROWS;
+                AdamStep ad;
+                {
+                    adam_t += 1;
+                    const double bc1 = 1.0 - pow(0.9, (double)adam_t), bc2 = 1.0 - pow(0.999, (double)adam_t);
+                    ad.step_size = (float)((double)a.lr / bc1);
+                    ad.inv_bc2s = (float)(1.0 / sqrt(bc2));
+                }
+                TSTAMP(q0);
+                if (svc < NPW) {   // the NEXT minibatch's rows, beside this one's pass (xpre[(m + 1) & 1] was last read in minibatch m - 1's forward pass)
+                    int e2 = epoch, m2 = mb + 1;
+                    if (m2 == n_mb) { m2 = 0; e2 = epoch + 1; }
+                    if (e2 < a.max_epochs) rows_prepare<U>(a, e2, m2, wg, xpre[(mbcount + 1) & 1]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_fetch_add(&sflag[SF_X], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                TSTAMP(q1);
+                const unsigned int arrived = (unsigned int)G * (unsigned int)(mbcount + 1);
+                const int want = mbcount + 1;
+                int pending = (1 << B) - 1;
+                if (owner) {
+                    // ---- W + A: this wave's weight-gradient job; Adam on the tile's parameters in this wave's registers ----
+                    if (!pipe_wait_ctr(arrival + 32 * jblock, arrived, abort_w, a.gerr)) { fail(); break; }
+                    TSTAMP(q2);
+                    const int bn = Jmine / NJOBS;
+                    int q = Jmine % NJOBS;
+                    const float *stg = a.gstage + (size_t)bn * SM::count * TRAIN_MAX_ROWS * 16;
+                    f32x4 bt = {0.f, 0.f, 0.f, 0.f}, t;
+                    constexpr int J_W3 = U, J_W2 = 1;
+                    if (q < J_W3) {
+                        t = contract_rows_grid<true>(stg, rows_pad, SM::gout(q), SM::act(1, 0), lane, bt);
+                    } else if (q - J_W3 < J_W2) {
+                        t = contract_rows_grid<true>(stg, rows_pad, SM::gpre(1, 0), SM::act(0, 0), lane, bt);
+                    } else {
+                        q -= J_W3 + J_W2;
+                        t = q == 0 ? contract_rows_grid<true>(stg, rows_pad, SM::gpre(0, 0), SM::m(q), lane, bt)
+                                   : contract_rows_grid<false>(stg, rows_pad, SM::gpre(0, 0), SM::m(q), lane, bt);
+                    }
+                    const float gt[4] = {t.x, t.y, t.z, t.w}, gb[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (os.wt[r] >= 0) adam_reg(a, ad, os.tw[r], gt[r], os.tm[r], os.tv[r]);
+                        if (os.bt[r] >= 0) adam_reg(a, ad, os.bw[r], gb[r], os.bm[r], os.bv[r]);
+                    }
+                    // the NEW weights, every one with the minibatch's TAG beside it ({w, tag} granules of 8 bytes inside 16-byte
+                    // stores: element i of the backward fragment image at pub[2 i], its tag at pub[2 i + 1])
+                    const float tg = __int_as_float(want);
+                    st_sc1_f32x4(pub + 2 * (off_b + lane * 4), (f32x4){os.tw[0], tg, os.tw[1], tg});
+                    st_sc1_f32x4(pub + 2 * (off_b + lane * 4) + 4, (f32x4){os.tw[2], tg, os.tw[3], tg});
+                    if (off_bias >= 0 && (lane & 15) == 0) {
+                        st_sc1_f32x4(pub + 2 * (off_bias + (lane >> 4) * 4), (f32x4){os.bw[0], tg, os.bw[1], tg});
+                        st_sc1_f32x4(pub + 2 * (off_bias + (lane >> 4) * 4) + 4, (f32x4){os.bw[2], tg, os.bw[3], tg});
+                    }
+                    TSTAMP(q3);
+                    // the blocks published by now or about to be (this wave's own and the ones above it): all their granules at once
+                    const int first = ((1 << B) - 1) & ~((1 << jblock) - 1);
+                    refresh(first, want);
+                    if (!alive) break;
+                    pending &= ~first;
+                } else {
+                    TSTAMP(q2); TSTAMP(q3);
+                }
+                for (int k = dead0 + lane; k < dead1; k += 64) {   // the parameters no job reaches: zero gradient, weight decay only
+                    float w_ = dw[k], m_ = dm[k], v_ = dv[k];
+                    adam_reg(a, ad, w_, 0.f, m_, v_);
+                    dw[k] = w_; dm[k] = m_; dv[k] = v_;
+                }
+                // ---- R: the remaining blocks in the order the backward pass frees them; a block's tiles can only carry this
+                // minibatch's tag behind its arrivals, so the cheap counter is polled first and the granules behind it
+#pragma unroll 1
+                for (int b = B - 1; b >= 0 && alive; --b) {
+                    if (!((pending >> b) & 1)) continue;
+                    if (!pipe_wait_ctr(arrival + 32 * b, arrived, abort_w, a.gerr)) { fail(); break; }
+                    for (int i = 0; i < sl_r; ++i) __builtin_amdgcn_s_sleep(1);   // (the owners' tiles are an operand round trip + a step away)
+                    refresh(1 << b, want);
+                }
+                if (!alive) break;
+                TSTAMP(q4);
+                if (svc == 0) { TACC(ph[0], q1, q0); TACC(ph[1], q2, q1); TACC(ph[2], q3, q2); TACC(ph[3], q4, q3); }
+                // loss = -mean(log_probs)  (trainer.py:394) over the rows' words: complete behind block 0's arrivals; only the
+                // wave that reports the epoch losses needs it (the words are triple-buffered: nothing waits for this sum)
+                if (wg == 0 && svc == PIPE_SVC - 1) epoch_loss += -sum_rows(part) / (float)M;
+            }
+            const bool go_on = epoch_end(epoch, [&]() {
+                if (wg == 0 && svc == PIPE_SVC - 1 && lane == 0) ctlf[1] = epoch_loss / (float)a.n_train;   // trainer.py:403
+            }, snapshot);
+            if (!go_on) break;
+        }
+        // every owner writes what it owns back -- write-through stores, one writer per entry (launch_repack rebuilds the inference
+        // kernels' forward image from a.w behind this launch)
+        __syncthreads();
+        const bool restore = ctl[0] != 0 || (a.flags & NNEST_TRAIN_FINALIZE);   // netG.load_state_dict(best_model)  (trainer.py:241)
+        if (owner) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (os.wt[r] >= 0) {
+                    st_sc1(a.w + os.wt[r], restore ? ld_sc1(a.best_w + os.wt[r]) : os.tw[r]);
+                    st_sc1(a.m + os.wt[r], os.tm[r]); st_sc1(a.v + os.wt[r], os.tv[r]);
+                }
+                if (os.bt[r] >= 0) {
+                    st_sc1(a.w + os.bt[r], restore ? ld_sc1(a.best_w + os.bt[r]) : os.bw[r]);
+                    st_sc1(a.m + os.bt[r], os.bm[r]); st_sc1(a.v + os.bt[r], os.bv[r]);
+                }
+            }
+        }
+        for (int k = dead0 + lane; k < dead1; k += 64) {
+            const int pidx = a.gdead[k];
+            st_sc1(a.w + pidx, restore ? ld_sc1(a.best_w + pidx) : dw[k]);
+            st_sc1(a.m + pidx, dm[k]); st_sc1(a.v + pidx, dv[k]);
+        }
+#ifdef NNEST_STAMP
+        // service wave 0 of workgroup 0: row preparation, wait for its block's arrivals, job + Adam + publish, refresh
+        if (a.losses && wg == 0 && svc == 0 && lane == 0) for (int i = 0; i < 4; ++i) a.losses[4 + i] = (float)ph[i];
+#endif
+        if (wg == 0 && sidx == 0 && a.adam_step) *a.adam_step = adam_t;   // (a service wave: it has counted the Adam steps)
+    }
+    if (wg == 0 && threadIdx.x == 0) {
+        a.result->epochs_run = a.epoch_offset + epochs_run;
+        a.result->best_epoch = ctl[2];
+        a.result->best_validation_loss = ctlf[0];
+        a.result->last_train_loss = last_train_loss;
+        a.result->counter = ctl[1];
+        a.result->stopped = *a.gerr ? 2 : (ctl[0] != 0 ? 1 : 0);   // 2: a wait ran out (include/nnest_hip.h)
+    }
+}
+
+// NNEST_TRAIN_FORM=rows in the environment keeps train_kernel_rows, =grid train_kernel_grid (diagnostics)
+static bool pipe_eligible(const TrainArgs &a) {
+    static const bool off = [] { const char *e = getenv("NNEST_TRAIN_FORM"); return e && (!strcmp(e, "rows") || !strcmp(e, "grid")); }();
+    return !off && rows_eligible(a);
+}
+
+template <int U>
+static hipError_t launch_train_pipe_t(TrainArgs a, float *gridws, hipStream_t st) {
+    typedef GridSizes<U, 1, 1> GS;
+    // (the workspace layout of launch_train_grid_t)
+    a.gstage = gridws;
+    a.gtile = a.gstage + GS::stage(a.s);
+    a.gpos = reinterpret_cast<int *>(a.gtile + GS::tiles(a.s));
+    a.gpart = reinterpret_cast<float *>(a.gpos + a.s.num_params());
+    a.gsync = reinterpret_cast<unsigned int *>(a.gpart + 64);
+    a.gerr = reinterpret_cast<int *>(a.gsync + 8);
+    a.gndead = reinterpret_cast<int *>(a.gsync + 12);
+    a.gdead = reinterpret_cast<int *>(a.gpart + 64 + 16);
+    a.gown = reinterpret_cast<float *>(a.gdead + a.s.num_params());
+    a.gown += (64 - ((size_t)(a.gown - gridws) & 63)) & 63;
+    a.gdst = a.gown + (size_t)GRID_WG * TRAIN_WAVES * 64 * 32;
+    a.gimgf = a.gdst + (size_t)3 * ((a.s.num_params() + 63) & ~63) + 64;
+    a.gimgf += (64 - ((size_t)(a.gimgf - gridws) & 63)) & 63;
+    a.gimgb = a.gimgf + ((a.s.image_floats + 63) & ~63);
+    static_assert(GS::NJOBS * 2 * ROWS_B * 2 * 256 >= 2048, "the rows' words and the arrival counters live in the tile area");
+    hipError_t e = hipMemsetAsync(a.gstage, 0, GS::stage(a.s) * sizeof(float), st);   // rows beyond the batch are never written: they must read 0
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.gtile, 0, 2048 * sizeof(float), st);   // the rows' words, the arrival counters
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.gpos, 0xFF, (size_t)a.s.num_params() * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.gimgf, 0, (size_t)2 * ((a.s.image_floats + 63) & ~63) * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.gpart, 0, (64 + 16) * sizeof(float), st);  // the barrier counter, the error word, the dead count
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((grid_gpos_kernel<U, 1, 1>), dim3(32), dim3(256), 0, st, a.gpos, a.s);
+    hipLaunchKernelGGL(grid_dead_kernel, dim3(32), dim3(256), 0, st, a.gpos, a.s.num_params(), a.gdead, a.gndead);
+    hipLaunchKernelGGL((rows_maps_kernel<U>), dim3(32), dim3(256), 0, st, reinterpret_cast<int *>(a.gown), a.s);   // (the owners' record area of train_kernel_grid: unused here)
+    {   // how long a refresh's first data poll is held back behind its block's arrivals (units of 64 cycles; NNEST_K5_SLEEP overrides)
+        int r = 8;
+        if (const char *ev = getenv("NNEST_K5_SLEEP")) sscanf(ev, "%d", &r);
+        a.gld_in = (float)(r & 255);   // (the VJP's scalar: unused by the training loop)
+    }
+    const int NJ = ROWS_B * 2 * (2 * U + 1);
+    const int G = max((a.batch + ROWS_PER_WG - 1) / ROWS_PER_WG, (NJ + PIPE_SVC - 1) / PIPE_SVC);
+    const size_t lds = (size_t)2 * ROWS_B * SOLO4_NF * 64 * sizeof(float);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(train_kernel_pipe<U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((train_kernel_pipe<U>), dim3(G), dim3(TRAIN_THREADS), lds, st, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_repack(a.w, a.img_fwd, a.s, st);
+}
+
+static hipError_t dispatch_train_pipe(const TrainArgs &a, float *gridws, hipStream_t st) {
+    switch (a.s.NT) {
+        case 1: return launch_train_pipe_t<1>(a, gridws, st);
+        case 2: return launch_train_pipe_t<2>(a, gridws, st);
+        case 3: return launch_train_pipe_t<3>(a, gridws, st);
+        case 4: return launch_train_pipe_t<4>(a, gridws, st);
+    }
+    return hipErrorInvalidConfiguration;
+}

@@ -195,7 +195,8 @@ static __device__ __forceinline__ void rows_stage_slots(float *stg_net, int ct0,
 // ---- reverse mode through one coupling block (block_backward_grid's arithmetic on one row) ----
 // in: ytrans = the block's OUTPUT on the transformed side, gtrans / gcond = d loss / d (block outputs);
 // out: ytrans = the block's input, gtrans = d loss / d (that input), gcond += the two nets' contributions
-template <int U>
+// STAGE_FWD = false: the activations and the conditioning input were staged by the forward pass (rows_stage_forward, nnest_train_pipe.h)
+template <int U, bool STAGE_FWD = true>
 static __device__ __forceinline__ void rows_block_backward(const Solo4Lds &wb_, unsigned sel, bool h1, bool translate_half, int pos, int D, int ct,
                                                            bool row_ok, float gld, const float (&cond)[U], float (&ytrans)[U], float (&gcond)[U],
                                                            float (&gtrans)[U], const RowsKeep<U> &kp, float *stg_net, int row, bool stager) {
@@ -248,14 +249,14 @@ static __device__ __forceinline__ void rows_block_backward(const Solo4Lds &wb_, 
     wb_.load8(w2, 32);   // (requested ahead of the activation gradient, as in the forward pass)
     const float g_a2 = rows_act_grad(solo_join_rot(a0 + a1), kp.h2, sel);   // (h = 1 rows: rotated by 8, like kp.h2)
     rows_stage(stg_net, SM::gpre(1, 0), row, pos, g_a2, stager);
-    rows_stage(stg_net, SM::act(1, 0), row, pos, kp.h2, stager);
+    if constexpr (STAGE_FWD) rows_stage(stg_net, SM::act(1, 0), row, pos, kp.h2, stager);
     // g_h1 = W1^T g_a2
     if constexpr (U >= 2) { wb_.load8(w3a, 40); wb_.load8(w3b, 48); }
     solo_chain_1(a0, a1, 0.f, g_a2, w2);
     const float g_a1 = rows_act_grad(solo_join_rot(a0 + a1), kp.h1, sel);
     rows_stage(stg_net, SM::gpre(0, 0), row, pos, g_a1, stager);
-    rows_stage(stg_net, SM::act(0, 0), row, pos, kp.h1, stager);
-    {
+    if constexpr (STAGE_FWD) rows_stage(stg_net, SM::act(0, 0), row, pos, kp.h1, stager);
+    if constexpr (STAGE_FWD) {
         float cm[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) cm[u] = row_ok ? cond[u] : 0.f;

@@ -35,11 +35,12 @@ if os.environ.get('NNEST_HIP_LIB', '').endswith('STAMP.so'):   # NNEST_STAMP bui
     nvp = flow.HipNVP(D, 16, 3, 1, seed=1)
     res = nvp.train_epochs(live[nv:], live[:nv], perms, None, max_epochs=E, seed=1, jitter=0.01, batch=100, patience=1000)
     ph = res['losses'].cpu().numpy().ravel()[:8] / (E * ((N - nv + 99) // 100))
-    # (train_kernel_rows, the form that runs by default: the tagged publish took the second grid barrier's place, what is left of that
-    # slot is the workgroup barrier in front of the refresh)
-    print('rows kernel, cycles per minibatch: forward %d  backward+staging %d  first grid barrier %d  weight-gradient jobs + Adam + publish %d  '
-          'workgroup barrier %d  loss + image refresh (tag polls) %d  [first barrier: drain + workgroup barrier %d cycles, %.2f missed polls]' % tuple(ph[:8]))
-    raw = res['losses'].cpu().numpy().ravel()
-    arr, st = raw[20:20 + 25], raw[50:50 + 25]
-    print('rows kernel, minibatch 20: start of the minibatch per workgroup (10 ns ticks, relative):', (st - st.min()).astype(int).tolist())
-    print('rows kernel, minibatch 20: arrival at the first grid barrier per workgroup (relative to the earliest start):', (arr - st.min()).astype(int).tolist())
+    if os.environ.get('NNEST_TRAIN_FORM', '') == 'rows':
+        print('rows kernel, cycles per minibatch: forward %d  backward+staging %d  first grid barrier %d  weight-gradient jobs + Adam + publish %d  '
+              'workgroup barrier %d  loss + image refresh (tag polls) %d  [first barrier: drain + workgroup barrier %d cycles, %.2f missed polls]' % tuple(ph[:8]))
+    else:
+        # train_kernel_pipe (the default form): row wave 0 and service wave 0 of workgroup 0 (the owner of a block-0 job)
+        print('pipe kernel, cycles per minibatch, row wave: wait for rows + block 0 images %d  forward (+ staging, waits for blocks 1, 2) %d  '
+              'backward to the last store %d  drain in front of the last arrival %d  | sum %d' % (tuple(ph[:4]) + (ph[:4].sum(),)))
+        print('pipe kernel, cycles per minibatch, service wave 0: row preparation %d  wait for its block\'s arrivals %d  job + Adam + publish %d  '
+              'refresh %d  | sum %d' % (tuple(ph[4:8]) + (ph[4:8].sum(),)))
