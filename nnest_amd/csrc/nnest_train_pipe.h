@@ -27,6 +27,13 @@
 // in a row wave); the wave that polled a counter loads only after its poll matched; published weights are tagged granules (R2).
 // Every wait is bounded; one that runs out sets the error word and the launch ends with result.stopped = 2.
 
+// diagnostic build: absolute time stamps of one minibatch (workgroup 0: all its waves read the same clock), a.losses[16 + k]
+#ifdef NNEST_STAMP
+#define TLINE(k) do { if (mbcount == 20 && wg == 0 && lane == 0) { __builtin_amdgcn_sched_barrier(0); tline[k] = (float)(__builtin_amdgcn_s_memtime() & 0xffffffull); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define TLINE(k) do { } while (0)
+#endif
+
 enum { PIPE_SVC = 4, SF_REF = 0, SF_X = 3, SF_ARR = 4, SF_ABORT = 7, SF_N = 8 };
 
 static __device__ __forceinline__ int pipe_lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -54,6 +61,12 @@ static __device__ __forceinline__ bool pipe_wait_ctr(const unsigned int *ctr, un
     return ok;
 }
 
+// hipcc hoists loop-invariant ADDRESS arithmetic out of the epoch loop and then spills it (a register pair per load of the refresh,
+// per operand base of a job, per owned parameter): each such load then waits for a scratch reload first.  Passing the base through an
+// empty asm inside the loop keeps the arithmetic where it is used.
+template <class T> static __device__ __forceinline__ T *pipe_opaque(T *p) { asm volatile("" : "+s"(p)); return p; }
+static __device__ __forceinline__ int pipe_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
 // what the forward pass stages for the block's weight-gradient jobs: the two hidden activations and the conditioning input
 template <int U>
 static __device__ __forceinline__ void rows_stage_forward(float *stg_net, int row, int pos, bool row_ok, const float (&cond)[U],
@@ -67,18 +80,47 @@ static __device__ __forceinline__ void rows_stage_forward(float *stg_net, int ro
     rows_stage_slots<U>(stg_net, SM::m(0), row, pos, cm, stager);
 }
 
+// the refresh map of train_kernel_pipe: for element i of the published backward fragment image (weights as bwd_image_src lays them
+// out, biases where the forward image keeps them) its two destinations in a workgroup's LDS as FLOAT offsets into smem, packed in
+// one word: bits 0..14 the forward solo image, bits 15..29 the transposed one (IMG + offset), bit 31 = stored times the tanh
+// prescale.  An element without a destination on a side points at one of 64 dummy floats behind the images (2 IMG + lane-distinct
+// index), so that the re-lay is two unconditional ds_write_b32 per element.
+template <int U>
+__global__ void pipe_maps_kernel(unsigned int *__restrict__ maps, FlowShape s) {
+    constexpr int IMG = ROWS_B * SOLO4_NF * 64;
+    static_assert(2 * IMG + 64 <= (1 << 15), "refresh map packing");
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < s.image_floats; i += gridDim.x * blockDim.x) {
+        const unsigned int dummy = 2 * IMG + ((i >> 2) & 63);
+        unsigned int mf = dummy, mb = dummy, sc_bit = 0;
+        const int o = i % s.net_floats;
+        const int p = o >= frag_off_b1(U, 1, 1) ? fwd_image_src(s, i) : bwd_image_src(s, i);
+        if (p >= 0) {
+            const int bn = p / s.net_params;
+            int df, db; bool sc;
+            rows_param_dest<U>(s.D, bn >> 1, bn & 1, p - bn * s.net_params, df, db, sc);
+            if (df >= 0) { mf = df; sc_bit = sc ? 0x80000000u : 0u; }
+            if (db >= 0) mb = IMG + db;
+        }
+        maps[i] = mf | (mb << 15) | sc_bit;
+    }
+}
+
 template <int U>
 __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) {
     typedef StageMap<U, 1, 1> SM;
     constexpr int B = ROWS_B, IMG = ROWS_B * SOLO4_NF * 64;
     constexpr int NBS = 2 + (U == 4 ? 1 : U);   // vector-memory stores of one block's backward pass (gout, g_pre of the two hidden layers)
     constexpr int NPW = (ROWS_PER_WG * 8 * U + 63) / 64;   // service waves that prepare rows
+    constexpr int IMGF_ = ROWS_B * 2 * (2 * U * 256 + 256 + 16 + 16 + 16 * U);   // image_floats of the shape
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *imgf = smem;          // forward solo image  [B][SOLO4_NF / 4][64][4]
     float *imgb = smem + IMG;    // transposed solo image
     __shared__ __attribute__((aligned(16))) float xpre[2][ROWS_PER_WG * 32 * U];   // the minibatch's rows, flat, a minibatch ahead
     __shared__ int ctl[4];      // [0] stop flag, [1] counter, [2] best epoch
     __shared__ float ctlf[2];   // [0] best validation loss, [1] the epoch's training loss (workgroup 0)
+#ifdef NNEST_STAMP
+    __shared__ float tline[24];
+#endif
     __shared__ int sflag[SF_N]; // [SF_REF + b] service waves that have refreshed block b (monotonic), [SF_X] row preparations done,
                                 // [SF_ARR + b] row waves arrived behind block b's backward stores, [SF_ABORT]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -87,6 +129,18 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
     constexpr int NJOBS = 2 * U + 1;
     const bool row_wave = wave < ROWS_PER_WG;
     int phase = 0;
+    // Who re-lays the published tiles into the LDS images: the four ROW waves (behind their last arrival they have nothing to do
+    // until the images are refreshed), the service waves without a job, and the owners of block 2's jobs (the first block the
+    // backward pass frees: its owners are done before the other blocks' tiles exist).  The owners of block 1's and block 0's jobs
+    // do nothing else -- block 0's job is the critical path of a minibatch.  Jobs are numbered block 0 first and dealt
+    // service-wave-major (job J on service wave J / G of workgroup J % G), so at least two service waves of a workgroup re-lay.
+    const int NJ = B * 2 * NJOBS;
+    auto relays = [&](int sv) { const int J = sv * G + wg; return J >= NJ || J / (2 * NJOBS) == B - 1; };
+    int NREL = ROWS_PER_WG, ridx0 = row_wave ? wave : ROWS_PER_WG;   // re-laying waves of this workgroup; this wave's rank among them
+    for (int sv = 0; sv < PIPE_SVC; ++sv) {
+        if (relays(sv)) { if (!row_wave && sv < wave - ROWS_PER_WG) ridx0 += 1; NREL += 1; }
+    }
+    const bool relayer = row_wave || relays(wave - ROWS_PER_WG);
 
     // ---- the two solo images from the packed weights ----
     for (int i = threadIdx.x; i < 2 * IMG; i += blockDim.x) smem[i] = 0.f;
@@ -170,6 +224,96 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
         return ctl[0] == 0;
     };
 
+    // ---- the re-lay.  The owners publish their new weights as tiles of the backward FRAGMENT image (+ the biases in its forward-image
+    // bias area): element i of that image is parameter src(i), whose places in the two solo images pipe_maps_kernel has packed into
+    // one word.  Block b's part of the image is elements [2 b net_floats, 2 (b + 1) net_floats): QB quads of four; the workgroup's
+    // NREL re-laying waves share them out, thread ridx taking quads ridx + 64 NREL u, whose map words it keeps in registers.
+    constexpr int NETF = 2 * U * 256 + 256 + 16 + 16 + 16 * U;   // net_floats of the shape (flow_tile.h frag_net_floats)
+    constexpr int QB = NETF / 2;
+    constexpr int RU = (QB + 64 * (ROWS_PER_WG + 2) - 1) / (64 * (ROWS_PER_WG + 2));   // rounds of a thread per block with six re-laying waves
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int NRT = 64 * NREL, ridx = 64 * ridx0 + lane;
+    const int sl_r = (int)a.gld_in & 255;   // hold-back of block 0's data poll behind its hint, units of 64 cycles (launch_train_pipe_t)
+    float *pub = a.gimgf;                    // the published weights: {weight, tag} pairs, 2 x image_floats floats
+    unsigned int *hint = arrival + 32 * B;   // [b] at + 32 b: tiles of block b whose publish stores have been ISSUED (a hint, not an order: the tags decide)
+    const __amdgpu_buffer_rsrc_t pubr = __builtin_amdgcn_make_buffer_rsrc(pub, 0, 2 * IMGF_ * (int)sizeof(float), 0x00020000);
+    u32x4 mapw[B][RU];
+    if (relayer) {
+        const u32x4 *gmap = reinterpret_cast<const u32x4 *>(a.gown);
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int u = 0; u < RU; ++u) mapw[b][u] = gmap[b * QB + min(ridx + NRT * u, QB - 1)];
+    }
+    // a block's granules are requested (issue), later checked and written into the two images (finish); the three blocks' requests
+    // overlap.  (Buffer loads with the sc1 bit: loads the compiler SEES -- it counts them in its own s_waitcnt and never copies a
+    // destination register before the data has landed, which an asm load that is waited for elsewhere does not rule out; the offset
+    // goes through an empty asm, so no two requests are the same load to the compiler and none leaves its loop.)
+    auto issue = [&](int b, f32x4 (&va_)[RU], f32x4 (&vc_)[RU]) {
+        const int rx = pipe_opaque(ridx);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {   // (rounds beyond the thread's last ask for the block's last quad again: every register is defined)
+            const int qd = b * QB + min(rx + NRT * u, QB - 1);
+            va_[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pubr, 32 * qd, 0, 16 /* sc1 */));
+            vc_[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pubr, 32 * qd + 16, 0, 16));
+        }
+    };
+    // true: every lane of the wave found its granules of the block fresh (tag `want`), and they are in the images now
+    auto finish = [&](int b, int want, const f32x4 (&va_)[RU], const f32x4 (&vc_)[RU]) {
+        bool fresh = true;
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+            fresh = fresh && __float_as_int(va_[u].y) == want && __float_as_int(va_[u].w) == want && __float_as_int(vc_[u].y) == want &&
+                    __float_as_int(vc_[u].w) == want;
+        if (!__all(fresh)) return false;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            if (ridx + NRT * u < QB) {
+                const float e4[4] = {va_[u].x, va_[u].z, vc_[u].x, vc_[u].z};
+                const unsigned int m4[4] = {mapw[b][u].x, mapw[b][u].y, mapw[b][u].z, mapw[b][u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int mw = (unsigned int)pipe_opaque((int)m4[e]);   // (unpacked here, not hoisted into 2 registers + a mask per element)
+                    const float es = (int)mw < 0 ? SOLO_TANH_PRESCALE * e4[e] : e4[e];
+                    smem[mw & 0x7fff] = es;
+                    smem[(mw >> 15) & 0x7fff] = e4[e];
+                }
+            }
+        }
+        return true;
+    };
+    auto complete = [&](int b, int want, f32x4 (&va_)[RU], f32x4 (&vc_)[RU]) {
+        for (int polls = 0; !finish(b, want, va_, vc_); ++polls) {
+            if (polls > GRID_MAX_POLLS / 64 || pipe_lds_ld(abort_w)) { fail(); return; }
+            __builtin_amdgcn_s_sleep(2);
+            issue(b, va_, vc_);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&sflag[SF_REF + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // The blocks in the order the backward pass frees them.  The cheap counter says when a block's tiles are on their way (every
+    // owner adds to it right behind its publish stores, unordered: a hint); the tags say when they are there.  Block 1's request goes
+    // out before block 2 is written, block 0's before block 1 is: the round trips overlap the writing.
+    auto relay_all = [&](int want) {
+        const unsigned int published = (unsigned int)(2 * NJOBS) * (unsigned int)want;
+        f32x4 va[B][RU], vc[B][RU];
+        if (!pipe_wait_ctr(hint + 32 * 2, published, abort_w, a.gerr)) { fail(); return; }
+        if (wave == 7) TLINE(12);
+        issue(2, va[2], vc[2]);
+        if (!pipe_wait_ctr(hint + 32 * 1, published, abort_w, a.gerr)) { fail(); return; }
+        if (wave == 7) TLINE(13);
+        issue(1, va[1], vc[1]);
+        complete(2, want, va[2], vc[2]);
+        if (wave == 7) TLINE(15);
+        if (!alive || !pipe_wait_ctr(hint + 32 * 0, published, abort_w, a.gerr)) { fail(); return; }
+        if (wave == 7) TLINE(14);
+        for (int i = 0; i < sl_r; ++i) __builtin_amdgcn_s_sleep(1);
+        issue(0, va[0], vc[0]);
+        complete(1, want, va[1], vc[1]);
+        if (wave == 7) TLINE(16);
+        if (alive) complete(0, want, va[0], vc[0]);
+    };
+
     if (row_wave) {
         // =====================================================================================================================
         // a row of every minibatch: forward, backward, arrivals
@@ -212,20 +356,22 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                     for (int u = 0; u < U; ++u) { xs[0][u] = xr[2 * u]; xs[1][u] = xr[2 * u + 1]; }
                     RowsKeep<U> kp[B];
                     // NormalizingFlow.forward (networks.py:24-32); a block's images must be the ones the last minibatch's weights were re-laid into
-                    bool okw = pipe_wait_lds(&sflag[SF_REF + 0], PIPE_SVC * mbcount, abort_w);
+                    bool okw = pipe_wait_lds(&sflag[SF_REF + 0], NREL * mbcount, abort_w);
                     TSTAMP(q1);
+                    if (wave == 0) TLINE(0);
                     float ld_lane = rows_block_forward<U>(Solo4Lds{imgf, lane}, sel, h1, xs[1], xs[0], kp[0]);
                     rows_stage_forward<U>(stg_net0, row, pos, row_ok, xs[1], kp[0], stager);
-                    okw = okw && pipe_wait_lds(&sflag[SF_REF + 1], PIPE_SVC * mbcount, abort_w);
+                    okw = okw && pipe_wait_lds(&sflag[SF_REF + 1], NREL * mbcount, abort_w);
                     ld_lane += rows_block_forward<U>(Solo4Lds{imgf + SOLO4_NF * 64, lane}, sel, h1, xs[0], xs[1], kp[1]);
                     rows_stage_forward<U>(stg_net0 + RS, row, pos, row_ok, xs[0], kp[1], stager);
-                    okw = okw && pipe_wait_lds(&sflag[SF_REF + 2], PIPE_SVC * mbcount, abort_w);
+                    okw = okw && pipe_wait_lds(&sflag[SF_REF + 2], NREL * mbcount, abort_w);
                     ld_lane += rows_block_forward<U>(Solo4Lds{imgf + 2 * SOLO4_NF * 64, lane}, sel, h1, xs[1], xs[0], kp[2]);
                     rows_stage_forward<U>(stg_net0 + 2 * RS, row, pos, row_ok, xs[1], kp[2], stager);
                     if (!okw) { fail(); break; }
                     const float lp = row_ok ? log_prob(xs, ld_lane) : 0.f;
                     if (lane == 0) st_sc1(part + row, lp);
                     TSTAMP(q2);
+                    if (wave == 0) TLINE(1);
                     // d(loss)/du = dE/du / M ; d(loss)/d(logdet) = -1/M
                     const float invM = 1.0f / (float)M, gld = -invM;
 #pragma unroll
@@ -237,26 +383,39 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                     // block 2's stores (and everything before them) are complete once at most block 1's NBS are outstanding
                     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NBS) : "memory");
                     arrive(2);
+                    if (wave == 0) TLINE(2);
                     rows_block_backward<U, false>(Solo4Lds{imgb, lane}, sel, h1, translate_half, pos, D, 0, row_ok, gld, xs[1], xs[0], gs[1], gs[0], kp[0], stg_net0, row, stager);
                     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NBS) : "memory");
                     arrive(1);
                     TSTAMP(q3);
+                    if (wave == 0) TLINE(3);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     arrive(0);
                     TSTAMP(q4);
+                    if (wave == 0) TLINE(4);
                     if (wave == 0) { TACC(ph[0], q1, q0); TACC(ph[1], q2, q1); TACC(ph[2], q3, q2); TACC(ph[3], q4, q3); }
                 } else {
+                    // a wave without a row arrives for its workgroup all the same -- but only behind the last minibatch's refresh, like a
+                    // wave with one: an arrival counted early would complete the LAST minibatch's count for an owner still waiting on it
+                    bool okw = true;
+#pragma unroll
+                    for (int b = 0; b < B; ++b) okw = okw && pipe_wait_lds(&sflag[SF_REF + b], NREL * mbcount, abort_w);
+                    if (!okw) { fail(); break; }
                     if (lane == 0) st_sc1(part + row, 0.f);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     arrive(2); arrive(1); arrive(0);
                 }
+                // ---- R: nothing to do until the images are refreshed -- so the row waves do their share of it
+                relay_all(mbcount + 1);
+                if (wave == 0) { TLINE(20); }
+                if (!alive) break;
             }
             // ---- Trainer._validate (trainer.py:405-418): validation row r on wave r % 4 of workgroup (r / 4) % G ----
             const bool go_on = epoch_end(epoch, [&]() {
                 float vsum = 0.f;
                 bool okw = true;
 #pragma unroll
-                for (int b = 0; b < B; ++b) okw = okw && pipe_wait_lds(&sflag[SF_REF + b], PIPE_SVC * mbcount, abort_w);
+                for (int b = 0; b < B; ++b) okw = okw && pipe_wait_lds(&sflag[SF_REF + b], NREL * mbcount, abort_w);
                 if (!okw) { fail(); return; }
                 for (int r = row; r < a.n_valid; r += ROWS_PER_WG * G) {
                     float xs[2][U];
@@ -288,27 +447,6 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
         // service wave: the next minibatch's rows, this wave's weight-gradient job, the refresh block by block
         // =====================================================================================================================
         const int svc = wave - ROWS_PER_WG;                      // 0..3
-        const int sidx = (int)threadIdx.x - 64 * ROWS_PER_WG;   // 0..255
-        const int sl_r = (int)a.gld_in & 255;   // hold-back of the first data poll behind a block's arrivals, units of 64 cycles (launch_train_pipe_t)
-        const int NJ = B * 2 * NJOBS;
-        float *pub = a.gimgf;         // the published weights: {weight, tag} pairs, 2 x image_floats floats
-        // The owners publish their new weights as tiles of the backward FRAGMENT image (+ the biases in its forward-image bias
-        // area): element i of that image is parameter src(i), whose places in the two solo images rows_maps_kernel has packed into
-        // one word.  Block b's part of the image is elements [2 b net_floats, 2 (b + 1) net_floats): QB quads of four; service
-        // thread sidx re-lays quads sidx + 256 u of every block.
-        constexpr int NETF = 2 * U * 256 + 256 + 16 + 16 + 16 * U;   // net_floats of the shape (flow_tile.h frag_net_floats)
-        constexpr int QB = NETF / 2;
-        constexpr int RUB = (QB + 64 * PIPE_SVC - 1) / (64 * PIPE_SVC);
-        typedef int i32x4 __attribute__((ext_vector_type(4)));
-        static_assert(2 * IMG < 0xffff && IMG < (1 << 14), "refresh map packing");
-        i32x4 mp[B][RUB];
-        {
-            const i32x4 *gmap = reinterpret_cast<const i32x4 *>(a.gown);
-#pragma unroll
-            for (int b = 0; b < B; ++b)
-#pragma unroll
-                for (int u = 0; u < RUB; ++u) mp[b][u] = gmap[b * QB + min(sidx + 64 * PIPE_SVC * u, QB - 1)];
-        }
         // ---- who owns what: service wave (wg, svc) runs job Jmine of every minibatch and keeps that tile's parameters and moments
         const int Jmine = svc * G + wg;
         const bool owner = Jmine < NJ;
@@ -343,63 +481,14 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
             if (owner) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (os.wt[r] >= 0) st_sc1(a.best_w + os.wt[r], os.tw[r]);
-                    if (os.bt[r] >= 0) st_sc1(a.best_w + os.bt[r], os.bw[r]);
+                    const int wt = pipe_opaque(os.wt[r]), bt = pipe_opaque(os.bt[r]);
+                    if (wt >= 0) st_sc1(a.best_w + wt, os.tw[r]);
+                    if (bt >= 0) st_sc1(a.best_w + bt, os.bw[r]);
                 }
             }
             for (int k = dead0 + lane; k < dead1; k += 64) st_sc1(a.best_w + a.gdead[k], dw[k]);
         };
         if (!resume) snapshot();
-        // re-lay the blocks of `mask` whose published tiles all carry tag `want`; returns the blocks still missing.  All loads of
-        // the wave are requested at once; a block is taken when every lane of the wave found its granules fresh.
-        auto refresh_try = [&](int mask, int want) {
-            f32x4 va[B][RUB], vc[B][RUB];
-#pragma unroll
-            for (int b = 0; b < B; ++b) {
-                if (!((mask >> b) & 1)) continue;
-#pragma unroll
-                for (int u = 0; u < RUB; ++u) {
-                    const size_t qd = (size_t)b * QB + min(sidx + 64 * PIPE_SVC * u, QB - 1);
-                    va[b][u] = ld_sc1_x4_issue(pub + 8 * qd);
-                    vc[b][u] = ld_sc1_x4_issue(pub + 8 * qd + 4);
-                }
-            }
-#pragma unroll
-            for (int b = B - 1; b >= 0; --b) {
-                if (!((mask >> b) & 1)) continue;
-#pragma unroll
-                for (int u = 0; u < RUB; ++u) asm volatile("s_waitcnt vmcnt(0)" : "+v"(va[b][u]), "+v"(vc[b][u]) : : "memory");
-                bool fresh = true;
-#pragma unroll
-                for (int u = 0; u < RUB; ++u)
-                    fresh = fresh && __float_as_int(va[b][u].y) == want && __float_as_int(va[b][u].w) == want && __float_as_int(vc[b][u].y) == want &&
-                            __float_as_int(vc[b][u].w) == want;
-                if (!__all(fresh)) continue;
-#pragma unroll
-                for (int u = 0; u < RUB; ++u) {
-                    if (sidx + 64 * PIPE_SVC * u < QB) {
-                        const float e4[4] = {va[b][u].x, va[b][u].z, vc[b][u].x, vc[b][u].z};
-                        const int m4[4] = {mp[b][u].x, mp[b][u].y, mp[b][u].z, mp[b][u].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int f = m4[e] & 0xffff, k = (m4[e] >> 16) & 0xffff;
-                            if (f != 0xffff) smem[f & 0x3fff] = (f >> 14) ? SOLO_TANH_PRESCALE * e4[e] : e4[e];
-                            if (k != 0xffff) smem[k] = e4[e];
-                        }
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(&sflag[SF_REF + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                mask &= ~(1 << b);
-            }
-            return mask;
-        };
-        auto refresh = [&](int mask, int want) {
-            for (int polls = 0; mask; ++polls) {
-                if (polls > GRID_MAX_POLLS / 64 || pipe_lds_ld(abort_w)) { fail(); break; }
-                mask = refresh_try(mask, want);
-            }
-        };
         int adam_t = a.adam_step ? *a.adam_step : 0;
         for (int epoch = 0; epoch < a.max_epochs; ++epoch) {
             float epoch_loss = 0.f;
@@ -415,6 +504,8 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                     ad.inv_bc2s = (float)(1.0 / sqrt(bc2));
                 }
                 TSTAMP(q0);
+                if (svc == 1) TLINE(18);
+                if (svc == PIPE_SVC - 1) TLINE(19);
                 if (svc < NPW) {   // the NEXT minibatch's rows, beside this one's pass (xpre[(m + 1) & 1] was last read in minibatch m - 1's forward pass)
                     int e2 = epoch, m2 = mb + 1;
                     if (m2 == n_mb) { m2 = 0; e2 = epoch + 1; }
@@ -425,26 +516,30 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                 TSTAMP(q1);
                 const unsigned int arrived = (unsigned int)G * (unsigned int)(mbcount + 1);
                 const int want = mbcount + 1;
-                int pending = (1 << B) - 1;
                 if (owner) {
                     // ---- W + A: this wave's weight-gradient job; Adam on the tile's parameters in this wave's registers ----
                     if (!pipe_wait_ctr(arrival + 32 * jblock, arrived, abort_w, a.gerr)) { fail(); break; }
                     TSTAMP(q2);
+                    if (svc == 0) TLINE(8);
+                    if (svc == 1) TLINE(5);
                     const int bn = Jmine / NJOBS;
                     int q = Jmine % NJOBS;
-                    const float *stg = a.gstage + (size_t)bn * SM::count * TRAIN_MAX_ROWS * 16;
+                    const float *stg = pipe_opaque(a.gstage) + (size_t)bn * SM::count * TRAIN_MAX_ROWS * 16;
+                    const int lane_o = pipe_opaque(lane);
                     f32x4 bt = {0.f, 0.f, 0.f, 0.f}, t;
                     constexpr int J_W3 = U, J_W2 = 1;
                     if (q < J_W3) {
-                        t = contract_rows_grid<true>(stg, rows_pad, SM::gout(q), SM::act(1, 0), lane, bt);
+                        t = contract_rows_grid<true>(stg, rows_pad, SM::gout(q), SM::act(1, 0), lane_o, bt);
                     } else if (q - J_W3 < J_W2) {
-                        t = contract_rows_grid<true>(stg, rows_pad, SM::gpre(1, 0), SM::act(0, 0), lane, bt);
+                        t = contract_rows_grid<true>(stg, rows_pad, SM::gpre(1, 0), SM::act(0, 0), lane_o, bt);
                     } else {
                         q -= J_W3 + J_W2;
-                        t = q == 0 ? contract_rows_grid<true>(stg, rows_pad, SM::gpre(0, 0), SM::m(q), lane, bt)
-                                   : contract_rows_grid<false>(stg, rows_pad, SM::gpre(0, 0), SM::m(q), lane, bt);
+                        t = q == 0 ? contract_rows_grid<true>(stg, rows_pad, SM::gpre(0, 0), SM::m(q), lane_o, bt)
+                                   : contract_rows_grid<false>(stg, rows_pad, SM::gpre(0, 0), SM::m(q), lane_o, bt);
                     }
                     const float gt[4] = {t.x, t.y, t.z, t.w}, gb[4] = {bt.x, bt.y, bt.z, bt.w};
+                    if (svc == 0) TLINE(9);
+                    if (svc == 1) TLINE(6);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (os.wt[r] >= 0) adam_reg(a, ad, os.tw[r], gt[r], os.tm[r], os.tv[r]);
@@ -453,18 +548,17 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                     // the NEW weights, every one with the minibatch's TAG beside it ({w, tag} granules of 8 bytes inside 16-byte
                     // stores: element i of the backward fragment image at pub[2 i], its tag at pub[2 i + 1])
                     const float tg = __int_as_float(want);
-                    st_sc1_f32x4(pub + 2 * (off_b + lane * 4), (f32x4){os.tw[0], tg, os.tw[1], tg});
-                    st_sc1_f32x4(pub + 2 * (off_b + lane * 4) + 4, (f32x4){os.tw[2], tg, os.tw[3], tg});
+                    float *pb = pipe_opaque(pub);
+                    st_sc1_f32x4(pb + 2 * (off_b + lane_o * 4), (f32x4){os.tw[0], tg, os.tw[1], tg});
+                    st_sc1_f32x4(pb + 2 * (off_b + lane_o * 4) + 4, (f32x4){os.tw[2], tg, os.tw[3], tg});
                     if (off_bias >= 0 && (lane & 15) == 0) {
-                        st_sc1_f32x4(pub + 2 * (off_bias + (lane >> 4) * 4), (f32x4){os.bw[0], tg, os.bw[1], tg});
-                        st_sc1_f32x4(pub + 2 * (off_bias + (lane >> 4) * 4) + 4, (f32x4){os.bw[2], tg, os.bw[3], tg});
+                        st_sc1_f32x4(pb + 2 * (off_bias + (lane_o >> 4) * 4), (f32x4){os.bw[0], tg, os.bw[1], tg});
+                        st_sc1_f32x4(pb + 2 * (off_bias + (lane_o >> 4) * 4) + 4, (f32x4){os.bw[2], tg, os.bw[3], tg});
                     }
+                    if (lane == 0) __hip_atomic_fetch_add(hint + 32 * jblock, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     TSTAMP(q3);
-                    // the blocks published by now or about to be (this wave's own and the ones above it): all their granules at once
-                    const int first = ((1 << B) - 1) & ~((1 << jblock) - 1);
-                    refresh(first, want);
-                    if (!alive) break;
-                    pending &= ~first;
+                    if (svc == 0) TLINE(10);
+                    if (svc == 1) TLINE(7);
                 } else {
                     TSTAMP(q2); TSTAMP(q3);
                 }
@@ -473,14 +567,10 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                     adam_reg(a, ad, w_, 0.f, m_, v_);
                     dw[k] = w_; dm[k] = m_; dv[k] = v_;
                 }
-                // ---- R: the remaining blocks in the order the backward pass frees them; a block's tiles can only carry this
-                // minibatch's tag behind its arrivals, so the cheap counter is polled first and the granules behind it
-#pragma unroll 1
-                for (int b = B - 1; b >= 0 && alive; --b) {
-                    if (!((pending >> b) & 1)) continue;
-                    if (!pipe_wait_ctr(arrival + 32 * b, arrived, abort_w, a.gerr)) { fail(); break; }
-                    for (int i = 0; i < sl_r; ++i) __builtin_amdgcn_s_sleep(1);   // (the owners' tiles are an operand round trip + a step away)
-                    refresh(1 << b, want);
+                // ---- R: this wave's share of the refresh (the owners of block 1's and block 0's jobs have none)
+                if (relayer) {
+                    relay_all(want);
+                    if (svc == PIPE_SVC - 1) TLINE(17);
                 }
                 if (!alive) break;
                 TSTAMP(q4);
@@ -501,13 +591,14 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
         if (owner) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (os.wt[r] >= 0) {
-                    st_sc1(a.w + os.wt[r], restore ? ld_sc1(a.best_w + os.wt[r]) : os.tw[r]);
-                    st_sc1(a.m + os.wt[r], os.tm[r]); st_sc1(a.v + os.wt[r], os.tv[r]);
+                const int wt = pipe_opaque(os.wt[r]), bt = pipe_opaque(os.bt[r]);
+                if (wt >= 0) {
+                    st_sc1(a.w + wt, restore ? ld_sc1(a.best_w + wt) : os.tw[r]);
+                    st_sc1(a.m + wt, os.tm[r]); st_sc1(a.v + wt, os.tv[r]);
                 }
-                if (os.bt[r] >= 0) {
-                    st_sc1(a.w + os.bt[r], restore ? ld_sc1(a.best_w + os.bt[r]) : os.bw[r]);
-                    st_sc1(a.m + os.bt[r], os.bm[r]); st_sc1(a.v + os.bt[r], os.bv[r]);
+                if (bt >= 0) {
+                    st_sc1(a.w + bt, restore ? ld_sc1(a.best_w + bt) : os.bw[r]);
+                    st_sc1(a.m + bt, os.bm[r]); st_sc1(a.v + bt, os.bv[r]);
                 }
             }
         }
@@ -520,8 +611,12 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
         // service wave 0 of workgroup 0: row preparation, wait for its block's arrivals, job + Adam + publish, refresh
         if (a.losses && wg == 0 && svc == 0 && lane == 0) for (int i = 0; i < 4; ++i) a.losses[4 + i] = (float)ph[i];
 #endif
-        if (wg == 0 && sidx == 0 && a.adam_step) *a.adam_step = adam_t;   // (a service wave: it has counted the Adam steps)
+        if (wg == 0 && svc == 0 && lane == 0 && a.adam_step) *a.adam_step = adam_t;   // (a service wave: it has counted the Adam steps)
     }
+#ifdef NNEST_STAMP
+    __syncthreads();
+    if (wg == 0 && threadIdx.x < 24 && a.losses) a.losses[16 + threadIdx.x] = tline[threadIdx.x];
+#endif
     if (wg == 0 && threadIdx.x == 0) {
         a.result->epochs_run = a.epoch_offset + epochs_run;
         a.result->best_epoch = ctl[2];
@@ -569,15 +664,15 @@ static hipError_t launch_train_pipe_t(TrainArgs a, float *gridws, hipStream_t st
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((grid_gpos_kernel<U, 1, 1>), dim3(32), dim3(256), 0, st, a.gpos, a.s);
     hipLaunchKernelGGL(grid_dead_kernel, dim3(32), dim3(256), 0, st, a.gpos, a.s.num_params(), a.gdead, a.gndead);
-    hipLaunchKernelGGL((rows_maps_kernel<U>), dim3(32), dim3(256), 0, st, reinterpret_cast<int *>(a.gown), a.s);   // (the owners' record area of train_kernel_grid: unused here)
+    hipLaunchKernelGGL((pipe_maps_kernel<U>), dim3(32), dim3(256), 0, st, reinterpret_cast<unsigned int *>(a.gown), a.s);   // (the owners' record area of train_kernel_grid: unused here)
     {   // how long a refresh's first data poll is held back behind its block's arrivals (units of 64 cycles; NNEST_K5_SLEEP overrides)
-        int r = 8;
+        int r = 0;
         if (const char *ev = getenv("NNEST_K5_SLEEP")) sscanf(ev, "%d", &r);
         a.gld_in = (float)(r & 255);   // (the VJP's scalar: unused by the training loop)
     }
     const int NJ = ROWS_B * 2 * (2 * U + 1);
     const int G = max((a.batch + ROWS_PER_WG - 1) / ROWS_PER_WG, (NJ + PIPE_SVC - 1) / PIPE_SVC);
-    const size_t lds = (size_t)2 * ROWS_B * SOLO4_NF * 64 * sizeof(float);
+    const size_t lds = ((size_t)2 * ROWS_B * SOLO4_NF * 64 + 64) * sizeof(float);   // the two images + the re-lay's dummy floats
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(train_kernel_pipe<U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((train_kernel_pipe<U>), dim3(G), dim3(TRAIN_THREADS), lds, st, a);

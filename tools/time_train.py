@@ -39,6 +39,13 @@ if os.environ.get('NNEST_HIP_LIB', '').endswith('STAMP.so'):   # NNEST_STAMP bui
         print('rows kernel, cycles per minibatch: forward %d  backward+staging %d  first grid barrier %d  weight-gradient jobs + Adam + publish %d  '
               'workgroup barrier %d  loss + image refresh (tag polls) %d  [first barrier: drain + workgroup barrier %d cycles, %.2f missed polls]' % tuple(ph[:8]))
     else:
+        tl = res['losses'].cpu().numpy().ravel()[16:16 + 24]
+        t0 = tl[0]
+        rel = [int((x - t0) % (1 << 24)) if x else -1 for x in tl]
+        print('pipe kernel, minibatch 20, cycles since the row wave entered block 0 forward: row wave 0: forward done %d, arrive(2) %d, arrive(1) %d, arrive(0) %d | '
+              'owner of a block-0 job: arrivals seen %d, contracted %d, published %d | a re-laying wave: hints seen (block 2, 1, 0) %d %d %d, blocks in the images %d %d %d'
+              % (rel[1], rel[2], rel[3], rel[4], rel[8], rel[9], rel[10], rel[12], rel[13], rel[14], rel[15], rel[16], rel[17]))
+        print('   owner of a block-2 job (service wave 1): top of its loop %d, arrivals seen %d, contracted %d, published %d; re-laying wave: top of its loop %d; row wave 0 done with its share of the refresh %d' % (rel[18], rel[5], rel[6], rel[7], rel[19], rel[20]))
         # train_kernel_pipe (the default form): row wave 0 and service wave 0 of workgroup 0 (the owner of a block-0 job)
         print('pipe kernel, cycles per minibatch, row wave: wait for rows + block 0 images %d  forward (+ staging, waits for blocks 1, 2) %d  '
               'backward to the last store %d  drain in front of the last arrival %d  | sum %d' % (tuple(ph[:4]) + (ph[:4].sum(),)))
