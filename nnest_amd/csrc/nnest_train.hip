@@ -1114,6 +1114,9 @@ hipError_t launch_train(float *packed, float *adam_m, float *adam_v, float *best
     a.epoch_offset = epoch_offset; a.flags = flags;
     a.mode = TRAIN_MODE_EPOCHS;
     if (grid_eligible(a) && pipe_eligible(a)) return dispatch_train_pipe(a, workspace + ((single_workspace_floats(s) + 63) & ~(size_t)63), st);
+#ifdef NNEST_DEV_PIPE2
+    if (a.mode == TRAIN_MODE_EPOCHS) return hipErrorInvalidConfiguration;
+#endif
     if (grid_eligible(a) && rows_eligible(a)) return dispatch_train_rows(a, workspace + ((single_workspace_floats(s) + 63) & ~(size_t)63), st);
     if (grid_eligible(a)) return dispatch_train_grid(a, workspace + ((single_workspace_floats(s) + 63) & ~(size_t)63), st);
     return dispatch_train(a, st);

@@ -943,7 +943,8 @@ static size_t grid_workspace_floats(const FlowShape &s) {
     return (size_t)s.B * 2 * CT * TRAIN_MAX_ROWS * 16 + (size_t)2 * s.B * 2 * NJOBS * 256 + (size_t)s.num_params() + 64 + 16 + 64 +
            (size_t)s.num_params() /* dead list */ +
            (size_t)GRID_WG * TRAIN_WAVES * 64 * 32 + 64 /* owners' records */ + (size_t)3 * (s.num_params() + 64) + 128 /* dead state */ +
-           (size_t)2 * (s.image_floats + 64) + 64 /* the published images */;
+           (size_t)2 * (s.image_floats + 64) + 64 /* the published images */ +
+           (size_t)2 * s.B * 2 * CT * TRAIN_MAX_ROWS * 16 + 192 /* train_kernel_pipe's tagged staging area */;
 }
 
 static hipError_t dispatch_train_grid(const TrainArgs &a, float *gridws, hipStream_t st) {

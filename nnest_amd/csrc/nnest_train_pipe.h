@@ -69,15 +69,65 @@ static __device__ __forceinline__ int pipe_opaque(int v) { asm volatile("" : "+v
 
 // what the forward pass stages for the block's weight-gradient jobs: the two hidden activations and the conditioning input
 template <int U>
-static __device__ __forceinline__ void rows_stage_forward(float *stg_net, int row, int pos, bool row_ok, const float (&cond)[U],
-                                                          const RowsKeep<U> &kp, bool stager) {
+static __device__ __forceinline__ void rows_stage_forward(const RowsTagged &t, bool row_ok, const float (&cond)[U], float h1, float h2, bool stager) {
     typedef StageMap<U, 1, 1> SM;
-    rows_stage(stg_net, SM::act(1, 0), row, pos, kp.h2, stager);
-    rows_stage(stg_net, SM::act(0, 0), row, pos, kp.h1, stager);
+    rows_stage_t(t, SM::act(1, 0), h2, stager);
+    rows_stage_t(t, SM::act(0, 0), h1, stager);
     float cm[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cm[u] = row_ok ? cond[u] : 0.f;
-    rows_stage_slots<U>(stg_net, SM::m(0), row, pos, cm, stager);
+    rows_stage_slots_t<U>(t, SM::m(0), cm, stager);
+}
+
+// contract_rows_grid over the TAGGED staging area: every operand as an 8-byte {value, tag} granule (sc1 buffer loads, all requested
+// before the first use); `fresh` comes back false when a granule of a row below rows_live (the rows some wave runs) did not carry tag `want` yet (the caller
+// asks again).  Same operand order as contract_rows_grid: the same bits.
+template <bool WITH_BIAS>
+__device__ __forceinline__ f32x4 contract_rows_tagged(__amdgpu_buffer_rsrc_t stgr, int base_g, int base_a, int rows_pad, int rows_live, int lane, int want,
+                                                      f32x4 &bias, bool &fresh) {
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
+    float bs = 0.f;
+    constexpr int NIT = TRAIN_MAX_ROWS / 16;
+    const int lo = (lane >> 4) * 256 + (lane & 15) * 16;   // (gq, j) inside a row group of granules (rows_tagged_row_off)
+    u32x4_ gv[NIT][2], ev[NIT][2];   // [it][m]: {value of MFMA 2 m, tag, value of MFMA 2 m + 1, tag}
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int r = it * 16 < rows_pad ? it * 16 : 0;   // (rows beyond rows_pad hold an earlier minibatch's data: tile 0 again, products skipped)
+        // (one vector register of offsets for all 56 requests: the row group's base goes in the instruction's scalar offset, the MFMA pair in its immediate)
+        const int sg = __builtin_amdgcn_readfirstlane(base_g + r * 128), sa = __builtin_amdgcn_readfirstlane(base_a + r * 128);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            gv[it][m] = __builtin_amdgcn_raw_buffer_load_b128(stgr, lo + 1024 * m, sg, 16 /* sc1 */);
+            ev[it][m] = __builtin_amdgcn_raw_buffer_load_b128(stgr, lo + 1024 * m, sa, 16);
+        }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        if (it * 16 < rows_pad) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {   // (rows of the last tile that no wave runs -- the grid has ceil(batch / 4) workgroups -- are never written: zeros without a tag)
+                ok = ok && (it * 16 + 8 * m + (lane >> 4) >= rows_live || ((int)gv[it][m].y == want && (int)ev[it][m].y == want));
+                ok = ok && (it * 16 + 8 * m + 4 + (lane >> 4) >= rows_live || ((int)gv[it][m].w == want && (int)ev[it][m].w == want));
+            }
+            const float g0 = __uint_as_float(gv[it][0].x), g1 = __uint_as_float(gv[it][0].z), g2 = __uint_as_float(gv[it][1].x), g3 = __uint_as_float(gv[it][1].z);
+            a0 = mfma4(g0, __uint_as_float(ev[it][0].x), a0);
+            a1 = mfma4(g1, __uint_as_float(ev[it][0].z), a1);
+            a2 = mfma4(g2, __uint_as_float(ev[it][1].x), a2);
+            a3 = mfma4(g3, __uint_as_float(ev[it][1].z), a3);
+            if (WITH_BIAS) bs += (g0 + g1) + (g2 + g3);
+        }
+    }
+    fresh = __all(ok);
+    if (WITH_BIAS) {
+        bs += __shfl_xor(bs, 16);
+        bs += __shfl_xor(bs, 32);
+        const int q4 = (lane >> 4) * 4;
+        bias = (f32x4){__shfl(bs, q4 + 0), __shfl(bs, q4 + 1), __shfl(bs, q4 + 2), __shfl(bs, q4 + 3)};
+    }
+    return (a0 + a1) + (a2 + a3);
 }
 
 // the refresh map of train_kernel_pipe: for element i of the published backward fragment image (weights as bwd_image_src lays them
@@ -105,29 +155,56 @@ __global__ void pipe_maps_kernel(unsigned int *__restrict__ maps, FlowShape s) {
     }
 }
 
-template <int U>
-__global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) {
+// The two kinds of wave run two FUNCTIONS (pipe_body<U, 0> the row waves, pipe_body<U, 1> the service waves), not two branches of
+// one: as one function hipcc's register allocation sees 11 k instructions with the service waves' 112 operand registers and the row
+// waves' kept activations in one interference graph and spills in both (the row waves' activations went to scratch with 100 of 256
+// registers in use); as two, each gets an allocation of its own.  The kernel's arguments are read from the kernarg segment where
+// they are needed, everything the waves share sits in the workgroup's dynamic LDS: the two images, the re-lay's dummy floats, the
+// prepared rows, the control words.
+template <int U> struct PipeLds {
+    static constexpr int IMG = ROWS_B * SOLO4_NF * 64;
+    static constexpr int XPRE = 2 * IMG + 64;                       // float offsets into the dynamic LDS
+    static constexpr int CTL = XPRE + 2 * ROWS_PER_WG * 32 * U;     // int [4]: [0] stop flag, [1] counter, [2] best epoch
+    static constexpr int CTLF = CTL + 4;                            // float [2]: [0] best validation loss, [1] the epoch's training loss (workgroup 0)
+    static constexpr int SFLAG = CTLF + 4;                          // int [SF_N]
+    static constexpr int TLINE = SFLAG + 8;                         // float [24] (diagnostic build)
+    static constexpr int FLOATS = TLINE + 24;
+};
+
+template <int U, int ROLE>
+__device__ __attribute__((noinline)) void pipe_body() {
+    TrainArgs a;   // the kernel's one argument, word by word from the kernarg segment (scalar loads where they are used)
+    {
+        static_assert(sizeof(TrainArgs) % 4 == 0, "TrainArgs in words");
+        // (a callable function is handed the IMPLICIT-argument pointer, not the kernarg segment's: the hidden arguments start at
+        // the first 8-byte boundary behind the kernel's explicit ones, i.e. behind its one TrainArgs)
+        const __attribute__((address_space(4))) unsigned int *kw = (const __attribute__((address_space(4))) unsigned int *)(
+            (const __attribute__((address_space(4))) char *)__builtin_amdgcn_implicitarg_ptr() - ((sizeof(TrainArgs) + 7) & ~(size_t)7));
+        unsigned int *aw = reinterpret_cast<unsigned int *>(&a);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(TrainArgs) / 4); ++i) aw[i] = kw[i];
+    }
     typedef StageMap<U, 1, 1> SM;
+    typedef PipeLds<U> PL;
     constexpr int B = ROWS_B, IMG = ROWS_B * SOLO4_NF * 64;
-    constexpr int NBS = 2 + (U == 4 ? 1 : U);   // vector-memory stores of one block's backward pass (gout, g_pre of the two hidden layers)
     constexpr int NPW = (ROWS_PER_WG * 8 * U + 63) / 64;   // service waves that prepare rows
     constexpr int IMGF_ = ROWS_B * 2 * (2 * U * 256 + 256 + 16 + 16 + 16 * U);   // image_floats of the shape
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *imgf = smem;          // forward solo image  [B][SOLO4_NF / 4][64][4]
     float *imgb = smem + IMG;    // transposed solo image
-    __shared__ __attribute__((aligned(16))) float xpre[2][ROWS_PER_WG * 32 * U];   // the minibatch's rows, flat, a minibatch ahead
-    __shared__ int ctl[4];      // [0] stop flag, [1] counter, [2] best epoch
-    __shared__ float ctlf[2];   // [0] best validation loss, [1] the epoch's training loss (workgroup 0)
+    float (*xpre)[ROWS_PER_WG * 32 * U] = reinterpret_cast<float (*)[ROWS_PER_WG * 32 * U]>(smem + PL::XPRE);   // the minibatch's rows, flat, a minibatch ahead
+    int *ctl = reinterpret_cast<int *>(smem + PL::CTL);
+    float *ctlf = smem + PL::CTLF;
 #ifdef NNEST_STAMP
-    __shared__ float tline[24];
+    float *tline = smem + PL::TLINE;
 #endif
-    __shared__ int sflag[SF_N]; // [SF_REF + b] service waves that have refreshed block b (monotonic), [SF_X] row preparations done,
-                                // [SF_ARR + b] row waves arrived behind block b's backward stores, [SF_ABORT]
+    int *sflag = reinterpret_cast<int *>(smem + PL::SFLAG);   // [SF_REF + b] waves that have refreshed block b (monotonic), [SF_X] row preparations done,
+                                                              // [SF_ARR + b] row waves arrived behind block b's backward stores, [SF_ABORT]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wg = blockIdx.x, G = gridDim.x;
     const int D = a.s.D;
     constexpr int NJOBS = 2 * U + 1;
-    const bool row_wave = wave < ROWS_PER_WG;
+    constexpr bool row_wave = ROLE == 0;
     int phase = 0;
     // Who re-lays the published tiles into the LDS images: the four ROW waves (behind their last arrival they have nothing to do
     // until the images are refreshed), the service waves without a job, and the owners of block 2's jobs (the first block the
@@ -166,7 +243,8 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
     if (a.max_epochs > 0) rows_prepare<U>(a, 0, 0, wg, xpre[0]);
     __syncthreads();
 
-    float *part_base = a.gtile;   // [3][128] log p of a minibatch's rows, [2][128] validation sums of the row waves (sc1 words, one writer each)
+    float *part_base = a.gtile;   // [3][128] {log p of a minibatch's row, tag} granules, then [2][128] validation sums of the row waves (sc1 words, one writer each)
+    float *valid_base = a.gtile + 3 * 2 * TRAIN_MAX_ROWS;
     unsigned int *arrival = reinterpret_cast<unsigned int *>(a.gtile + 1024);   // [b] at + 32 b: workgroups whose rows are behind block b's backward stores
     const int *abort_w = &sflag[SF_ABORT];
     // the sum of the 4 G row waves' words in a fixed order: lane l takes words l and l + 64, then a butterfly over the lanes
@@ -181,9 +259,14 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
     int epochs_run = 0, mbcount = 0;
     float last_train_loss = 0.f;
     bool alive = true;
-    auto fail = [&]() {   // a wait ran out (or another wave's did): every wave of the workgroup leaves its loops, the launch ends
+    // a wait ran out (or another wave's did): every wave of the workgroup leaves its loops, the launch ends.  The error word says
+    // which wait (code), of which wave of which workgroup, in which minibatch (the first one to fail writes it)
+    auto fail = [&](int code) {
         alive = false;
-        if (lane == 0) { sflag[SF_ABORT] = 1; *a.gerr = 1; }
+        if (lane == 0) {
+            sflag[SF_ABORT] = 1;
+            atomicCAS(a.gerr, 0, code | (wave << 4) | (wg << 8) | ((mbcount & 0xffff) << 16));
+        }
     };
     // What both kinds of wave do at the end of an epoch, barrier for barrier (the two kinds run different code: a workgroup barrier
     // counts waves, not program counters).  validate(): the role's share of Trainer._validate; snapshot(): the role's share of
@@ -197,7 +280,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
         if (!alive) return false;
         alive = grid_barrier(a.gsync, phase, G, a.gerr);
         if (!alive) return false;
-        const float vtot = sum_rows(part_base + (3 + (epoch & 1)) * TRAIN_MAX_ROWS);
+        const float vtot = sum_rows(valid_base + (epoch & 1) * TRAIN_MAX_ROWS);
         const float valid_loss = (-vtot / (float)a.n_valid) / (float)a.n_valid;  // mean, then / len(dataset)  :418
         const float train_loss = ctlf[1];
         last_train_loss = train_loss;
@@ -233,7 +316,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
     constexpr int RU = (QB + 64 * (ROWS_PER_WG + 2) - 1) / (64 * (ROWS_PER_WG + 2));   // rounds of a thread per block with six re-laying waves
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int NRT = 64 * NREL, ridx = 64 * ridx0 + lane;
-    const int sl_r = (int)a.gld_in & 255;   // hold-back of block 0's data poll behind its hint, units of 64 cycles (launch_train_pipe_t)
+    const int sl_r = (int)a.gld_in & 255, sl_j = ((int)a.gld_in >> 8) & 255;   // hold-backs of block 0's data poll behind its hint / of a job's operand loads behind its block's arrivals, units of 64 cycles (launch_train_pipe_t)
     float *pub = a.gimgf;                    // the published weights: {weight, tag} pairs, 2 x image_floats floats
     unsigned int *hint = arrival + 32 * B;   // [b] at + 32 b: tiles of block b whose publish stores have been ISSUED (a hint, not an order: the tags decide)
     const __amdgpu_buffer_rsrc_t pubr = __builtin_amdgcn_make_buffer_rsrc(pub, 0, 2 * IMGF_ * (int)sizeof(float), 0x00020000);
@@ -259,7 +342,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
         }
     };
     // true: every lane of the wave found its granules of the block fresh (tag `want`), and they are in the images now
-    auto finish = [&](int b, int want, const f32x4 (&va_)[RU], const f32x4 (&vc_)[RU]) {
+    auto finish = [&](const u32x4 (&mp_)[RU], int want, const f32x4 (&va_)[RU], const f32x4 (&vc_)[RU]) {
         bool fresh = true;
 #pragma unroll
         for (int u = 0; u < RU; ++u)
@@ -270,7 +353,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
         for (int u = 0; u < RU; ++u) {
             if (ridx + NRT * u < QB) {
                 const float e4[4] = {va_[u].x, va_[u].z, vc_[u].x, vc_[u].z};
-                const unsigned int m4[4] = {mapw[b][u].x, mapw[b][u].y, mapw[b][u].z, mapw[b][u].w};
+                const unsigned int m4[4] = {mp_[u].x, mp_[u].y, mp_[u].z, mp_[u].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const unsigned int mw = (unsigned int)pipe_opaque((int)m4[e]);   // (unpacked here, not hoisted into 2 registers + a mask per element)
@@ -282,9 +365,9 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
         }
         return true;
     };
-    auto complete = [&](int b, int want, f32x4 (&va_)[RU], f32x4 (&vc_)[RU]) {
-        for (int polls = 0; !finish(b, want, va_, vc_); ++polls) {
-            if (polls > GRID_MAX_POLLS / 64 || pipe_lds_ld(abort_w)) { fail(); return; }
+    auto complete = [&](int b, const u32x4 (&mp_)[RU], int want, f32x4 (&va_)[RU], f32x4 (&vc_)[RU]) {
+        for (int polls = 0; !finish(mp_, want, va_, vc_); ++polls) {
+            if (polls > GRID_MAX_POLLS / 64 || pipe_lds_ld(abort_w)) { fail(6); return; }
             __builtin_amdgcn_s_sleep(2);
             issue(b, va_, vc_);
         }
@@ -297,24 +380,24 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
     auto relay_all = [&](int want) {
         const unsigned int published = (unsigned int)(2 * NJOBS) * (unsigned int)want;
         f32x4 va[B][RU], vc[B][RU];
-        if (!pipe_wait_ctr(hint + 32 * 2, published, abort_w, a.gerr)) { fail(); return; }
+        if (!pipe_wait_ctr(hint + 32 * 2, published, abort_w, a.gerr)) { fail(5); return; }
         if (wave == 7) TLINE(12);
         issue(2, va[2], vc[2]);
-        if (!pipe_wait_ctr(hint + 32 * 1, published, abort_w, a.gerr)) { fail(); return; }
+        if (!pipe_wait_ctr(hint + 32 * 1, published, abort_w, a.gerr)) { fail(5); return; }
         if (wave == 7) TLINE(13);
         issue(1, va[1], vc[1]);
-        complete(2, want, va[2], vc[2]);
+        complete(2, mapw[2], want, va[2], vc[2]);
         if (wave == 7) TLINE(15);
-        if (!alive || !pipe_wait_ctr(hint + 32 * 0, published, abort_w, a.gerr)) { fail(); return; }
+        if (!alive || !pipe_wait_ctr(hint + 32 * 0, published, abort_w, a.gerr)) { fail(5); return; }
         if (wave == 7) TLINE(14);
         for (int i = 0; i < sl_r; ++i) __builtin_amdgcn_s_sleep(1);
         issue(0, va[0], vc[0]);
-        complete(1, want, va[1], vc[1]);
+        complete(1, mapw[1], want, va[1], vc[1]);
         if (wave == 7) TLINE(16);
-        if (alive) complete(0, want, va[0], vc[0]);
+        if (alive) complete(0, mapw[0], want, va[0], vc[0]);
     };
 
-    if (row_wave) {
+    if constexpr (ROLE == 0) {
         // =====================================================================================================================
         // a row of every minibatch: forward, backward, arrivals
         // =====================================================================================================================
@@ -322,10 +405,11 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
         const bool h1 = (lane & 16) != 0, translate_half = lane >= 32, stager = (lane & 16) == 0;
         const unsigned sel = translate_half ? 0xffffffffu : 0u;
         const int row = wg * ROWS_PER_WG + wave;
-        float *stg_net0 = a.gstage + (size_t)(translate_half ? 1 : 0) * SM::count * TRAIN_MAX_ROWS * 16;   // + 2 b regions per block
-        constexpr size_t RS = (size_t)2 * SM::count * TRAIN_MAX_ROWS * 16;   // a block's two staging regions
-        // the stores of block b's backward pass (and everything before them) have completed -> count the wave in; the workgroup's
-        // last wave counts the workgroup in
+        constexpr size_t RS = (size_t)2 * 2 * SM::count * TRAIN_MAX_ROWS * 16;   // floats of a block's two staging regions (granules: 2 floats per value)
+        const int voff_net = (translate_half ? SM::count * ROWS_CTB : 0) + rows_tagged_row_off(row);
+        const int voff_pos = voff_net + 16 * pos, voff_slot = voff_net + ((U * pos) >> 4) * ROWS_CTB + 16 * ((U * pos) & 15);
+        // the stores of block b's backward pass have been ISSUED -> count the wave in; the workgroup's last wave counts the workgroup
+        // in.  Nothing waits for the stores: the count is a hint for the block's owners (when to look), the tags decide
         auto arrive = [&](int b) {
             if (lane == 0) {
                 const int old = __hip_atomic_fetch_add(&sflag[SF_ARR + b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -345,10 +429,13 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
             for (int mb = 0; mb < n_mb && alive; ++mb, ++mbcount) {
                 const int M = min(a.batch, a.n_train - mb * a.batch);
                 const int rows_pad = ((M + 15) >> 4) * 16;
-                float *part = part_base + (mbcount % 3) * TRAIN_MAX_ROWS;
+                float *part = part_base + (mbcount % 3) * 2 * TRAIN_MAX_ROWS;
+                const float tg = __int_as_float(mbcount + 1);
+                float *stg0 = pipe_opaque(a.gstage);
+                const RowsTagged t0 = {stg0, voff_pos, voff_slot, tg}, t1 = {stg0 + RS, voff_pos, voff_slot, tg}, t2 = {stg0 + 2 * RS, voff_pos, voff_slot, tg};
                 const bool row_ok = row < M;
                 TSTAMP(q0);
-                if (!pipe_wait_lds(&sflag[SF_X], NPW * (mbcount + 1), abort_w)) { fail(); break; }
+                if (!pipe_wait_lds(&sflag[SF_X], NPW * (mbcount + 1), abort_w)) { fail(1); break; }
                 if (row < rows_pad) {   // (rows M .. rows_pad - 1 run on zeros with row_ok = false: their staged gradients must read 0)
                     float xs[2][U], gs[2][U];
                     const float *xr = xpre[mbcount & 1] + wave * 32 * U + 2 * U * pos;
@@ -360,16 +447,16 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                     TSTAMP(q1);
                     if (wave == 0) TLINE(0);
                     float ld_lane = rows_block_forward<U>(Solo4Lds{imgf, lane}, sel, h1, xs[1], xs[0], kp[0]);
-                    rows_stage_forward<U>(stg_net0, row, pos, row_ok, xs[1], kp[0], stager);
+                    rows_stage_forward<U>(t0, row_ok, xs[1], kp[0].h1, kp[0].h2, stager);
                     okw = okw && pipe_wait_lds(&sflag[SF_REF + 1], NREL * mbcount, abort_w);
                     ld_lane += rows_block_forward<U>(Solo4Lds{imgf + SOLO4_NF * 64, lane}, sel, h1, xs[0], xs[1], kp[1]);
-                    rows_stage_forward<U>(stg_net0 + RS, row, pos, row_ok, xs[0], kp[1], stager);
+                    rows_stage_forward<U>(t1, row_ok, xs[0], kp[1].h1, kp[1].h2, stager);
                     okw = okw && pipe_wait_lds(&sflag[SF_REF + 2], NREL * mbcount, abort_w);
                     ld_lane += rows_block_forward<U>(Solo4Lds{imgf + 2 * SOLO4_NF * 64, lane}, sel, h1, xs[1], xs[0], kp[2]);
-                    rows_stage_forward<U>(stg_net0 + 2 * RS, row, pos, row_ok, xs[1], kp[2], stager);
-                    if (!okw) { fail(); break; }
+                    rows_stage_forward<U>(t2, row_ok, xs[1], kp[2].h1, kp[2].h2, stager);
+                    if (!okw) { fail(2); break; }
                     const float lp = row_ok ? log_prob(xs, ld_lane) : 0.f;
-                    if (lane == 0) st_sc1(part + row, lp);
+                    if (lane == 0) st_sc1_x2(part + 2 * row, lp, tg);
                     TSTAMP(q2);
                     if (wave == 0) TLINE(1);
                     // d(loss)/du = dE/du / M ; d(loss)/d(logdet) = -1/M
@@ -378,18 +465,14 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int u = 0; u < U; ++u) gs[c][u] = row_ok ? base_dE(xs[c][u], a.s.base_beta) * invM : 0.f;
-                    rows_block_backward<U, false>(Solo4Lds{imgb + 2 * SOLO4_NF * 64, lane}, sel, h1, translate_half, pos, D, 0, row_ok, gld, xs[1], xs[0], gs[1], gs[0], kp[2], stg_net0 + 2 * RS, row, stager);
-                    rows_block_backward<U, false>(Solo4Lds{imgb + SOLO4_NF * 64, lane}, sel, h1, translate_half, pos, D, 1, row_ok, gld, xs[0], xs[1], gs[0], gs[1], kp[1], stg_net0 + RS, row, stager);
-                    // block 2's stores (and everything before them) are complete once at most block 1's NBS are outstanding
-                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NBS) : "memory");
+                    rows_block_backward<U, false, true>(Solo4Lds{imgb + 2 * SOLO4_NF * 64, lane}, sel, h1, translate_half, pos, D, 0, row_ok, gld, xs[1], xs[0], gs[1], gs[0], kp[2], nullptr, row, stager, t2);
                     arrive(2);
                     if (wave == 0) TLINE(2);
-                    rows_block_backward<U, false>(Solo4Lds{imgb, lane}, sel, h1, translate_half, pos, D, 0, row_ok, gld, xs[1], xs[0], gs[1], gs[0], kp[0], stg_net0, row, stager);
-                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NBS) : "memory");
+                    rows_block_backward<U, false, true>(Solo4Lds{imgb + SOLO4_NF * 64, lane}, sel, h1, translate_half, pos, D, 1, row_ok, gld, xs[0], xs[1], gs[0], gs[1], kp[1], nullptr, row, stager, t1);
                     arrive(1);
                     TSTAMP(q3);
                     if (wave == 0) TLINE(3);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    rows_block_backward<U, false, true>(Solo4Lds{imgb, lane}, sel, h1, translate_half, pos, D, 0, row_ok, gld, xs[1], xs[0], gs[1], gs[0], kp[0], nullptr, row, stager, t0);
                     arrive(0);
                     TSTAMP(q4);
                     if (wave == 0) TLINE(4);
@@ -400,9 +483,8 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                     bool okw = true;
 #pragma unroll
                     for (int b = 0; b < B; ++b) okw = okw && pipe_wait_lds(&sflag[SF_REF + b], NREL * mbcount, abort_w);
-                    if (!okw) { fail(); break; }
-                    if (lane == 0) st_sc1(part + row, 0.f);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!okw) { fail(2); break; }
+                    if (lane == 0) st_sc1_x2(part + 2 * row, 0.f, tg);
                     arrive(2); arrive(1); arrive(0);
                 }
                 // ---- R: nothing to do until the images are refreshed -- so the row waves do their share of it
@@ -416,7 +498,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                 bool okw = true;
 #pragma unroll
                 for (int b = 0; b < B; ++b) okw = okw && pipe_wait_lds(&sflag[SF_REF + b], NREL * mbcount, abort_w);
-                if (!okw) { fail(); return; }
+                if (!okw) { fail(2); return; }
                 for (int r = row; r < a.n_valid; r += ROWS_PER_WG * G) {
                     float xs[2][U];
 #pragma unroll
@@ -432,7 +514,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                     ld_lane += rows_block_forward<U>(Solo4Lds{imgf + 2 * SOLO4_NF * 64, lane}, sel, h1, xs[1], xs[0], kp[2]);
                     vsum += log_prob(xs, ld_lane);
                 }
-                if (lane == 0) st_sc1(part_base + (3 + (epoch & 1)) * TRAIN_MAX_ROWS + row, vsum);
+                if (lane == 0) st_sc1(valid_base + (epoch & 1) * TRAIN_MAX_ROWS + row, vsum);
             }, [&]() {});
             if (!go_on) break;
         }
@@ -489,13 +571,14 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
             for (int k = dead0 + lane; k < dead1; k += 64) st_sc1(a.best_w + a.gdead[k], dw[k]);
         };
         if (!resume) snapshot();
+        const __amdgpu_buffer_rsrc_t partr = __builtin_amdgcn_make_buffer_rsrc(part_base, 0, 3 * 2 * TRAIN_MAX_ROWS * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t stgr = __builtin_amdgcn_make_buffer_rsrc(a.gstage, 0, B * 2 * SM::count * TRAIN_MAX_ROWS * 16 * 8, 0x00020000);
         int adam_t = a.adam_step ? *a.adam_step : 0;
         for (int epoch = 0; epoch < a.max_epochs; ++epoch) {
             float epoch_loss = 0.f;
             for (int mb = 0; mb < n_mb && alive; ++mb, ++mbcount) {
                 const int M = min(a.batch, a.n_train - mb * a.batch);
                 const int rows_pad = ((M + 15) >> 4) * 16;
-                const float *part = part_base + (mbcount % 3) * TRAIN_MAX_ROWS;
                 AdamStep ad;
                 {
                     adam_t += 1;
@@ -518,25 +601,31 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                 const int want = mbcount + 1;
                 if (owner) {
                     // ---- W + A: this wave's weight-gradient job; Adam on the tile's parameters in this wave's registers ----
-                    if (!pipe_wait_ctr(arrival + 32 * jblock, arrived, abort_w, a.gerr)) { fail(); break; }
+                    if (!pipe_wait_ctr(arrival + 32 * jblock, arrived, abort_w, a.gerr)) { fail(3); break; }
                     TSTAMP(q2);
                     if (svc == 0) TLINE(8);
                     if (svc == 1) TLINE(5);
                     const int bn = Jmine / NJOBS;
-                    int q = Jmine % NJOBS;
-                    const float *stg = pipe_opaque(a.gstage) + (size_t)bn * SM::count * TRAIN_MAX_ROWS * 16;
+                    const int q = Jmine % NJOBS;
                     const int lane_o = pipe_opaque(lane);
                     f32x4 bt = {0.f, 0.f, 0.f, 0.f}, t;
                     constexpr int J_W3 = U, J_W2 = 1;
-                    if (q < J_W3) {
-                        t = contract_rows_grid<true>(stg, rows_pad, SM::gout(q), SM::act(1, 0), lane_o, bt);
-                    } else if (q - J_W3 < J_W2) {
-                        t = contract_rows_grid<true>(stg, rows_pad, SM::gpre(1, 0), SM::act(0, 0), lane_o, bt);
-                    } else {
-                        q -= J_W3 + J_W2;
-                        t = q == 0 ? contract_rows_grid<true>(stg, rows_pad, SM::gpre(0, 0), SM::m(q), lane_o, bt)
-                                   : contract_rows_grid<false>(stg, rows_pad, SM::gpre(0, 0), SM::m(q), lane_o, bt);
+                    constexpr int CTB = TRAIN_MAX_ROWS * 16 * 8;   // bytes of one column tile of granules
+                    const int rb = pipe_opaque(bn * SM::count * CTB);   // this job's (block, net) region
+                    // (the arrivals were counted when the rows' stores were issued, not when they landed: an operand without this
+                    // minibatch's tag sends the wave round again)
+                    // the job's two operands (weight_grad_jobs' enumeration): gradient tile x activation tile of the (block, net) region
+                    const int ct_g = q < J_W3 ? SM::gout(q) : (q - J_W3 < J_W2 ? SM::gpre(1, 0) : SM::gpre(0, 0));
+                    const int ct_a = q < J_W3 ? SM::act(1, 0) : (q - J_W3 < J_W2 ? SM::act(0, 0) : SM::m(q - J_W3 - J_W2));
+                    for (int i = 0; i < sl_j; ++i) __builtin_amdgcn_s_sleep(1);   // (the count runs ahead of the rows' stores by their way to memory)
+                    for (int polls = 0; ; ++polls) {
+                        bool fresh;
+                        t = contract_rows_tagged<true>(stgr, rb + ct_g * CTB, rb + ct_a * CTB, rows_pad, min(rows_pad, ROWS_PER_WG * G), lane_o, want, bt, fresh);   // (the bias sum of a job without a bias goes nowhere: os.bt = -1)
+                        if (fresh) break;
+                        if (polls > GRID_MAX_POLLS / 64 || pipe_lds_ld(abort_w)) { fail(4); break; }
+                        __builtin_amdgcn_s_sleep(2);
                     }
+                    if (!alive) break;
                     const float gt[4] = {t.x, t.y, t.z, t.w}, gb[4] = {bt.x, bt.y, bt.z, bt.w};
                     if (svc == 0) TLINE(9);
                     if (svc == 1) TLINE(6);
@@ -577,7 +666,25 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
                 if (svc == 0) { TACC(ph[0], q1, q0); TACC(ph[1], q2, q1); TACC(ph[2], q3, q2); TACC(ph[3], q4, q3); }
                 // loss = -mean(log_probs)  (trainer.py:394) over the rows' words: complete behind block 0's arrivals; only the
                 // wave that reports the epoch losses needs it (the words are triple-buffered: nothing waits for this sum)
-                if (wg == 0 && svc == PIPE_SVC - 1) epoch_loss += -sum_rows(part) / (float)M;
+                if (wg == 0 && svc == PIPE_SVC - 1) {
+                    float lsum = 0.f;
+                    for (int polls = 0; ; ++polls) {   // (the words are granules too: {log p, tag})
+                        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                        const f32x2_ w0 = __builtin_bit_cast(f32x2_, __builtin_amdgcn_raw_buffer_load_b64(partr, pipe_opaque((mbcount % 3) * 2 * TRAIN_MAX_ROWS * 4 + 8 * min(lane, ROWS_PER_WG * G - 1)), 0, 16));
+                        const f32x2_ w1 = __builtin_bit_cast(f32x2_, __builtin_amdgcn_raw_buffer_load_b64(partr, pipe_opaque((mbcount % 3) * 2 * TRAIN_MAX_ROWS * 4 + 8 * min(lane + 64, ROWS_PER_WG * G - 1)), 0, 16));
+                        const bool ok = __float_as_int(w0.y) == want && __float_as_int(w1.y) == want;
+                        if (__all(ok)) {
+                            float v = (lane < ROWS_PER_WG * G ? w0.x : 0.f) + (lane + 64 < ROWS_PER_WG * G ? w1.x : 0.f);
+#pragma unroll
+                            for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+                            lsum = v;
+                            break;
+                        }
+                        if (polls > GRID_MAX_POLLS / 64 || pipe_lds_ld(abort_w)) { fail(7); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    epoch_loss += -lsum / (float)M;
+                }
             }
             const bool go_on = epoch_end(epoch, [&]() {
                 if (wg == 0 && svc == PIPE_SVC - 1 && lane == 0) ctlf[1] = epoch_loss / (float)a.n_train;   // trainer.py:403
@@ -622,9 +729,16 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
         a.result->best_epoch = ctl[2];
         a.result->best_validation_loss = ctlf[0];
         a.result->last_train_loss = last_train_loss;
-        a.result->counter = ctl[1];
+        a.result->counter = *a.gerr ? *a.gerr : ctl[1];   // (a wait ran out: which one, fail())
         a.result->stopped = *a.gerr ? 2 : (ctl[0] != 0 ? 1 : 0);   // 2: a wait ran out (include/nnest_hip.h)
     }
+}
+
+template <int U>
+__global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) {
+    (void)a;   // (read from the kernarg segment by the two bodies)
+    if ((threadIdx.x >> 6) < ROWS_PER_WG) pipe_body<U, 0>();
+    else pipe_body<U, 1>();
 }
 
 // NNEST_TRAIN_FORM=rows in the environment keeps train_kernel_rows, =grid train_kernel_grid (diagnostics)
@@ -652,7 +766,9 @@ static hipError_t launch_train_pipe_t(TrainArgs a, float *gridws, hipStream_t st
     a.gimgf += (64 - ((size_t)(a.gimgf - gridws) & 63)) & 63;
     a.gimgb = a.gimgf + ((a.s.image_floats + 63) & ~63);
     static_assert(GS::NJOBS * 2 * ROWS_B * 2 * 256 >= 2048, "the rows' words and the arrival counters live in the tile area");
-    hipError_t e = hipMemsetAsync(a.gstage, 0, GS::stage(a.s) * sizeof(float), st);   // rows beyond the batch are never written: they must read 0
+    a.gstage = a.gimgb + ((a.s.image_floats + 63) & ~63) + 64;   // the TAGGED staging area: 2 floats per value (pipe_extra_workspace_floats)
+    a.gstage += (64 - ((size_t)(a.gstage - gridws) & 63)) & 63;
+    hipError_t e = hipMemsetAsync(a.gstage, 0, 2 * GS::stage(a.s) * sizeof(float), st);   // tag 0: no minibatch's
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(a.gtile, 0, 2048 * sizeof(float), st);   // the rows' words, the arrival counters
     if (e != hipSuccess) return e;
@@ -666,13 +782,13 @@ static hipError_t launch_train_pipe_t(TrainArgs a, float *gridws, hipStream_t st
     hipLaunchKernelGGL(grid_dead_kernel, dim3(32), dim3(256), 0, st, a.gpos, a.s.num_params(), a.gdead, a.gndead);
     hipLaunchKernelGGL((pipe_maps_kernel<U>), dim3(32), dim3(256), 0, st, reinterpret_cast<unsigned int *>(a.gown), a.s);   // (the owners' record area of train_kernel_grid: unused here)
     {   // how long a refresh's first data poll is held back behind its block's arrivals (units of 64 cycles; NNEST_K5_SLEEP overrides)
-        int r = 0;
-        if (const char *ev = getenv("NNEST_K5_SLEEP")) sscanf(ev, "%d", &r);
-        a.gld_in = (float)(r & 255);   // (the VJP's scalar: unused by the training loop)
+        int r = 0, j = 0;
+        if (const char *ev = getenv("NNEST_K5_SLEEP")) sscanf(ev, "%d,%d", &r, &j);
+        a.gld_in = (float)((r & 255) + 256 * (j & 255));   // (the VJP's scalar: unused by the training loop)
     }
     const int NJ = ROWS_B * 2 * (2 * U + 1);
     const int G = max((a.batch + ROWS_PER_WG - 1) / ROWS_PER_WG, (NJ + PIPE_SVC - 1) / PIPE_SVC);
-    const size_t lds = ((size_t)2 * ROWS_B * SOLO4_NF * 64 + 64) * sizeof(float);   // the two images + the re-lay's dummy floats
+    const size_t lds = (size_t)PipeLds<U>::FLOATS * sizeof(float);   // the two images + the re-lay's dummy floats + the prepared rows + the control words
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(train_kernel_pipe<U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((train_kernel_pipe<U>), dim3(G), dim3(TRAIN_THREADS), lds, st, a);
@@ -683,10 +799,12 @@ static hipError_t launch_train_pipe_t(TrainArgs a, float *gridws, hipStream_t st
 
 static hipError_t dispatch_train_pipe(const TrainArgs &a, float *gridws, hipStream_t st) {
     switch (a.s.NT) {
-        case 1: return launch_train_pipe_t<1>(a, gridws, st);
         case 2: return launch_train_pipe_t<2>(a, gridws, st);
+#ifndef NNEST_DEV_PIPE2
+        case 1: return launch_train_pipe_t<1>(a, gridws, st);
         case 3: return launch_train_pipe_t<3>(a, gridws, st);
         case 4: return launch_train_pipe_t<4>(a, gridws, st);
+#endif
     }
     return hipErrorInvalidConfiguration;
 }

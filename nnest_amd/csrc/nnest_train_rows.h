@@ -192,14 +192,78 @@ static __device__ __forceinline__ void rows_stage_slots(float *stg_net, int ct0,
     }
 }
 
+// TAGGED staging (train_kernel_pipe): every staged value travels as an 8-byte {value, tag} granule: a reader that finds the
+// minibatch's tag has the minibatch's value, whatever the order its loads were served in (MI355X_MICROARCH.md, "R2"), so the writer
+// never waits for its stores.  Inside a column tile (128 rows x 16 columns) the granules are laid out for the READER, the
+// weight-gradient job's v_mfma_f32_16x16x4: lane (gq, j) of MFMA k of row group `it` takes row 16 it + 4 k + gq, column j -- so the
+// two rows k = 2 m, 2 m + 1 of a lane sit side by side, one 16-byte load for two MFMAs (56 loads per job; as 112 8-byte loads they
+// ran over the 63 a wave can have in flight, measured: two latencies instead of one):
+//     byte offset of (row r, column j) = 2048 (r >> 4) + 256 (4 m + gq) + 16 j + 8 p,   gq = r & 3, k = (r >> 2) & 3, m = k >> 1, p = k & 1.
+// A store takes the block's base + the column tile in SCALAR registers and the lane's (net, row, column) as one 32-bit offset that
+// is the same for every store of the launch (voff_pos; voff_slot for the per-slot tensors): no 64-bit address per store for hipcc to
+// hoist and spill.
+struct RowsTagged {
+    float *blk;        // the block's staging region (uniform)
+    int voff_pos;      // byte offset of (net, row, column = pos)
+    int voff_slot;     // byte offset of (net, row, the lane's first slot: tile (U pos) >> 4, column (U pos) & 15)
+    float tg;
+};
+constexpr int ROWS_CTB = TRAIN_MAX_ROWS * 16 * 8;   // bytes of one column tile of granules
+static __device__ __forceinline__ int rows_tagged_row_off(int r) {   // the row's part of a granule's offset
+    const int gq = r & 3, k = (r >> 2) & 3;
+    return 2048 * (r >> 4) + 256 * (4 * (k >> 1) + gq) + 8 * (k & 1);
+}
+__device__ __forceinline__ void st_sc1_x2(float *p, float v, float tg) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ d = {v, tg};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(d) : "memory");
+}
+static __device__ __forceinline__ float pipe_opaque_f(float v) { asm volatile("" : "+v"(v)); return v; }
+// one granule at byte offset voff (+ imm) behind the scalar base
+template <int IMM>
+static __device__ __forceinline__ void rows_granule(const float *sb, int voff, float v, float tg, bool stager) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ d;   // (built from two scalars behind an empty asm: as a vector literal of a kept activation hipcc widened the KEPT value into memory)
+    d.x = pipe_opaque_f(v);
+    d.y = tg;
+    if (stager) asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 sc1" : : "v"(voff), "v"(d), "s"(sb), "n"(IMM) : "memory");
+}
+static __device__ __forceinline__ void rows_stage_t(const RowsTagged &t, int ct, float v, bool stager) {
+    rows_granule<0>(t.blk + (size_t)ct * (ROWS_CTB / 4), t.voff_pos, v, t.tg, stager);
+}
+template <int U>
+static __device__ __forceinline__ void rows_stage_slots_t(const RowsTagged &t, int ct0, const float (&v)[U], bool stager) {
+    const float *sb = t.blk + (size_t)ct0 * (ROWS_CTB / 4);
+    if constexpr (U == 3) {   // slots 3 pos .. 3 pos + 2 may straddle a column tile
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int col0 = (t.voff_slot >> 4) & 15;   // the first slot's column
+            const int wrap = col0 + u > 15 ? ROWS_CTB - 256 : 0;
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            f32x2_ d;
+            d.x = pipe_opaque_f(v[u]);
+            d.y = t.tg;
+            if (stager) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" : : "v"(t.voff_slot + 16 * u + wrap), "v"(d), "s"(sb) : "memory");
+        }
+    } else {   // U = 1, 2, 4: the lane's slots are columns of one tile, 16 bytes apart
+        rows_granule<0>(sb, t.voff_slot, v[0], t.tg, stager);
+        if constexpr (U >= 2) rows_granule<16>(sb, t.voff_slot, v[U >= 2 ? 1 : 0], t.tg, stager);
+        if constexpr (U == 4) {
+            rows_granule<32>(sb, t.voff_slot, v[U == 4 ? 2 : 0], t.tg, stager);
+            rows_granule<48>(sb, t.voff_slot, v[U == 4 ? 3 : 0], t.tg, stager);
+        }
+    }
+}
+
 // ---- reverse mode through one coupling block (block_backward_grid's arithmetic on one row) ----
 // in: ytrans = the block's OUTPUT on the transformed side, gtrans / gcond = d loss / d (block outputs);
 // out: ytrans = the block's input, gtrans = d loss / d (that input), gcond += the two nets' contributions
 // STAGE_FWD = false: the activations and the conditioning input were staged by the forward pass (rows_stage_forward, nnest_train_pipe.h)
-template <int U, bool STAGE_FWD = true>
+// TAGGED: the staged values as {value, tag} granules (rows_stage_t) with tag `tg`
+template <int U, bool STAGE_FWD = true, bool TAGGED = false>
 static __device__ __forceinline__ void rows_block_backward(const Solo4Lds &wb_, unsigned sel, bool h1, bool translate_half, int pos, int D, int ct,
                                                            bool row_ok, float gld, const float (&cond)[U], float (&ytrans)[U], float (&gcond)[U],
-                                                           float (&gtrans)[U], const RowsKeep<U> &kp, float *stg_net, int row, bool stager) {
+                                                           float (&gtrans)[U], const RowsKeep<U> &kp, float *stg_net, int row, bool stager, const RowsTagged &tgd = RowsTagged{}) {
     typedef StageMap<U, 1, 1> SM;
     float go[U];
 #pragma unroll
@@ -226,7 +290,8 @@ static __device__ __forceinline__ void rows_block_backward(const Solo4Lds &wb_, 
         gtrans[U - 1] = gv * __expf(kp.ls[U / 2]);
         go[U - 1] = translate_half ? g_t : g_ls;
     }
-    rows_stage_slots<U>(stg_net, SM::gout(0), row, pos, go, stager);
+    if constexpr (TAGGED) rows_stage_slots_t<U>(tgd, SM::gout(0), go, stager);
+    else rows_stage_slots<U>(stg_net, SM::gout(0), row, pos, go, stager);
     // g_h2 = Wo^T g_out   (the transposed image's first U field groups)
     float wa[8], wb[8], a0, a1;
     if constexpr (U >= 2) {
@@ -248,13 +313,15 @@ static __device__ __forceinline__ void rows_block_backward(const Solo4Lds &wb_, 
     float w2[8], w3a[8], w3b[8];
     wb_.load8(w2, 32);   // (requested ahead of the activation gradient, as in the forward pass)
     const float g_a2 = rows_act_grad(solo_join_rot(a0 + a1), kp.h2, sel);   // (h = 1 rows: rotated by 8, like kp.h2)
-    rows_stage(stg_net, SM::gpre(1, 0), row, pos, g_a2, stager);
+    if constexpr (TAGGED) rows_stage_t(tgd, SM::gpre(1, 0), g_a2, stager);
+    else rows_stage(stg_net, SM::gpre(1, 0), row, pos, g_a2, stager);
     if constexpr (STAGE_FWD) rows_stage(stg_net, SM::act(1, 0), row, pos, kp.h2, stager);
     // g_h1 = W1^T g_a2
     if constexpr (U >= 2) { wb_.load8(w3a, 40); wb_.load8(w3b, 48); }
     solo_chain_1(a0, a1, 0.f, g_a2, w2);
     const float g_a1 = rows_act_grad(solo_join_rot(a0 + a1), kp.h1, sel);
-    rows_stage(stg_net, SM::gpre(0, 0), row, pos, g_a1, stager);
+    if constexpr (TAGGED) rows_stage_t(tgd, SM::gpre(0, 0), g_a1, stager);
+    else rows_stage(stg_net, SM::gpre(0, 0), row, pos, g_a1, stager);
     if constexpr (STAGE_FWD) rows_stage(stg_net, SM::act(0, 0), row, pos, kp.h1, stager);
     if constexpr (STAGE_FWD) {
         float cm[U];

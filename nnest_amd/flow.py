@@ -431,7 +431,7 @@ class HipNVP(_HipFlow):
                                                  _lib.ptr(result), _lib.current_stream(dev)))
         r = result.cpu()
         if int(r[5]) == 2:
-            raise _lib.NnestHipError('nnest_nvp_train: a grid barrier of the multi-CU training kernel ran out (results invalid)')
+            raise _lib.NnestHipError('nnest_nvp_train: a grid barrier of the multi-CU training kernel ran out (results invalid; error word 0x%x)' % (int(r[4]) & 0xffffffff))
         fl = r[2:4].view(torch.float32)
         return dict(losses=losses, epochs_run=int(r[0]), best_epoch=int(r[1]), best_validation_loss=float(fl[0]),
                     last_train_loss=float(fl[1]), counter=int(r[4]), stopped=bool(int(r[5])), result=result)
