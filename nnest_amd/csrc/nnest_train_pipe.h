@@ -741,10 +741,12 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel_pipe(TrainArgs a) 
     else pipe_body<U, 1>();
 }
 
-// NNEST_TRAIN_FORM=rows in the environment keeps train_kernel_rows, =grid train_kernel_grid (diagnostics)
+// The pipelined form is OPT-IN (NNEST_TRAIN_FORM=pipe in the environment): measured at 12.1-12.7 us per minibatch at config 2 against
+// train_kernel_rows' 11.4 (profiles/r05/k5_pipe_timeline.txt; DESIGN.md 3.2 has the timeline and why pipelining per block does not
+// shorten a chain of memory-side round trips).  Kept, tested (tests/test_gpu_train.py runs both forms), not the default.
 static bool pipe_eligible(const TrainArgs &a) {
-    static const bool off = [] { const char *e = getenv("NNEST_TRAIN_FORM"); return e && (!strcmp(e, "rows") || !strcmp(e, "grid")); }();
-    return !off && rows_eligible(a);
+    static const bool on = [] { const char *e = getenv("NNEST_TRAIN_FORM"); return e && !strcmp(e, "pipe"); }();
+    return on && rows_eligible(a);
 }
 
 template <int U>
