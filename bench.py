@@ -17,6 +17,12 @@ the ranks (--config 4: Himmelblau x_dim=32, 4000 live points; --config 5: Rosenb
 the product, the kernel form of the whole batch is pinned on the shards only under a fixed step (where it makes the
 sharded batch the unsharded one bit for bit) -- under the step rule every rank runs the fastest form of its shard.
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: bench.py LAUNCHES the N ranks itself (one fresh child process per
+GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before anything in the parent touches a GPU; the reference's own
+multi-process entry is `mpirun` over nnest/sampler.py:165-177), relays rank 0's one JSON line and exits non-zero if a rank
+failed.  Under an outer `torchrun` (WORLD_SIZE set) it is one of the ranks, as before.  The line carries n_gpus == rccl_ranks == N,
+`collective_backend`, the weak value and `strong_config2`.
+
   python bench.py --gpus 1 --steps 20 --warmup 3
 """
 import argparse
@@ -217,6 +223,46 @@ def logz_report(dev, live_run):
     return out
 
 
+def launch_ranks(n, argv):
+    """`--gpus n` without an outer launcher: n fresh child processes, one per GPU (never an exec of a process that has touched
+    a GPU: the parent has not), rank 0's stdout relayed, non-zero exit if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:   # a free rendezvous port on the loopback
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', str(port)), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit('bench.py --gpus %d: rank(s) failed: %s' % (n, ', '.join('%d (exit %d)' % rc for rc in bad)))
+
+
+def stub_rank(args, rank, world):
+    """NNEST_BENCH_STUB=1: the launcher / rendezvous / one-line plumbing on CPUs (gloo), no kernel: what the `not gpu` test of
+    `--gpus N` runs.  The line says so (`stub`: true) and carries no measurement."""
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('gloo')
+    dist.barrier()
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)   # the max-over-ranks reduction of the timed region
+    if rank == 0:
+        print(json.dumps({'metric': METRIC % CONFIGS[args.config][1], 'value': None, 'unit': 'evals/s', 'n_gpus': world,
+                          'rccl_ranks': dist.get_world_size(), 'collective_backend': dist.get_backend(), 'steps': args.steps,
+                          'warmup': args.warmup, 'stub': True, 'max_over_ranks': float(t.item())}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -237,9 +283,15 @@ def main():
     if args.bare:
         args.no_cpu_baseline = args.no_saturation = args.no_spline = args.no_logz = True
 
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or os.environ.get('NNEST_BENCH_LAUNCHER') == '1'):
+        return launch_ranks(args.gpus, sys.argv[1:])   # (NNEST_BENCH_LAUNCHER=1: also for one rank -- the launcher path under test)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (one rank per GPU)' % (args.gpus, world))
+    if os.environ.get('NNEST_BENCH_STUB') == '1':
+        return stub_rank(args, rank, world)
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit('bench.py needs an MI355X (no GPU visible); there is no CPU fallback')
@@ -406,9 +458,10 @@ def main():
                                  % (tiles, cu)},
             'device': info['name'],
         }
-        if dist is not None:
-            out['rccl_ranks'] = dist.get_world_size()
-            out['collective_backend'] = dist.get_backend()
+        out['rccl_ranks'] = dist.get_world_size() if dist is not None else 1
+        out['collective_backend'] = dist.get_backend() if dist is not None else None
+        out['step_rule_scope'] = ('whole batch' if world == 1 else
+                                  'per rank: under sharding every rank applies the batch-wide rule to ITS walkers (DESIGN.md 6)')
         if strong is not None:
             out['strong_config2'] = strong
         if world == 1 and dist is None and not args.bare:

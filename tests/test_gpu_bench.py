@@ -82,3 +82,18 @@ def test_smoke_entry_point():
     out = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.smoke()'], cwd=ROOT, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
+
+
+def test_bench_gpus_1_through_the_rank_launcher():
+    """the path `--gpus N` takes for N > 1 (bench.py starts its own ranks, relays rank 0's line), with one rank: what a one-GPU box
+    can run of it.  The line says how many ranks the collective saw and which backend carried it."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(NNEST_BENCH_LAUNCHER='1', NNEST_BENCH_FORCE_DIST='1')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--bare'],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['rccl_ranks'] == 1 and d['collective_backend'] == 'nccl' and d['value'] > 0
+    assert 'strong_config2' in d and 'step_rule_scope' in d
