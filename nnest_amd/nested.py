@@ -145,10 +145,49 @@ class NestedSampler(Sampler):
             seed = np.array([self._next_seed() & 0x7FFFFFFF if self.mpi_rank == 0 else 0], dtype=np.int64)
             seed = int(self._broadcast(seed)[0])
             self.trainer.train(active_u, max_iters=train_iters, jitter=jitter, rng_seed=seed)
+            self._guard_replicas()
             return
         if self.mpi_rank == 0:
             self.trainer.train(active_u, max_iters=train_iters, jitter=jitter)
         self._broadcast_weights()
+
+    def _replica_state(self):
+        """what a replica is: the packed weights and, where the flow exposes them, Adam's moments and step count"""
+        netG = self.trainer.netG
+        parts = [np.ascontiguousarray(netG.store_packed(), dtype=np.float32)]
+        if hasattr(netG, 'adam_moments') and hasattr(netG, 'set_adam'):
+            m, v = netG.adam_moments()
+            parts += [np.ascontiguousarray(m, dtype=np.float32), np.ascontiguousarray(v, dtype=np.float32),
+                      np.array([netG.adam_step_count()], dtype=np.int64)]
+        return parts
+
+    def _guard_replicas(self):
+        """The replicas of a replicated retrain are identical because the training kernels are bitwise reproducible -- which
+        this checks instead of trusting: a 64-bit checksum of the replica's state (weights + Adam) is gathered over the ranks
+        (8 bytes each) after every retrain; on a mismatch the run says so loudly, takes rank 0's weights and Adam state (C3's
+        path) and goes on.  A silent divergence would desynchronise the replicated evidence state (nested.py:311-314 trains on
+        rank 0 only and never has the question)."""
+        import zlib
+        parts = self._replica_state()
+        h = 0
+        for a in parts:
+            h = zlib.crc32(a.tobytes(), h)
+        h2 = zlib.adler32(b''.join(a.tobytes() for a in parts))
+        mine = np.array([(h << 32) | h2], dtype=np.uint64).view(np.int64)
+        every = self._all_gather_rows(mine)
+        self.replica_checks = getattr(self, 'replica_checks', 0) + 1
+        if np.all(every == every[0]):
+            return True
+        self.replica_repairs = getattr(self, 'replica_repairs', 0) + 1
+        self.logger.error('REPLICA DIVERGENCE after retrain %d: checksums %s -- taking rank 0\'s weights and Adam state' %
+                          (self.replica_checks, ' '.join('%016x' % int(x) for x in every.view(np.uint64))))
+        self._broadcast_weights()
+        netG = self.trainer.netG
+        if len(parts) == 4:
+            m, v, step = self._broadcast(parts[1]), self._broadcast(parts[2]), int(self._broadcast(parts[3])[0])
+            if self.mpi_rank != 0:
+                netG.set_adam(m, v, step)
+        return False
 
     def _broadcast_weights(self):
         """C3: rank 0's packed weights (<= 86 KB for the NVP shapes) to every rank"""

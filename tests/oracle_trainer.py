@@ -75,7 +75,14 @@ class OracleTrainer(object):
         z = torch.randn(n, self.x_dim)
         return z.numpy() if to_numpy else z
 
-    def train(self, samples, max_iters=10000, jitter=0.0, validation_fraction=0.1, patience=50, **kw):
+    def train(self, samples, max_iters=10000, jitter=0.0, validation_fraction=0.1, patience=50, rng_seed=None, **kw):
+        if rng_seed is not None:   # a replicated retrain (nnest_amd/nested.py::_train): every rank draws the same split / permutations / noise
+            saved = np.random.get_state()
+            np.random.seed(int(rng_seed) & 0x7FFFFFFF)
+            try:
+                return self.train(samples, max_iters=max_iters, jitter=jitter, validation_fraction=validation_fraction, patience=patience, **kw)
+            finally:
+                np.random.set_state(saved)
         samples = np.asarray(samples)
         N = samples.shape[0]
         if jitter < 0:

@@ -196,3 +196,47 @@ def test_bench_gpus_n_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], cwd=root,
                          env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and '--gpus 2 but WORLD_SIZE=1' in bad.stderr
+
+
+def _guard_worker(rank, world, port, tmp, out):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from nnest_amd.nested import NestedSampler
+        from nnest_amd.likelihoods import Rosenbrock
+        from tests.oracle_trainer import OracleTrainer
+        np.random.seed(5)
+        torch.manual_seed(5)
+        tr = OracleTrainer(2, seed=7)
+        tr.replicable = True            # every rank trains its own replica from one broadcast seed (the product trainer's mode)
+        plain = tr.train
+        hits = []
+
+        def train(*a, **kw):            # rank 1's replica goes wrong once, silently: the second retrain leaves it perturbed
+            plain(*a, **kw)
+            if rank == 1 and tr.num_trains == 2 and not hits:
+                tr.nvp.w[3] += 1e-3
+                hits.append(tr.num_trains)
+        tr.train = train
+        s = NestedSampler(2, Rosenbrock(2), transform=lambda x: 5 * x, log_dir=tmp, num_live_points=200, trainer=tr, log_level=40)
+        s.run(train_iters=50, mcmc_num_chains=8, mcmc_dynamic_step_size=False, max_iters=700)
+        out.put((rank, getattr(s, 'replica_checks', 0), getattr(s, 'replica_repairs', 0), tr.num_trains,
+                 float(np.sum(np.abs(tr.netG.store_packed()).astype(np.float64))), float(s.logz), len(hits)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_replica_guard_finds_and_repairs_a_diverged_replica(tmp_path):
+    """Replicated retraining trusts the training kernels' bitwise reproducibility; the guard checks it (a 64-bit checksum of
+    weights + Adam state gathered after every retrain) and, when a replica has gone its own way, says so, takes rank 0's state
+    and goes on.  Here rank 1's weights are perturbed behind the second retrain: exactly one repair on BOTH ranks (the decision is
+    collective), every retrain checked, the ranks end as replicas (weights and evidence)."""
+    res = _spawn(_guard_worker, 2, (str(tmp_path),))
+    (r0, c0, f0, n0, w0, z0, h0), (r1, c1, f1, n1, w1, z1, h1) = res
+    assert (r0, r1) == (0, 1) and h1 == 1 and h0 == 0
+    assert c0 == c1 == n0 == n1 and n0 >= 3                    # one check per retrain, on every rank
+    assert f0 == f1 == 1                                       # found once, by both
+    assert w0 == w1 and z0 == z1                               # replicas again
