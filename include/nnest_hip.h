@@ -159,7 +159,11 @@ int nnest_loglike(const nnest_like_t *like, const float *x_unit_dev, double *log
  *   logl_dev [C] f64   in: init_loglikes; out: final log-likelihoods
  *   loglstar           hard constraint logl > loglstar (sampler.py:361)
  *   step_size          initial proposal scale (sampler.py:255)
- *   noise_dz_dev       NULL -> in-kernel Philox4x32-10 + Box-Muller keyed by (seed, walker_offset + walker, step, dim);
+ *   noise_dz_dev       NULL -> in-kernel noise: every (walker, lane group) and every walker's uniform draw runs a
+ *                      xoshiro128++ stream (add / xor / rotate: full-rate VALU) SEEDED by one Philox4x32-10 block keyed by
+ *                      (seed; walker_offset + walker, lane group, stream), the normals by Box-Muller -- so a walker's draws
+ *                      depend on (seed, its global index) only and a sharded batch draws what the unsharded one draws
+ *                      (csrc/flow_tile.h "proposal stream of the persistent MH kernel"; nnest_mh_fill_noise replays them);
  *                      else recorded noise [steps, C, D] (torch.randn_like(z), sampler.py:310)
  *   noise_u_dev        recorded uniforms [steps, C] (torch.rand, sampler.py:334); required iff noise_dz_dev
  *   hist_x_dev         optional [C, steps+1, D] history of x (reference return layout, sampler.py:455);
@@ -198,7 +202,9 @@ int nnest_mh_fill_noise(float *dz_dev, float *u_dev, int steps, int C, int D, ui
  * (trainer.py:405-418), early stopping with `patience` and best-model restore (trainer.py:205-209, :241).
  *   xtrain_dev [n_train,D], xvalid_dev [n_valid,D] float32
  *   perm_dev [max_epochs, n_train] int32 (DataLoader shuffle order per epoch, trainer.py:185)
- *   noise_dev  NULL -> in-kernel Philox normals keyed by (seed, epoch, row, dim); else [max_epochs, n_train, D]
+ *   noise_dev  NULL -> in-kernel normals, one Philox4x32-10 block + Box-Muller per (seed; position of the row in the epoch's
+ *              order, epoch_offset + epoch, group of four dims) -- no stream state: any kernel form draws the same jitter;
+ *              else [max_epochs, n_train, D]
  *              in perm order (torch.randn_like(data), trainer.py:392)
  *   losses_dev optional float32 [max_epochs, 2]: (train, validation) loss per epoch, normalised as the
  *              reference logs them (/len(dataset), trainer.py:403, :418)
