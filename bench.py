@@ -491,7 +491,10 @@ def main():
                         torch.cuda.synchronize(dev)
                         tms.append(a.elapsed_time(b))
                     ms = float(np.median(tms[1:]))
-                    out[key] = {'kernel_ms': ms, 'evals_per_s': C * S / (ms * 1e-3)}
+                    out[key] = {'kernel_ms': ms, 'evals_per_s': C * S / (ms * 1e-3), 'kernel': 'mh_kernel_%s' % nvp.mh_form_for(C, **kw),
+                                'frac': C * S * fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                'what': ('no step-size adaptation' if key == 'fixed_step' else
+                                         'the reference\'s rule itself (nnest/sampler.py:422-431: the whole batch\'s vote on step s sets the scale of step s + 1)')}
         if not args.no_saturation and world == 1 and dist is None:
             # the same step at a population that fills the chip (not the headline: BASELINE's config is 1000)
             Cs = 16 * 4 * cu * 8  # 8 walker tiles per SIMD

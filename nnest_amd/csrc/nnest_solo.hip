@@ -157,6 +157,7 @@ static constexpr int SOLO_ETAB = 1024;   // steps + 2 <= SOLO_ETAB: exp(1 / (1 +
 template <int U, int WPG> constexpr bool solo_lds_weights() { return U >= 3 || WPG > 4; }
 template <int U, int WPG> constexpr int solo_reg_blocks() { return !solo_lds_weights<U, WPG>() ? 3 : (WPG == 4 ? 1 : (U <= 2 && WPG == 8 ? 1 : 0)); }
 
+enum { MH_SOLO_LAG_INTERNAL = 8 };   // the relay's schedule under lag 0 (no lagged step exists then: only its bookkeeping uses it)
 template <int U, bool DBG, int LK, int WPG>
 __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];  // the packed weights
@@ -176,17 +177,21 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
     const bool recorded = DBG && a.noise_dz;
     const bool dynamic = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;  // the per-16-walker rule belongs to the 16-walker forms
     const bool use_tab = S + 2 <= SOLO_ETAB;
-    const int lag = mh_flag_lag(a.flags);                          // >= 3 (solo_form_eligible): the rule is always relayed
-    // the first `warm` steps apply the rule exactly (lag 0: a grid-wide wait per step) -- where its gain 1 / (1 + n) is large and
-    // the scale still far from where it settles -- the rest `lag` steps behind (mh_common.h); at most S - 1
-    const int warm = dynamic ? min(mh_flag_warm(a.flags), S - 1) : 0;
+    // lag 0 = the reference's rule itself (sampler.py:422-431: the vote of step s sets the scale of step s + 1): EVERY step is an
+    // exact step -- the two-candidate evaluation below, which hides the vote's round trip -- and the last step's vote is applied
+    // too, for scale_out (round 5; round 4 sent lag 0 to the quad form, which waits out a grid-wide round trip per step).
+    const bool exact_all = dynamic && mh_flag_lag(a.flags) == 0;
+    const int lag = exact_all ? MH_SOLO_LAG_INTERNAL : mh_flag_lag(a.flags);   // otherwise >= 3 (solo_form_eligible): the rule is always relayed
+    // the first `warm` steps apply the rule exactly (a grid-wide wait per step, hidden behind two evaluations) -- where its gain
+    // 1 / (1 + n) is large and the scale still far from where it settles -- the rest `lag` steps behind (mh_common.h); at most S - 1
+    const int warm = dynamic ? min(exact_all ? S : mh_flag_warm(a.flags), S - 1) : 0;
     constexpr bool LDSW = solo_lds_weights<U, WPG>();
     constexpr int RB = solo_reg_blocks<U, WPG>();
     const int ntiles = (C + WPG - 1) / WPG;
     if (tile >= ntiles) {
         // batch-wide step rule (mh_common.h): the one workgroup behind the tiles sums every step's counters as soon as they
         // are complete and publishes the total; its other waves leave at once
-        if (dynamic && wave == 0) mh_sync_publisher(a.sync, S, max(S - lag, warm), ntiles, C, lane, a.sync_err);
+        if (dynamic && wave == 0) mh_sync_publisher(a.sync, S, exact_all ? S : max(S - lag, warm), ntiles, C, lane, a.sync_err);
         return;
     }
     {
@@ -391,6 +396,20 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
         }
 #undef SOLO_RELAY_ITERATION
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa), "+v"(qb) : : "memory");   // no request outlives its registers
+        if (exact_all) {   // the vote of the LAST step: no step follows it, but the reference updates the scale all the same (scale_out)
+            solo_barrier();               // the net waves have decided step S
+            if (lane == 0) {
+                const int *ac = acc_lds[S & 1];
+                int acs = 0;
+#pragma unroll
+                for (int w_ = 0; w_ < WPG; ++w_) acs += ac[w_];
+                mh_sync_post(a.sync, S, tile, acs);
+            }
+            const bool up = mh_window_vote(a.sync, S, S, tile, 0ull, a.sync_err);
+            if (up) accept += 1; else reject += 1;
+            if (accept > reject) scale *= use_tab ? etab[accept] : exp(1.0 / (1 + accept));
+            if (accept < reject) scale /= use_tab ? etab[reject] : exp(1.0 / (1 + reject));
+        }
 #ifndef NNEST_STAMP
         // scale_out has one entry per 16 walkers (nnest_mh_num_groups): the tile that holds a group's first walker reports
         if (a.scale_out && lane == 0) {
@@ -590,6 +609,7 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
         a_prop += st1 - st0; a_inv += st2 - st1; a_post += st3 - st2; a_tot += st3 - st0;
 #endif
     }
+    if (exact_all) solo_barrier();   // (the relay wave reads the last step's accepts behind it)
 #ifdef NNEST_STAMP
     if (a.scale_out && lane == 0 && tile == 0) {
         float *o = a.scale_out;
@@ -627,7 +647,7 @@ bool solo_form_eligible(const MhArgs &a, int num_cu) {
     // 132 weight registers at NT = 2; NT = 3, 4 (x_dim 65..128) and more than one walker per SIMD keep the weights in LDS
     if (s.H != 16 || s.B != 3 || s.L != 1 || s.scale_mode != 0 || s.NT < 1 || s.NT > 4) return false;
     if (a.flags & NNEST_MH_DYNAMIC_STEP) return false;  // the per-16-walker rule belongs to the 16-walker forms
-    if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && mh_flag_lag(a.flags) < 3) return false;  // the relay posts step k - 2 in iteration k and asks for step k - lag before that: lag < 3 runs the quad form
+    if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && (mh_flag_lag(a.flags) == 1 || mh_flag_lag(a.flags) == 2)) return false;  // the relay posts step k - 2 in iteration k and asks for step k - lag before that: lag 1, 2 run the quad form (lag 0: every step exact)
     const int wpg = solo_walkers_per_group(a.C, num_cu);
     if (wpg != 4 && (a.noise_dz || a.hist_x || a.hist_logl)) return false;   // history / recorded noise: the one-walker-per-SIMD build only
     return wpg != 0;

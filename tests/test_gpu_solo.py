@@ -41,11 +41,12 @@ def trained(hip):
 
 def test_solo_is_what_config_2_runs(hip):
     """the library's own answer (nnest_mh_form_for): 1000 walkers at x_dim 50 run the solo form under a fixed step and under
-    the batch-wide rule at the default lag; lag 0 / 1 (no time for the relay), the per-group rule and
+    the batch-wide rule at the default lag and at lag 0 (every step exact); lag 1 / 2 (no time for the relay), the per-group rule and
     populations beyond four walkers per CU go to the other forms"""
     nvp, _, _ = trained(hip)
     assert nvp.mh_form_for(1000) == 'solo' and nvp.mh_form_for(1000, dynamic='batch') == 'solo'
-    assert nvp.mh_form_for(1000, dynamic='batch', lag=0) == 'quad' and nvp.mh_form_for(1000, dynamic='batch', lag=2) == 'quad' and nvp.mh_form_for(1000, dynamic='group') in ('team', 'reg', 'image')
+    # round 5: lag 0 -- the reference's rule itself -- is a solo schedule too (every step an exact step); lag 1 / 2 stay with the quad form
+    assert nvp.mh_form_for(1000, dynamic='batch', lag=0) == 'solo' and nvp.mh_form_for(1000, dynamic='batch', lag=2) == 'quad' and nvp.mh_form_for(1000, dynamic='group') in ('team', 'reg', 'image')
     # round 4: two / three walkers per SIMD (8 / 12 net waves per workgroup, weights in LDS) carry the form to 3060 walkers
     assert nvp.mh_form_for(2000) == 'solo' and nvp.mh_form_for(3000) == 'solo' and nvp.mh_form_for(3061) != 'solo'
     assert nvp.mh_form_for(4000) == 'team' and nvp.mh_form_for(100000) == 'image'
@@ -54,7 +55,7 @@ def test_solo_is_what_config_2_runs(hip):
     big = hip.HipNVP(100, 16, 3, 1, seed=0)
     assert big.mh_form_for(1000) == 'solo' and big.mh_form_for(8000) == 'image' and big.mh_form_for(8000, form='reg') is None   # x_dim 97..128: weights in LDS
     mid = hip.HipNVP(80, 16, 3, 1, seed=0)
-    assert mid.mh_form_for(1000) == 'solo' and mid.mh_form_for(1000, dynamic='batch', lag=0) == 'quad'   # x_dim 65..96: three slots per class
+    assert mid.mh_form_for(1000) == 'solo' and mid.mh_form_for(1000, dynamic='batch', lag=0) == 'solo' and mid.mh_form_for(1000, dynamic='batch', lag=1) == 'quad'   # x_dim 65..96: three slots per class
     wide = hip.HipNVP(20, 32, 3, 1, seed=0)
     assert wide.mh_form_for(500) == 'image' and wide.mh_form_for(500, form='quad') is None
 
@@ -136,10 +137,11 @@ def test_solo_shapes_and_likelihoods_vs_oracle(hip, D, like, scale):
 
 
 @pytest.mark.parametrize('C,lag,warm', [(1000, 3, 0), (1000, 4, 0), (333, 5, 0), (1017, 8, 0), (64, 15, 0), (1000, 8, 16), (333, 3, 1),
-                                        (1017, 8, 39), (500, 5, 200), (64, 15, 7)])
+                                        (1017, 8, 39), (500, 5, 200), (64, 15, 7), (1000, 0, 0), (333, 0, 0), (5, 0, 0)])
 def test_solo_batch_wide_step_rule_vs_oracle(hip, C, lag, warm):
     """NNEST_MH_DYNAMIC_BATCH relayed by the noise wave: the accept count is taken over the WHOLE launch, `lag` steps behind --
-    after `warm` steps under the exact rule (NNEST_MH_WARM; the product's default is 16 in front of lag 8).
+    after `warm` steps under the exact rule (NNEST_MH_WARM; the product's default is 16 in front of lag 8).  lag 0 (round 5) is the
+    reference's rule itself, sampler.py:422-431: every step exact, the last step's vote in scale_out.
     The oracle runs the whole batch with the same schedule: same scale sequence, same chains."""
     nvp, o, g = trained(hip)
     rng = np.random.RandomState(C + lag)
@@ -256,6 +258,27 @@ def test_solo_golden_trace_recorded_noise(hip):
     assert int(res['n_call'].sum()) == int(g['ncall']) and int(res['n_accept'].sum()) == int(g['total_accepted'])
     assert rel(cpu(res['hist_x']), g['samples']) < 3e-5 and rel(cpu(res['hist_logl']), g['loglikes']) < 3e-5
     assert rel(cpu(z), g['latent'][:, -1]) < 3e-5
+
+
+def test_solo_golden_dynamic_trace_recorded_noise_under_the_exact_rule(hip):
+    """the reference's recorded trace WITH its step-size adaptation on (tests/golden/mcmc_rosen_d50_dyn.npz: torch's noise, every
+    state, the final scale) through the solo form at lag 0 -- the rule of sampler.py:422-431 applied over the whole batch, every
+    step: each decision, each state, the scale the reference ends with (round 4 could only run this trace on the quad form)."""
+    g = np.load(os.path.join(G, 'mcmc_rosen_d50_dyn.npz'))
+    assert bool(g['dynamic'])
+    nvp = hip.HipNVP(50, 16, 3, 1)
+    nvp.load_packed(g['w'])
+    S, C, _ = g['dz'].shape
+    assert nvp.mh_form_for(C, dynamic='batch', lag=0) == 'solo'
+    z, _ = nvp.forward(g['init'])
+    logl = torch.from_numpy(g['init_logl']).cuda().contiguous()
+    res = nvp.mh_steps(0, float(g['scale']), z, logl, float(g['loglstar']), float(g['step']), S, dynamic='batch', lag=0,
+                       noise=(torch.from_numpy(g['dz']), torch.from_numpy(g['u'])), history=True, form='solo')
+    hip.HipNVP.check_sync(res)
+    assert int(res['n_call'].sum()) == int(g['ncall']) and int(res['n_accept'].sum()) == int(g['total_accepted'])
+    assert rel(cpu(res['hist_x']), g['samples']) < 3e-5 and rel(cpu(res['hist_logl']), g['loglikes']) < 3e-5
+    assert rel(cpu(z), g['latent'][:, -1]) < 3e-5
+    assert abs(float(res['scale'][0]) - float(g['scale_out'])) < 1e-6 * max(1.0, float(g['scale_out']))
 
 
 @pytest.mark.parametrize('C', [1000, 2000, 3000])
