@@ -347,7 +347,7 @@ def main():
         res = nvp.mh_steps(LIKE_ID[like], scale, zs[i], ls[i], loglstar, step_size, S, dynamic=dynamic, lag=lag, seed=42 + i,
                            walker_offset=rank * C, form=form)
         if dist is not None:   # C2: what the nested-sampling loop consumes of a batch, gathered on every rank (device memory)
-            moved = res['n_accept'] > 0   # (as nnest_amd/sampler.py::_mcmc_endpoints_fused)
+            moved = res['moved']   # (as nnest_amd/sampler.py::_mcmc_endpoints_fused)
             ends = torch.cat([res['x'].double(), ls[i][:, None], moved[:, None].double()], dim=1)
             dist.all_gather_into_tensor(gathered, ends)
         return res
@@ -399,7 +399,7 @@ def main():
         def launch2(i):
             r = nvp.mh_steps(LIKE_ID[like], scale, zs2[i], ls2[i], star2, step_size, S, dynamic=dynamic, lag=lag, seed=142 + i,
                              walker_offset=rank * Cr)
-            dist.all_gather_into_tensor(g2, torch.cat([r['x'].double(), ls2[i][:, None], (r['n_accept'] > 0)[:, None].double()], dim=1))
+            dist.all_gather_into_tensor(g2, torch.cat([r['x'].double(), ls2[i][:, None], r['moved'][:, None].double()], dim=1))
             return r
         for i in range(args.warmup):
             launch2(i)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NNEST_HIP_ABI_VERSION 14
+#define NNEST_HIP_ABI_VERSION 15
 
 enum {
     NNEST_OK = 0,
@@ -84,7 +84,8 @@ enum {
 enum { NNEST_MH_FORM_AUTO = 0, NNEST_MH_FORM_IMAGE = 1, NNEST_MH_FORM_REG = 2, NNEST_MH_FORM_TEAM = 3, NNEST_MH_FORM_QUAD = 4,
        NNEST_MH_FORM_QUAD1 = 5, /* the quad tile with both nets on one wave (same bits as QUAD; A/B diagnostic) */
        NNEST_MH_FORM_SOLO = 6   /* one walker per wave, layers as v_fmac_f32 + DPP row rotations (nnest_solo.hip): <= 4 walkers per CU,
-                                 * x_dim <= 128 (beyond 64 with the weights in LDS), fixed step or the batch-wide rule at lag >= 3 */ };
+                                 * x_dim <= 128 (beyond 64 with the weights in LDS), fixed step or the batch-wide rule at lag >= 3 or at lag 0
+                                 * (round 5: the reference's rule itself, every step an exact step) */ };
 #define NNEST_MH_FORM(f) (((f) & 15) << 16)
 
 typedef struct nnest_nvp nnest_nvp_t; /* opaque: RealNVP coupling stack + Adam state on one device */
@@ -168,7 +169,11 @@ int nnest_loglike(const nnest_like_t *like, const float *x_unit_dev, double *log
  *   noise_u_dev        recorded uniforms [steps, C] (torch.rand, sampler.py:334); required iff noise_dz_dev
  *   hist_x_dev         optional [C, steps+1, D] history of x (reference return layout, sampler.py:455);
  *   hist_logl_dev      optional [C, steps+1] f64
- *   n_accept_dev [C]   out int32: accepted moves per walker  (sampler.py:418-420)
+ *   n_accept_dev [C]   out int32: accepted moves per walker  (sampler.py:418-420) in bits 0..29; bit 30 (NNEST_MH_ALL_MOVED) is set
+ *                      when EVERY coordinate of the chain's last x differs from its first x = f^-1(z_0) -- the reference's test
+ *                      of a chain before its end may replace a live point (nested.py:432: np.all(samples[:,0] != samples[:,-1]));
+ *                      evaluated at the end of the launch against the first x, which the kernel parks in x_dev meanwhile
+ *                      (x_dev NULL: the bit says "accepted at least once")
  *   n_call_dev [C]     out int32: likelihood calls per walker (rows that passed the prior/Jacobian test,
  *                      sampler.py:358-363)
  *   scale_out_dev      optional float32 [ngroups]: final scale per adaptation group (sampler.py:422-431)

@@ -522,6 +522,24 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ rows, long r
     }
 }
 
+// every coordinate d < D of the tile's walkers differs between a and b (the walker's dims are spread over its four lane groups): the
+// same answer in the four lanes of a walker
+template <int NT>
+__device__ __forceinline__ int mh_all_coordinates_differ(const f32x4 (&a)[2][NT], const f32x4 (&b)[2][NT], int D, int lane) {
+    const int g = lane >> 4, w = lane & 15;
+    bool all = true;
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int d0 = 32 * tau + 8 * g + c;   // load_tile: component r of class c is dim 32 tau + 8 g + 2 r + c
+            all = all && (d0 >= D || a[c][tau].x != b[c][tau].x) && (d0 + 2 >= D || a[c][tau].y != b[c][tau].y) &&
+                  (d0 + 4 >= D || a[c][tau].z != b[c][tau].z) && (d0 + 6 >= D || a[c][tau].w != b[c][tau].w);
+        }
+    const unsigned long long m = __ballot(all);
+    return (int)((m >> w) & (m >> (w + 16)) & (m >> (w + 32)) & (m >> (w + 48)) & 1ull);
+}
+
 template <int NT>
 __device__ __forceinline__ void store_tile(float *__restrict__ rows, long row, bool row_ok, int D, int lane,
                                            const f32x4 (&xs)[2][NT]) {

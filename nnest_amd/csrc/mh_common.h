@@ -16,6 +16,9 @@ namespace nnest {
 // flags word of nnest_mh_constrained_steps: low bits NNEST_MH_*, bits 8..11 the lag of the batch-wide step rule,
 // bits 16..19 the kernel form (0 = chosen by population)
 enum { MH_FORM_AUTO = 0, MH_FORM_IMAGE = 1, MH_FORM_REG = 2, MH_FORM_TEAM = 3, MH_FORM_QUAD = 4, MH_FORM_QUAD1 = 5, MH_FORM_SOLO = 6 };
+// n_accept_dev words: the accept count, and NNEST_MH_ALL_MOVED set when every coordinate of the chain's last x differs from its
+// first x = f^-1(z_0) (what nnest/nested.py:432 asks of a chain before its end may replace a live point)
+enum { NNEST_MH_ALL_MOVED = 1 << 30 };
 __host__ __device__ inline int mh_flag_lag(int flags) { return (flags >> 8) & 15; }
 __host__ __device__ inline int mh_flag_form(int flags) { return (flags >> 16) & 15; }
 __host__ __device__ inline int mh_flag_warm(int flags) { return (flags >> 20) & 255; }   // NNEST_MH_WARM

@@ -189,6 +189,9 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
     double scale = (double)a.step_size;  // python float in the reference (sampler.py:255, :428-431)
     int accept = 0, reject = 0, n_acc = 0, n_call = 0;
 
+    // the chain's first x stays in the x output buffer for the launch: the reference counts a chain only if EVERY coordinate of its
+    // last x differs from its first (nested.py:432), tested at the end (no register is held for it)
+    if (writer && a.x) store_tile<NT>(a.x, row, ok, D, lane, x);
     if (DBG && writer) {
         if (a.hist_x) store_tile<NT>(a.hist_x, (long)row * (S + 1), ok, D, lane, x);
         if (a.hist_logl && ok && g == 0) a.hist_logl[(size_t)row * (S + 1)] = logl;
@@ -322,10 +325,16 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
     if (!writer) return;
 #endif
     store_tile<NT>(a.z, row, ok, D, lane, z);
-    if (a.x) store_tile<NT>(a.x, row, ok, D, lane, x);
+    int all_moved = n_acc > 0 ? 1 : 0;   // (no x buffer: the accept count stands in)
+    if (a.x) {
+        f32x4 x0[2][NT];
+        load_tile<NT>(a.x, row, ok, D, lane, x0);
+        all_moved = mh_all_coordinates_differ<NT>(x, x0, D, lane);
+        store_tile<NT>(a.x, row, ok, D, lane, x);
+    }
     if (ok && g == 0) {
         a.logl[row] = logl;
-        if (a.n_accept) a.n_accept[row] = n_acc;
+        if (a.n_accept) a.n_accept[row] = n_acc | (all_moved ? NNEST_MH_ALL_MOVED : 0);
         if (a.n_call) a.n_call[row] = n_call;
     }
 #ifndef NNEST_STAMP

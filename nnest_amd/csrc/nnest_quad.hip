@@ -500,6 +500,9 @@ __global__ void __launch_bounds__(TEAM ? 192 : 128, 1) mh_kernel_quad(MhArgs a) 
                 if (d < D) base[r * D + d] = v[c][u];
             }
     };
+    // the chain's first x stays in the x output buffer for the launch: the reference counts a chain only if EVERY coordinate of its
+    // last x differs from its first (nested.py:432), tested at the end (no register is held for it)
+    if (writer && ok && a.x) store_row(a.x, (size_t)row, x);
     if (DBG && writer) {
         if (a.hist_x && ok) store_row(a.hist_x, (size_t)row * (S + 1), x);
         if (a.hist_logl && ok && m == 0) a.hist_logl[(size_t)row * (S + 1)] = logl;
@@ -630,12 +633,25 @@ __global__ void __launch_bounds__(TEAM ? 192 : 128, 1) mh_kernel_quad(MhArgs a) 
         o[4] = (float)a_p0; o[5] = (float)a_p1; o[6] = (float)a_p2; o[7] = (float)a_p3;
     }
 #endif
+    bool all_moved = n_acc > 0;   // (no x buffer: the accept count stands in)
+    if (a.x) {
+        bool mine = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int d = 2 * U * m + 2 * u + c;
+                const float x0 = (ok && d < D) ? a.x[(size_t)row * D + d] : 0.f;
+                mine = mine && (d >= D || x[c][u] != x0);
+            }
+        all_moved = (__ballot(mine) & walker_lanes) == walker_lanes;   // every position of walker j
+    }
     if (ok) {
         store_row(a.z, (size_t)row, z);
         if (a.x) store_row(a.x, (size_t)row, x);
         if (m == 0) {
             a.logl[row] = logl;
-            if (a.n_accept) a.n_accept[row] = n_acc;
+            if (a.n_accept) a.n_accept[row] = n_acc | (all_moved ? NNEST_MH_ALL_MOVED : 0);
             if (a.n_call) a.n_call[row] = n_call;
         }
     }

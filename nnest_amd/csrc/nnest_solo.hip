@@ -481,6 +481,9 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
                 if (d < D) base[r * D + d] = v[c][u];
             }
     };
+    // the chain's first x stays in the x output buffer for the launch: the reference counts a chain only if EVERY coordinate of its
+    // last x differs from its first (nested.py:432), tested at the end (no register is held for it)
+    if (writer_lane && ok && a.x) store_row(a.x, (size_t)row, x);
     if (DBG && writer_lane && ok) {
         if (a.hist_x) store_row(a.hist_x, (size_t)row * (S + 1), x);
         if (a.hist_logl && pos == 0) a.hist_logl[(size_t)row * (S + 1)] = logl;
@@ -617,12 +620,27 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
         if (j < 4) { o[8 + 2 * j] = (float)a_inv; o[9 + 2 * j] = (float)a_post; }   // the four net waves: which one shares its SIMD with the noise wave
     }
 #endif
+    bool all_moved = n_acc > 0;   // (no x buffer: the accept count stands in)
+    if (a.x) {
+        bool mine = true;
+        if (writer_lane) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int d = 2 * U * pos + 2 * u + c;
+                    const float x0 = (ok && d < D) ? a.x[(size_t)row * D + d] : 0.f;
+                    mine = mine && (d >= D || x[c][u] != x0);
+                }
+        }
+        all_moved = (__ballot(mine) & 0xffffull) == 0xffffull;   // the 16 positions (the writer row holds the walker once)
+    }
     if (writer_lane && ok) {
         store_row(a.z, (size_t)row, z);
         if (a.x) store_row(a.x, (size_t)row, x);
         if (pos == 0) {
             a.logl[row] = logl;
-            if (a.n_accept) a.n_accept[row] = n_acc;
+            if (a.n_accept) a.n_accept[row] = n_acc | (all_moved ? NNEST_MH_ALL_MOVED : 0);
             if (a.n_call) a.n_call[row] = n_call;
         }
     }

@@ -190,7 +190,11 @@ class _HipFlow(object):
                 float(step_size), int(steps), C, flags, _lib.ptr(dz), _lib.ptr(u),
                 int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), _lib.ptr(hx), _lib.ptr(hl), _lib.ptr(n_acc),
                 _lib.ptr(n_call), _lib.ptr(scale_out), _lib.ptr(sync), _lib.current_stream(dev)))
-        return dict(x=x, n_accept=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl, sync=sync)
+        # the kernels report in the count's bit 30 whether EVERY coordinate of the chain's last x differs from its first
+        # (include/nnest_hip.h NNEST_MH_ALL_MOVED): the reference's usable-chain test, nested.py:432
+        moved = (n_acc & _lib.MH_ALL_MOVED) != 0
+        n_acc = n_acc & (_lib.MH_ALL_MOVED - 1)
+        return dict(x=x, n_accept=n_acc, n_call=n_call, moved=moved, scale=scale_out, hist_x=hx, hist_logl=hl, sync=sync)
 
     def mh_form_for(self, C, dynamic=False, lag=None, free=False, form=None, warm=0):
         """the K4 form (name) `mh_steps` runs for C walkers under this step rule -- asked of the library

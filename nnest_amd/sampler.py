@@ -338,10 +338,10 @@ class Sampler(object):
         C = init_samples.shape[0]
         res, z0, z, logl = self._fused_launch(mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar,
                                               walker_offset, seed, form)
-        # "every coordinate moved" (nested.py:432: samples[:, 0] != samples[:, -1] in every dimension): a chain that accepted at
-        # least one proposal -- a latent move z + scale * eps displaces every coordinate of x = f^-1(z) -- and only such a chain;
-        # the kernel's accept count says it without the start x (which would take one more inverse pass to produce)
-        moved = res['n_accept'] > 0
+        # "every coordinate moved" (nested.py:432: samples[:, 0] != samples[:, -1] in every dimension): the kernel's own test of the
+        # chain's last x against its first x = f^-1(z_0), coordinate by coordinate (NNEST_MH_ALL_MOVED; round 4 took "accepted at
+        # least once" for it, which differs once a proposal is so small that a coordinate of x does not change in float32)
+        moved = res['moved']
         ends = torch.cat([res['x'].double(), logl[:, None], moved[:, None].double()], dim=1)
         counts = torch.stack([res['n_call'].sum(), res['n_accept'].sum()]).cpu()   # one small copy; orders the stream too
         netG.check_sync(res)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(_lib.SIGNATURES), set(syms) ^ set(_lib.SIGNATURES)
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.nnest_hip_version() == 14
+    assert lib.nnest_hip_version() == 15
 
 
 def test_argument_errors_are_reported_not_thrown():

@@ -318,27 +318,30 @@ def test_eight_and_twelve_walkers_per_workgroup_run_the_same_chains(hip, C):
     assert rel(cpu(res['x'])[same], so[same, -1]) < 5e-5
 
 
-def test_usable_chain_flag_from_the_accept_count(hip):
-    """ADVICE r03 / stated deviation: the driver marks a chain usable when the kernel's accept count is non-zero, where the
-    reference tests that every coordinate of x moved (nested.py:432: samples[:, 0] != samples[:, -1]).  The two agree whenever an
-    accepted latent move displaces every float32 coordinate -- checked here over a launch at a late-run proposal scale, and at a
-    scale a hundred times below anything the step rule reaches -- and every form writes both counters of every walker (the driver
-    allocates them uninitialised)."""
+@pytest.mark.parametrize('form', ['solo', 'quad', 'team', 'reg', 'image'])
+def test_usable_chain_flag_is_the_references_test(hip, form):
+    """nested.py:432: a chain's end may replace a live point only if EVERY coordinate of its last x differs from its first
+    (np.all(samples[:, 0] != samples[:, -1])).  Every K4 form evaluates exactly that at the end of the launch against the first x it
+    computed (NNEST_MH_ALL_MOVED in the accept count's word; round 4 took "accepted at least once" for it -- a stated deviation,
+    now gone).  Checked against the launch's own history, at a late-run proposal scale and at scales so small that an accepted
+    move leaves some float32 coordinates where they were -- where the two notions part."""
     nvp, o, g = trained(hip)
-    for C, step in ((1000, 0.05), (1000, 5e-4), (2000, 0.02), (4000, 0.02)):
-        rng = np.random.RandomState(C)
+    C = 600
+    parted = 0
+    for step in (0.05, 1e-5, 2e-7):
+        rng = np.random.RandomState(17)
         init = g['init'][rng.randint(0, g['init'].shape[0], size=C)]
-        z0, _ = nvp.forward(init)
-        x0, _ = nvp.inverse(z0)
-        l0 = hip.loglike(0, init, 5.0)
-        z, l = z0.clone(), l0.clone()
-        star = float(np.median(cpu(l0)))
-        res = nvp.mh_steps(0, 5.0, z, l, star, step, 60, seed=3, dynamic='batch')
-        nvp.check_sync(res)
-        na, nc = cpu(res['n_accept']), cpu(res['n_call'])
-        assert np.all((na >= 0) & (na <= 60) & (nc >= na) & (nc <= 60))      # written for every walker, by every form
-        moved_ref = np.all(cpu(x0) != cpu(res['x']), axis=1)
-        assert np.array_equal(moved_ref, na > 0), (C, step, int(np.sum(moved_ref != (na > 0))))
+        z, _ = nvp.forward(init)
+        l = hip.loglike(0, init, 5.0)
+        star = float(np.min(cpu(l))) - 1e3
+        res = nvp.mh_steps(0, 5.0, z, l, star, step, 12, seed=3, history=True, form=form)
+        hx, na = cpu(res['hist_x']), cpu(res['n_accept'])
+        assert np.all((na >= 0) & (na <= 12))                                  # the flag does not leak into the count
+        moved_ref = np.all(hx[:, 0] != hx[:, -1], axis=1)
+        assert np.array_equal(cpu(res['moved']), moved_ref), (form, step, int(np.sum(cpu(res['moved']) != moved_ref)))
+        assert not np.any(moved_ref & (na == 0))                               # no move without an accept
+        parted += int(np.sum((na > 0) & ~moved_ref))
+    assert parted > 0                                                          # the small scales did separate the two notions
 
 
 @pytest.mark.gpu
