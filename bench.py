@@ -111,7 +111,7 @@ def cpu_baseline(D, w, like, scale, walkers, target_seconds=10.0):
                           walkers, steps_all, threads, cores)}
 
 
-def committed_traffic(kernel, tag='r04'):
+def committed_traffic(kernel, tag='r05'):
     """HBM bytes per K4 launch from this round's committed rocprofv3 PMC passes of THIS command (scripts/profile_bench.sh ->
     profiles/<tag>/bench_pmc.json); None when the profile is absent or was taken on another kernel than the one that just ran"""
     path = os.path.join(ROOT, 'profiles', tag, 'bench_pmc.json')
@@ -537,7 +537,7 @@ def main():
                                   'roofline': {'bound': 'mfma', 'flops_per_unit': sp_flops, 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
                                                'achieved': C * S * sp_flops / (ms * 1e-3) / 1e12,
                                                'frac': C * S * sp_flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                               'kernel': 'spline_mh_kernel_team', 'profile': 'profiles/r04/spline_kernel_stats.csv'},
+                                               'kernel': 'spline_mh_kernel_team', 'profile': 'profiles/r05/spline_kernel_stats.csv'},
                                   'note': 'SingleSpeedSpline hidden=%d blocks=%d bins=8; VALU-bound on the spline arithmetic' % (H, B)}
             if C >= 200:  # its training epoch at this population (90 % train / 10 % validation, batch 100: trainer.py:159-176)
                 nv = C // 10
@@ -557,7 +557,7 @@ def main():
                 out['spline_flow']['train_roofline'] = {'bound': 'mfma', 'flops_per_unit': tf, 'unit_is': 'epoch', 'unit': 'TFLOP/s',
                                                         'peak': FP32_PEAK_TFLOPS, 'achieved': tf / (best * 1e-3) / 1e12,
                                                         'frac': tf / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 'kernel': 'spl_grad_kernel + spl_update_kernel',
-                                                        'profile': 'profiles/r04/spline_train_kernel_stats.csv'}
+                                                        'profile': 'profiles/r05/spline_train_kernel_stats.csv'}
         if world == 1 and dist is None and not args.bare and args.config in (2, 5):
             # the same workload on the build-defined MAF (BASELINE config 5 names it): reported beside, never
             # as `value`.  Its inverse -- the direction the proposals need -- is `num_groups` passes of the nets per block
@@ -620,7 +620,7 @@ def main():
                                'what': 'Trainer.train epoch loop in one launch (nnest_nvp_train), %d live points' % C,
                                'roofline': {'bound': 'valu', 'flops_per_unit': kfl, 'unit_is': 'epoch', 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
                                             'achieved': kfl / (best * 1e-3) / 1e12, 'frac': kfl / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                            'kernel': 'train_kernel_rows<2>', 'profile': 'profiles/r04/train_kernel_stats.csv',
+                                            'kernel': 'train_kernel_rows<2>', 'profile': 'profiles/r05/train_kernel_stats.csv',
                                             'note': 'latency-bound: per minibatch one forward + backward chain per row (100 waves on 25 '
                                                     'CUs) and four cross-CU round trips (two grid barriers, the operand loads of the '
                                                     'weight-gradient jobs, the image refresh)'}}

@@ -19,6 +19,9 @@ enum { MH_FORM_AUTO = 0, MH_FORM_IMAGE = 1, MH_FORM_REG = 2, MH_FORM_TEAM = 3, M
 // n_accept_dev words: the accept count, and NNEST_MH_ALL_MOVED set when every coordinate of the chain's last x differs from its
 // first x = f^-1(z_0) (what nnest/nested.py:432 asks of a chain before its end may replace a live point)
 enum { NNEST_MH_ALL_MOVED = 1 << 30 };
+// flags bit 28 (diagnostic, set by the launcher from NNEST_SOLO_VOTE=window): the solo form's exact steps wait for the publisher's window word
+// instead of reading the tiles' counters themselves
+enum { NNEST_MH_WINDOW_VOTES_ONLY = 1 << 28 };
 __host__ __device__ inline int mh_flag_lag(int flags) { return (flags >> 8) & 15; }
 __host__ __device__ inline int mh_flag_form(int flags) { return (flags >> 16) & 15; }
 __host__ __device__ inline int mh_flag_warm(int flags) { return (flags >> 20) & 255; }   // NNEST_MH_WARM

@@ -27,6 +27,7 @@
 // global-memory operation; ONE workgroup barrier per step.
 // Summation order differs from the other forms (K split in two halves, left to right), so results agree with them (and with a
 // CPU restatement) to rounding, not bitwise; decisions on the same noise are the same except at rounding-borderline ratios.
+#include <string.h>
 #include "mh_common.h"
 #include "nnest_internal.h"
 #include "solo_tile.h"
@@ -181,6 +182,7 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
     // exact step -- the two-candidate evaluation below, which hides the vote's round trip -- and the last step's vote is applied
     // too, for scale_out (round 5; round 4 sent lag 0 to the quad form, which waits out a grid-wide round trip per step).
     const bool exact_all = dynamic && mh_flag_lag(a.flags) == 0;
+    const bool direct_votes = (a.flags & NNEST_MH_WINDOW_VOTES_ONLY) == 0;
     const int lag = exact_all ? MH_SOLO_LAG_INTERNAL : mh_flag_lag(a.flags);   // otherwise >= 3 (solo_form_eligible): the rule is always relayed
     // the first `warm` steps apply the rule exactly (a grid-wide wait per step, hidden behind two evaluations) -- where its gain
     // 1 / (1 + n) is large and the scale still far from where it settles -- the rest `lag` steps behind (mh_common.h); at most S - 1
@@ -377,7 +379,10 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
                     fsbuf[(k + 1) & 1] = (float)scale;   // (buffer k + 1's scale is not used: step k + 2 takes fs_exact or a candidate)
                 }
                 solo_barrier();               // P_{k+1}
-                const bool up = mh_window_vote(a.sync, S, k, tile, 0ull, a.sync_err);
+                // (an exact step's vote is read from the tiles' counters themselves -- one memory-side hop less than the window word
+                // the publisher workgroup writes for the lagged steps: counters -> publisher -> window; NNEST_SOLO_VOTE=window keeps the latter)
+                const bool up = direct_votes ? 2 * mh_sync_total(a.sync, k, ntiles, 0ull, a.sync_err) > C
+                                             : mh_window_vote(a.sync, S, k, tile, 0ull, a.sync_err);
                 if (up) accept += 1; else reject += 1;
                 scale = next_scale(accept, reject, scale);
                 if (lane == 0) {
@@ -405,7 +410,7 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
                 for (int w_ = 0; w_ < WPG; ++w_) acs += ac[w_];
                 mh_sync_post(a.sync, S, tile, acs);
             }
-            const bool up = mh_window_vote(a.sync, S, S, tile, 0ull, a.sync_err);
+            const bool up = direct_votes ? 2 * mh_sync_total(a.sync, S, ntiles, 0ull, a.sync_err) > C : mh_window_vote(a.sync, S, S, tile, 0ull, a.sync_err);
             if (up) accept += 1; else reject += 1;
             if (accept > reject) scale *= use_tab ? etab[accept] : exp(1.0 / (1 + accept));
             if (accept < reject) scale /= use_tab ? etab[reject] : exp(1.0 / (1 + reject));
@@ -692,7 +697,10 @@ static hipError_t launch_solo_w(const MhArgs &a, int wpg, hipStream_t st) {
     return hipErrorInvalidConfiguration;
 }
 
-hipError_t launch_mh_solo(const MhArgs &a, int num_cu, hipStream_t st) {
+hipError_t launch_mh_solo(const MhArgs &a_in, int num_cu, hipStream_t st) {
+    MhArgs a = a_in;
+    static const bool window_votes = [] { const char *e = getenv("NNEST_SOLO_VOTE"); return e && !strcmp(e, "window"); }();
+    if (window_votes) a.flags |= NNEST_MH_WINDOW_VOTES_ONLY;
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
     const int wpg = solo_walkers_per_group(a.C, num_cu);
     // the production kernel of the BASELINE likelihood (Rosenbrock) is compiled with the likelihood fixed: the step loop then

@@ -342,7 +342,10 @@ class HipNVP(_HipFlow):
         return out
 
     def state_dict(self):
-        packed = self.store_packed()
+        return self.state_dict_from_packed(self.store_packed())
+
+    def state_dict_from_packed(self, packed):
+        """the reference's state_dict out of a packed-layout vector (no device access: safe on a worker thread)"""
         sd = {}
         for name, shape, off in self.layer_shapes():
             n = int(np.prod(shape))

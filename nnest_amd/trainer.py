@@ -209,11 +209,13 @@ class Trainer(object):
             ran = res['epochs_run'] - done
             losses = res['losses'][:ran].cpu().numpy()
             all_losses.append(losses)
-            for k in range(ran):
-                epoch = done + k + 1
-                if self.log and (epoch == 1 or epoch % log_interval == 0):
-                    self.logger.info('Epoch [%i] train loss [%5.4f] validation loss [%5.4f]' % (epoch, losses[k, 0], losses[k, 1]))
-                self.writer.add_scalar('loss', losses[k, 1], self.total_iters + epoch)
+            if self.log:
+                for k in range(ran):
+                    epoch = done + k + 1
+                    if epoch == 1 or epoch % log_interval == 0:
+                        self.logger.info('Epoch [%i] train loss [%5.4f] validation loss [%5.4f]' % (epoch, losses[k, 0], losses[k, 1]))
+            if ran > 0:   # (in bulk: 31 500 epochs of a config-2 run were 31 500 add_scalar calls)
+                self.writer.add_scalars('loss', np.arange(self.total_iters + done + 1, self.total_iters + done + ran + 1), losses[:ran, 1])
             done = res['epochs_run']
             if res['stopped']:
                 self.logger.info('Epoch [%i] ran out of patience' % done)
@@ -229,7 +231,7 @@ class Trainer(object):
             # (only where the owner asks for it -- NestedSampler.run does, and waits at its end; a plain train() call returns with
             # the file written, as in the reference)
             if getattr(self, 'async_save', False):
-                self._save_async(self.netG.state_dict(), os.path.join(self.path, 'models', 'netG.pt'))
+                self._save_async(self.netG, os.path.join(self.path, 'models', 'netG.pt'))
             else:
                 torch.save(self.netG.state_dict(), os.path.join(self.path, 'models', 'netG.pt'))
             if self.flow == 'spline':
@@ -238,10 +240,15 @@ class Trainer(object):
         self.logger.info('Best epoch [%i] validation loss [%5.4f] train time (s) [%5.4f]]'
                          % (self.best_validation_epoch, self.best_validation_loss, time.time() - start_time))
 
-    def _save_async(self, state, path):
+    def _save_async(self, netG, path):
+        # the packed weights are read back NOW (one small copy); slicing them into the state dict, pickling and writing happen
+        # on the worker thread beside the next GPU work
+        packed = netG.store_packed() if hasattr(netG, 'state_dict_from_packed') else None
+        state = None if packed is not None else netG.state_dict()
+
         def work():
             tmp = path + '.tmp'
-            torch.save(state, tmp)
+            torch.save(netG.state_dict_from_packed(packed) if packed is not None else state, tmp)
             os.replace(tmp, path)
         self.background_jobs().submit(work)
 

@@ -14,6 +14,7 @@ from tests.mh_checks import assert_borderline
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope='module')
@@ -379,3 +380,39 @@ def test_every_form_writes_both_counters_of_every_walker(hip, monkeypatch):
         lag = nvp.default_lag(C) if dyn == 'batch' else 0
         forms.add(nvp.mh_form_for(C, dynamic=dyn, lag=lag, warm=nvp.default_warm(C, dyn, lag) if lag else 0))
     assert len(forms) >= 3, forms     # solo, quad / team / image ... all went through it
+
+
+def test_exact_steps_reading_the_counters_themselves_give_the_window_words_chains(hip, tmp_path):
+    """Round 5: an exact step's vote is read from the tiles' counters directly (one memory-side hop less than the window word the
+    publisher workgroup writes).  Same counters, same rule (2 x accepted > walkers): the chains under lag 0 and under the product's
+    schedule are the ones NNEST_SOLO_VOTE=window (the round-4 path) produces, bit for bit."""
+    import subprocess
+    import sys
+    code = '''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from nnest_amd import flow
+nvp = flow.HipNVP(50, 16, 3, 1, seed=0)
+u0 = np.random.RandomState(0).uniform(-1, 1, size=(1000, 50))
+z0, _ = nvp.forward(u0)
+l0 = flow.loglike(0, u0, 5.0)
+out = {}
+for name, kw in (('lag0', dict(dynamic='batch', lag=0)), ('product', dict(dynamic='batch'))):
+    z, l = z0.clone(), l0.clone()
+    res = nvp.mh_steps(0, 5.0, z, l, float(l0.min()), 1 / np.sqrt(50), 60, seed=11, form='solo', **kw)
+    flow.HipNVP.check_sync(res)
+    out[name + '_x'] = res['x'].cpu().numpy(); out[name + '_a'] = res['n_accept'].cpu().numpy(); out[name + '_s'] = res['scale'].cpu().numpy()
+np.savez(sys.argv[1], **out)
+''' % ROOT
+    outs = {}
+    for mode in ('direct', 'window'):
+        p = str(tmp_path / (mode + '.npz'))
+        env = dict(os.environ)
+        env.pop('NNEST_SOLO_VOTE', None)
+        if mode == 'window':
+            env['NNEST_SOLO_VOTE'] = 'window'
+        r = subprocess.run([sys.executable, '-c', code, p], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(p)
+    for k in outs['direct'].files:
+        assert np.array_equal(outs['direct'][k], outs['window'][k]), k

@@ -17,7 +17,8 @@ live = rng.uniform(-1, 1, size=(N, D))
 nv = N // 10
 E = 40
 perms = torch.stack([torch.randperm(N - nv) for _ in range(E)]).int()
-for name, one_cu in (('multi-CU (train_kernel_rows)', False), ('one CU   (train_kernel)', True)):
+FORM = 'train_kernel_pipe' if os.environ.get('NNEST_TRAIN_FORM', '') == 'pipe' else 'train_kernel_rows'
+for name, one_cu in (('multi-CU (%s)' % FORM, False), ('one CU   (train_kernel)', True)):
     nvp = flow.HipNVP(D, 16, 3, 1, seed=1)
     kw = dict(seed=1, jitter=0.01, batch=100, patience=1000, one_cu=one_cu)
     nvp.train_epochs(live[nv:], live[:nv], perms[:2], None, max_epochs=2, **kw)
@@ -35,7 +36,7 @@ if os.environ.get('NNEST_HIP_LIB', '').endswith('STAMP.so'):   # NNEST_STAMP bui
     nvp = flow.HipNVP(D, 16, 3, 1, seed=1)
     res = nvp.train_epochs(live[nv:], live[:nv], perms, None, max_epochs=E, seed=1, jitter=0.01, batch=100, patience=1000)
     ph = res['losses'].cpu().numpy().ravel()[:8] / (E * ((N - nv + 99) // 100))
-    if os.environ.get('NNEST_TRAIN_FORM', '') == 'rows':
+    if os.environ.get('NNEST_TRAIN_FORM', '') != 'pipe':   # (the default form: train_kernel_rows)
         print('rows kernel, cycles per minibatch: forward %d  backward+staging %d  first grid barrier %d  weight-gradient jobs + Adam + publish %d  '
               'workgroup barrier %d  loss + image refresh (tag polls) %d  [first barrier: drain + workgroup barrier %d cycles, %.2f missed polls]' % tuple(ph[:8]))
     else:
