@@ -540,6 +540,27 @@ __device__ __forceinline__ int mh_all_coordinates_differ(const f32x4 (&a)[2][NT]
     return (int)((m >> w) & (m >> (w + 16)) & (m >> (w + 32)) & (m >> (w + 48)) & 1ull);
 }
 
+// the same against a tile still in memory (`rows` in load_tile's layout), a few coordinates at a time: no second tile in registers
+template <int NT>
+__device__ __forceinline__ int mh_all_coordinates_differ_from(const f32x4 (&a)[2][NT], const float *__restrict__ rows, long row, bool row_ok, int D, int lane) {
+    const int g = lane >> 4, w = lane & 15;
+    const float *p = rows + (size_t)row * D;
+    bool all = true;
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+        const int d0 = 32 * tau + 8 * g;
+        const float av[8] = {a[0][tau].x, a[1][tau].x, a[0][tau].y, a[1][tau].y, a[0][tau].z, a[1][tau].z, a[0][tau].w, a[1][tau].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool valid = row_ok && d0 + j < D;
+            const float b = valid ? p[d0 + j] : 0.f;
+            all = all && (!valid || av[j] != b);
+        }
+    }
+    const unsigned long long m = __ballot(all);
+    return (int)((m >> w) & (m >> (w + 16)) & (m >> (w + 32)) & (m >> (w + 48)) & 1ull);
+}
+
 template <int NT>
 __device__ __forceinline__ void store_tile(float *__restrict__ rows, long row, bool row_ok, int D, int lane,
                                            const f32x4 (&xs)[2][NT]) {

@@ -63,10 +63,15 @@ struct MhArgs {
     int *n_accept;
     int *n_call;
     float *scale_out;
+    float *x0;                  // the 16-walker-tile forms: where the chains' FIRST x goes (mh_first_x_buffer), for the usable-chain test behind the launch; or NULL
     const float *packed;        // packed weights (state_dict order): the quad form gathers its fragments from these
     unsigned long long *sync;   // batch-wide step rule: [steps + 2][MH_SYNC_SHARDS][MH_SYNC_STRIDE], zeroed before the launch
     int *sync_err;              // set to 1 if a bounded poll of `sync` ran out (a workgroup was not resident)
 };
+
+// the usable-chain test of the 16-walker-tile forms behind their launch (nnest_kernels.hip)
+float *mh_first_x_buffer(size_t floats);
+hipError_t launch_mh_all_moved(const MhArgs &a, hipStream_t st);
 
 // in-wave proposal streams: normals per (walker, lane group); the accept uniform per walker (identical in its 4
 // lanes).  Padded dims get exactly 0 (their weight fragments are 0, but 0 * inf would poison the accumulators).

@@ -191,7 +191,11 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
 
     // the chain's first x stays in the x output buffer for the launch: the reference counts a chain only if EVERY coordinate of its
     // last x differs from its first (nested.py:432), tested at the end (no register is held for it)
-    if (writer && a.x) store_tile<NT>(a.x, row, ok, D, lane, x);
+    // the chain's first x goes to a side buffer: the reference counts a chain only if EVERY coordinate of its last x differs from its first
+    // (nested.py:432), tested by mh_all_moved_kernel behind this launch.  (NOT in this kernel: the compare at the end of the body --
+    // sixteen loads, a ballot -- took the spline team kernel, whose 20 k-instruction step loop hipcc schedules precariously, from
+    // 7.9 to 11.4 ms per launch although the loop's own instruction count moved by 2 %; profiles/r05/spline_all_moved_regression.txt)
+    if (writer && a.x0) store_tile<NT>(a.x0, row, ok, D, lane, x);
     if (DBG && writer) {
         if (a.hist_x) store_tile<NT>(a.hist_x, (long)row * (S + 1), ok, D, lane, x);
         if (a.hist_logl && ok && g == 0) a.hist_logl[(size_t)row * (S + 1)] = logl;
@@ -325,16 +329,10 @@ __device__ __forceinline__ void mh_body(const MhArgs &a, int tile, int lane, con
     if (!writer) return;
 #endif
     store_tile<NT>(a.z, row, ok, D, lane, z);
-    int all_moved = n_acc > 0 ? 1 : 0;   // (no x buffer: the accept count stands in)
-    if (a.x) {
-        f32x4 x0[2][NT];
-        load_tile<NT>(a.x, row, ok, D, lane, x0);
-        all_moved = mh_all_coordinates_differ<NT>(x, x0, D, lane);
-        store_tile<NT>(a.x, row, ok, D, lane, x);
-    }
+    if (a.x) store_tile<NT>(a.x, row, ok, D, lane, x);
     if (ok && g == 0) {
         a.logl[row] = logl;
-        if (a.n_accept) a.n_accept[row] = n_acc | (all_moved ? NNEST_MH_ALL_MOVED : 0);
+        if (a.n_accept) a.n_accept[row] = n_acc | ((!a.x0 && n_acc > 0) ? NNEST_MH_ALL_MOVED : 0);   // (no side buffer: the accept count stands in)
         if (a.n_call) a.n_call[row] = n_call;
     }
 #ifndef NNEST_STAMP
@@ -753,19 +751,63 @@ static int pick_mh_form(const MhArgs &a, int num_cu) {
     return MH_FORM_IMAGE;
 }
 
+// ---- the usable-chain test of the 16-walker-tile forms (nested.py:432), behind their launch --------------------------------------
+// one wave per walker: every coordinate of the last x differs from the first -> NNEST_MH_ALL_MOVED into the accept count's word
+__global__ void __launch_bounds__(256) mh_all_moved_kernel(const float *__restrict__ x0, const float *__restrict__ x, int *__restrict__ n_accept, int C, int D) {
+    const int lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); c < C; c += gridDim.x * (blockDim.x >> 6)) {
+        bool all = true;
+        for (int d = lane; d < D; d += 64) all = all && x[(size_t)c * D + d] != x0[(size_t)c * D + d];
+        if (__ballot(all) == ~0ull && lane == 0) n_accept[c] |= NNEST_MH_ALL_MOVED;
+    }
+}
+// the side buffer the tile forms park the first x in: one per device, grown on demand, reused by every launch (launches of one
+// device are ordered by the stream they share with the follow-up kernel; growing frees the old buffer, which waits for the device)
+float *mh_first_x_buffer(size_t floats) {
+    static float *buf[16] = {};
+    static size_t cap[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (cap[dev] < floats) {
+        if (buf[dev]) (void)hipFree(buf[dev]);
+        buf[dev] = nullptr; cap[dev] = 0;
+        const size_t want = floats + floats / 2 + 4096;
+        if (hipMalloc((void **)&buf[dev], want * sizeof(float)) != hipSuccess) return nullptr;
+        cap[dev] = want;
+    }
+    return buf[dev];
+}
+hipError_t launch_mh_all_moved(const MhArgs &a, hipStream_t st) {
+    if (!a.x0 || !a.x || !a.n_accept) return hipSuccess;
+    const int grid = min((a.C + 3) / 4, 2048);
+    hipLaunchKernelGGL(mh_all_moved_kernel, dim3(grid), dim3(256), 0, st, a.x0, a.x, a.n_accept, a.C, a.s.D);
+    return hipGetLastError();
+}
+
 // Which form runs (DESIGN.md "K4"): solo (1 walker per wave, nnest_solo.hip) / quad (4 walkers per tile, nnest_quad.hip) while their
 // tiles fit the CUs, then team, register, image by population; flags bits 16..19 pin a form (a caller that shards one batch over ranks
 // pins the form the whole batch would get, so a shard reproduces the slice of the unsharded run bit for bit).  The batch-wide
 // step rule needs every workgroup resident: it is refused where the grid could exceed the chip.
 template <int NT, int NH, int LT>
-static hipError_t launch_mh_t(const MhArgs &a, int num_cu, hipStream_t st) {
+static hipError_t launch_mh_tiles_t(const MhArgs &a, int form, int num_cu, hipStream_t st);
+template <int NT, int NH, int LT>
+static hipError_t launch_mh_t(const MhArgs &a_in, int num_cu, hipStream_t st) {
+    const bool batch = (a_in.flags & NNEST_MH_DYNAMIC_BATCH) != 0;
+    if (batch && !a_in.sync) return hipErrorInvalidValue;
+    const int form = pick_mh_form<NT, NH, LT>(a_in, num_cu);
+    if (form < 0) return hipErrorInvalidConfiguration;
+    if (form == MH_FORM_SOLO) return launch_mh_solo(a_in, num_cu, st);   // (solo and quad test the chain in-kernel)
+    if (form == MH_FORM_QUAD || form == MH_FORM_QUAD1) return launch_mh_quad(a_in, num_cu, st);
+    MhArgs a = a_in;
+    if (a.x && a.n_accept) a.x0 = mh_first_x_buffer((size_t)a.C * a.s.D);
+    hipError_t e = launch_mh_tiles_t<NT, NH, LT>(a, form, num_cu, st);
+    if (e != hipSuccess) return e;
+    return launch_mh_all_moved(a, st);
+}
+template <int NT, int NH, int LT>
+static hipError_t launch_mh_tiles_t(const MhArgs &a, int form, int num_cu, hipStream_t st) {
     const int ntiles = (a.C + 15) / 16;
     const bool batch = (a.flags & NNEST_MH_DYNAMIC_BATCH) != 0;
-    if (batch && !a.sync) return hipErrorInvalidValue;
-    const int form = pick_mh_form<NT, NH, LT>(a, num_cu);
-    if (form < 0) return hipErrorInvalidConfiguration;
-    if (form == MH_FORM_SOLO) return launch_mh_solo(a, num_cu, st);
-    if (form == MH_FORM_QUAD || form == MH_FORM_QUAD1) return launch_mh_quad(a, num_cu, st);
     if constexpr (LT == 1 && NH == 1) {
         if (form == MH_FORM_TEAM) {
             const size_t timg = NT <= 2 ? 0 : (size_t)a.s.image_floats * 4;  // 3-4 tiles per class: fragments from an LDS image
@@ -905,7 +947,12 @@ hipError_t launch_mh(const float *img, const FlowShape &s, const LikeSpec &like,
     a.steps = steps; a.C = C; a.flags = flags; a.like = like;
     a.noise_dz = noise_dz; a.noise_u = noise_u; a.seed = seed; a.walker_offset = walker_offset;
     a.hist_x = hist_x; a.hist_logl = hist_logl; a.n_accept = n_accept; a.n_call = n_call; a.scale_out = scale_out;
-    if (s.kind == FLOW_KIND_MAF) return launch_maf_mh(a, num_cu, st);
+    a.x0 = nullptr;
+    if (s.kind == FLOW_KIND_MAF) {
+        if (a.x && a.n_accept) a.x0 = mh_first_x_buffer((size_t)C * s.D);
+        hipError_t e = launch_maf_mh(a, num_cu, st);
+        return e != hipSuccess ? e : launch_mh_all_moved(a, st);
+    }
     DISPATCH_SHAPE(launch_mh_t, s, a, num_cu, st);
 }
 
