@@ -172,8 +172,10 @@ int nnest_loglike(const nnest_like_t *like, const float *x_unit_dev, double *log
  *   n_accept_dev [C]   out int32: accepted moves per walker  (sampler.py:418-420) in bits 0..29; bit 30 (NNEST_MH_ALL_MOVED) is set
  *                      when EVERY coordinate of the chain's last x differs from its first x = f^-1(z_0) -- the reference's test
  *                      of a chain before its end may replace a live point (nested.py:432: np.all(samples[:,0] != samples[:,-1]));
- *                      evaluated at the end of the launch against the first x, which the kernel parks in x_dev meanwhile
- *                      (x_dev NULL: the bit says "accepted at least once")
+ *                      evaluated against the first x the launch computed -- in-kernel by the solo and quad forms (the first x
+ *                      parked in x_dev meanwhile), by a follow-up kernel on the launch's stream for the 16-walker-tile forms
+ *                      and the spline / MAF flows (the first x in a side buffer of the library); x_dev NULL: the bit says
+ *                      "accepted at least once"
  *   n_call_dev [C]     out int32: likelihood calls per walker (rows that passed the prior/Jacobian test,
  *                      sampler.py:358-363)
  *   scale_out_dev      optional float32 [ngroups]: final scale per adaptation group (sampler.py:422-431)
