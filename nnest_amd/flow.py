@@ -192,9 +192,8 @@ class _HipFlow(object):
                 _lib.ptr(n_call), _lib.ptr(scale_out), _lib.ptr(sync), _lib.current_stream(dev)))
         # the kernels report in the count's bit 30 whether EVERY coordinate of the chain's last x differs from its first
         # (include/nnest_hip.h NNEST_MH_ALL_MOVED): the reference's usable-chain test, nested.py:432
-        moved = (n_acc & _lib.MH_ALL_MOVED) != 0
-        n_acc = n_acc & (_lib.MH_ALL_MOVED - 1)
-        return dict(x=x, n_accept=n_acc, n_call=n_call, moved=moved, scale=scale_out, hist_x=hx, hist_logl=hl, sync=sync)
+        # (split on first use: two element-wise launches that a caller who reads neither does not pay for)
+        return _MhResult(x=x, n_accept_word=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl, sync=sync)
 
     def mh_form_for(self, C, dynamic=False, lag=None, free=False, form=None, warm=0):
         """the K4 form (name) `mh_steps` runs for C walkers under this step rule -- asked of the library
@@ -239,6 +238,25 @@ class _HipFlow(object):
                                                      int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset),
                                                      _lib.current_stream(self.device)))
         return dz, u
+
+
+class _MhResult(dict):
+    """what mh_steps returns; 'n_accept' (the count) and 'moved' (the reference's usable-chain test, nested.py:432) are split off
+    the kernel's word (NNEST_MH_ALL_MOVED) when first asked for"""
+
+    def __missing__(self, key):
+        if key in ('n_accept', 'moved'):
+            w = dict.__getitem__(self, 'n_accept_word')
+            self['moved'] = (w & _lib.MH_ALL_MOVED) != 0
+            self['n_accept'] = w & (_lib.MH_ALL_MOVED - 1)
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
 
 
 class HipNVP(_HipFlow):
