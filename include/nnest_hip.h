@@ -73,6 +73,10 @@ enum {
                                  * Needs every workgroup resident: NNEST_E_UNSUPPORTED beyond ~16 walkers x 8 x CUs */
 };
 #define NNEST_MH_LAG(n) (((n) & 15) << 8)
+/* flags bits 29 / 30: sync_dev is one half of a double buffer whose other half lies BEHIND it (bit 29) / IN FRONT of it (bit 30),
+ * nnest_mh_sync_words(steps) words away, and the launch zeroes that other half for the next launch (see sync_dev below) */
+#define NNEST_MH_SYNC_ZERO_NEXT (1 << 29)
+#define NNEST_MH_SYNC_ZERO_PREV (1 << 30)
 /* flags bits 20..27, with NNEST_MH_DYNAMIC_BATCH and lag >= 1: the first n steps of the launch apply the rule EXACTLY (lag 0, a
  * grid-wide wait on each of them) and only the steps after them run `lag` behind: votes 1..n are applied as the reference
  * applies them, the votes of the steps s > n from step s + 1 + lag on.  The rule's gain is 1 / (1 + votes) and every launch
@@ -179,8 +183,12 @@ int nnest_loglike(const nnest_like_t *like, const float *x_unit_dev, double *log
  *   n_call_dev [C]     out int32: likelihood calls per walker (rows that passed the prior/Jacobian test,
  *                      sampler.py:358-363)
  *   scale_out_dev      optional float32 [ngroups]: final scale per adaptation group (sampler.py:422-431)
- *   sync_dev           NNEST_MH_DYNAMIC_BATCH only (else NULL): nnest_mh_sync_words(steps) 8-byte words, ZEROED by the
- *                      caller before every launch; the last word is an error flag (non-zero: a bounded wait ran out)
+ *   sync_dev           NNEST_MH_DYNAMIC_BATCH only (else NULL): nnest_mh_sync_words(steps) 8-byte words, ZERO at the launch;
+ *                      the last word is an error flag (non-zero: a bounded wait ran out).  Either the caller zeroes them in
+ *                      front of every launch, or it keeps a double buffer of 2 x nnest_mh_sync_words(steps) words, zeroes it
+ *                      once, passes the halves alternately and sets NNEST_MH_SYNC_ZERO_NEXT (the other half lies behind
+ *                      sync_dev) or NNEST_MH_SYNC_ZERO_PREV (in front of it): the launch then zeroes the other half for the
+ *                      next one (the solo form in-kernel, on spare waves: no fill launch in front of a K4 launch)
  */
 int nnest_mh_constrained_steps(nnest_nvp_t *nvp, const nnest_like_t *like, float *z_dev, float *x_dev,
                                double *logl_dev, double loglstar, float step_size, int steps, int C, int flags,

@@ -24,6 +24,7 @@ MH_FORMS = {None: 0, 'auto': 0, 'image': 1, 'reg': 2, 'team': 3, 'quad': 4, 'qua
 MH_FORM_NAMES = {v: k for k, v in MH_FORMS.items() if isinstance(k, str) and v}
 MH_DEFAULT_LAG = 4      # steps between a step and the scale that reflects its batch-wide count
 MH_WARM_STEPS = 16      # exact steps in front of the lagged rule where the form implements them (NNEST_MH_WARM)
+MH_SYNC_ZERO_NEXT, MH_SYNC_ZERO_PREV = 1 << 29, 1 << 30   # sync_dev as one half of a double buffer (include/nnest_hip.h)
 MH_ALL_MOVED = 1 << 30  # n_accept words: every coordinate of the chain's last x differs from its first (include/nnest_hip.h)
 MH_SOLO_LAG = 8         # ... where the solo form runs (its steps are shorter: the same ~10 us of latency)
 TRAIN_RESUME = 1

@@ -22,6 +22,10 @@ enum { NNEST_MH_ALL_MOVED = 1 << 30 };
 // flags bit 28 (diagnostic, set by the launcher from NNEST_SOLO_VOTE=window): the solo form's exact steps wait for the publisher's window word
 // instead of reading the tiles' counters themselves
 enum { NNEST_MH_WINDOW_VOTES_ONLY = 1 << 28 };
+// flags bits 29 / 30 (include/nnest_hip.h): sync_dev is one half of a double buffer, and the launch ZEROES the other half -- the
+// one behind it (bit 29) or in front of it (bit 30), nnest_mh_sync_words(steps) words away -- for the next launch, on the spare
+// waves of the workgroup that publishes the batch totals: the caller's fill launch in front of every K4 launch goes away (solo form)
+// (NNEST_MH_SYNC_ZERO_NEXT / NNEST_MH_SYNC_ZERO_PREV: include/nnest_hip.h)
 __host__ __device__ inline int mh_flag_lag(int flags) { return (flags >> 8) & 15; }
 __host__ __device__ inline int mh_flag_form(int flags) { return (flags >> 16) & 15; }
 __host__ __device__ inline int mh_flag_warm(int flags) { return (flags >> 20) & 255; }   // NNEST_MH_WARM
@@ -72,6 +76,7 @@ struct MhArgs {
 // the usable-chain test of the 16-walker-tile forms behind their launch (nnest_kernels.hip)
 float *mh_first_x_buffer(size_t floats);
 hipError_t launch_mh_all_moved(const MhArgs &a, hipStream_t st);
+hipError_t launch_mh_zero_other_sync(const MhArgs &a, hipStream_t st);
 
 // in-wave proposal streams: normals per (walker, lane group); the accept uniform per walker (identical in its 4
 // lanes).  Padded dims get exactly 0 (their weight fragments are 0, but 0 * inf would poison the accumulators).

@@ -777,6 +777,13 @@ float *mh_first_x_buffer(size_t floats) {
     }
     return buf[dev];
 }
+// NNEST_MH_SYNC_ZERO_NEXT / _PREV for the forms that do not zero the other half of the caller's double buffer themselves
+hipError_t launch_mh_zero_other_sync(const MhArgs &a, hipStream_t st) {
+    if (!a.sync || !(a.flags & (NNEST_MH_SYNC_ZERO_NEXT | NNEST_MH_SYNC_ZERO_PREV))) return hipSuccess;
+    const size_t W = mh_sync_words(a.steps) + 1;
+    unsigned long long *other = (a.flags & NNEST_MH_SYNC_ZERO_NEXT) ? a.sync + W : a.sync - W;
+    return hipMemsetAsync(other, 0, W * sizeof(unsigned long long), st);
+}
 hipError_t launch_mh_all_moved(const MhArgs &a, hipStream_t st) {
     if (!a.x0 || !a.x || !a.n_accept) return hipSuccess;
     const int grid = min((a.C + 3) / 4, 2048);
@@ -797,10 +804,15 @@ static hipError_t launch_mh_t(const MhArgs &a_in, int num_cu, hipStream_t st) {
     const int form = pick_mh_form<NT, NH, LT>(a_in, num_cu);
     if (form < 0) return hipErrorInvalidConfiguration;
     if (form == MH_FORM_SOLO) return launch_mh_solo(a_in, num_cu, st);   // (solo and quad test the chain in-kernel)
-    if (form == MH_FORM_QUAD || form == MH_FORM_QUAD1) return launch_mh_quad(a_in, num_cu, st);
+    if (form == MH_FORM_QUAD || form == MH_FORM_QUAD1) {
+        hipError_t e = launch_mh_quad(a_in, num_cu, st);
+        return e != hipSuccess ? e : launch_mh_zero_other_sync(a_in, st);
+    }
     MhArgs a = a_in;
     if (a.x && a.n_accept) a.x0 = mh_first_x_buffer((size_t)a.C * a.s.D);
     hipError_t e = launch_mh_tiles_t<NT, NH, LT>(a, form, num_cu, st);
+    if (e != hipSuccess) return e;
+    e = launch_mh_zero_other_sync(a, st);
     if (e != hipSuccess) return e;
     return launch_mh_all_moved(a, st);
 }
@@ -951,6 +963,7 @@ hipError_t launch_mh(const float *img, const FlowShape &s, const LikeSpec &like,
     if (s.kind == FLOW_KIND_MAF) {
         if (a.x && a.n_accept) a.x0 = mh_first_x_buffer((size_t)C * s.D);
         hipError_t e = launch_maf_mh(a, num_cu, st);
+        if (e == hipSuccess) e = launch_mh_zero_other_sync(a, st);
         return e != hipSuccess ? e : launch_mh_all_moved(a, st);
     }
     DISPATCH_SHAPE(launch_mh_t, s, a, num_cu, st);

@@ -194,6 +194,14 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
         // batch-wide step rule (mh_common.h): the one workgroup behind the tiles sums every step's counters as soon as they
         // are complete and publishes the total; its other waves leave at once
         if (dynamic && wave == 0) mh_sync_publisher(a.sync, S, exact_all ? S : max(S - lag, warm), ntiles, C, lane, a.sync_err);
+        else if (dynamic && (a.flags & (NNEST_MH_SYNC_ZERO_NEXT | NNEST_MH_SYNC_ZERO_PREV))) {
+            // this workgroup's other waves: the OTHER half of the caller's double buffer, zeroed for the next launch (nothing of this
+            // launch touches it; the kernel boundary orders it in front of the next one)
+            const size_t W = (size_t)mh_sync_words(S) + 1;   // (+ the error word)
+            unsigned long long *other = (a.flags & NNEST_MH_SYNC_ZERO_NEXT) ? a.sync + W : a.sync - W;
+            const int nthr = (int)blockDim.x - 64;
+            for (size_t i = threadIdx.x - 64; i < W; i += nthr) other[i] = 0ull;
+        }
         return;
     }
     {

@@ -215,5 +215,6 @@ hipError_t launch_spline_mh(const float *img, const SplineShape &sp, const LikeS
     SplArgs q = {img, sp};
     if (a.x && a.n_accept) a.x0 = mh_first_x_buffer((size_t)C * sp.D);
     hipError_t e = [&]() -> hipError_t { DISPATCH_SPLINE(launch_spline_mh_t, sp, a, q, num_cu, st); }();
+    if (e == hipSuccess) e = launch_mh_zero_other_sync(a, st);
     return e != hipSuccess ? e : launch_mh_all_moved(a, st);
 }

@@ -181,8 +181,17 @@ class _HipFlow(object):
             warm = self.default_warm(C, dynamic, lag, form)
         flags = _lib.mh_flags(dynamic, free, lag, form, warm)
         sync = None
-        if flags & _lib.MH_DYNAMIC_BATCH:   # per-step batch counters, zeroed for every launch; last word = error flag
-            sync = torch.zeros(self._lib.nnest_mh_sync_words(int(steps)), dtype=torch.int64, device=dev)
+        if flags & _lib.MH_DYNAMIC_BATCH:   # per-step batch counters, zero at every launch; last word = error flag
+            # a double buffer per step count, zeroed ONCE: each launch zeroes the half the next launch will use (in-kernel where the
+            # solo form runs: the fill launch in front of every K4 launch -- 3 % of a config-2 launch -- is gone)
+            W = int(self._lib.nnest_mh_sync_words(int(steps)))
+            pool = self.__dict__.setdefault('_sync_pool', {})
+            ent = pool.get(int(steps))
+            if ent is None:
+                ent = pool[int(steps)] = [torch.zeros(2 * W, dtype=torch.int64, device=dev), 0]
+            half, ent[1] = ent[1], ent[1] ^ 1
+            sync = ent[0][half * W:(half + 1) * W]
+            flags |= _lib.MH_SYNC_ZERO_PREV if half else _lib.MH_SYNC_ZERO_NEXT
         with torch.cuda.device(dev):
             lk = _lib.like_spec(like_id, like_scale, like_params)
             _lib.check(self._sym['mh'](

@@ -266,3 +266,18 @@ def test_grid_training_vs_single_workgroup(hip, D, L, N, batch):
         assert np.max(np.abs(x - y)) <= 1e-4 * (1e-3 + np.max(np.abs(x)))
     assert a[5:9] == b[5:9] and abs(a[9] - b[9]) <= 1e-5 * abs(a[9])
     assert a[5] >= 6 and a[8] > 0 and np.all(np.isfinite(a[3]))
+
+
+def test_the_pipelined_training_form_is_held_to_the_same_fixtures():
+    """train_kernel_pipe (NNEST_TRAIN_FORM=pipe: the form pipelined per coupling block, round 5 -- built, measured, not faster, kept
+    opt-in) against everything this file holds the default form to: the reference's recorded steps and runs, bitwise
+    reproducibility, patience, the single-workgroup kernel.  The form is read from the environment once per process, so the file
+    runs again in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NNEST_TRAIN_FORM='pipe')
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k', 'not pipelined_training_form'],
+                         env=env, capture_output=True, text=True, timeout=900,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert ' passed' in out.stdout and 'failed' not in out.stdout
