@@ -224,6 +224,8 @@ class NestedSampler(Sampler):
 
     def _checkpoint(self, it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt, state):
         cp = self.logs['checkpoint']
+        if hasattr(self.trainer, 'flush_pending_files'):   # models/netG.pt as of this checkpoint (the trainer batches its file writes)
+            self.trainer.flush_pending_files()
         np.save(os.path.join(cp, 'active_u_%s.npy' % it), active_u)
         np.save(os.path.join(cp, 'active_v_%s.npy' % it), active_v)
         np.save(os.path.join(cp, 'active_logl_%s.npy' % it), active_logl)

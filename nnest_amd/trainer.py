@@ -165,7 +165,7 @@ class Trainer(object):
         samples = np.asarray(samples)
         if self.path:
             if getattr(self, 'async_save', False):   # (a copy: the caller's live points move on while the worker writes)
-                self.background_jobs().submit(lambda a=np.array(samples), p=os.path.join(self.path, 'data', 'originals.npy'): np.save(p, a))
+                self._pending_files['originals'] = (np.array(samples), os.path.join(self.path, 'data', 'originals.npy'))
             else:
                 np.save(os.path.join(self.path, 'data', 'originals.npy'), samples)
         training_jitter = self.training_jitter(samples) if jitter < 0 else jitter
@@ -231,7 +231,13 @@ class Trainer(object):
             # (only where the owner asks for it -- NestedSampler.run does, and waits at its end; a plain train() call returns with
             # the file written, as in the reference)
             if getattr(self, 'async_save', False):
-                self._save_async(self.netG, os.path.join(self.path, 'models', 'netG.pt'))
+                # (the packed weights are read back NOW; the file follows at most SAVE_EVERY seconds later -- and at every checkpoint,
+                # and at the end of the run: a config-2 run retrains 390 times in 4 s, and 390 pickles on the worker thread held the
+                # interpreter lock for 0.2 s of the main thread's time)
+                self._pending_files['netG'] = (self.netG.store_packed() if hasattr(self.netG, 'state_dict_from_packed') else self.netG.state_dict(),
+                                               os.path.join(self.path, 'models', 'netG.pt'))
+                if time.time() - getattr(self, '_last_flush', 0.0) >= self.SAVE_EVERY:
+                    self.flush_pending_files()
             else:
                 torch.save(self.netG.state_dict(), os.path.join(self.path, 'models', 'netG.pt'))
             if self.flow == 'spline':
@@ -240,17 +246,30 @@ class Trainer(object):
         self.logger.info('Best epoch [%i] validation loss [%5.4f] train time (s) [%5.4f]]'
                          % (self.best_validation_epoch, self.best_validation_loss, time.time() - start_time))
 
-    def _save_async(self, netG, path):
-        # the packed weights are read back NOW (one small copy); slicing them into the state dict, pickling and writing happen
-        # on the worker thread beside the next GPU work
-        packed = netG.store_packed() if hasattr(netG, 'state_dict_from_packed') else None
-        state = None if packed is not None else netG.state_dict()
+    SAVE_EVERY = 0.25   # seconds between writes of models/netG.pt and data/originals.npy while a run owns the trainer (async_save)
+
+    @property
+    def _pending_files(self):
+        return self.__dict__.setdefault('_pending', {})
+
+    def flush_pending_files(self):
+        """hand the latest models/netG.pt and data/originals.npy to the worker thread (slicing the packed weights into the state
+        dict, pickling and writing happen there, to a temporary file that then replaces the old one: a reader never sees half
+        a file).  Called by train() every SAVE_EVERY seconds, by the sampler in front of every checkpoint and at the end of run()."""
+        pend, self._pending = self._pending_files, {}
+        self._last_flush = time.time()
+        netG = self.netG
 
         def work():
-            tmp = path + '.tmp'
-            torch.save(netG.state_dict_from_packed(packed) if packed is not None else state, tmp)
-            os.replace(tmp, path)
-        self.background_jobs().submit(work)
+            if 'originals' in pend:
+                np.save(pend['originals'][1], pend['originals'][0])
+            if 'netG' in pend:
+                state, path = pend['netG']
+                tmp = path + '.tmp'
+                torch.save(netG.state_dict_from_packed(state) if isinstance(state, np.ndarray) else state, tmp)
+                os.replace(tmp, path)
+        if pend:
+            self.background_jobs().submit(work)
 
     def background_jobs(self):
         """the worker that writes files the run does not wait for (utils.BackgroundJobs), created at first use"""
@@ -261,6 +280,7 @@ class Trainer(object):
 
     def wait_for_saves(self):
         """block until models/netG.pt holds the last trained weights (and everything else handed to background_jobs() is done)"""
+        self.flush_pending_files()
         if getattr(self, '_jobs', None) is not None:
             self._jobs.wait()
 

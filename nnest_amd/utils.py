@@ -90,30 +90,51 @@ class ScalarWriter(object):
         self._buf = []
         self.jobs = None    # a BackgroundJobs: bulk rows are formatted and appended there (NestedSampler.run lends the trainer's)
 
+    # Rows are kept as they arrive -- single rows as text, bulk rows as (tag, steps, values) arrays -- and turned into text when
+    # there is something to gain from writing: every WRITE_EVERY seconds on the worker thread where there is one (a config-2 run
+    # logs 230 000 rows; formatting them as they came held the interpreter lock for a quarter of a second of the run), at flush()
+    # at the latest.  The file keeps the order of the calls.
+    WRITE_EVERY = 0.5
+
     def add_scalar(self, tag, value, step=None):
         if self.path is None:
             return
         self._buf.append('%s,%s,%r\n' % (tag, step, float(value)))
-        if len(self._buf) >= 256:
-            self.flush()
+        self._maybe_write()
 
     def add_scalars(self, tag, steps, values):
         """add_scalar for a run of steps at once (the native nested-sampling loop reports log Z per accepted point in bulk)"""
         if self.path is None:
             return
-        if self.jobs is not None:   # rows buffered so far go first, then these: the file keeps the order of the calls
-            head, self._buf = self._buf, []
-            ks, vs = np.array(steps).tolist(), np.array(values, dtype=np.float64).tolist()
+        self._buf.append((tag, np.array(steps), np.array(values, dtype=np.float64)))
+        self._maybe_write()
 
-            def work(path=self.path):
-                with open(path, 'a') as f:
-                    f.writelines(head)
-                    f.writelines(['%s,%s,%r\n' % (tag, k, v) for k, v in zip(ks, vs)])
-            self.jobs.submit(work)
-            return
-        self._buf.extend('%s,%s,%r\n' % (tag, int(k), float(v)) for k, v in zip(steps, values))
-        if len(self._buf) >= 256:
-            self.flush()
+    def _maybe_write(self):
+        import time
+        now = time.time()
+        if self.jobs is None:
+            if len(self._buf) >= 256:
+                self._write(self._take())
+        elif now - getattr(self, '_last_write', 0.0) >= self.WRITE_EVERY:
+            self._last_write = now
+            rows = self._take()
+            self.jobs.submit(lambda: self._write(rows))
+
+    def _take(self):
+        rows, self._buf = self._buf, []
+        return rows
+
+    def _write(self, rows):
+        out = []
+        for r in rows:
+            if isinstance(r, str):
+                out.append(r)
+            else:
+                tag, ks, vs = r
+                out.extend(['%s,%s,%r\n' % (tag, k, v) for k, v in zip(ks.tolist(), vs.tolist())])
+        if out:
+            with open(self.path, 'a') as f:
+                f.writelines(out)
 
     def add_figure(self, *a, **k):
         pass
@@ -122,9 +143,7 @@ class ScalarWriter(object):
         if self.jobs is not None:
             self.jobs.wait()
         if self.path is not None and self._buf:
-            with open(self.path, 'a') as f:
-                f.writelines(self._buf)
-            self._buf = []
+            self._write(self._take())
 
     def __del__(self):
         try:

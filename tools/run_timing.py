@@ -84,6 +84,6 @@ np.random.seed(0); torch.manual_seed(0)
 s = NestedSampler(like.x_dim, like, transform=lambda x: scale * x, log_dir=tempfile.mkdtemp(dir='/tmp'), num_live_points=N, log_level=30, flow=flow)
 t0 = time.time()
 s.run(mcmc_num_chains=N)
-print('wall %.1f s logz %.3f' % (time.time() - t0, s.logz))
+print('wall %.2f s logz %.3f' % (time.time() - t0, s.logz))
 for k, (t, n) in sorted(T.items(), key=lambda kv: -kv[1][0]):
     print('  %-32s %8.2f s  %7d calls  %8.3f ms each' % (k, t, n, t / n * 1e3))
