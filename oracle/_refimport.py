@@ -44,7 +44,12 @@ def import_reference():
         gd.mcsamples = gm
         sys.modules['getdist'] = gd
         sys.modules['getdist.mcsamples'] = gm
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
-    import nnest  # noqa: F401
+    # on the path for the import only: the reference has a `tests` package of its own, and a path entry left behind would
+    # shadow this repo's `tests` in every process spawned later (spawn hands the parent's sys.path to the child)
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        import nnest  # noqa: F401
+        import nnest.nested, nnest.mcmc, nnest.sampler, nnest.trainer, nnest.networks  # noqa: F401,E401
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
     return nnest
