@@ -347,6 +347,14 @@ int nnest_chol_adam_step(nnest_chol_t *chol, const float *grad_dev, float lr, fl
  * a bad argument. */
 long nnest_format_rows_e5(const double *rows_host, long n_rows, int n_cols, char *out_host, long out_cap, int threads);
 
+/* Host-side (no GPU involved): the rows "<tag>,<step>,<value>\n" of the scalar log (utils.ScalarWriter, which stands where the
+ * reference keeps trainer.writer.add_scalar, nnest/nested.py:467) for a run of steps, the value written as Python's repr(float)
+ * writes it (the shortest digits that read back to the same double, ".0" after an integral value, exponent form below 1e-4 and
+ * from 1e16, "nan" / "inf").  out_host: capacity >= n * (strlen(tag) + 48) + 1 bytes.  Returns the number of bytes written, -1 on
+ * a bad argument.  (Added within ABI 15: host-only, nothing else changed.) */
+long nnest_format_scalar_rows(const char *tag, const long long *steps_host, const double *values_host, long n, char *out_host,
+                              long out_cap);
+
 /* Host-side (no GPU involved): the per-iteration body of the nested-sampling loop while the MCMC strategy is in force --
  * NestedSampler.run, nnest/nested.py:269-293 (worst live point, evidence update, dead-point append), :429-437 (consume the next
  * usable chain of the batch), :458-471 (volume shell, remaining-evidence test) -- as ONE call per event instead of ~7 us of

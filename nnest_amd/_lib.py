@@ -138,6 +138,7 @@ SIGNATURES = {
     'nnest_nvp_loss_grad': [_vp, _vp, _i, _vp, _vp, _vp],
     'nnest_training_jitter': [_vp, _i, _i, _vp, _vp],
     'nnest_format_rows_e5': [_vp, ctypes.c_long, _i, _vp, ctypes.c_long, _i],
+    'nnest_format_scalar_rows': [ctypes.c_char_p, _vp, _vp, ctypes.c_long, _vp, ctypes.c_long],
     'nnest_host_mcmc_consume': [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong,
                                 _d, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong],
     'nnest_host_h_update': [_d, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong],
@@ -165,7 +166,7 @@ def load():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
             fn.argtypes = argtypes
-            fn.restype = (ctypes.c_char_p if name == 'nnest_hip_last_error' else ctypes.c_long if name == 'nnest_format_rows_e5'
+            fn.restype = (ctypes.c_char_p if name == 'nnest_hip_last_error' else ctypes.c_long if name in ('nnest_format_rows_e5', 'nnest_format_scalar_rows')
                           else ctypes.c_double if name == 'nnest_host_h_update' else ctypes.c_int)
         _lib = lib
     return _lib

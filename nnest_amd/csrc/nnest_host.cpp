@@ -5,8 +5,10 @@
 // '\n' after every row).  np.savetxt formats row by row in Python (9 us per 52-column row: 1.8 s for a config-2 chain of 2e5
 // rows, 15 % of the run); here blocks of rows are formatted with snprintf("%.5E") -- the C library's correctly rounded
 // conversion, the same digits Python's '%' produces -- on a few threads.
+#include <charconv>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -45,6 +47,63 @@ extern "C" long nnest_format_rows_e5(const double *rows, long n_rows, int n_cols
         total += used[t];
     }
     return total;
+}
+
+// nnest_format_scalar_rows: "<tag>,<step>,<repr(value)>\n".  repr(float) = the shortest decimal digits that read back to the
+// same double (std::to_chars gives exactly those), laid out as CPython's float_repr does: with decpt = the position of the
+// decimal point relative to the digit string, exponent form "d[.ddd]e+XX" if decpt <= -4 or decpt > 16, else positional with at
+// least one digit either side of the point (".0" after an integral value); "nan", "inf", "-inf".
+static char *repr_double(char *p, double v) {
+    if (std::isnan(v)) { memcpy(p, "nan", 3); return p + 3; }
+    if (std::isinf(v)) { if (v < 0) *p++ = '-'; memcpy(p, "inf", 3); return p + 3; }
+    char sci[40];
+    const auto r = std::to_chars(sci, sci + sizeof sci - 1, v, std::chars_format::scientific);   // [-]d[.ddd]e[+-]XX
+    *r.ptr = 0;
+    const char *q = sci;
+    if (*q == '-') { *p++ = '-'; ++q; }
+    char digits[24] = {0};
+    int nd = 0;
+    for (; q < r.ptr && *q != 'e'; ++q)
+        if (*q != '.') digits[nd++] = *q;
+    const int decpt = (int)strtol(q + 1, nullptr, 10) + 1;
+    if (decpt <= -4 || decpt > 16) {
+        *p++ = digits[0];
+        if (nd > 1) { *p++ = '.'; memcpy(p, digits + 1, nd - 1); p += nd - 1; }
+        return p + snprintf(p, 8, "e%c%02d", decpt - 1 < 0 ? '-' : '+', decpt - 1 < 0 ? 1 - decpt : decpt - 1);
+    }
+    if (decpt <= 0) {
+        *p++ = '0'; *p++ = '.';
+        for (int k = 0; k < -decpt; ++k) *p++ = '0';
+        memcpy(p, digits, nd);
+        return p + nd;
+    }
+    if (decpt >= nd) {
+        memcpy(p, digits, nd); p += nd;
+        for (int k = nd; k < decpt; ++k) *p++ = '0';
+        *p++ = '.'; *p++ = '0';
+        return p;
+    }
+    memcpy(p, digits, decpt); p += decpt;
+    *p++ = '.';
+    memcpy(p, digits + decpt, nd - decpt);
+    return p + (nd - decpt);
+}
+
+extern "C" long nnest_format_scalar_rows(const char *tag, const long long *steps, const double *values, long n, char *out, long out_cap) {
+    if (!tag || !steps || !values || !out || n < 0) return -1;
+    const size_t tl = strlen(tag);
+    if (out_cap < n * (long)(tl + 48) + 1) return -1;
+    char *p = out;
+    for (long i = 0; i < n; ++i) {
+        memcpy(p, tag, tl);
+        p += tl;
+        *p++ = ',';
+        p = std::to_chars(p, p + 21, steps[i]).ptr;
+        *p++ = ',';
+        p = repr_double(p, values[i]);
+        *p++ = '\n';
+    }
+    return p - out;
 }
 
 // ---- the nested-sampling loop's per-iteration body (include/nnest_hip.h; nnest/nested.py:269-293, :429-437, :458-471) ----

@@ -309,6 +309,7 @@ class NestedSampler(Sampler):
         fixed = [P(a) for a in (active_u, active_v, active_logl, active_derived, end_u, end_v, end_logl, moved, end_derived)]
         deadp = [P(dead[k]) for k in ('v', 'logl', 'logwt', 'zprev')]
         stp = ctypes.byref(st)
+        results_f = None
         while True:
             reason = lib.nnest_host_mcmc_consume(stp, N, D, nd, *fixed, C, *deadp, cap, float(dlogz),
                                                  int(max_iters), int(update_interval), int(log_interval))
@@ -365,9 +366,12 @@ class NestedSampler(Sampler):
                     acc = self.total_accepted / max(1, self.total_accepted + self.total_rejected)
                     self.logger.info('Step [%d] loglstar [%5.4e] maxlogl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
                                      'scale [%5.4f]' % (st.it, st.loglstar, st.max_logl, st.logz, np.exp(-st.it / N), total_calls, scale))
-                    with open(os.path.join(self.logs['results'], 'results.csv'), 'a') as f:
-                        csv.writer(f).writerow([st.it, acc, float('nan'), float('nan'), float('nan'), scale, np.float64(st.loglstar),
-                                                np.float64(st.logz), np.float64(st.fraction_remain), total_calls])
+                    # (one handle for the loop, flushed row by row: a config-2 run appends 1000 rows, and open/close per row was 25 ms)
+                    if results_f is None:
+                        results_f = open(os.path.join(self.logs['results'], 'results.csv'), 'a')
+                    csv.writer(results_f).writerow([st.it, acc, float('nan'), float('nan'), float('nan'), scale, np.float64(st.loglstar),
+                                                    np.float64(st.logz), np.float64(st.fraction_remain), total_calls])
+                    results_f.flush()
                 st.resume = _lib.HOST_AFTER_LOG
             elif reason == _lib.HOST_CHECKPOINT:             # nested.py:473-485
                 scalars()
@@ -389,6 +393,8 @@ class NestedSampler(Sampler):
                 st.resume = _lib.HOST_TOP
             else:
                 raise RuntimeError('nnest_host_mcmc_consume returned %d' % reason)
+        if results_f is not None:
+            results_f.close()
         scalars()
         catch_up()
         n = st.n_dead
@@ -590,16 +596,18 @@ class NestedSampler(Sampler):
                             s_x, s_l, s_d, nc = self._density_sample(loglstar)
                         s_x, s_l = np.atleast_2d(s_x), np.ravel(s_l)
                         s_d = np.empty((len(s_l), 0)) if nd == 0 else np.asarray(s_d, dtype=np.float64).reshape(len(s_l), nd)
-                        # one row per candidate: [x | logl | derived], then the call count
-                        pack = np.concatenate([np.concatenate([s_x, s_l[:, None], s_d], axis=1).ravel(), [float(nc)]])
                     if self.use_mpi:
+                        if primary:   # one row per candidate: [x | logl | derived], then the call count
+                            pack = np.concatenate([np.concatenate([s_x, s_l[:, None], s_d], axis=1).ravel(), [float(nc)]])
                         n_rows = rejection_trials if (rejection_trials and current_method == 'rejection_prior') else 1
                         if not primary:
                             pack = np.empty(n_rows * (self.x_dim + 1 + nd) + 1)
                         pack = self._broadcast(pack)
-                    rows = pack[:-1].reshape(-1, self.x_dim + 1 + nd)
-                    samples, loglikes, derived_samples = rows[:, :self.x_dim], rows[:, self.x_dim], rows[:, self.x_dim + 1:]
-                    nc = pack[-1]
+                        rows = pack[:-1].reshape(-1, self.x_dim + 1 + nd)
+                        samples, loglikes, derived_samples = rows[:, :self.x_dim], rows[:, self.x_dim], rows[:, self.x_dim + 1:]
+                        nc = pack[-1]
+                    else:         # (nothing to hand to other ranks: the candidates as they came -- 5 300 iterations of a config-2 run)
+                        samples, loglikes, derived_samples, nc = s_x, s_l, s_d, float(nc)
                     ncs.append(nc)
                     mean_calls = np.mean(ncs[-20:]) if len(ncs) > 20 else 0
                     mcmc_valid = 'mcmc' in strategy and 'mcmc' not in expired_strategies

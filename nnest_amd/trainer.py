@@ -143,12 +143,17 @@ class Trainer(object):
     # ------------------------------------------------------------------------------------------------
     def training_jitter(self, samples):
         """trainer.py:168-171 (jitter < 0): 0.2 * mean(cKDTree(samples).query(samples, 2) distances)"""
+        return float(self._training_jitter_launch(samples).item())
+
+    def _training_jitter_launch(self, samples):
+        """the kernel of training_jitter queued, its result still on the device (train() reads it after it has queued the uploads
+        of the training and validation rows: the read-back waits for work that is already done by then)"""
         x = torch.as_tensor(np.ascontiguousarray(samples, dtype=np.float64)).to(self.gpu)
         out = torch.zeros(1, dtype=torch.float64, device=self.gpu)
         with torch.cuda.device(self.gpu):
             _lib.check(_lib.load().nnest_training_jitter(_lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(out),
                                                          _lib.current_stream(self.gpu)))
-        return float(out.item())
+        return out
 
     def train(self, samples, max_iters=10000, log_interval=100, save_interval=100, jitter=0.0,
               validation_fraction=0.1, patience=50, l2_norm=0.0, split=None, perms=None, noises=None, rng_seed=None):
@@ -168,10 +173,9 @@ class Trainer(object):
                 self._pending_files['originals'] = (np.array(samples), os.path.join(self.path, 'data', 'originals.npy'))
             else:
                 np.save(os.path.join(self.path, 'data', 'originals.npy'), samples)
-        training_jitter = self.training_jitter(samples) if jitter < 0 else jitter
+        jitter_dev = self._training_jitter_launch(samples) if jitter < 0 else None
         if self.log:
             self.logger.info('Number of training samples [%d]' % samples.shape[0])
-            self.logger.info('Training jitter [%5.4f]' % training_jitter)
         # train_test_split(samples, test_size=validation_fraction): ShuffleSplit draws rng.permutation(N) from
         # numpy's global state; test = first n_test, train = next n_train (sklearn/model_selection/_split.py)
         N = samples.shape[0]
@@ -193,6 +197,9 @@ class Trainer(object):
         x_valid = _as_dev_f32(samples[perm_split[:n_valid]], self.gpu)
         x_train = _as_dev_f32(samples[perm_split[n_valid:n_valid + n_train]], self.gpu)
         seed = rng_seed if rng_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
+        training_jitter = float(jitter_dev.item()) if jitter_dev is not None else jitter
+        if self.log:
+            self.logger.info('Training jitter [%5.4f]' % training_jitter)
         result, res, done, all_losses = None, None, 0, []
         while done < max_iters:
             chunk = min(getattr(self.netG, 'epoch_chunk', EPOCH_CHUNK), max_iters - done)
@@ -234,7 +241,9 @@ class Trainer(object):
                 # (the packed weights are read back NOW; the file follows at most SAVE_EVERY seconds later -- and at every checkpoint,
                 # and at the end of the run: a config-2 run retrains 390 times in 4 s, and 390 pickles on the worker thread held the
                 # interpreter lock for 0.2 s of the main thread's time)
-                self._pending_files['netG'] = (self.netG.store_packed() if hasattr(self.netG, 'state_dict_from_packed') else self.netG.state_dict(),
+                # (round 5: for the flows whose weights live in the library handle not even read back -- flush_pending_files() does
+                # that when a file is actually due: 16 read-backs in a config-2 run instead of 392)
+                self._pending_files['netG'] = (None if hasattr(self.netG, 'state_dict_from_packed') else self.netG.state_dict(),
                                                os.path.join(self.path, 'models', 'netG.pt'))
                 if time.time() - getattr(self, '_last_flush', 0.0) >= self.SAVE_EVERY:
                     self.flush_pending_files()
@@ -259,6 +268,10 @@ class Trainer(object):
         pend, self._pending = self._pending_files, {}
         self._last_flush = time.time()
         netG = self.netG
+        if 'netG' in pend and pend['netG'][0] is None:
+            # the weights as they are NOW: nothing trains between the train() that left the entry and this call (train() itself, a
+            # checkpoint or the end of the run, all on the thread that owns the device)
+            pend['netG'] = (netG.store_packed(), pend['netG'][1])
 
         def work():
             if 'originals' in pend:

@@ -81,6 +81,28 @@ class BackgroundJobs(object):
             raise e
 
 
+def _format_scalar_rows(tag, steps, values):
+    """the rows '<tag>,<step>,<repr(value)>\\n' of a run of steps as bytes, formatted by the native library
+    (nnest_format_scalar_rows: no interpreter lock held, which matters on the worker thread of a run -- 230 000 rows at config 2);
+    None where the library is not at hand"""
+    try:
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        ks = np.ascontiguousarray(steps, dtype=np.int64)
+        vs = np.ascontiguousarray(values, dtype=np.float64)
+        if ks.ndim != 1 or ks.shape != vs.shape:
+            return None
+        tagb = str(tag).encode()
+        cap = ks.size * (len(tagb) + 48) + 1
+        buf = np.empty(cap, dtype=np.uint8)
+        n = lib.nnest_format_scalar_rows(tagb, ks.ctypes.data_as(ctypes.c_void_p), vs.ctypes.data_as(ctypes.c_void_p), ks.size,
+                                         buf.ctypes.data_as(ctypes.c_void_p), cap)
+        return None if n < 0 else buf[:n].tobytes()
+    except (OSError, AttributeError, ValueError, RuntimeError, TypeError):
+        return None
+
+
 class ScalarWriter(object):
     """Stands where the reference keeps a TensorBoard SummaryWriter (trainer.py:127-129; used by
     nested.py:467): scalars are appended to <path>/scalars.csv; figures are dropped."""
@@ -128,12 +150,15 @@ class ScalarWriter(object):
         out = []
         for r in rows:
             if isinstance(r, str):
-                out.append(r)
+                out.append(r.encode())
             else:
                 tag, ks, vs = r
-                out.extend(['%s,%s,%r\n' % (tag, k, v) for k, v in zip(ks.tolist(), vs.tolist())])
+                text = _format_scalar_rows(tag, ks, vs)
+                if text is None:
+                    text = ''.join(['%s,%s,%r\n' % (tag, k, v) for k, v in zip(ks.tolist(), vs.tolist())]).encode()
+                out.append(text)
         if out:
-            with open(self.path, 'a') as f:
+            with open(self.path, 'ab') as f:
                 f.writelines(out)
 
     def add_figure(self, *a, **k):

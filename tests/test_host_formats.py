@@ -137,3 +137,22 @@ def test_growing_npy_is_a_valid_npy_after_every_sync(tmp_path):
         s.sync(vals)
         assert np.array_equal(np.load(str(tmp_path / 'v.npy')), np.array(rows).reshape(-1, 3))
         assert np.array_equal(np.load(str(tmp_path / 'l.npy')), np.array(vals))
+
+
+def test_scalar_rows_are_pythons_repr_byte_for_byte():
+    """scalars.csv (the stand-in for trainer.writer.add_scalar, nnest/nested.py:467): the bulk rows are formatted by the native library
+    (nnest_format_scalar_rows, no interpreter lock held on the run's worker thread) and must be the text the single-row path writes
+    -- '%s,%s,%r' -- for every double: shortest round-trip digits, '.0' after integral values, exponent form below 1e-4 and from 1e16,
+    signed zero, denormals, nan and the infinities."""
+    from nnest_amd.utils import _format_scalar_rows
+    rng = np.random.default_rng(5)
+    v = np.concatenate([rng.standard_normal(40000) * 10.0 ** rng.integers(-30, 30, 40000),
+                        rng.integers(-10 ** 17, 10 ** 17, 5000).astype(float),
+                        np.frombuffer(rng.bytes(8 * 20000), dtype=np.float64),
+                        [-2.0, 0.75, 0.0, -0.0, 1e-5, 1.5e-5, 1e-4, 9.9e-5, 123456789012345.0, 1e15, 9999999999999998.0, 1e16, 1e17, 0.1,
+                         1 / 3, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, np.inf, -np.inf, np.nan, -241.37396826186236]])
+    k = rng.integers(-2 ** 62, 2 ** 62, len(v))
+    got = _format_scalar_rows('logz', k, v)
+    assert got is not None, 'the native library is part of the build'
+    assert got.decode() == ''.join('%s,%s,%r\n' % ('logz', a, b) for a, b in zip(k.tolist(), v.tolist()))
+    assert _format_scalar_rows('loss', [], []) == b''

@@ -34,7 +34,7 @@ def _h2d_split(x, device):
         e = T.setdefault(key, [0.0, 0]); e[0] += d; e[1] += 1
     return out
 tmod._as_dev_f32 = _h2d_split
-wrap(tmod.Trainer, 'training_jitter', 'training_jitter')
+wrap(tmod.Trainer, '_training_jitter_launch', 'training_jitter (upload + launch)')
 wrap(tmod.Trainer, 'train', 'Trainer.train')
 _te = nflow.HipNVP.train_epochs
 def _te_events(self, *a, **k):
@@ -80,10 +80,20 @@ def _consume_timed(*a):
 _L.nnest_host_mcmc_consume = _consume_timed
 wrap(NestedSampler, '_mcmc_endpoints_fused', 'K4 batch (launch + read-back)')
 wrap(NestedSampler, '_checkpoint', 'checkpoint')
+if hasattr(NestedSampler, '_mcmc_loop_native'):
+    wrap(NestedSampler, '_mcmc_loop_native', 'MCMC phase (native evidence loop + K4 + retrains)')
+MARK = {}
+_train0 = NestedSampler._train
+def _train_marked(self, *a, **k):
+    MARK.setdefault('first retrain', time.time())
+    return _train0(self, *a, **k)
+NestedSampler._train = _train_marked
 np.random.seed(0); torch.manual_seed(0)
 s = NestedSampler(like.x_dim, like, transform=lambda x: scale * x, log_dir=tempfile.mkdtemp(dir='/tmp'), num_live_points=N, log_level=30, flow=flow)
 t0 = time.time()
 s.run(mcmc_num_chains=N)
 print('wall %.2f s logz %.3f' % (time.time() - t0, s.logz))
+if 'first retrain' in MARK:
+    print('  prior-rejection phase (run() up to the first retrain): %.2f s' % (MARK['first retrain'] - t0))
 for k, (t, n) in sorted(T.items(), key=lambda kv: -kv[1][0]):
     print('  %-32s %8.2f s  %7d calls  %8.3f ms each' % (k, t, n, t / n * 1e3))
