@@ -532,12 +532,16 @@ def main():
                 t_ms.append(e0.elapsed_time(e1))
             ms = float(np.median(t_ms[1:]))
             sp_flops = 136000   # per eval: 2 x 68 k multiply-adds on the matrix cores; the ~150 spline evaluations on top are not counted
-            out['spline_flow'] = {'kernel': 'spline_mh_kernel_team' if (C + 15) // 16 <= 2 * cu else 'spline_mh_kernel',
+            # (the form the library picks, spline_kernels.h: 8-walker pair form while its tiles fit one per CU and x_dim > 32, else
+            # the 16-walker team form, else one wave per tile)
+            sp_kernel = ('spline_mh_kernel_pair' if (D + 1) // 2 > 16 and (C + 7) // 8 <= cu and os.environ.get('NNEST_SPLINE_MH_FORM') != 'team'
+                         else 'spline_mh_kernel_team' if (C + 15) // 16 <= 2 * cu else 'spline_mh_kernel')
+            out['spline_flow'] = {'kernel': sp_kernel,
                                   'kernel_ms': ms, 'evals_per_s': C * S / (ms * 1e-3),
                                   'roofline': {'bound': 'mfma', 'flops_per_unit': sp_flops, 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
                                                'achieved': C * S * sp_flops / (ms * 1e-3) / 1e12,
                                                'frac': C * S * sp_flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                               'kernel': 'spline_mh_kernel_team', 'profile': 'profiles/r05/spline_kernel_stats.csv'},
+                                               'kernel': sp_kernel, 'profile': 'profiles/r05/spline_kernel_stats.csv'},
                                   'note': 'SingleSpeedSpline hidden=%d blocks=%d bins=8; VALU-bound on the spline arithmetic' % (H, B)}
             if C >= 200:  # its training epoch at this population (90 % train / 10 % validation, batch 100: trainer.py:159-176)
                 nv = C // 10

@@ -35,7 +35,13 @@ hipError_t launch_fill_noise(float *dz, float *u, int steps, int C, int D, uint6
                              hipStream_t st);
 int mh_num_groups(int C);
 
-// neural-spline flow (spline_kernels.h inside nnest_kernels.hip; host side in nnest_spline.hip)
+// neural-spline flow (spline_kernels.h inside nnest_kernels.hip; the pair form of the proposal kernel in nnest_spline_mh.hip; host
+// side in nnest_spline.hip)
+struct SplArgs {
+    const float *img;
+    SplineShape sp;
+};
+hipError_t launch_spline_mh_pair(const MhArgs &a, const SplArgs &q, bool dbg, hipStream_t st);   // nnest_spline_mh.hip
 bool spline_shape_supported(const SplineShape &s);
 hipError_t launch_spline_pass(const float *img, const SplineShape &sp, int mode, const float *in, float *out, float *logdet,
                               double *logl, int *inbox, int N, const LikeSpec &like, int num_cu, hipStream_t st);

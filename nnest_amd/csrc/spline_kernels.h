@@ -3,19 +3,18 @@
 // code and the row-major tile I/O are the SAME code the RealNVP path runs.
 //
 //   spline_pass_kernel   forward / inverse / log_probs / inverse + box + likelihood   (networks.py:24-42, :71-76)
-//   spline_mh_kernel     Sampler._mcmc_sample's constrained Metropolis loop with the spline inverse (sampler.py:229-463)
+//   spline_mh_kernel     Sampler._mcmc_sample's constrained Metropolis loop with the spline inverse (sampler.py:229-463);
+//                        _team: four waves per 16-walker tile (small populations); the 8-walker PAIR form, which takes over at
+//                        x_dim > 32 while its tiles fit one per CU, is compiled in nnest_spline_mh.hip
 //
 // One wave per 16 walkers.  The state lives in the parity-class tiles of flow_tile.h (what mh_body, loglike_tile,
 // inbox_tile and load/store_tile work on); around each flow evaluation it is re-laid into the contiguous-halves tiles
 // of spline_tile.h through a 16 x (D+1) float LDS buffer private to the wave.  The weight image (258 KB at x_dim 50) is
 // read from global memory / L2: every fragment load is one coalesced 256-byte line per wave.
 #pragma once
-#include "spline_tile.h"
+#include "spline_train_tile.h"   // (already in at file scope: the fragment-prefetch helpers and the paired coupling of the 8-walker form)
 
-struct SplArgs {
-    const float *img;
-    SplineShape sp;
-};
+// (struct SplArgs: nnest_internal.h)
 
 template <int NT, int NH>
 __global__ void __launch_bounds__(256) spline_pass_kernel(PassArgs a, SplArgs q) {
@@ -172,6 +171,14 @@ static hipError_t launch_spline_mh_t(const MhArgs &a, const SplArgs &q, int num_
     // (eight waves per tile measured slower than four: 12.0 vs 8.0 ms at x_dim 50 -- the 512-thread workgroup halves the
     // register budget and the redundant trunk / affine work grows)
     if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && ntiles > num_cu) return hipErrorInvalidConfiguration;  // batch rule: resident grid only
+    // 8-walker tiles where a wave of the team form has two super-tiles per coupling (x_dim > 32) and they still fit one per CU;
+    // not under the per-16-walker rule (its group is the team form's tile).  NNEST_SPLINE_MH_FORM=team keeps the team form (tests).
+    if constexpr (NT >= 2) {
+        static const bool team_only = [] { const char *e = getenv("NNEST_SPLINE_MH_FORM"); return e && !strcmp(e, "team"); }();
+        const int ntiles8 = (a.C + 7) / 8;
+        const bool group_rule = (a.flags & NNEST_MH_DYNAMIC_STEP) && !(a.flags & NNEST_MH_DYNAMIC_BATCH);
+        if (!team_only && !group_rule && ntiles8 <= num_cu) return launch_spline_mh_pair(a, q, dbg, st);   // nnest_spline_mh.hip
+    }
     if (ntiles <= 2 * num_cu) {  // small population: four waves per walker tile
         const size_t ldsb = (size_t)(((4 * 16 * (q.sp.D + 1) + 3) & ~3) + 4 * NT * 64 * 4 + 4 * 16) * sizeof(float);
         if (dbg) hipLaunchKernelGGL((spline_mh_kernel_team<NT, NH, 4, true>), dim3(ntiles), dim3(256), ldsb, st, a, q);

@@ -271,7 +271,11 @@ __device__ __forceinline__ float spl_coupling(const float *__restrict__ net, int
             // lane (g, w): dimension 4 s + g of the transformed half = slot (t = s >> 2, g, r = s & 3)
             const float x = reg_of(tr[s >> 2], s & 3);
             float l = 0.f;
+#ifdef PROBE_NOEVAL
+            const float y = x + raw[0].x + raw[1].y + raw[2].z + raw[3].w + raw[4].x + raw[5].y;
+#else
             const float y = spl_rqs<INV>(raw, tail, x, l);
+#endif
             const bool valid = 4 * s + g < n_out;
             set_reg(tr[s >> 2], s & 3, valid ? y : 0.f);
             ld += valid ? l : 0.f;
@@ -289,6 +293,14 @@ __device__ __forceinline__ float spl_coupling(const float *__restrict__ net, int
     }
     return ld;
 }
+
+// ---- the two halves of the 16 columns (8-row tiles: lanes w and w ^ 8 carry the same row / walker) --------------------------
+// value of the partner lane w ^ 8 (DPP row_ror:8 inside the 16-lane row)
+__device__ __forceinline__ float half_swap(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+}
+__device__ __forceinline__ f32x4 half_swap4(f32x4 v) { return (f32x4){half_swap(v.x), half_swap(v.y), half_swap(v.z), half_swap(v.w)}; }
+__device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return (f32x4){c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w}; }
 
 // Values made opaque to the optimiser at the top of every block iteration of the TRAINING kernel.  The unrolled coupling
 // bodies derive dozens of masks and offsets from the lane index and the half sizes; all of them are invariant over the

@@ -230,13 +230,8 @@ __device__ __forceinline__ void spl_rawfrags_load(const float *__restrict__ net,
     spl_raw_load<NH>(L4, b4, sB, lane, f.wB, f.bB);
 }
 
-// ---- the two halves of the 16 columns (8-row tiles of the training kernel: lanes w and w ^ 8 carry the same row) ----------------
-// value of the partner lane w ^ 8 (DPP row_ror:8 inside the 16-lane row)
-__device__ __forceinline__ float half_swap(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
-}
-__device__ __forceinline__ f32x4 half_swap4(f32x4 v) { return (f32x4){half_swap(v.x), half_swap(v.y), half_swap(v.z), half_swap(v.w)}; }
-__device__ __forceinline__ f32x4 sel4(bool c, f32x4 a, f32x4 b) { return (f32x4){c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w}; }
+// (half_swap / half_swap4 / sel4 -- the two halves of the 16 columns of an 8-row tile -- live in spline_tile.h: the proposal kernel's
+// 8-walker form uses them too)
 
 // f32x4 per lane that one wave keeps per coupling (spl_coupling_pair): 3 NH activations + 6 per pair of super-tiles
 __host__ __device__ inline int spl_keep_floats4(int NTh, int NH) { return 3 * NH + ((NTh + 1) / 2) * SPL_QT; }
@@ -316,6 +311,94 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
     for (int t = 0; t < NTh; ++t)
         tr[t] = (f32x4){xch[(0 * NTh + t) * 64 + lane].x, xch[(1 * NTh + t) * 64 + lane].y, xch[(2 * NTh + t) * 64 + lane].z, xch[(3 * NTh + t) * 64 + lane].w};
     spl_team_barrier();
+    return ld;
+}
+
+// ---- the proposal kernel's 8-walker form (spline_kernels.h: spline_mh_kernel_pair) ---------------------------------------------
+// spl_coupling<NTh, NH, INV, 4> on an 8-walker tile whose walkers sit in BOTH halves of the 16 columns: wave wv owns the super-tiles
+// s = wv + 4t (register wv of tile t) and takes them two at a time -- tile t in the low half of the columns, tile t + 1 in the high
+// half -- so ONE spline evaluation per lane serves two super-tiles (the matrix work per super-tile is unchanged; the spline
+// arithmetic, the bulk of the instruction stream, halves).  Both halves leave with the full transformed half (results swapped
+// across) and with the same log-det partial, summed in the order spl_coupling sums it: the walkers' values are those of the
+// 16-walker form up to the multiply-add contractions hipcc picks per kernel.
+// (The fragments are loaded where they are used.  Requesting them a coupling ahead, as the training kernel's forward pass does,
+// was measured here and is WORSE -- tools/spline_inv_probe.hip: 38.4 us per inverse against 23.1 without, team form 28.4 -- hipcc
+// parks the early fragments in accumulation registers and waits for every one of them on the way.)
+template <int NTh, int NH, bool INV>
+__device__ __forceinline__ float spl_coupling_halves(const float *__restrict__ net, int S, int n_out, float tail, int lane,
+                                                     const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv, f32x4 *xch) {
+    const int g = lane >> 4;
+    const bool lo = (lane & 15) < 8;
+    f32x4 h[NH];
+    spl_hidden<NTh, NH>(net, lane, cond, h);
+    const float *L4 = net + spl_cond_hidden_floats(NTh, NH);
+    const float *b4 = L4 + (size_t)S * SPL_QT * NH * 256;
+    float ld = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r != wv) continue;  // uniform over the wave
+#pragma unroll
+        for (int k = 0; k < NTh; k += 2) {
+            const int sA = 4 * k + r, sB = 4 * (k + 1) + r;
+            if (sA >= S) continue;
+            const bool hasB = (k + 1 < NTh) && sB < S;
+            f32x4 raw[SPL_QT];
+            spl_raw<NH>(L4, b4, sA, lane, h, raw);
+            float x = reg_of(tr[k], r);
+            if (k + 1 < NTh) {
+                if (hasB) {
+                    f32x4 rawB[SPL_QT];
+                    spl_raw<NH>(L4, b4, sB, lane, h, rawB);
+#pragma unroll
+                    for (int q = 0; q < SPL_QT; ++q) raw[q] = sel4(lo, raw[q], rawB[q]);
+                }
+                x = lo ? x : reg_of(tr[(k + 1 < NTh) ? k + 1 : k], r);
+            }
+            const bool valid = lo ? (4 * sA + g < n_out) : (hasB && 4 * sB + g < n_out);
+            float l = 0.f;
+#ifdef PROBE_NOEVAL
+            const float y = x + raw[0].x + raw[1].y + raw[2].z + raw[3].w + raw[4].x + raw[5].y;
+#else
+            const float y = spl_rqs<INV>(raw, tail, x, l);
+#endif
+            const float yo = valid ? y : 0.f, yp = half_swap(yo);
+            const float lv = valid ? l : 0.f, lp = half_swap(lv);
+            ld += lo ? lv : lp;   // super-tile sA's share, then sB's: spl_coupling's order, in both halves
+            ld += lo ? lp : lv;
+            set_reg(tr[k], r, lo ? yo : yp);
+            if (k + 1 < NTh && hasB) set_reg(tr[(k + 1 < NTh) ? k + 1 : k], r, lo ? yp : yo);
+        }
+    }
+    // super-tile s = 4t + r (register r of tile t) comes from wave r
+#pragma unroll
+    for (int t = 0; t < NTh; ++t) xch[(wv * NTh + t) * 64 + lane] = tr[t];
+    spl_team_barrier();
+#pragma unroll
+    for (int t = 0; t < NTh; ++t)
+        tr[t] = (f32x4){xch[(0 * NTh + t) * 64 + lane].x, xch[(1 * NTh + t) * 64 + lane].y, xch[(2 * NTh + t) * 64 + lane].z, xch[(3 * NTh + t) * 64 + lane].w};
+    spl_team_barrier();
+    return ld;
+}
+
+// the inverse on an 8-walker tile held in both halves of the columns (spl_coupling_halves), four waves per tile
+template <int NTh, int NH>
+__device__ __forceinline__ float spline_inverse_tile_halves(const float *__restrict__ img, const SplineShape &s, int lane, f32x4 (&xs)[2][NTh],
+                                                            int wv, f32x4 *xch) {
+    float ld = 0.f;
+    for (int b = s.B - 1; b >= 0; --b) {
+        const int nu = s.nu, nl = s.nl, SU = s.SU, SL = s.SL;
+        const float *blk = img + (size_t)b * s.blk_floats;
+        const float *f1 = blk + 2 * s.aff_floats, *f2 = f1 + s.f1_floats;
+        ld += spl_coupling_halves<NTh, NH, true>(f2, SL, nl, s.tail, lane, xs[1], xs[0], wv, xch);  // networks.py:605-614
+        ld += spl_coupling_halves<NTh, NH, true>(f1, SU, nu, s.tail, lane, xs[0], xs[1], wv, xch);  // :615-621
+        f32x4 y[2][NTh];
+        spl_affine<NTh>(blk + s.aff_floats, lane, xs, y);
+        if (lane < 16 && wv == 0) ld -= (f2 + s.f2_floats)[0];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < NTh; ++t) xs[c][t] = y[c][t];
+    }
     return ld;
 }
 

@@ -13,6 +13,7 @@ torch = pytest.importorskip('torch')
 from oracle import oracle as orc  # noqa: E402  (checker only)
 
 G = os.path.join(os.path.dirname(__file__), 'golden')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = sorted(glob.glob(os.path.join(G, 'spline_*.npz')))
 IDS = [os.path.basename(p)[7:-4] for p in FILES]
 
@@ -137,9 +138,98 @@ def test_fused_proposal_kernel_vs_oracle(hip, name, C):
     assert torch.equal(z2, z) and torch.equal(logl2, logl) and torch.equal(res2['x'], res['x'])
 
 
-def spline_mcmc_trace(o, z0, logl0, loglstar, step, dz, u):
-    """Sampler._mcmc_sample, hard-constraint branch (sampler.py:291-444), one 16-walker adaptation group, the flow
-    evaluated by the oracle: returns the per-step x / logl histories and the counters."""
+@pytest.mark.parametrize('C,rule', [(40, False), (1000, False), (333, 'batch'), (1000, 'batch')])
+def test_pair_form_of_the_proposal_kernel_vs_oracle(hip, C, rule):
+    """round 5: at x_dim > 32, a fixed step or the batch-wide rule and up to 8 walkers per CU the proposal kernel runs its PAIR form
+    (nnest_spline_mh.hip: 8 walkers per workgroup held in both halves of the matrix-core columns, one spline evaluation per lane
+    serving two super-tiles).  Held to the oracle's restatement of sampler.py:291-444 on the kernel's own noise -- fixed step per
+    16 walkers, the batch rule (lag 0: the reference's own) over the whole batch -- and to the team form it replaces."""
+    g = np.load(os.path.join(G, 'spline_d50.npz'))
+    D, H, B, K = int(g['D']), int(g['H']), int(g['B']), int(g['K'])
+    sp = hip.HipSpline(D, H, B, K, 3.0)
+    sp.load_packed(g['w_trained'], g['P'])
+    sp.data_dep_init_done = True
+    o = orc.Spline(D, H, B, K, 3.0, g['w_trained'], g['P'])
+    rng = np.random.RandomState(C)
+    S = 8
+    init = rng.uniform(-0.5, 0.5, size=(C, D))
+    init_logl = orc.loglike('rosenbrock', init, 5.0)
+    dz, u = sp.fill_noise(S, C, seed=5)
+    z, _ = sp.forward(init)
+    z0 = cpu(z).copy()
+    logl = torch.from_numpy(init_logl).cuda()
+    step = 0.1 / np.sqrt(D)
+    kw = dict(dynamic='batch', lag=0) if rule == 'batch' else dict(dynamic=False)
+    res = sp.mh_steps(0, 5.0, z, logl, -1e12, step, S, seed=5, history=True, **kw)
+    groups = [slice(0, C)] if rule == 'batch' else [slice(g0, min(g0 + 16, C)) for g0 in range(0, min(C, 96), 16)]
+    ngood = 0
+    for sl in groups:
+        tr = spline_mcmc_trace(o, z0[sl], init_logl[sl], -1e12, step, cpu(dz)[:, sl], cpu(u)[:, sl], adapt=rule == 'batch')
+        if tr['ncall'] == int(res['n_call'][sl].sum()) and tr['nacc'] == int(res['n_accept'][sl].sum()):
+            assert rel(cpu(res['hist_x'])[sl], tr['x']) < 3e-4
+            hl = cpu(res['hist_logl'])[sl]
+            assert np.max(np.abs(hl - tr['logl'])) < 2e-3 * (1.0 + np.max(np.abs(tr['logl'])))
+            if rule == 'batch':
+                assert abs(float(res['scale'][0]) - tr['scale']) < 1e-5 * tr['scale']
+                assert float(res['scale'].min()) == float(res['scale'].max())
+            ngood += 1
+        elif rule == 'batch':   # one borderline decision among C x S: the counts may differ by that one, the rule's votes rarely
+            assert abs(tr['nacc'] - int(res['n_accept'][sl].sum())) <= 2 and abs(tr['ncall'] - int(res['n_call'][sl].sum())) <= 2
+            ngood += 1
+    assert ngood >= max(1, len(groups) - 1)
+    assert int(res['n_accept'].sum()) > 0
+    if rule is False:
+        assert np.all(cpu(res['scale']) == np.float32(step))
+    # the production instantiation lands on the same state
+    z2 = torch.from_numpy(z0).cuda()
+    logl2 = torch.from_numpy(init_logl).cuda()
+    res2 = sp.mh_steps(0, 5.0, z2, logl2, -1e12, step, S, seed=5, **kw)
+    assert torch.equal(z2, z) and torch.equal(logl2, logl) and torch.equal(res2['x'], res['x'])
+    assert torch.equal(res2['n_accept'], res['n_accept']) and torch.equal(res2['moved'], res['moved'])
+
+
+def test_pair_form_against_the_team_form(hip):
+    """the same launch through the two small-population forms (NNEST_SPLINE_MH_FORM=team keeps the team form; read once per process,
+    so each form runs in a process of its own): same walkers, same noise streams, the same arithmetic per walker -- up to the
+    multiply-add contractions hipcc chooses per kernel, which can flip a borderline decision: nearly every chain ends on the same
+    point up to rounding, and the accept counts agree to a fraction of a percent"""
+    import subprocess
+    import sys
+    code = '''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from nnest_amd.spline import HipSpline
+import nnest_amd.flow as nflow
+g = np.load(%r)
+sp = HipSpline(int(g['D']), int(g['H']), int(g['B']), int(g['K']), 3.0)
+sp.load_packed(g['w_trained'], g['P']); sp.data_dep_init_done = True
+rng = np.random.RandomState(3)
+init = rng.uniform(-0.5, 0.5, size=(1000, int(g['D'])))
+logl = nflow.loglike(0, init, 5.0, device=torch.device('cuda', 0))
+z, _ = sp.forward(init)
+res = sp.mh_steps(0, 5.0, z, logl, float(logl.min()) - 1.0, 0.1 / np.sqrt(int(g['D'])), 50, seed=11, dynamic=False)
+np.savez(sys.argv[1], x=res['x'].cpu().numpy(), n_accept=res['n_accept'].cpu().numpy(), n_call=res['n_call'].cpu().numpy(), logl=logl.cpu().numpy())
+''' % (ROOT, os.path.join(G, 'spline_d50.npz'))
+    import tempfile
+    out = {}
+    for form in ('pair', 'team'):
+        with tempfile.NamedTemporaryFile(suffix='.npz') as f:
+            env = dict(os.environ, NNEST_SPLINE_MH_FORM=form)
+            subprocess.run([sys.executable, '-c', code, f.name], check=True, env=env, timeout=600)
+            out[form] = dict(np.load(f.name))
+    a, b = out['pair'], out['team']
+    close = np.max(np.abs(a['x'] - b['x']), axis=1) < 1e-4      # (a chain that took the same decisions ends within rounding)
+    assert close.mean() > 0.97, close.mean()
+    assert np.mean(a['n_accept'] == b['n_accept']) > 0.97
+    assert abs(int(a['n_accept'].sum()) - int(b['n_accept'].sum())) <= 0.01 * int(b['n_accept'].sum()) + 5
+    assert int(b['n_accept'].sum()) > 1000
+    np.testing.assert_allclose(a['logl'][close], b['logl'][close], rtol=1e-4, atol=1e-3)
+
+
+def spline_mcmc_trace(o, z0, logl0, loglstar, step, dz, u, adapt=True):
+    """Sampler._mcmc_sample, hard-constraint branch (sampler.py:291-444), one adaptation group (16 walkers under the per-group rule,
+    the whole batch under the reference's own; adapt=False: a fixed step), the flow evaluated by the oracle: returns the per-step
+    x / logl histories and the counters."""
     S, C, D = dz.shape
     z = z0.astype(np.float32).copy()
     x, ld = o.inverse(z)
@@ -162,14 +252,15 @@ def spline_mcmc_trace(o, z0, logl0, loglstar, step, dz, u):
         ncall += int(pre.sum())
         nacc += int(acc.sum())
         z[acc] = zp[acc]; x[acc] = xp[acc]; ld[acc] = ldp[acc]; logl[acc] = lp[acc]
-        if 2 * int(acc.sum()) > C:
-            accept += 1
-        else:
-            reject += 1
-        if accept > reject:
-            scale *= np.exp(1. / (1 + accept))
-        if accept < reject:
-            scale /= np.exp(1. / (1 + reject))
+        if adapt:
+            if 2 * int(acc.sum()) > C:
+                accept += 1
+            else:
+                reject += 1
+            if accept > reject:
+                scale *= np.exp(1. / (1 + accept))
+            if accept < reject:
+                scale /= np.exp(1. / (1 + reject))
         hx.append(x.copy())
         hl.append(logl.copy())
     return dict(x=np.stack(hx, 1), logl=np.stack(hl, 1), ncall=ncall, nacc=nacc, scale=scale)

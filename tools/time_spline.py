@@ -16,12 +16,18 @@ from nnest_amd.spline import HipSpline  # noqa: E402
 
 def main():
     dev = torch.device('cuda', 0)
+    only_d = int(sys.argv[1]) if len(sys.argv) > 1 else None      # (python tools/time_spline.py [D] [walkers]: one case, K4 only)
+    only_c = int(sys.argv[2]) if len(sys.argv) > 2 else None
     for D in (50, 20):
+        if only_d is not None and D != only_d:
+            continue
         sp = HipSpline(D, 16, 3, seed=0)
         rng = np.random.RandomState(0)
         live = rng.uniform(-1, 1, size=(1000, D))
         sp.actnorm_init(live[:100])
         for C, S in ((1000, 5 * D), (65536, 10)):
+            if only_c is not None and C != only_c:
+                continue
             u0 = rng.uniform(-1, 1, size=(C, D))
             z0, _ = sp.forward(u0)
             logl0 = nflow.loglike(0, u0, 5.0, device=dev)
@@ -38,6 +44,8 @@ def main():
             ms = float(np.median(ts[1:]))
             print('K4-spline D=%d walkers=%d steps=%d: %.3f ms per launch -> %.3e evals/s (accept %.2f)' % (
                 D, C, S, ms, C * S / (ms * 1e-3), float(res['n_accept'].sum()) / (C * S)))
+        if only_c is not None:
+            continue
         # training
         E = 40
         perms = torch.stack([torch.randperm(900) for _ in range(E)]).int()
