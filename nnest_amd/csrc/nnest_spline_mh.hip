@@ -5,6 +5,10 @@
 // different dimensions (spl_coupling_halves, spline_train_tile.h), so a wave evaluates one spline per coupling where the team form
 // (spline_kernels.h) evaluates two, and 1000 walkers are 125 workgroups instead of 63.  Same walkers, same streams, the same
 // arithmetic per walker as the team form (the per-16-walker step rule stays with the team form: its adaptation group is the tile).
+// Two more things the team form does not do: the folded ActNorm + 1x1 conv of a block is dealt out over the four waves (one output
+// tile each, exchanged through LDS: every wave of the team form repeats all 64 matrix instructions), and the conditioners' hidden
+// layers -- the part of the image all four waves read -- sit in LDS for the launch (26 KB at x_dim 50).
+// Per 1000 x 250 launch at x_dim 50: team form 7.93 ms; pair form 6.72; + dealt affine 5.98; + trunks in LDS 5.85.
 //
 // Why the flag: the step loop runs 250 times around ~20 000 instructions that derive dozens of masks, offsets and addresses from
 // the lane index.  hipcc's MachineLICM hoists them all out of the loop, runs out of registers and parks them in accumulation
@@ -31,6 +35,7 @@ struct SplineInverseHalves {
     float *buf;     // this wave's 16 x (D+1) layout-exchange buffer
     f32x4 *xch;     // [4][NT][64]
     float *ldred;   // [4][16]
+    const float *trunks;   // the conditioners' hidden parts in LDS (spline_stage_trunks)
     int lane, wv;
 #ifdef NNEST_STAMP
     unsigned long long t_mlp = 0, t_xch = 0, t_upd = 0;
@@ -38,7 +43,7 @@ struct SplineInverseHalves {
     __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
         f32x4 t[2][NT];
         spl_from_parity<NT>(buf, sp.D, sp.nl, lane, xs, t);
-        float ld = group_sum(spline_inverse_tile_halves<NT, NH>(img, sp, lane, t, wv, xch));
+        float ld = group_sum(spline_inverse_tile_halves<NT, NH>(img, sp, lane, t, wv, xch, trunks));
         if (lane < 16) ldred[wv * 16 + lane] = ld;
         spl_team_barrier();
         const int w = lane & 15;
@@ -59,7 +64,10 @@ __global__ void __launch_bounds__(256) spline_mh_kernel_pair(MhArgs a, SplArgs q
     float *bufs = lds_buf;                                                        // 4 x 16 x (D+1)
     f32x4 *xch = reinterpret_cast<f32x4 *>(lds_buf + ((4 * 16 * (q.sp.D + 1) + 3) & ~3));  // 4 x NT x 64 f32x4
     float *ldred = reinterpret_cast<float *>(xch + 4 * NT * 64);                  // 4 x 16
-    SplineInverseHalves<NT, NH> inv = {q.img, q.sp, bufs + (size_t)wv * 16 * (q.sp.D + 1), xch, ldred, lane, wv};
+    float *trunks = ldred + 4 * 16;                                               // B x 2 x spl_cond_hidden_floats
+    spline_stage_trunks<NT, NH>(q.img, q.sp, trunks, threadIdx.x, 256);
+    __syncthreads();
+    SplineInverseHalves<NT, NH> inv = {q.img, q.sp, bufs + (size_t)wv * 16 * (q.sp.D + 1), xch, ldred, trunks, lane, wv};
     XoshiroNoise<NT> noise;
     noise.init(a.seed, a.walker_offset + (uint64_t)(tile * 8 + (lane & 7)), lane >> 4, q.sp.D);
     mh_body<NT, DBG, SplineInverseHalves<NT, NH>, XoshiroNoise<NT>, 8>(a, tile, lane, inv, noise, wv == 0);
@@ -68,7 +76,12 @@ __global__ void __launch_bounds__(256) spline_mh_kernel_pair(MhArgs a, SplArgs q
 template <int NT, int NH>
 static hipError_t launch_pair_t(const MhArgs &a, const SplArgs &q, bool dbg, hipStream_t st) {
     const int ntiles8 = (a.C + 7) / 8;
-    const size_t ldsb = (size_t)(((4 * 16 * (q.sp.D + 1) + 3) & ~3) + 4 * NT * 64 * 4 + 4 * 16) * sizeof(float);
+    const size_t ldsb = (size_t)(((4 * 16 * (q.sp.D + 1) + 3) & ~3) + 4 * NT * 64 * 4 + 4 * 16 + q.sp.B * 2 * spl_cond_hidden_floats(NT, NH)) * sizeof(float);
+    if (ldsb > 64 * 1024) {   // (above 64 KB of dynamic LDS a kernel has to be told so once)
+        hipError_t e = dbg ? hipFuncSetAttribute(reinterpret_cast<const void *>(spline_mh_kernel_pair<NT, NH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(spline_mh_kernel_pair<NT, NH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        if (e != hipSuccess) return e;
+    }
     if (dbg) hipLaunchKernelGGL((spline_mh_kernel_pair<NT, NH, true>), dim3(ntiles8), dim3(256), ldsb, st, a, q);
     else hipLaunchKernelGGL((spline_mh_kernel_pair<NT, NH, false>), dim3(ntiles8), dim3(256), ldsb, st, a, q);
     return hipGetLastError();

@@ -271,7 +271,7 @@ __device__ __forceinline__ float spl_coupling(const float *__restrict__ net, int
             // lane (g, w): dimension 4 s + g of the transformed half = slot (t = s >> 2, g, r = s & 3)
             const float x = reg_of(tr[s >> 2], s & 3);
             float l = 0.f;
-#ifdef PROBE_NOEVAL
+#ifdef PROBE_NOEVAL   // (tools/spline_inv_probe.hip -DPROBE_NOEVAL: the inverse without its spline arithmetic -- never defined in the library)
             const float y = x + raw[0].x + raw[1].y + raw[2].z + raw[3].w + raw[4].x + raw[5].y;
 #else
             const float y = spl_rqs<INV>(raw, tail, x, l);

@@ -321,16 +321,19 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
 // arithmetic, the bulk of the instruction stream, halves).  Both halves leave with the full transformed half (results swapped
 // across) and with the same log-det partial, summed in the order spl_coupling sums it: the walkers' values are those of the
 // 16-walker form up to the multiply-add contractions hipcc picks per kernel.
-// (The fragments are loaded where they are used.  Requesting them a coupling ahead, as the training kernel's forward pass does,
-// was measured here and is WORSE -- tools/spline_inv_probe.hip: 38.4 us per inverse against 23.1 without, team form 28.4 -- hipcc
-// parks the early fragments in accumulation registers and waits for every one of them on the way.)
+// (The last layer's fragments are loaded where they are used.  Requesting them a coupling ahead, as the training kernel's forward pass
+// does, was measured here twice and is WORSE -- 38.4 us per inverse against 23.1 in tools/spline_inv_probe.hip, 6.4 ms per launch
+// against 5.9 in tools/spline_mh_probe.hip: hipcc parks the early fragments in accumulation registers and waits for them on the way.)
+// `trunk`: the conditioner's hidden part (spl_hidden's image: the first spl_cond_hidden_floats of `net`) -- the workgroup's copy in
+// LDS where the kernel keeps one (all four waves read the same 4 KB per coupling: from L2 that is a 0.7 us round trip in front of
+// every trunk; the last layer's 9 KB per wave and coupling do not fit and stay in L2)
 template <int NTh, int NH, bool INV>
-__device__ __forceinline__ float spl_coupling_halves(const float *__restrict__ net, int S, int n_out, float tail, int lane,
+__device__ __forceinline__ float spl_coupling_halves(const float *__restrict__ net, const float *trunk, int S, int n_out, float tail, int lane,
                                                      const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv, f32x4 *xch) {
     const int g = lane >> 4;
     const bool lo = (lane & 15) < 8;
     f32x4 h[NH];
-    spl_hidden<NTh, NH>(net, lane, cond, h);
+    spl_hidden<NTh, NH>(trunk, lane, cond, h);
     const float *L4 = net + spl_cond_hidden_floats(NTh, NH);
     const float *b4 = L4 + (size_t)S * SPL_QT * NH * 256;
     float ld = 0.f;
@@ -356,7 +359,7 @@ __device__ __forceinline__ float spl_coupling_halves(const float *__restrict__ n
             }
             const bool valid = lo ? (4 * sA + g < n_out) : (hasB && 4 * sB + g < n_out);
             float l = 0.f;
-#ifdef PROBE_NOEVAL
+#ifdef PROBE_NOEVAL   // (tools/spline_inv_probe.hip -DPROBE_NOEVAL: the inverse without its spline arithmetic -- never defined in the library)
             const float y = x + raw[0].x + raw[1].y + raw[2].z + raw[3].w + raw[4].x + raw[5].y;
 #else
             const float y = spl_rqs<INV>(raw, tail, x, l);
@@ -380,19 +383,66 @@ __device__ __forceinline__ float spl_coupling_halves(const float *__restrict__ n
     return ld;
 }
 
+// the workgroup's LDS copy of the conditioners' hidden parts: [block][f1 | f2][spl_cond_hidden_floats] (B x 2 x 4.3 KB at x_dim 50)
+template <int NTh, int NH>
+__device__ __forceinline__ void spline_stage_trunks(const float *__restrict__ img, const SplineShape &s, float *trunks, int tid, int nthreads) {
+    constexpr int TF = NH * NTh * 256 + 2 * NH * NH * 256 + 3 * 16 * NH;
+    for (int i = tid; i < s.B * 2 * TF; i += nthreads) {
+        const int c = i / TF, j = i - c * TF;
+        const float *net = img + (size_t)(c >> 1) * s.blk_floats + 2 * s.aff_floats + ((c & 1) ? s.f1_floats : 0);
+        trunks[i] = net[j];
+    }
+}
+
+// spl_affine with its output tiles dealt out over the four waves of the team (tile `to` to wave `to & 3`) and exchanged through LDS
+// (`xch`: at least 2 NTh x 64 f32x4): every wave of the team form repeats all (2 NTh)^2 x 4 matrix instructions -- 64 of them, 0.85 us,
+// per block at x_dim 50.  Same accumulation order as spl_affine: the same values.
+template <int NTh>
+__device__ __forceinline__ void spl_affine_team(const float *__restrict__ aff, int lane, int wv, f32x4 *xch, const f32x4 (&in)[2][NTh],
+                                                f32x4 (&out)[2][NTh]) {
+    constexpr int T2 = 2 * NTh;
+    const int g = lane >> 4;
+    const float *bias = aff + T2 * T2 * 256;
+#pragma unroll
+    for (int to = 0; to < T2; ++to) {
+        if ((to & 3) != wv) continue;  // uniform over the wave
+        float wf[T2 * 4];
+        load_frags<T2 * 4>(aff + (size_t)to * T2 * 256, lane, wf);
+        f32x4 acc0 = *reinterpret_cast<const f32x4 *>(bias + (to * 4 + g) * 4);
+        f32x4 acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ti = 0; ti < T2; ++ti) {
+            const f32x4 v = in[ti / NTh][ti % NTh];
+            acc0 = mfma4(wf[ti * 4 + 0], v.x, acc0);
+            acc1 = mfma4(wf[ti * 4 + 1], v.y, acc1);
+            acc0 = mfma4(wf[ti * 4 + 2], v.z, acc0);
+            acc1 = mfma4(wf[ti * 4 + 3], v.w, acc1);
+        }
+        xch[to * 64 + lane] = acc0 + acc1;
+    }
+    spl_team_barrier();
+#pragma unroll
+    for (int to = 0; to < T2; ++to) out[to / NTh][to % NTh] = xch[to * 64 + lane];
+    spl_team_barrier();
+}
+
 // the inverse on an 8-walker tile held in both halves of the columns (spl_coupling_halves), four waves per tile
+// `trunks`: NULL, or the workgroup's LDS copy of every conditioner's hidden part, [block][f1 | f2][spl_cond_hidden_floats]
+// (spline_stage_trunks)
 template <int NTh, int NH>
 __device__ __forceinline__ float spline_inverse_tile_halves(const float *__restrict__ img, const SplineShape &s, int lane, f32x4 (&xs)[2][NTh],
-                                                            int wv, f32x4 *xch) {
+                                                            int wv, f32x4 *xch, const float *trunks = nullptr) {
     float ld = 0.f;
+    constexpr int TF = NH * NTh * 256 + 2 * NH * NH * 256 + 3 * 16 * NH;   // spl_cond_hidden_floats(NTh, NH)
     for (int b = s.B - 1; b >= 0; --b) {
         const int nu = s.nu, nl = s.nl, SU = s.SU, SL = s.SL;
         const float *blk = img + (size_t)b * s.blk_floats;
         const float *f1 = blk + 2 * s.aff_floats, *f2 = f1 + s.f1_floats;
-        ld += spl_coupling_halves<NTh, NH, true>(f2, SL, nl, s.tail, lane, xs[1], xs[0], wv, xch);  // networks.py:605-614
-        ld += spl_coupling_halves<NTh, NH, true>(f1, SU, nu, s.tail, lane, xs[0], xs[1], wv, xch);  // :615-621
+        const float *t1 = trunks ? trunks + (size_t)(2 * b) * TF : f1, *t2 = trunks ? trunks + (size_t)(2 * b + 1) * TF : f2;
+        ld += spl_coupling_halves<NTh, NH, true>(f2, t2, SL, nl, s.tail, lane, xs[1], xs[0], wv, xch);  // networks.py:605-614
+        ld += spl_coupling_halves<NTh, NH, true>(f1, t1, SU, nu, s.tail, lane, xs[0], xs[1], wv, xch);  // :615-621
         f32x4 y[2][NTh];
-        spl_affine<NTh>(blk + s.aff_floats, lane, xs, y);
+        spl_affine_team<NTh>(blk + s.aff_floats, lane, wv, xch, xs, y);
         if (lane < 16 && wv == 0) ld -= (f2 + s.f2_floats)[0];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
