@@ -323,7 +323,10 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
 // 16-walker form up to the multiply-add contractions hipcc picks per kernel.
 // (The last layer's fragments are loaded where they are used.  Requesting them a coupling ahead, as the training kernel's forward pass
 // does, was measured here twice and is WORSE -- 38.4 us per inverse against 23.1 in tools/spline_inv_probe.hip, 6.4 ms per launch
-// against 5.9 in tools/spline_mh_probe.hip: hipcc parks the early fragments in accumulation registers and waits for them on the way.)
+// against 5.9 in tools/spline_mh_probe.hip: hipcc parks the early fragments in accumulation registers and waits for them on the way.
+// Sending them to a per-wave LDS slot by LDS-DMA instead (global_load_lds, 12 x 1 KB per coupling, issued in front of the spline
+// arithmetic, read back with ds_read_b32) gave the same chains and 6.05 ms: no gain either -- the step is a chain of dependent
+// vector instructions on a lone wave, not a queue of exposed loads.)
 // `trunk`: the conditioner's hidden part (spl_hidden's image: the first spl_cond_hidden_floats of `net`) -- the workgroup's copy in
 // LDS where the kernel keeps one (all four waves read the same 4 KB per coupling: from L2 that is a 0.7 us round trip in front of
 // every trunk; the last layer's 9 KB per wave and coupling do not fit and stay in L2)
