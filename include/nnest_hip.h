@@ -297,7 +297,11 @@ int nnest_spline_inverse(nnest_spline_t *spl, const float *z_dev, float *x_dev, 
 int nnest_spline_log_probs(nnest_spline_t *spl, const float *x_dev, float *logp_dev, int N, void *stream);
 int nnest_spline_inverse_loglike(nnest_spline_t *spl, const nnest_like_t *like, const float *z_dev, float *x_dev,
                                  float *logdet_dev, double *logl_dev, int *inbox_dev, int N, void *stream);
-/* Sampler._mcmc_sample (sampler.py:229-463) with the spline inverse: arguments as nnest_mh_constrained_steps */
+/* Sampler._mcmc_sample (sampler.py:229-463) with the spline inverse: arguments as nnest_mh_constrained_steps.  Kernel forms (chosen
+ * by the library; the walkers' results do not depend on the form beyond float32 rounding): one wave per 16 walkers at large
+ * populations; four waves per 16-walker tile while the tiles fit two per CU; four waves per EIGHT walkers (each held in both
+ * halves of the matrix-core columns: one spline evaluation per lane serves two groups of four dimensions) at x_dim > 32 under a
+ * fixed step or NNEST_MH_DYNAMIC_BATCH while those tiles fit one per CU.  scale_out_dev has one entry per 16 walkers in every form. */
 int nnest_spline_mh_constrained_steps(nnest_spline_t *spl, const nnest_like_t *like, float *z_dev, float *x_dev,
                                       double *logl_dev, double loglstar, float step_size, int steps, int C, int flags,
                                       const float *noise_dz_dev, const float *noise_u_dev, uint64_t seed,
