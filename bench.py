@@ -532,10 +532,7 @@ def main():
                 t_ms.append(e0.elapsed_time(e1))
             ms = float(np.median(t_ms[1:]))
             sp_flops = 136000   # per eval: 2 x 68 k multiply-adds on the matrix cores; the ~150 spline evaluations on top are not counted
-            # (the form the library picks, spline_kernels.h: 8-walker pair form while its tiles fit one per CU and x_dim > 32, else
-            # the 16-walker team form, else one wave per tile)
-            sp_kernel = ('spline_mh_kernel_pair' if (D + 1) // 2 > 16 and (C + 7) // 8 <= cu and os.environ.get('NNEST_SPLINE_MH_FORM') != 'team'
-                         else 'spline_mh_kernel_team' if (C + 15) // 16 <= 2 * cu else 'spline_mh_kernel')
+            sp_kernel = {'pair': 'spline_mh_kernel_pair', 'team': 'spline_mh_kernel_team', 'wave': 'spline_mh_kernel'}[sp.kernel_form_for(C)]   # (asked of the library)
             out['spline_flow'] = {'kernel': sp_kernel,
                                   'kernel_ms': ms, 'evals_per_s': C * S / (ms * 1e-3),
                                   'roofline': {'bound': 'mfma', 'flops_per_unit': sp_flops, 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,

@@ -308,6 +308,11 @@ int nnest_spline_mh_constrained_steps(nnest_spline_t *spl, const nnest_like_t *l
                                       uint64_t walker_offset, float *hist_x_dev, double *hist_logl_dev, int *n_accept_dev,
                                       int *n_call_dev, float *scale_out_dev, void *sync_dev, void *stream);
 
+/* The form of the proposal kernel nnest_spline_mh_constrained_steps runs for C walkers under `flags` (the three above), -1 if the
+ * launch would be refused (the batch-wide rule on a grid that is not resident).  (Added within ABI 15.) */
+enum { NNEST_SPLINE_MH_WAVE = 0, NNEST_SPLINE_MH_TEAM = 1, NNEST_SPLINE_MH_PAIR = 2 };
+int nnest_spline_mh_form_for(const nnest_spline_t *spl, int C, int flags);
+
 /* Training.  ActNorm's data-dependent initialisation (networks.py:698-705): s = -log std(x) (unbiased), t = -mean(x e^s)
  * block after block from the batch x_dev [N,D] -- in the reference this happens inside the first forward pass of a
  * fresh model, which under Trainer.train is the first (jittered) minibatch. */

@@ -324,6 +324,11 @@ int nnest_spline_inverse_loglike(nnest_spline_t *h, const nnest_like_t *like, co
     return NNEST_OK;
 }
 
+int nnest_spline_mh_form_for(const nnest_spline_t *h, int C, int flags) {
+    if (!h || C <= 0) return -1;
+    return spline_mh_form(h->s, C, flags, h->num_cu);
+}
+
 int nnest_spline_mh_constrained_steps(nnest_spline_t *h, const nnest_like_t *like, float *z_dev, float *x_dev, double *logl_dev,
                                       double loglstar, float step_size, int steps, int C, int flags, const float *noise_dz_dev,
                                       const float *noise_u_dev, uint64_t seed, uint64_t walker_offset, float *hist_x_dev,

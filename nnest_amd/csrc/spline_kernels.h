@@ -164,22 +164,40 @@ static hipError_t launch_spline_pass_t(const PassArgs &a, const SplArgs &q, int 
     return hipGetLastError();
 }
 
+// Which form of the proposal kernel runs for C walkers under `flags` (nnest_spline_mh_form_for, include/nnest_hip.h):
+//   NNEST_SPLINE_MH_PAIR  8-walker tiles, each walker in both halves of the columns (nnest_spline_mh.hip): x_dim > 32 (two or more
+//                         16-slot tiles per half -- below that a wave of the team form has one super-tile per coupling already),
+//                         a fixed step or the batch-wide rule (the per-16-walker rule's group is the team form's tile), tiles that
+//                         fit one per CU; NNEST_SPLINE_MH_FORM=team in the environment keeps the team form (tests)
+//   NNEST_SPLINE_MH_TEAM  four waves per 16-walker tile while the tiles fit two per CU
+//   NNEST_SPLINE_MH_WAVE  one wave per 16-walker tile
+// -1: the batch-wide rule on a grid that would not be resident
+int spline_mh_form(const SplineShape &sp, int C, int flags, int num_cu) {
+    const int ntiles = (C + 15) / 16, ntiles8 = (C + 7) / 8;
+    const bool batch = (flags & NNEST_MH_DYNAMIC_BATCH) != 0;
+    if (batch && ntiles > num_cu) return -1;
+    if (sp.NTh >= 2) {
+        static const bool team_only = [] { const char *e = getenv("NNEST_SPLINE_MH_FORM"); return e && !strcmp(e, "team"); }();
+        const bool group_rule = (flags & NNEST_MH_DYNAMIC_STEP) && !batch;
+        if (!team_only && !group_rule && ntiles8 <= num_cu) return NNEST_SPLINE_MH_PAIR;
+    }
+    if (ntiles <= 2 * num_cu) return NNEST_SPLINE_MH_TEAM;
+    int block, grid;
+    pick_geometry(ntiles, num_cu, 4, &block, &grid);
+    if (batch && grid > num_cu) return -1;
+    return NNEST_SPLINE_MH_WAVE;
+}
+
 template <int NT, int NH>
 static hipError_t launch_spline_mh_t(const MhArgs &a, const SplArgs &q, int num_cu, hipStream_t st) {
     const int ntiles = (a.C + 15) / 16;
     const bool dbg = a.noise_dz || a.hist_x || a.hist_logl;
     // (eight waves per tile measured slower than four: 12.0 vs 8.0 ms at x_dim 50 -- the 512-thread workgroup halves the
     // register budget and the redundant trunk / affine work grows)
-    if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && ntiles > num_cu) return hipErrorInvalidConfiguration;  // batch rule: resident grid only
-    // 8-walker tiles where a wave of the team form has two super-tiles per coupling (x_dim > 32) and they still fit one per CU;
-    // not under the per-16-walker rule (its group is the team form's tile).  NNEST_SPLINE_MH_FORM=team keeps the team form (tests).
-    if constexpr (NT >= 2) {
-        static const bool team_only = [] { const char *e = getenv("NNEST_SPLINE_MH_FORM"); return e && !strcmp(e, "team"); }();
-        const int ntiles8 = (a.C + 7) / 8;
-        const bool group_rule = (a.flags & NNEST_MH_DYNAMIC_STEP) && !(a.flags & NNEST_MH_DYNAMIC_BATCH);
-        if (!team_only && !group_rule && ntiles8 <= num_cu) return launch_spline_mh_pair(a, q, dbg, st);   // nnest_spline_mh.hip
-    }
-    if (ntiles <= 2 * num_cu) {  // small population: four waves per walker tile
+    const int form = spline_mh_form(q.sp, a.C, a.flags, num_cu);
+    if (form < 0) return hipErrorInvalidConfiguration;  // batch rule: resident grid only
+    if (form == NNEST_SPLINE_MH_PAIR) return launch_spline_mh_pair(a, q, dbg, st);   // nnest_spline_mh.hip
+    if (form == NNEST_SPLINE_MH_TEAM) {
         const size_t ldsb = (size_t)(((4 * 16 * (q.sp.D + 1) + 3) & ~3) + 4 * NT * 64 * 4 + 4 * 16) * sizeof(float);
         if (dbg) hipLaunchKernelGGL((spline_mh_kernel_team<NT, NH, 4, true>), dim3(ntiles), dim3(256), ldsb, st, a, q);
         else hipLaunchKernelGGL((spline_mh_kernel_team<NT, NH, 4, false>), dim3(ntiles), dim3(256), ldsb, st, a, q);
@@ -187,9 +205,8 @@ static hipError_t launch_spline_mh_t(const MhArgs &a, const SplArgs &q, int num_
     }
     int block, grid;
     pick_geometry(ntiles, num_cu, 4, &block, &grid);
-    if ((a.flags & NNEST_MH_DYNAMIC_BATCH) && grid > num_cu) return hipErrorInvalidConfiguration;  // batch rule: resident grid only
     const size_t lds = (size_t)(block / 64) * 16 * (q.sp.D + 1) * sizeof(float);
-    if (a.noise_dz || a.hist_x || a.hist_logl)
+    if (dbg)
         hipLaunchKernelGGL((spline_mh_kernel<NT, NH, true>), dim3(grid), dim3(block), lds, st, a, q);
     else
         hipLaunchKernelGGL((spline_mh_kernel<NT, NH, false>), dim3(grid), dim3(block), lds, st, a, q);

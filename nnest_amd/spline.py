@@ -46,6 +46,16 @@ class HipSpline(_HipFlow):
         w, P = self.default_init(seed)
         self.load_packed(w, P)
 
+    SPLINE_MH_FORMS = {0: 'wave', 1: 'team', 2: 'pair'}
+
+    def kernel_form_for(self, C, dynamic=False, lag=None):
+        """the form of the proposal kernel `mh_steps` runs for C walkers under this step rule (nnest_spline_mh_form_for): 'pair'
+        (8 walkers per workgroup, each in both halves of the matrix-core columns), 'team' (four waves per 16 walkers), 'wave' (one
+        wave per 16 walkers); None if the launch would be refused.  (Not `mh_form_for`: the spline forms cannot be pinned -- they
+        agree to rounding, not to the bit.)"""
+        f = self._lib.nnest_spline_mh_form_for(self._h, int(C), _lib.mh_flags(dynamic, False, lag, None, 0))
+        return self.SPLINE_MH_FORMS.get(f)
+
     def __del__(self):
         try:
             if getattr(self, '_h', None) is not None and self._h.value:

@@ -188,6 +188,22 @@ def test_pair_form_of_the_proposal_kernel_vs_oracle(hip, C, rule):
     assert torch.equal(res2['n_accept'], res['n_accept']) and torch.equal(res2['moved'], res['moved'])
 
 
+def test_the_library_says_which_proposal_form_runs(hip):
+    """nnest_spline_mh_form_for: pair at x_dim 50 under a fixed step / the batch rule up to 8 walkers per CU, team under the
+    per-16-walker rule, at small x_dim and up to 32 walkers per CU, one wave per tile beyond; the test above therefore drove the
+    pair form"""
+    cu = torch.cuda.get_device_properties(0).multi_processor_count
+    big = hip.HipSpline(50, 16, 3, 8, 3.0)
+    assert big.kernel_form_for(1000) == 'pair' and big.kernel_form_for(40) == 'pair' and big.kernel_form_for(8 * cu) == 'pair'
+    assert big.kernel_form_for(1000, dynamic='batch', lag=0) == 'pair' and big.kernel_form_for(333, dynamic='batch', lag=4) == 'pair'
+    assert big.kernel_form_for(1000, dynamic='group') == 'team'
+    assert big.kernel_form_for(8 * cu + 1) == 'team' and big.kernel_form_for(32 * cu) == 'team'
+    assert big.kernel_form_for(32 * cu + 1) == 'wave'
+    assert big.kernel_form_for(16 * cu + 1, dynamic='batch', lag=0) is None     # the batch rule needs a resident grid
+    small = hip.HipSpline(20, 16, 3, 8, 3.0)
+    assert small.kernel_form_for(1000) == 'team' and small.kernel_form_for(32 * cu + 1) == 'wave'
+
+
 def test_pair_form_against_the_team_form(hip):
     """the same launch through the two small-population forms (NNEST_SPLINE_MH_FORM=team keeps the team form; read once per process,
     so each form runs in a process of its own): same walkers, same noise streams, the same arithmetic per walker -- up to the
