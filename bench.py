@@ -266,8 +266,10 @@ def stub_rank(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # (defaults: 50 + 50 launches of 0.29 ms -- the first few tens of launches of a process run 3-4 % slower than the steady state
+    # the sampler works in, which launches 282 of them per run: clocks and caches; `warmup` is reported in the line)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS), help='BASELINE.json configuration')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--walkers', type=int, default=0, help='walkers per GPU (weak) / in total (strong); 0 = the config')

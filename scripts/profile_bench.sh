@@ -11,7 +11,7 @@ KERN=${2:-mh_kernel_solo<2, false, 0, 4>}   # the kernel the default bench comma
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 20 --warmup 3 --bare"
+BENCH="python3 $PWD/bench.py --steps 50 --warmup 50 --bare"   # (bench.py's defaults)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > /dev/null 2> "$OUT/pmc_fetch.log"
@@ -35,7 +35,7 @@ for d in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
             vals[c] = sum(v) / len(v)
             n = len(v)
 with open('bench_pmc_summary.txt', 'w') as o:
-    o.write('# rocprofv3 PMC passes of `python bench.py --steps 20 --warmup 3 --bare` (scripts/profile_bench.sh %s);\n'
+    o.write('# rocprofv3 PMC passes of `python bench.py --steps 50 --warmup 50 --bare` (scripts/profile_bench.sh %s);\n'
             '# mean per dispatch of %s (%d dispatches); FETCH_SIZE / WRITE_SIZE raw counter units are KiB; SQ cycle counters count '
             '4 clocks\n' % (tag, kern, n))
     for c in sorted(vals):
