@@ -900,22 +900,23 @@ __global__ void __launch_bounds__(TRAIN_THREADS) train_kernel(TrainArgs a) {
 
 // ---- training jitter (trainer.py:168-171): 0.2 * mean over both columns of cKDTree(samples).query(samples, 2)
 // = 0.2 * sum_i nn_dist(i) / (2N).  Brute force in float64: N is the live-point count (<= ~1e4).
-// 16 lanes per row i (lane l scans j = l, l+16, ...), 16 rows per workgroup: N/16 workgroups instead of N/256, and each
-// thread's serial scan is 16x shorter (the first version, one thread per row, took 6.3 ms at N = 1000, D = 50)
+// One wave per row i (lane l scans j = l, l + 64, ...), four rows per workgroup: N / 4 workgroups, each thread's serial scan N / 64
+// rows long (the first version, one thread per row, took 6.3 ms at N = 1000, D = 50; 16 lanes per row 60 us -- which a config-2
+// run waits for 392 times; this one ~20 us).  The minimum over j does not depend on the order it is taken in.
 __global__ void __launch_bounds__(256) nn_distance_kernel(const double *__restrict__ X, int N, int D, double *__restrict__ out) {
-    extern __shared__ double xrow[];  // [16][D]
-    __shared__ double red[16];
-    const int l = threadIdx.x & 15, r = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + r;
-    for (int k = threadIdx.x; k < 16 * D; k += 256) {
-        const int row = blockIdx.x * 16 + k / D;
+    extern __shared__ double xrow[];  // [4][D]
+    __shared__ double red[4];
+    const int l = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + r;
+    for (int k = threadIdx.x; k < 4 * D; k += 256) {
+        const int row = blockIdx.x * 4 + k / D;
         xrow[k] = row < N ? X[(size_t)row * D + k % D] : 0.0;
     }
     __syncthreads();
     const double *xi = xrow + r * D;
     double best = INFINITY;
     if (i < N)
-        for (int j = l; j < N; j += 16) {
+        for (int j = l; j < N; j += 64) {
             if (j == i) continue;
             const double *xj = X + (size_t)j * D;
             double s = 0.0;
@@ -926,7 +927,7 @@ __global__ void __launch_bounds__(256) nn_distance_kernel(const double *__restri
             best = s < best ? s : best;
         }
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
+    for (int o = 1; o < 64; o <<= 1) {
         const double other = __shfl_xor(best, o);
         best = other < best ? other : best;
     }
@@ -934,7 +935,7 @@ __global__ void __launch_bounds__(256) nn_distance_kernel(const double *__restri
     __syncthreads();
     if (threadIdx.x == 0) {
         double tot = 0.0;
-        for (int k = 0; k < 16; ++k) tot += red[k];
+        for (int k = 0; k < 4; ++k) tot += red[k];
         atomicAdd(out, tot * 0.2 / (2.0 * N));
     }
 }
@@ -942,8 +943,8 @@ __global__ void __launch_bounds__(256) nn_distance_kernel(const double *__restri
 hipError_t launch_training_jitter(const double *samples, int N, int D, double *out, hipStream_t st) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
     if (e != hipSuccess) return e;
-    int grid = (N + 15) / 16;
-    hipLaunchKernelGGL(nn_distance_kernel, dim3(grid), dim3(256), (size_t)16 * D * sizeof(double), st, samples, N, D, out);
+    int grid = (N + 3) / 4;
+    hipLaunchKernelGGL(nn_distance_kernel, dim3(grid), dim3(256), (size_t)4 * D * sizeof(double), st, samples, N, D, out);
     return hipGetLastError();
 }
 
