@@ -42,6 +42,7 @@ struct SplArgs {
     SplineShape sp;
 };
 hipError_t launch_spline_mh_pair(const MhArgs &a, const SplArgs &q, bool dbg, hipStream_t st);   // nnest_spline_mh.hip
+hipError_t launch_spline_mh_team(const MhArgs &a, const SplArgs &q, bool dbg, hipStream_t st);   // nnest_spline_mh.hip
 int spline_mh_form(const SplineShape &sp, int C, int flags, int num_cu);   // spline_kernels.h
 bool spline_shape_supported(const SplineShape &s);
 hipError_t launch_spline_pass(const float *img, const SplineShape &sp, int mode, const float *in, float *out, float *logdet,

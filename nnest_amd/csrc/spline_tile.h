@@ -170,6 +170,45 @@ __device__ __forceinline__ void spl_knots(const float (&logits)[SPL_K], float ta
     for (int k = 0; k < SPL_K; ++k) size[k] = edge[k + 1] - edge[k];
 }
 
+// the same for the two axes of a spline at once, {width, height} in the two halves of a float pair: the two constructions are the same
+// instruction stream on different numbers, and on packed operands (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) half of it -- 120 of
+// the ~350 instructions of an evaluation.  Operation for operation what spl_knots does (the exponentials, the reciprocals and the
+// maxima stay scalar): the same values.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void spl_softmax8x2(const f32x2 (&in)[SPL_K], f32x2 (&out)[SPL_K]) {
+    f32x2 mx = in[0];
+#pragma unroll
+    for (int k = 1; k < SPL_K; ++k) { mx.x = fmaxf(mx.x, in[k].x); mx.y = fmaxf(mx.y, in[k].y); }
+    f32x2 s = (f32x2){0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) {
+        const f32x2 d = (in[k] - mx) * 1.4426950408889634f;
+        out[k] = (f32x2){__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
+        s += out[k];
+    }
+    const f32x2 rs = (f32x2){spl_rcp(s.x), spl_rcp(s.y)};
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) out[k] = out[k] * rs;
+}
+__device__ __forceinline__ void spl_knots2(const f32x2 (&logits)[SPL_K], float tail, f32x2 (&edge)[SPL_K + 1], f32x2 (&size)[SPL_K]) {
+    f32x2 a[SPL_K], u[SPL_K], p[SPL_K];
+    spl_softmax8x2(logits, a);
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) u[k] = (2.f * tail) * a[k];
+    spl_softmax8x2(u, p);
+    f32x2 c = (f32x2){0.f, 0.f};
+    edge[0] = (f32x2){-tail, -tail};
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) {
+        const f32x2 wk = 1e-3f + (1.f - 1e-3f * SPL_K) * p[k];
+        c += wk;
+        edge[k + 1] = (2.f * tail) * c + (-tail);
+    }
+    edge[SPL_K] = (f32x2){tail, tail};
+#pragma unroll
+    for (int k = 0; k < SPL_K; ++k) size[k] = edge[k + 1] - edge[k];
+}
+
 // inner-knot derivative k (1..K-1) from its logit: min_derivative + softplus(softplus(v)); the end knots are
 // min_derivative + softplus(log(e^{1 - min_derivative} - 1)) = 1 (networks.py:436-439, :486)
 __device__ __forceinline__ float spl_knot_deriv(const float (&ldv)[SPL_K - 1], int k) {
@@ -187,8 +226,21 @@ __device__ __forceinline__ float spl_rqs(const f32x4 (&raw)[SPL_QT], float tail,
     float ldv[SPL_K - 1] = {raw[4].x, raw[4].y, raw[4].z, raw[4].w, raw[5].x, raw[5].y, raw[5].z};
     const bool inside = x >= -tail && x <= tail;
     float cw[SPL_K + 1], wd[SPL_K], ch[SPL_K + 1], ht[SPL_K];
+#ifdef SPL_KNOTS_SCALAR   // (the two axes one after the other: tools/spline_mh_probe.hip -DSPL_KNOTS_SCALAR, for the A/B)
     spl_knots(lw, tail, cw, wd);
     spl_knots(lh, tail, ch, ht);
+#else
+    {
+        f32x2 l2[SPL_K], e2[SPL_K + 1], s2[SPL_K];
+#pragma unroll
+        for (int k = 0; k < SPL_K; ++k) l2[k] = (f32x2){lw[k], lh[k]};
+        spl_knots2(l2, tail, e2, s2);
+#pragma unroll
+        for (int k = 0; k <= SPL_K; ++k) { cw[k] = e2[k].x; ch[k] = e2[k].y; }
+#pragma unroll
+        for (int k = 0; k < SPL_K; ++k) { wd[k] = s2[k].x; ht[k] = s2[k].y; }
+    }
+#endif
     // searchsorted (networks.py:417-422): edges <= x, last edge + 1e-6
     int bin = -1;
 #pragma unroll

@@ -9,54 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "nnest_spline_mh.hip"   // the pair form as the library compiles it (and mh_body.h inside namespace nnest)
-namespace nnest {
-// (the team form's functor and kernel, from spline_kernels.h)
-// Team form for small populations (fewer walker tiles than CUs): one workgroup of four waves per tile.  All four carry the
-// same proposal state (same noise streams, same decisions); only the spline evaluations of the flow inverse are divided
-// (spl_coupling TEAM = 4), and the log-det partials are summed through LDS.  Wave 0 writes the results.
-template <int NT, int NH, int TEAM>
-struct SplineInverseTeam {
-    const float *img;
-    SplineShape sp;
-    float *buf;     // this wave's 16 x (D+1) layout-exchange buffer
-    f32x4 *xch;     // [TEAM][NT][64]
-    float *ldred;   // [TEAM][16]
-    int lane, wv;
-#ifdef NNEST_STAMP
-    unsigned long long t_mlp = 0, t_xch = 0, t_upd = 0;
-#endif
-    __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
-        f32x4 t[2][NT];
-        spl_from_parity<NT>(buf, sp.D, sp.nl, lane, xs, t);
-        float ld = group_sum(spline_inverse_tile<NT, NH, TEAM>(img, sp, lane, t, wv, xch));
-        if (lane < 16) ldred[wv * 16 + lane] = ld;
-        spl_team_barrier();
-        const int w = lane & 15;
-        ld = 0.f;
-#pragma unroll
-        for (int k = 0; k < TEAM; ++k) ld += ldred[k * 16 + w];
-        spl_team_barrier();
-        spl_to_parity<NT>(buf, sp.D, sp.nl, lane, t, xs);
-        return 0.25f * ld;  // the caller sums the four lanes of a walker
-    }
-};
-
-template <int NT, int NH, int TEAM, bool DBG>
-__global__ void __launch_bounds__(64 * TEAM) spline_mh_kernel_team(MhArgs a, SplArgs q) {
-    extern __shared__ __attribute__((aligned(16))) float lds_buf[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int tile = blockIdx.x;
-    float *bufs = lds_buf;                                                        // TEAM x 16 x (D+1)
-    f32x4 *xch = reinterpret_cast<f32x4 *>(lds_buf + ((TEAM * 16 * (q.sp.D + 1) + 3) & ~3));  // TEAM x NT x 64 f32x4
-    float *ldred = reinterpret_cast<float *>(xch + TEAM * NT * 64);               // TEAM x 16
-    SplineInverseTeam<NT, NH, TEAM> inv = {q.img, q.sp, bufs + (size_t)wv * 16 * (q.sp.D + 1), xch, ldred, lane, wv};
-    XoshiroNoise<NT> noise;
-    noise.init(a.seed, a.walker_offset + (uint64_t)(tile * 16 + (lane & 15)), lane >> 4, q.sp.D);
-    mh_body<NT, DBG>(a, tile, lane, inv, noise, wv == 0);
-}
-
-}  // namespace nnest
+#include "nnest_spline_mh.hip"   // the two forms as the library compiles them (and mh_body.h inside namespace nnest)
 using namespace nnest;
 
 static SplineShape make_shape(int D, int H, int B) {
