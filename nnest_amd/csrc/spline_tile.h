@@ -190,8 +190,10 @@ __device__ __forceinline__ void spl_softmax8x2(const f32x2 (&in)[SPL_K], f32x2 (
 #pragma unroll
     for (int k = 0; k < SPL_K; ++k) out[k] = out[k] * rs;
 }
-__device__ __forceinline__ void spl_knots2(const f32x2 (&logits)[SPL_K], float tail, f32x2 (&edge)[SPL_K + 1], f32x2 (&size)[SPL_K]) {
-    f32x2 a[SPL_K], u[SPL_K], p[SPL_K];
+// (a, p: the two softmax outputs, which the reverse mode of the training kernel needs again -- spl_knots_bwd2)
+__device__ __forceinline__ void spl_knots2(const f32x2 (&logits)[SPL_K], float tail, f32x2 (&edge)[SPL_K + 1], f32x2 (&size)[SPL_K],
+                                           f32x2 (&a)[SPL_K], f32x2 (&p)[SPL_K]) {
+    f32x2 u[SPL_K];
     spl_softmax8x2(logits, a);
 #pragma unroll
     for (int k = 0; k < SPL_K; ++k) u[k] = (2.f * tail) * a[k];
@@ -207,6 +209,11 @@ __device__ __forceinline__ void spl_knots2(const f32x2 (&logits)[SPL_K], float t
     edge[SPL_K] = (f32x2){tail, tail};
 #pragma unroll
     for (int k = 0; k < SPL_K; ++k) size[k] = edge[k + 1] - edge[k];
+}
+
+__device__ __forceinline__ void spl_knots2(const f32x2 (&logits)[SPL_K], float tail, f32x2 (&edge)[SPL_K + 1], f32x2 (&size)[SPL_K]) {
+    f32x2 a[SPL_K], p[SPL_K];
+    spl_knots2(logits, tail, edge, size, a, p);
 }
 
 // inner-knot derivative k (1..K-1) from its logit: min_derivative + softplus(softplus(v)); the end knots are
