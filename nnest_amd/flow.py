@@ -190,16 +190,25 @@ class _HipFlow(object):
             ent = pool.get(int(steps))
             if ent is None:
                 ent = pool[int(steps)] = [torch.zeros(2 * W, dtype=torch.int64, device=dev), 0]
-            half, ent[1] = ent[1], ent[1] ^ 1
+            half = ent[1]
             sync = ent[0][half * W:(half + 1) * W]
             flags |= _lib.MH_SYNC_ZERO_PREV if half else _lib.MH_SYNC_ZERO_NEXT
         with torch.cuda.device(dev):
             lk = _lib.like_spec(like_id, like_scale, like_params)
-            _lib.check(self._sym['mh'](
-                self._h, ctypes.byref(lk), _lib.ptr(z), _lib.ptr(x), _lib.ptr(logl), float(loglstar),
-                float(step_size), int(steps), C, flags, _lib.ptr(dz), _lib.ptr(u),
-                int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), _lib.ptr(hx), _lib.ptr(hl), _lib.ptr(n_acc),
-                _lib.ptr(n_call), _lib.ptr(scale_out), _lib.ptr(sync), _lib.current_stream(dev)))
+            try:
+                _lib.check(self._sym['mh'](
+                    self._h, ctypes.byref(lk), _lib.ptr(z), _lib.ptr(x), _lib.ptr(logl), float(loglstar),
+                    float(step_size), int(steps), C, flags, _lib.ptr(dz), _lib.ptr(u),
+                    int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), _lib.ptr(hx), _lib.ptr(hl), _lib.ptr(n_acc),
+                    _lib.ptr(n_call), _lib.ptr(scale_out), _lib.ptr(sync), _lib.current_stream(dev)))
+            except Exception:
+                # a refused launch ran nothing: the half it was given may or may not be the one the last launch zeroed for it,
+                # and the other half was not zeroed for the launch after -- start the pair over from fresh zeros
+                if sync is not None:
+                    self._sync_pool.pop(int(steps), None)
+                raise
+        if sync is not None:
+            ent[1] ^= 1   # the halves change roles only behind a launch that ran (it zeroed the other one)
         # the kernels report in the count's bit 30 whether EVERY coordinate of the chain's last x differs from its first
         # (include/nnest_hip.h NNEST_MH_ALL_MOVED): the reference's usable-chain test, nested.py:432
         # (split on first use: two element-wise launches that a caller who reads neither does not pay for)

@@ -59,3 +59,37 @@ def test_k5_repeated_launches_never_run_out_of_a_wait_and_repeat_their_bits(hip,
         if ref is None:
             ref = w
         assert np.array_equal(ref, w), 'launch %d: weights differ from the first launch (max %.3g)' % (k, np.abs(ref - w).max())
+
+
+def test_a_refused_launch_does_not_hand_the_next_one_dirty_sync_words(hip):
+    """the double-buffered sync words (flow.mh_steps) changed halves BEFORE the launch was known to have run; a launch the
+    library refuses (here: exact warm-up steps asked of the quad form, NNEST_E_UNSUPPORTED -- what sampler.py's fallback path does)
+    zeroed nothing, and the next launch of the same step count got the half that was dirty from two launches ago.  Successful
+    launches, a refused one, successful ones again: no wait runs out, and the chains are those of a flow that never saw the refusal."""
+    D, C, S = 50, 1000, 60
+    u0 = np.random.RandomState(0).uniform(-1, 1, size=(C, D))
+    l0 = hip.loglike(0, u0, 5.0)
+    star, step = float(l0.min()), 1 / np.sqrt(D)
+    kw = dict(form='solo', dynamic='batch', lag=8, warm=16)
+
+    def launch(nvp, seed, **over):
+        z, _ = nvp.forward(u0)
+        l = l0.clone()
+        res = nvp.mh_steps(0, 5.0, z, l, star, step, S, seed=seed, **dict(kw, **over))
+        hip.HipNVP.check_sync(res)
+        return res['x'].clone(), l, res['n_accept'].clone(), float(res['scale'][0].item())
+
+    clean = hip.HipNVP(D, 16, 3, 1, seed=0)
+    want = [launch(clean, k) for k in range(6)]
+    nvp = hip.HipNVP(D, 16, 3, 1, seed=0)
+    got = [launch(nvp, k) for k in range(3)]
+    for _ in range(2):   # (an odd and an even number of refusals in a row)
+        with pytest.raises(hip._lib.NnestHipError):
+            launch(nvp, 99, form='quad')
+        got.append(launch(nvp, len(got)))
+    with pytest.raises(hip._lib.NnestHipError):
+        launch(nvp, 99, form='quad')
+    got.append(launch(nvp, len(got)))
+    assert len(got) == 6
+    for a, b in zip(got, want):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3]
