@@ -223,39 +223,82 @@ def logz_report(dev, live_run):
     return out
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, timeout_s=1800.0):
     """`--gpus n` without an outer launcher: n fresh child processes, one per GPU (never an exec of a process that has touched
-    a GPU: the parent has not), rank 0's stdout relayed, non-zero exit if any rank fails."""
+    a GPU: the parent has not), rank 0's stdout relayed.  ALL children are polled: the first one that exits non-zero is named, its
+    siblings are terminated (they would otherwise sit in the rendezvous or in a collective until the store's timeout, minutes) and
+    the parent exits non-zero within seconds; `--launch-timeout` bounds the whole run the same way.  Each child gets its own
+    process group, so a teardown takes the rank's helpers with it and nothing else."""
     import socket
     import subprocess
-    with socket.socket() as sk:   # a free rendezvous port on the loopback
+    import tempfile
+    with socket.socket() as sk:   # a free rendezvous port on the loopback (probed, then closed: taken again by rank 0's store)
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
-    procs = []
+    procs, out0 = [], tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', str(port)), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, start_new_session=True,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+
+    def teardown():
+        import signal
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except (ProcessLookupError, PermissionError):
+                    pass
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+                p.wait()
+
+    t0, failed = time.monotonic(), None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = 'rank %d exited with code %d' % bad[0] + (' (and %d more)' % (len(bad) - 1) if len(bad) > 1 else '')
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() - t0 > timeout_s:
+                failed = 'no result after %.0f s (--launch-timeout); still running: ranks %s' % (
+                    timeout_s, ', '.join(str(r) for r, c in enumerate(codes) if c is None))
+                break
+            time.sleep(0.05)
+    finally:
+        teardown()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        raise SystemExit('bench.py --gpus %d: rank(s) failed: %s' % (n, ', '.join('%d (exit %d)' % rc for rc in bad)))
+    if failed:
+        raise SystemExit('bench.py --gpus %d: %s; the other ranks were stopped' % (n, failed))
 
 
 def stub_rank(args, rank, world):
     """NNEST_BENCH_STUB=1: the launcher / rendezvous / one-line plumbing on CPUs (gloo), no kernel: what the `not gpu` test of
     `--gpus N` runs.  The line says so (`stub`: true) and carries no measurement."""
     import torch.distributed as dist
+    die = os.environ.get('NNEST_BENCH_STUB_DIE', '')   # "rank:code": that rank exits before the rendezvous (the launcher's fail-fast test)
+    if die and int(die.split(':')[0]) == rank:
+        raise SystemExit(int(die.split(':')[1]))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     dist.init_process_group('gloo')
     dist.barrier()
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)   # the max-over-ranks reduction of the timed region
     if rank == 0:
+        assert dist.get_world_size() == world == args.gpus
         print(json.dumps({'metric': METRIC % CONFIGS[args.config][1], 'value': None, 'unit': 'evals/s', 'n_gpus': world,
                           'rccl_ranks': dist.get_world_size(), 'collective_backend': dist.get_backend(), 'steps': args.steps,
                           'warmup': args.warmup, 'stub': True, 'max_over_ranks': float(t.item())}))
@@ -281,12 +324,13 @@ def main():
     ap.add_argument('--no-spline', action='store_true')
     ap.add_argument('--no-logz', action='store_true', help='skip the live nested run (the fixtures are still reported)')
     ap.add_argument('--bare', action='store_true', help='the timed launches only (profiling runs: scripts/profile_bench.sh)')
+    ap.add_argument('--launch-timeout', type=float, default=1800.0, help='--gpus N launcher: seconds before the ranks are stopped')
     args = ap.parse_args()
     if args.bare:
         args.no_cpu_baseline = args.no_saturation = args.no_spline = args.no_logz = True
 
     if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or os.environ.get('NNEST_BENCH_LAUNCHER') == '1'):
-        return launch_ranks(args.gpus, sys.argv[1:])   # (NNEST_BENCH_LAUNCHER=1: also for one rank -- the launcher path under test)
+        return launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout)   # (NNEST_BENCH_LAUNCHER=1: also for one rank -- the launcher path under test)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -297,6 +341,9 @@ def main():
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit('bench.py needs an MI355X (no GPU visible); there is no CPU fallback')
+    if os.environ.get('NNEST_BENCH_BACKEND', 'nccl') == 'nccl' and ndev <= local_rank:
+        raise SystemExit('bench.py rank %d: LOCAL_RANK %d but only %d GPU(s) visible (one rank per GPU: --gpus %d needs %d devices)'
+                         % (rank, local_rank, ndev, args.gpus, args.gpus))
     # one rank per GPU; NNEST_BENCH_BACKEND=gloo is a single-GPU smoke test of the multi-rank code path only
     backend = os.environ.get('NNEST_BENCH_BACKEND', 'nccl')
     dev_index = local_rank if backend == 'nccl' else local_rank % ndev
@@ -461,6 +508,9 @@ def main():
             'device': info['name'],
         }
         out['rccl_ranks'] = dist.get_world_size() if dist is not None else 1
+        if not (out['n_gpus'] == out['rccl_ranks'] == world == args.gpus):   # the line must not claim GPUs the collectives did not span
+            raise SystemExit('bench.py: n_gpus %r, rccl_ranks %r, WORLD_SIZE %d, --gpus %d disagree'
+                             % (out['n_gpus'], out['rccl_ranks'], world, args.gpus))
         out['collective_backend'] = dist.get_backend() if dist is not None else None
         out['step_rule_scope'] = ('whole batch' if world == 1 else
                                   'per rank: under sharding every rank applies the batch-wide rule to ITS walkers (DESIGN.md 6)')

@@ -198,6 +198,33 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert bad.returncode != 0 and '--gpus 2 but WORLD_SIZE=1' in bad.stderr
 
 
+def test_bench_launcher_fails_fast_when_a_rank_dies():
+    """Round-5 verdict item 6 / ADVICE r05: `launch_ranks` used to block on rank 0's pipe -- a rank that died at start left rank 0 in
+    the rendezvous until the store's timeout (minutes) before the parent said anything.  Rank 1 exits 3 before the rendezvous: the
+    parent names it, stops rank 0 and returns non-zero within seconds.  And the overall timeout stops ranks that never finish."""
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(NNEST_BENCH_STUB='1', NNEST_BENCH_STUB_DIE='1:3')
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'], cwd=root,
+                         env=env, capture_output=True, text=True, timeout=120)
+    took = time.time() - t0
+    assert out.returncode != 0 and 'rank 1 exited with code 3' in out.stderr, out.stderr[-2000:]
+    assert took < 30, took
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]   # no line from a run that did not happen
+    # rank 0 dies instead: rank 1 is the one left waiting
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], cwd=root,
+                         env=dict(env, NNEST_BENCH_STUB_DIE='0:5'), capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and 'rank 0 exited with code 5' in out.stderr
+    # nobody dies, nobody finishes in time: a launch timeout shorter than the interpreter's start-up
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--launch-timeout', '0.2'], cwd=root,
+                         env={k: v for k, v in env.items() if k != 'NNEST_BENCH_STUB_DIE'}, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and '--launch-timeout' in out.stderr and time.time() - t0 < 30
+
+
 def _guard_worker(rank, world, port, tmp, out):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
