@@ -17,6 +17,7 @@ Fixture families:
                       every gradient, post-Adam weights and moments (nnest/trainer.py:384-418)
   G5 mcmc_*.npz       Sampler._mcmc_sample traces with recorded proposal noise
                       (nnest/sampler.py:229-463)
+  G5b mcmc_spline_*.npz  the same on the reference's default flow (flow='spline', nnest/networks.py:458-556, :708-715)
   G6 nested_cfg1.json seeded end-to-end NestedSampler.run on config 1 (nnest/nested.py:97-510)
   G7 trainrun_*.npz   Trainer.train() for a few epochs: split, per-epoch perms, noise, losses
                       (nnest/trainer.py:134-245)
@@ -364,6 +365,55 @@ def gen_mcmc():
         moved = np.mean(np.any(samples[:, 0] != samples[:, -1], axis=1))
         print('G5 mcmc', name, 'ncall', ncall, 'scale', scale_out, 'moved frac', moved,
               'acc', s.total_accepted, 'rej', s.total_rejected)
+
+
+def gen_mcmc_spline():
+    """G5b mcmc_spline_*.npz: Sampler._mcmc_sample (nnest/sampler.py:291-444) on the reference's DEFAULT flow (flow='spline':
+    NSF_CL couplings, nnest/networks.py:458-556, behind ActNorm + 1x1 conv) with the torch.randn_like / torch.rand draws recorded:
+    every accept / reject decision of the reference itself, fixed and dynamic step, x_dim 5 and 50 (round-5 verdict item 2)."""
+    cases = [('rosen_d5', Rosenbrock, 5, 5.0, 16, 24, False, 10, 1.0), ('rosen_d5_dyn', Rosenbrock, 5, 5.0, 16, 40, True, 10, 1.0),
+             ('rosen_d50', Rosenbrock, 50, 5.0, 16, 16, False, 6, 0.25), ('rosen_d50_dyn', Rosenbrock, 50, 5.0, 16, 30, True, 6, 1.0),
+             ('rosen_d50_c40_dyn', Rosenbrock, 50, 5.0, 40, 16, True, 6, 1.0)]
+    for name, cls, D, scale, C, S, dyn, iters, step_f in cases:
+        np.random.seed(9)
+        torch.manual_seed(9)
+        like = cls(D)
+        tmp = tempfile.mkdtemp()
+        s = NestedSampler(D, like, transform=lambda x, sc=scale: sc * x, log_dir=tmp, flow='spline',
+                          num_live_points=400, learning_rate=1e-3, log_level=logging.WARNING)
+        live_u = s.sample_prior(400)
+        live_logl, _ = s.loglike(live_u)
+        order = np.argsort(live_logl)
+        live_u = live_u[order[100:]]
+        live_logl = live_logl[order[100:]]
+        s.trainer.train(live_u, max_iters=iters, jitter=0.01)
+        s.trainer.path = None
+        loglstar = float(np.min(live_logl))
+        idx = np.random.randint(0, live_u.shape[0], size=C)
+        init = live_u[idx]
+        init_l = live_logl[idx]
+        step = step_f / np.sqrt(D)
+        torch.manual_seed(77)
+        rng_state = torch.get_rng_state()
+        dzs, us = [], []
+        for _ in range(S):
+            dzs.append(torch.randn(C, D).numpy())   # torch.randn_like(z)   sampler.py:310
+            us.append(torch.rand(C).numpy())        # torch.rand(shape)     sampler.py:334
+        torch.set_rng_state(rng_state)
+        calls0, acc0, rej0 = s.total_calls, s.total_accepted, s.total_rejected
+        samples, latent, derived, loglikes, scale_out, ncall = s._mcmc_sample(
+            S, init_samples=init, init_loglikes=init_l, init_derived=np.empty((C, 0)),
+            loglstar=loglstar, step_size=step, dynamic_step_size=dyn, plot_trace=False)
+        np.savez_compressed(
+            os.path.join(OUT, 'mcmc_spline_%s.npz' % name), D=D, H=16, B=3, K=8, tail=3.0, like=cls.__name__, scale=scale,
+            w=pack_state_dict(s.trainer.netG), P=spline_P(s.trainer.netG), init=init, init_logl=init_l, loglstar=loglstar, step=step,
+            dynamic=dyn, dz=np.stack(dzs), u=np.stack(us), samples=samples, latent=latent,
+            loglikes=loglikes, scale_out=scale_out, ncall=ncall, total_calls=s.total_calls - calls0,
+            total_accepted=int(s.total_accepted - acc0), total_rejected=int(s.total_rejected - rej0))
+        shutil.rmtree(tmp, ignore_errors=True)
+        moved = np.mean(np.any(samples[:, 0] != samples[:, -1], axis=1))
+        print('G5b mcmc spline', name, 'ncall', ncall, 'scale', scale_out, 'moved frac', moved,
+              'acc', s.total_accepted - acc0, 'rej', s.total_rejected - rej0)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -795,8 +845,8 @@ def gen_cholesky():
 if __name__ == '__main__':
     if 'cholesky' in (sys.argv[1:] or ['cholesky']):
         gen_cholesky()
-    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'nested', 'scale', 'spline', 'base', 'fastslow',
-                             'fastslowspline']
+    which = sys.argv[1:] or ['flow', 'like', 'like2', 'train', 'trainrun', 'mcmc', 'mcmcspline', 'nested', 'scale', 'spline', 'base',
+                             'fastslow', 'fastslowspline']
     if 'fastslowspline' in which:
         gen_fastslow_spline()
     if 'fastslow' in which:
@@ -819,6 +869,8 @@ if __name__ == '__main__':
         gen_train_run()
     if 'mcmc' in which:
         gen_mcmc()
+    if 'mcmcspline' in which:
+        gen_mcmc_spline()
     if 'nested' in which:
         gen_nested()
     if 'formats' in which:

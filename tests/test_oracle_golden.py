@@ -176,6 +176,30 @@ def test_mcmc_sample_trace(path):
     assert rel(loglikes, g['loglikes']) < (1e-4 if np.isnan(float(g['loglstar'])) else 2e-5)
 
 
+MCMC_SPLINE_FILES = sorted(glob.glob(os.path.join(G, 'mcmc_spline_*.npz')))
+
+
+@pytest.mark.parametrize('path', MCMC_SPLINE_FILES, ids=[os.path.basename(p)[12:-4] for p in MCMC_SPLINE_FILES])
+def test_mcmc_sample_trace_spline_flow(path):
+    """round-5 verdict item 2: the reference's own accept / reject decisions on its DEFAULT flow (flow='spline': NSF_CL couplings,
+    nnest/networks.py:458-556) -- Sampler._mcmc_sample (nnest/sampler.py:291-444) with torch's draws recorded
+    (oracle/gen_golden.py::gen_mcmc_spline) -- replayed through the oracle's spline flow: every decision, every state, the final
+    scale.  The GPU proposal kernels are held to the same fixtures in tests/test_gpu_spline.py."""
+    from tests.mh_checks import spline_mcmc_trace
+    g = np.load(path)
+    D = int(g['D'])
+    o = orc.Spline(D, int(g['H']), int(g['B']), int(g['K']), float(g['tail']), g['w'], g['P'])
+    z0, _ = o.forward(g['init'].astype(np.float32))          # sampler.py:264
+    assert rel(z0, g['latent'][:, 0]) < 2e-5
+    tr = spline_mcmc_trace(o, z0, g['init_logl'], float(g['loglstar']), float(g['step']), g['dz'], g['u'], adapt=bool(g['dynamic']),
+                           like='rosenbrock', like_scale=float(g['scale']))
+    assert tr['ncall'] == int(g['ncall']) and tr['nacc'] == int(g['total_accepted'])
+    assert abs(tr['scale'] - float(g['scale_out'])) < 1e-12 * max(1.0, abs(tr['scale']))
+    assert rel(tr['z'], g['latent']) < 2e-5
+    assert rel(tr['x'], g['samples']) < 2e-5
+    assert rel(tr['logl'], g['loglikes']) < 5e-5
+
+
 def test_lagged_step_rule_schedules_against_the_reference_rule():
     """the build-defined schedules of the step rule (orc_set_step_lag / orc_set_step_warm: what the GPU's batch-wide mode runs)
     against the reference's rule (lag 0, pinned by the golden traces above) on one set of noise: a lag L leaves the first L + 1
