@@ -395,6 +395,34 @@ int nnest_host_mcmc_consume(nnest_host_state_t *state, int N, int D, int nd, dou
                             const unsigned char *moved, const double *end_derived, int C, double *dead_v, double *dead_logl,
                             double *dead_logwt, double *dead_logz_prev, long long dead_cap, double dlogz, long long max_iters,
                             long long update_interval, long long log_interval);
+/* The same loop while 'rejection_prior' is the strategy in force (nnest/nested.py:322-334, :362-373 over
+ * Sampler._rejection_prior_sample, nnest/sampler.py:529-543): the reference draws one prior sample per likelihood call until one lies
+ * above loglstar; the draws are independent, so the caller evaluates them a block per launch and hands over the block's candidates
+ * -- the indices (ascending) that were above the threshold when the block was made, cand_logl32 (the kernel's likelihood of
+ * float32(x)) and cand_logl64 (the reference's float64 one) per candidate, their rows cand_u / transformed rows cand_v [n_cand, D],
+ * derived [n_cand, nd].  Candidates are examined in order, each once; an iteration's call count is the number examined up to and
+ * including the accepted one (blocks used up without a hit carry over in pending_calls).  Returns as nnest_host_mcmc_consume, plus
+ *   NNEST_HOST_NEED_SAMPLES  no block / block used up: make one of prior.block_next draws, set prior.n / n_cand / pos = k = hits = 0,
+ *                            resume = NNEST_HOST_AFTER_SAMPLES
+ *   NNEST_HOST_EXPIRED       the strategy expired in the pass before (volume_switch, or the last 20 call counts average more than
+ *                            mcmc_steps and MCMC is available: nested.py:328-334); nothing of the next pass has been done.
+ * NNEST_HOST_LOG here is nested.py:374-378 ((it + 1) % log_interval == 0).  (Added within ABI 15: host-only.) */
+enum { NNEST_HOST_EXPIRED = 6 };
+typedef struct {
+    long long pos, k, hits, n, n_cand;   /* the walk through the current block */
+    long long pending_calls;             /* candidates examined since the last accepted one, in blocks used up */
+    long long total_calls;               /* Sampler.total_calls (sampler.py:119) */
+    long long block_next;                /* size of the next block */
+    double ncs[20];                      /* the last 20 call counts (nested.py:325-326) */
+    double mean_calls;
+    int ncs_len, expired;
+} nnest_host_prior_t;
+int nnest_host_prior_consume(nnest_host_state_t *state, nnest_host_prior_t *prior, int N, int D, int nd, double *active_u,
+                             double *active_v, double *active_logl, double *active_derived, const long long *cand_idx,
+                             const double *cand_logl32, const double *cand_logl64, const double *cand_u, const double *cand_v,
+                             const double *cand_derived, double *dead_v, double *dead_logl, double *dead_logwt,
+                             double *dead_logz_prev, long long dead_cap, double dlogz, long long max_iters, long long log_interval,
+                             double volume_switch, double mcmc_steps, int mcmc_valid);
 /* h <- exp(logwt - total) * logl + exp(logz_prev - total) * (h + logz_prev) - total  over n dead points (nested.py:281-283), the two
  * exponentials supplied by the caller (e1, e2); every operation rounded by itself.  Returns the new h. */
 double nnest_host_h_update(double h, const double *e1, const double *e2, const double *logl, const double *logz_prev,

@@ -143,8 +143,11 @@ SIGNATURES = {
     'nnest_host_mcmc_consume': [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong,
                                 _d, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong],
     'nnest_host_h_update': [_d, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong],
+    'nnest_host_prior_consume': [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 ctypes.c_longlong, _d, ctypes.c_longlong, ctypes.c_longlong, _d, _d, _i],
 }
 HOST_FINISHED, HOST_RETRAIN, HOST_NEED_SAMPLES, HOST_LOG, HOST_CHECKPOINT, HOST_DEAD_FULL = range(6)   # include/nnest_hip.h NNEST_HOST_*
+HOST_EXPIRED = 6
 HOST_TOP, HOST_AFTER_TRAIN, HOST_AFTER_SAMPLES, HOST_AFTER_LOG = range(4)
 
 
@@ -152,6 +155,13 @@ class HostState(ctypes.Structure):   # nnest_host_state_t
     _fields_ = [('logz', _d), ('logvol', _d), ('fraction_remain', _d), ('max_logl', _d), ('loglstar', _d),
                 ('it', ctypes.c_longlong), ('n_dead', ctypes.c_longlong),
                 ('accept_point', _i), ('nb', _i), ('first_time', _i), ('resume', _i), ('worst', _i), ('pad_', _i)]
+
+
+class HostPrior(ctypes.Structure):   # nnest_host_prior_t
+    _fields_ = [('pos', ctypes.c_longlong), ('k', ctypes.c_longlong), ('hits', ctypes.c_longlong), ('n', ctypes.c_longlong),
+                ('n_cand', ctypes.c_longlong), ('pending_calls', ctypes.c_longlong), ('total_calls', ctypes.c_longlong),
+                ('block_next', ctypes.c_longlong), ('ncs', _d * 20), ('mean_calls', _d), ('ncs_len', _i), ('expired', _i)]
+
 
 _lib = None
 

@@ -198,6 +198,110 @@ extern "C" int nnest_host_mcmc_consume(nnest_host_state_t *st, int N, int D, int
     }
 }
 
+// ---- the same loop while 'rejection_prior' is the strategy in force (nnest/nested.py:322-334, :362-373; Sampler._rejection_prior_sample,
+// nnest/sampler.py:529-543) -------------------------------------------------------------------------------------------------
+// The reference draws one prior sample per likelihood call until one lies above loglstar.  The draws are independent, so the host
+// driver evaluates them a block per launch of the likelihood kernel (nnest_amd/sampler.py::_rejection_prior_sample) and walks the
+// block: candidates are examined in order, each once; the first above the threshold is this iteration's new live point and the
+// iteration's call count is the number of candidates examined up to and including it.  What this function is handed is the
+// block's candidate list -- the (sorted) indices that were above the threshold when the block was made, with their float32-input
+// and float64 likelihoods, their rows and their transformed rows: the threshold only rises, so every later hit is among them.
+extern "C" int nnest_host_prior_consume(nnest_host_state_t *st, nnest_host_prior_t *pr, int N, int D, int nd, double *active_u,
+                                        double *active_v, double *active_logl, double *active_derived, const long long *cand_idx,
+                                        const double *cand_logl32, const double *cand_logl64, const double *cand_u, const double *cand_v,
+                                        const double *cand_derived, double *dead_v, double *dead_logl, double *dead_logwt,
+                                        double *dead_logz_prev, long long dead_cap, double dlogz, long long max_iters,
+                                        long long log_interval, double volume_switch, double mcmc_steps, int mcmc_valid) {
+    const int W = D + nd;
+    int resume = st->resume;
+    st->resume = NNEST_HOST_TOP;
+    for (;;) {
+        if (resume == NNEST_HOST_TOP) {
+            if (!(st->fraction_remain > dlogz && st->it <= max_iters)) return NNEST_HOST_FINISHED;   // nested.py:269
+            if (pr->expired) return NNEST_HOST_EXPIRED;              // the next pass takes the next strategy (nested.py:300-306)
+            if (st->accept_point && st->n_dead >= dead_cap) return NNEST_HOST_DEAD_FULL;
+            int worst = 0;                                           // np.argmin: the first smallest (nested.py:272)
+            for (int i = 1; i < N; ++i)
+                if (active_logl[i] < active_logl[worst]) worst = i;
+            st->worst = worst;
+            st->loglstar = active_logl[worst];
+            if (st->accept_point) {                                  // nested.py:280-293
+                const double logwt = st->logvol + active_logl[worst];
+                const long long k = st->n_dead;
+                dead_logz_prev[k] = st->logz;
+                st->logz = host_logaddexp(st->logz, logwt);
+                memcpy(dead_v + k * W, active_v + (size_t)worst * D, sizeof(double) * D);
+                if (nd > 0) memcpy(dead_v + k * W + D, active_derived + (size_t)worst * nd, sizeof(double) * nd);
+                dead_logwt[k] = logwt;
+                dead_logl[k] = st->loglstar;
+                st->n_dead = k + 1;
+                st->accept_point = 0;
+            }
+        }
+        if (resume == NNEST_HOST_TOP || resume == NNEST_HOST_AFTER_SAMPLES) {
+            // Sampler._rejection_prior_sample: the next candidate of the block above the threshold
+            const double loglstar = st->loglstar;
+            if (pr->pos >= pr->n) return NNEST_HOST_NEED_SAMPLES;    // no block, or used up: a new one, resume = NNEST_HOST_AFTER_SAMPLES
+            long long k = pr->k, j = -1;
+            for (; k < pr->n_cand; ++k) {
+                const long long c = cand_idx[k];
+                if (c >= pr->pos && cand_logl32[k] > loglstar && cand_logl64[k] > loglstar) { j = c; break; }
+            }
+            if (j < 0) {                                             // the rest of the block holds nothing above the threshold
+                pr->total_calls += pr->n - pr->pos;
+                pr->pending_calls += pr->n - pr->pos;
+                if (pr->hits == 0) { const long long b = 4 * pr->n; pr->block_next = b < 65536 ? b : 65536; }
+                pr->pos = pr->n; pr->k = pr->n_cand;
+                return NNEST_HOST_NEED_SAMPLES;
+            }
+            const long long examined = j + 1 - pr->pos;
+            pr->total_calls += examined;
+            const double nc = (double)(pr->pending_calls + examined);   // candidates examined up to and including the accepted one
+            pr->pending_calls = 0;
+            pr->pos = j + 1; pr->k = k + 1; pr->hits += 1;
+            {   // the next block: ~ 16 acceptances' worth of candidates at the rate seen, bounded
+                double b = 16.0 * (double)(j + 1) / (double)pr->hits;
+                if (b < 256.0) b = 256.0;
+                if (b > 65536.0) b = 65536.0;
+                pr->block_next = (long long)b;
+            }
+            // ncs.append(nc); mean_calls = np.mean(ncs[-20:]) if len(ncs) > 20 else 0   (nested.py:325-326; the counts are integers:
+            // their sum is exact in any order)
+            pr->ncs[pr->ncs_len % 20] = nc;
+            pr->ncs_len += 1;
+            double mean_calls = 0.0;
+            if (pr->ncs_len > 20) {
+                double sum = 0.0;
+                for (int q = 0; q < 20; ++q) sum += pr->ncs[q];
+                mean_calls = sum / 20.0;
+            }
+            pr->mean_calls = mean_calls;
+            // nested.py:328-334: np.exp(-it / N) < volume_switch >= 0 or (volume_switch < 0 and mean_calls > mcmc_steps and mcmc_valid)
+            const bool expire = (volume_switch >= 0.0 && exp(-(double)st->it / (double)N) < volume_switch) ||
+                                (volume_switch < 0.0 && mean_calls > mcmc_steps && mcmc_valid);
+            if (expire) { pr->expired = 1; pr->ncs_len = 0; }
+            // nested.py:362-373: the candidate replaces the worst live point
+            const int worst = st->worst;
+            const long long kk = k;
+            memcpy(active_u + (size_t)worst * D, cand_u + (size_t)kk * D, sizeof(double) * D);
+            memcpy(active_v + (size_t)worst * D, cand_v + (size_t)kk * D, sizeof(double) * D);
+            active_logl[worst] = cand_logl64[kk];
+            if (cand_logl64[kk] > st->max_logl) st->max_logl = cand_logl64[kk];
+            if (nd > 0) memcpy(active_derived + (size_t)worst * nd, cand_derived + (size_t)kk * nd, sizeof(double) * nd);
+            st->accept_point = 1;
+            if (st->it > 0 && (st->it + 1) % log_interval == 0) return NNEST_HOST_LOG;   // nested.py:374-378 (before `it` advances)
+        }
+        resume = NNEST_HOST_TOP;
+        if (st->accept_point) {                                      // nested.py:458-471
+            st->logvol -= 1.0 / (double)N;
+            const double logz_remain = st->max_logl - (double)st->it / (double)N;
+            st->fraction_remain = host_logaddexp(st->logz, logz_remain) - st->logz;
+            st->it += 1;
+            if (st->it > 0 && st->it % log_interval == 0) return NNEST_HOST_CHECKPOINT;   // nested.py:473-485
+        }
+    }
+}
+
 extern "C" double nnest_host_h_update(double h, const double *e1, const double *e2, const double *logl, const double *logz_prev,
                                       const double *total, long long n) {
     for (long long k = 0; k < n; ++k) {

@@ -988,6 +988,11 @@ static hipError_t dispatch_train(const TrainArgs &a, hipStream_t st) {
     TRY_SHAPE(1, 1, 2); TRY_SHAPE(2, 1, 2); TRY_SHAPE(3, 1, 2); TRY_SHAPE(4, 1, 2);
     TRY_SHAPE(1, 2, 1); TRY_SHAPE(2, 2, 1); TRY_SHAPE(1, 2, 2); TRY_SHAPE(2, 2, 2);
     TRY_SHAPE(1, 4, 1);
+    // round 6: the rest of what the reference's Trainer(hidden_dim, num_layers) can ask for inside the instantiated tile shapes
+    // (nnest/networks.py:253-287 takes any num_layers): three hidden layers, and the wide nets without / with two of them
+    TRY_SHAPE(1, 1, 3); TRY_SHAPE(2, 1, 3); TRY_SHAPE(3, 1, 3); TRY_SHAPE(4, 1, 3);
+    TRY_SHAPE(1, 2, 0); TRY_SHAPE(2, 2, 0); TRY_SHAPE(1, 2, 3); TRY_SHAPE(2, 2, 3);
+    TRY_SHAPE(1, 4, 0); TRY_SHAPE(1, 4, 2); TRY_SHAPE(1, 4, 3);
 #undef TRY_SHAPE
     return hipErrorInvalidConfiguration;
 }

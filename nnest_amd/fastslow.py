@@ -235,19 +235,10 @@ class HipFastSlowNVP(object):
     epoch_chunk = 1 << 30
 
     def _vjp(self, net, x, gz, gld):
-        M = x.shape[0]
-        grad = torch.empty(net.num_params, dtype=torch.float32, device=self.device)
-        gx = torch.empty_like(x)
-        fn = self._lib.nnest_nvp_vjp if isinstance(net, HipNVP) else self._lib.nnest_spline_vjp
-        with torch.cuda.device(self.device):
-            _lib.check(fn(net._h, _lib.ptr(x), _lib.ptr(gz.contiguous()), ctypes.c_float(gld), M, _lib.ptr(grad), _lib.ptr(gx),
-                          _lib.current_stream(self.device)))
-        return grad, gx
+        return net.vjp(x, gz, gld)
 
     def _adam(self, net, grad, lr, wd):
-        fn = self._lib.nnest_nvp_adam_step if isinstance(net, HipNVP) else self._lib.nnest_spline_adam_step
-        with torch.cuda.device(self.device):
-            _lib.check(fn(net._h, _lib.ptr(grad), ctypes.c_float(lr), ctypes.c_float(wd), _lib.current_stream(self.device)))
+        net.adam_step(grad, lr, wd)
 
     def loss_grad(self, x):
         """loss = -mean(log_probs(x)) and its gradient in the three stages' packed layouts (fast, slow, coupling)"""

@@ -58,6 +58,7 @@ def _as_dev_f32(x, device):
 
 
 SCALE_MODES = {'': 0, 'translate': 1, 'constant': 2}
+TRAIN_KERNEL_MAX_BATCH = 128   # row slots of the one-launch training kernels (nnest_train.hip TRAIN_MAX_ROWS; nnest_spline_train.hip)
 
 
 class _HipFlow(object):
@@ -278,7 +279,130 @@ class _MhResult(dict):
             return default
 
 
-class HipNVP(_HipFlow):
+def train_epochs_host(net, xtrain, xvalid, perm, noise, seed, jitter, batch, max_epochs, patience, lr, weight_decay, chunk_rows):
+    """Trainer.train's epoch loop (nnest/trainer.py:198-241, :384-418) driven from the host for the shapes the one-launch training
+    kernels do not take (batch_size > 128: they hold a minibatch in one grid of 128 row slots): per minibatch the gradient of
+    -mean(log_probs) from `net.loss_grad` over chunks of at most `chunk_rows` rows -- the mean over M rows is the chunk means
+    weighted m_c / M, exact up to rounding -- and one `net.adam_step`; the early-stopping books as the reference keeps them.  A slower
+    path (a few launches per minibatch), not a refusal.  Arguments and return value as HipNVP.train_epochs."""
+    dev = net.device
+    xtrain = _as_dev_f32(xtrain, dev)
+    xvalid = _as_dev_f32(xvalid, dev)
+    n_train, n_valid, D = xtrain.shape[0], xvalid.shape[0], xtrain.shape[1]
+    perm = perm.to(device=dev, dtype=torch.int64).view(max_epochs, n_train)
+    if noise is not None:
+        noise = noise.to(device=dev, dtype=torch.float32).view(max_epochs, n_train, D)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+    losses = np.zeros((max(max_epochs, 1), 2), np.float32)
+    best, best_epoch, counter, stopped, epochs_run = float('inf'), 0, 0, False, 0
+    best_w = net.store_packed()                                            # best_model = deepcopy(netG)  trainer.py:194
+    for epoch in range(max_epochs):
+        rows_all = xtrain[perm[epoch]]
+        if jitter != 0.0:                                                  # data + jitter * randn_like(data)  trainer.py:392
+            nz = noise[epoch] if noise is not None else torch.randn(rows_all.shape, device=dev, generator=gen)
+            rows_all = rows_all + float(jitter) * nz
+        tot = torch.zeros((), dtype=torch.float32, device=dev)
+        for lo in range(0, n_train, int(batch)):
+            rows = rows_all[lo:lo + int(batch)]
+            M = rows.shape[0]
+            if getattr(net, 'data_dep_init_done', True) is False:          # ActNorm: the first minibatch pushed forward through a
+                net.actnorm_init(rows.contiguous())                        # fresh spline flow initialises it (networks.py:698-705)
+            grad = loss = None
+            for c0 in range(0, M, int(chunk_rows)):
+                part = rows[c0:c0 + int(chunk_rows)].contiguous()
+                l_c, g_c = net.loss_grad(part)
+                wgt = part.shape[0] / M
+                grad = g_c * wgt if grad is None else grad + g_c * wgt
+                loss = l_c[0] * wgt if loss is None else loss + l_c[0] * wgt
+            net.adam_step(grad, lr, weight_decay)                          # trainer.py:400-401
+            tot = tot + loss                                               # train_loss += loss.item()  trainer.py:398
+        vsum = -net.log_probs(xvalid).mean()                               # one full batch  trainer.py:190, :405-418
+        both = torch.stack([tot, vsum.to(tot.dtype)]).cpu()                # one read-back per epoch
+        train_loss, valid_loss = float(both[0]) / n_train, float(both[1]) / n_valid
+        losses[epoch] = (train_loss, valid_loss)
+        epochs_run = epoch + 1
+        if valid_loss < best:                                              # trainer.py:205-209
+            best, best_epoch, counter, best_w = valid_loss, epoch + 1, 0, net.store_packed()
+        counter += 1
+        if counter > patience:                                             # trainer.py:223-232
+            stopped = True
+            break
+    if hasattr(net, 'P'):
+        net.load_packed(best_w, net.P)                                     # netG.load_state_dict(best_model)  trainer.py:241
+    else:
+        net.load_packed(best_w)
+    return dict(losses=torch.from_numpy(losses), epochs_run=epochs_run, best_epoch=best_epoch, best_validation_loss=best,
+                last_train_loss=float(losses[max(epochs_run - 1, 0), 0]), counter=counter, stopped=stopped, result=None)
+
+
+def native_hidden(H):
+    """the hidden width the kernels are instantiated for that holds H: 16, 32 or 64 (one, two or four 16-wide matrix-core tiles);
+    beyond 64 the next multiple of 16 (the library says what it cannot take)"""
+    for w in (16, 32, 64):
+        if H <= w:
+            return w
+    return -(-H // 16) * 16
+
+
+def pad_index(blocks):
+    """blocks: [(user_shape, native_shape, native_offset)] in the order of the user's packed vector -> for every element of that
+    vector its position in the native one (a tensor of user_shape sits in the leading corner of a zero tensor of native_shape)."""
+    out = []
+    for su, sn, off in blocks:
+        if len(su) == 0:
+            out.append(np.array([off], dtype=np.int64))
+            continue
+        ix = np.indices(su).reshape(len(su), -1)
+        out.append(np.ravel_multi_index(ix, sn).astype(np.int64) + off)
+    return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+
+class _PaddedVectors(object):
+    """A flow whose hidden width is not a multiple of the 16-wide matrix-core tile runs on a native handle of the next multiple:
+    the extra hidden units have zero weights in and out and zero biases.  That is EXACT, not an approximation: their
+    pre-activations are 0, tanh 0 = relu 0 = leaky_relu 0 = 0, nothing flows out of them; in reverse mode the gradient reaching them
+    is W_out^T g = 0 and the gradients of their own weights are products with those zeros; Adam with coupled weight decay maps
+    (w, g, m, v) = (0, 0, 0, 0) to itself.  (The reference accepts any hidden_dim: nnest/networks.py:253-287, trainer.py:32-48.)
+    `_pidx` (None when nothing is padded): position of every element of the user's packed vector in the native one."""
+    _pidx = None
+    _pidx_dev = None
+    _native_params = None
+
+    def _set_pad_index(self, idx, native_params):
+        self._native_params = int(native_params)
+        if idx is None or (len(idx) == native_params and np.array_equal(idx, np.arange(native_params))):
+            self._pidx = self._pidx_dev = None
+            return
+        self._pidx = idx
+        self._pidx_dev = torch.from_numpy(idx).to(self.device)
+
+    def _to_native(self, vec):
+        vec = np.ascontiguousarray(vec, dtype=np.float32)
+        if self._pidx is None:
+            return vec
+        out = np.zeros(self._native_params, np.float32)
+        out[self._pidx] = vec
+        return out
+
+    def _from_native(self, vec):
+        return vec if self._pidx is None else np.ascontiguousarray(vec[self._pidx])
+
+    def _native_buffer(self):
+        return np.empty(self._native_params if self._native_params is not None else self.num_params, np.float32)
+
+    def _to_native_dev(self, t):
+        if self._pidx_dev is None:
+            return t.contiguous()
+        out = torch.zeros(self._native_params, dtype=torch.float32, device=self.device)
+        out[self._pidx_dev] = t
+        return out
+
+    def _from_native_dev(self, t):
+        return t if self._pidx_dev is None else t[self._pidx_dev].contiguous()
+
+
+class HipNVP(_PaddedVectors, _HipFlow):
     """num_inputs=D, num_hidden=H, num_blocks=B, num_layers=L, scale as SingleSpeedNVP (networks.py:328-347).
 
     scale='translate' / 'constant' (translate-only couplings; 'constant' adds a ScaleLayer scalar after each block):
@@ -300,10 +424,11 @@ class HipNVP(_HipFlow):
         self._sym = dict(forward=L.nnest_nvp_forward, inverse=L.nnest_nvp_inverse, log_probs=L.nnest_nvp_log_probs,
                          inverse_loglike=L.nnest_nvp_inverse_loglike, mh=L.nnest_mh_constrained_steps, set_base=L.nnest_nvp_set_base)
         self._h = ctypes.c_void_p()
+        self._Hn = native_hidden(self.H)     # the native handle's hidden width (_PaddedVectors)
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.nnest_nvp_create_scaled(self.D, self.H, self.B, self.L, SCALE_MODES[scale],
+            _lib.check(self._lib.nnest_nvp_create_scaled(self.D, self._Hn, self.B, self.L, SCALE_MODES[scale],
                                                          ctypes.byref(self._h)))
-        self.num_params = self._lib.nnest_nvp_num_params(self._h)
+        self._init_padding()
         self.prior = torch.distributions.MultivariateNormal(torch.zeros(self.D, device=self.device),
                                                             torch.eye(self.D, device=self.device))
         self.load_packed(self.default_init(seed))
@@ -315,6 +440,27 @@ class HipNVP(_HipFlow):
                 self._h = ctypes.c_void_p()
         except Exception:
             pass
+
+    def _init_padding(self):
+        """num_params and the packed layout are the USER's (hidden width H); the native vector has width _Hn"""
+        D, H, Hn, L, B = self.D, self.H, getattr(self, '_Hn', self.H), self.L, self.B
+        native = self._lib.nnest_nvp_num_params(self._h)
+        ns = H * D + H + L * (H * H + H) + D * H + D
+        self.num_params = 2 * B * ns + (B if self.scale == 'constant' else 0)
+        if Hn == H:
+            assert self.num_params == native
+            return self._set_pad_index(None, native)
+        nn_ = Hn * D + Hn + L * (Hn * Hn + Hn) + D * Hn + D
+        blocks = []
+        for k in range(2 * B):
+            off = k * nn_
+            for su, sn in [((H, D), (Hn, D)), ((H,), (Hn,))] + [((H, H), (Hn, Hn)), ((H,), (Hn,))] * L + [((D, H), (D, Hn)), ((D,), (D,))]:
+                blocks.append((su, sn, off))
+                off += int(np.prod(sn))
+        if self.scale == 'constant':
+            blocks += [((), (), 2 * B * nn_ + b) for b in range(B)]
+        self._set_pad_index(pad_index(blocks), native)
+        assert len(self._pidx) == self.num_params
 
     # ---- weights ---------------------------------------------------------------------------------
     def layer_shapes(self):
@@ -367,16 +513,17 @@ class HipNVP(_HipFlow):
         packed = np.ascontiguousarray(packed, dtype=np.float32)
         if packed.size != self.num_params:
             raise ValueError('expected %d packed weights, got %d' % (self.num_params, packed.size))
+        packed = self._to_native(packed)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.nnest_nvp_load_weights(self._h, packed.ctypes.data_as(ctypes.c_void_p),
                                                         _lib.current_stream(self.device)))
 
     def store_packed(self):
-        out = np.empty(self.num_params, np.float32)
+        out = self._native_buffer()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.nnest_nvp_store_weights(self._h, out.ctypes.data_as(ctypes.c_void_p),
                                                          _lib.current_stream(self.device)))
-        return out
+        return self._from_native(out)
 
     def state_dict(self):
         return self.state_dict_from_packed(self.store_packed())
@@ -419,16 +566,16 @@ class HipNVP(_HipFlow):
 
     def adam_moments(self):
         """host copies of Adam's (exp_avg, exp_avg_sq)"""
-        m = np.empty(self.num_params, np.float32)
-        v = np.empty(self.num_params, np.float32)
+        m = self._native_buffer()
+        v = self._native_buffer()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.nnest_nvp_store_adam(self._h, m.ctypes.data_as(ctypes.c_void_p),
                                                       v.ctypes.data_as(ctypes.c_void_p), _lib.current_stream(self.device)))
-        return m, v
+        return self._from_native(m), self._from_native(v)
 
     def set_adam(self, m, v, step):
-        m = np.ascontiguousarray(m, dtype=np.float32)
-        v = np.ascontiguousarray(v, dtype=np.float32)
+        m = self._to_native(m)
+        v = self._to_native(v)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.nnest_nvp_load_adam(self._h, m.ctypes.data_as(ctypes.c_void_p),
                                                      v.ctypes.data_as(ctypes.c_void_p), _lib.current_stream(self.device)))
@@ -438,12 +585,30 @@ class HipNVP(_HipFlow):
         """loss = -mean(log_probs(x)) and dloss/dw (packed order) for one minibatch of <= 128 rows
         (loss.backward(), trainer.py:394-400), no weight update."""
         x = _as_dev_f32(x, self.device)
-        grad = torch.empty(self.num_params, dtype=torch.float32, device=self.device)
+        grad = torch.empty(self._native_params, dtype=torch.float32, device=self.device)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.nnest_nvp_loss_grad(self._h, _lib.ptr(x), x.shape[0], _lib.ptr(grad), _lib.ptr(loss),
                                                      _lib.current_stream(self.device)))
-        return loss, grad
+        return loss, self._from_native_dev(grad)
+
+    def vjp(self, x, gz, gld):
+        """the flow as one stage of a composite model (nnest_nvp_vjp): upstream gradient gz [M,D] and dL/d(logdet) in,
+        dL/dw (packed order) and dL/dx out"""
+        M = x.shape[0]
+        grad = torch.empty(self._native_params, dtype=torch.float32, device=self.device)
+        gx = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_nvp_vjp(self._h, _lib.ptr(x), _lib.ptr(gz.contiguous()), ctypes.c_float(gld), M, _lib.ptr(grad),
+                                               _lib.ptr(gx), _lib.current_stream(self.device)))
+        return self._from_native_dev(grad), gx
+
+    def adam_step(self, grad, lr, weight_decay):
+        """one torch.optim.Adam step (coupled weight decay, trainer.py:121-122) from a gradient in packed order"""
+        grad = self._to_native_dev(grad)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_nvp_adam_step(self._h, _lib.ptr(grad), ctypes.c_float(lr), ctypes.c_float(weight_decay),
+                                                     _lib.current_stream(self.device)))
 
     def train_epochs(self, xtrain, xvalid, perm, noise=None, seed=0, jitter=0.0, batch=100, max_epochs=1, patience=50,
                      lr=1e-3, weight_decay=1e-6, epoch_offset=0, resume=False, finalize=True, result=None, one_cu=False):
@@ -454,6 +619,10 @@ class HipNVP(_HipFlow):
         Returns dict(losses [epochs,2] tensor, epochs_run, best_epoch, best_validation_loss, last_train_loss,
         counter, stopped, result)."""
         dev = self.device
+        if int(batch) > TRAIN_KERNEL_MAX_BATCH:   # the reference takes any batch_size (trainer.py:36, :76, :185): a slower path, not a refusal
+            assert not resume and epoch_offset == 0, 'batch_size > %d: the host-driven loop takes a run in one call' % TRAIN_KERNEL_MAX_BATCH
+            return train_epochs_host(self, xtrain, xvalid, perm, noise, seed, jitter, batch, max_epochs, patience, lr, weight_decay,
+                                     chunk_rows=TRAIN_KERNEL_MAX_BATCH)
         xtrain = _as_dev_f32(xtrain, dev)
         xvalid = _as_dev_f32(xvalid, dev)
         perm = perm.to(device=dev, dtype=torch.int32).contiguous()

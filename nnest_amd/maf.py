@@ -40,16 +40,11 @@ class HipMAF(HipNVP):
         with torch.cuda.device(self.device):
             _lib.check(L.nnest_maf_create(self.D, self.H, self.B, self.L, ctypes.byref(self._h)))
         self.num_params = L.nnest_nvp_num_params(self._h)
+        self._set_pad_index(None, self.num_params)
         self.num_groups = L.nnest_maf_num_groups(self._h)   # passes of the nets per block in the sampling direction
         self.prior = torch.distributions.MultivariateNormal(torch.zeros(self.D, device=self.device),
                                                             torch.eye(self.D, device=self.device))
         self.load_packed(self.default_init(seed))
-
-    def adam_step(self, grad, lr, weight_decay):
-        """one torch.optim.Adam step (coupled weight decay, trainer.py:121-122) from a gradient of loss_grad"""
-        with torch.cuda.device(self.device):
-            _lib.check(self._lib.nnest_nvp_adam_step(self._h, _lib.ptr(grad), ctypes.c_float(lr), ctypes.c_float(weight_decay),
-                                                     _lib.current_stream(self.device)))
 
     def train_epochs(self, xtrain, xvalid, perm, noise=None, seed=0, jitter=0.0, batch=100, max_epochs=1, patience=50,
                      lr=1e-3, weight_decay=1e-6, epoch_offset=0, resume=False, finalize=True, result=None, one_cu=False):

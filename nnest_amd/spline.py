@@ -15,10 +15,10 @@ import numpy as np
 import torch
 
 from . import _lib
-from .flow import _HipFlow, _as_dev_f32
+from .flow import _HipFlow, _PaddedVectors, _as_dev_f32, pad_index, native_hidden, train_epochs_host, TRAIN_KERNEL_MAX_BATCH
 
 
-class HipSpline(_HipFlow):
+class HipSpline(_PaddedVectors, _HipFlow):
 
     def __init__(self, num_inputs, hidden_dim=16, num_blocks=3, num_bins=8, tail_bound=3.0, device=None, seed=None):
         if not torch.cuda.is_available():
@@ -36,10 +36,23 @@ class HipSpline(_HipFlow):
                          inverse_loglike=L.nnest_spline_inverse_loglike, mh=L.nnest_spline_mh_constrained_steps,
                          set_base=L.nnest_spline_set_base)
         self._h = ctypes.c_void_p()
+        self._Hn = native_hidden(self.H)     # the native handle's hidden width (flow._PaddedVectors: zero-padded, exact)
         with torch.cuda.device(self.device):
-            _lib.check(L.nnest_spline_create(self.D, self.H, self.B, self.K, ctypes.c_float(self.tail_bound),
+            _lib.check(L.nnest_spline_create(self.D, self._Hn, self.B, self.K, ctypes.c_float(self.tail_bound),
                                              ctypes.byref(self._h)))
-        self.num_params = L.nnest_spline_num_params(self._h)
+        native = L.nnest_spline_num_params(self._h)
+        self.num_params = sum(int(np.prod(shape)) for _, shape in self.layer_shapes())
+        if self._Hn == self.H:
+            assert self.num_params == native
+            self._set_pad_index(None, native)
+        else:
+            H, Hn, blocks, off = self.H, self._Hn, [], 0
+            for _, su, axes in self._layer_shapes_axes():
+                sn = tuple(Hn if k in axes else d for k, d in enumerate(su))
+                blocks.append((su, sn, off))
+                off += int(np.prod(sn))
+            assert off == native
+            self._set_pad_index(pad_index(blocks), native)
         self.prior = torch.distributions.MultivariateNormal(torch.zeros(self.D, device=self.device),
                                                             torch.eye(self.D, device=self.device))
         self.data_dep_init_done = False
@@ -67,17 +80,21 @@ class HipSpline(_HipFlow):
     # ---- weights ---------------------------------------------------------------------------------
     def layer_shapes(self):
         """[(name, shape)] in torch state_dict order"""
+        return [(n, sh) for n, sh, _ in self._layer_shapes_axes()]
+
+    def _layer_shapes_axes(self):
+        """[(name, shape, axes of the shape that are the conditioners' hidden width)]"""
         out = []
         D, H, Pn = self.D, self.H, 3 * self.K - 1
         for b in range(self.B):
-            out += [('flow.flows.%d.s' % (3 * b), (1, D)), ('flow.flows.%d.t' % (3 * b), (1, D))]
-            out += [('flow.flows.%d.L' % (3 * b + 1), (D, D)), ('flow.flows.%d.S' % (3 * b + 1), (D,)),
-                    ('flow.flows.%d.U' % (3 * b + 1), (D, D))]
+            out += [('flow.flows.%d.s' % (3 * b), (1, D), ()), ('flow.flows.%d.t' % (3 * b), (1, D), ())]
+            out += [('flow.flows.%d.L' % (3 * b + 1), (D, D), ()), ('flow.flows.%d.S' % (3 * b + 1), (D,), ()),
+                    ('flow.flows.%d.U' % (3 * b + 1), (D, D), ())]
             for f, nin, nout in (('f1', self.nl, Pn * self.nu), ('f2', self.nu, Pn * self.nl)):
-                dims = [(H, nin), (H, H), (H, H), (nout, H)]
-                for i, (o, k) in enumerate(dims):
-                    out.append(('flow.flows.%d.%s.net.%d.weight' % (3 * b + 2, f, 2 * i), (o, k)))
-                    out.append(('flow.flows.%d.%s.net.%d.bias' % (3 * b + 2, f, 2 * i), (o,)))
+                dims = [((H, nin), (0,), (0,)), ((H, H), (0, 1), (0,)), ((H, H), (0, 1), (0,)), ((nout, H), (1,), ())]
+                for i, (sh, wax, bax) in enumerate(dims):
+                    out.append(('flow.flows.%d.%s.net.%d.weight' % (3 * b + 2, f, 2 * i), sh, wax))
+                    out.append(('flow.flows.%d.%s.net.%d.bias' % (3 * b + 2, f, 2 * i), (sh[0],), bax))
         return out
 
     def default_init(self, seed=None):
@@ -113,6 +130,7 @@ class HipSpline(_HipFlow):
         packed = np.ascontiguousarray(packed, dtype=np.float32)
         if packed.size != self.num_params:
             raise ValueError('expected %d packed weights, got %d' % (self.num_params, packed.size))
+        packed = self._to_native(packed)
         pp = None
         if P is not None:
             P = np.ascontiguousarray(P, dtype=np.float32)
@@ -124,9 +142,9 @@ class HipSpline(_HipFlow):
                                                            _lib.current_stream(self.device)))
 
     def store_packed(self):
-        out = np.empty(self.num_params, np.float32)
+        out = self._native_buffer()
         _lib.check(self._lib.nnest_spline_store_weights(self._h, out.ctypes.data_as(ctypes.c_void_p), None, None))
-        return out
+        return self._from_native(out)
 
     @property
     def P(self):
@@ -176,12 +194,30 @@ class HipSpline(_HipFlow):
     def loss_grad(self, x):
         """loss = -mean(log_probs(x)) and dloss/dw (packed order), no weight update (trainer.py:394-400)"""
         x = _as_dev_f32(x, self.device)
-        grad = torch.empty(self.num_params, dtype=torch.float32, device=self.device)
+        grad = torch.empty(self._native_params, dtype=torch.float32, device=self.device)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.nnest_spline_loss_grad(self._h, _lib.ptr(x), x.shape[0], _lib.ptr(grad), _lib.ptr(loss),
                                                         _lib.current_stream(self.device)))
-        return loss, grad
+        return loss, self._from_native_dev(grad)
+
+    def vjp(self, x, gz, gld):
+        """the flow as one stage of a composite model (nnest_spline_vjp): upstream gradient gz [M,D] and dL/d(logdet) in,
+        dL/dw (packed order) and dL/dx out"""
+        M = x.shape[0]
+        grad = torch.empty(self._native_params, dtype=torch.float32, device=self.device)
+        gx = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_spline_vjp(self._h, _lib.ptr(x), _lib.ptr(gz.contiguous()), ctypes.c_float(gld), M, _lib.ptr(grad),
+                                                  _lib.ptr(gx), _lib.current_stream(self.device)))
+        return self._from_native_dev(grad), gx
+
+    def adam_step(self, grad, lr, weight_decay):
+        """one torch.optim.Adam step (coupled weight decay, trainer.py:121-122) from a gradient in packed order"""
+        grad = self._to_native_dev(grad)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_spline_adam_step(self._h, _lib.ptr(grad), ctypes.c_float(lr), ctypes.c_float(weight_decay),
+                                                        _lib.current_stream(self.device)))
 
     def train_epochs(self, xtrain, xvalid, perm, noise=None, seed=0, jitter=0.0, batch=100, max_epochs=1, patience=50,
                      lr=1e-3, weight_decay=1e-6, epoch_offset=0, resume=False, finalize=True, result=None):
@@ -189,6 +225,9 @@ class HipSpline(_HipFlow):
         best-validation weights are restored on return."""
         assert not resume and epoch_offset == 0, 'the spline trainer takes a run in one call'
         dev = self.device
+        if int(batch) > TRAIN_KERNEL_MAX_BATCH:   # the reference takes any batch_size (trainer.py:36, :76, :185): a slower path, not a refusal
+            return train_epochs_host(self, xtrain, xvalid, perm, noise, seed, jitter, batch, max_epochs, patience, lr, weight_decay,
+                                     chunk_rows=1 << 30)   # (nnest_spline_loss_grad takes a minibatch of any size in one call)
         xtrain = _as_dev_f32(xtrain, dev)
         xvalid = _as_dev_f32(xvalid, dev)
         perm = perm.to(device=dev, dtype=torch.int32).contiguous()

@@ -72,8 +72,9 @@ class Trainer(object):
                     ok = mean.shape == (x_dim,) and bool(torch.all(mean == 0)) and bool(torch.equal(cov, torch.eye(x_dim)))
                 if not ok:
                     raise NotImplementedError('base_dist: N(0, I) or GeneralisedNormal(0, 1, beta)')
-        if batch_size > 128:
-            raise NotImplementedError('batch_size > 128: one workgroup holds a minibatch (nnest_train.hip)')
+        if batch_size > 128 and (self.flow in ('maf', 'choleksy') or num_slow > 0):
+            raise NotImplementedError("batch_size > 128 with flow=%r / num_slow > 0: only 'nvp' and 'spline' have the host-driven loop "
+                                      "for minibatches beyond the training kernels' 128 row slots" % self.flow)
         # host_tensors=True: forward/inverse/... return CPU tensors and `.device` reads 'cpu' while the arithmetic
         # still runs on the GPU.  Needed only under the UNMODIFIED reference sampler, whose _mcmc_sample mixes CPU
         # tensors into the loop (nnest/sampler.py:305, :344) and therefore cannot consume CUDA tensors.
@@ -107,6 +108,8 @@ class Trainer(object):
         else:
             self.netG = HipNVP(x_dim, hidden_dim, num_blocks, num_layers, device=self.gpu, seed=seed, scale=scale)
         self.replicable = self.flow in ('nvp', 'spline') and num_slow == 0   # the two single-launch training paths
+        if batch_size > 128:
+            self.netG.epoch_chunk = 1 << 30   # flow.train_epochs_host takes a run in one call
         if gen_normal is not None:
             self.netG.set_base(gen_normal)
             self.netG.prior = gen_normal

@@ -616,7 +616,9 @@ def spline_P(netG):
 
 
 def gen_spline():
-    for name, D, H, B in [('d2', 2, 16, 3), ('d5', 5, 16, 3), ('d8_h32', 8, 32, 2), ('d50', 50, 16, 3)]:
+    for name, D, H, B in [('d2', 2, 16, 3), ('d5', 5, 16, 3), ('d8_h32', 8, 32, 2), ('d50', 50, 16, 3), ('d6_h10', 6, 10, 3)]:
+        if not wanted(name):
+            continue
         np.random.seed(0)
         torch.manual_seed(6)
         t = Trainer(D, hidden_dim=H, num_blocks=B, flow='spline', log_dir=None, learning_rate=1e-3,

@@ -68,9 +68,44 @@ def test_flow_every_instantiated_shape(hip, D, H, B, L):
 
 def test_unsupported_shapes_fail_loudly(hip):
     from nnest_amd import _lib
-    for D, H in [(129, 16), (65, 32), (33, 64), (10, 24), (10, 128)]:
+    for D, H in [(129, 16), (65, 32), (33, 64), (65, 24), (33, 40), (10, 128)]:   # (24 / 40 run on the 32 / 64 wide kernels, zero-padded)
         with pytest.raises(_lib.NnestHipError):
             hip.HipNVP(D, H, 3, 1)
+
+
+@pytest.mark.parametrize('flow', ['nvp', 'spline'])
+def test_the_references_trainer_envelope_runs(flow, tmp_path):
+    """Round-5 verdict item 8: `Trainer(x_dim, hidden_dim, num_blocks, num_layers, batch_size, flow)` of the reference accepts any
+    hidden_dim / num_layers / batch_size (nnest/trainer.py:32-48, :76; nnest/networks.py:253-287; examples/nested/run.py:62-86
+    passes --hidden_dim / --num_layers / --num_blocks through).  Here a hidden width that is not a multiple of the 16-wide
+    matrix-core tile runs zero-padded on the next instantiated width (exact: flow._PaddedVectors), num_layers up to 3 trains in
+    the one-launch kernels, and batch_size > 128 takes the host-driven loop.  The reference's own flow tests
+    (tests/test_flows.py:56-72, :75-91: shapes, round trip <= 1e-5, log-det antisymmetry) over that envelope, then a train() call
+    that must lower the validation loss, then the weights must round-trip through state_dict() with the reference's shapes."""
+    from nnest_amd.trainer import Trainer
+    rng = np.random.RandomState(0)
+    cases = [(2, 10, 3, 1, 100), (5, 8, 2, 0, 100), (5, 24, 3, 2, 100), (7, 16, 3, 3, 100), (4, 50, 2, 1, 100), (6, 16, 3, 1, 256),
+             (20, 20, 3, 1, 300)]
+    if flow == 'spline':
+        cases = [(2, 10, 3, 1, 100), (5, 8, 2, 1, 100), (5, 24, 3, 1, 100), (6, 16, 3, 1, 256)]
+    for D, H, B, L, batch in cases:
+        t = Trainer(D, hidden_dim=H, num_blocks=B, num_layers=L, batch_size=batch, flow=flow, log_dir=None)
+        x = torch.from_numpy(rng.normal(size=(10, D))).float()
+        z, ldz = t.forward(x)
+        assert z.shape == torch.Size([10, D]) and ldz.shape == torch.Size([10])
+        xb, ldx = t.inverse(z)
+        assert abs(float(torch.max(xb.cpu() - x))) <= 1e-5 and abs(float(torch.max(ldx + ldz))) <= 1e-5
+        assert t.get_synthetic_samples(10).shape == torch.Size([10, D]) and t.log_probs(x).shape == torch.Size([10])
+        sd = t.netG.state_dict()
+        hidden = [tuple(v.shape) for k, v in sd.items() if k.endswith('.2.weight')]
+        assert all(sh == (H, H) for sh in hidden) or L == 0     # the reference's shapes, not the padded ones
+        live = rng.uniform(-1, 1, size=(700 if batch > 128 else 300, D)) * np.linspace(0.2, 1.0, D)
+        t.train(live, max_iters=8, jitter=0.01)
+        assert t.best_validation_epoch >= 1 and np.isfinite(t.best_validation_loss)
+        assert t.losses[-1, 1] < t.losses[0, 1], (flow, D, H, L, batch, t.losses[:, 1])
+        w = t.netG.store_packed()
+        t.netG.load_state_dict(t.netG.state_dict())
+        assert np.array_equal(t.netG.store_packed(), w)
 
 
 MH_SHAPES = [(2, 16, 3, 1), (20, 16, 3, 1), (50, 16, 3, 1), (70, 16, 3, 1), (100, 16, 3, 1), (10, 16, 4, 0), (10, 16, 3, 2),
