@@ -243,8 +243,15 @@ class NestedSampler(Sampler):
         with open(os.path.join(cp, 'checkpoint_%s.txt' % it), 'w') as f:
             json.dump(state, f)
 
+    def _native_prior_ok(self, strategy, expired_strategies, rejection_trials):
+        """the 'rejection_prior' phase can run in the native loop too: block-evaluated candidates (the fused likelihood kernel), one
+        process, no derived parameters, and 'mcmc' as the strategy that follows (the native loop runs on into it)"""
+        rest = [m for m in strategy if m not in expired_strategies and m != 'rejection_prior']
+        return (self._fused_like_id is not None and rejection_trials is None and not self.use_mpi and self.num_derived == 0
+                and len(rest) > 0 and rest[0] == 'mcmc')
+
     def _mcmc_loop_native(self, loc, strategy, expired_strategies, mcmc_steps, C, dynamic, step_size, train_iters, jitter,
-                          update_interval, log_interval, dlogz, max_iters, primary):
+                          update_interval, log_interval, dlogz, max_iters, primary, prior_phase=False, volume_switch=-1.0):
         """The rest of run()'s while loop once 'mcmc' is the strategy in force: nnest_host_mcmc_consume does the per-iteration
         body (nested.py:269-293, :429-437, :458-471); this method does what it returns for -- retrain (nested.py:311-314), a new
         batch of chains (nested.py:399-427), the log line + results.csv row (nested.py:439-456), the checkpoint
@@ -310,18 +317,101 @@ class NestedSampler(Sampler):
         deadp = [P(dead[k]) for k in ('v', 'logl', 'logwt', 'zprev')]
         stp = ctypes.byref(st)
         results_f = None
-        while True:
+
+        def grow_dead():
+            nonlocal cap, deadp
+            cap *= 2
+            for k, a in dead.items():
+                b = np.empty((cap,) + a.shape[1:])
+                b[:a.shape[0]] = a
+                dead[k] = b
+            deadp = [P(dead[k]) for k in ('v', 'logl', 'logwt', 'zprev')]
+
+        def checkpoint():                                    # nested.py:473-485
+            nonlocal last_checkpoint, last_chain
+            scalars()
+            if primary and time.time() - last_checkpoint >= self.checkpoint_min_seconds:
+                last_checkpoint = time.time()
+                catch_up()
+                n = st.n_dead
+                self._checkpoint(st.it, active_u, active_v, active_logl, active_derived, dead['v'][:n], dead['logl'][:n],
+                                 dead['logwt'][:n],
+                                 {'logz': ev.logz, 'h': ev.h, 'logvol': st.logvol, 'ncall': total_calls,
+                                  'fraction_remain': st.fraction_remain, 'strategy': strategy,
+                                  'expired_strategies': expired_strategies})
+                if last_checkpoint - last_chain >= self.chain_min_seconds:
+                    last_chain = last_checkpoint
+                    self.samples = np.array(dead['v'][:n])
+                    self.weights = np.exp(dead['logwt'][:n] - ev.logz)
+                    self.loglikes = np.array(dead['logl'][:n])
+                    self._save_samples(self.samples, self.loglikes, weights=self.weights)
+
+        finished = False
+        if prior_phase:
+            # 'rejection_prior' in force (nested.py:322-334, :362-373): nnest_host_prior_consume walks the candidates of a block of
+            # prior draws evaluated by one launch of the likelihood kernel (the rule of Sampler._rejection_prior_sample above, value
+            # for value) and returns for a new block, the log line, the checkpoint and when the strategy expires
+            from . import flow
+            pr = _lib.HostPrior()
+            pr.block_next = int(getattr(self, '_prior_block', 256))
+            pr.total_calls = int(self.total_calls)
+            prp = ctypes.byref(pr)
+            mcmc_valid = int('mcmc' in strategy and 'mcmc' not in expired_strategies)
+            i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+            blk = dict(idx=i64(np.zeros(1)), l32=np.zeros(1), l64=np.zeros(1), u=np.zeros((1, D)), v=np.zeros((1, D)), d=np.zeros((1, max(nd, 1))))
+            blkp = [P(blk[k]) for k in ('idx', 'l32', 'l64', 'u', 'v', 'd')]
+            while True:
+                reason = lib.nnest_host_prior_consume(stp, prp, N, D, nd, *fixed[:4], *blkp, *deadp, cap, float(dlogz), int(max_iters),
+                                                      int(log_interval), float(volume_switch), float(mcmc_steps), mcmc_valid)
+                self.total_calls = total_calls = int(pr.total_calls)
+                if pr.expired and 'rejection_prior' not in expired_strategies:   # nested.py:328-334 (said where the reference says it:
+                    if primary:                                                  # before the pass's log line)
+                        self.logger.info('Rejection prior no longer efficient, switching sampling method')
+                    expired_strategies.append('rejection_prior')
+                if reason == _lib.HOST_FINISHED:
+                    finished = True
+                    break
+                if reason == _lib.HOST_EXPIRED:
+                    break
+                if reason == _lib.HOST_DEAD_FULL:
+                    grow_dead()
+                    st.resume = _lib.HOST_TOP
+                elif reason == _lib.HOST_NEED_SAMPLES:       # a block of prior draws, one launch of the likelihood kernel
+                    x = self.sample_prior(int(pr.block_next))
+                    logl = flow.loglike(self._fused_like_id, x, self._linear_scale, device=self.trainer.netG.device,
+                                        like_params=self._fused_like_params).cpu().numpy()
+                    cand = np.flatnonzero(logl > st.loglstar)
+                    if len(cand):   # the kernel works on float32(x); the stored value is the reference's float64 one
+                        xc = np.ascontiguousarray(x[cand], dtype=np.float64)
+                        calls = self.total_calls
+                        l64, _d64 = self.loglike(xc)
+                        self.total_calls = calls
+                        blk = dict(idx=i64(cand), l32=np.ascontiguousarray(logl[cand], dtype=np.float64),
+                                   l64=np.ascontiguousarray(l64, dtype=np.float64), u=xc,
+                                   v=np.ascontiguousarray(self.transform(xc), dtype=np.float64), d=np.zeros((1, max(nd, 1))))
+                        blkp = [P(blk[k]) for k in ('idx', 'l32', 'l64', 'u', 'v', 'd')]
+                    pr.n, pr.n_cand, pr.pos, pr.k, pr.hits = len(logl), len(cand), 0, 0, 0
+                    st.resume = _lib.HOST_AFTER_SAMPLES
+                elif reason == _lib.HOST_LOG:                # nested.py:374-378 (before `it` advances)
+                    if primary:
+                        self.logger.info('Step [%d] loglstar [%5.4e] max logl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
+                                         'mean calls [%5.4f]' % (st.it + 1, st.loglstar, st.max_logl, st.logz, np.exp(-st.it / N),
+                                                                 total_calls, pr.mean_calls))
+                    st.resume = _lib.HOST_AFTER_LOG
+                elif reason == _lib.HOST_CHECKPOINT:
+                    checkpoint()
+                    st.resume = _lib.HOST_TOP
+                else:
+                    raise RuntimeError('nnest_host_prior_consume returned %d' % reason)
+            self._prior_block = int(pr.block_next)
+            st.nb, st.resume = C, _lib.HOST_TOP              # the MCMC strategy starts with a batch of its own (nested.py:307-309)
+        while not finished:
             reason = lib.nnest_host_mcmc_consume(stp, N, D, nd, *fixed, C, *deadp, cap, float(dlogz),
                                                  int(max_iters), int(update_interval), int(log_interval))
             if reason == _lib.HOST_FINISHED:
                 break
             if reason == _lib.HOST_DEAD_FULL:
-                cap *= 2
-                for k, a in dead.items():
-                    b = np.empty((cap,) + a.shape[1:])
-                    b[:a.shape[0]] = a
-                    dead[k] = b
-                deadp = [P(dead[k]) for k in ('v', 'logl', 'logwt', 'zprev')]
+                grow_dead()
                 st.resume = _lib.HOST_TOP
             elif reason == _lib.HOST_RETRAIN:
                 self._train(active_u, train_iters, jitter)   # nested.py:311-314
@@ -374,22 +464,7 @@ class NestedSampler(Sampler):
                     results_f.flush()
                 st.resume = _lib.HOST_AFTER_LOG
             elif reason == _lib.HOST_CHECKPOINT:             # nested.py:473-485
-                scalars()
-                if primary and time.time() - last_checkpoint >= self.checkpoint_min_seconds:
-                    last_checkpoint = time.time()
-                    catch_up()
-                    n = st.n_dead
-                    self._checkpoint(st.it, active_u, active_v, active_logl, active_derived, dead['v'][:n], dead['logl'][:n],
-                                     dead['logwt'][:n],
-                                     {'logz': ev.logz, 'h': ev.h, 'logvol': st.logvol, 'ncall': total_calls,
-                                      'fraction_remain': st.fraction_remain, 'strategy': strategy,
-                                      'expired_strategies': expired_strategies})
-                    if last_checkpoint - last_chain >= self.chain_min_seconds:
-                        last_chain = last_checkpoint
-                        self.samples = np.array(dead['v'][:n])
-                        self.weights = np.exp(dead['logwt'][:n] - ev.logz)
-                        self.loglikes = np.array(dead['logl'][:n])
-                        self._save_samples(self.samples, self.loglikes, weights=self.weights)
+                checkpoint()
                 st.resume = _lib.HOST_TOP
             else:
                 raise RuntimeError('nnest_host_mcmc_consume returned %d' % reason)
@@ -548,13 +623,16 @@ class NestedSampler(Sampler):
         # the reference takes np.max over the live points at every iteration, nested.py:461 -- the same value)
         max_logl = np.max(active_logl)
         while fraction_remain > dlogz and it <= max_iters:
-            if self.native_loop and _first_live(strategy, expired_strategies) == 'mcmc':
+            live = _first_live(strategy, expired_strategies)
+            if self.native_loop and (live == 'mcmc' or (live == 'rejection_prior' and current_method in ('', 'rejection_prior')
+                                                        and self._native_prior_ok(strategy, expired_strategies, rejection_trials))):
                 # From here on the strategy in force is 'mcmc' for good (strategies only expire, nested.py:300-306, and 'mcmc'
                 # never does): the per-iteration body runs in the native library, which returns for everything that is not
                 # that arithmetic (nnest_host_mcmc_consume, include/nnest_hip.h)
                 native = self._mcmc_loop_native(
                     locals(), strategy, expired_strategies, mcmc_steps, mcmc_num_chains, mcmc_dynamic_step_size, step_size, train_iters,
-                    jitter, update_interval, log_interval, dlogz, max_iters, primary)
+                    jitter, update_interval, log_interval, dlogz, max_iters, primary, prior_phase=live == 'rejection_prior',
+                    volume_switch=volume_switch)
                 (active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt, ev, logvol, fraction_remain, it,
                  total_calls, scale) = native
                 break
