@@ -224,7 +224,11 @@ class NestedSampler(Sampler):
 
     def _checkpoint(self, it, active_u, active_v, active_logl, active_derived, saved_v, saved_logl, saved_logwt, state):
         cp = self.logs['checkpoint']
-        if hasattr(self.trainer, 'flush_pending_files'):   # models/netG.pt as of this checkpoint (the trainer batches its file writes)
+        # models/netG.pt as of this checkpoint (the trainer batches its file writes and a worker thread does them): handed over AND
+        # waited for, so that a resume never pairs these live points with an older flow
+        if hasattr(self.trainer, 'wait_for_saves'):
+            self.trainer.wait_for_saves()
+        elif hasattr(self.trainer, 'flush_pending_files'):
             self.trainer.flush_pending_files()
         np.save(os.path.join(cp, 'active_u_%s.npy' % it), active_u)
         np.save(os.path.join(cp, 'active_v_%s.npy' % it), active_v)
@@ -346,130 +350,132 @@ class NestedSampler(Sampler):
                     self.loglikes = np.array(dead['logl'][:n])
                     self._save_samples(self.samples, self.loglikes, weights=self.weights)
 
-        finished = False
-        if prior_phase:
-            # 'rejection_prior' in force (nested.py:322-334, :362-373): nnest_host_prior_consume walks the candidates of a block of
-            # prior draws evaluated by one launch of the likelihood kernel (the rule of Sampler._rejection_prior_sample above, value
-            # for value) and returns for a new block, the log line, the checkpoint and when the strategy expires
-            from . import flow
-            pr = _lib.HostPrior()
-            pr.block_next = int(getattr(self, '_prior_block', 256))
-            pr.total_calls = int(self.total_calls)
-            prp = ctypes.byref(pr)
-            mcmc_valid = int('mcmc' in strategy and 'mcmc' not in expired_strategies)
-            i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
-            blk = dict(idx=i64(np.zeros(1)), l32=np.zeros(1), l64=np.zeros(1), u=np.zeros((1, D)), v=np.zeros((1, D)), d=np.zeros((1, max(nd, 1))))
-            blkp = [P(blk[k]) for k in ('idx', 'l32', 'l64', 'u', 'v', 'd')]
-            while True:
-                reason = lib.nnest_host_prior_consume(stp, prp, N, D, nd, *fixed[:4], *blkp, *deadp, cap, float(dlogz), int(max_iters),
-                                                      int(log_interval), float(volume_switch), float(mcmc_steps), mcmc_valid)
-                self.total_calls = total_calls = int(pr.total_calls)
-                if pr.expired and 'rejection_prior' not in expired_strategies:   # nested.py:328-334 (said where the reference says it:
-                    if primary:                                                  # before the pass's log line)
-                        self.logger.info('Rejection prior no longer efficient, switching sampling method')
-                    expired_strategies.append('rejection_prior')
+        try:
+            finished = False
+            if prior_phase:
+                # 'rejection_prior' in force (nested.py:322-334, :362-373): nnest_host_prior_consume walks the candidates of a block of
+                # prior draws evaluated by one launch of the likelihood kernel (the rule of Sampler._rejection_prior_sample above, value
+                # for value) and returns for a new block, the log line, the checkpoint and when the strategy expires
+                from . import flow
+                pr = _lib.HostPrior()
+                pr.block_next = int(getattr(self, '_prior_block', 256))
+                pr.total_calls = int(self.total_calls)
+                prp = ctypes.byref(pr)
+                mcmc_valid = int('mcmc' in strategy and 'mcmc' not in expired_strategies)
+                i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+                blk = dict(idx=i64(np.zeros(1)), l32=np.zeros(1), l64=np.zeros(1), u=np.zeros((1, D)), v=np.zeros((1, D)), d=np.zeros((1, max(nd, 1))))
+                blkp = [P(blk[k]) for k in ('idx', 'l32', 'l64', 'u', 'v', 'd')]
+                while True:
+                    reason = lib.nnest_host_prior_consume(stp, prp, N, D, nd, *fixed[:4], *blkp, *deadp, cap, float(dlogz), int(max_iters),
+                                                          int(log_interval), float(volume_switch), float(mcmc_steps), mcmc_valid)
+                    self.total_calls = total_calls = int(pr.total_calls)
+                    if pr.expired and 'rejection_prior' not in expired_strategies:   # nested.py:328-334 (said where the reference says it:
+                        if primary:                                                  # before the pass's log line)
+                            self.logger.info('Rejection prior no longer efficient, switching sampling method')
+                        expired_strategies.append('rejection_prior')
+                    if reason == _lib.HOST_FINISHED:
+                        finished = True
+                        break
+                    if reason == _lib.HOST_EXPIRED:
+                        break
+                    if reason == _lib.HOST_DEAD_FULL:
+                        grow_dead()
+                        st.resume = _lib.HOST_TOP
+                    elif reason == _lib.HOST_NEED_SAMPLES:       # a block of prior draws, one launch of the likelihood kernel
+                        x = self.sample_prior(int(pr.block_next))
+                        logl = flow.loglike(self._fused_like_id, x, self._linear_scale, device=self.trainer.netG.device,
+                                            like_params=self._fused_like_params).cpu().numpy()
+                        cand = np.flatnonzero(logl > st.loglstar)
+                        if len(cand):   # the kernel works on float32(x); the stored value is the reference's float64 one
+                            xc = np.ascontiguousarray(x[cand], dtype=np.float64)
+                            calls = self.total_calls
+                            l64, _d64 = self.loglike(xc)
+                            self.total_calls = calls
+                            blk = dict(idx=i64(cand), l32=np.ascontiguousarray(logl[cand], dtype=np.float64),
+                                       l64=np.ascontiguousarray(l64, dtype=np.float64), u=xc,
+                                       v=np.ascontiguousarray(self.transform(xc), dtype=np.float64), d=np.zeros((1, max(nd, 1))))
+                            blkp = [P(blk[k]) for k in ('idx', 'l32', 'l64', 'u', 'v', 'd')]
+                        pr.n, pr.n_cand, pr.pos, pr.k, pr.hits = len(logl), len(cand), 0, 0, 0
+                        st.resume = _lib.HOST_AFTER_SAMPLES
+                    elif reason == _lib.HOST_LOG:                # nested.py:374-378 (before `it` advances)
+                        if primary:
+                            self.logger.info('Step [%d] loglstar [%5.4e] max logl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
+                                             'mean calls [%5.4f]' % (st.it + 1, st.loglstar, st.max_logl, st.logz, np.exp(-st.it / N),
+                                                                     total_calls, pr.mean_calls))
+                        st.resume = _lib.HOST_AFTER_LOG
+                    elif reason == _lib.HOST_CHECKPOINT:
+                        checkpoint()
+                        st.resume = _lib.HOST_TOP
+                    else:
+                        raise RuntimeError('nnest_host_prior_consume returned %d' % reason)
+                self._prior_block = int(pr.block_next)
+                st.nb, st.resume = C, _lib.HOST_TOP              # the MCMC strategy starts with a batch of its own (nested.py:307-309)
+            while not finished:
+                reason = lib.nnest_host_mcmc_consume(stp, N, D, nd, *fixed, C, *deadp, cap, float(dlogz),
+                                                     int(max_iters), int(update_interval), int(log_interval))
                 if reason == _lib.HOST_FINISHED:
-                    finished = True
-                    break
-                if reason == _lib.HOST_EXPIRED:
                     break
                 if reason == _lib.HOST_DEAD_FULL:
                     grow_dead()
                     st.resume = _lib.HOST_TOP
-                elif reason == _lib.HOST_NEED_SAMPLES:       # a block of prior draws, one launch of the likelihood kernel
-                    x = self.sample_prior(int(pr.block_next))
-                    logl = flow.loglike(self._fused_like_id, x, self._linear_scale, device=self.trainer.netG.device,
-                                        like_params=self._fused_like_params).cpu().numpy()
-                    cand = np.flatnonzero(logl > st.loglstar)
-                    if len(cand):   # the kernel works on float32(x); the stored value is the reference's float64 one
-                        xc = np.ascontiguousarray(x[cand], dtype=np.float64)
-                        calls = self.total_calls
-                        l64, _d64 = self.loglike(xc)
-                        self.total_calls = calls
-                        blk = dict(idx=i64(cand), l32=np.ascontiguousarray(logl[cand], dtype=np.float64),
-                                   l64=np.ascontiguousarray(l64, dtype=np.float64), u=xc,
-                                   v=np.ascontiguousarray(self.transform(xc), dtype=np.float64), d=np.zeros((1, max(nd, 1))))
-                        blkp = [P(blk[k]) for k in ('idx', 'l32', 'l64', 'u', 'v', 'd')]
-                    pr.n, pr.n_cand, pr.pos, pr.k, pr.hits = len(logl), len(cand), 0, 0, 0
-                    st.resume = _lib.HOST_AFTER_SAMPLES
-                elif reason == _lib.HOST_LOG:                # nested.py:374-378 (before `it` advances)
+                elif reason == _lib.HOST_RETRAIN:
+                    self._train(active_u, train_iters, jitter)   # nested.py:311-314
+                    self.num_retrains += 1
+                    st.first_time = 0
+                    st.resume = _lib.HOST_AFTER_TRAIN
+                elif reason == _lib.HOST_NEED_SAMPLES:           # nested.py:399-427
+                    per = -(-C // self.mpi_size)
+                    ctl = np.zeros(per * self.mpi_size + 1, dtype=np.int64)
                     if primary:
-                        self.logger.info('Step [%d] loglstar [%5.4e] max logl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
-                                         'mean calls [%5.4f]' % (st.it + 1, st.loglstar, st.max_logl, st.logz, np.exp(-st.it / N),
-                                                                 total_calls, pr.mean_calls))
+                        idx = np.random.randint(low=0, high=N, size=C)      # nested.py:405
+                        ctl[:-1] = np.resize(idx, per * self.mpi_size)
+                        if self._fused_like_id is not None:   # only the HIP kernel's noise streams consume a seed
+                            ctl[-1] = self._next_seed() & 0x7FFFFFFFFFFFFFFF
+                    ctl = self._broadcast(ctl)
+                    lo = self.mpi_rank * per
+                    my = ctl[lo:lo + per]
+                    kw = dict(init_samples=active_u[my, :], init_loglikes=active_logl[my], loglstar=st.loglstar,
+                              walker_offset=lo, seed=int(ctl[-1]), form=self._pinned_form(C, dynamic))
+                    if self._fused_like_id is not None and nd == 0:
+                        ends, scale, nc = self._mcmc_endpoints_fused(mcmc_steps, step_size, dynamic, **kw)
+                    else:
+                        s_x, _lat, s_d, s_l, scale, nc = self._mcmc_sample(
+                            mcmc_steps, step_size=step_size, dynamic_step_size=dynamic,
+                            init_derived=active_derived[my, :] if nd > 0 else np.empty((per, 0)), **kw)
+                        mv = np.all(s_x[:, 0, :] != s_x[:, -1, :], axis=1)   # a chain is usable if every coordinate moved (nested.py:432)
+                        ends = np.concatenate([s_x[:, -1, :], s_l[:, -1:], mv[:, None], s_d[:, -1, :]], axis=1).astype(np.float64)
+                    ends = self._all_gather_rows(ends)[:C]
+                    ends = ends.cpu().numpy() if torch.is_tensor(ends) else ends
+                    end_u[:] = ends[:, :D]
+                    end_logl[:] = ends[:, D]
+                    moved[:] = ends[:, D + 1] != 0
+                    if nd > 0:
+                        end_derived[:] = ends[:, D + 2:]
+                    end_v[:] = self.transform(end_u)
+                    self.num_batches += 1
+                    total_calls = int(self._all_sum(self.total_calls))
+                    st.nb = 0
+                    st.resume = _lib.HOST_AFTER_SAMPLES
+                elif reason == _lib.HOST_LOG:                    # nested.py:439-456 (before `it` advances)
+                    if primary:
+                        acc = self.total_accepted / max(1, self.total_accepted + self.total_rejected)
+                        self.logger.info('Step [%d] loglstar [%5.4e] maxlogl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
+                                         'scale [%5.4f]' % (st.it, st.loglstar, st.max_logl, st.logz, np.exp(-st.it / N), total_calls, scale))
+                        # (one handle for the loop, flushed row by row: a config-2 run appends 1000 rows, and open/close per row was 25 ms)
+                        if results_f is None:
+                            results_f = open(os.path.join(self.logs['results'], 'results.csv'), 'a')
+                        csv.writer(results_f).writerow([st.it, acc, float('nan'), float('nan'), float('nan'), scale, np.float64(st.loglstar),
+                                                        np.float64(st.logz), np.float64(st.fraction_remain), total_calls])
+                        results_f.flush()
                     st.resume = _lib.HOST_AFTER_LOG
-                elif reason == _lib.HOST_CHECKPOINT:
+                elif reason == _lib.HOST_CHECKPOINT:             # nested.py:473-485
                     checkpoint()
                     st.resume = _lib.HOST_TOP
                 else:
-                    raise RuntimeError('nnest_host_prior_consume returned %d' % reason)
-            self._prior_block = int(pr.block_next)
-            st.nb, st.resume = C, _lib.HOST_TOP              # the MCMC strategy starts with a batch of its own (nested.py:307-309)
-        while not finished:
-            reason = lib.nnest_host_mcmc_consume(stp, N, D, nd, *fixed, C, *deadp, cap, float(dlogz),
-                                                 int(max_iters), int(update_interval), int(log_interval))
-            if reason == _lib.HOST_FINISHED:
-                break
-            if reason == _lib.HOST_DEAD_FULL:
-                grow_dead()
-                st.resume = _lib.HOST_TOP
-            elif reason == _lib.HOST_RETRAIN:
-                self._train(active_u, train_iters, jitter)   # nested.py:311-314
-                self.num_retrains += 1
-                st.first_time = 0
-                st.resume = _lib.HOST_AFTER_TRAIN
-            elif reason == _lib.HOST_NEED_SAMPLES:           # nested.py:399-427
-                per = -(-C // self.mpi_size)
-                ctl = np.zeros(per * self.mpi_size + 1, dtype=np.int64)
-                if primary:
-                    idx = np.random.randint(low=0, high=N, size=C)      # nested.py:405
-                    ctl[:-1] = np.resize(idx, per * self.mpi_size)
-                    if self._fused_like_id is not None:   # only the HIP kernel's noise streams consume a seed
-                        ctl[-1] = self._next_seed() & 0x7FFFFFFFFFFFFFFF
-                ctl = self._broadcast(ctl)
-                lo = self.mpi_rank * per
-                my = ctl[lo:lo + per]
-                kw = dict(init_samples=active_u[my, :], init_loglikes=active_logl[my], loglstar=st.loglstar,
-                          walker_offset=lo, seed=int(ctl[-1]), form=self._pinned_form(C, dynamic))
-                if self._fused_like_id is not None and nd == 0:
-                    ends, scale, nc = self._mcmc_endpoints_fused(mcmc_steps, step_size, dynamic, **kw)
-                else:
-                    s_x, _lat, s_d, s_l, scale, nc = self._mcmc_sample(
-                        mcmc_steps, step_size=step_size, dynamic_step_size=dynamic,
-                        init_derived=active_derived[my, :] if nd > 0 else np.empty((per, 0)), **kw)
-                    mv = np.all(s_x[:, 0, :] != s_x[:, -1, :], axis=1)   # a chain is usable if every coordinate moved (nested.py:432)
-                    ends = np.concatenate([s_x[:, -1, :], s_l[:, -1:], mv[:, None], s_d[:, -1, :]], axis=1).astype(np.float64)
-                ends = self._all_gather_rows(ends)[:C]
-                ends = ends.cpu().numpy() if torch.is_tensor(ends) else ends
-                end_u[:] = ends[:, :D]
-                end_logl[:] = ends[:, D]
-                moved[:] = ends[:, D + 1] != 0
-                if nd > 0:
-                    end_derived[:] = ends[:, D + 2:]
-                end_v[:] = self.transform(end_u)
-                self.num_batches += 1
-                total_calls = int(self._all_sum(self.total_calls))
-                st.nb = 0
-                st.resume = _lib.HOST_AFTER_SAMPLES
-            elif reason == _lib.HOST_LOG:                    # nested.py:439-456 (before `it` advances)
-                if primary:
-                    acc = self.total_accepted / max(1, self.total_accepted + self.total_rejected)
-                    self.logger.info('Step [%d] loglstar [%5.4e] maxlogl [%5.4e] logz [%5.4e] vol [%6.5e] ncalls [%d] '
-                                     'scale [%5.4f]' % (st.it, st.loglstar, st.max_logl, st.logz, np.exp(-st.it / N), total_calls, scale))
-                    # (one handle for the loop, flushed row by row: a config-2 run appends 1000 rows, and open/close per row was 25 ms)
-                    if results_f is None:
-                        results_f = open(os.path.join(self.logs['results'], 'results.csv'), 'a')
-                    csv.writer(results_f).writerow([st.it, acc, float('nan'), float('nan'), float('nan'), scale, np.float64(st.loglstar),
-                                                    np.float64(st.logz), np.float64(st.fraction_remain), total_calls])
-                    results_f.flush()
-                st.resume = _lib.HOST_AFTER_LOG
-            elif reason == _lib.HOST_CHECKPOINT:             # nested.py:473-485
-                checkpoint()
-                st.resume = _lib.HOST_TOP
-            else:
-                raise RuntimeError('nnest_host_mcmc_consume returned %d' % reason)
-        if results_f is not None:
-            results_f.close()
+                    raise RuntimeError('nnest_host_mcmc_consume returned %d' % reason)
+        finally:   # (the results.csv handle of the loop, also when a callback raises)
+            if results_f is not None:
+                results_f.close()
         scalars()
         catch_up()
         n = st.n_dead

@@ -47,7 +47,7 @@ if os.environ.get('NNEST_HIP_LIB', '').endswith('STAMP.so'):   # NNEST_STAMP bui
               'owner of a block-0 job: arrivals seen %d, contracted %d, published %d | a re-laying wave: hints seen (block 2, 1, 0) %d %d %d, blocks in the images %d %d %d'
               % (rel[1], rel[2], rel[3], rel[4], rel[8], rel[9], rel[10], rel[12], rel[13], rel[14], rel[15], rel[16], rel[17]))
         print('   owner of a block-2 job (service wave 1): top of its loop %d, arrivals seen %d, contracted %d, published %d; re-laying wave: top of its loop %d; row wave 0 done with its share of the refresh %d' % (rel[18], rel[5], rel[6], rel[7], rel[19], rel[20]))
-        # train_kernel_pipe (the default form): row wave 0 and service wave 0 of workgroup 0 (the owner of a block-0 job)
+        # train_kernel_pipe (opt-in: NNEST_TRAIN_FORM=pipe; the default form is train_kernel_rows): row wave 0 and service wave 0 of workgroup 0 (the owner of a block-0 job)
         print('pipe kernel, cycles per minibatch, row wave: wait for rows + block 0 images %d  forward (+ staging, waits for blocks 1, 2) %d  '
               'backward to the last store %d  drain in front of the last arrival %d  | sum %d' % (tuple(ph[:4]) + (ph[:4].sum(),)))
         print('pipe kernel, cycles per minibatch, service wave 0: row preparation %d  wait for its block\'s arrivals %d  job + Adam + publish %d  '
