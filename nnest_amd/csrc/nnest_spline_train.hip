@@ -17,6 +17,7 @@
 // it, so the host queues epochs without draining the stream.  ActNorm's data-dependent initialisation (networks.py:698-705)
 // runs as spl_init_kernel on the first batch pushed forward through a fresh flow.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -247,6 +248,9 @@ struct SplGradArgs {
     int Mv;
     int rows_per_tile;  // 16, 8 or 4: a minibatch is only 100 rows, so the tiles are made shallower to spread them over
                         // more waves / CUs (the matrix-core columns of the unused walkers idle; the launch is latency-bound)
+    int lds_heads;      // round 6: the blocks' conv fragments (each wave: the output tile it is dealt) and ActNorm vectors are staged in
+                        // LDS by the prologue, beside the rows' loads -- every block's conv and ActNorm stage used to open with a round
+                        // trip to L2 of its own (stamps: 3.6 us per block in the forward pass, of which the arithmetic is a tenth)
 };
 
 template <int NTh>
@@ -312,6 +316,33 @@ __device__ __forceinline__ void spl_matmul_team(const float *__restrict__ frag, 
             acc1 = mfma4(wf[ti * 4 + 3], v.w, acc1);
         }
         xch[to * 64 + lane] = acc0 + acc1;
+    }
+    spl_team_barrier();
+#pragma unroll
+    for (int to = 0; to < T2; ++to) out[to / NTh][to % NTh] = xch[to * 64 + lane];
+    spl_team_barrier();
+}
+
+// the same, the wave's output tile `wv` (TEAM >= 2 NTh: one tile per wave at most) with its fragments read from the wave's LDS slot
+template <int NTh, int TEAM>
+__device__ __forceinline__ void spl_matmul_team_lds(const float *slot /* LDS: [2 NTh * 4][64] */, int lane, int wv, f32x4 *xch, const f32x4 (&in)[2][NTh],
+                                                    f32x4 (&out)[2][NTh]) {
+    constexpr int T2 = 2 * NTh;
+    static_assert(T2 <= TEAM, "one output tile per wave");
+    if (wv < T2) {   // uniform over the wave
+        float wf[T2 * 4];
+#pragma unroll
+        for (int i = 0; i < T2 * 4; ++i) wf[i] = slot[i * 64 + lane];
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ti = 0; ti < T2; ++ti) {
+            const f32x4 v = in[ti / NTh][ti % NTh];
+            acc0 = mfma4(wf[ti * 4 + 0], v.x, acc0);
+            acc1 = mfma4(wf[ti * 4 + 1], v.y, acc1);
+            acc0 = mfma4(wf[ti * 4 + 2], v.z, acc0);
+            acc1 = mfma4(wf[ti * 4 + 3], v.w, acc1);
+        }
+        xch[wv * 64 + lane] = acc0 + acc1;
     }
     spl_team_barrier();
 #pragma unroll
@@ -622,6 +653,13 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     float *lds17 = buf + 16 * (D + 1);           // SPL_TBATCH x 16 x 17: tile transposes (per wave)
     f32x4 *xch = reinterpret_cast<f32x4 *>(lds + (size_t)TEAM * per_wave);  // [TEAM][NTh + NH][64]
     float *ldred = reinterpret_cast<float *>(xch + TEAM * (NTh + NH) * 64);  // [TEAM][16]
+    // (lds_heads) per block: the conv fragments of output tile `wv` -- forward first, the transposed ones take their place once the
+    // forward product has used them -- [B][2 NTh][2 NTh * 4][64] floats, and ActNorm's e^s | t as this lane holds them [B][4 NTh][64] f32x4
+    constexpr int T2K = 2 * NTh;
+    constexpr bool LDS_OK = T2K <= TEAM;
+    const bool lds_heads = LDS_OK && a.lds_heads != 0;
+    float *lconv = ldred + TEAM * 16;
+    f32x4 *lact = reinterpret_cast<f32x4 *>(lconv + (size_t)s.B * T2K * T2K * 256);
     const int ntl = (int)gridDim.x - a.val_tiles;  // the batch's own tiles
     const bool vtile = tile >= ntl;
     const int mode = vtile ? (int)SPL_MODE_LOSS : a.mode;
@@ -686,7 +724,46 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
             }
         }
     }
+    if constexpr (LDS_OK) {
+        if (lds_heads) {
+            // the wave's conv fragments of every block (three blocks' loads in flight at a time) and the ActNorm vectors, block b by
+            // wave b mod TEAM (they depend on the lane only: every wave would compute the same)
+            for (int b0 = 0; b0 < B; b0 += 3) {
+                float cf[3][T2K * 4];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int b = b0 + u < B ? b0 + u : B - 1;
+                    const float *src = a.timg + (size_t)b * ts.tblk_floats + (size_t)(wv < T2K ? wv : 0) * T2K * 256;
+#pragma unroll
+                    for (int i = 0; i < T2K * 4; ++i) cf[u][i] = src[i * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    if (b0 + u < B && wv < T2K) {
+                        float *dst = lconv + ((size_t)(b0 + u) * T2K + wv) * T2K * 256;
+#pragma unroll
+                        for (int i = 0; i < T2K * 4; ++i) dst[i * 64 + lane] = cf[u][i];
+                    }
+                }
+            }
+            for (int b = wv; b < B; b += TEAM) {
+                f32x4 es[2][NTh], tv[2][NTh];
+                spl_actnorm_vecs<NTh>(ts, a.w + (size_t)b * s.blk_params, lane, es, tv);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int t = 0; t < NTh; ++t) {
+                        lact[((size_t)b * 4 * NTh + hf * NTh + t) * 64 + lane] = es[hf][t];
+                        lact[((size_t)b * 4 * NTh + 2 * NTh + hf * NTh + t) * 64 + lane] = tv[hf][t];
+                    }
+            }
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");  // the warm-up's target register is free again only now
+    if constexpr (LDS_OK) {
+        if (lds_heads) spl_team_barrier();   // (the ActNorm vectors are read by every wave)
+    }
     spl_from_parity<NTh>(buf, D, s.nl, lane, xp, xs);
 #ifdef NNEST_STAMP
     long long st_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_0 = wall_clock64(), st_a, cb_t[4] = {0, 0, 0, 0};
@@ -717,12 +794,32 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
                 for (int t = 0; t < NTh; ++t) stash[((size_t)b * SPL_STASH * NTh + c * NTh + t) * 64 + lane] = xs[c][t];
         }
         f32x4 es[2][NTh], tv[2][NTh], av[2][NTh], c[2][NTh];
-        spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);
+        bool staged = false;
+        if constexpr (LDS_OK) {
+            if (lds_heads) {
+                staged = true;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int t = 0; t < NTh; ++t) {
+                        es[hf][t] = lact[((size_t)b * 4 * NTh + hf * NTh + t) * 64 + lane];
+                        tv[hf][t] = lact[((size_t)b * 4 * NTh + 2 * NTh + hf * NTh + t) * 64 + lane];
+                    }
+            }
+        }
+        if (!staged) spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int t = 0; t < NTh; ++t) av[hf][t] = xs[hf][t] * es[hf][t] + tv[hf][t];
-        spl_matmul_team<NTh, TEAM>(blk, lane, wv, xch, av, c);
+        float ctf[LDS_OK ? T2K * 4 : 1];   // (lds_heads) the transposed conv fragments of this block: requested now, in LDS behind coupling 1
+        if constexpr (LDS_OK) {
+            if (staged) {
+                spl_matmul_team_lds<NTh, TEAM>(lconv + ((size_t)b * T2K + (wv < T2K ? wv : 0)) * T2K * 256, lane, wv, xch, av, c);
+                if (mode != SPL_MODE_LOSS) load_frags<T2K * 4>(blk + ts.conv_floats + (size_t)(wv < T2K ? wv : 0) * T2K * 256, lane, ctf);
+            }
+        }
+        if (!staged) spl_matmul_team<NTh, TEAM>(blk, lane, wv, xch, av, c);
         if (mode != SPL_MODE_LOSS) {  // ActNorm and conv outputs: the backward pass does not repeat them
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
@@ -739,6 +836,13 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         if (mode != SPL_MODE_LOSS) {  // upper' conditions the second coupling: kept for the backward pass
 #pragma unroll
             for (int t = 0; t < NTh; ++t) stash[((size_t)b * SPL_STASH * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
+        }
+        if constexpr (LDS_OK) {
+            if (staged && mode != SPL_MODE_LOSS && wv < T2K) {   // (the wave's own slot: nobody else reads it)
+                float *dst = lconv + ((size_t)b * T2K + wv) * T2K * 256;
+#pragma unroll
+                for (int i = 0; i < T2K * 4; ++i) dst[i * 64 + lane] = ctf[i];
+            }
         }
         ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch, kpf ? kpf + spl_keep_floats4(NTh, NH) * 64 : nullptr, tfr, rfr,
                                                      b + 1 < B ? blk + ts.tblk_floats + 2 * ts.conv_floats : nullptr, SU_o)
@@ -807,7 +911,17 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
                 av[hf][t] = stash[((size_t)b * SPL_STASH * NTh + (3 + hf) * NTh + t) * 64 + lane];
                 c[hf][t] = stash[((size_t)b * SPL_STASH * NTh + (5 + hf) * NTh + t) * 64 + lane];
             }
-        spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);  // (e^s for the ActNorm gradients at the end of the block)
+        bool staged = false;
+        if constexpr (LDS_OK) {
+            if (lds_heads) {
+                staged = true;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int t = 0; t < NTh; ++t) es[hf][t] = lact[((size_t)b * 4 * NTh + hf * NTh + t) * 64 + lane];
+            }
+        }
+        if (!staged) spl_actnorm_vecs<NTh>(ts, pb, lane, es, tv);  // (e^s for the ActNorm gradients at the end of the block)
         SPL_STAMP(5)
         // upper' = RQS(upper; f1(lower)) is the conditioning input of the second coupling
         f32x4 up2[NTh];
@@ -868,7 +982,10 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #endif
         SPL_STAMP(7)
         f32x4 ga[2][NTh];
-        spl_matmul_team<NTh, TEAM>(blk + ts.conv_floats, lane, wv, xch, gs, ga);
+        if constexpr (LDS_OK) {
+            if (staged) spl_matmul_team_lds<NTh, TEAM>(lconv + ((size_t)b * T2K + (wv < T2K ? wv : 0)) * T2K * 256, lane, wv, xch, gs, ga);
+        }
+        if (!staged) spl_matmul_team<NTh, TEAM>(blk + ts.conv_floats, lane, wv, xch, gs, ga);
         SPL_STAMP(8)
         // ActNorm a = x e^s + t: g_s = sum_rows g_a x e^s, g_t = sum_rows g_a, g_x = g_a e^s  (the -1 of log|det| is added by the reducer)
 #pragma unroll
@@ -1595,10 +1712,17 @@ __global__ void __launch_bounds__(512) spl_init_kernel(SplInitArgs a) {
 
 static int grad_tiles(const SplGradArgs &a) { return (a.M + a.rows_per_tile - 1) / a.rows_per_tile; }
 
-static hipError_t launch_grad(const SplGradArgs &a, hipStream_t st) {
+static hipError_t launch_grad(const SplGradArgs &a_in, hipStream_t st) {
+    SplGradArgs a = a_in;
     const int tiles = grad_tiles(a);
     const int per_wave = ((16 * (a.ts.s.D + 1) + SPL_TBATCH * 16 * 17) + 3) & ~3;
-    const size_t ldsb = (size_t)(SPL_TEAM * per_wave + SPL_TEAM * (a.ts.s.NTh + a.ts.s.NH) * 64 * 4 + SPL_TEAM * 16) * sizeof(float);
+    size_t ldsb = (size_t)(SPL_TEAM * per_wave + SPL_TEAM * (a.ts.s.NTh + a.ts.s.NH) * 64 * 4 + SPL_TEAM * 16) * sizeof(float);
+    // the blocks' conv fragments and ActNorm vectors in LDS where they fit (x_dim 50, three blocks: 48 + 12 KB on top of 61 KB)
+    static const bool heads_off = [] { const char *e = getenv("NNEST_SPL_LDS_HEADS"); return e && !strcmp(e, "0"); }();   // (diagnostic)
+    const int T2 = 2 * a.ts.s.NTh;
+    const size_t heads_b = (size_t)a.ts.s.B * (T2 * T2 * 256 + 4 * a.ts.s.NTh * 64 * 4) * sizeof(float);
+    a.lds_heads = (!heads_off && T2 <= SPL_TEAM && ldsb + heads_b <= (size_t)156 * 1024) ? 1 : 0;
+    if (a.lds_heads) ldsb += heads_b;
     DISPATCH_SPLT(spl_grad_kernel, a.ts.s, tiles + a.val_tiles, 64 * SPL_TEAM, ldsb, st, a);
     return hipGetLastError();
 }
