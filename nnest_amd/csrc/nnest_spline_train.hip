@@ -374,7 +374,9 @@ template <int NTh, int NH, int TEAM, bool DUP>
 __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const float *__restrict__ cf, const float *__restrict__ cbw, int pnet,
                                                  int nin, int nout, int S, int lane, bool row_ok, bool cmask, float gld, float *lds17, float *gp,
                                                  const f32x4 (&cond)[NTh], const f32x4 (&x_tr)[NTh], f32x4 (&g_tr)[NTh], f32x4 (&g_cond)[NTh],
-                                                 int wv, f32x4 *xch, f32x4 *__restrict__ gq, f32x4 *__restrict__ hq, int item_stride, const f32x4 *__restrict__ keep
+                                                 int wv, f32x4 *xch, f32x4 *__restrict__ gq, f32x4 *__restrict__ hq, int item_stride, const f32x4 *__restrict__ keep,
+                                                 int w0_wave   // the wave that has the FIRST layer's weight-gradient job (round 6: it was the last wave's too, which then came
+                                                               // ~0.6 us per coupling late to the block's closing barrier: the stamps' "matmulT" of the other three)
 #ifdef NNEST_STAMP
                                                  , long long *cst
 #endif
@@ -451,7 +453,14 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
                 const bool valid = row_ok && (lo ? (4 * sA + g < nout) : (hasB && 4 * sB + g < nout));
                 const float gy = valid ? gyr : 0.f;
                 float y, lad;
+#ifdef NNEST_STAMP
+                long long c_b = wall_clock64();
+                { asm volatile("" :: "v"(raw[0].x + raw[5].z)); const long long c_n = wall_clock64(); cst[4] += c_n - c_b; c_b = c_n; }
+#endif
                 const float gx = spl_rqs_fwd_bwd(raw, tail, x, gy, valid ? gld : 0.f, y, lad, graw);
+#ifdef NNEST_STAMP
+                { asm volatile("" :: "v"(gx + graw[0].x + graw[5].z)); const long long c_n = wall_clock64(); cst[5] += c_n - c_b; c_b = c_n; }
+#endif
                 const float gxo = valid ? gx : 0.f, gxp = half_swap(gxo);
                 set_reg(g_tr[k], r, lo ? gxo : gxp);
                 if (k + 1 < NTh && hasB) set_reg(g_tr[kb], r, lo ? gxp : gxo);
@@ -483,6 +492,9 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
                         }
                     }
                 }
+#ifdef NNEST_STAMP
+                { asm volatile("" :: "v"(g_h[0].x)); const long long c_n = wall_clock64(); cst[6] += c_n - c_b; }
+#endif
             }
         }
     } else {
@@ -583,7 +595,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
     }
     // first layer: W0 over the conditioning half
     {
-        const bool mine = TEAM == 1 || wv == TEAM - 1;
+        const bool mine = TEAM == 1 || wv == w0_wave;
         f32x4 g_pre[NH];
         float gT[NH][4];
 #pragma unroll
@@ -766,7 +778,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     }
     spl_from_parity<NTh>(buf, D, s.nl, lane, xp, xs);
 #ifdef NNEST_STAMP
-    long long st_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_0 = wall_clock64(), st_a, cb_t[4] = {0, 0, 0, 0};
+    long long st_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_0 = wall_clock64(), st_a, cb_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cf_t[4] = {0, 0, 0, 0}, cv_t = 0, cv_a = st_0;
 #define SPL_STAMP(i) { const long long st_n = wall_clock64(); st_t[i] += st_n - st_a; st_a = st_n; }
     st_a = st_0;
 #else
@@ -831,8 +843,14 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         }
         const float *f1 = blk + 2 * ts.conv_floats, *f2 = f1 + ts.cf[0];
         f32x4 *kpf = mode != SPL_MODE_LOSS ? reinterpret_cast<f32x4 *>(a.keep) + (((size_t)tile * TEAM + wv) * B + b) * 2 * spl_keep_floats4(NTh, NH) * 64 : nullptr;
-        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch, kpf, tfr, rfr, f2, SL_o)
-                  : spl_coupling<NTh, NH, false, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch);
+#ifdef NNEST_STAMP
+        { asm volatile("" :: "v"(c[0][0].x)); const long long n_ = wall_clock64(); cv_t += n_ - cv_a; }   // (stash + ActNorm + conv of this block)
+#define SPL_FST , cf_t
+#else
+#define SPL_FST
+#endif
+        if constexpr (DUP) ld += spl_coupling_pair<NTh, NH, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch, kpf, tfr, rfr, f2, SL_o SPL_FST);
+        else ld += spl_coupling<NTh, NH, false, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch);
         if (mode != SPL_MODE_LOSS) {  // upper' conditions the second coupling: kept for the backward pass
 #pragma unroll
             for (int t = 0; t < NTh; ++t) stash[((size_t)b * SPL_STASH * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
@@ -844,9 +862,12 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
                 for (int i = 0; i < T2K * 4; ++i) dst[i * 64 + lane] = ctf[i];
             }
         }
-        ld += DUP ? spl_coupling_pair<NTh, NH, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch, kpf ? kpf + spl_keep_floats4(NTh, NH) * 64 : nullptr, tfr, rfr,
-                                                     b + 1 < B ? blk + ts.tblk_floats + 2 * ts.conv_floats : nullptr, SU_o)
-                  : spl_coupling<NTh, NH, false, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch);
+        if constexpr (DUP) ld += spl_coupling_pair<NTh, NH, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch, kpf ? kpf + spl_keep_floats4(NTh, NH) * 64 : nullptr, tfr, rfr,
+                                                                  b + 1 < B ? blk + ts.tblk_floats + 2 * ts.conv_floats : nullptr, SU_o SPL_FST);
+        else ld += spl_coupling<NTh, NH, false, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch);
+#ifdef NNEST_STAMP
+        cv_a = wall_clock64();
+#endif
         if (lane < (DUP ? 8 : 16) && wv == 0) ld += blk[ts.tblk_floats - 4];  // (once per row: DUP adds the halves up below)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -935,14 +956,14 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         f32x4 *hq2 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 1) * ntl + tile) * NH * 64;
         f32x4 *hq1 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 0) * ntl + tile) * NH * 64;
         const f32x4 *kp = reinterpret_cast<const f32x4 *>(a.keep) + (((size_t)tile * TEAM + wv) * B + b) * 2 * spl_keep_floats4(NTh, NH) * 64;
-        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, cmask, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch, gq2, hq2, item_stride, kp + spl_keep_floats4(NTh, NH) * 64
+        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, cmask, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch, gq2, hq2, item_stride, kp + spl_keep_floats4(NTh, NH) * 64, TEAM > 1 ? (2 * b + 1) % (TEAM > 1 ? TEAM - 1 : 1) : 0
 #ifdef NNEST_STAMP
             , cb_t
 #endif
             );
         SPL_STAMP(2)
         // first coupling: upper' = RQS(upper; f1(lower))      (networks.py:582-588)
-        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, cmask, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch, gq1, hq1, item_stride, kp
+        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, cmask, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch, gq1, hq1, item_stride, kp, TEAM > 1 ? (2 * b) % (TEAM > 1 ? TEAM - 1 : 1) : 0
 #ifdef NNEST_STAMP
             , cb_t
 #endif
@@ -1010,7 +1031,10 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         printf("spl_grad wave %d: fwd %lld | stash+actnorm %lld matmul %lld | c2_bwd %lld c1_bwd %lld | transposes %lld dW %lld matmulT %lld actnorm %lld (x10 ns)\n", wv,
                st_t[0], st_t[5], st_t[1], st_t[2], st_t[3], st_t[6], st_t[7], st_t[8], st_t[4]);
     if (tile == 0 && lane == 0)
-        printf("   couplings (6) wave %d: trunk+transposes %lld | super-tiles %lld | merge %lld | trunk backward %lld (x10 ns)\n", wv, cb_t[0], cb_t[1], cb_t[2], cb_t[3]);
+        printf("   forward (3 blocks) wave %d: stash+actnorm+conv %lld | six couplings: trunk %lld | last layer %lld | keep stores + spline evaluation %lld | exchange %lld (x10 ns)\n", wv,
+               cv_t, cf_t[0], cf_t[1], cf_t[2], cf_t[3]);
+    if (tile == 0 && lane == 0)
+        printf("   couplings (6) wave %d: trunk+transposes %lld | super-tiles %lld [kept parameters arrived %lld | evaluation fwd+bwd %lld | G stores + W3^T G %lld] | merge %lld | trunk backward %lld (x10 ns)\n", wv, cb_t[0], cb_t[1], cb_t[4], cb_t[5], cb_t[6], cb_t[2], cb_t[3]);
 #endif
     if (mode == SPL_MODE_VJP) {
         f32x4 gp4[2][NTh];

@@ -244,8 +244,18 @@ template <int NTh, int NH, int TEAM>
 __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net, int S, int n_out, float tail, int lane,
                                                    const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv, f32x4 *xch,
                                                    f32x4 *__restrict__ keep, SplTrunkFrags<NTh, NH> &tf, SplRawFrags<NH> &rf,
-                                                   const float *__restrict__ next_net, int next_S) {
+                                                   const float *__restrict__ next_net, int next_S
+#ifdef NNEST_STAMP
+                                                   , long long *fst = nullptr
+#endif
+                                                   ) {
     static_assert(TEAM == 4, "one wave per register of a tile");
+#ifdef NNEST_STAMP   // (diagnostic build: where a forward coupling's time goes -- tools/stamp_spline_train.py)
+    long long f_a = wall_clock64();
+#define CF_STAMP(i, v) { if (fst) { asm volatile("" :: "v"(v)); const long long f_n = wall_clock64(); fst[i] += f_n - f_a; f_a = f_n; } }
+#else
+#define CF_STAMP(i, v)
+#endif
     const int g = lane >> 4;
     const bool lo = (lane & 15) < 8;
     // `keep` (this wave's slice, spl_keep_floats4): the three hidden activations and the spline parameters of the wave's pairs
@@ -254,6 +264,7 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
     // this trunk has consumed them, and arrive behind the spline arithmetic
     f32x4 hk[3][NH];
     spl_hidden_keep_pre<NTh, NH>(tf, cond, hk);
+    CF_STAMP(0, hk[2][0].x)
     if (next_net) spl_trunk_load<NTh, NH>(next_net, lane, tf);
     f32x4 h[NH];
 #pragma unroll
@@ -289,6 +300,7 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
                 }
                 x = lo ? x : reg_of(tr[(k + 1 < NTh) ? k + 1 : k], r);
             }
+            CF_STAMP(1, raw[0].x + raw[5].z)
             if (keep) {
 #pragma unroll
                 for (int q = 0; q < SPL_QT; ++q) keep[(3 * NH + (k >> 1) * SPL_QT + q) * 64 + lane] = raw[q];
@@ -300,6 +312,7 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
             ld += valid ? l : 0.f;
             set_reg(tr[k], r, lo ? yo : yp);
             if (k + 1 < NTh && hasB) set_reg(tr[(k + 1 < NTh) ? k + 1 : k], r, lo ? yp : yo);
+            CF_STAMP(2, yo + ld)
         }
     }
     if (next_net) spl_rawfrags_load<NTh, NH>(next_net, next_S, wv, lane, rf);
@@ -311,6 +324,7 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
     for (int t = 0; t < NTh; ++t)
         tr[t] = (f32x4){xch[(0 * NTh + t) * 64 + lane].x, xch[(1 * NTh + t) * 64 + lane].y, xch[(2 * NTh + t) * 64 + lane].z, xch[(3 * NTh + t) * 64 + lane].w};
     spl_team_barrier();
+    CF_STAMP(3, tr[0].x)
     return ld;
 }
 
