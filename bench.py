@@ -111,7 +111,7 @@ def cpu_baseline(D, w, like, scale, walkers, target_seconds=10.0):
                           walkers, steps_all, threads, cores)}
 
 
-def committed_traffic(kernel, tag='r05'):
+def committed_traffic(kernel, tag='r06'):
     """HBM bytes per K4 launch from this round's committed rocprofv3 PMC passes of THIS command (scripts/profile_bench.sh ->
     profiles/<tag>/bench_pmc.json); None when the profile is absent or was taken on another kernel than the one that just ran"""
     path = os.path.join(ROOT, 'profiles', tag, 'bench_pmc.json')
@@ -583,6 +583,17 @@ def main():
                                 'frac': C * S * fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                                 'what': ('no step-size adaptation' if key == 'fixed_step' else
                                          'the reference\'s rule itself (nnest/sampler.py:422-431: the whole batch\'s vote on step s sets the scale of step s + 1)')}
+                # which rule is the product default, and what the reference's own rule would cost as the default (round-5 verdict item 4)
+                out['step_rule'] = {
+                    'product_default': 'batch-wide rule, the first %d steps of a launch exact (lag 0), then %d steps behind' % (
+                        nvp.default_warm(C, 'batch', nvp.default_lag(C, form), form), nvp.default_lag(C, form)),
+                    'reference_rule': 'lag 0 throughout (mcmc_step_lag=0): every decision of the reference\'s recorded traces reproduced '
+                                      '(tests/test_gpu_solo.py)',
+                    'reference_rule_cost': out['batch_rule_lag0']['kernel_ms'] / kern_ms,
+                    'note': 'the factor is the second candidate evaluation of every step (the vote\'s round trip is hidden behind the two): '
+                            'two waves per walker instead of two evaluations per wave were built and are no faster '
+                            '(profiles/r06/k4_lag0_duo_experiment.txt); at config 2 a run spends 4 % of its wall in K4, so lag 0 as the '
+                            'default would cost ~4 % end to end'}
         if not args.no_saturation and world == 1 and dist is None:
             # the same step at a population that fills the chip (not the headline: BASELINE's config is 1000)
             Cs = 16 * 4 * cu * 8  # 8 walker tiles per SIMD
@@ -626,7 +637,7 @@ def main():
                                   'roofline': {'bound': 'mfma', 'flops_per_unit': sp_flops, 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
                                                'achieved': C * S * sp_flops / (ms * 1e-3) / 1e12,
                                                'frac': C * S * sp_flops / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                               'kernel': sp_kernel, 'profile': 'profiles/r05/spline_kernel_stats.csv'},
+                                               'kernel': sp_kernel, 'profile': 'profiles/r06/spline_kernel_stats.csv'},
                                   'note': 'SingleSpeedSpline hidden=%d blocks=%d bins=8; VALU-bound on the spline arithmetic' % (H, B)}
             if C >= 200:  # its training epoch at this population (90 % train / 10 % validation, batch 100: trainer.py:159-176)
                 nv = C // 10
@@ -646,7 +657,7 @@ def main():
                 out['spline_flow']['train_roofline'] = {'bound': 'mfma', 'flops_per_unit': tf, 'unit_is': 'epoch', 'unit': 'TFLOP/s',
                                                         'peak': FP32_PEAK_TFLOPS, 'achieved': tf / (best * 1e-3) / 1e12,
                                                         'frac': tf / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 'kernel': 'spl_grad_kernel + spl_update_kernel',
-                                                        'profile': 'profiles/r05/spline_train_kernel_stats.csv'}
+                                                        'profile': 'profiles/r06/spline_train_kernel_stats.csv'}
         if world == 1 and dist is None and not args.bare and args.config in (2, 5):
             # the same workload on the build-defined MAF (BASELINE config 5 names it): reported beside, never
             # as `value`.  Its inverse -- the direction the proposals need -- is `num_groups` passes of the nets per block
@@ -680,10 +691,10 @@ def main():
             out['maf_flow'] = {'kernel': 'maf_mh_kernel (image form, grouped sequential inverse)', 'num_groups': mf.num_groups,
                                'roofline': {'bound': 'mfma', 'flops_per_unit': mfl, 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
                                             'achieved': C * Sm * mfl / (ms * 1e-3) / 1e12, 'frac': C * Sm * mfl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                            'executed_over_algorithmic': mf.num_groups, 'kernel': 'maf_mh_kernel', 'profile': None},
+                                            'executed_over_algorithmic': mf.num_groups, 'kernel': 'maf_mh_kernel', 'profile': 'profiles/r06/maf_kernel_stats.csv'},
                                'train_roofline': {'bound': 'mfma', 'flops_per_unit': tfm, 'unit_is': 'epoch', 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
                                                   'achieved': tfm / (t_ep * 1e-3) / 1e12, 'frac': tfm / (t_ep * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                                  'kernel': 'maf_grad_kernel + maf_update_kernel', 'profile': None},
+                                                  'kernel': 'maf_grad_kernel + maf_update_kernel', 'profile': 'profiles/r06/maf_kernel_stats.csv'},
                                'walkers': C, 'mcmc_steps_timed': Sm, 'kernel_ms': ms, 'evals_per_s': C * Sm / (ms * 1e-3),
                                'train_ms_per_epoch': t_ep,
                                'train_what': 'host-driven epoch loop (loss_grad + adam_step per minibatch), %d points' % Xm.shape[0],
@@ -709,7 +720,7 @@ def main():
                                'what': 'Trainer.train epoch loop in one launch (nnest_nvp_train), %d live points' % C,
                                'roofline': {'bound': 'valu', 'flops_per_unit': kfl, 'unit_is': 'epoch', 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
                                             'achieved': kfl / (best * 1e-3) / 1e12, 'frac': kfl / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                            'kernel': 'train_kernel_rows<2>', 'profile': 'profiles/r05/train_kernel_stats.csv',
+                                            'kernel': 'train_kernel_rows<2>', 'profile': 'profiles/r06/train_kernel_stats.csv',
                                             'note': 'latency-bound: per minibatch one forward + backward chain per row (100 waves on 25 '
                                                     'CUs) and four cross-CU round trips (two grid barriers, the operand loads of the '
                                                     'weight-gradient jobs, the image refresh)'}}

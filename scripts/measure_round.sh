@@ -3,7 +3,7 @@
 # profiles/<tag>/.  `tools/build_stamp.sh` must have been run in the build container first (tools/ab/lib_STAMP.so travels).
 #   scripts/measure_round.sh [tag]
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 python tools/time_quad.py                                             2>/dev/null > "$OUT/k4_forms_and_step_rules.txt"

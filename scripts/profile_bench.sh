@@ -6,7 +6,7 @@
 #   bench_pmc.json           {"traffic_bytes_per_launch": ...} read back by bench.py (roofline.traffic)
 #   bench_under_rocprof.json the bench line printed under the profiler
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 KERN=${2:-mh_kernel_solo<2, false, 0, 4>}   # the kernel the default bench command runs (roofline.kernel)
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

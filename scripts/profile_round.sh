@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): every rocprofv3 pass of the round, summaries under gpurun_out/<tag>/ ready for profiles/<tag>/.
 #   scripts/profile_round.sh [tag]
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 bash scripts/profile_bench.sh "$TAG" > "$OUT/profile_bench.log" 2>&1

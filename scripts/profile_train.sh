@@ -2,7 +2,7 @@
 # Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + SQ counters of the training kernels (tools/time_train.py:
 # the eight-CU kernel and the one-CU kernel at config 2).  Summaries to gpurun_out/prof_train_<tag>/ for profiles/<tag>/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$PWD/gpurun_out/prof_train_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
 R=$PWD
 cd /tmp
