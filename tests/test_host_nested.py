@@ -280,3 +280,58 @@ def test_background_jobs_keep_the_order_of_the_scalar_rows(tmp_path):
     with pytest.raises(OSError):
         jobs.wait()
     jobs.wait()   # reported once
+
+
+@pytest.mark.parametrize('kw', [dict(volume_switch=0.4), dict(), dict(max_iters=90), dict(volume_switch=0.4, log_interval=7)],
+                         ids=['volume_switch', 'efficiency_switch', 'ends_in_the_prior_phase', 'odd_log_interval'])
+def test_native_prior_phase_equals_the_python_loop(tmp_path, monkeypatch, kw):
+    """Round 6: the 'rejection_prior' phase of run() in the native library (nnest_host_prior_consume: nnest/nested.py:322-334, :362-373
+    over Sampler._rejection_prior_sample, nnest/sampler.py:529-543, candidates evaluated a block per launch) against the Python loop
+    of nnest_amd/nested.py + nnest_amd/sampler.py on the same seeds -- EQUAL in log Z, H, iterations, likelihood calls, every dead
+    point, results.csv and the checkpoint files -- through the hand-over to the MCMC phase.  No GPU here: the likelihood kernel is
+    stood in for by the oracle on float32(x) (what the kernel computes), the MCMC batches take the host protocol."""
+    import nnest_amd.flow as nflow
+    from oracle import oracle as orc  # checker only
+    D = 3
+    like = Rosenbrock(D)
+    monkeypatch.setattr(nflow, 'loglike', lambda like_id, x, scale, device=None, like_params=None:
+                        torch.from_numpy(orc.loglike('rosenbrock', np.asarray(x, dtype=np.float32), scale)))
+
+    class S(NestedSampler):
+        def _mcmc_endpoints_fused(self, mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar, walker_offset, seed, form=None):
+            fid, self._fused_like_id = self._fused_like_id, None     # (the host protocol for the chains: there is no kernel here)
+            try:
+                s_x, _lat, s_d, s_l, scale, nc = self._mcmc_sample(mcmc_steps, step_size=step_size, dynamic_step_size=dynamic,
+                                                                   init_samples=init_samples, init_loglikes=init_loglikes,
+                                                                   init_derived=np.empty((init_samples.shape[0], 0)), loglstar=loglstar)
+            finally:
+                self._fused_like_id = fid
+            mv = np.all(s_x[:, 0, :] != s_x[:, -1, :], axis=1)
+            return np.concatenate([s_x[:, -1, :], s_l[:, -1:], mv[:, None]], axis=1).astype(np.float64), scale, nc
+
+    def go(native, sub):
+        np.random.seed(5)
+        torch.manual_seed(5)
+        tr = OracleTrainer(D, seed=2)
+        tr.netG.device = torch.device('cpu')
+        s = S(D, like, transform=lambda x: 5 * x, log_dir=str(tmp_path / sub), num_live_points=100, trainer=tr, log_level=30,
+              append_run_num=False, checkpoint_min_seconds=0.0, chain_min_seconds=0.0, native_loop=native, fused=False)
+        s._fused_like_id, s._fused_like_params = 0, ()      # as Sampler._fused_eligibility leaves them on a GPU
+        assert s._linear_scale == 5.0
+        if native:
+            assert s._native_prior_ok(['rejection_prior', 'mcmc'], [], None)
+        s.run(train_iters=15, mcmc_num_chains=8, mcmc_steps=6, **dict(dict(log_interval=20), **kw))
+        return s
+
+    a, b = go(False, 'py'), go(True, 'native')
+    assert a.niter > 60
+    assert a.logz == b.logz and a.h == b.h and a.niter == b.niter and a.ncall == b.ncall and a.num_retrains == b.num_retrains
+    for k in ('samples', 'weights', 'loglikes'):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    for name in ('results/results.csv', 'results/final.csv'):
+        assert open(str(tmp_path / 'py' / name)).read() == open(str(tmp_path / 'native' / name)).read(), name
+    cps = sorted(f for f in os.listdir(str(tmp_path / 'py' / 'checkpoint')) if f.startswith('checkpoint_'))
+    assert cps == sorted(f for f in os.listdir(str(tmp_path / 'native' / 'checkpoint')) if f.startswith('checkpoint_')) and len(cps) > 2
+    for f in ('saved_v.npy', 'saved_logl.npy', 'saved_logwt.npy'):
+        assert np.array_equal(np.load(str(tmp_path / 'py' / 'checkpoint' / f)), np.load(str(tmp_path / 'native' / 'checkpoint' / f))), f
+    assert open(str(tmp_path / 'py' / 'checkpoint' / cps[-1])).read() == open(str(tmp_path / 'native' / 'checkpoint' / cps[-1])).read()
