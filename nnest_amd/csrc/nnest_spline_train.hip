@@ -297,7 +297,7 @@ __device__ __forceinline__ void spl_matmul(const float *__restrict__ frag, int l
 
 // the same product with its output tiles dealt out over the team's waves (to mod TEAM) and exchanged through LDS: every wave
 // repeated all (2 NTh)^2 x 4 matrix instructions before, 0.85 us per product at x_dim 50
-template <int NTh, int TEAM>
+template <int NTh, int TEAM, bool TAILB = true>
 __device__ __forceinline__ void spl_matmul_team(const float *__restrict__ frag, int lane, int wv, f32x4 *xch, const f32x4 (&in)[2][NTh],
                                                 f32x4 (&out)[2][NTh]) {
     constexpr int T2 = 2 * NTh;
@@ -320,11 +320,11 @@ __device__ __forceinline__ void spl_matmul_team(const float *__restrict__ frag, 
     spl_team_barrier();
 #pragma unroll
     for (int to = 0; to < T2; ++to) out[to / NTh][to % NTh] = xch[to * 64 + lane];
-    spl_team_barrier();
+    if constexpr (TAILB) spl_team_barrier();
 }
 
 // the same, the wave's output tile `wv` (TEAM >= 2 NTh: one tile per wave at most) with its fragments read from the wave's LDS slot
-template <int NTh, int TEAM>
+template <int NTh, int TEAM, bool TAILB = true>
 __device__ __forceinline__ void spl_matmul_team_lds(const float *slot /* LDS: [2 NTh * 4][64] */, int lane, int wv, f32x4 *xch, const f32x4 (&in)[2][NTh],
                                                     f32x4 (&out)[2][NTh]) {
     constexpr int T2 = 2 * NTh;
@@ -347,7 +347,7 @@ __device__ __forceinline__ void spl_matmul_team_lds(const float *slot /* LDS: [2
     spl_team_barrier();
 #pragma unroll
     for (int to = 0; to < T2; ++to) out[to / NTh][to % NTh] = xch[to * 64 + lane];
-    spl_team_barrier();
+    if constexpr (TAILB) spl_team_barrier();
 }
 
 // sum over the 16 rows (lanes w) of a tile; valid in every lane
@@ -370,7 +370,7 @@ __device__ __forceinline__ f32x4 rows_sum(f32x4 v) {
 // Team of four waves per tile (TEAM = 4): wave wv owns the super-tiles s = wv (mod 4) -- their spline reverse mode, last-layer
 // weight gradients and share of g_h3 -- and the hidden layers' weight gradients are dealt out one layer per wave; the
 // delta propagation through the trunk is repeated by every wave so that all four leave with the same g_tr / g_cond.
-template <int NTh, int NH, int TEAM, bool DUP>
+template <int NTh, int NH, int TEAM, bool DUP, bool TAILB = true>
 __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const float *__restrict__ cf, const float *__restrict__ cbw, int pnet,
                                                  int nin, int nout, int S, int lane, bool row_ok, bool cmask, float gld, float *lds17, float *gp,
                                                  const f32x4 (&cond)[NTh], const f32x4 (&x_tr)[NTh], f32x4 (&g_tr)[NTh], f32x4 (&g_cond)[NTh],
@@ -544,7 +544,7 @@ __device__ __forceinline__ void spl_coupling_bwd(const SplTrainShape &ts, const 
             for (int k = 1; k < TEAM; ++k) acc = acc + xch[(TEAM * NTh + k * NH + ht) * 64 + lane];
             g_h[ht] = DUP ? acc + half_swap4(acc) : acc;  // (DUP: column w has the A share, column w ^ 8 the B share of the row)
         }
-        spl_team_barrier();
+        if constexpr (TAILB) spl_team_barrier();
     }
     CB_STAMP(2)
     // hidden layers 3 and 2 (W2 over h[1], W1 over h[0])
@@ -663,8 +663,14 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     const int per_wave = ((16 * (D + 1) + SPL_TBATCH * 16 * 17) + 3) & ~3;
     float *buf = lds + (size_t)wv * per_wave;   // 16 x (D+1): layout exchange (per wave)
     float *lds17 = buf + 16 * (D + 1);           // SPL_TBATCH x 16 x 17: tile transposes (per wave)
-    f32x4 *xch = reinterpret_cast<f32x4 *>(lds + (size_t)TEAM * per_wave);  // [TEAM][NTh + NH][64]
-    float *ldred = reinterpret_cast<float *>(xch + TEAM * (NTh + NH) * 64);  // [TEAM][16]
+    // the team's exchange buffer, twice: exchanges alternate between the two, which lets each do with ONE barrier (between its
+    // writes and its reads) -- the barrier that kept the next exchange's writes off this one's reads is the next exchange's own
+    // (round 6; 21 exchanges per minibatch)
+    f32x4 *xch0 = reinterpret_cast<f32x4 *>(lds + (size_t)TEAM * per_wave);  // 2 x [TEAM][NTh + NH][64]
+    constexpr int XCH_N = TEAM * (NTh + NH) * 64;
+    int xsel = 0;
+    auto next_xch = [&]() -> f32x4 * { f32x4 *p = xch0 + ((xsel & 1) ? XCH_N : 0); xsel ^= 1; return p; };
+    float *ldred = reinterpret_cast<float *>(xch0 + 2 * XCH_N);  // [TEAM][16]
     // (lds_heads) per block: the conv fragments of output tile `wv` -- forward first, the transposed ones take their place once the
     // forward product has used them -- [B][2 NTh][2 NTh * 4][64] floats, and ActNorm's e^s | t as this lane holds them [B][4 NTh][64] f32x4
     constexpr int T2K = 2 * NTh;
@@ -827,11 +833,11 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         float ctf[LDS_OK ? T2K * 4 : 1];   // (lds_heads) the transposed conv fragments of this block: requested now, in LDS behind coupling 1
         if constexpr (LDS_OK) {
             if (staged) {
-                spl_matmul_team_lds<NTh, TEAM>(lconv + ((size_t)b * T2K + (wv < T2K ? wv : 0)) * T2K * 256, lane, wv, xch, av, c);
+                spl_matmul_team_lds<NTh, TEAM, false>(lconv + ((size_t)b * T2K + (wv < T2K ? wv : 0)) * T2K * 256, lane, wv, next_xch(), av, c);
                 if (mode != SPL_MODE_LOSS) load_frags<T2K * 4>(blk + ts.conv_floats + (size_t)(wv < T2K ? wv : 0) * T2K * 256, lane, ctf);
             }
         }
-        if (!staged) spl_matmul_team<NTh, TEAM>(blk, lane, wv, xch, av, c);
+        if (!staged) spl_matmul_team<NTh, TEAM, false>(blk, lane, wv, next_xch(), av, c);
         if (mode != SPL_MODE_LOSS) {  // ActNorm and conv outputs: the backward pass does not repeat them
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
@@ -849,8 +855,8 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
 #else
 #define SPL_FST
 #endif
-        if constexpr (DUP) ld += spl_coupling_pair<NTh, NH, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch, kpf, tfr, rfr, f2, SL_o SPL_FST);
-        else ld += spl_coupling<NTh, NH, false, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, xch);
+        if constexpr (DUP) ld += spl_coupling_pair<NTh, NH, TEAM, false>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, next_xch(), kpf, tfr, rfr, f2, SL_o SPL_FST);
+        else ld += spl_coupling<NTh, NH, false, TEAM>(f1, SU_o, nu_o, s.tail, lane, c[0], c[1], wv, next_xch());
         if (mode != SPL_MODE_LOSS) {  // upper' conditions the second coupling: kept for the backward pass
 #pragma unroll
             for (int t = 0; t < NTh; ++t) stash[((size_t)b * SPL_STASH * NTh + 2 * NTh + t) * 64 + lane] = c[1][t];
@@ -862,9 +868,9 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
                 for (int i = 0; i < T2K * 4; ++i) dst[i * 64 + lane] = ctf[i];
             }
         }
-        if constexpr (DUP) ld += spl_coupling_pair<NTh, NH, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch, kpf ? kpf + spl_keep_floats4(NTh, NH) * 64 : nullptr, tfr, rfr,
+        if constexpr (DUP) ld += spl_coupling_pair<NTh, NH, TEAM, false>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, next_xch(), kpf ? kpf + spl_keep_floats4(NTh, NH) * 64 : nullptr, tfr, rfr,
                                                                   b + 1 < B ? blk + ts.tblk_floats + 2 * ts.conv_floats : nullptr, SU_o SPL_FST);
-        else ld += spl_coupling<NTh, NH, false, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, xch);
+        else ld += spl_coupling<NTh, NH, false, TEAM>(f2, SL_o, nl_o, s.tail, lane, c[1], c[0], wv, next_xch());
 #ifdef NNEST_STAMP
         cv_a = wall_clock64();
 #endif
@@ -956,14 +962,14 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         f32x4 *hq2 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 1) * ntl + tile) * NH * 64;
         f32x4 *hq1 = reinterpret_cast<f32x4 *>(a.hbuf) + ((size_t)(2 * b + 0) * ntl + tile) * NH * 64;
         const f32x4 *kp = reinterpret_cast<const f32x4 *>(a.keep) + (((size_t)tile * TEAM + wv) * B + b) * 2 * spl_keep_floats4(NTh, NH) * 64;
-        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, cmask, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, xch, gq2, hq2, item_stride, kp + spl_keep_floats4(NTh, NH) * 64, TEAM > 1 ? (2 * b + 1) % (TEAM > 1 ? TEAM - 1 : 1) : 0
+        spl_coupling_bwd<NTh, NH, TEAM, DUP, false>(ts, f2, f2b, pblk + ts.p_f[1], nu_o, nl_o, SL_o, lane, ok, cmask, gld, lds17, gp, up2, c[0], gs[0], gs[1], wv, next_xch(), gq2, hq2, item_stride, kp + spl_keep_floats4(NTh, NH) * 64, TEAM > 1 ? (2 * b + 1) % (TEAM > 1 ? TEAM - 1 : 1) : 0
 #ifdef NNEST_STAMP
             , cb_t
 #endif
             );
         SPL_STAMP(2)
         // first coupling: upper' = RQS(upper; f1(lower))      (networks.py:582-588)
-        spl_coupling_bwd<NTh, NH, TEAM, DUP>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, cmask, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, xch, gq1, hq1, item_stride, kp, TEAM > 1 ? (2 * b) % (TEAM > 1 ? TEAM - 1 : 1) : 0
+        spl_coupling_bwd<NTh, NH, TEAM, DUP, false>(ts, f1, f1b, pblk + ts.p_f[0], nl_o, nu_o, SU_o, lane, ok, cmask, gld, lds17, gp, c[0], c[1], gs[1], gs[0], wv, next_xch(), gq1, hq1, item_stride, kp, TEAM > 1 ? (2 * b) % (TEAM > 1 ? TEAM - 1 : 1) : 0
 #ifdef NNEST_STAMP
             , cb_t
 #endif
@@ -1004,9 +1010,9 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
         SPL_STAMP(7)
         f32x4 ga[2][NTh];
         if constexpr (LDS_OK) {
-            if (staged) spl_matmul_team_lds<NTh, TEAM>(lconv + ((size_t)b * T2K + (wv < T2K ? wv : 0)) * T2K * 256, lane, wv, xch, gs, ga);
+            if (staged) spl_matmul_team_lds<NTh, TEAM, false>(lconv + ((size_t)b * T2K + (wv < T2K ? wv : 0)) * T2K * 256, lane, wv, next_xch(), gs, ga);
         }
-        if (!staged) spl_matmul_team<NTh, TEAM>(blk + ts.conv_floats, lane, wv, xch, gs, ga);
+        if (!staged) spl_matmul_team<NTh, TEAM, false>(blk + ts.conv_floats, lane, wv, next_xch(), gs, ga);
         SPL_STAMP(8)
         // ActNorm a = x e^s + t: g_s = sum_rows g_a x e^s, g_t = sum_rows g_a, g_x = g_a e^s  (the -1 of log|det| is added by the reducer)
 #pragma unroll
@@ -1740,7 +1746,7 @@ static hipError_t launch_grad(const SplGradArgs &a_in, hipStream_t st) {
     SplGradArgs a = a_in;
     const int tiles = grad_tiles(a);
     const int per_wave = ((16 * (a.ts.s.D + 1) + SPL_TBATCH * 16 * 17) + 3) & ~3;
-    size_t ldsb = (size_t)(SPL_TEAM * per_wave + SPL_TEAM * (a.ts.s.NTh + a.ts.s.NH) * 64 * 4 + SPL_TEAM * 16) * sizeof(float);
+    size_t ldsb = (size_t)(SPL_TEAM * per_wave + 2 * SPL_TEAM * (a.ts.s.NTh + a.ts.s.NH) * 64 * 4 + SPL_TEAM * 16) * sizeof(float);
     // the blocks' conv fragments and ActNorm vectors in LDS where they fit (x_dim 50, three blocks: 48 + 12 KB on top of 61 KB)
     static const bool heads_off = [] { const char *e = getenv("NNEST_SPL_LDS_HEADS"); return e && !strcmp(e, "0"); }();   // (diagnostic)
     const int T2 = 2 * a.ts.s.NTh;

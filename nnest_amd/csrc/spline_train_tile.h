@@ -240,7 +240,9 @@ __host__ __device__ inline int spl_keep_floats4(int NTh, int NH) { return 3 * NH
 // at a time: (k, k + 1) go to the low / high half of the columns, so ONE spline evaluation per lane serves two super-tiles
 // (the matrix work per super-tile is unchanged, the spline arithmetic -- the bulk of the instruction stream -- halves).
 // Both halves leave with the full transformed half again (results swapped across).  Returns this lane's share of log|det|.
-template <int NTh, int NH, int TEAM>
+// TAILB = false: no barrier behind the exchange's reads -- the caller alternates between two exchange buffers, so the next
+// exchange writes the other one and the one after it lies behind that exchange's barrier (round 6: one barrier per exchange)
+template <int NTh, int NH, int TEAM, bool TAILB = true>
 __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net, int S, int n_out, float tail, int lane,
                                                    const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv, f32x4 *xch,
                                                    f32x4 *__restrict__ keep, SplTrunkFrags<NTh, NH> &tf, SplRawFrags<NH> &rf,
@@ -323,7 +325,7 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
 #pragma unroll
     for (int t = 0; t < NTh; ++t)
         tr[t] = (f32x4){xch[(0 * NTh + t) * 64 + lane].x, xch[(1 * NTh + t) * 64 + lane].y, xch[(2 * NTh + t) * 64 + lane].z, xch[(3 * NTh + t) * 64 + lane].w};
-    spl_team_barrier();
+    if constexpr (TAILB) spl_team_barrier();
     CF_STAMP(3, tr[0].x)
     return ld;
 }
