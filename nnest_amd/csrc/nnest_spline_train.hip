@@ -655,7 +655,11 @@ template <int NTh, int NH>
 __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TEAM = SPL_TEAM;
-    if (a.stop && *a.stop) return;
+    // The early-stopping flag is REQUESTED here and looked at behind the prologue's loads (the first thing with a side effect
+    // outside the workgroup comes later): as the kernel's first statement it was a cold round trip to memory of its own in front
+    // of every launch (round 6).  The flag was written by an earlier launch: every wave reads the same value.
+    int stop_flag = 0;
+    if (a.stop) asm volatile("global_load_dword %0, %1, off" : "=v"(stop_flag) : "v"(a.stop) : "memory");
     const SplTrainShape &ts = a.ts;
     const SplineShape &s = ts.s;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, w = lane & 15, g = lane >> 4, tile = blockIdx.x, lane_k = lane;
@@ -778,7 +782,8 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");  // the warm-up's target register is free again only now
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink), "+v"(stop_flag) : : "memory");  // the warm-up's target register is free again only now
+    if (stop_flag) return;   // (uniform over the workgroup, in front of its first barrier)
     if constexpr (LDS_OK) {
         if (lds_heads) spl_team_barrier();   // (the ActNorm vectors are read by every wave)
     }
@@ -1311,7 +1316,11 @@ __device__ __forceinline__ void spl_lds_barrier() { asm volatile("s_waitcnt lgkm
 
 template <int NTh, int NH>
 __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
-    if (a.stop && *a.stop) return;
+    // (the early-stopping flag: requested now, looked at behind each role's first batch of loads and in front of its first store --
+    // see spl_grad_kernel)
+    int stop_flag = 0;
+    if (a.stop) asm volatile("global_load_dword %0, %1, off" : "=v"(stop_flag) : "v"(a.stop) : "memory");
+#define SPL_STOP_CHECK() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(stop_flag) : : "memory"); if (stop_flag) return; }
     extern __shared__ float ulds[];
     const SplTrainShape &ts = a.ts;
     const SplineShape &s = ts.s;
@@ -1374,7 +1383,33 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
                 gd[u] = idx < D * D ? a.pi[b * D + ic / D] * DP + ic % D : -1;
             }
             const float *pan = a.partial + base + (an ? tid : 0);
-            if (a.tiles <= 16) {  // two rounds of 8 tiles x 5 elements in flight (the 1024-thread workgroup has 128 registers per lane)
+            if (a.tiles <= 13 && D * D <= 3 * 1024) {
+                // round 6: ONE round -- up to 13 tiles (a minibatch of 100 rows in 8-row tiles) x (3 elements of dLoss/dW + 1 ActNorm
+                // element) = 52 loads in flight: at x_dim <= 55 the fourth element of every thread lay past D * D (a quarter of the
+                // loads fetched element 0 again), and the second round was a second cold round trip to memory (~3.5 us)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gs[u] = 0.f;
+                float pv[4][13];
+#pragma unroll
+                for (int t = 0; t < 13; ++t) {
+                    const size_t off = (size_t)(t < a.tiles ? t : a.tiles - 1) * n;
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int idx = tid + u * 1024, ic = idx < D * D ? idx : 0;
+                        pv[u][t] = a.partial[off + np + b * D * D + ic];
+                    }
+                    pv[3][t] = pan[off];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 13; ++t) {   // (summed in tile order, as the two-round form sums them)
+                    const bool live = t < a.tiles;
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) gs[u] += live ? pv[u][t] : 0.f;
+                    an_g += live ? pv[3][t] : 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (a.tiles <= 16) {  // two rounds of 8 tiles x 5 elements in flight (the 1024-thread workgroup has 128 registers per lane)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) gs[u] = 0.f;
 #pragma unroll
@@ -1431,6 +1466,7 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
             for (int u = 0; u < 4; ++u) if (gd[u] >= 0) G[gd[u]] = gs[u];
             for (int i = tid; i < D; i += blockDim.x) spi[i] = a.pi[b * D + i];
         }
+        SPL_STOP_CHECK()   // (every load of the phase has been consumed by now: the wait is free; uniform over the workgroup)
         spl_lds_barrier();
         U_STAMP(1)
         // dLoss/dL = tril(G Um^T, -1) and dLoss/d(Um) = triu(Lm^T G): two D^3 products on the matrix cores, one 16x16 output tile
@@ -1546,16 +1582,20 @@ __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
             pi_[4 * NH] = (lane < 16 && jo < nout && pp < SPL_P) ? pb3 + jo * SPL_P + pp : -1;
             gi_[4 * NH] = db;
         }
+        SPL_STOP_CHECK()
         step.template many<4 * NH + 1>(pi_, gi_);
         return;
     }
     // the trunks: W0, b0, W1, b1, W2, b2 of both conditioners of every block
     const int tr0 = H * s.nl + H + 2 * (H * H + H), tr1 = H * s.nu + H + 2 * (H * H + H), per = tr0 + tr1;
     const int nw = (int)gridDim.x - B - a.n_w3, first = (int)blockIdx.x - B - a.n_w3;
+    bool stop_checked = false;
     for (int idx = first * (int)blockDim.x + tid; idx < B * per; idx += nw * (int)blockDim.x) {
         const int b = idx / per, o = idx - b * per;
         const int p = b * s.blk_params + (o < tr0 ? ts.p_f[0] + o : ts.p_f[1] + (o - tr0));
-        step(p, spl_sum_tiles(a.partial + p, n, a.tiles));
+        const float gsum = spl_sum_tiles(a.partial + p, n, a.tiles);
+        if (!stop_checked) { SPL_STOP_CHECK() stop_checked = true; }   // (behind the first sums' loads, in front of the first store)
+        step(p, gsum);
     }
     if (first == 0 && tid == 0 && a.loss_out) {
         float acc = 0.f;

@@ -508,3 +508,38 @@ def test_wider_shapes_vs_oracle(hip, D, H):
     res = sp.train_epochs(x0[:80], x0[80:], perms, None, seed=1, jitter=0.01, batch=100, max_epochs=4, patience=50)
     l = res['losses'].numpy()
     assert np.all(np.isfinite(l)) and l[-1, 0] < l[0, 0]
+
+
+@pytest.mark.parametrize('D', [6, 50])
+def test_spline_training_stops_when_patience_runs_out_and_queued_launches_do_nothing(hip, D):
+    """Trainer.train's early stopping (nnest/trainer.py:205-209, :223-232) on the spline flow: the epoch books live on the device
+    and the host queues launches ahead of them, so the launches queued past the stop must leave weights, Adam state and step count
+    alone (every training kernel looks at the stop flag in front of its first store -- round 6: behind its first loads).  A run with
+    a validation set that gets worse: it ends `patience` epochs after its best epoch, restores that epoch's weights, and is -- bit
+    for bit -- the run that was only ever asked for that many epochs."""
+    rng = np.random.RandomState(1)
+    X = rng.uniform(-1, 1, size=(240, D)).astype(np.float32)
+    Xv = (rng.uniform(-1, 1, size=(30, D)) * 2.5).astype(np.float32)   # off-distribution: the validation loss turns around early
+    E = 120
+    perm = torch.stack([torch.randperm(240, generator=torch.Generator().manual_seed(e)) for e in range(E)]).int()
+    kw = dict(seed=1, jitter=0.0, batch=100, patience=4, lr=5e-3)
+
+    def run(max_epochs):
+        sp = hip.HipSpline(D, 16, 3, seed=5)
+        res = sp.train_epochs(X, Xv, perm[:max_epochs], None, max_epochs=max_epochs, **kw)
+        return sp, res
+
+    sp, res = run(E)
+    assert res['stopped'] and res['epochs_run'] < E - 16          # (the host runs up to two chunks of eight epochs ahead)
+    assert res['epochs_run'] == res['best_epoch'] + 4
+    losses = res['losses'].numpy()[:res['epochs_run']]
+    assert abs(losses[res['best_epoch'] - 1, 1] - res['best_validation_loss']) < 1e-7
+    assert np.all(losses[res['best_epoch']:, 1] >= res['best_validation_loss'])
+    sp2, res2 = run(res['epochs_run'])                             # nothing queued past the stop
+    assert res2['epochs_run'] == res['epochs_run'] and res2['best_epoch'] == res['best_epoch']
+    assert np.array_equal(res2['losses'].numpy()[:res['epochs_run']], losses)
+    assert np.array_equal(sp2.store_packed(), sp.store_packed())   # the best epoch's weights, the same bits
+    # the optimiser's state too: one more epoch from either lands on the same weights
+    for s_ in (sp, sp2):
+        s_.train_epochs(X, Xv, perm[:1], None, max_epochs=1, **kw)
+    assert np.array_equal(sp2.store_packed(), sp.store_packed())
