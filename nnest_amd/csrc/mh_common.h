@@ -74,7 +74,7 @@ struct MhArgs {
 };
 
 // the usable-chain test of the 16-walker-tile forms behind their launch (nnest_kernels.hip)
-float *mh_first_x_buffer(size_t floats);
+float *mh_first_x_buffer(size_t floats, hipStream_t st);
 hipError_t launch_mh_all_moved(const MhArgs &a, hipStream_t st);
 hipError_t launch_mh_zero_other_sync(const MhArgs &a, hipStream_t st);
 

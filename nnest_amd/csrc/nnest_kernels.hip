@@ -5,6 +5,9 @@
 //   mh_kernel                 K4 persistent multi-step constrained Metropolis (Sampler._mcmc_sample)
 //   fill_noise_kernel         the in-kernel proposal noise as arrays (tests)
 // Launch wrappers (C++, used by nnest_abi.hip) are at the bottom.  See flow_tile.h for the data layout.
+#include <map>
+#include <mutex>
+#include <utility>
 #include <string.h>
 
 #include "flow_tile.h"
@@ -579,21 +582,27 @@ __global__ void __launch_bounds__(256) mh_all_moved_kernel(const float *__restri
         if (__ballot(all) == ~0ull && lane == 0) n_accept[c] |= NNEST_MH_ALL_MOVED;
     }
 }
-// the side buffer the tile forms park the first x in: one per device, grown on demand, reused by every launch (launches of one
-// device are ordered by the stream they share with the follow-up kernel; growing frees the old buffer, which waits for the device)
-float *mh_first_x_buffer(size_t floats) {
-    static float *buf[16] = {};
-    static size_t cap[16] = {};
+// the side buffer the tile forms park the first x in (for the usable-chain test behind the launch): one per (device, stream), grown on
+// demand under a lock and reused by that stream's launches -- the MH kernel and mh_all_moved_kernel that reads the buffer are
+// ordered by the stream, and launches on OTHER streams (another flow, another host thread: ctypes releases the interpreter lock)
+// have a buffer of their own (round 6, ADVICE r05: it was one unlocked buffer per device).  Growing frees the old buffer, which
+// waits for the device.  NULL = allocation failed: the caller fails the launch (the flag's meaning must not change silently).
+float *mh_first_x_buffer(size_t floats, hipStream_t st) {
+    struct Buf { float *p = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (cap[dev] < floats) {
-        if (buf[dev]) (void)hipFree(buf[dev]);
-        buf[dev] = nullptr; cap[dev] = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    Buf &b = bufs[std::make_pair(dev, st)];
+    if (b.cap < floats) {
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr; b.cap = 0;
         const size_t want = floats + floats / 2 + 4096;
-        if (hipMalloc((void **)&buf[dev], want * sizeof(float)) != hipSuccess) return nullptr;
-        cap[dev] = want;
+        if (hipMalloc((void **)&b.p, want * sizeof(float)) != hipSuccess) { b.p = nullptr; return nullptr; }
+        b.cap = want;
     }
-    return buf[dev];
+    return b.p;
 }
 // NNEST_MH_SYNC_ZERO_NEXT / _PREV for the forms that do not zero the other half of the caller's double buffer themselves
 hipError_t launch_mh_zero_other_sync(const MhArgs &a, hipStream_t st) {
@@ -627,7 +636,7 @@ static hipError_t launch_mh_t(const MhArgs &a_in, int num_cu, hipStream_t st) {
         return e != hipSuccess ? e : launch_mh_zero_other_sync(a_in, st);
     }
     MhArgs a = a_in;
-    if (a.x && a.n_accept) a.x0 = mh_first_x_buffer((size_t)a.C * a.s.D);
+    if (a.x && a.n_accept && !(a.x0 = mh_first_x_buffer((size_t)a.C * a.s.D, st))) return hipErrorOutOfMemory;
     hipError_t e = launch_mh_tiles_t<NT, NH, LT>(a, form, num_cu, st);
     if (e != hipSuccess) return e;
     e = launch_mh_zero_other_sync(a, st);
@@ -779,7 +788,7 @@ hipError_t launch_mh(const float *img, const FlowShape &s, const LikeSpec &like,
     a.hist_x = hist_x; a.hist_logl = hist_logl; a.n_accept = n_accept; a.n_call = n_call; a.scale_out = scale_out;
     a.x0 = nullptr;
     if (s.kind == FLOW_KIND_MAF) {
-        if (a.x && a.n_accept) a.x0 = mh_first_x_buffer((size_t)C * s.D);
+        if (a.x && a.n_accept && !(a.x0 = mh_first_x_buffer((size_t)C * s.D, st))) return hipErrorOutOfMemory;
         hipError_t e = launch_maf_mh(a, num_cu, st);
         if (e == hipSuccess) e = launch_mh_zero_other_sync(a, st);
         return e != hipSuccess ? e : launch_mh_all_moved(a, st);

@@ -190,7 +190,7 @@ hipError_t launch_spline_mh(const float *img, const SplineShape &sp, const LikeS
     a.like = like; a.noise_dz = noise_dz; a.noise_u = noise_u; a.seed = seed; a.walker_offset = walker_offset;
     a.hist_x = hist_x; a.hist_logl = hist_logl; a.n_accept = n_accept; a.n_call = n_call; a.scale_out = scale_out;
     SplArgs q = {img, sp};
-    if (a.x && a.n_accept) a.x0 = mh_first_x_buffer((size_t)C * sp.D);
+    if (a.x && a.n_accept && !(a.x0 = mh_first_x_buffer((size_t)C * sp.D, st))) return hipErrorOutOfMemory;
     hipError_t e = [&]() -> hipError_t { DISPATCH_SPLINE(launch_spline_mh_t, sp, a, q, num_cu, st); }();
     if (e == hipSuccess) e = launch_mh_zero_other_sync(a, st);
     return e != hipSuccess ? e : launch_mh_all_moved(a, st);
