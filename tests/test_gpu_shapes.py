@@ -39,7 +39,9 @@ def make(hip, D, H, B, L, seed=0):
 
 SHAPES = [(1, 16, 3, 1), (2, 16, 3, 1), (31, 16, 3, 1), (33, 16, 3, 1), (64, 16, 3, 1), (65, 16, 3, 1), (97, 16, 2, 1),
           (128, 16, 3, 1), (10, 16, 4, 0), (10, 16, 3, 2), (40, 16, 3, 3), (9, 32, 3, 1), (64, 32, 2, 2), (20, 64, 5, 1),
-          (32, 64, 2, 2)]
+          (32, 64, 2, 2),
+          # hidden widths that are not 16 / 32 / 64: zero-padded on the next instantiated width (flow._PaddedVectors), the oracle at the true width
+          (5, 10, 3, 1), (20, 24, 3, 1), (9, 40, 2, 1), (50, 8, 3, 1)]
 
 
 @pytest.mark.parametrize('D,H,B,L', SHAPES, ids=['D%d_H%d_B%d_L%d' % s for s in SHAPES])
@@ -109,7 +111,7 @@ def test_the_references_trainer_envelope_runs(flow, tmp_path):
 
 
 MH_SHAPES = [(2, 16, 3, 1), (20, 16, 3, 1), (50, 16, 3, 1), (70, 16, 3, 1), (100, 16, 3, 1), (10, 16, 4, 0), (10, 16, 3, 2),
-             (12, 32, 3, 1), (8, 64, 2, 1), (50, 16, 5, 1)]
+             (12, 32, 3, 1), (8, 64, 2, 1), (50, 16, 5, 1), (5, 10, 3, 1), (20, 24, 3, 1), (50, 12, 3, 1)]
 
 
 @pytest.mark.parametrize('D,H,B,L', MH_SHAPES, ids=['D%d_H%d_B%d_L%d' % s for s in MH_SHAPES])
