@@ -201,6 +201,25 @@ int nnest_mh_constrained_steps(nnest_nvp_t *nvp, const nnest_like_t *like, float
  * walkers over ranks asks with C = C_total and pins the answer on every shard (reference: the MPI scatter of one batch,
  * nnest/nested.py:405-427, has no such choice -- every rank runs the same Python). */
 int nnest_mh_form_for(const nnest_nvp_t *nvp, int C, int flags);
+
+/* SLICE proposal in latent space (BASELINE.json north_star: "the slice/MH proposal step in latent space").
+ * ABSENT FROM THE REFERENCE: Sampler._mcmc_sample proposes Gaussian random-walk Metropolis moves only (nnest/sampler.py:310-316), so
+ * this step is build-defined and its parity UNPINNED; it is held to a CPU restatement of the same definition
+ * (oracle/oracle.py::slice_sample).  `steps` slice-sampling updates (Neal 2003: stepping out, shrinkage) of every walker along a
+ * fresh random direction of latent space, of the target the reference's constrained Metropolis step leaves invariant
+ * (sampler.py:326-361): density |det dx/dz| on {x(z) in the unit box, logL(x(z)) > loglstar}.  Per step: eps ~ N(0, I),
+ * candidates z + t * width * eps; log y = log|det|(z) + log u1; bracket [-u0, 1 - u0], stepped out by 1 up to max_stepout times per
+ * side while the end lies in the slice; then up to max_shrink shrinkage draws t = t_l + (t_r - t_l) u_k.  z_dev [C,D] and logl_dev [C]
+ * are updated in place, x_dev [C,D] receives the chains' ends; n_call_dev [C]: candidates whose likelihood decided (inside the box and
+ * above the slice level), n_move_dev [C]: steps that moved, with NNEST_MH_ALL_MOVED as in nnest_mh_constrained_steps, n_eval_dev [C]
+ * (or NULL): evaluations of the flow.  noise_dz_dev [steps,C,D] replays recorded directions (NULL: in-kernel Philox, the draws
+ * nnest_slice_fill_noise exports); the uniforms are Philox4x32-10 words of (seed, walker, 64 step + k), exact in float32.
+ * hist_x_dev [C, steps + 1, D] or NULL.  One walker per wave, no cross-workgroup wait: any C.  Shapes: the reference's defaults
+ * (hidden 16, 3 blocks, 1 layer, scale ''), x_dim <= 128; NNEST_E_UNSUPPORTED otherwise.  (Added within ABI 15.) */
+int nnest_slice_steps(nnest_nvp_t *nvp, const nnest_like_t *like, float *z_dev, float *x_dev, double *logl_dev, double loglstar,
+                      float width, int steps, int C, int max_stepout, int max_shrink, const float *noise_dz_dev, uint64_t seed,
+                      uint64_t walker_offset, float *hist_x_dev, int *n_call_dev, int *n_move_dev, int *n_eval_dev, void *stream);
+int nnest_slice_fill_noise(float *dz_dev, int steps, int C, int D, uint64_t seed, uint64_t walker_offset, void *stream);
 /* size of sync_dev in 8-byte words for a launch of `steps` steps */
 int nnest_mh_sync_words(int steps);
 /* number of adaptation groups nnest_mh_constrained_steps uses for C walkers (size of scale_out_dev) */

@@ -143,6 +143,8 @@ SIGNATURES = {
     'nnest_host_mcmc_consume': [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong,
                                 _d, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong],
     'nnest_host_h_update': [_d, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong],
+    'nnest_slice_steps': [_vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i, _i, _i, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp],
+    'nnest_slice_fill_noise': [_vp, _i, _i, _i, _u64, _u64, _vp],
     'nnest_host_prior_consume': [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  ctypes.c_longlong, _d, ctypes.c_longlong, ctypes.c_longlong, _d, _d, _i],
 }

@@ -373,6 +373,29 @@ int nnest_mh_constrained_steps(nnest_nvp_t *h, const nnest_like_t *like, float *
     return NNEST_OK;
 }
 
+int nnest_slice_steps(nnest_nvp_t *h, const nnest_like_t *like, float *z_dev, float *x_dev, double *logl_dev, double loglstar,
+                      float width, int steps, int C, int max_stepout, int max_shrink, const float *noise_dz_dev, uint64_t seed,
+                      uint64_t walker_offset, float *hist_x_dev, int *n_call_dev, int *n_move_dev, int *n_eval_dev, void *stream) {
+    int rc = check_rows(h, z_dev, logl_dev, C);
+    if (rc) return rc;
+    LikeSpec lk;
+    if ((rc = check_like(like, h->s.D, &lk))) return rc;
+    if (steps < 0 || max_stepout < 0 || max_shrink < 1 || max_shrink > 60 || !(width > 0.f))
+        return fail(NNEST_E_ARG, "steps=%d max_stepout=%d max_shrink=%d (1..60) width=%g", steps, max_stepout, max_shrink, (double)width);
+    if (!slice_form_eligible(h->s))
+        return fail(NNEST_E_UNSUPPORTED, "slice proposal: hidden 16, 3 blocks, 1 layer, scale '' (the one-walker-per-wave layout), x_dim <= 128");
+    hipError_t e = launch_slice_solo(h->s, h->w, lk, z_dev, x_dev, logl_dev, loglstar, width, steps, C, max_stepout, max_shrink, seed,
+                                     walker_offset, noise_dz_dev, hist_x_dev, n_call_dev, n_move_dev, n_eval_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(NNEST_E_HIP, "launch_slice_solo: %s", hipGetErrorString(e));
+    return NNEST_OK;
+}
+
+int nnest_slice_fill_noise(float *dz_dev, int steps, int C, int D, uint64_t seed, uint64_t walker_offset, void *stream) {
+    if (!dz_dev || steps < 0 || C < 0 || D < 1) return fail(NNEST_E_ARG, "bad argument");
+    HIP_TRY(launch_slice_fill_noise(dz_dev, steps, C, D, seed, walker_offset, (hipStream_t)stream));
+    return NNEST_OK;
+}
+
 int nnest_mh_form_for(const nnest_nvp_t *h, int C, int flags) {
     if (!h || C < 1) return -1;
     return mh_form_for(h->s, C, flags, h->num_cu);

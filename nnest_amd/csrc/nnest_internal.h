@@ -78,5 +78,11 @@ hipError_t launch_maf_train_minibatch(const FlowShape &s, float *imgf, float *im
 hipError_t launch_maf_loss_grad(const FlowShape &s, const float *imgf, const float *imgb, const int *gpos, const float *x, int M,
                                 float *grad, float *loss, float *workspace, hipStream_t st);
 hipError_t launch_training_jitter(const double *samples, int N, int D, double *out, hipStream_t st);
+// slice proposal in latent space (nnest_solo.hip; build-defined: the reference has none)
+bool slice_form_eligible(const FlowShape &s);
+hipError_t launch_slice_solo(const FlowShape &s, const float *packed, const LikeSpec &like, float *z, float *x, double *logl, double loglstar,
+                             float width, int steps, int C, int max_out, int max_shrink, uint64_t seed, uint64_t walker_offset,
+                             const float *noise_dz, float *hist_x, int *n_call, int *n_move, int *n_eval, hipStream_t st);
+hipError_t launch_slice_fill_noise(float *dz, int steps, int C, int D, uint64_t seed, uint64_t walker_offset, hipStream_t st);
 
 }  // namespace nnest

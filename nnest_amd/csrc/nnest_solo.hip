@@ -660,6 +660,263 @@ __global__ void __launch_bounds__(64 * (WPG + 2)) mh_kernel_solo(MhArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// SLICE proposal in latent space (BASELINE north_star: "the slice/MH proposal step in latent space").
+// ABSENT FROM THE REFERENCE -- nnest/sampler.py:310-316 proposes Gaussian random-walk Metropolis moves only -- so the step is
+// build-defined and its parity unpinned: univariate slice sampling (Neal 2003: stepping out + shrinkage) along a
+// random direction of latent space, of the SAME target the reference's constrained Metropolis step leaves invariant
+// (sampler.py:326-361): pi(z) ~ |det dx/dz| (the uniform prior's density seen from latent space) on {x(z) in the prior box,
+// logL(x(z)) > L*}.  Per step and walker:
+//   eps ~ N(0, I_D) (noise_normal4, stream DZ);  candidates z(t) = z + t * width * eps,  t in R
+//   log y = log|det|(z) + log u_1;   inside(t) := x(z(t)) in the box  and  log|det|(z(t)) > log y  and  logL(x(z(t))) > L*
+//   bracket [t_l, t_r] = [-u_0, 1 - u_0];  stepping out: while inside(t_l) and fewer than `max_out` steps: t_l -= 1 (the same to the right)
+//   shrinkage: t = t_l + (t_r - t_l) u_k (k = 2, 3, ...); inside(t) -> the walker moves there; else the bracket's end on t's side
+//   becomes t; after `max_shrink` draws the walker stays.
+// Every evaluation is one "eval" of the hot path (coupling-stack inverse + log-det + box + likelihood); n_call counts, as the
+// Metropolis kernel does, the candidates whose likelihood decided (those that passed the box and the slice level).
+// One walker per wave (the solo layout): the data-dependent loops of a walker are uniform over its wave, walkers do not wait for
+// each other, and no step crosses a workgroup -- any population, no resident-grid requirement.  u_k = noise_uniform(seed, walker,
+// 64 step + k): exact in float32, so the CPU checker of the tests restates them word for word; the normals are exported for
+// it (nnest_slice_fill_noise), like nnest_mh_fill_noise exports the Metropolis kernel's.
+struct SliceArgs {
+    FlowShape s;
+    const float *packed;
+    float *z, *x;
+    double *logl;
+    double loglstar;
+    float width;
+    int steps, C, max_out, max_shrink;
+    LikeSpec like;
+    uint64_t seed, walker_offset;
+    const float *noise_dz;   // recorded directions [steps][C][D] (tests) or NULL
+    float *hist_x;           // [C][steps + 1][D] or NULL
+    int *n_call, *n_move, *n_eval;
+};
+
+template <int U>   // this lane's 2U normals of (walker, step): dims 2U pos + 2u + c, the quads of noise_normal4
+static __device__ __forceinline__ void slice_normals(uint64_t seed, uint64_t walker, uint32_t step, int pos, int D, float (&e)[2][U]) {
+    const int d0 = 2 * U * pos;
+    f32x4 q[(2 * U + 3) / 4 + 1];
+    const int q0 = d0 >> 2;
+#pragma unroll
+    for (int k = 0; k < (2 * U + 3) / 4 + 1; ++k) q[k] = noise_normal4(seed, walker, step, (uint32_t)(q0 + k), NOISE_STREAM_DZ);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int d = d0 + 2 * u + c, k = (d >> 2) - q0, r = d & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < (2 * U + 3) / 4 + 1; ++kk)
+                if (kk == k) v = r == 0 ? q[kk].x : (r == 1 ? q[kk].y : (r == 2 ? q[kk].z : q[kk].w));
+            e[c][u] = d < D ? v : 0.f;
+        }
+}
+
+template <int U, int LK>
+__global__ void __launch_bounds__(256) slice_kernel_solo(SliceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int D = a.s.D, S = a.steps, C = a.C;
+    constexpr bool LDSW = solo_lds_weights<U, 4>();
+    {
+        if constexpr (!LDSW) {
+            const int n = a.s.nets_params();
+            for (int i = threadIdx.x; i < n; i += blockDim.x) wlds[i] = a.packed[i];
+        } else if (wave < 3) {
+            SoloNet<U> nb;
+            solo_gather<U>(nb, a.packed + (size_t)(wave * 2 + (lane >= 32 ? 1 : 0)) * a.s.net_params, D, (wave + 1) & 1, wave & 1, lane);
+            solo4_store<U>(wlds, wave, nb, lane);
+        }
+    }
+    __syncthreads();
+    const int pos = lane & 15;
+    const bool translate_half = lane >= 32, writer_lane = lane < 16;
+    const int row = blockIdx.x * 4 + wave;
+    const bool ok = row < C;
+    if (!ok) return;   // (no barrier behind this point)
+    const LikeSpec like = a.like;
+    const double loglstar = a.loglstar;
+    SoloNet<U> net[LDSW ? 1 : 3];
+    if constexpr (!LDSW) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            solo_gather<U>(net[b], wlds + (size_t)(b * 2 + (translate_half ? 1 : 0)) * a.s.net_params, D, (b + 1) & 1, b & 1, lane);
+    }
+    const unsigned sel = translate_half ? 0xffffffffu : 0u;
+    const bool h1 = (lane & 16) != 0;
+    auto inverse = [&](float (&xs)[2][U]) {   // NormalizingFlow.inverse (networks.py:34-42), blocks 2, 1, 0
+        if constexpr (LDSW) {
+            float ld = solo_coupling_inverse4<U>(Solo4Lds{wlds + (size_t)2 * SOLO4_NF * 64, lane}, sel, h1, xs[1], xs[0]);
+            ld += solo_coupling_inverse4<U>(Solo4Lds{wlds + (size_t)1 * SOLO4_NF * 64, lane}, sel, h1, xs[0], xs[1]);
+            ld += solo_coupling_inverse4<U>(Solo4Lds{wlds, lane}, sel, h1, xs[1], xs[0]);
+            return ld;
+        } else {
+            float ld = solo_coupling_inverse<U>(net[2], sel, h1, xs[1], xs[0]);
+            ld += solo_coupling_inverse<U>(net[1], sel, h1, xs[0], xs[1]);
+            ld += solo_coupling_inverse<U>(net[0], sel, h1, xs[1], xs[0]);
+            return ld;
+        }
+    };
+    auto store_row = [&](float *base, size_t r, const float (&v)[2][U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int d = 2 * U * pos + 2 * u + c;
+                if (d < D) base[r * D + d] = v[c][u];
+            }
+    };
+    float z[2][U], x[2][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int d = 2 * U * pos + 2 * u + c;
+            z[c][u] = d < D ? a.z[(size_t)row * D + d] : 0.f;
+            x[c][u] = z[c][u];
+        }
+    float ld = solo_logdet_total(inverse(x));
+    double logl = a.logl[row];
+    if (writer_lane && a.x) store_row(a.x, (size_t)row, x);   // the chain's first x (usable-chain test at the end, nested.py:432)
+    if (writer_lane && a.hist_x) store_row(a.hist_x, (size_t)row * (S + 1), x);
+    const uint64_t walker = a.walker_offset + (uint64_t)row;
+    int n_call = 0, n_move = 0, n_eval = 0;
+    float zc[2][U], xc[2][U], ldc = 0.f;
+    double lc = 0.0;
+    for (int it = 1; it <= S; ++it) {
+        float e[2][U];
+        if (a.noise_dz) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int d = 2 * U * pos + 2 * u + c;
+                    e[c][u] = d < D ? a.noise_dz[((size_t)(it - 1) * C + row) * D + d] : 0.f;
+                }
+        } else {
+            slice_normals<U>(a.seed, walker, (uint32_t)it, pos, D, e);
+        }
+        const float u0 = noise_uniform(a.seed, walker, 64u * (uint32_t)it + 0u), u1 = noise_uniform(a.seed, walker, 64u * (uint32_t)it + 1u);
+        const float logy = ld + __logf(u1);   // (u1 = 0: -inf, the whole feasible line is the slice)
+        // one evaluation: candidate t -> (zc, xc, ldc, lc); true if it lies in the slice
+        auto inside = [&](float t) -> bool {
+            const float tw = t * a.width;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) { zc[c][u] = __builtin_fmaf(e[c][u], tw, z[c][u]); xc[c][u] = zc[c][u]; }
+            ldc = solo_logdet_total(inverse(xc));
+            int okl = 1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int u = 0; u < U; ++u) okl &= !(xc[c][u] < -1.f || xc[c][u] > 1.f);   // UniformPrior(D, -1, 1): priors.py:39-43
+            const bool inb = __ballot(okl != 0) == ~0ull;
+            const bool pre = inb && (ldc > logy);
+            lc = solo_loglike<U, LK>(like, D, lane, xc);
+            n_eval += 1;
+            n_call += pre ? 1 : 0;
+            return pre && (lc > loglstar);
+        };
+        float tl = -u0, tr = 1.0f - u0;
+        for (int j = 0; j < a.max_out; ++j) { if (!inside(tl)) break; tl -= 1.0f; }
+        for (int j = 0; j < a.max_out; ++j) { if (!inside(tr)) break; tr += 1.0f; }
+        bool moved = false;
+        for (int k = 0; k < a.max_shrink; ++k) {
+            const float uk = noise_uniform(a.seed, walker, 64u * (uint32_t)it + 2u + (uint32_t)k);
+            const float t = __builtin_fmaf(tr - tl, uk, tl);
+            if (inside(t)) { moved = true; break; }
+            if (t < 0.f) tl = t; else tr = t;
+        }
+        if (moved) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int u = 0; u < U; ++u) { z[c][u] = zc[c][u]; x[c][u] = xc[c][u]; }
+            ld = ldc; logl = lc; n_move += 1;
+        }
+        if (writer_lane && a.hist_x) store_row(a.hist_x, (size_t)row * (S + 1) + it, x);
+    }
+    bool all_moved = n_move > 0;
+    if (a.x) {
+        bool mine = true;
+        if (writer_lane) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int d = 2 * U * pos + 2 * u + c;
+                    const float x0 = d < D ? a.x[(size_t)row * D + d] : 0.f;
+                    mine = mine && (d >= D || x[c][u] != x0);
+                }
+        }
+        all_moved = (__ballot(mine) & 0xffffull) == 0xffffull;
+    }
+    if (writer_lane) {
+        store_row(a.z, (size_t)row, z);
+        if (a.x) store_row(a.x, (size_t)row, x);
+        if (pos == 0) {
+            a.logl[row] = logl;
+            if (a.n_call) a.n_call[row] = n_call;
+            if (a.n_move) a.n_move[row] = n_move | (all_moved ? NNEST_MH_ALL_MOVED : 0);
+            if (a.n_eval) a.n_eval[row] = n_eval;
+        }
+    }
+}
+
+// the directions the slice kernel draws (noise_normal4, stream DZ), exported for the checker: dz [steps][C][D]
+__global__ void slice_fill_noise_kernel(float *__restrict__ dz, int steps, int C, int D, uint64_t seed, uint64_t walker_offset) {
+    const long nq = (long)steps * C * ((D + 3) / 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (long)gridDim.x * blockDim.x) {
+        const int Q = (D + 3) / 4, q = (int)(i % Q), c = (int)((i / Q) % C), it = (int)(i / ((long)Q * C)) + 1;
+        const f32x4 n = noise_normal4(seed, walker_offset + (uint64_t)c, (uint32_t)it, (uint32_t)q, NOISE_STREAM_DZ);
+        float *o = dz + ((size_t)(it - 1) * C + c) * D + 4 * q;
+        if (4 * q + 0 < D) o[0] = n.x;
+        if (4 * q + 1 < D) o[1] = n.y;
+        if (4 * q + 2 < D) o[2] = n.z;
+        if (4 * q + 3 < D) o[3] = n.w;
+    }
+}
+
+template <int U, int LK>
+static hipError_t launch_slice_k(const SliceArgs &a, hipStream_t st) {
+    const size_t lds = solo_lds_weights<U, 4>() ? (size_t)3 * SOLO4_NF * 64 * sizeof(float) : (size_t)a.s.nets_params() * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(slice_kernel_solo<U, LK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((slice_kernel_solo<U, LK>), dim3((a.C + 3) / 4), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+bool slice_form_eligible(const FlowShape &s) {
+    return s.kind == FLOW_KIND_NVP && s.H == 16 && s.B == 3 && s.L == 1 && s.scale_mode == 0 && s.NT >= 1 && s.NT <= 4;
+}
+
+hipError_t launch_slice_solo(const FlowShape &s, const float *packed, const LikeSpec &like, float *z, float *x, double *logl, double loglstar,
+                             float width, int steps, int C, int max_out, int max_shrink, uint64_t seed, uint64_t walker_offset,
+                             const float *noise_dz, float *hist_x, int *n_call, int *n_move, int *n_eval, hipStream_t st) {
+    if (C <= 0) return hipSuccess;
+    if (!slice_form_eligible(s)) return hipErrorInvalidConfiguration;
+    SliceArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s = s; a.packed = packed; a.z = z; a.x = x; a.logl = logl; a.loglstar = loglstar; a.width = width; a.steps = steps; a.C = C;
+    a.max_out = max_out; a.max_shrink = max_shrink; a.like = like; a.seed = seed; a.walker_offset = walker_offset;
+    a.noise_dz = noise_dz; a.hist_x = hist_x; a.n_call = n_call; a.n_move = n_move; a.n_eval = n_eval;
+    const bool rosen = like.id == NNEST_LIKE_ROSENBROCK;
+    switch (s.NT) {
+        case 1: return rosen ? launch_slice_k<1, NNEST_LIKE_ROSENBROCK>(a, st) : launch_slice_k<1, -1>(a, st);
+        case 2: return rosen ? launch_slice_k<2, NNEST_LIKE_ROSENBROCK>(a, st) : launch_slice_k<2, -1>(a, st);
+        case 3: return rosen ? launch_slice_k<3, NNEST_LIKE_ROSENBROCK>(a, st) : launch_slice_k<3, -1>(a, st);
+        case 4: return rosen ? launch_slice_k<4, NNEST_LIKE_ROSENBROCK>(a, st) : launch_slice_k<4, -1>(a, st);
+    }
+    return hipErrorInvalidConfiguration;
+}
+
+hipError_t launch_slice_fill_noise(float *dz, int steps, int C, int D, uint64_t seed, uint64_t walker_offset, hipStream_t st) {
+    hipLaunchKernelGGL(slice_fill_noise_kernel, dim3(256), dim3(256), 0, st, dz, steps, C, D, seed, walker_offset);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // walkers (net waves) per workgroup for a population: 4 while one walker per SIMD covers it, then 8 and 12 (two / three walkers
 // per SIMD: the SIMD issues one vector instruction per 2 cycles, a lone wave one per 4 -- MI355X_MICROARCH.md).  0 = the
 // population does not fit the form (every workgroup must be resident: the batch rule's waits span the grid).

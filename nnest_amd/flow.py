@@ -215,6 +215,42 @@ class _HipFlow(object):
         # (split on first use: two element-wise launches that a caller who reads neither does not pay for)
         return _MhResult(x=x, n_accept_word=n_acc, n_call=n_call, scale=scale_out, hist_x=hx, hist_logl=hl, sync=sync)
 
+    def slice_steps(self, like_id, like_scale, z, logl, loglstar, width, steps, max_stepout=8, max_shrink=32, noise=None, seed=0,
+                    walker_offset=0, history=False, like_params=None):
+        """SLICE proposal in latent space (nnest_slice_steps; BUILD-DEFINED: the reference has none, nnest/sampler.py:310-316 is
+        random-walk Metropolis): `steps` slice-sampling updates (stepping out + shrinkage along a random direction) of every walker
+        under the hard constraint logL > loglstar, the target the reference's Metropolis step leaves invariant.  z [C,D] float32 and
+        logl [C] float64 are updated in place.  noise = dz [steps,C,D] replays recorded directions.  Returns x, n_call (candidates
+        whose likelihood decided), n_move, moved (nested.py:432), n_eval (flow evaluations), hist_x."""
+        assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous()
+        assert logl.is_cuda and logl.dtype == torch.float64 and logl.is_contiguous()
+        C, dev = z.shape[0], self.device
+        x = torch.empty_like(z)
+        n_call = torch.empty(C, dtype=torch.int32, device=dev)
+        n_move = torch.empty(C, dtype=torch.int32, device=dev)
+        n_eval = torch.empty(C, dtype=torch.int32, device=dev)
+        hx = torch.empty(C, steps + 1, self.D, dtype=torch.float32, device=dev) if history else None
+        dz = None
+        if noise is not None:
+            dz = _as_dev_f32(noise.reshape(-1, self.D), dev)
+            assert dz.shape[0] == steps * C
+        with torch.cuda.device(dev):
+            lk = _lib.like_spec(like_id, like_scale, like_params)
+            _lib.check(self._lib.nnest_slice_steps(self._h, ctypes.byref(lk), _lib.ptr(z), _lib.ptr(x), _lib.ptr(logl), float(loglstar),
+                                                   float(width), int(steps), C, int(max_stepout), int(max_shrink), _lib.ptr(dz),
+                                                   int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker_offset), _lib.ptr(hx), _lib.ptr(n_call),
+                                                   _lib.ptr(n_move), _lib.ptr(n_eval), _lib.current_stream(dev)))
+        return dict(x=x, n_call=n_call, n_move=n_move & (_lib.MH_ALL_MOVED - 1), moved=(n_move & _lib.MH_ALL_MOVED) != 0, n_eval=n_eval,
+                    hist_x=hx)
+
+    def fill_slice_noise(self, steps, C, seed=0, walker_offset=0):
+        """the directions nnest_slice_steps draws (Philox normals), exported for the checker: dz [steps, C, D]"""
+        dz = torch.empty(steps, C, self.D, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nnest_slice_fill_noise(_lib.ptr(dz), steps, C, self.D, int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                        int(walker_offset), _lib.current_stream(self.device)))
+        return dz
+
     def mh_form_for(self, C, dynamic=False, lag=None, free=False, form=None, warm=0):
         """the K4 form (name) `mh_steps` runs for C walkers under this step rule -- asked of the library
         (nnest_mh_form_for), which knows the shapes each form is built for; None if the launch would be refused.  A caller

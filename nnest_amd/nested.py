@@ -85,7 +85,8 @@ class NestedSampler(Sampler):
                  mcmc_history=False,
                  checkpoint_min_seconds=2.0,
                  chain_min_seconds=30.0,
-                 native_loop=True):
+                 native_loop=True,
+                 mcmc_proposal='mh'):
         prior = UniformPrior(x_dim, -1, 1)  # nested.py:76
         super(NestedSampler, self).__init__(x_dim, loglike, transform=transform, append_run_num=append_run_num,
                                             hidden_dim=hidden_dim, num_slow=num_slow, num_derived=num_derived,
@@ -94,7 +95,7 @@ class NestedSampler(Sampler):
                                             resume=resume, use_gpu=use_gpu, base_dist=base_dist, scale=scale,
                                             trainer=trainer, prior=prior, transform_prior=False, log_level=log_level,
                                             param_names=param_names, oversample_rate=oversample_rate, fused=fused,
-                                            mcmc_history=mcmc_history)
+                                            mcmc_history=mcmc_history, mcmc_proposal=mcmc_proposal)
         self.num_live_points = num_live_points
         self.checkpoint_min_seconds = checkpoint_min_seconds
         self.chain_min_seconds = chain_min_seconds

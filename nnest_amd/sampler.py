@@ -65,7 +65,14 @@ class Sampler(object):
                  log_level=logging.INFO,
                  param_names=None,
                  fused=True,
-                 mcmc_history=False):
+                 mcmc_history=False,
+                 mcmc_proposal='mh'):
+        # mcmc_proposal (not in the reference, whose _mcmc_sample proposes random-walk Metropolis moves only, sampler.py:310-316):
+        # 'mh' = that step; 'slice' = the build-defined slice proposal in latent space (BASELINE north_star; nnest_slice_steps,
+        # include/nnest_hip.h; parity unpinned) on the fused kernel path
+        if mcmc_proposal not in ('mh', 'slice'):
+            raise ValueError("mcmc_proposal=%r: 'mh' (the reference's step) or 'slice' (build-defined)" % (mcmc_proposal,))
+        self.mcmc_proposal = mcmc_proposal
         self.x_dim = x_dim
         self.num_derived = num_derived
         self.num_params = x_dim + num_derived
@@ -336,6 +343,26 @@ class Sampler(object):
         points (round 2 gathered [C, 2 D + 1])."""
         netG = self.trainer.netG
         C = init_samples.shape[0]
+        if self.mcmc_proposal == 'slice':
+            # BUILD-DEFINED (the reference has no slice proposal): `mcmc_steps` slice-sampling updates per chain along random
+            # directions of latent space.  Initial bracket: twice the Metropolis step (z + t * 2 step_size * eps, |eps| ~ sqrt(D): with
+            # the default step_size = 1 / sqrt(D) a bracket of length ~2, the chord of a latent ball of radius sqrt(D) through a point
+            # near its surface in a random direction); every update moves (no rejection), so the scale is not adapted -- stepping
+            # out and shrinkage find the slice's extent
+            if loglstar is None:
+                raise NotImplementedError("mcmc_proposal='slice' samples under the hard constraint logL > loglstar only")
+            z, _ = netG.forward(init_samples)
+            logl = torch.as_tensor(np.asarray(init_loglikes, dtype=np.float64), device=z.device).contiguous()
+            res = netG.slice_steps(self._fused_like_id, self._linear_scale, z, logl, float(loglstar), 2.0 * float(step_size),
+                                   int(mcmc_steps), seed=self._next_seed() if seed is None else seed, walker_offset=walker_offset,
+                                   like_params=self._fused_like_params)
+            ends = torch.cat([res['x'].double(), logl[:, None], res['moved'][:, None].double()], dim=1)
+            counts = torch.stack([res['n_call'].sum(), res['n_move'].sum()]).cpu()
+            ncall, nmove = int(counts[0]), int(counts[1])
+            self.total_calls += ncall
+            self.total_accepted += nmove
+            self.total_rejected += C * int(mcmc_steps) - nmove
+            return ends, float(step_size), ncall
         res, z0, z, logl = self._fused_launch(mcmc_steps, step_size, dynamic, init_samples, init_loglikes, loglstar,
                                               walker_offset, seed, form)
         # "every coordinate moved" (nested.py:432: samples[:, 0] != samples[:, -1] in every dimension): the kernel's own test of the

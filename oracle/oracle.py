@@ -366,6 +366,82 @@ def philox4x32_10(ctr, key):
     return [int(v) for v in o]
 
 
+def slice_uniform(seed, walker, idx):
+    """the slice kernel's uniform draw k of step s (idx = 64 s + k): Philox4x32-10 of (seed; walker, idx), stream U, 24 bits
+    (flow_tile.h noise_uniform) -- exact in float32"""
+    seed, walker = int(seed) & 0xFFFFFFFFFFFFFFFF, int(walker) & 0xFFFFFFFFFFFFFFFF
+    ctr = [0, walker & 0xffffffff, int(idx) & 0xffffffff, ((walker >> 32) & 0x0fffffff) | (1 << 28)]
+    r = philox4x32_10(ctr, [seed & 0xffffffff, seed >> 32])
+    return np.float32((r[0] >> 8) * 5.9604644775390625e-08)
+
+
+def slice_sample(flow, like, like_scale, z0, logl0, loglstar, width, dz, seed, walker_offset=0, max_stepout=8, max_shrink=32,
+                 margins=None):
+    """[BUILD-DEFINED, parity unpinned: the reference proposes random-walk Metropolis moves only, nnest/sampler.py:310-316]
+    CPU restatement of the slice proposal kernel (nnest_amd/csrc/nnest_solo.hip slice_kernel_solo; include/nnest_hip.h
+    nnest_slice_steps): univariate slice sampling (stepping out + shrinkage) along the recorded directions dz [S, C, D] of the target
+    |det dx/dz| on {x(z) in the unit box, logL > loglstar}; `flow` is an oracle flow object (NVP).  Returns the per-step x history
+    [C, S + 1, D], the final z, logl, and the counters.  margins [S, C] (optional): the smallest distance of any evaluated candidate of
+    the step from a decision threshold (box edge, slice level, L*) -- a chain that differs from the kernel's must have come close."""
+    S, C, D = dz.shape
+    z = np.asarray(z0, dtype=np.float32).copy()
+    x, ld = flow.inverse(z)
+    logl = np.asarray(logl0, dtype=np.float64).copy()
+    hx = np.empty((C, S + 1, D), np.float32)
+    hx[:, 0] = x
+    n_call, n_move, n_eval = np.zeros(C, int), np.zeros(C, int), np.zeros(C, int)
+    w32 = np.float32(width)
+    for c in range(C):
+        zc, xc, ldc, lc = z[c].copy(), x[c].copy(), np.float32(ld[c]), float(logl[c])
+        for it in range(1, S + 1):
+            e = dz[it - 1, c].astype(np.float32)
+            u0, u1 = slice_uniform(seed, walker_offset + c, 64 * it), slice_uniform(seed, walker_offset + c, 64 * it + 1)
+            with np.errstate(divide='ignore'):
+                logy = np.float32(ldc + np.log(u1, dtype=np.float32))
+            mg = [np.inf]
+
+            def inside(t):
+                tw = np.float32(np.float32(t) * w32)
+                zp = (zc.astype(np.float64) + e.astype(np.float64) * np.float64(tw)).astype(np.float32)   # one fused multiply-add per dim
+                xp, ldp = flow.inverse(zp[None])
+                xp, ldp = xp[0], np.float32(ldp[0])
+                inb = bool(prior_inbox(xp[None])[0] == 0)
+                pre = inb and bool(ldp > logy)
+                lp = float(loglike(like, xp[None], like_scale)[0])
+                n_eval[c] += 1
+                n_call[c] += 1 if pre else 0
+                mg[0] = min(mg[0], float(np.min(np.abs(np.abs(xp.astype(np.float64)) - 1.0))), abs(float(ldp) - float(logy)),
+                            abs(lp - loglstar) / (1.0 + abs(loglstar)))
+                return (pre and lp > loglstar), zp, xp, ldp, lp
+
+            tl, tr = np.float32(-u0), np.float32(np.float32(1.0) - u0)
+            for _ in range(max_stepout):
+                if not inside(tl)[0]:
+                    break
+                tl = np.float32(tl - np.float32(1.0))
+            for _ in range(max_stepout):
+                if not inside(tr)[0]:
+                    break
+                tr = np.float32(tr + np.float32(1.0))
+            for k in range(max_shrink):
+                uk = slice_uniform(seed, walker_offset + c, 64 * it + 2 + k)
+                t = np.float32(np.float64(np.float32(tr - tl)) * np.float64(uk) + np.float64(tl))   # fmaf(tr - tl, uk, tl)
+                ok, zp, xp, ldp, lp = inside(t)
+                if ok:
+                    zc, xc, ldc, lc = zp, xp, ldp, lp
+                    n_move[c] += 1
+                    break
+                if t < 0:
+                    tl = t
+                else:
+                    tr = t
+            hx[c, it] = xc
+            if margins is not None:
+                margins[it - 1, c] = mg[0]
+        z[c], logl[c] = zc, lc
+    return dict(x=hx, z=z, logl=logl, n_call=n_call, n_move=n_move, n_eval=n_eval)
+
+
 class FastSlowNVP(object):
     """FastSlowNVP (nnest/networks.py:86-150, :350-380): slow NVP on x[:, :S], fast NVP on x[:, S:], then one coupling layer
     (hidden 64, one hidden layer) with mask = (1,)*S + (0,)*F.  Weights: the concatenated reference state_dict
