@@ -658,6 +658,32 @@ def main():
                                                         'peak': FP32_PEAK_TFLOPS, 'achieved': tf / (best * 1e-3) / 1e12,
                                                         'frac': tf / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 'kernel': 'spl_grad_kernel + spl_update_kernel',
                                                         'profile': 'profiles/r06/spline_train_kernel_stats.csv'}
+        if world == 1 and dist is None and not args.bare and args.config == 2:
+            # the slice proposal in latent space (north_star "slice/MH"): build-defined, the reference has none --
+            # reported beside, never as `value`.  Its unit is the same eval (one coupling-stack inverse + box + likelihood); an update
+            # takes a handful of them and always moves.
+            Sl = 25
+            t_ms, n_eval, n_move = [], 0, 0
+            for k in range(4):
+                zz, ll = z0.clone(), logl0.clone()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rs = nvp.slice_steps(LIKE_ID[like], scale, zz, ll, loglstar, 2.0 * step_size, Sl, seed=11 + k)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                t_ms.append(e0.elapsed_time(e1))
+                n_eval, n_move = int(rs['n_eval'].sum()), int(rs['n_move'].sum())
+            ms = float(np.median(t_ms[1:]))
+            out['slice_proposal'] = {'kernel': 'slice_kernel_solo', 'walkers': C, 'updates_per_walker': Sl, 'kernel_ms': ms,
+                                     'evals_per_s': n_eval / (ms * 1e-3), 'evals_per_update': n_eval / max(1, C * Sl),
+                                     'updates_per_s': C * Sl / (ms * 1e-3), 'moved_fraction': n_move / max(1, C * Sl),
+                                     'roofline': {'bound': 'valu', 'flops_per_unit': fl, 'unit': 'TFLOP/s', 'peak': FP32_PEAK_TFLOPS,
+                                                  'achieved': n_eval * fl / (ms * 1e-3) / 1e12,
+                                                  'frac': n_eval * fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 'kernel': 'slice_kernel_solo',
+                                                  'profile': 'profiles/r06/slice_kernel_stats.csv'},
+                                     'note': 'UNPINNED: the reference proposes random-walk Metropolis moves only (nnest/sampler.py:310-316); '
+                                             'parity is against the CPU restatement of the build-defined step (tests/test_gpu_slice.py)'}
         if world == 1 and dist is None and not args.bare and args.config in (2, 5):
             # the same workload on the build-defined MAF (BASELINE config 5 names it): reported beside, never
             # as `value`.  Its inverse -- the direction the proposals need -- is `num_groups` passes of the nets per block

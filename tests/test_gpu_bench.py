@@ -41,8 +41,12 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert d['k3']['evals_per_s'] > 0 and d['k5_train']['ms_per_epoch'] > 0
     # every kernel on the path carries its own roofline object (round-3 verdict): flops per unit, achieved, fraction, kernel
     for ro in (d['k5_train']['roofline'], d['spline_flow']['roofline'], d['spline_flow']['train_roofline'], d['maf_flow']['roofline'],
-               d['maf_flow']['train_roofline']):
+               d['maf_flow']['train_roofline'], d['slice_proposal']['roofline']):
         assert ro['flops_per_unit'] > 0 and 0 < ro['frac'] < 1 and abs(ro['frac'] - ro['achieved'] / ro['peak']) < 1e-9 and ro['kernel']
+    assert all(ro.get('profile') for ro in (d['maf_flow']['roofline'], d['maf_flow']['train_roofline']))   # (round-5 verdict: was null)
+    sp = d['slice_proposal']                                    # build-defined, beside the line: a handful of evals per update, all move
+    assert 2.0 < sp['evals_per_update'] < 20.0 and sp['moved_fraction'] > 0.9 and sp['evals_per_s'] > 1e7
+    assert d['ms_per_step_first20'] > 0 and d['launch_profile']['kernel_ms_steady'] > 0 and d['step_rule']['reference_rule_cost'] > 1.0
     e = d['e2e']                                                # where the wall time of the live config-2 run went
     assert e['wall_s'] > 0 and e['k5_s'] > 0 and e['k4_s'] > 0 and abs(e['wall_s'] - e['k5_s'] - e['k4_s'] - e['host_s']) < 1e-6
     assert e['k5_epochs'] > 1000 and e['k4_launches'] > 100
