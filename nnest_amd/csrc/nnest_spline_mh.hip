@@ -35,24 +35,26 @@ struct SplineInverseHalves {
     const float *img;
     SplineShape sp;
     float *buf;     // this wave's 16 x (D+1) layout-exchange buffer
-    f32x4 *xch;     // [4][NT][64]
-    float *ldred;   // [4][16]
+    f32x4 *xch;     // 2 x [4][NT][64]: the exchanges alternate between the two (one barrier each, round 6)
+    float *ldred;   // 2 x [4][16], likewise
     const float *trunks;   // the conditioners' hidden parts in LDS (spline_stage_trunks)
     int lane, wv;
+    mutable int xsel = 0, lsel = 0;
 #ifdef NNEST_STAMP
     unsigned long long t_mlp = 0, t_xch = 0, t_upd = 0;
 #endif
     __device__ __forceinline__ float operator()(f32x4 (&xs)[2][NT]) const {
         f32x4 t[2][NT];
         spl_from_parity<NT>(buf, sp.D, sp.nl, lane, xs, t);
-        float ld = group_sum(spline_inverse_tile_halves<NT, NH>(img, sp, lane, t, wv, xch, trunks));
-        if (lane < 16) ldred[wv * 16 + lane] = ld;
+        float ld = group_sum(spline_inverse_tile_halves<NT, NH>(img, sp, lane, t, wv, xch, xsel, trunks));
+        float *lr = ldred + ((lsel & 1) ? 64 : 0);
+        lsel ^= 1;
+        if (lane < 16) lr[wv * 16 + lane] = ld;
         spl_team_barrier();
         const int w = lane & 15;
         ld = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ld += ldred[k * 16 + w];
-        spl_team_barrier();
+        for (int k = 0; k < 4; ++k) ld += lr[k * 16 + w];
         spl_to_parity<NT>(buf, sp.D, sp.nl, lane, t, xs);
         return 0.25f * ld;  // the caller sums the four lanes of a walker
     }
@@ -64,9 +66,9 @@ __global__ void __launch_bounds__(256) spline_mh_kernel_pair(MhArgs a, SplArgs q
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tile = blockIdx.x;
     float *bufs = lds_buf;                                                        // 4 x 16 x (D+1)
-    f32x4 *xch = reinterpret_cast<f32x4 *>(lds_buf + ((4 * 16 * (q.sp.D + 1) + 3) & ~3));  // 4 x NT x 64 f32x4
-    float *ldred = reinterpret_cast<float *>(xch + 4 * NT * 64);                  // 4 x 16
-    float *trunks = ldred + 4 * 16;                                               // B x 2 x spl_cond_hidden_floats
+    f32x4 *xch = reinterpret_cast<f32x4 *>(lds_buf + ((4 * 16 * (q.sp.D + 1) + 3) & ~3));  // 2 x 4 x NT x 64 f32x4
+    float *ldred = reinterpret_cast<float *>(xch + 2 * 4 * NT * 64);              // 2 x 4 x 16
+    float *trunks = ldred + 2 * 4 * 16;                                           // B x 2 x spl_cond_hidden_floats
     spline_stage_trunks<NT, NH>(q.img, q.sp, trunks, threadIdx.x, 256);
     __syncthreads();
     SplineInverseHalves<NT, NH> inv = {q.img, q.sp, bufs + (size_t)wv * 16 * (q.sp.D + 1), xch, ldred, trunks, lane, wv};
@@ -143,7 +145,7 @@ hipError_t launch_spline_mh_team(const MhArgs &a, const SplArgs &q, bool dbg, hi
 template <int NT, int NH>
 static hipError_t launch_pair_t(const MhArgs &a, const SplArgs &q, bool dbg, hipStream_t st) {
     const int ntiles8 = (a.C + 7) / 8;
-    const size_t ldsb = (size_t)(((4 * 16 * (q.sp.D + 1) + 3) & ~3) + 4 * NT * 64 * 4 + 4 * 16 + q.sp.B * 2 * spl_cond_hidden_floats(NT, NH)) * sizeof(float);
+    const size_t ldsb = (size_t)(((4 * 16 * (q.sp.D + 1) + 3) & ~3) + 2 * 4 * NT * 64 * 4 + 2 * 4 * 16 + q.sp.B * 2 * spl_cond_hidden_floats(NT, NH)) * sizeof(float);
     if (ldsb > 64 * 1024) {   // (above 64 KB of dynamic LDS a kernel has to be told so once)
         hipError_t e = dbg ? hipFuncSetAttribute(reinterpret_cast<const void *>(spline_mh_kernel_pair<NT, NH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)
                            : hipFuncSetAttribute(reinterpret_cast<const void *>(spline_mh_kernel_pair<NT, NH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);

@@ -346,7 +346,7 @@ __device__ __forceinline__ float spl_coupling_pair(const float *__restrict__ net
 // `trunk`: the conditioner's hidden part (spl_hidden's image: the first spl_cond_hidden_floats of `net`) -- the workgroup's copy in
 // LDS where the kernel keeps one (all four waves read the same 4 KB per coupling: from L2 that is a 0.7 us round trip in front of
 // every trunk; the last layer's 9 KB per wave and coupling do not fit and stay in L2)
-template <int NTh, int NH, bool INV>
+template <int NTh, int NH, bool INV, bool TAILB = true>   // TAILB = false: the caller alternates exchange buffers (spl_coupling_pair)
 __device__ __forceinline__ float spl_coupling_halves(const float *__restrict__ net, const float *trunk, int S, int n_out, float tail, int lane,
                                                      const f32x4 (&cond)[NTh], f32x4 (&tr)[NTh], int wv, f32x4 *xch) {
     const int g = lane >> 4;
@@ -398,7 +398,7 @@ __device__ __forceinline__ float spl_coupling_halves(const float *__restrict__ n
 #pragma unroll
     for (int t = 0; t < NTh; ++t)
         tr[t] = (f32x4){xch[(0 * NTh + t) * 64 + lane].x, xch[(1 * NTh + t) * 64 + lane].y, xch[(2 * NTh + t) * 64 + lane].z, xch[(3 * NTh + t) * 64 + lane].w};
-    spl_team_barrier();
+    if constexpr (TAILB) spl_team_barrier();
     return ld;
 }
 
@@ -416,7 +416,7 @@ __device__ __forceinline__ void spline_stage_trunks(const float *__restrict__ im
 // spl_affine with its output tiles dealt out over the four waves of the team (tile `to` to wave `to & 3`) and exchanged through LDS
 // (`xch`: at least 2 NTh x 64 f32x4): every wave of the team form repeats all (2 NTh)^2 x 4 matrix instructions -- 64 of them, 0.85 us,
 // per block at x_dim 50.  Same accumulation order as spl_affine: the same values.
-template <int NTh>
+template <int NTh, bool TAILB = true>
 __device__ __forceinline__ void spl_affine_team(const float *__restrict__ aff, int lane, int wv, f32x4 *xch, const f32x4 (&in)[2][NTh],
                                                 f32x4 (&out)[2][NTh]) {
     constexpr int T2 = 2 * NTh;
@@ -442,15 +442,19 @@ __device__ __forceinline__ void spl_affine_team(const float *__restrict__ aff, i
     spl_team_barrier();
 #pragma unroll
     for (int to = 0; to < T2; ++to) out[to / NTh][to % NTh] = xch[to * 64 + lane];
-    spl_team_barrier();
+    if constexpr (TAILB) spl_team_barrier();
 }
 
 // the inverse on an 8-walker tile held in both halves of the columns (spl_coupling_halves), four waves per tile
 // `trunks`: NULL, or the workgroup's LDS copy of every conditioner's hidden part, [block][f1 | f2][spl_cond_hidden_floats]
 // (spline_stage_trunks)
+// (round 6) `xch`: TWO exchange buffers of 4 NTh x 64 f32x4 back to back, `xsel` which of them the next exchange takes: the nine
+// exchanges of a pass alternate between the two and keep ONE barrier each (between an exchange's writes and its reads) -- the
+// barrier that kept the next exchange's writes off this one's reads is the next exchange's own
 template <int NTh, int NH>
 __device__ __forceinline__ float spline_inverse_tile_halves(const float *__restrict__ img, const SplineShape &s, int lane, f32x4 (&xs)[2][NTh],
-                                                            int wv, f32x4 *xch, const float *trunks = nullptr) {
+                                                            int wv, f32x4 *xch, int &xsel, const float *trunks = nullptr) {
+    auto next_xch = [&]() -> f32x4 * { f32x4 *p = xch + ((xsel & 1) ? 4 * NTh * 64 : 0); xsel ^= 1; return p; };
     float ld = 0.f;
     constexpr int TF = NH * NTh * 256 + 2 * NH * NH * 256 + 3 * 16 * NH;   // spl_cond_hidden_floats(NTh, NH)
     for (int b = s.B - 1; b >= 0; --b) {
@@ -458,10 +462,10 @@ __device__ __forceinline__ float spline_inverse_tile_halves(const float *__restr
         const float *blk = img + (size_t)b * s.blk_floats;
         const float *f1 = blk + 2 * s.aff_floats, *f2 = f1 + s.f1_floats;
         const float *t1 = trunks ? trunks + (size_t)(2 * b) * TF : f1, *t2 = trunks ? trunks + (size_t)(2 * b + 1) * TF : f2;
-        ld += spl_coupling_halves<NTh, NH, true>(f2, t2, SL, nl, s.tail, lane, xs[1], xs[0], wv, xch);  // networks.py:605-614
-        ld += spl_coupling_halves<NTh, NH, true>(f1, t1, SU, nu, s.tail, lane, xs[0], xs[1], wv, xch);  // :615-621
+        ld += spl_coupling_halves<NTh, NH, true, false>(f2, t2, SL, nl, s.tail, lane, xs[1], xs[0], wv, next_xch());  // networks.py:605-614
+        ld += spl_coupling_halves<NTh, NH, true, false>(f1, t1, SU, nu, s.tail, lane, xs[0], xs[1], wv, next_xch());  // :615-621
         f32x4 y[2][NTh];
-        spl_affine_team<NTh>(blk + s.aff_floats, lane, wv, xch, xs, y);
+        spl_affine_team<NTh, false>(blk + s.aff_floats, lane, wv, next_xch(), xs, y);
         if (lane < 16 && wv == 0) ld -= (f2 + s.f2_floats)[0];
 #pragma unroll
         for (int c = 0; c < 2; ++c)

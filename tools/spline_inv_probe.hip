@@ -37,7 +37,8 @@ __global__ void __launch_bounds__(256) probe(const float *img, SplineShape sp, c
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tile = blockIdx.x;
 #endif
     f32x4 *xch = reinterpret_cast<f32x4 *>(lds_buf);
-    float *ldred = reinterpret_cast<float *>(xch + 4 * NT * 64);
+    float *ldred = reinterpret_cast<float *>(xch + 2 * 4 * NT * 64);   // (two exchange buffers: spline_inverse_tile_halves alternates)
+    int xsel = 0;
     const int GW = FORM == 0 ? 16 : 8;
     const int w = lane & 15, row = tile * GW + (w & (GW - 1));
     const bool ok = row < C;
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(256) probe(const float *img, SplineShape sp, c
     for (int it = 0; it < S; ++it) {
         float ld;
         if (FORM == 0) ld = group_sum(spline_inverse_tile<NT, NH, 4>(img, sp, lane, t, wv, xch));
-        else ld = group_sum(spline_inverse_tile_halves<NT, NH>(img, sp, lane, t, wv, xch));
+        else ld = group_sum(spline_inverse_tile_halves<NT, NH>(img, sp, lane, t, wv, xch, xsel));
         if (lane < 16) ldred[wv * 16 + lane] = ld;
         spl_team_barrier();
         ld = 0.f;
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(256) probe(const float *img, SplineShape sp, c
 template <int FORM>
 static void run(const float *img, const SplineShape &sp, const float *x, float *out, int C, int S, long long *cyc, std::vector<float> &host) {
     const int GW = FORM == 0 ? 16 : 8, grid = (C + GW - 1) / GW;
-    const size_t lds = (size_t)(4 * 2 * 64 * 4 + 64) * sizeof(float);
+    const size_t lds = (size_t)(2 * 4 * 2 * 64 * 4 + 64) * sizeof(float);
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     float best = 1e30f;

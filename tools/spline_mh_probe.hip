@@ -55,7 +55,7 @@ int main(int argc, char **argv) {
             a.like.id = 0; a.like.scale = 5.0f;
             a.seed = 7; a.n_accept = nacc; a.n_call = ncall;
             SplArgs q = {img, sp};
-            const size_t ldsb = (size_t)(((4 * 16 * (D + 1) + 3) & ~3) + 4 * 2 * 64 * 4 + 4 * 16 + sp.B * 2 * spl_cond_hidden_floats(2, 1)) * sizeof(float);
+            const size_t ldsb = (size_t)(((4 * 16 * (D + 1) + 3) & ~3) + 2 * 4 * 2 * 64 * 4 + 2 * 4 * 16 + sp.B * 2 * spl_cond_hidden_floats(2, 1)) * sizeof(float);
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0);
