@@ -39,3 +39,20 @@ def test_slice_sample_keeps_the_constraint_and_moves():
     c = orc.slice_sample(nvp, 'rosenbrock', 5.0, z0, l0, star, 0.7, dz, seed=4, walker_offset=10)
     assert not np.array_equal(a['x'], c['x'])
     assert np.all(np.isfinite(margins)) and np.all(margins >= 0)
+
+
+def test_exact_rosenbrock_evidence_by_transfer_quadrature():
+    """oracle/rosenbrock_exact.py (the known answer the slice proposal's convergence is judged by): equals the 2-D closed
+    form the nested tests use (-5.804), a brute-force 3-D grid sum of the oracle's own log-likelihood, and is converged in the grid step."""
+    from oracle.rosenbrock_exact import log_evidence
+    assert abs(log_evidence(2) + 5.804132) < 1e-5
+    h = 0.04
+    g = np.arange(-5 + h / 2, 5, h)                       # midpoint rule, 250^3 cells
+    tot = 0.0
+    for x1 in g:
+        pts = np.stack(np.meshgrid([x1], g, g, indexing='ij'), axis=-1).reshape(-1, 3) / 5.0
+        tot += np.exp(orc.loglike('rosenbrock', pts, 5.0)).sum()
+    brute = np.log(tot * h ** 3) - 3 * np.log(10.0)
+    assert abs(log_evidence(3) - brute) < 2e-3, (log_evidence(3), brute)
+    assert abs(log_evidence(50, h=0.01) - log_evidence(50, h=0.005)) < 1e-6
+    assert abs(log_evidence(50) + 231.9384) < 1e-3
