@@ -236,6 +236,7 @@ int nnest_spline_destroy(nnest_spline_t *h) {
     (void)hipFree(h->wmat); (void)hipFree(h->timg); (void)hipFree(h->partial); (void)hipFree(h->grad); (void)hipFree(h->gwsum);
     (void)hipFree(h->stash); (void)hipFree(h->gbuf); (void)hipFree(h->hbuf); (void)hipFree(h->keep); (void)hipFree(h->losses_dev); (void)hipFree(h->ctl_dev); (void)hipFree(h->epoch_losses_dev);
     if (h->ctl_host) (void)hipHostFree(h->ctl_host);
+    spline_rows_free(h);
     delete h;
     return NNEST_OK;
 }

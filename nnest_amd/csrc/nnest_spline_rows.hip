@@ -1,0 +1,1114 @@
+// nnest_spline_rows.hip -- the "rows" form of the spline flow's training step (round 6): ONE ROW OF THE MINIBATCH PER WORKGROUP.
+//
+// Reference: Trainer._train on SingleSpeedSpline (nnest/trainer.py:384-403; networks.py:393-715): loss = -mean(log_probs(X[perm] +
+// jitter * randn)), Adam with coupled weight decay.  The tile form (nnest_spline_train.hip: spl_grad_kernel + spl_update_kernel)
+// gives every lane one whole rational-quadratic-spline evaluation per coupling -- ~1100 vector instructions per wave and coupling
+// pass, 46 of them quarter-rate transcendentals, on 13 workgroups; a minibatch is a chain of twelve such passes.  Here the
+// evaluation itself is spread: item (row, transformed dimension) sits on EIGHT lanes, lane k holding bin k (its width / height
+// logits and the derivative logit of its right knot); softmax sums, the knot positions (a prefix sum) and the bin search are
+// DPP operations inside the 8-lane group.  A row of x_dim 50 is 25 items = 200 lanes = four waves, a minibatch of 100 rows is
+// 100 workgroups on 100 CUs, and a coupling pass is ~350 vector instructions per wave.  Layout of one coupling pass:
+//   trunk (3 hidden layers of 16): every wave computes it redundantly in "row layout" (lane o & 15 holds unit o), the layer
+//       inputs broadcast with v_readlane, the weights read straight from the PACKED state_dict-order vector (no image);
+//   last layer (16 -> 23 n_out): "quad per output row" -- four lanes share an output row, each reads a 16-byte quarter of it
+//       (one instruction = 16 full 64-byte lines, coalesced) and the quad adds up; the raw parameters go through LDS to the
+//   evaluation in the item layout above; the transformed values go back to the row vector in LDS.
+// The backward pass mirrors it (the forward pass's per-lane intermediates are kept in LDS: 16 floats per lane and coupling).
+// Parameter gradients are NOT accumulated here: each row stages the operands (activations, pre-activation gradients, raw-parameter
+// gradients, the 1x1 conv's input / output gradient) and splr_update_kernel contracts them over the rows of the minibatch on the
+// matrix cores, one 16x16 output tile per wave (K = rows), takes the Adam step in registers and writes the packed vector --
+// fixed summation order, no atomics: bitwise repeatable.  The 1x1 conv's LU parameters are stepped by one workgroup per block as in
+// the tile form (spl_update_kernel's head), from the contraction instead of 13 tiles' partial sums.
+//
+// Shapes: hidden_dim 16, num_bins 8, x_dim <= 64, minibatch <= 128 rows (the reference's defaults and BASELINE configs 1-3 with
+// flow='spline'); everything else keeps the tile form.  NNEST_SPL_ROWS=0 pins the tile form (A/B, tests of both).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "spline_host.h"
+#include "spline_train_tile.h"
+
+using namespace nnest;
+
+namespace nnest {
+
+enum { SPLR_TROW = 160, SPLR_VROW = 64, SPLR_NS = 12 };  // trunk staging row: h0 h1 h2 d0 d1 d2 (16 each) + u (64); block rows; last-layer steps
+
+// staging buffer (floats): T[c] = off_T + (c rows_cap + r) 160; G[c] = off_G + (c rows_cap + r) grow; V[b][which] = off_V + ((3b + which)
+// rows_cap + r) 64 with which = 0: a (ActNorm output = conv input), 1: g_c (gradient at the conv output), 2: g_a (at the conv input)
+struct SplRowsLayout {
+    int rows_cap, grow;
+    size_t off_T, off_G, off_V, total;
+};
+
+struct SplRowsState {
+    SplRowsLayout lay;
+    float *stg;
+    float *wmatT;   // [B][D][D]
+    float *ldc;     // [B]: sum(s) + sum(log|S|) of a block (networks.py:650, :676)
+    float *rowlp;   // [rows_cap + valid_cap]
+    int valid_cap;
+};
+
+struct SplRowsArgs {
+    const float *w, *wmat, *wmatT, *ldc;
+    SplTrainShape ts;
+    const float *x;
+    const int *perm;
+    int M, mtot;
+    const float *noise;
+    uint64_t seed;
+    long noise_row0;
+    int epoch;
+    float jitter;
+    const float *xv;
+    int Mv;
+    float *rowlp;
+    float *stg;
+    SplRowsLayout lay;
+    const int *stop;
+};
+
+// ---- lane primitives ------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float splr_dpp(float v) {   // invalid source lanes read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// over the 8 lanes of an item (lanes 8j .. 8j+7 of a wave): every lane ends with the same bits (each stage adds a pair both partners see)
+__device__ __forceinline__ float splr_sum8(float v) {
+    v += splr_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += splr_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += splr_dpp<0x141>(v);   // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ float splr_max8(float v) {
+    v = fmaxf(v, splr_dpp<0xB1>(v));
+    v = fmaxf(v, splr_dpp<0x4E>(v));
+    v = fmaxf(v, splr_dpp<0x141>(v));
+    return v;
+}
+// inclusive prefix sum over the 8 lanes of an item (k = lane & 7)
+__device__ __forceinline__ float splr_scan8(float v, int k) {
+    float t = splr_dpp<0x111>(v);  // row_shr:1
+    v += k >= 1 ? t : 0.f;
+    t = splr_dpp<0x112>(v);
+    v += k >= 2 ? t : 0.f;
+    t = splr_dpp<0x114>(v);
+    v += k >= 4 ? t : 0.f;
+    return v;
+}
+__device__ __forceinline__ float splr_rl(float v, int lane) {   // lane: wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ f32x4 splr_ldx4(const float *p) {   // 16 bytes from a dword-aligned address (the packed vector's offsets are odd)
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// The inline-asm loads are invisible to the compiler's wait-count bookkeeping: splr_wait_vm() waits for them, and splr_fence() makes
+// every later use of a loaded register depend on a (empty) statement behind that wait -- volatile statements keep their order.
+__device__ __forceinline__ void splr_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void splr_fence(f32x4 &v) { asm volatile("" : "+v"(v)); }
+template <int N>
+__device__ __forceinline__ void splr_fence(f32x4 (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) splr_fence(v[i]);
+}
+__device__ __forceinline__ void splr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float splr_lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
+__device__ __forceinline__ float splr_slope(float post) { return post > 0.f ? 1.f : 0.2f; }   // (the activation keeps the sign)
+__device__ __forceinline__ float splr_comp(const f32x4 &v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+// what the backward pass needs again of a lane's share of an evaluation (LDS, 16 floats per lane and coupling)
+struct SplrKeep {
+    float a_w, p_w, a_h, p_h;      // the two softmax stages of the width / height logits (spl_knots)
+    float dd, left, width, chl;    // d(right knot derivative)/d(logit); this bin's left edge, width, bottom edge
+    float ht, d0, d1, x;           // height, knot derivatives, the input
+    float cnt, use, pad0, pad1;    // selected bin (as a float), 1 if this lane IS the selected bin of an input inside the interval
+};
+
+// forward evaluation, lane k of an item: logits rw, rh (bins) and rd (right knot of bin k; unused for k = 7).  Returns y (all 8
+// lanes), adds the log-derivative to `ld` on the selected lane.  networks.py:425-556 through NSF_CL's :583-587, as spl_rqs.
+__device__ __forceinline__ float splr_eval(float rw, float rh, float rd, float x, float tail, int k, bool active, float &ld, SplrKeep &kp) {
+    const float T2 = 2.f * tail, cmin = 1.f - 1e-3f * SPL_K;
+    const bool inside = x >= -tail && x <= tail;
+    // widths
+    float e = spl_exp(rw - splr_max8(rw));
+    const float a_w = e * spl_rcp(splr_sum8(e));
+    e = spl_exp(T2 * a_w - T2);                       // (the second softmax: its arguments lie in [0, 2 tail])
+    const float p_w = e * spl_rcp(splr_sum8(e));
+    const float wk = 1e-3f + cmin * p_w;
+    const float cw_in = splr_scan8(wk, k);
+    float t = splr_dpp<0x111>(cw_in);
+    const float left = k == 0 ? -tail : T2 * t + (-tail);
+    const float right = k == SPL_K - 1 ? tail : T2 * cw_in + (-tail);
+    const float width = right - left;
+    // heights
+    e = spl_exp(rh - splr_max8(rh));
+    const float a_h = e * spl_rcp(splr_sum8(e));
+    e = spl_exp(T2 * a_h - T2);
+    const float p_h = e * spl_rcp(splr_sum8(e));
+    const float hk = 1e-3f + cmin * p_h;
+    const float ch_in = splr_scan8(hk, k);
+    t = splr_dpp<0x111>(ch_in);
+    const float chl = k == 0 ? -tail : T2 * t + (-tail);
+    const float chr = k == SPL_K - 1 ? tail : T2 * ch_in + (-tail);
+    const float ht = chr - chl;
+    // knot derivatives: the right knot of bin k is inner knot k + 1 (k < 7), the end knots are 1
+    const float s1 = spl_softplus(rd);
+    const float dr = 1e-3f + spl_softplus(s1);
+    const float d1 = k == SPL_K - 1 ? 1.0f : dr;
+    t = splr_dpp<0x111>(d1);
+    const float d0 = k == 0 ? 1.0f : t;
+    const float dd = k == SPL_K - 1 ? 0.f : spl_sigmoid(s1) * spl_sigmoid(rd);
+    // searchsorted (networks.py:417-422): the inner edges <= x (edge 0 = -tail always is, the last one + 1e-6 never)
+    const float cnt = splr_sum8((k >= 1 && x >= left) ? 1.f : 0.f);
+    const bool sel = (float)k == cnt;
+    // the rational-quadratic map on this lane's bin (networks.py:541-556); only the selected lane's result is used
+    const float ribw = spl_rcp(width);
+    const float delta = ht * ribw;
+    const float theta = (x - left) * ribw;
+    const float tomt = theta * (1.f - theta);
+    const float Nn = ht * (delta * theta * theta + d0 * tomt);
+    const float Dn = delta + (d0 + d1 - 2.f * delta) * tomt;
+    const float Q = d1 * theta * theta + 2.f * delta * tomt + d0 * (1.f - theta) * (1.f - theta);
+    const bool use = sel && inside;
+    const float y_own = use ? chl + Nn * spl_rcp(Dn) : 0.f;
+    const float y = inside ? splr_sum8(y_own) : x;
+    if (use && active) ld += spl_log(delta * delta * Q) - 2.f * spl_log(Dn);
+    kp.a_w = a_w; kp.p_w = p_w; kp.a_h = a_h; kp.p_h = p_h;
+    kp.dd = dd; kp.left = left; kp.width = width; kp.chl = chl;
+    kp.ht = ht; kp.d0 = d0; kp.d1 = d1; kp.x = x;
+    kp.cnt = cnt; kp.use = use ? 1.f : 0.f; kp.pad0 = 0.f; kp.pad1 = 0.f;
+    return y;
+}
+
+// reverse mode of the same (spl_rqs_fwd_bwd restated on the 8-lane layout): gy = dLoss/dy of the item, gl = dLoss/d(log-derivative).
+// Returns dLoss/dx (all 8 lanes) and this lane's dLoss/d(rw, rh, rd).
+__device__ __forceinline__ float splr_eval_bwd(const SplrKeep &kp, float tail, int k, float gy, float gl, float &g_rw, float &g_rh, float &g_rd) {
+    const float T2 = 2.f * tail, cmin = 1.f - 1e-3f * SPL_K;
+    const bool inside = kp.x >= -tail && kp.x <= tail;
+    const bool use = kp.use != 0.f;
+    const float ih = kp.ht, d0 = kp.d0, d1 = kp.d1;
+    const float ribw = spl_rcp(kp.width);
+    const float delta = ih * ribw;
+    const float theta = (kp.x - kp.left) * ribw;
+    const float tomt = theta * (1.f - theta);
+    const float sdd = d0 + d1 - 2.f * delta;
+    const float Nn = ih * (delta * theta * theta + d0 * tomt);
+    const float Dn = delta + sdd * tomt;
+    const float rDn = spl_rcp(Dn);
+    const float Q = d1 * theta * theta + 2.f * delta * tomt + d0 * (1.f - theta) * (1.f - theta);
+    const float dn = delta * delta * Q;
+    float g_ich = gy, g_N = gy * rDn, g_Dn = -gy * Nn * rDn * rDn - 2.f * gl * rDn;
+    const float g_dn = gl * spl_rcp(dn);
+    float g_delta = g_dn * (2.f * delta * Q + delta * delta * 2.f * tomt);
+    const float g_Q = g_dn * delta * delta;
+    float g_d1 = g_Q * theta * theta, g_d0 = g_Q * (1.f - theta) * (1.f - theta);
+    float g_theta = g_Q * (2.f * d1 * theta - 2.f * d0 * (1.f - theta));
+    float g_t = g_Q * 2.f * delta;
+    g_delta += g_Dn * (1.f - 2.f * tomt);
+    g_d0 += g_Dn * tomt; g_d1 += g_Dn * tomt;
+    g_t += g_Dn * sdd;
+    float g_ih = g_N * (delta * theta * theta + d0 * tomt);
+    g_delta += g_N * ih * theta * theta;
+    g_theta += g_N * ih * delta * 2.f * theta;
+    g_d0 += g_N * ih * tomt;
+    g_t += g_N * ih * d0;
+    g_theta += g_t * (1.f - 2.f * theta);
+    g_ih += g_delta * ribw;
+    float g_ibw = -g_delta * ih * ribw * ribw;
+    const float gx_own = g_theta * ribw;
+    const float g_icw = -g_theta * ribw;
+    g_ibw += -g_theta * theta * ribw;
+    // the selected lane's results, in all 8 lanes
+    const float G_icw = splr_sum8(use ? g_icw : 0.f), G_ibw = splr_sum8(use ? g_ibw : 0.f);
+    const float G_ich = splr_sum8(use ? g_ich : 0.f), G_ih = splr_sum8(use ? g_ih : 0.f);
+    const float gx = inside ? splr_sum8(use ? gx_own : 0.f) : gy;
+    // knot construction, reverse (spl_knots_bwd): edge_k = -B + 2B sum_{i<k} w_i, size_k = 2B w_k
+    const bool below = (float)k < kp.cnt, at = (float)k == kp.cnt;
+    {
+        const float gp = cmin * (T2 * ((below ? G_icw : 0.f) + (at ? G_ibw : 0.f)));
+        const float dot = splr_sum8(kp.p_w * gp);
+        const float ga = T2 * (kp.p_w * (gp - dot));
+        const float dot2 = splr_sum8(kp.a_w * ga);
+        g_rw = inside ? kp.a_w * (ga - dot2) : 0.f;
+    }
+    {
+        const float gp = cmin * (T2 * ((below ? G_ich : 0.f) + (at ? G_ih : 0.f)));
+        const float dot = splr_sum8(kp.p_h * gp);
+        const float ga = T2 * (kp.p_h * (gp - dot));
+        const float dot2 = splr_sum8(kp.a_h * ga);
+        g_rh = inside ? kp.a_h * (ga - dot2) : 0.f;
+    }
+    // this lane's logit is the right knot of its bin: d1 of bin k, d0 of bin k + 1
+    const float from_next = splr_dpp<0x101>(use ? g_d0 : 0.f);   // row_shl:1: lane k <- lane k + 1
+    g_rd = ((use ? g_d1 : 0.f) + (k < SPL_K - 1 ? from_next : 0.f)) * kp.dd;
+    return gx;
+}
+
+// ---- the gradient kernel -----------------------------------------------------------------------------------------------------
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at a dword-aligned address: the packed vector's offsets are odd
+__device__ __forceinline__ f32x4 splr_ld4(const float *p) { const f32x4u v = *reinterpret_cast<const f32x4u *>(p); return (f32x4){v.x, v.y, v.z, v.w}; }
+
+// The weights of one coupling pass as this lane reads them.  Every set is loaded right behind the LAST USE of the set before it
+// (the trunk of coupling c + 1 behind the trunk of coupling c, ...): the registers are the same, the loads have the rest of the
+// running coupling to arrive, and no pass opens with a round trip to L2 (stamps of the first version: 1.8 us per coupling waited).
+template <int NC>
+struct SplrTrunkRows {   // forward: the layers' ROWS (unit o16 of every layer), the layer inputs come by v_readlane
+    f32x4 w0[4 * NC], w1[4], w2[4];
+    float b0, b1, b2;
+    __device__ __forceinline__ void load(const float *pn, int nin, int o16) {
+        const float *W0 = pn, *pb0 = pn + 16 * nin, *W1 = pb0 + 16, *pb1 = W1 + 256, *W2 = pb1 + 16, *pb2 = W2 + 256;
+#pragma unroll
+        for (int q = 0; q < 4 * NC; ++q) w0[q] = splr_ld4(W0 + o16 * nin + 4 * q);   // (past the row's end: inside the net, multiplied by 0)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { w1[q] = splr_ld4(W1 + o16 * 16 + 4 * q); w2[q] = splr_ld4(W2 + o16 * 16 + 4 * q); }
+        b0 = pb0[o16]; b1 = pb1[o16]; b2 = pb2[o16];
+    }
+};
+struct SplrTrunkCols {   // backward: the layers' COLUMNS (transposed products)
+    float w2c[16], w1c[16], w0c[16];
+    __device__ __forceinline__ void load(const float *pn, int nin, int o16, int lane) {
+        const float *W0 = pn, *W1 = pn + 16 * nin + 16, *W2 = W1 + 256 + 16;
+        const int il = lane < nin ? lane : nin - 1;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) { w2c[o] = W2[o * 16 + o16]; w1c[o] = W1[o * 16 + o16]; w0c[o] = W0[o * nin + il]; }
+    }
+};
+template <int NW>
+struct SplrLast {        // the last layer, four lanes per output row: this lane's quarter of rows 16 (wv + NW st) + (lane >> 2)
+    f32x4 w3[SPLR_NS];
+    float b3[SPLR_NS];
+    __device__ __forceinline__ void load(const float *pn, int nin, int nout, int wv, int lane, bool bias) {
+        const float *W3 = pn + 16 * nin + 16 + 2 * (256 + 16), *pb3 = W3 + (size_t)SPL_P * nout * 16;
+        const int nrows = SPL_P * nout;
+#pragma unroll
+        for (int st = 0; st < SPLR_NS; ++st) {
+            const int o = 16 * (wv + NW * st) + (lane >> 2), oc = o < nrows ? o : nrows - 1;
+            w3[st] = splr_ld4(W3 + (size_t)oc * 16 + 4 * (lane & 3));
+            if (bias) b3[st] = pb3[oc];
+        }
+    }
+};
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
+    constexpr int NC = NW > 2 ? 2 : 1;   // 16-lane chunks of a conditioner's inputs (x_dim <= 16 NW)
+    constexpr int NT = 64 * NW;
+    constexpr int PM = 64 / NW;          // conv: input indices per wave (x_dim <= 64)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // The early-stopping flag of the running training call is REQUESTED here and looked at behind the first batch of loads: as the
+    // kernel's first statement it was a cold round trip of its own.  A plain (volatile) load: the compiler's own wait sits at the use.
+    // (An inline-asm load whose result is waited for later can be copied by the register allocator BEFORE the data is there.)
+    int stop_flag = a.stop ? *reinterpret_cast<const volatile int *>(a.stop) : 0;
+    const SplTrainShape &ts = a.ts;
+    const SplineShape &s = ts.s;
+    const int D = s.D, B = s.B, nl = s.nl, nu = s.nu;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), o16 = lane & 15, q4 = lane & 3;
+    const int item = tid >> 3, k = tid & 7;
+    float *xrow = lds;                       // [64] the row
+    float *grow = xrow + 64;                 // [64] its gradient
+    float *red = grow + 64;                  // [NW][64]
+    float *hred = red + NW * 64;             // [4 NW][16]
+    float *trk = hred + 4 * NW * 16;         // [2B][3][16] trunk activations
+    float *rawbuf = trk + 2 * B * 48;        // [grow]
+    f32x4 *keep = reinterpret_cast<f32x4 *>(rawbuf + a.lay.grow);   // [2B][NT][4]
+    const bool vrow = (int)blockIdx.x >= a.M;
+    const int row = vrow ? (int)blockIdx.x - a.M : (int)blockIdx.x;
+    const int jl = lane < D ? lane : D - 1;
+    long src = row;
+    if (!vrow && a.perm) src = a.perm[row];
+    // the weights were written by the update kernel, i.e. into other XCDs' L2s: one dword per 128-byte line, all in flight at once,
+    // brings what the pass reads into this XCD's L2 (spl_grad_kernel has the measurement)
+    float sink = 0.f;
+    {
+        const size_t nb_w = (size_t)s.num_params * sizeof(float), nb_m = (size_t)B * D * D * sizeof(float);
+        const int l_w = (int)((nb_w + 127) >> 7), l_m = (int)((nb_m + 127) >> 7);
+        for (int i = tid; i < l_w + 2 * l_m; i += NT) {
+            const char *p = i < l_w ? reinterpret_cast<const char *>(a.w) + ((size_t)i << 7)
+                                    : (i < l_w + l_m ? reinterpret_cast<const char *>(a.wmat) + ((size_t)(i - l_w) << 7)
+                                                     : reinterpret_cast<const char *>(a.wmatT) + ((size_t)(i - l_w - l_m) << 7));
+            asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
+        }
+    }
+    // data = X[perm] + jitter * randn (trainer.py:392); the noise of dim d is component d & 3 of quad d >> 2 (spl_grad_kernel's numbering)
+    if (wv == 0) {
+        float xv = (vrow ? a.xv : a.x)[(size_t)src * D + jl];
+        if (!vrow && a.jitter != 0.f) {
+            float nz;
+            if (a.noise) nz = a.noise[(size_t)row * D + jl];
+            else {
+                const f32x4 n4 = noise_normal4(a.seed, (uint64_t)(a.noise_row0 + row), (uint32_t)a.epoch, (uint32_t)(jl >> 2), NOISE_STREAM_JITTER);
+                nz = splr_comp(n4, jl & 3);
+            }
+            xv += nz * a.jitter;
+        }
+        if (lane < D) xrow[lane] = xv;
+    }
+    // the first block's conv column, ActNorm vectors and the first coupling's weights ride behind the warm-up
+    const int ci0 = wv * PM;
+    auto load_col = [&](const float *Mt, float (&wcol)[PM]) {
+#pragma unroll
+        for (int t = 0; t < PM; ++t) { const int i = ci0 + t < D ? ci0 + t : D - 1; wcol[t] = Mt[(size_t)i * D + jl]; }
+    };
+    float wcol[PM], an_s, an_t;
+    SplrTrunkRows<NC> tw;
+    SplrLast<NW> lw;
+    SplrTrunkCols tc;
+    load_col(a.wmat, wcol);
+    an_s = a.w[ts.p_s + jl]; an_t = a.w[ts.p_t + jl];
+    tw.load(a.w + ts.p_f[0], nl, o16);
+    lw.load(a.w + ts.p_f[0], nl, nu, wv, lane, true);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
+    if (stop_flag) return;   // (uniform over the workgroup, in front of its first barrier)
+    splr_barrier();
+    float *const T0 = a.stg + a.lay.off_T, *const G0 = a.stg + a.lay.off_G, *const V0 = a.stg + a.lay.off_V;
+    const size_t rc = (size_t)a.lay.rows_cap;
+    float ld = 0.f;
+#ifdef NNEST_STAMP
+    long long st_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_a = wall_clock64();
+    const long long st_0 = st_a;
+#define R_STAMP(i) { const long long st_n = wall_clock64(); st_t[i] += st_n - st_a; st_a = st_n; }
+#else
+#define R_STAMP(i)
+#endif
+
+    // c = v M of the row vector held one element per lane (M's rows ci0 .. of this wave in `wcol`); result in every wave's lanes j < D
+    auto matvec = [&](const float (&wc)[PM], float v) -> float {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < PM; ++t) {
+            const int i = ci0 + t;
+            const float vi = splr_rl(v, i < 63 ? i : 63);
+            acc = fmaf(i < D ? vi : 0.f, wc[t], acc);
+        }
+        red[wv * 64 + lane] = acc;
+        splr_barrier();
+        float c = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) c += red[w * 64 + lane];
+        return c;
+    };
+    auto net_of = [&](int ci) -> const float * { return a.w + (size_t)(ci >> 1) * s.blk_params + ts.p_f[ci & 1]; };
+
+    // ---- forward (networks.py:24-32) ----------------------------------------------------------------------------------------
+    for (int b = 0; b < B; ++b) {
+        // ActNorm (networks.py:672-677) and the 1x1 conv z = x W (:649)
+        {
+            const float xd = xrow[jl];
+            const float av = lane < D ? xd * spl_exp(an_s) + an_t : 0.f;
+            if (wv == 0 && !vrow && lane < D) V0[((size_t)(3 * b + 0) * rc + row) * SPLR_VROW + lane] = av;
+            const float c = matvec(wcol, av);
+            if (wv == 0 && lane < D) xrow[lane] = c;
+            if (b + 1 < B) {   // the next block's: two couplings to arrive
+                const float *pbn = a.w + (size_t)(b + 1) * s.blk_params;
+                load_col(a.wmat + (size_t)(b + 1) * D * D, wcol);
+                an_s = pbn[ts.p_s + jl]; an_t = pbn[ts.p_t + jl];
+            }
+            splr_barrier();
+        }
+        R_STAMP(0)
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            const int ci = 2 * b + c;
+            const int nin = c ? nu : nl, nout = c ? nl : nu, idoff = c ? nl : 0, troff = c ? 0 : nl;
+            const int nrows = SPL_P * nout;
+            const float uL = lane < nin ? xrow[idoff + lane] : 0.f;
+            R_STAMP(1)
+            // trunk (networks.py:393-409): Linear LReLU x3, every wave the same
+            float h = tw.b0;
+#pragma unroll
+            for (int i = 0; i < 16 * NC; ++i) h = fmaf(i < nin ? splr_comp(tw.w0[i >> 2], i & 3) : 0.f, splr_rl(uL, i), h);
+            const float h0 = splr_lrelu(h);
+            h = tw.b1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h = fmaf(splr_comp(tw.w1[i >> 2], i & 3), splr_rl(h0, i), h);
+            const float h1 = splr_lrelu(h);
+            h = tw.b2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h = fmaf(splr_comp(tw.w2[i >> 2], i & 3), splr_rl(h1, i), h);
+            const float h2 = splr_lrelu(h);
+            // the next coupling's trunk rows into the same registers; at the turn, the last coupling's columns for the way back
+            if (ci + 1 < 2 * B) tw.load(net_of(ci + 1), c ? nl : nu, o16);
+            else if (!vrow) tc.load(net_of(ci), nin, o16, lane);
+            if (wv == 0 && !vrow) {
+                float *Tr = T0 + ((size_t)ci * rc + row) * SPLR_TROW;
+                if (lane < 16) { Tr[lane] = h0; Tr[16 + lane] = h1; Tr[32 + lane] = h2; trk[ci * 48 + lane] = h0; trk[ci * 48 + 16 + lane] = h1; trk[ci * 48 + 32 + lane] = h2; }
+                Tr[96 + lane] = uL;
+            }
+            R_STAMP(2)
+            // last layer, four lanes per output row
+            float hq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hq[e] = __shfl(h2, 4 * q4 + e);
+#pragma unroll
+            for (int st = 0; st < SPLR_NS; ++st) {
+                const int o = 16 * (wv + NW * st) + (lane >> 2);
+                float p = lw.w3[st].x * hq[0];
+                p = fmaf(lw.w3[st].y, hq[1], p); p = fmaf(lw.w3[st].z, hq[2], p); p = fmaf(lw.w3[st].w, hq[3], p);
+                p += splr_dpp<0xB1>(p);
+                p += splr_dpp<0x4E>(p);
+                if (q4 == 0 && o < nrows) rawbuf[o] = p + lw.b3[st];
+            }
+            if (ci + 1 < 2 * B) lw.load(net_of(ci + 1), c ? nl : nu, c ? nu : nl, wv, lane, true);   // (the last coupling's stay: the way back starts there)
+            splr_barrier();
+            R_STAMP(3)
+            // the spline, eight lanes per item (networks.py:583-587, :425-556)
+            {
+                const bool active = item < nout;
+                const int jb = SPL_P * (active ? item : 0);
+                const float rw = rawbuf[jb + k], rh = rawbuf[jb + 8 + k], rd = rawbuf[jb + 16 + (k < 7 ? k : 6)];
+                const float x = xrow[troff + (active ? item : 0)];
+                SplrKeep kp;
+                const float y = splr_eval(rw, rh, rd, x, s.tail, k, active, ld, kp);
+                if (!vrow) {
+                    f32x4 *kq = keep + ((size_t)ci * NT + tid) * 4;
+                    kq[0] = (f32x4){kp.a_w, kp.p_w, kp.a_h, kp.p_h}; kq[1] = (f32x4){kp.dd, kp.left, kp.width, kp.chl};
+                    kq[2] = (f32x4){kp.ht, kp.d0, kp.d1, kp.x}; kq[3] = (f32x4){kp.cnt, kp.use, 0.f, 0.f};
+                }
+                if (active && k == 0) xrow[troff + item] = y;
+            }
+            splr_barrier();
+            R_STAMP(4)
+        }
+    }
+    // log_probs (networks.py:71-76): base density of z + the log-determinants
+    {
+        if (!vrow) {   // the way back opens with the last block: its W^T column and ActNorm scale
+            load_col(a.wmatT + (size_t)(B - 1) * D * D, wcol);
+            an_s = a.w[(size_t)(B - 1) * s.blk_params + ts.p_s + jl];
+        }
+        float v = lane < D ? base_E(xrow[jl], s.base_beta) : 0.f;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ld += __shfl_xor(ld, o);
+        if (lane == 0) red[wv] = ld;
+        splr_barrier();
+        if (tid == 0) {
+            float lt = 0.f;
+            for (int w = 0; w < NW; ++w) lt += red[w];
+            for (int b = 0; b < B; ++b) lt += a.ldc[b];
+            a.rowlp[vrow ? a.M + row : row] = -v + s.base_const * (float)D + lt;
+        }
+    }
+    if (vrow) return;
+    R_STAMP(5)
+
+    // ---- backward: loss = -mean(log_probs) (trainer.py:394) ------------------------------------------------------------------
+    const float invM = 1.0f / (float)a.mtot, gld = -invM;
+    if (wv == 0 && lane < D) grow[lane] = base_dE(xrow[lane], s.base_beta) * invM;
+    splr_barrier();
+    for (int b = B - 1; b >= 0; --b) {
+#pragma unroll 1
+        for (int c = 1; c >= 0; --c) {
+            const int ci = 2 * b + c;
+            const int nin = c ? nu : nl, nout = c ? nl : nu, idoff = c ? nl : 0, troff = c ? 0 : nl;
+            const int nrows = SPL_P * nout;
+            // evaluation, reverse
+            {
+                const bool active = item < nout;
+                const f32x4 *kq = keep + ((size_t)ci * NT + tid) * 4;
+                const f32x4 k0 = kq[0], k1 = kq[1], k2 = kq[2], k3 = kq[3];
+                SplrKeep kp;
+                kp.a_w = k0.x; kp.p_w = k0.y; kp.a_h = k0.z; kp.p_h = k0.w; kp.dd = k1.x; kp.left = k1.y; kp.width = k1.z; kp.chl = k1.w;
+                kp.ht = k2.x; kp.d0 = k2.y; kp.d1 = k2.z; kp.x = k2.w; kp.cnt = k3.x; kp.use = k3.y; kp.pad0 = 0.f; kp.pad1 = 0.f;
+                const float gy = grow[troff + (active ? item : 0)];
+                float g_rw, g_rh, g_rd;
+                const float gx = splr_eval_bwd(kp, s.tail, k, gy, gld, g_rw, g_rh, g_rd);
+                if (active) {
+                    const int jb = SPL_P * item;
+                    rawbuf[jb + k] = g_rw; rawbuf[jb + 8 + k] = g_rh;
+                    if (k < 7) rawbuf[jb + 16 + k] = g_rd;
+                    if (k == 0) grow[troff + item] = gx;
+                }
+            }
+            splr_barrier();
+            R_STAMP(6)
+            // dLoss/d(raw) of the row: staged for the contraction over rows; dLoss/dh2 = W3^T g, four lanes per row of W3
+            {
+                float pt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < SPLR_NS; ++st) {
+                    const int o = 16 * (wv + NW * st) + (lane >> 2);
+                    const float g = o < nrows ? rawbuf[o < nrows ? o : 0] : 0.f;
+                    pt[0] = fmaf(g, lw.w3[st].x, pt[0]); pt[1] = fmaf(g, lw.w3[st].y, pt[1]); pt[2] = fmaf(g, lw.w3[st].z, pt[2]); pt[3] = fmaf(g, lw.w3[st].w, pt[3]);
+                }
+                if (ci > 0) lw.load(net_of(ci - 1), c ? nl : nu, c ? nu : nl, wv, lane, false);   // the coupling before, into the same registers
+                float *Gr = G0 + ((size_t)ci * rc + row) * a.lay.grow;
+                for (int o = tid; o < nrows; o += NT) Gr[o] = rawbuf[o];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pt[e] += splr_dpp<0x124>(pt[e]);   // row_ror:4
+                    pt[e] += splr_dpp<0x128>(pt[e]);   // row_ror:8
+                }
+                if (o16 < 4) *reinterpret_cast<f32x4 *>(hred + (wv * 4 + (lane >> 4)) * 16 + 4 * o16) = (f32x4){pt[0], pt[1], pt[2], pt[3]};
+            }
+            splr_barrier();
+            R_STAMP(7)
+            // trunk, reverse (every wave the same)
+            {
+                float dh = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4 * NW; ++e) dh += hred[e * 16 + o16];
+                const float h0 = trk[ci * 48 + o16], h1 = trk[ci * 48 + 16 + o16], h2 = trk[ci * 48 + 32 + o16];
+                const float d2 = dh * splr_slope(h2);
+                dh = 0.f;
+#pragma unroll
+                for (int o = 0; o < 16; ++o) dh = fmaf(tc.w2c[o], splr_rl(d2, o), dh);
+                const float d1 = dh * splr_slope(h1);
+                dh = 0.f;
+#pragma unroll
+                for (int o = 0; o < 16; ++o) dh = fmaf(tc.w1c[o], splr_rl(d1, o), dh);
+                const float d0 = dh * splr_slope(h0);
+                float du = 0.f;
+#pragma unroll
+                for (int o = 0; o < 16; ++o) du = fmaf(tc.w0c[o], splr_rl(d0, o), du);
+                if (ci > 0) tc.load(net_of(ci - 1), c ? nl : nu, o16, lane);
+                if (wv == 0) {
+                    float *Tr = T0 + ((size_t)ci * rc + row) * SPLR_TROW;
+                    if (lane < 16) { Tr[48 + lane] = d0; Tr[64 + lane] = d1; Tr[80 + lane] = d2; }
+                    if (lane < nin) grow[idoff + lane] += du;
+                }
+            }
+            splr_barrier();
+            R_STAMP(8)
+        }
+        // 1x1 conv c = a W: g_a = g_c W^T (dLoss/dW = sum_rows a^T g_c: the update kernel's contraction); ActNorm a = x e^s + t
+        {
+            const float gc = lane < D ? grow[jl] : 0.f;
+            if (wv == 0 && lane < D) V0[((size_t)(3 * b + 1) * rc + row) * SPLR_VROW + lane] = gc;
+            const float es = spl_exp(an_s);
+            const float ga = matvec(wcol, gc);
+            if (wv == 0 && lane < D) grow[lane] = ga * es;   // (ActNorm's own gradients: from dLoss/dW in the update kernel)
+            if (b > 0) {
+                load_col(a.wmatT + (size_t)(b - 1) * D * D, wcol);
+                an_s = a.w[(size_t)(b - 1) * s.blk_params + ts.p_s + jl];
+            }
+            splr_barrier();
+        }
+        R_STAMP(9)
+    }
+#ifdef NNEST_STAMP
+    if (blockIdx.x == 0 && tid == 0)
+        printf("splr_update head (the launch before): loads issued %.0f | old head to LDS %.0f | contraction + wait %.0f | LU grads + Adam %.0f | W, W^T %.0f | logdet %.0f; job 97: %.0f (x10 ns)\n",
+               a.ldc[4], a.ldc[5], a.ldc[6], a.ldc[7], a.ldc[8], a.ldc[9], a.ldc[10]);
+    if (blockIdx.x == 0 && tid == 0)
+        printf("   phase 3: Adam-state loads issued %.0f | G %.0f | old head staged %.0f | barrier %.0f ;  LU: ActNorm sums %.0f | first product %.0f | both tiles' steps %.0f | ActNorm step %.0f | barrier %.0f\n",
+               a.ldc[11], a.ldc[12], a.ldc[13], a.ldc[14], a.ldc[15], a.ldc[16], a.ldc[17], a.ldc[18], a.ldc[19]);
+    if (blockIdx.x == 0 && lane == 0)
+        printf("splr_grad wave %d: total %lld | fwd: conv %lld, loads waited %lld, trunk %lld, last layer %lld, eval %lld | logp %lld | bwd: eval %lld, W3^T g %lld, trunk %lld, conv %lld (x10 ns)\n",
+               wv, wall_clock64() - st_0, st_t[0], st_t[1], st_t[2], st_t[3], st_t[4], st_t[5], st_t[6], st_t[7], st_t[8], st_t[9]);
+#endif
+}
+
+// ---- the parameter update of a minibatch: contractions over its rows + Adam, one launch ----------------------------------------
+struct SplRowsUpdArgs {
+    float *w, *m, *v;
+    const float *stg;
+    SplRowsLayout lay;
+    const float *rowlp;
+    const int *pi, *pi_inv;
+    float *wmat, *wmatT, *ldc;
+    SplTrainShape ts;
+    int M;
+    float step_size, inv_bc2s, wd, ldw;
+    float *loss_out;
+    float loss_scale;
+    const int *stop;
+    float *grad_out, *gwsum_out;   // both non-NULL: gradient only (packed conditioner / ActNorm gradients, dLoss/dW of the convs), no step
+    int n_jobs;
+};
+
+// one Adam step of one parameter (torch/optim/adam.py _single_tensor_adam, coupled weight decay), as spl_adam_one
+__device__ __forceinline__ float splr_adam_one(float w, float g, float &m, float &v, float step_size, float inv_bc2s, float wd) {
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const float gi = g + wd * w;
+    m = m + (gi - m) * (1.0f - b1);
+    v = v * b2 + (1.0f - b2) * gi * gi;
+    // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sequences (~25 instructions per element): the block heads
+    // are one compute unit's instruction throughput (16 waves x 10 elements), and 3e-7 of an update of 1e-3 w is nothing
+    return w - step_size * (m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * inv_bc2s + eps));
+}
+__device__ __forceinline__ int splr_div_small(int x, int n) {   // x / n for 0 <= x < 64, 1 <= n <= 4 (tile counts): no integer division
+    return n == 4 ? x >> 2 : (n == 2 ? x >> 1 : (n == 1 ? x : (x * 43) >> 7));
+}
+
+__host__ __device__ inline int splr_jobs_of(const SplineShape &s, int c) {   // conditioner c of a block: W3 tiles + W2 + W1 + W0 tiles
+    const int nin = c ? s.nu : s.nl, nout = c ? s.nl : s.nu;
+    return (SPL_P * nout + 15) / 16 + 2 + (nin + 15) / 16;
+}
+
+// One wave, one 16x16 tile of one weight matrix of one conditioner: dW[o][i] = sum_rows A[row][o] B[row][i] with A the staged
+// gradient at the layer's output (g_raw, d2, d1, d0) and B its staged input (h2, h1, h0, u); the bias gradient is A's column sum.
+template <int STEPS>
+__device__ __forceinline__ void splr_job(const SplRowsUpdArgs &a, int id, int lane, int &stop_flag) {
+#ifdef NNEST_STAMP
+    const long long j_0 = wall_clock64();
+#endif
+    const SplTrainShape &ts = a.ts;
+    const SplineShape &s = ts.s;
+    const int j0 = splr_jobs_of(s, 0), j1 = splr_jobs_of(s, 1), jb = j0 + j1;
+    const int b = id / jb;
+    int r = id - b * jb;
+    const int c = r >= j0 ? 1 : 0;
+    r -= c * j0;
+    const int ci = 2 * b + c, nin = c ? s.nu : s.nl, nout = c ? s.nl : s.nu, n3 = (SPL_P * nout + 15) / 16;
+    const int pn = b * s.blk_params + ts.p_f[c];
+    const int pW0 = pn, pb0 = pW0 + 16 * nin, pW1 = pb0 + 16, pb1 = pW1 + 256, pW2 = pb1 + 16, pb2 = pW2 + 256, pW3 = pb2 + 16, pb3 = pW3 + SPL_P * nout * 16;
+    const size_t rc = (size_t)a.lay.rows_cap;
+    const float *T = a.stg + a.lay.off_T + (size_t)ci * rc * SPLR_TROW, *G = a.stg + a.lay.off_G + (size_t)ci * rc * a.lay.grow;
+    const float *Ap, *Bp;
+    int as, obase = 0, ibase = 0, wbase, instride, bbase, nov, niv;
+    if (r < n3) { Ap = G + 16 * r; as = a.lay.grow; Bp = T + 32; obase = 16 * r; wbase = pW3; instride = 16; bbase = pb3; nov = SPL_P * nout; niv = 16; }
+    else if (r == n3) { Ap = T + 80; as = SPLR_TROW; Bp = T + 16; wbase = pW2; instride = 16; bbase = pb2; nov = 16; niv = 16; }
+    else if (r == n3 + 1) { Ap = T + 64; as = SPLR_TROW; Bp = T + 0; wbase = pW1; instride = 16; bbase = pb1; nov = 16; niv = 16; }
+    else { const int t = r - n3 - 2; Ap = T + 48; as = SPLR_TROW; Bp = T + 96 + 16 * t; ibase = 16 * t; wbase = pW0; instride = nin; bbase = t == 0 ? pb0 : -1; nov = 16; niv = nin; }
+    const int p = lane & 15, kq = lane >> 4, M = a.M;
+    // (rows past the minibatch are read as they lie -- the buffers hold 128 rows, finite values or zeros -- and masked: clamping the row
+    // index made every load's address a value of its own, 2 x 52 of them live at once, spilled)
+    float av[STEPS], bv[STEPS];
+    {
+        const float *pa = Ap + (size_t)kq * as + p, *pb = Bp + (size_t)kq * SPLR_TROW + p;
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) { av[st] = *pa; bv[st] = *pb; pa += 4 * as; pb += 4 * SPLR_TROW; }
+    }
+    // the Adam state of the tile's elements (requested with the operands: one round trip)
+    int idx[5];
+    float wi[5], mi[5], vi[5];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int o = obase + 4 * kq + e, i = ibase + p;
+        idx[e] = (o < nov && i < niv) ? wbase + o * instride + i : -1;
+    }
+    idx[4] = (kq == 0 && bbase >= 0 && obase + p < nov) ? bbase + obase + p : -1;
+    const bool stepping = a.grad_out == nullptr;
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+        const int q = idx[e] >= 0 ? idx[e] : 0;
+        wi[e] = a.w[q];
+        mi[e] = stepping ? a.m[q] : 0.f;
+        vi[e] = stepping ? a.v[q] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float db = 0.f;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        const bool live = 4 * st + kq < M;
+        const float x = live ? av[st] : 0.f;
+        acc = mfma4(x, live ? bv[st] : 0.f, acc);
+        db += x;
+    }
+    db += __shfl_xor(db, 16);
+    db += __shfl_xor(db, 32);
+    const float g[5] = {acc.x, acc.y, acc.z, acc.w, db};
+    if (stop_flag) return;
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+        if (idx[e] < 0) continue;
+        if (!stepping) { a.grad_out[idx[e]] = g[e]; continue; }
+        const float wn = splr_adam_one(wi[e], g[e], mi[e], vi[e], a.step_size, a.inv_bc2s, a.wd);
+        a.m[idx[e]] = mi[e]; a.v[idx[e]] = vi[e]; a.w[idx[e]] = wn;
+    }
+#ifdef NNEST_STAMP
+    if (id == 97 && lane == 0) a.ldc[10] = (float)(wall_clock64() - j_0);
+#endif
+}
+
+// Workgroup b < B: the head of block b (ActNorm s, t; the 1x1 conv's L, S, U) -- dLoss/dW = a^T g_c contracted over the rows on the
+//   matrix cores, then as spl_update_kernel's head: dLoss/dW -> dLoss/d(L, S, U), the step, W and W^T from the new values, the
+//   log-det constant.
+// Workgroups B .. : sixteen waves = sixteen splr_job tiles each.  The last workgroup's wave 0 also sums the rows' log_probs.
+template <int STEPS>   // k-steps of the contractions over rows: 4 STEPS >= the minibatch
+__global__ void __launch_bounds__(1024) splr_update_kernel(SplRowsUpdArgs a) {
+    // The early-stopping flag of the running training call is REQUESTED here and looked at behind the first batch of loads: as the
+    // kernel's first statement it was a cold round trip of its own.  A plain (volatile) load: the compiler's own wait sits at the use.
+    // (An inline-asm load whose result is waited for later can be copied by the register allocator BEFORE the data is there.)
+    int stop_flag = a.stop ? *reinterpret_cast<const volatile int *>(a.stop) : 0;
+    extern __shared__ float ulds[];
+    const SplTrainShape &ts = a.ts;
+    const SplineShape &s = ts.s;
+    const int D = s.D, B = s.B, nhead = ts.p_f[0], tid = threadIdx.x, M = a.M;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool stepping = a.grad_out == nullptr;
+    if ((int)blockIdx.x >= B) {
+        const int id = ((int)blockIdx.x - B) * 16 + wave;
+        if (id < a.n_jobs) splr_job<STEPS>(a, id, lane, stop_flag);
+        else if (id == a.n_jobs && a.loss_out) {   // loss = -mean(log_probs) of the minibatch, rows added in a fixed order
+            float v = (lane < M ? a.rowlp[lane] : 0.f) + (lane + 64 < M ? a.rowlp[lane + 64] : 0.f);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            if (!stop_flag && lane == 0) *a.loss_out = v * a.loss_scale;
+        }
+        return;
+    }
+    const int b = blockIdx.x, base = b * s.blk_params;
+#ifdef NNEST_STAMP
+    long long u_t[8], u_f[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u_t[0] = wall_clock64();
+#define F_STAMP(i) u_f[i] = wall_clock64();
+#define U_STAMP(i) u_t[i] = wall_clock64();
+#else
+#define U_STAMP(i)
+#define F_STAMP(i)
+#endif
+    constexpr int DP = 65, MAT = 64 * DP;
+    float *hold = ulds, *G = ulds + nhead, *Um = G + MAT, *Lm = Um + MAT, *UmN = Lm + MAT, *LmN = UmN + MAT, *snew = LmN + MAT;
+    int *spi = reinterpret_cast<int *>(snew + 64);
+    float *anp = reinterpret_cast<float *>(spi + 64);   // [2][4][64]: ActNorm partial sums, one per column tile of the contraction
+    const int nwv = (int)(blockDim.x >> 6), nt = (D + 15) >> 4, li = lane & 15, lk = lane >> 4;
+    const size_t rc = (size_t)a.lay.rows_cap;
+    const float *Va = a.stg + a.lay.off_V + (size_t)(3 * b + 0) * rc * SPLR_VROW, *Vgc = Va + rc * SPLR_VROW;
+    // Round 1 (what other XCDs' gradient workgroups wrote: the long round trip): the contraction's operands and the ActNorm sums' rows
+    float av[STEPS], bv[STEPS];
+    const bool ctile = wave < nt * nt;
+    const int cti = splr_div_small(wave, nt), ctj = wave - cti * nt;
+    {
+        const float *pa = Va + (size_t)lk * SPLR_VROW + 16 * (ctile ? cti : 0) + li, *pb = Vgc + (size_t)lk * SPLR_VROW + 16 * (ctile ? ctj : 0) + li;
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) { av[st] = pa[st * 4 * SPLR_VROW]; bv[st] = pb[st * 4 * SPLR_VROW]; }   // (rows past the minibatch: masked below)
+    }
+    // ActNorm's gradients come out of the same contraction: sum_rows g_a a = sum_j W[d][j] dW[d][j] and sum_rows g_a = sum_j W[d][j]
+    // colsum_j(g_c), because g_a = g_c W^T -- this lane's four elements of the (old) W instead of two more operand streams
+    float Wt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int d = 16 * cti + 4 * lk + r, j = 16 * ctj + li;
+        Wt[r] = a.wmat[(size_t)b * D * D + ((ctile && d < D && j < D) ? d * D + j : 0)];
+    }
+    int prow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int i = 16 * cti + 4 * lk + r; prow[r] = (ctile && i < D) ? a.pi[b * D + i] : -1; }
+    for (int i = tid; i < D; i += blockDim.x) spi[i] = a.pi[b * D + i];
+    // ... and this block's own head and Adam state, in the same batch (a second batch behind the contraction was a second cold round trip:
+    // the L2 does not keep the last launch's lines); rows of 64 columns, no division
+    const int hrow = tid >> 6, hcol = lane;          // 16 rows x 64 columns per pass; x_dim <= 64: four passes per matrix
+    float hL[4], hU[4], hS = 0.f, hst = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = hrow + 16 * u, ok = row < D && hcol < D, o = ok ? row * D + hcol : 0;
+        hL[u] = a.w[base + ts.p_L + o];
+        hU[u] = a.w[base + ts.p_U + o];
+    }
+    if (tid < D) hS = a.w[base + ts.p_S + tid];
+    const bool an = tid < ts.p_L;
+    if (an) hst = a.w[base + tid];
+    __builtin_amdgcn_sched_barrier(0);
+    U_STAMP(1)
+    for (int idx = tid; idx < MAT; idx += blockDim.x) {  // the padding of the five matrices (no operand yet: the loads are in flight)
+        const int row = idx / DP, col = idx - row * DP;
+        if (row >= D || col >= D) { G[idx] = 0.f; Um[idx] = 0.f; Lm[idx] = 0.f; UmN[idx] = 0.f; LmN[idx] = 0.f; }
+    }
+    // dLoss/dW[i][j] = sum_rows a[row][i] g_c[row][j]
+    f32x4 cacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        const bool live = 4 * st + lk < M;
+        const float gcv = live ? bv[st] : 0.f;
+        cacc = mfma4(live ? av[st] : 0.f, gcv, cacc);
+        csum += gcv;
+    }
+    csum += __shfl_xor(csum, 16);
+    csum += __shfl_xor(csum, 32);   // column 16 ctj + li of g_c, summed over the rows
+    if (ctile) {
+        const float cv[4] = {cacc.x, cacc.y, cacc.z, cacc.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = 16 * cti + 4 * lk + r, j = 16 * ctj + li;
+            const bool in = d < D && j < D;
+            float p0 = in ? Wt[r] * csum : 0.f, p1 = in ? Wt[r] * cv[r] : 0.f;
+            p0 += splr_dpp<0x128>(p0); p1 += splr_dpp<0x128>(p1);   // over the tile's 16 columns (row_ror 8, 4, 2, 1)
+            p0 += splr_dpp<0x124>(p0); p1 += splr_dpp<0x124>(p1);
+            p0 += splr_dpp<0x122>(p0); p1 += splr_dpp<0x122>(p1);
+            p0 += splr_dpp<0x121>(p0); p1 += splr_dpp<0x121>(p1);
+            if (li == 0 && d < D) { anp[ctj * 64 + d] = p0; anp[256 + ctj * 64 + d] = p1; }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    U_STAMP(2)
+    // the Adam state of the head's elements: requested now (the operands' registers are free), used behind the barrier and the products
+    int hi[2][5];
+    float hm[2][5], hv[2][5];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int tile = wave + u * nwv;
+        const bool live = tile < 2 * nt * nt, isU = tile >= nt * nt;
+        const int tt = isU ? tile - nt * nt : tile, ti = splr_div_small(tt, nt), tj = tt - ti * nt, col = 16 * tj + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + 4 * lk + r;
+            hi[u][r] = (live && row < D && col < D) ? (isU ? ts.p_U : ts.p_L) + row * D + col : -1;
+        }
+        const int rd = col - 16 * ti - 4 * lk;
+        hi[u][4] = (live && isU && col < D && rd >= 0 && rd < 4) ? ts.p_S + col : -1;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int ii = hi[u][r] >= 0 ? hi[u][r] : 0;
+            hm[u][r] = stepping ? a.m[base + ii] : 0.f; hv[u][r] = stepping ? a.v[base + ii] : 0.f;
+        }
+    }
+    float an_m = stepping ? a.m[base + (an ? tid : 0)] : 0.f, an_v = stepping ? a.v[base + (an ? tid : 0)] : 0.f;
+    F_STAMP(0)
+    // G = dLoss/dW with its rows permuted as P does: G[pi(i)][j]
+    if (ctile) {
+        const float cv[4] = {cacc.x, cacc.y, cacc.z, cacc.w};
+        const int j = 16 * ctj + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (prow[r] < 0 || j >= D) continue;
+            G[prow[r] * DP + j] = cv[r];
+            if (!stepping) a.gwsum_out[(size_t)b * D * D + (size_t)(16 * cti + 4 * lk + r) * D + j] = cv[r];
+        }
+    }
+    F_STAMP(1)
+    // the old head: L, U (dense operands Lm = tril(L,-1) + I, Um = triu(U,1) + diag(S)), S, and ActNorm's s, t
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = hrow + 16 * u;
+        if (row < D && hcol < D) {
+            hold[ts.p_L + row * D + hcol] = hL[u];
+            hold[ts.p_U + row * D + hcol] = hU[u];
+            Lm[row * DP + hcol] = hcol < row ? hL[u] : (hcol == row ? 1.f : 0.f);
+            if (row != hcol) Um[row * DP + hcol] = row < hcol ? hU[u] : 0.f;
+        }
+    }
+    if (tid < D) { hold[ts.p_S + tid] = hS; Um[tid * (DP + 1)] = hS; }
+    if (an) hold[tid] = hst;
+    F_STAMP(2)
+    if (stop_flag) return;   // (uniform over the workgroup)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    U_STAMP(3)
+    // ActNorm a = x e^s + t: g_s = sum_rows g_a x e^s = sum g_a a - t sum g_a (+ the log-det term), g_t = sum_rows g_a
+    float an_g = 0.f;
+    if (an) {
+        const int d = tid < ts.p_t ? tid : tid - ts.p_t;
+        float s0 = 0.f, s1 = 0.f;
+        for (int tj = 0; tj < nt; ++tj) { s0 += anp[tj * 64 + d]; s1 += anp[256 + tj * 64 + d]; }
+        an_g = tid < ts.p_t ? s1 - hold[ts.p_t + d] * s0 + a.ldw : s0;
+        if (!stepping) a.grad_out[base + tid] = an_g;
+    }
+    if (!stepping) return;
+    F_STAMP(3)
+    const float *Sp = hold + ts.p_S;
+    const int KP = 16 * nt;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int tile = wave + u * nwv;
+        if (tile >= 2 * nt * nt) continue;
+        const bool isU = tile >= nt * nt;
+        const int tt = isU ? tile - nt * nt : tile, ti = splr_div_small(tt, nt), tj = tt - ti * nt;
+        const int i = 16 * ti + li, j = 16 * tj + li;
+        // C[r][c] = sum_k G[r][k] Um[c][k]   |   C[c][j] = sum_k Lm[k][c] G[k][j]
+        const float *pa = isU ? Lm + lk * DP + i : G + i * DP + lk, *pb = isU ? G + lk * DP + j : Um + j * DP + lk;
+        const int sa = isU ? 4 * DP : 4, sb = isU ? 4 * DP : 4;
+        float fa[16], fb[16];   // (all LDS reads of the product up front: x_dim <= 64 is at most 16 k-steps)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int qq = 4 * q < KP ? q : 0; fa[q] = pa[qq * sa]; fb[q] = pb[qq * sb]; }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (4 * q < KP) acc = mfma4(fa[q], fb[q], acc);
+        const float cv[4] = {acc.x, acc.y, acc.z, acc.w};
+        if (u == 0) { asm volatile("" :: "v"(cv[0])); F_STAMP(4) }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int e = hi[u][r];
+            if (e < 0) continue;
+            const int col = 16 * tj + li, row = r < 4 ? 16 * ti + 4 * lk + r : col;
+            float g;
+            if (r < 4) g = (isU ? row < col : col < row) ? cv[r] : 0.f;
+            else {
+                const int rd = col - 16 * ti - 4 * lk;
+                g = (rd == 0 ? cv[0] : rd == 1 ? cv[1] : rd == 2 ? cv[2] : cv[3]) + a.ldw * __builtin_amdgcn_rcpf(Sp[col]);  // + the conv's log-det term
+            }
+            const float wn = splr_adam_one(hold[e], g, hm[u][r], hv[u][r], a.step_size, a.inv_bc2s, a.wd);
+            a.m[base + e] = hm[u][r]; a.v[base + e] = hv[u][r]; a.w[base + e] = wn;
+            if (!isU) LmN[row * DP + col] = col < row ? wn : (col == row ? 1.f : 0.f);
+            else if (r == 4) { UmN[col * (DP + 1)] = wn; snew[col] = wn; }
+            else if (row != col) UmN[row * DP + col] = row < col ? wn : 0.f;
+        }
+    }
+    F_STAMP(5)
+    if (an) {
+        const float wn = splr_adam_one(hold[tid], an_g, an_m, an_v, a.step_size, a.inv_bc2s, a.wd);
+        a.m[base + tid] = an_m; a.v[base + tid] = an_v; a.w[base + tid] = wn;
+        if (tid < ts.p_t) hold[tid] = wn;  // (the new s, for the log-det constant)
+    }
+    F_STAMP(6)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    U_STAMP(4)
+    // W = (P Lm) Um from the new values, and its transpose (the gradient kernel reads both row-major)
+    float *Wm = a.wmat + (size_t)b * D * D, *WmT = a.wmatT + (size_t)b * D * D;
+    if (wave < nt * nt) {
+        const int ti = splr_div_small(wave, nt), tj = wave - ti * nt, i = 16 * ti + li, j = 16 * tj + li;
+        const int pr = i < D ? spi[i] : 63;
+        const float *pa = LmN + pr * DP + lk, *pb = UmN + lk * DP + j;
+        float fa[16], fb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int qq = 4 * q < KP ? q : 0; fa[q] = pa[4 * qq]; fb[q] = pb[4 * qq * DP]; }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (4 * q < KP) acc = mfma4(fa[q], fb[q], acc);
+        const float cv[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + 4 * lk + r, col = 16 * tj + li;
+            if (row < D && col < D) { Wm[row * D + col] = cv[r]; WmT[col * D + row] = cv[r]; }
+        }
+    }
+    U_STAMP(5)
+    // log|det| of ActNorm + conv (networks.py:650, :676): the terms in parallel, summed in d order
+    if (wave == nwv - 1) {   // (the last wave: its product tile, if it has one, is done)
+        float t = lane < D ? hold[ts.p_s + lane] + logf(fabsf(snew[lane < D ? lane : 0])) : 0.f;
+        float acc = 0.f;
+        for (int d = 0; d < D; ++d) acc += splr_rl(t, d);
+        if (lane == 0) a.ldc[b] = acc;
+    }
+#ifdef NNEST_STAMP
+    U_STAMP(6)
+    // (device printf from this kernel's 1024-thread workgroups does not come out on this image: the gradient kernel of the NEXT launch
+    // prints what is left here, behind the log-det constants)
+    if (tid == 0 && b == 0) {
+        for (int i = 0; i < 6; ++i) a.ldc[4 + i] = (float)(u_t[i + 1] - u_t[i]);
+        a.ldc[11] = (float)(u_f[0] - u_t[2]); a.ldc[12] = (float)(u_f[1] - u_f[0]); a.ldc[13] = (float)(u_f[2] - u_f[1]); a.ldc[14] = (float)(u_t[3] - u_f[2]);
+        a.ldc[15] = (float)(u_f[3] - u_t[3]); a.ldc[16] = (float)(u_f[4] - u_f[3]); a.ldc[17] = (float)(u_f[5] - u_f[4]); a.ldc[18] = (float)(u_f[6] - u_f[5]); a.ldc[19] = (float)(u_t[4] - u_f[6]);
+    }
+#endif
+}
+
+// W^T and the log-det constants from the current packed weights / W (start of a training call, and the gradient-only entry)
+__global__ void splr_init_kernel(const float *__restrict__ w, const float *__restrict__ wmat, float *__restrict__ wmatT, float *__restrict__ ldc,
+                                 SplTrainShape ts, const int *__restrict__ stop) {
+    if (stop && *stop) return;
+    const int D = ts.s.D, n = ts.s.B * D * D;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        const int b = idx / (D * D), i = (idx / D) % D, j = idx % D;
+        wmatT[(size_t)b * D * D + (size_t)j * D + i] = wmat[idx];
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ts.s.B) {
+        const float *pb = w + (size_t)threadIdx.x * ts.s.blk_params;
+        float acc = 0.f;
+        for (int d = 0; d < D; ++d) acc += pb[ts.p_s + d] + logf(fabsf(pb[ts.p_S + d]));
+        ldc[threadIdx.x] = acc;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------------
+bool spline_rows_eligible(const SplineShape &s, int batch) {
+    static const bool off = [] { const char *e = getenv("NNEST_SPL_ROWS"); return e && !strcmp(e, "0"); }();
+    return !off && s.H == 16 && s.K == SPL_K && s.D >= 2 && s.D <= 64 && batch >= 1 && batch <= 128 && s.B >= 1 && s.B <= 4;
+}
+
+static int rows_waves(const SplineShape &s) { const int n = 8 * (s.nl > s.nu ? s.nl : s.nu); return n <= 64 ? 1 : (n <= 128 ? 2 : 4); }
+
+static size_t rows_grad_lds(const SplineShape &s, const SplRowsLayout &lay) {
+    const int NW = rows_waves(s);
+    return (size_t)(64 + 64 + NW * 64 + 4 * NW * 16 + 2 * s.B * 48 + lay.grow + 2 * s.B * 64 * NW * 16) * sizeof(float);
+}
+
+void spline_rows_free(nnest_spline *h) {
+    SplRowsState *r = (SplRowsState *)h->rows;
+    if (!r) return;
+    (void)hipFree(r->stg); (void)hipFree(r->wmatT); (void)hipFree(r->ldc); (void)hipFree(r->rowlp);
+    delete r;
+    h->rows = nullptr;
+}
+
+// buffers for minibatches of up to `max_rows` rows (+ `valid_rows` forward-only rows in the same launch); W^T and the log-det constants
+// from the current w_dev / wmat (queued on `st` behind whatever wrote them)
+int spline_rows_prepare(nnest_spline *h, const SplTrainShape &ts, int max_rows, int valid_rows, hipStream_t st, const int *stop) {
+    const SplineShape &s = h->s;
+    SplRowsState *r = (SplRowsState *)h->rows;
+    if (!r) {
+        r = new SplRowsState();
+        memset(r, 0, sizeof(*r));
+        h->rows = r;
+        SHIP_TRY(hipMalloc((void **)&r->wmatT, (size_t)s.B * s.D * s.D * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&r->ldc, 32 * sizeof(float)));
+    }
+    if (max_rows < 128) max_rows = 128;   // (the contractions read 4 x 26 or 4 x 32 rows whatever the minibatch)
+    if (max_rows > r->lay.rows_cap) {
+        if (r->stg) (void)hipFree(r->stg);
+        r->stg = nullptr;
+        SplRowsLayout &l = r->lay;
+        l.rows_cap = max_rows;
+        const int nmax = s.nl > s.nu ? s.nl : s.nu;
+        l.grow = ((SPL_P * nmax + 15) / 16) * 16;
+        l.off_T = 0;
+        l.off_G = l.off_T + (size_t)2 * s.B * l.rows_cap * SPLR_TROW;
+        l.off_V = l.off_G + (size_t)2 * s.B * l.rows_cap * l.grow;
+        l.total = l.off_V + (size_t)3 * s.B * l.rows_cap * SPLR_VROW;
+        SHIP_TRY(hipMalloc((void **)&r->stg, l.total * sizeof(float)));
+        SHIP_TRY(hipMemsetAsync(r->stg, 0, l.total * sizeof(float), st));   // (columns past a conditioner's outputs are read by the contraction tiles and discarded)
+        if (r->rowlp) (void)hipFree(r->rowlp);
+        r->rowlp = nullptr; r->valid_cap = 0;
+    }
+    if (!r->rowlp || valid_rows > r->valid_cap) {
+        if (r->rowlp) (void)hipFree(r->rowlp);
+        r->rowlp = nullptr;
+        SHIP_TRY(hipMalloc((void **)&r->rowlp, (size_t)(r->lay.rows_cap + valid_rows + 4) * sizeof(float)));
+        r->valid_cap = valid_rows;
+    }
+    if (rows_grad_lds(s, r->lay) > (size_t)160 * 1024) return spline_fail(NNEST_E_UNSUPPORTED, "rows form: LDS");
+    hipLaunchKernelGGL(splr_init_kernel, dim3(32), dim3(256), 0, st, h->w_dev, h->wmat, r->wmatT, r->ldc, ts, stop);
+    SHIP_TRY(hipGetLastError());
+    return NNEST_OK;
+}
+
+float *spline_rows_rowlp(nnest_spline *h) { return ((SplRowsState *)h->rows)->rowlp; }
+
+hipError_t spline_rows_grad(nnest_spline *h, const SplTrainShape &ts, const SplRowsBatch &bt, hipStream_t st) {
+    SplRowsState *r = (SplRowsState *)h->rows;
+    SplRowsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = h->w_dev; a.wmat = h->wmat; a.wmatT = r->wmatT; a.ldc = r->ldc; a.ts = ts;
+    a.x = bt.x; a.perm = bt.perm; a.M = bt.M; a.mtot = bt.mtot; a.noise = bt.noise; a.seed = bt.seed; a.noise_row0 = bt.noise_row0;
+    a.epoch = bt.epoch; a.jitter = bt.jitter; a.xv = bt.xv; a.Mv = bt.Mv; a.rowlp = r->rowlp; a.stg = r->stg; a.lay = r->lay; a.stop = bt.stop;
+    const size_t ldsb = rows_grad_lds(h->s, r->lay);
+    const int NW = rows_waves(h->s), grid = bt.M + bt.Mv;
+    hipError_t e = hipSuccess;
+    if (NW == 1) {
+        static bool attr1 = false;
+        if (!attr1) { e = hipFuncSetAttribute((const void *)splr_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+        if (e == hipSuccess) hipLaunchKernelGGL(splr_grad_kernel<1>, dim3(grid), dim3(64), ldsb, st, a);
+    } else if (NW == 2) {
+        static bool attr2 = false;
+        if (!attr2) { e = hipFuncSetAttribute((const void *)splr_grad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
+        if (e == hipSuccess) hipLaunchKernelGGL(splr_grad_kernel<2>, dim3(grid), dim3(128), ldsb, st, a);
+    } else {
+        static bool attr4 = false;
+        if (!attr4) { e = hipFuncSetAttribute((const void *)splr_grad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr4 = true; }
+        if (e == hipSuccess) hipLaunchKernelGGL(splr_grad_kernel<4>, dim3(grid), dim3(256), ldsb, st, a);
+    }
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
+hipError_t spline_rows_update(nnest_spline *h, const SplTrainShape &ts, const SplRowsStep &u, hipStream_t st) {
+    SplRowsState *r = (SplRowsState *)h->rows;
+    const SplineShape &s = h->s;
+    SplRowsUpdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = h->w_dev; a.m = h->adam_m; a.v = h->adam_v; a.stg = r->stg; a.lay = r->lay; a.rowlp = r->rowlp;
+    a.pi = h->pi_dev; a.pi_inv = h->pi_dev + s.B * s.D; a.wmat = h->wmat; a.wmatT = r->wmatT; a.ldc = r->ldc; a.ts = ts; a.M = u.M;
+    a.step_size = u.step_size; a.inv_bc2s = u.inv_bc2s; a.wd = u.wd; a.ldw = u.ldw; a.loss_out = u.loss_out; a.loss_scale = u.loss_scale;
+    a.stop = u.stop; a.grad_out = u.grad_out; a.gwsum_out = u.gwsum_out;
+    a.n_jobs = s.B * (splr_jobs_of(s, 0) + splr_jobs_of(s, 1));
+    const size_t ldsb = ((size_t)ts.p_f[0] + 5 * 64 * 65 + 64 + 2048) * sizeof(float) + 64 * sizeof(int);
+    static bool attr = false;
+    hipError_t e = hipSuccess;
+    if (!attr) {
+        e = hipFuncSetAttribute((const void *)splr_update_kernel<26>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)splr_update_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (e != hipSuccess) return e;
+    const dim3 grid(s.B + (a.n_jobs + 1 + 15) / 16);
+    static const bool s32 = getenv("NNEST_SPLR_STEPS32") != nullptr;   // (diagnostic)
+    if (u.M <= 104 && !s32) hipLaunchKernelGGL(splr_update_kernel<26>, grid, dim3(1024), ldsb, st, a);
+    else hipLaunchKernelGGL(splr_update_kernel<32>, grid, dim3(1024), ldsb, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace nnest

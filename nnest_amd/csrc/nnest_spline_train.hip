@@ -1913,6 +1913,21 @@ int nnest_spline_loss_grad(nnest_spline_t *h, const float *x_dev, int M, float *
     int rc = ensure_train_state(h, M > 128 ? M : 128, st);
     if (rc) return rc;
     const SplTrainShape ts = make_train_shape(h->s);
+    if (spline_rows_eligible(h->s, M)) {   // one row per workgroup (nnest_spline_rows.hip); the gradient instead of the step
+        hipLaunchKernelGGL(spl_assemble_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev, h->wmat, ts, (const int *)nullptr);
+        if ((rc = spline_rows_prepare(h, ts, 128, 0, st, nullptr))) return rc;
+        SplRowsBatch bt;
+        memset(&bt, 0, sizeof(bt));
+        bt.x = x_dev; bt.M = M; bt.mtot = M;
+        SHIP_TRY(spline_rows_grad(h, ts, bt, st));
+        SplRowsStep u;
+        memset(&u, 0, sizeof(u));
+        u.M = M; u.ldw = -1.0f; u.loss_out = loss_dev; u.loss_scale = -1.0f / (float)M; u.grad_out = grad_dev; u.gwsum_out = h->gwsum;
+        SHIP_TRY(spline_rows_update(h, ts, u, st));
+        hipLaunchKernelGGL(spl_lu_grad_kernel, dim3(64), dim3(256), 2 * (size_t)h->s.B * h->s.D * sizeof(int), st, h->w_dev, h->pi_dev + h->s.B * h->s.D, h->pi_dev, h->gwsum, grad_dev, ts, -1.0f, (const int *)nullptr);
+        SHIP_TRY(hipGetLastError());
+        return NNEST_OK;
+    }
     if ((rc = build_timage(h, ts, st))) return rc;
     SplGradArgs a;
     memset(&a, 0, sizeof(a));
@@ -2010,6 +2025,12 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
     // the next one (forward-only tiles on other CUs; the weights do not change in between), followed by the epoch's bookkeeping.
     // The larger shapes rebuild the image per minibatch (their conv images are too much work for one workgroup per block).
     const bool fused = h->s.NTh <= 2;
+    // the rows form (nnest_spline_rows.hip): one row per workgroup, the parameter gradients contracted over the rows in its update kernel
+    const bool rows = spline_rows_eligible(h->s, batch);
+    if (rows) {
+        hipLaunchKernelGGL(spl_assemble_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev, h->wmat, ts, (const int *)nullptr);
+        if ((rc = spline_rows_prepare(h, ts, 128, n_valid, st, nullptr))) return rc;
+    }
     const int CHUNK = 8;
     hipEvent_t ev[2];
     SHIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
@@ -2050,7 +2071,25 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             const int tiles = grad_tiles(a);
             h->adam_step += 1;
             const double bc1 = 1.0 - pow(0.9, (double)h->adam_step), bc2 = 1.0 - pow(0.999, (double)h->adam_step);
-            if (fused) {
+            if (rows) {
+                const bool ride = mb == 0 && epoch > 0;  // the validation pass of the epoch before: forward-only rows behind the minibatch's
+                SplRowsBatch bt;
+                memset(&bt, 0, sizeof(bt));
+                bt.x = a.x; bt.perm = a.perm; bt.M = M; bt.mtot = M; bt.noise = a.noise; bt.seed = seed; bt.noise_row0 = a.noise_row0; bt.epoch = epoch;
+                bt.jitter = jitter; bt.stop = stop;
+                if (ride) { bt.xv = xvalid_dev; bt.Mv = n_valid; }
+                SHIP_TRY(spline_rows_grad(h, ts, bt, st));
+                if (ride) {
+                    hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch - 1, patience,
+                                       h->epoch_losses_dev, spline_rows_rowlp(h) + M + 3, 1, n_valid, h->w_dev, h->best_w, np);
+                    if ((rc = snapshot(epoch))) return rc;
+                }
+                SplRowsStep u;
+                memset(&u, 0, sizeof(u));
+                u.M = M; u.step_size = (float)((double)lr / bc1); u.inv_bc2s = (float)(1.0 / sqrt(bc2)); u.wd = weight_decay; u.ldw = -1.0f;
+                u.loss_out = h->losses_dev + mb; u.loss_scale = -1.0f / (float)M; u.stop = stop;
+                SHIP_TRY(spline_rows_update(h, ts, u, st));
+            } else if (fused) {
                 if (mb == 0 && epoch == 0 && (rc = build_timage(h, ts, st, stop))) return rc;
                 const bool ride = mb == 0 && epoch > 0;  // the validation pass of the epoch before
                 if (ride) { a.val_tiles = vtiles; a.xv = xvalid_dev; a.Mv = n_valid; }
@@ -2084,8 +2123,19 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             }
         }
         SHIP_TRY(hipGetLastError());
-        if (fused && epoch + 1 < max_epochs) continue;  // this epoch's validation rides with the next epoch's first gradient pass
+        if ((fused || rows) && epoch + 1 < max_epochs) continue;  // this epoch's validation rides with the next epoch's first gradient pass
         // Trainer._validate (trainer.py:405-418): one full batch; mean, then / len(dataset)
+        if (rows) {
+            SplRowsBatch bt;
+            memset(&bt, 0, sizeof(bt));
+            bt.xv = xvalid_dev; bt.Mv = n_valid; bt.stop = stop;
+            SHIP_TRY(spline_rows_grad(h, ts, bt, st));
+            hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch, patience,
+                               h->epoch_losses_dev, spline_rows_rowlp(h) + 3, 1, n_valid, h->w_dev, h->best_w, np);
+            SHIP_TRY(hipGetLastError());
+            if ((rc = snapshot(epoch + 1))) return rc;
+            continue;
+        }
         if (!fused && (rc = build_timage(h, ts, st, stop))) return rc;
         {
             const SplGradArgs a = valid_args();

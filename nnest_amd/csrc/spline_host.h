@@ -30,9 +30,39 @@ struct nnest_spline {
     int partial_tiles;
     int adam_step;
     bool w_dev_current;       // w_dev holds the same weights as w
+    void *rows;               // SplRowsState: the rows form's staging buffers, W^T and log-det constants (nnest_spline_rows.hip)
 };
 
 namespace nnest {
+struct SplTrainShape;
+// ---- the rows form of the training step (nnest_spline_rows.hip) ----
+struct SplRowsBatch {   // one gradient launch: a minibatch (+ Mv forward-only validation rows behind it)
+    const float *x;
+    const int *perm;
+    int M, mtot;
+    const float *noise;
+    uint64_t seed;
+    long noise_row0;
+    int epoch;
+    float jitter;
+    const float *xv;
+    int Mv;
+    const int *stop;
+};
+struct SplRowsStep {    // one update launch
+    int M;
+    float step_size, inv_bc2s, wd, ldw;
+    float *loss_out;
+    float loss_scale;
+    const int *stop;
+    float *grad_out, *gwsum_out;   // both non-NULL: write the gradient instead of stepping
+};
+bool spline_rows_eligible(const SplineShape &s, int batch);
+int spline_rows_prepare(nnest_spline *h, const SplTrainShape &ts, int max_rows, int valid_rows, hipStream_t st, const int *stop);
+hipError_t spline_rows_grad(nnest_spline *h, const SplTrainShape &ts, const SplRowsBatch &bt, hipStream_t st);
+hipError_t spline_rows_update(nnest_spline *h, const SplTrainShape &ts, const SplRowsStep &u, hipStream_t st);
+float *spline_rows_rowlp(nnest_spline *h);
+void spline_rows_free(nnest_spline *h);
 int spline_fail(int code, const char *fmt, ...);
 int spline_build_image(nnest_spline *h);
 int spline_mlp_params(int nin, int nout, int H);
