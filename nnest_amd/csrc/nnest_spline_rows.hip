@@ -252,48 +252,75 @@ __device__ __forceinline__ float splr_eval_bwd(const SplrKeep &kp, float tail, i
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes at a dword-aligned address: the packed vector's offsets are odd
 __device__ __forceinline__ f32x4 splr_ld4(const float *p) { const f32x4u v = *reinterpret_cast<const f32x4u *>(p); return (f32x4){v.x, v.y, v.z, v.w}; }
 
-// The weights of one coupling pass as this lane reads them.  Every set is loaded right behind the LAST USE of the set before it
-// (the trunk of coupling c + 1 behind the trunk of coupling c, ...): the registers are the same, the loads have the rest of the
-// running coupling to arrive, and no pass opens with a round trip to L2 (stamps of the first version: 1.8 us per coupling waited).
+// The conditioner's trunk and last layer on the matrix cores, one row per workgroup: y = W x as D = A B with A the weights and B the
+// vector in ALL sixteen columns -- fifteen of them are redundant, but a 16 -> 16 layer is four v_mfma_f32_16x16x4 instead of 16
+// v_readlane + 16 v_fmac on a lone wave's dependent chain, and a lane holds 4 weights of the layer instead of 16.
+// Layout of a 16-vector y: the lanes of k-group lk = lane >> 4 hold y[4 lk + r] in register r (the same in all 16 columns).  The
+// contraction index of step s, group lk is 4 lk + s -- so a lane's four A operands of a layer are 16 contiguous bytes of the weight row
+// (one load), its B operand of step s is its own register s of the layer's input, and a product leaves row 4 lk + r of D in register r:
+// the layers chain without any exchange between lanes.  (A first version had the contraction index 4 s + lk: four 4-byte loads per
+// lane and layer, 79 loads in flight per wave -- more than the 63 the counter holds: the prefetch serialised, 4.4 us per last layer.)
+__device__ __forceinline__ f32x4 splr_lrelu4(f32x4 v) { return (f32x4){splr_lrelu(v.x), splr_lrelu(v.y), splr_lrelu(v.z), splr_lrelu(v.w)}; }
+__device__ __forceinline__ f32x4 splr_slope4(f32x4 g, f32x4 post) {
+    return (f32x4){g.x * splr_slope(post.x), g.y * splr_slope(post.y), g.z * splr_slope(post.z), g.w * splr_slope(post.w)};
+}
+// D += W[:, 4 lk .. 4 lk + 3] x[4 lk .. 4 lk + 3] over the four k-groups: four products on two accumulators
+__device__ __forceinline__ f32x4 splr_mv16(const f32x4 &w, const f32x4 &x, f32x4 acc) {
+    f32x4 a2 = mfma4(w.y, x.y, (f32x4){0.f, 0.f, 0.f, 0.f});
+    acc = mfma4(w.x, x.x, acc);
+    a2 = mfma4(w.w, x.w, a2);
+    acc = mfma4(w.z, x.z, acc);
+    return acc + a2;
+}
+
+// Every set is loaded right behind the LAST USE of the set before it (the trunk of coupling c + 1 behind the trunk of coupling c, ...):
+// the registers are the same, the loads have the rest of the running coupling to arrive, and no pass opens with a round trip to L2
+// (stamps of the first version: 1.8 us per coupling waited).
 template <int NC>
-struct SplrTrunkRows {   // forward: the layers' ROWS (unit o16 of every layer), the layer inputs come by v_readlane
-    f32x4 w0[4 * NC], w1[4], w2[4];
-    float b0, b1, b2;
-    __device__ __forceinline__ void load(const float *pn, int nin, int o16) {
+struct SplrTrunkF {   // forward trunk: this lane's quarter of row c16 of the three layers, the biases of its four units
+    f32x4 t0[NC], t1, t2, b0, b1, b2;
+    __device__ __forceinline__ void load(const float *pn, int nin, int c16, int lk) {
         const float *W0 = pn, *pb0 = pn + 16 * nin, *W1 = pb0 + 16, *pb1 = W1 + 256, *W2 = pb1 + 16, *pb2 = W2 + 256;
 #pragma unroll
-        for (int q = 0; q < 4 * NC; ++q) w0[q] = splr_ld4(W0 + o16 * nin + 4 * q);   // (past the row's end: inside the net, multiplied by 0)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { w1[q] = splr_ld4(W1 + o16 * 16 + 4 * q); w2[q] = splr_ld4(W2 + o16 * 16 + 4 * q); }
-        b0 = pb0[o16]; b1 = pb1[o16]; b2 = pb2[o16];
+        for (int t = 0; t < NC; ++t) t0[t] = splr_ld4(W0 + c16 * nin + 16 * t + 4 * lk);   // (past the row's end: inside the net, finite; the B operand there is 0)
+        t1 = splr_ld4(W1 + c16 * 16 + 4 * lk); t2 = splr_ld4(W2 + c16 * 16 + 4 * lk);
+        b0 = splr_ld4(pb0 + 4 * lk); b1 = splr_ld4(pb1 + 4 * lk); b2 = splr_ld4(pb2 + 4 * lk);
     }
 };
-struct SplrTrunkCols {   // backward: the layers' COLUMNS (transposed products)
-    float w2c[16], w1c[16], w0c[16];
-    __device__ __forceinline__ void load(const float *pn, int nin, int o16, int lane) {
-        const float *W0 = pn, *W1 = pn + 16 * nin + 16, *W2 = W1 + 256 + 16;
-        const int il = lane < nin ? lane : nin - 1;
-#pragma unroll
-        for (int o = 0; o < 16; ++o) { w2c[o] = W2[o * 16 + o16]; w1c[o] = W1[o * 16 + o16]; w0c[o] = W0[o * nin + il]; }
-    }
-};
-template <int NW>
-struct SplrLast {        // the last layer, four lanes per output row: this lane's quarter of rows 16 (wv + NW st) + (lane >> 2)
-    f32x4 w3[SPLR_NS];
-    float b3[SPLR_NS];
-    __device__ __forceinline__ void load(const float *pn, int nin, int nout, int wv, int lane, bool bias) {
+template <int NW, int NS>
+struct SplrLastW {    // the last layer, tile st of this wave = output rows 16 (wv + NW st) .. + 15: this lane's quarter 4 lk .. of row c16 of
+    f32x4 l3[NS];     // the tile -- forward as A operands, on the way back as the weights of sum_o g[o] W3[o][:]; e0..2: the three biases
+    float e0, e1, e2; // of the outputs this lane reads back as (item, bin), added there
+    __device__ __forceinline__ void load(const float *pn, int nin, int nout, int wv, int c16, int lk, int item, int k, bool bias) {
         const float *W3 = pn + 16 * nin + 16 + 2 * (256 + 16), *pb3 = W3 + (size_t)SPL_P * nout * 16;
         const int nrows = SPL_P * nout;
 #pragma unroll
-        for (int st = 0; st < SPLR_NS; ++st) {
-            const int o = 16 * (wv + NW * st) + (lane >> 2), oc = o < nrows ? o : nrows - 1;
-            w3[st] = splr_ld4(W3 + (size_t)oc * 16 + 4 * (lane & 3));
-            if (bias) b3[st] = pb3[oc];
+        for (int st = 0; st < NS; ++st) {
+            const int o = 16 * (wv + NW * st) + c16, oc = o < nrows ? o : nrows - 1;   // (rows past the outputs: never read forward, times 0 on the way back)
+            l3[st] = splr_ld4(W3 + (size_t)oc * 16 + 4 * lk);
+        }
+        if (bias) {
+            const int jb = SPL_P * (item < nout ? item : 0);
+            e0 = pb3[jb + k]; e1 = pb3[jb + 8 + k]; e2 = pb3[jb + 16 + (k < 7 ? k : 6)];
+        }
+    }
+};
+template <int NC>
+struct SplrTrunkB {   // the trunk's transposed layers: A[i = c16][k = 4 lk + s] = W[4 lk + s][i]
+    float c2[4], c1[4], c0[NC][4];
+    __device__ __forceinline__ void load(const float *pn, int nin, int c16, int lk) {
+        const float *W0 = pn, *W1 = pn + 16 * nin + 16, *W2 = W1 + 256 + 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c2[q] = W2[(4 * lk + q) * 16 + c16];
+            c1[q] = W1[(4 * lk + q) * 16 + c16];
+#pragma unroll
+            for (int t = 0; t < NC; ++t) { const int i = 16 * t + c16; c0[t][q] = W0[(4 * lk + q) * nin + (i < nin ? i : 0)]; }   // (rows past the inputs are not written back)
         }
     }
 };
 
-template <int NW>
+template <int NW, int NS>   // waves per row; last-layer tiles per wave
 __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     constexpr int NC = NW > 2 ? 2 : 1;   // 16-lane chunks of a conditioner's inputs (x_dim <= 16 NW)
     constexpr int NT = 64 * NW;
@@ -354,13 +381,14 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
         for (int t = 0; t < PM; ++t) { const int i = ci0 + t < D ? ci0 + t : D - 1; wcol[t] = Mt[(size_t)i * D + jl]; }
     };
     float wcol[PM], an_s, an_t;
-    SplrTrunkRows<NC> tw;
-    SplrLast<NW> lw;
-    SplrTrunkCols tc;
+    SplrTrunkF<NC> tw;
+    SplrLastW<NW, NS> lw;
+    SplrTrunkB<NC> bw;
+    const int lk = lane >> 4;
     load_col(a.wmat, wcol);
     an_s = a.w[ts.p_s + jl]; an_t = a.w[ts.p_t + jl];
-    tw.load(a.w + ts.p_f[0], nl, o16);
-    lw.load(a.w + ts.p_f[0], nl, nu, wv, lane, true);
+    tw.load(a.w + ts.p_f[0], nl, o16, lk);
+    lw.load(a.w + ts.p_f[0], nl, nu, wv, o16, lk, item, k, true);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
     if (stop_flag) return;   // (uniform over the workgroup, in front of its first barrier)
     splr_barrier();
@@ -415,51 +443,53 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
             const int ci = 2 * b + c;
             const int nin = c ? nu : nl, nout = c ? nl : nu, idoff = c ? nl : 0, troff = c ? 0 : nl;
             const int nrows = SPL_P * nout;
-            const float uL = lane < nin ? xrow[idoff + lane] : 0.f;
+            // trunk (networks.py:393-409): Linear LReLU x3 on the matrix cores, every wave the same
+            f32x4 ub[NC];
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                const int i = 16 * t + 4 * lk;
+                ub[t] = (f32x4){i + 0 < nin ? xrow[idoff + i + 0] : 0.f, i + 1 < nin ? xrow[idoff + i + 1] : 0.f,
+                                i + 2 < nin ? xrow[idoff + i + 2] : 0.f, i + 3 < nin ? xrow[idoff + i + 3] : 0.f};
+            }
+            const float uL = lane < nin ? xrow[idoff + lane] : 0.f;   // (for the staging only)
             R_STAMP(1)
-            // trunk (networks.py:393-409): Linear LReLU x3, every wave the same
-            float h = tw.b0;
+            f32x4 acc = tw.b0;
 #pragma unroll
-            for (int i = 0; i < 16 * NC; ++i) h = fmaf(i < nin ? splr_comp(tw.w0[i >> 2], i & 3) : 0.f, splr_rl(uL, i), h);
-            const float h0 = splr_lrelu(h);
-            h = tw.b1;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) h = fmaf(splr_comp(tw.w1[i >> 2], i & 3), splr_rl(h0, i), h);
-            const float h1 = splr_lrelu(h);
-            h = tw.b2;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) h = fmaf(splr_comp(tw.w2[i >> 2], i & 3), splr_rl(h1, i), h);
-            const float h2 = splr_lrelu(h);
-            // the next coupling's trunk rows into the same registers; at the turn, the last coupling's columns for the way back
-            if (ci + 1 < 2 * B) tw.load(net_of(ci + 1), c ? nl : nu, o16);
-            else if (!vrow) tc.load(net_of(ci), nin, o16, lane);
-            if (wv == 0 && !vrow) {
+            for (int t = 0; t < NC; ++t) acc = splr_mv16(tw.t0[t], ub[t], acc);
+            const f32x4 h0 = splr_lrelu4(acc);
+            const f32x4 h1 = splr_lrelu4(splr_mv16(tw.t1, h0, tw.b1));
+            const f32x4 h2 = splr_lrelu4(splr_mv16(tw.t2, h1, tw.b2));
+            // the next coupling's trunk into the same registers
+            if (ci + 1 < 2 * B) tw.load(net_of(ci + 1), c ? nl : nu, o16, lk);
+            if (wv == 0 && !vrow) {   // staged for the contractions, kept for the way back: group lk's four units, 16 bytes
                 float *Tr = T0 + ((size_t)ci * rc + row) * SPLR_TROW;
-                if (lane < 16) { Tr[lane] = h0; Tr[16 + lane] = h1; Tr[32 + lane] = h2; trk[ci * 48 + lane] = h0; trk[ci * 48 + 16 + lane] = h1; trk[ci * 48 + 32 + lane] = h2; }
+                if (o16 == 0) {
+                    *reinterpret_cast<f32x4 *>(Tr + 4 * lk) = h0; *reinterpret_cast<f32x4 *>(Tr + 16 + 4 * lk) = h1; *reinterpret_cast<f32x4 *>(Tr + 32 + 4 * lk) = h2;
+                    *reinterpret_cast<f32x4 *>(trk + ci * 48 + 4 * lk) = h0;
+                    *reinterpret_cast<f32x4 *>(trk + ci * 48 + 16 + 4 * lk) = h1;
+                    *reinterpret_cast<f32x4 *>(trk + ci * 48 + 32 + 4 * lk) = h2;
+                }
                 Tr[96 + lane] = uL;
             }
             R_STAMP(2)
-            // last layer, four lanes per output row
-            float hq[4];
+            // last layer: tile st of this wave, sixteen output rows a product
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hq[e] = __shfl(h2, 4 * q4 + e);
-#pragma unroll
-            for (int st = 0; st < SPLR_NS; ++st) {
-                const int o = 16 * (wv + NW * st) + (lane >> 2);
-                float p = lw.w3[st].x * hq[0];
-                p = fmaf(lw.w3[st].y, hq[1], p); p = fmaf(lw.w3[st].z, hq[2], p); p = fmaf(lw.w3[st].w, hq[3], p);
-                p += splr_dpp<0xB1>(p);
-                p += splr_dpp<0x4E>(p);
-                if (q4 == 0 && o < nrows) rawbuf[o] = p + lw.b3[st];
+            for (int st = 0; st < NS; ++st) {
+                const int o = 16 * (wv + NW * st);
+                if (o < nrows) {
+                    const f32x4 r = splr_mv16(lw.l3[st], h2, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    if (o16 == 0) *reinterpret_cast<f32x4 *>(rawbuf + o + 4 * lk) = r;
+                }
             }
-            if (ci + 1 < 2 * B) lw.load(net_of(ci + 1), c ? nl : nu, c ? nu : nl, wv, lane, true);   // (the last coupling's stay: the way back starts there)
+            const float e0 = lw.e0, e1 = lw.e1, e2 = lw.e2;
+            if (ci + 1 < 2 * B) lw.load(net_of(ci + 1), c ? nl : nu, c ? nu : nl, wv, o16, lk, item, k, true);   // (the last coupling's stay: the way back starts there)
             splr_barrier();
             R_STAMP(3)
             // the spline, eight lanes per item (networks.py:583-587, :425-556)
             {
                 const bool active = item < nout;
                 const int jb = SPL_P * (active ? item : 0);
-                const float rw = rawbuf[jb + k], rh = rawbuf[jb + 8 + k], rd = rawbuf[jb + 16 + (k < 7 ? k : 6)];
+                const float rw = rawbuf[jb + k] + e0, rh = rawbuf[jb + 8 + k] + e1, rd = rawbuf[jb + 16 + (k < 7 ? k : 6)] + e2;
                 const float x = xrow[troff + (active ? item : 0)];
                 SplrKeep kp;
                 const float y = splr_eval(rw, rh, rd, x, s.tail, k, active, ld, kp);
@@ -476,9 +506,10 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     }
     // log_probs (networks.py:71-76): base density of z + the log-determinants
     {
-        if (!vrow) {   // the way back opens with the last block: its W^T column and ActNorm scale
+        if (!vrow) {   // the way back opens with the last block: its W^T column and ActNorm scale, its second coupling's transposed weights
             load_col(a.wmatT + (size_t)(B - 1) * D * D, wcol);
             an_s = a.w[(size_t)(B - 1) * s.blk_params + ts.p_s + jl];
+            bw.load(net_of(2 * B - 1), nu, o16, lk);
         }
         float v = lane < D ? base_E(xrow[jl], s.base_beta) : 0.f;
 #pragma unroll
@@ -527,50 +558,56 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
             }
             splr_barrier();
             R_STAMP(6)
-            // dLoss/d(raw) of the row: staged for the contraction over rows; dLoss/dh2 = W3^T g, four lanes per row of W3
+            // dLoss/d(raw) of the row: staged for the contraction over rows; dLoss/dh2 = W3^T g: this lane's row of each tile times its
+            // quarter of W3, then the sum over the tile's rows (the 16 columns of the lane's k-group) -- group lk ends with units 4 lk ..
             {
                 float pt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int st = 0; st < SPLR_NS; ++st) {
-                    const int o = 16 * (wv + NW * st) + (lane >> 2);
+                for (int st = 0; st < NS; ++st) {
+                    const int o = 16 * (wv + NW * st) + o16;
                     const float g = o < nrows ? rawbuf[o < nrows ? o : 0] : 0.f;
-                    pt[0] = fmaf(g, lw.w3[st].x, pt[0]); pt[1] = fmaf(g, lw.w3[st].y, pt[1]); pt[2] = fmaf(g, lw.w3[st].z, pt[2]); pt[3] = fmaf(g, lw.w3[st].w, pt[3]);
+                    pt[0] = fmaf(g, lw.l3[st].x, pt[0]); pt[1] = fmaf(g, lw.l3[st].y, pt[1]); pt[2] = fmaf(g, lw.l3[st].z, pt[2]); pt[3] = fmaf(g, lw.l3[st].w, pt[3]);
                 }
-                if (ci > 0) lw.load(net_of(ci - 1), c ? nl : nu, c ? nu : nl, wv, lane, false);   // the coupling before, into the same registers
+                if (ci > 0) lw.load(net_of(ci - 1), c ? nl : nu, c ? nu : nl, wv, o16, lk, item, k, false);   // the coupling before, into the same registers
                 float *Gr = G0 + ((size_t)ci * rc + row) * a.lay.grow;
                 for (int o = tid; o < nrows; o += NT) Gr[o] = rawbuf[o];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    pt[e] += splr_dpp<0x124>(pt[e]);   // row_ror:4
-                    pt[e] += splr_dpp<0x128>(pt[e]);   // row_ror:8
+                    pt[e] += splr_dpp<0x128>(pt[e]);   // row_ror 8, 4, 2, 1: every lane of the row ends with the row's sum
+                    pt[e] += splr_dpp<0x124>(pt[e]);
+                    pt[e] += splr_dpp<0x122>(pt[e]);
+                    pt[e] += splr_dpp<0x121>(pt[e]);
                 }
-                if (o16 < 4) *reinterpret_cast<f32x4 *>(hred + (wv * 4 + (lane >> 4)) * 16 + 4 * o16) = (f32x4){pt[0], pt[1], pt[2], pt[3]};
+                if (o16 == 0) *reinterpret_cast<f32x4 *>(hred + wv * 16 + 4 * lk) = (f32x4){pt[0], pt[1], pt[2], pt[3]};
             }
             splr_barrier();
             R_STAMP(7)
-            // trunk, reverse (every wave the same)
+            // trunk, reverse (every wave the same): d = W^T d on the matrix cores
             {
-                float dh = 0.f;
+                f32x4 dh = *reinterpret_cast<const f32x4 *>(hred + 4 * lk);
 #pragma unroll
-                for (int e = 0; e < 4 * NW; ++e) dh += hred[e * 16 + o16];
-                const float h0 = trk[ci * 48 + o16], h1 = trk[ci * 48 + 16 + o16], h2 = trk[ci * 48 + 32 + o16];
-                const float d2 = dh * splr_slope(h2);
-                dh = 0.f;
+                for (int w = 1; w < NW; ++w) dh = dh + *reinterpret_cast<const f32x4 *>(hred + w * 16 + 4 * lk);
+                const f32x4 h0 = *reinterpret_cast<const f32x4 *>(trk + ci * 48 + 4 * lk), h1 = *reinterpret_cast<const f32x4 *>(trk + ci * 48 + 16 + 4 * lk),
+                            h2 = *reinterpret_cast<const f32x4 *>(trk + ci * 48 + 32 + 4 * lk);
+                const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 d2 = splr_slope4(dh, h2);
+                const f32x4 d1 = splr_slope4(splr_mv16((f32x4){bw.c2[0], bw.c2[1], bw.c2[2], bw.c2[3]}, d2, z4), h1);
+                const f32x4 d0 = splr_slope4(splr_mv16((f32x4){bw.c1[0], bw.c1[1], bw.c1[2], bw.c1[3]}, d1, z4), h0);
+                f32x4 du[NC];
 #pragma unroll
-                for (int o = 0; o < 16; ++o) dh = fmaf(tc.w2c[o], splr_rl(d2, o), dh);
-                const float d1 = dh * splr_slope(h1);
-                dh = 0.f;
-#pragma unroll
-                for (int o = 0; o < 16; ++o) dh = fmaf(tc.w1c[o], splr_rl(d1, o), dh);
-                const float d0 = dh * splr_slope(h0);
-                float du = 0.f;
-#pragma unroll
-                for (int o = 0; o < 16; ++o) du = fmaf(tc.w0c[o], splr_rl(d0, o), du);
-                if (ci > 0) tc.load(net_of(ci - 1), c ? nl : nu, o16, lane);
-                if (wv == 0) {
+                for (int t = 0; t < NC; ++t) du[t] = splr_mv16((f32x4){bw.c0[t][0], bw.c0[t][1], bw.c0[t][2], bw.c0[t][3]}, d0, z4);   // inputs 16 t + 4 lk + r
+                if (ci > 0) bw.load(net_of(ci - 1), c ? nl : nu, o16, lk);
+                if (wv == 0 && o16 == 0) {
                     float *Tr = T0 + ((size_t)ci * rc + row) * SPLR_TROW;
-                    if (lane < 16) { Tr[48 + lane] = d0; Tr[64 + lane] = d1; Tr[80 + lane] = d2; }
-                    if (lane < nin) grow[idoff + lane] += du;
+                    *reinterpret_cast<f32x4 *>(Tr + 48 + 4 * lk) = d0; *reinterpret_cast<f32x4 *>(Tr + 64 + 4 * lk) = d1; *reinterpret_cast<f32x4 *>(Tr + 80 + 4 * lk) = d2;
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) {
+                        const int i = 16 * t + 4 * lk;
+                        if (i + 0 < nin) grow[idoff + i + 0] += du[t].x;
+                        if (i + 1 < nin) grow[idoff + i + 1] += du[t].y;
+                        if (i + 2 < nin) grow[idoff + i + 2] += du[t].z;
+                        if (i + 3 < nin) grow[idoff + i + 3] += du[t].w;
+                    }
                 }
             }
             splr_barrier();
@@ -1069,19 +1106,18 @@ hipError_t spline_rows_grad(nnest_spline *h, const SplTrainShape &ts, const SplR
     const size_t ldsb = rows_grad_lds(h->s, r->lay);
     const int NW = rows_waves(h->s), grid = bt.M + bt.Mv;
     hipError_t e = hipSuccess;
-    if (NW == 1) {
-        static bool attr1 = false;
-        if (!attr1) { e = hipFuncSetAttribute((const void *)splr_grad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
-        if (e == hipSuccess) hipLaunchKernelGGL(splr_grad_kernel<1>, dim3(grid), dim3(64), ldsb, st, a);
-    } else if (NW == 2) {
-        static bool attr2 = false;
-        if (!attr2) { e = hipFuncSetAttribute((const void *)splr_grad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
-        if (e == hipSuccess) hipLaunchKernelGGL(splr_grad_kernel<2>, dim3(grid), dim3(128), ldsb, st, a);
-    } else {
-        static bool attr4 = false;
-        if (!attr4) { e = hipFuncSetAttribute((const void *)splr_grad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr4 = true; }
-        if (e == hipSuccess) hipLaunchKernelGGL(splr_grad_kernel<4>, dim3(grid), dim3(256), ldsb, st, a);
+    const int nmax = h->s.nl > h->s.nu ? h->s.nl : h->s.nu, tiles = (SPL_P * nmax + 15) / 16, ns = (tiles + NW - 1) / NW;
+#define SPLR_LAUNCH(NWv, NSv)                                                                                                              \
+    {                                                                                                                                      \
+        static bool attr = false;                                                                                                          \
+        if (!attr) { e = hipFuncSetAttribute((const void *)splr_grad_kernel<NWv, NSv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        if (e == hipSuccess) hipLaunchKernelGGL((splr_grad_kernel<NWv, NSv>), dim3(grid), dim3(64 * NWv), ldsb, st, a);                    \
     }
+    if (NW == 1) SPLR_LAUNCH(1, 12)
+    else if (NW == 2) SPLR_LAUNCH(2, 12)
+    else if (ns <= 9) SPLR_LAUNCH(4, 9)
+    else SPLR_LAUNCH(4, 12)
+#undef SPLR_LAUNCH
     return e != hipSuccess ? e : hipGetLastError();
 }
 
