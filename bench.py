@@ -656,7 +656,9 @@ def main():
                 tf = ((C - nv) * 3 + nv) * sp_flops   # forward + backward (2 x) over the training rows, forward over the validation rows
                 out['spline_flow']['train_roofline'] = {'bound': 'mfma', 'flops_per_unit': tf, 'unit_is': 'epoch', 'unit': 'TFLOP/s',
                                                         'peak': FP32_PEAK_TFLOPS, 'achieved': tf / (best * 1e-3) / 1e12,
-                                                        'frac': tf / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 'kernel': 'spl_grad_kernel + spl_update_kernel',
+                                                        'frac': tf / (best * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                                        'kernel': 'splr_grad_kernel + splr_update_kernel' if sp.train_form_for(100) == 'rows' else 'spl_grad_kernel + spl_update_kernel',
+                                                        'form': sp.train_form_for(100),   # (asked of the library: nnest_spline_train_form)
                                                         'profile': 'profiles/r06/spline_train_kernel_stats.csv'}
         if world == 1 and dist is None and not args.bare and args.config == 2:
             # the slice proposal in latent space (north_star "slice/MH"): build-defined, the reference has none --

@@ -339,9 +339,14 @@ int nnest_spline_actnorm_init(nnest_spline_t *spl, const float *x_dev, int N, vo
 /* loss = -mean(log_probs(x)) and its gradient wrt the packed weights (loss.backward(), trainer.py:394-400) */
 int nnest_spline_loss_grad(nnest_spline_t *spl, const float *x_dev, int M, float *grad_dev, float *loss_dev, void *stream);
 /* Trainer.train's epoch loop (trainer.py:198-241) as nnest_nvp_train, except that the loop is driven from the host
- * (six small launches per minibatch, one read-back per epoch): losses_host [max_epochs,2] and result_host are HOST
+ * (two launches per minibatch, the epoch's books kept on the device): losses_host [max_epochs,2] and result_host are HOST
  * pointers, the best-validation weights are restored on return and the call synchronises `stream`.  The Adam moments
- * persist across calls like torch.optim.Adam's state. */
+ * persist across calls like torch.optim.Adam's state.
+ * nnest_spline_train_form (added within ABI 15): the form a minibatch of `batch` rows runs in -- 1: one row per workgroup, the
+ * evaluation on eight lanes per item, weight gradients contracted over the rows (nnest_spline_rows.hip: hidden_dim 16, x_dim <= 64,
+ * batch <= 128); 0: sixteen / eight rows per workgroup of four waves (nnest_spline_train.hip).  Both follow the same reference
+ * arithmetic; they agree to rounding, not to the bit.  NNEST_SPL_ROWS=0 in the environment pins form 0. */
+int nnest_spline_train_form(const nnest_spline_t *spl, int batch);
 /* the spline flow as one stage of a composite model (FastSlowSpline, networks.py:718-731): as nnest_nvp_vjp / nnest_nvp_adam_step */
 int nnest_spline_vjp(nnest_spline_t *spl, const float *x_dev, const float *gz_dev, float gld, int M, float *grad_dev, float *gx_dev,
                      void *stream);

@@ -111,6 +111,7 @@ SIGNATURES = {
     'nnest_mh_sync_words': [_i],
     'nnest_mh_form_for': [_vp, _i, _i],
     'nnest_spline_mh_form_for': [_vp, _i, _i],
+    'nnest_spline_train_form': [_vp, _i],
     'nnest_spline_forward': [_vp, _vp, _vp, _vp, _i, _vp],
     'nnest_spline_inverse': [_vp, _vp, _vp, _vp, _i, _vp],
     'nnest_spline_log_probs': [_vp, _vp, _vp, _i, _vp],

@@ -658,8 +658,9 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
     // The early-stopping flag is REQUESTED here and looked at behind the prologue's loads (the first thing with a side effect
     // outside the workgroup comes later): as the kernel's first statement it was a cold round trip to memory of its own in front
     // of every launch (round 6).  The flag was written by an earlier launch: every wave reads the same value.
-    int stop_flag = 0;
-    if (a.stop) asm volatile("global_load_dword %0, %1, off" : "=v"(stop_flag) : "v"(a.stop) : "memory");
+    // (a plain volatile load: the compiler's own wait sits at the first use.  As an inline-asm load waited for later, the register
+    // allocator was free to copy the result BEFORE the data was there -- seen in nnest_spline_rows.hip)
+    int stop_flag = a.stop ? *reinterpret_cast<const volatile int *>(a.stop) : 0;
     const SplTrainShape &ts = a.ts;
     const SplineShape &s = ts.s;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, w = lane & 15, g = lane >> 4, tile = blockIdx.x, lane_k = lane;
@@ -782,7 +783,7 @@ __global__ void __launch_bounds__(64 * SPL_TEAM) spl_grad_kernel(SplGradArgs a) 
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink), "+v"(stop_flag) : : "memory");  // the warm-up's target register is free again only now
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");  // the warm-up's target register is free again only now
     if (stop_flag) return;   // (uniform over the workgroup, in front of its first barrier)
     if constexpr (LDS_OK) {
         if (lds_heads) spl_team_barrier();   // (the ActNorm vectors are read by every wave)
@@ -1318,9 +1319,10 @@ template <int NTh, int NH>
 __global__ void __launch_bounds__(1024) spl_update_kernel(SplUpdateArgs a) {
     // (the early-stopping flag: requested now, looked at behind each role's first batch of loads and in front of its first store --
     // see spl_grad_kernel)
-    int stop_flag = 0;
-    if (a.stop) asm volatile("global_load_dword %0, %1, off" : "=v"(stop_flag) : "v"(a.stop) : "memory");
-#define SPL_STOP_CHECK() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(stop_flag) : : "memory"); if (stop_flag) return; }
+    // (a plain volatile load: the compiler's own wait sits at the first use.  As an inline-asm load waited for later, the register
+    // allocator was free to copy the result BEFORE the data was there -- seen in nnest_spline_rows.hip)
+    int stop_flag = a.stop ? *reinterpret_cast<const volatile int *>(a.stop) : 0;
+#define SPL_STOP_CHECK() { if (stop_flag) return; }
     extern __shared__ float ulds[];
     const SplTrainShape &ts = a.ts;
     const SplineShape &s = ts.s;
@@ -1980,6 +1982,8 @@ int nnest_spline_adam_step(nnest_spline_t *h, const float *grad_dev, float lr, f
     SHIP_TRY(hipGetLastError());
     return sync_to_host(h, st);
 }
+
+int nnest_spline_train_form(const nnest_spline_t *h, int batch) { return (h && spline_rows_eligible(h->s, batch)) ? 1 : 0; }
 
 int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, const float *xvalid_dev, int n_valid,
                        const int *perm_dev, const float *noise_dev, uint64_t seed, float jitter, int batch, int max_epochs,

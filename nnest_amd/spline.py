@@ -69,6 +69,11 @@ class HipSpline(_PaddedVectors, _HipFlow):
         f = self._lib.nnest_spline_mh_form_for(self._h, int(C), _lib.mh_flags(dynamic, False, lag, None, 0))
         return self.SPLINE_MH_FORMS.get(f)
 
+    def train_form_for(self, batch):
+        """'rows' (one row of the minibatch per workgroup, nnest_spline_rows.hip) or 'tiles' (nnest_spline_train.hip): what a minibatch
+        of `batch` rows runs in (nnest_spline_train_form)"""
+        return 'rows' if self._lib.nnest_spline_train_form(self._h, int(batch)) == 1 else 'tiles'
+
     def __del__(self):
         try:
             if getattr(self, '_h', None) is not None and self._h.value:

@@ -318,6 +318,66 @@ np.savez(sys.argv[1], x=res['x'].cpu().numpy(), n_accept=res['n_accept'].cpu().n
 
 
 # ---- training -----------------------------------------------------------------------------------------------------
+def test_rows_form_of_the_training_step_against_the_tile_form(hip):
+    """the same gradient and the same training call through the two forms of the training step (nnest_spline_train_form: 'rows' -- one
+    row of the minibatch per workgroup, nnest_spline_rows.hip -- where the shape allows it; NNEST_SPL_ROWS=0 pins the tile form; read
+    once per process, so each form runs in a process of its own).  Same arithmetic per row, other summation orders (the rows form
+    contracts the weight gradients over the rows on the matrix cores): gradients agree to rounding, the loss trajectories of a short
+    call stay together.  The tests below drive the rows form at hidden_dim 16, x_dim <= 64;
+    test_tile_form_of_the_training_step_vs_the_reference_fixtures holds the tile form to the same fixtures."""
+    import subprocess
+    import sys
+    import tempfile
+    code = '''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from nnest_amd.spline import HipSpline
+out = {}
+for D in (2, 5, 50):
+    g = np.load(%r %% D)
+    sp = HipSpline(D, int(g['H']), int(g['B']), int(g['K']), float(g['tail']))
+    sp.load_packed(g['w_trained'], g['P']); sp.data_dep_init_done = True
+    rng = np.random.RandomState(D)
+    live = rng.uniform(-0.8, 0.8, size=(500, D))
+    loss, grad = sp.loss_grad(live[:100])
+    perms = torch.stack([torch.randperm(450, generator=torch.Generator().manual_seed(e)) for e in range(6)]).int()
+    res = sp.train_epochs(live[50:], live[:50], perms, None, seed=3, jitter=0.01, batch=100, max_epochs=6, patience=50)
+    out['form_%%d' %% D] = np.array(sp.train_form_for(100))
+    out['loss_%%d' %% D] = loss.cpu().numpy(); out['grad_%%d' %% D] = grad.cpu().numpy()
+    out['traj_%%d' %% D] = res['losses'].numpy()[:res['epochs_run']]
+    out['w_%%d' %% D] = sp.store_packed()
+np.savez(sys.argv[1], **out)
+''' % (ROOT, os.path.join(G, 'spline_d%d.npz'))
+    got = {}
+    for form, env in (('rows', {}), ('tiles', {'NNEST_SPL_ROWS': '0'})):
+        with tempfile.NamedTemporaryFile(suffix='.npz') as f:
+            subprocess.run([sys.executable, '-c', code, f.name], check=True, env=dict(os.environ, **env), timeout=600)
+            got[form] = dict(np.load(f.name))
+    for D in (2, 5, 50):
+        a, b = got['rows'], got['tiles']
+        assert str(a['form_%d' % D]) == 'rows' and str(b['form_%d' % D]) == 'tiles'
+        assert rel(a['loss_%d' % D], b['loss_%d' % D]) < 1e-5
+        assert rel(a['grad_%d' % D], b['grad_%d' % D]) < 2e-5, D
+        assert not np.array_equal(a['grad_%d' % D], b['grad_%d' % D])     # (two kernels, not one)
+        np.testing.assert_allclose(a['traj_%d' % D], b['traj_%d' % D], rtol=2e-3)
+        assert rel(a['w_%d' % D], b['w_%d' % D]) < 2e-2
+
+
+def test_tile_form_of_the_training_step_vs_the_reference_fixtures(hip):
+    """the training tests of this file once more with NNEST_SPL_ROWS=0 (the tile form, nnest_spline_train.hip, at the shapes where the
+    library would pick the rows form): autograd gradients, the reference's Adam trajectory, one step = gradient + Adam, early stopping"""
+    import subprocess
+    import sys
+    if os.environ.get('NNEST_SPL_ROWS') == '0':
+        pytest.skip('already inside the tile-form run')
+    k = ('test_loss_and_gradient_vs_reference_autograd or test_adam_steps_vs_reference_trajectory or test_one_training_step_is_gradient_plus_adam '
+         'or test_training_improves_and_is_reproducible or test_spline_training_stops_when_patience_runs_out')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', k, '-p', 'no:cacheprovider'],
+                       env=dict(os.environ, NNEST_SPL_ROWS='0'), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.parametrize('path', FILES, ids=IDS)
 def test_actnorm_data_dependent_init_vs_reference(hip, path):
     """networks.py:698-705: the first forward batch of a fresh model sets s = -log std, t = -mean(x e^s) per block"""
