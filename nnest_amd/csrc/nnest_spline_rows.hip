@@ -475,11 +475,11 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
             // last layer: tile st of this wave, sixteen output rows a product
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
+                // (no branch around a tile: the products of the wave's tiles are independent and should interleave; tiles past the
+                // outputs multiply clamped rows and are not stored)
                 const int o = 16 * (wv + NW * st);
-                if (o < nrows) {
-                    const f32x4 r = splr_mv16(lw.l3[st], h2, (f32x4){0.f, 0.f, 0.f, 0.f});
-                    if (o16 == 0) *reinterpret_cast<f32x4 *>(rawbuf + o + 4 * lk) = r;
-                }
+                const f32x4 r = splr_mv16(lw.l3[st], h2, (f32x4){0.f, 0.f, 0.f, 0.f});
+                if (o16 == 0 && o < nrows) *reinterpret_cast<f32x4 *>(rawbuf + o + 4 * lk) = r;
             }
             const float e0 = lw.e0, e1 = lw.e1, e2 = lw.e2;
             if (ci + 1 < 2 * B) lw.load(net_of(ci + 1), c ? nl : nu, c ? nu : nl, wv, o16, lk, item, k, true);   // (the last coupling's stay: the way back starts there)
