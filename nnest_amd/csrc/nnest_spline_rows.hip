@@ -1109,8 +1109,9 @@ hipError_t spline_rows_grad(nnest_spline *h, const SplTrainShape &ts, const SplR
     const int nmax = h->s.nl > h->s.nu ? h->s.nl : h->s.nu, tiles = (SPL_P * nmax + 15) / 16, ns = (tiles + NW - 1) / NW;
 #define SPLR_LAUNCH(NWv, NSv)                                                                                                              \
     {                                                                                                                                      \
-        static bool attr = false;                                                                                                          \
-        if (!attr) { e = hipFuncSetAttribute((const void *)splr_grad_kernel<NWv, NSv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        static bool attr[64] = {false};   /* (per device: the attribute belongs to the device's copy of the function) */                  \
+        const int dv = h->device & 63;                                                                                                     \
+        if (!attr[dv]) { e = hipFuncSetAttribute((const void *)splr_grad_kernel<NWv, NSv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dv] = true; } \
         if (e == hipSuccess) hipLaunchKernelGGL((splr_grad_kernel<NWv, NSv>), dim3(grid), dim3(64 * NWv), ldsb, st, a);                    \
     }
     if (NW == 1) SPLR_LAUNCH(1, 12)
@@ -1132,12 +1133,12 @@ hipError_t spline_rows_update(nnest_spline *h, const SplTrainShape &ts, const Sp
     a.stop = u.stop; a.grad_out = u.grad_out; a.gwsum_out = u.gwsum_out;
     a.n_jobs = s.B * (splr_jobs_of(s, 0) + splr_jobs_of(s, 1));
     const size_t ldsb = ((size_t)ts.p_f[0] + 5 * 64 * 65 + 64 + 2048) * sizeof(float) + 64 * sizeof(int);
-    static bool attr = false;
+    static bool attr[64] = {false};   // (per device)
     hipError_t e = hipSuccess;
-    if (!attr) {
+    if (!attr[h->device & 63]) {
         e = hipFuncSetAttribute((const void *)splr_update_kernel<26>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)splr_update_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
+        attr[h->device & 63] = true;
     }
     if (e != hipSuccess) return e;
     const dim3 grid(s.B + (a.n_jobs + 1 + 15) / 16);
