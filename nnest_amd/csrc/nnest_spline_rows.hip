@@ -632,9 +632,7 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     if (blockIdx.x == 0 && tid == 0)
         printf("splr_update head (the launch before): loads issued %.0f | old head to LDS %.0f | contraction + wait %.0f | LU grads + Adam %.0f | W, W^T %.0f | logdet %.0f; job 97: %.0f (x10 ns)\n",
                a.ldc[4], a.ldc[5], a.ldc[6], a.ldc[7], a.ldc[8], a.ldc[9], a.ldc[10]);
-    if (blockIdx.x == 0 && tid == 0)
-        printf("   phase 3: Adam-state loads issued %.0f | G %.0f | old head staged %.0f | barrier %.0f ;  LU: ActNorm sums %.0f | first product %.0f | both tiles' steps %.0f | ActNorm step %.0f | barrier %.0f\n",
-               a.ldc[11], a.ldc[12], a.ldc[13], a.ldc[14], a.ldc[15], a.ldc[16], a.ldc[17], a.ldc[18], a.ldc[19]);
+    if (blockIdx.x == 0 && tid == 0) printf("   (LU products up to their barrier: %.0f of the LU + Adam phase)\n", a.ldc[11]);
     if (blockIdx.x == 0 && lane == 0)
         printf("splr_grad wave %d: total %lld | fwd: conv %lld, loads waited %lld, trunk %lld, last layer %lld, eval %lld | logp %lld | bwd: eval %lld, W3^T g %lld, trunk %lld, conv %lld (x10 ns)\n",
                wv, wall_clock64() - st_0, st_t[0], st_t[1], st_t[2], st_t[3], st_t[4], st_t[5], st_t[6], st_t[7], st_t[8], st_t[9]);
@@ -792,13 +790,20 @@ __global__ void __launch_bounds__(1024) splr_update_kernel(SplRowsUpdArgs a) {
 #define F_STAMP(i)
 #endif
     constexpr int DP = 65, MAT = 64 * DP;
-    float *hold = ulds, *G = ulds + nhead, *Um = G + MAT, *Lm = Um + MAT, *UmN = Lm + MAT, *LmN = UmN + MAT, *snew = LmN + MAT;
-    int *spi = reinterpret_cast<int *>(snew + 64);
+    // LDS: five 64 x 64 operand matrices at stride 65 (zero-padded; the stride keeps a column walk off one bank): G = the row-permuted
+    // dLoss/dW, Um = triu(U,1) + diag(S) and Lm = tril(L,-1) + I of the old values; UmN / LmN first take the two products' results
+    // (dLoss/dUm, dLoss/dL), then the new values.
+    float *G = ulds, *Um = G + MAT, *Lm = Um + MAT, *UmN = Lm + MAT, *LmN = UmN + MAT, *snew = LmN + MAT, *sact = snew + 64, *tval = sact + 64;
+    int *spi = reinterpret_cast<int *>(tval + 64);
     float *anp = reinterpret_cast<float *>(spi + 64);   // [2][4][64]: ActNorm partial sums, one per column tile of the contraction
+    (void)nhead;
     const int nwv = (int)(blockDim.x >> 6), nt = (D + 15) >> 4, li = lane & 15, lk = lane >> 4;
     const size_t rc = (size_t)a.lay.rows_cap;
     const float *Va = a.stg + a.lay.off_V + (size_t)(3 * b + 0) * rc * SPLR_VROW, *Vgc = Va + rc * SPLR_VROW;
-    // Round 1 (what other XCDs' gradient workgroups wrote: the long round trip): the contraction's operands and the ActNorm sums' rows
+    // ---- every global load of the head, one batch: the contraction's operands (what other XCDs' gradient workgroups wrote: the long
+    // round trip), this lane's elements of the old W, and the head's parameters with their Adam state in rows of 64 columns -- thread
+    // (row = tid >> 6 + 16 u, col = lane) owns L[row][col] and U[row][col]; the thread on the diagonal owns S[col] too; thread tid < 2 D
+    // owns ActNorm's s / t.  Coalesced, no division, and the Adam step below runs in the same layout.
     float av[STEPS], bv[STEPS];
     const bool ctile = wave < nt * nt;
     const int cti = splr_div_small(wave, nt), ctj = wave - cti * nt;
@@ -819,19 +824,21 @@ __global__ void __launch_bounds__(1024) splr_update_kernel(SplRowsUpdArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const int i = 16 * cti + 4 * lk + r; prow[r] = (ctile && i < D) ? a.pi[b * D + i] : -1; }
     for (int i = tid; i < D; i += blockDim.x) spi[i] = a.pi[b * D + i];
-    // ... and this block's own head and Adam state, in the same batch (a second batch behind the contraction was a second cold round trip:
-    // the L2 does not keep the last launch's lines); rows of 64 columns, no division
-    const int hrow = tid >> 6, hcol = lane;          // 16 rows x 64 columns per pass; x_dim <= 64: four passes per matrix
-    float hL[4], hU[4], hS = 0.f, hst = 0.f;
+    const int hrow = tid >> 6, hcol = lane;
+    float wL[4], wU[4], mL[4], mU[4], vL[4], vU[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int row = hrow + 16 * u, ok = row < D && hcol < D, o = ok ? row * D + hcol : 0;
-        hL[u] = a.w[base + ts.p_L + o];
-        hU[u] = a.w[base + ts.p_U + o];
+        const int row = hrow + 16 * u, o = (row < D && hcol < D) ? row * D + hcol : 0;
+        wL[u] = a.w[base + ts.p_L + o]; wU[u] = a.w[base + ts.p_U + o];
+        mL[u] = stepping ? a.m[base + ts.p_L + o] : 0.f; mU[u] = stepping ? a.m[base + ts.p_U + o] : 0.f;
+        vL[u] = stepping ? a.v[base + ts.p_L + o] : 0.f; vU[u] = stepping ? a.v[base + ts.p_U + o] : 0.f;
     }
-    if (tid < D) hS = a.w[base + ts.p_S + tid];
+    const bool diag = (lane & 15) == hrow && hcol < D;   // exactly one u has row == col = lane: u = lane >> 4
+    const int sidx = base + ts.p_S + (diag ? hcol : 0);
+    float wS = a.w[sidx], mS = stepping ? a.m[sidx] : 0.f, vS = stepping ? a.v[sidx] : 0.f;
     const bool an = tid < ts.p_L;
-    if (an) hst = a.w[base + tid];
+    const int aidx = base + (an ? tid : 0);
+    float wA = a.w[aidx], mA = stepping ? a.m[aidx] : 0.f, vA = stepping ? a.v[aidx] : 0.f;
     __builtin_amdgcn_sched_barrier(0);
     U_STAMP(1)
     for (int idx = tid; idx < MAT; idx += blockDim.x) {  // the padding of the five matrices (no operand yet: the loads are in flight)
@@ -852,9 +859,10 @@ __global__ void __launch_bounds__(1024) splr_update_kernel(SplRowsUpdArgs a) {
     csum += __shfl_xor(csum, 32);   // column 16 ctj + li of g_c, summed over the rows
     if (ctile) {
         const float cv[4] = {cacc.x, cacc.y, cacc.z, cacc.w};
+        const int j = 16 * ctj + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int d = 16 * cti + 4 * lk + r, j = 16 * ctj + li;
+            const int d = 16 * cti + 4 * lk + r;
             const bool in = d < D && j < D;
             float p0 = in ? Wt[r] * csum : 0.f, p1 = in ? Wt[r] * cv[r] : 0.f;
             p0 += splr_dpp<0x128>(p0); p1 += splr_dpp<0x128>(p1);   // over the tile's 16 columns (row_ror 8, 4, 2, 1)
@@ -862,59 +870,25 @@ __global__ void __launch_bounds__(1024) splr_update_kernel(SplRowsUpdArgs a) {
             p0 += splr_dpp<0x122>(p0); p1 += splr_dpp<0x122>(p1);
             p0 += splr_dpp<0x121>(p0); p1 += splr_dpp<0x121>(p1);
             if (li == 0 && d < D) { anp[ctj * 64 + d] = p0; anp[256 + ctj * 64 + d] = p1; }
+            // G = dLoss/dW with its rows permuted as P does: G[pi(i)][j]
+            if (prow[r] >= 0 && j < D) {
+                G[prow[r] * DP + j] = cv[r];
+                if (!stepping) a.gwsum_out[(size_t)b * D * D + (size_t)d * D + j] = cv[r];
+            }
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
     U_STAMP(2)
-    // the Adam state of the head's elements: requested now (the operands' registers are free), used behind the barrier and the products
-    int hi[2][5];
-    float hm[2][5], hv[2][5];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int tile = wave + u * nwv;
-        const bool live = tile < 2 * nt * nt, isU = tile >= nt * nt;
-        const int tt = isU ? tile - nt * nt : tile, ti = splr_div_small(tt, nt), tj = tt - ti * nt, col = 16 * tj + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * ti + 4 * lk + r;
-            hi[u][r] = (live && row < D && col < D) ? (isU ? ts.p_U : ts.p_L) + row * D + col : -1;
-        }
-        const int rd = col - 16 * ti - 4 * lk;
-        hi[u][4] = (live && isU && col < D && rd >= 0 && rd < 4) ? ts.p_S + col : -1;
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int ii = hi[u][r] >= 0 ? hi[u][r] : 0;
-            hm[u][r] = stepping ? a.m[base + ii] : 0.f; hv[u][r] = stepping ? a.v[base + ii] : 0.f;
-        }
-    }
-    float an_m = stepping ? a.m[base + (an ? tid : 0)] : 0.f, an_v = stepping ? a.v[base + (an ? tid : 0)] : 0.f;
-    F_STAMP(0)
-    // G = dLoss/dW with its rows permuted as P does: G[pi(i)][j]
-    if (ctile) {
-        const float cv[4] = {cacc.x, cacc.y, cacc.z, cacc.w};
-        const int j = 16 * ctj + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (prow[r] < 0 || j >= D) continue;
-            G[prow[r] * DP + j] = cv[r];
-            if (!stepping) a.gwsum_out[(size_t)b * D * D + (size_t)(16 * cti + 4 * lk + r) * D + j] = cv[r];
-        }
-    }
-    F_STAMP(1)
-    // the old head: L, U (dense operands Lm = tril(L,-1) + I, Um = triu(U,1) + diag(S)), S, and ActNorm's s, t
+    // the old head as dense operands: Lm = tril(L,-1) + I, Um = triu(U,1) + diag(S)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int row = hrow + 16 * u;
         if (row < D && hcol < D) {
-            hold[ts.p_L + row * D + hcol] = hL[u];
-            hold[ts.p_U + row * D + hcol] = hU[u];
-            Lm[row * DP + hcol] = hcol < row ? hL[u] : (hcol == row ? 1.f : 0.f);
-            if (row != hcol) Um[row * DP + hcol] = row < hcol ? hU[u] : 0.f;
+            Lm[row * DP + hcol] = hcol < row ? wL[u] : (hcol == row ? 1.f : 0.f);
+            if (row != hcol) Um[row * DP + hcol] = row < hcol ? wU[u] : 0.f;
         }
     }
-    if (tid < D) { hold[ts.p_S + tid] = hS; Um[tid * (DP + 1)] = hS; }
-    if (an) hold[tid] = hst;
-    F_STAMP(2)
+    if (diag) Um[hcol * (DP + 1)] = wS;
+    if (an && tid >= ts.p_t) tval[tid - ts.p_t] = wA;
     if (stop_flag) return;   // (uniform over the workgroup)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     U_STAMP(3)
@@ -924,56 +898,70 @@ __global__ void __launch_bounds__(1024) splr_update_kernel(SplRowsUpdArgs a) {
         const int d = tid < ts.p_t ? tid : tid - ts.p_t;
         float s0 = 0.f, s1 = 0.f;
         for (int tj = 0; tj < nt; ++tj) { s0 += anp[tj * 64 + d]; s1 += anp[256 + tj * 64 + d]; }
-        an_g = tid < ts.p_t ? s1 - hold[ts.p_t + d] * s0 + a.ldw : s0;
+        an_g = tid < ts.p_t ? s1 - tval[d] * s0 + a.ldw : s0;
         if (!stepping) a.grad_out[base + tid] = an_g;
     }
     if (!stepping) return;
-    F_STAMP(3)
-    const float *Sp = hold + ts.p_S;
-    const int KP = 16 * nt;
+    // dLoss/dL = tril(G Um^T, -1) and dLoss/d(Um) = triu(Lm^T G): two D^3 products on the matrix cores, one 16x16 output tile per wave
+    // and round, left where the new values will go (LmN / UmN)
+    // Only the tiles that hold a kept element are computed (dL: on or below the diagonal, dUm: on or above it -- nt (nt + 1) of the
+    // 2 nt^2), and only the k-steps where the triangular operand is not structurally zero (Um[c][k] = 0 for k < c, Lm[k][c] = 0 for
+    // k < c): the heads are one compute unit's matrix throughput (sixteen waves on four matrix cores), half of these products is zeros.
+    // Live tile q of a triangle, rows first: (ti, tj) with tj <= ti for dL, mirrored for dUm; dealt to the waves longest first.
+    const int KP = 16 * nt, ntri = nt * (nt + 1) / 2;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int tile = wave + u * nwv;
-        if (tile >= 2 * nt * nt) continue;
-        const bool isU = tile >= nt * nt;
-        const int tt = isU ? tile - nt * nt : tile, ti = splr_div_small(tt, nt), tj = tt - ti * nt;
+        if (tile >= 2 * ntri) continue;
+        const bool isU = tile >= ntri;
+        int q = isU ? tile - ntri : tile, ta = 0;
+        while (q > ta) { q -= ta + 1; ++ta; }   // q-th pair (ta, q) with q <= ta
+        const int ti = isU ? q : ta, tj = isU ? ta : q;
         const int i = 16 * ti + li, j = 16 * tj + li;
-        // C[r][c] = sum_k G[r][k] Um[c][k]   |   C[c][j] = sum_k Lm[k][c] G[k][j]
+        // C[r][c] = sum_k G[r][k] Um[c][k] (k >= 16 tj)   |   C[c][j] = sum_k Lm[k][c] G[k][j] (k >= 16 ti)
         const float *pa = isU ? Lm + lk * DP + i : G + i * DP + lk, *pb = isU ? G + lk * DP + j : Um + j * DP + lk;
-        const int sa = isU ? 4 * DP : 4, sb = isU ? 4 * DP : 4;
+        const int sa = isU ? 4 * DP : 4, sb = isU ? 4 * DP : 4, q0 = 4 * (isU ? ti : tj);
         float fa[16], fb[16];   // (all LDS reads of the product up front: x_dim <= 64 is at most 16 k-steps)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { const int qq = 4 * q < KP ? q : 0; fa[q] = pa[qq * sa]; fb[q] = pb[qq * sb]; }
+        for (int qq = 0; qq < 16; ++qq) { const int qc = (qq >= q0 && 4 * qq < KP) ? qq : q0; fa[qq] = pa[qc * sa]; fb[qq] = pb[qc * sb]; }
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 16; ++q) if (4 * q < KP) acc = mfma4(fa[q], fb[q], acc);
-        const float cv[4] = {acc.x, acc.y, acc.z, acc.w};
-        if (u == 0) { asm volatile("" :: "v"(cv[0])); F_STAMP(4) }
+        for (int qq = 0; qq < 16; ++qq) if (qq >= q0 && 4 * qq < KP) acc = mfma4(fa[qq], fb[qq], acc);
+        float *dst = isU ? UmN : LmN;
+        const int col = 16 * tj + li;
+        dst[(16 * ti + 4 * lk + 0) * DP + col] = acc.x; dst[(16 * ti + 4 * lk + 1) * DP + col] = acc.y;
+        dst[(16 * ti + 4 * lk + 2) * DP + col] = acc.z; dst[(16 * ti + 4 * lk + 3) * DP + col] = acc.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    F_STAMP(0)
+    // the Adam step, element by element in the layout the parameters were loaded in; the new dense operands replace the gradients
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int e = hi[u][r];
-            if (e < 0) continue;
-            const int col = 16 * tj + li, row = r < 4 ? 16 * ti + 4 * lk + r : col;
-            float g;
-            if (r < 4) g = (isU ? row < col : col < row) ? cv[r] : 0.f;
-            else {
-                const int rd = col - 16 * ti - 4 * lk;
-                g = (rd == 0 ? cv[0] : rd == 1 ? cv[1] : rd == 2 ? cv[2] : cv[3]) + a.ldw * __builtin_amdgcn_rcpf(Sp[col]);  // + the conv's log-det term
+    for (int u = 0; u < 4; ++u) {
+        const int row = hrow + 16 * u;
+        if (row < D && hcol < D) {
+            const int o = row * D + hcol;
+            const float gL = hcol < row ? LmN[row * DP + hcol] : 0.f;
+            const float gUraw = UmN[row * DP + hcol], gU = row < hcol ? gUraw : 0.f;
+            const float nL = splr_adam_one(wL[u], gL, mL[u], vL[u], a.step_size, a.inv_bc2s, a.wd);
+            const float nU = splr_adam_one(wU[u], gU, mU[u], vU[u], a.step_size, a.inv_bc2s, a.wd);
+            a.m[base + ts.p_L + o] = mL[u]; a.v[base + ts.p_L + o] = vL[u]; a.w[base + ts.p_L + o] = nL;
+            a.m[base + ts.p_U + o] = mU[u]; a.v[base + ts.p_U + o] = vU[u]; a.w[base + ts.p_U + o] = nU;
+            LmN[row * DP + hcol] = hcol < row ? nL : (hcol == row ? 1.f : 0.f);
+            float nUm = row < hcol ? nU : 0.f;
+            if (row == hcol) {   // S[col]: its gradient is the diagonal of the second product + the conv's log-det term
+                const float nS = splr_adam_one(wS, gUraw + a.ldw * __builtin_amdgcn_rcpf(wS), mS, vS, a.step_size, a.inv_bc2s, a.wd);
+                a.m[sidx] = mS; a.v[sidx] = vS; a.w[sidx] = nS;
+                snew[hcol] = nS;
+                nUm = nS;
             }
-            const float wn = splr_adam_one(hold[e], g, hm[u][r], hv[u][r], a.step_size, a.inv_bc2s, a.wd);
-            a.m[base + e] = hm[u][r]; a.v[base + e] = hv[u][r]; a.w[base + e] = wn;
-            if (!isU) LmN[row * DP + col] = col < row ? wn : (col == row ? 1.f : 0.f);
-            else if (r == 4) { UmN[col * (DP + 1)] = wn; snew[col] = wn; }
-            else if (row != col) UmN[row * DP + col] = row < col ? wn : 0.f;
+            UmN[row * DP + hcol] = nUm;
         }
     }
-    F_STAMP(5)
     if (an) {
-        const float wn = splr_adam_one(hold[tid], an_g, an_m, an_v, a.step_size, a.inv_bc2s, a.wd);
-        a.m[base + tid] = an_m; a.v[base + tid] = an_v; a.w[base + tid] = wn;
-        if (tid < ts.p_t) hold[tid] = wn;  // (the new s, for the log-det constant)
+        const float wn = splr_adam_one(wA, an_g, mA, vA, a.step_size, a.inv_bc2s, a.wd);
+        a.m[aidx] = mA; a.v[aidx] = vA; a.w[aidx] = wn;
+        if (tid < ts.p_t) sact[tid] = wn;  // (the new s, for the log-det constant)
     }
-    F_STAMP(6)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     U_STAMP(4)
     // W = (P Lm) Um from the new values, and its transpose (the gradient kernel reads both row-major)
@@ -982,12 +970,13 @@ __global__ void __launch_bounds__(1024) splr_update_kernel(SplRowsUpdArgs a) {
         const int ti = splr_div_small(wave, nt), tj = wave - ti * nt, i = 16 * ti + li, j = 16 * tj + li;
         const int pr = i < D ? spi[i] : 63;
         const float *pa = LmN + pr * DP + lk, *pb = UmN + lk * DP + j;
+        const int q1 = 4 * (tj + 1);   // Um[k][j] = 0 for k > j: the k-steps past the column tile's last row are zeros
         float fa[16], fb[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { const int qq = 4 * q < KP ? q : 0; fa[q] = pa[4 * qq]; fb[q] = pb[4 * qq * DP]; }
+        for (int q = 0; q < 16; ++q) { const int qq = q < q1 ? q : 0; fa[q] = pa[4 * qq]; fb[q] = pb[4 * qq * DP]; }
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 16; ++q) if (4 * q < KP) acc = mfma4(fa[q], fb[q], acc);
+        for (int q = 0; q < 16; ++q) if (q < q1) acc = mfma4(fa[q], fb[q], acc);
         const float cv[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -998,7 +987,7 @@ __global__ void __launch_bounds__(1024) splr_update_kernel(SplRowsUpdArgs a) {
     U_STAMP(5)
     // log|det| of ActNorm + conv (networks.py:650, :676): the terms in parallel, summed in d order
     if (wave == nwv - 1) {   // (the last wave: its product tile, if it has one, is done)
-        float t = lane < D ? hold[ts.p_s + lane] + logf(fabsf(snew[lane < D ? lane : 0])) : 0.f;
+        float t = lane < D ? sact[lane] + logf(fabsf(snew[lane])) : 0.f;
         float acc = 0.f;
         for (int d = 0; d < D; ++d) acc += splr_rl(t, d);
         if (lane == 0) a.ldc[b] = acc;
@@ -1009,8 +998,7 @@ __global__ void __launch_bounds__(1024) splr_update_kernel(SplRowsUpdArgs a) {
     // prints what is left here, behind the log-det constants)
     if (tid == 0 && b == 0) {
         for (int i = 0; i < 6; ++i) a.ldc[4 + i] = (float)(u_t[i + 1] - u_t[i]);
-        a.ldc[11] = (float)(u_f[0] - u_t[2]); a.ldc[12] = (float)(u_f[1] - u_f[0]); a.ldc[13] = (float)(u_f[2] - u_f[1]); a.ldc[14] = (float)(u_t[3] - u_f[2]);
-        a.ldc[15] = (float)(u_f[3] - u_t[3]); a.ldc[16] = (float)(u_f[4] - u_f[3]); a.ldc[17] = (float)(u_f[5] - u_f[4]); a.ldc[18] = (float)(u_f[6] - u_f[5]); a.ldc[19] = (float)(u_t[4] - u_f[6]);
+        a.ldc[11] = (float)(u_f[0] - u_t[3]);
     }
 #endif
 }
@@ -1132,7 +1120,7 @@ hipError_t spline_rows_update(nnest_spline *h, const SplTrainShape &ts, const Sp
     a.step_size = u.step_size; a.inv_bc2s = u.inv_bc2s; a.wd = u.wd; a.ldw = u.ldw; a.loss_out = u.loss_out; a.loss_scale = u.loss_scale;
     a.stop = u.stop; a.grad_out = u.grad_out; a.gwsum_out = u.gwsum_out;
     a.n_jobs = s.B * (splr_jobs_of(s, 0) + splr_jobs_of(s, 1));
-    const size_t ldsb = ((size_t)ts.p_f[0] + 5 * 64 * 65 + 64 + 2048) * sizeof(float) + 64 * sizeof(int);
+    const size_t ldsb = ((size_t)5 * 64 * 65 + 3 * 64 + 512) * sizeof(float) + 64 * sizeof(int);
     static bool attr[64] = {false};   // (per device)
     hipError_t e = hipSuccess;
     if (!attr[h->device & 63]) {
