@@ -1103,6 +1103,7 @@ hipError_t spline_rows_grad(nnest_spline *h, const SplTrainShape &ts, const SplR
         if (e == hipSuccess) hipLaunchKernelGGL((splr_grad_kernel<NWv, NSv>), dim3(grid), dim3(64 * NWv), ldsb, st, a);                    \
     }
     if (NW == 1) SPLR_LAUNCH(1, 12)
+    else if (NW == 2 && ns <= 8) SPLR_LAUNCH(2, 8)
     else if (NW == 2) SPLR_LAUNCH(2, 12)
     else if (ns <= 9) SPLR_LAUNCH(4, 9)
     else SPLR_LAUNCH(4, 12)
