@@ -156,12 +156,15 @@ __device__ __forceinline__ float splr_eval(float rw, float rh, float rd, float x
     const float chr = k == SPL_K - 1 ? tail : T2 * ch_in + (-tail);
     const float ht = chr - chl;
     // knot derivatives: the right knot of bin k is inner knot k + 1 (k < 7), the end knots are 1
-    const float s1 = spl_softplus(rd);
-    const float dr = 1e-3f + spl_softplus(s1);
+    // softplus(softplus(v)) = log(1 + e^{log(1 + e^v)}) = log(2 + e^v), and its derivative sigmoid(softplus(v)) sigmoid(v) = e^v / (2 + e^v):
+    // one exponential, one logarithm, one reciprocal for what is written as two softplus and two sigmoids (v > 20: both softplus
+    // are the identity there, networks.py / F.softplus threshold, and the derivative is 1 to 2e-9)
+    const float ev = spl_exp(rd < 20.f ? rd : 20.f);
+    const float dr = 1e-3f + (rd > 20.f ? rd : spl_log(2.f + ev));
     const float d1 = k == SPL_K - 1 ? 1.0f : dr;
     t = splr_dpp<0x111>(d1);
     const float d0 = k == 0 ? 1.0f : t;
-    const float dd = k == SPL_K - 1 ? 0.f : spl_sigmoid(s1) * spl_sigmoid(rd);
+    const float dd = k == SPL_K - 1 ? 0.f : (rd > 20.f ? 1.f : ev * spl_rcp(2.f + ev));
     // searchsorted (networks.py:417-422): the inner edges <= x (edge 0 = -tail always is, the last one + 1e-6 never)
     const float cnt = splr_sum8((k >= 1 && x >= left) ? 1.f : 0.f);
     const bool sel = (float)k == cnt;
@@ -174,9 +177,10 @@ __device__ __forceinline__ float splr_eval(float rw, float rh, float rd, float x
     const float Dn = delta + (d0 + d1 - 2.f * delta) * tomt;
     const float Q = d1 * theta * theta + 2.f * delta * tomt + d0 * (1.f - theta) * (1.f - theta);
     const bool use = sel && inside;
-    const float y_own = use ? chl + Nn * spl_rcp(Dn) : 0.f;
+    const float rDn = spl_rcp(Dn);
+    const float y_own = use ? chl + Nn * rDn : 0.f;
     const float y = inside ? splr_sum8(y_own) : x;
-    if (use && active) ld += spl_log(delta * delta * Q) - 2.f * spl_log(Dn);
+    if (use && active) ld += spl_log((delta * rDn) * (delta * rDn) * Q);   // log(delta^2 Q) - 2 log(Dn)
     kp.a_w = a_w; kp.p_w = p_w; kp.a_h = a_h; kp.p_h = p_h;
     kp.dd = dd; kp.left = left; kp.width = width; kp.chl = chl;
     kp.ht = ht; kp.d0 = d0; kp.d1 = d1; kp.x = x;
