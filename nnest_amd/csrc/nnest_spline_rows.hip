@@ -8,10 +8,11 @@
 // logits and the derivative logit of its right knot); softmax sums, the knot positions (a prefix sum) and the bin search are
 // DPP operations inside the 8-lane group.  A row of x_dim 50 is 25 items = 200 lanes = four waves, a minibatch of 100 rows is
 // 100 workgroups on 100 CUs, and a coupling pass is ~350 vector instructions per wave.  Layout of one coupling pass:
-//   trunk (3 hidden layers of 16): every wave computes it redundantly in "row layout" (lane o & 15 holds unit o), the layer
-//       inputs broadcast with v_readlane, the weights read straight from the PACKED state_dict-order vector (no image);
-//   last layer (16 -> 23 n_out): "quad per output row" -- four lanes share an output row, each reads a 16-byte quarter of it
-//       (one instruction = 16 full 64-byte lines, coalesced) and the quad adds up; the raw parameters go through LDS to the
+//   trunk (3 hidden layers of 16): every wave computes it redundantly on the matrix cores (y = W x with the vector in all sixteen
+//       columns of the B operand; SplrTrunkF has the layout), the weights read straight from the PACKED state_dict-order vector (no
+//       image) -- a lane's four A operands of a layer are 16 contiguous bytes of the weight row;
+//   last layer (16 -> 23 n_out): the same product per sixteen output rows, the tiles dealt over the waves; the raw parameters go
+//       through LDS to the
 //   evaluation in the item layout above; the transformed values go back to the row vector in LDS.
 // The backward pass mirrors it (the forward pass's per-lane intermediates are kept in LDS: 16 floats per lane and coupling).
 // Parameter gradients are NOT accumulated here: each row stages the operands (activations, pre-activation gradients, raw-parameter
@@ -33,7 +34,7 @@ using namespace nnest;
 
 namespace nnest {
 
-enum { SPLR_TROW = 160, SPLR_VROW = 64, SPLR_NS = 12 };  // trunk staging row: h0 h1 h2 d0 d1 d2 (16 each) + u (64); block rows; last-layer steps
+enum { SPLR_TROW = 160, SPLR_VROW = 64 };  // trunk staging row: h0 h1 h2 d0 d1 d2 (16 each) + u (64); block staging rows
 
 // staging buffer (floats): T[c] = off_T + (c rows_cap + r) 160; G[c] = off_G + (c rows_cap + r) grow; V[b][which] = off_V + ((3b + which)
 // rows_cap + r) 64 with which = 0: a (ActNorm output = conv input), 1: g_c (gradient at the conv output), 2: g_a (at the conv input)
@@ -100,20 +101,6 @@ __device__ __forceinline__ float splr_scan8(float v, int k) {
 }
 __device__ __forceinline__ float splr_rl(float v, int lane) {   // lane: wave-uniform
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-__device__ __forceinline__ f32x4 splr_ldx4(const float *p) {   // 16 bytes from a dword-aligned address (the packed vector's offsets are odd)
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-// The inline-asm loads are invisible to the compiler's wait-count bookkeeping: splr_wait_vm() waits for them, and splr_fence() makes
-// every later use of a loaded register depend on a (empty) statement behind that wait -- volatile statements keep their order.
-__device__ __forceinline__ void splr_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void splr_fence(f32x4 &v) { asm volatile("" : "+v"(v)); }
-template <int N>
-__device__ __forceinline__ void splr_fence(f32x4 (&v)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) splr_fence(v[i]);
 }
 __device__ __forceinline__ void splr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float splr_lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
@@ -337,7 +324,7 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     const SplTrainShape &ts = a.ts;
     const SplineShape &s = ts.s;
     const int D = s.D, B = s.B, nl = s.nl, nu = s.nu;
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), o16 = lane & 15, q4 = lane & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), o16 = lane & 15;
     const int item = tid >> 3, k = tid & 7;
     float *xrow = lds;                       // [64] the row
     float *grow = xrow + 64;                 // [64] its gradient
