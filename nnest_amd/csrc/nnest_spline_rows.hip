@@ -816,20 +816,18 @@ __global__ void __launch_bounds__(1024) splr_update_kernel(SplRowsUpdArgs a) {
     for (int r = 0; r < 4; ++r) { const int i = 16 * cti + 4 * lk + r; prow[r] = (ctile && i < D) ? a.pi[b * D + i] : -1; }
     for (int i = tid; i < D; i += blockDim.x) spi[i] = a.pi[b * D + i];
     const int hrow = tid >> 6, hcol = lane;
-    float wL[4], wU[4], mL[4], mU[4], vL[4], vU[4];
+    float wL[4], wU[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int row = hrow + 16 * u, o = (row < D && hcol < D) ? row * D + hcol : 0;
         wL[u] = a.w[base + ts.p_L + o]; wU[u] = a.w[base + ts.p_U + o];
-        mL[u] = stepping ? a.m[base + ts.p_L + o] : 0.f; mU[u] = stepping ? a.m[base + ts.p_U + o] : 0.f;
-        vL[u] = stepping ? a.v[base + ts.p_L + o] : 0.f; vU[u] = stepping ? a.v[base + ts.p_U + o] : 0.f;
     }
     const bool diag = (lane & 15) == hrow && hcol < D;   // exactly one u has row == col = lane: u = lane >> 4
     const int sidx = base + ts.p_S + (diag ? hcol : 0);
-    float wS = a.w[sidx], mS = stepping ? a.m[sidx] : 0.f, vS = stepping ? a.v[sidx] : 0.f;
+    float wS = a.w[sidx];
     const bool an = tid < ts.p_L;
     const int aidx = base + (an ? tid : 0);
-    float wA = a.w[aidx], mA = stepping ? a.m[aidx] : 0.f, vA = stepping ? a.v[aidx] : 0.f;
+    float wA = a.w[aidx];
     __builtin_amdgcn_sched_barrier(0);
     U_STAMP(1)
     for (int idx = tid; idx < MAT; idx += blockDim.x) {  // the padding of the five matrices (no operand yet: the loads are in flight)
@@ -869,6 +867,16 @@ __global__ void __launch_bounds__(1024) splr_update_kernel(SplRowsUpdArgs a) {
         }
     }
     U_STAMP(2)
+    // the Adam moments (the same layout; 82 KB through this CU's load path): requested now, behind the contraction -- they are used behind
+    // two barriers and the products, and in the first batch they only stood in front of the operands the contraction waits for
+    float mL[4], mU[4], vL[4], vU[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int row = hrow + 16 * u, o = (row < D && hcol < D) ? row * D + hcol : 0;
+        mL[u] = stepping ? a.m[base + ts.p_L + o] : 0.f; mU[u] = stepping ? a.m[base + ts.p_U + o] : 0.f;
+        vL[u] = stepping ? a.v[base + ts.p_L + o] : 0.f; vU[u] = stepping ? a.v[base + ts.p_U + o] : 0.f;
+    }
+    float mS = stepping ? a.m[sidx] : 0.f, vS = stepping ? a.v[sidx] : 0.f, mA = stepping ? a.m[aidx] : 0.f, vA = stepping ? a.v[aidx] : 0.f;
     // the old head as dense operands: Lm = tril(L,-1) + I, Um = triu(U,1) + diag(S)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
