@@ -378,6 +378,8 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     const int lk = lane >> 4;
     load_col(a.wmat, wcol);
     an_s = a.w[ts.p_s + jl]; an_t = a.w[ts.p_t + jl];
+    float ldc_sum = 0.f;
+    for (int b = 0; b < B; ++b) ldc_sum += a.ldc[b];
     tw.load(a.w + ts.p_f[0], nl, o16, lk);
     lw.load(a.w + ts.p_f[0], nl, nu, wv, o16, lk, item, k, true);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
@@ -502,18 +504,17 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
             an_s = a.w[(size_t)(B - 1) * s.blk_params + ts.p_s + jl];
             bw.load(net_of(2 * B - 1), nu, o16, lk);
         }
-        float v = lane < D ? base_E(xrow[jl], s.base_beta) : 0.f;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) ld += __shfl_xor(ld, o);
-        if (lane == 0) red[wv] = ld;
+        // one reduction: the lanes' log-derivatives, minus (wave 0) the base density's terms; the blocks' log-det constants were
+        // requested in the prologue (written by the update kernel a launch ago: a cold load here was 1 us of the row's chain)
+        float t = ld - ((wv == 0 && lane < D) ? base_E(xrow[jl], s.base_beta) : 0.f);
+        t += splr_dpp<0x128>(t); t += splr_dpp<0x124>(t); t += splr_dpp<0x122>(t); t += splr_dpp<0x121>(t);   // the four rows of the wave
+        t = (splr_rl(t, 0) + splr_rl(t, 16)) + (splr_rl(t, 32) + splr_rl(t, 48));
+        if (lane == 0) red[wv] = t;
         splr_barrier();
         if (tid == 0) {
-            float lt = 0.f;
+            float lt = ldc_sum;
             for (int w = 0; w < NW; ++w) lt += red[w];
-            for (int b = 0; b < B; ++b) lt += a.ldc[b];
-            a.rowlp[vrow ? a.M + row : row] = -v + s.base_const * (float)D + lt;
+            a.rowlp[vrow ? a.M + row : row] = s.base_const * (float)D + lt;
         }
     }
     if (vrow) return;
