@@ -284,11 +284,11 @@ struct SplrLastW {    // the last layer, tile st of this wave = output rows 16 (
     float e0, e1, e2; // of the outputs this lane reads back as (item, bin), added there
     __device__ __forceinline__ void load(const float *pn, int nin, int nout, int wv, int c16, int lk, int item, int k, bool bias) {
         const float *W3 = pn + 16 * nin + 16 + 2 * (256 + 16), *pb3 = W3 + (size_t)SPL_P * nout * 16;
-        const int nrows = SPL_P * nout;
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
-            const int o = 16 * (wv + NW * st) + c16, oc = o < nrows ? o : nrows - 1;   // (rows past the outputs: never read forward, times 0 on the way back)
-            l3[st] = splr_ld4(W3 + (size_t)oc * 16 + 4 * lk);
+            // (rows past the outputs -- the biases, the next net, or w_dev's zeroed slack: finite values, never stored forward, times 0 on
+            // the way back; no clamp: the tiles' addresses stay one base + a constant stride)
+            l3[st] = splr_ld4(W3 + (size_t)(16 * (wv + NW * st) + c16) * 16 + 4 * lk);
         }
         if (bias) {
             const int jb = SPL_P * (item < nout ? item : 0);
@@ -306,7 +306,7 @@ struct SplrTrunkB {   // the trunk's transposed layers: A[i = c16][k = 4 lk + s]
             c2[q] = W2[(4 * lk + q) * 16 + c16];
             c1[q] = W1[(4 * lk + q) * 16 + c16];
 #pragma unroll
-            for (int t = 0; t < NC; ++t) { const int i = 16 * t + c16; c0[t][q] = W0[(4 * lk + q) * nin + (i < nin ? i : 0)]; }   // (rows past the inputs are not written back)
+            for (int t = 0; t < NC; ++t) c0[t][q] = W0[(4 * lk + q) * nin + 16 * t + c16];   // (columns past the inputs: the next rows' weights, finite; those outputs are not written back)
         }
     }
 };
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     const int ci0 = wv * PM;
     auto load_col = [&](const float *Mt, float (&wcol)[PM]) {
 #pragma unroll
-        for (int t = 0; t < PM; ++t) { const int i = ci0 + t < D ? ci0 + t : D - 1; wcol[t] = Mt[(size_t)i * D + jl]; }
+        for (int t = 0; t < PM; ++t) wcol[t] = Mt[(size_t)(ci0 + t) * D + jl];   // (rows past x_dim: the next block's, or the zeroed slack; times 0)
     };
     float wcol[PM], an_s, an_t;
     SplrTrunkF<NC> tw;
@@ -592,13 +592,19 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
                 if (wv == 0 && o16 == 0) {
                     float *Tr = T0 + ((size_t)ci * rc + row) * SPLR_TROW;
                     *reinterpret_cast<f32x4 *>(Tr + 48 + 4 * lk) = d0; *reinterpret_cast<f32x4 *>(Tr + 64 + 4 * lk) = d1; *reinterpret_cast<f32x4 *>(Tr + 80 + 4 * lk) = d2;
+                    // (all reads of the update first: as four guarded read-modify-writes per tile they were eight dependent LDS round
+                    // trips on the one wave the other three wait for)
+                    float gv[NC][4];
+#pragma unroll
+                    for (int t = 0; t < NC; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const int i = 16 * t + 4 * lk + e; gv[t][e] = grow[idoff + (i < nin ? i : 0)]; }
 #pragma unroll
                     for (int t = 0; t < NC; ++t) {
                         const int i = 16 * t + 4 * lk;
-                        if (i + 0 < nin) grow[idoff + i + 0] += du[t].x;
-                        if (i + 1 < nin) grow[idoff + i + 1] += du[t].y;
-                        if (i + 2 < nin) grow[idoff + i + 2] += du[t].z;
-                        if (i + 3 < nin) grow[idoff + i + 3] += du[t].w;
+                        const float dv[4] = {du[t].x, du[t].y, du[t].z, du[t].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (i + e < nin) grow[idoff + i + e] = gv[t][e] + dv[e];
                     }
                 }
             }
@@ -1050,7 +1056,8 @@ int spline_rows_prepare(nnest_spline *h, const SplTrainShape &ts, int max_rows, 
         r = new SplRowsState();
         memset(r, 0, sizeof(*r));
         h->rows = r;
-        SHIP_TRY(hipMalloc((void **)&r->wmatT, (size_t)s.B * s.D * s.D * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&r->wmatT, (size_t)s.B * s.D * s.D * sizeof(float) + SPL_W_SLACK_BYTES));   // (zeroed slack, as wmat's)
+        SHIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(r->wmatT) + (size_t)s.B * s.D * s.D * sizeof(float), 0, SPL_W_SLACK_BYTES, st));
         SHIP_TRY(hipMalloc((void **)&r->ldc, 32 * sizeof(float)));
     }
     if (max_rows < 128) max_rows = 128;   // (the contractions read 4 x 26 or 4 x 32 rows whatever the minibatch)

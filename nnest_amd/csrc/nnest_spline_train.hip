@@ -1821,13 +1821,17 @@ static int ensure_train_state(nnest_spline *h, int max_rows, hipStream_t st) {
     const int D = h->s.D, B = h->s.B;
     const size_t nb = (size_t)h->s.num_params * sizeof(float);
     if (!h->w_dev) {
-        SHIP_TRY(hipMalloc((void **)&h->w_dev, nb));
+        // (w_dev with zeroed slack behind it: the rows form's last-layer tiles read whole 16-row tiles, the last coupling's last tile past
+        // the end of the packed vector -- times 0 or never stored, but read)
+        SHIP_TRY(hipMalloc((void **)&h->w_dev, nb + SPL_W_SLACK_BYTES));
+        SHIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(h->w_dev) + nb, 0, SPL_W_SLACK_BYTES, st));
         SHIP_TRY(hipMalloc((void **)&h->adam_m, nb));
         SHIP_TRY(hipMalloc((void **)&h->adam_v, nb));
         SHIP_TRY(hipMalloc((void **)&h->best_w, nb));
         SHIP_TRY(hipMalloc((void **)&h->grad, nb));
         SHIP_TRY(hipMalloc((void **)&h->pi_dev, (size_t)2 * B * D * sizeof(int)));
-        SHIP_TRY(hipMalloc((void **)&h->wmat, (size_t)B * D * D * sizeof(float)));
+        SHIP_TRY(hipMalloc((void **)&h->wmat, (size_t)B * D * D * sizeof(float) + SPL_W_SLACK_BYTES));   // (zeroed slack: the rows form reads whole 16-row groups)
+        SHIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(h->wmat) + (size_t)B * D * D * sizeof(float), 0, SPL_W_SLACK_BYTES, st));
         SHIP_TRY(hipMalloc((void **)&h->gwsum, (size_t)B * D * D * sizeof(float)));
         SHIP_TRY(hipMalloc((void **)&h->timg, (size_t)ts.timage_floats * sizeof(float)));
         SHIP_TRY(hipMalloc((void **)&h->losses_dev, 1024 * sizeof(float)));

@@ -34,6 +34,7 @@ struct nnest_spline {
 };
 
 namespace nnest {
+enum { SPL_W_SLACK_BYTES = 64 * 1024 };   // zeroed bytes behind w_dev (nnest_spline_train.hip: ensure_train_state)
 struct SplTrainShape;
 // ---- the rows form of the training step (nnest_spline_rows.hip) ----
 struct SplRowsBatch {   // one gradient launch: a minibatch (+ Mv forward-only validation rows behind it)
