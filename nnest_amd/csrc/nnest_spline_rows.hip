@@ -398,13 +398,14 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
 
     // c = v M of the row vector held one element per lane (M's rows ci0 .. of this wave in `wcol`); result in every wave's lanes j < D
     auto matvec = [&](const float (&wc)[PM], float v) -> float {
-        float acc = 0.f;
+        // (v is 0 in the lanes past x_dim, so rows past x_dim of M -- finite -- add nothing; two accumulators: the chain is half as long)
+        float acc = 0.f, acc1 = 0.f;
 #pragma unroll
-        for (int t = 0; t < PM; ++t) {
-            const int i = ci0 + t;
-            const float vi = splr_rl(v, i < 63 ? i : 63);
-            acc = fmaf(i < D ? vi : 0.f, wc[t], acc);
+        for (int t = 0; t < PM; t += 2) {
+            acc = fmaf(splr_rl(v, ci0 + t), wc[t], acc);
+            if (t + 1 < PM) acc1 = fmaf(splr_rl(v, ci0 + t + 1), wc[t + 1], acc1);
         }
+        acc += acc1;
         red[wv * 64 + lane] = acc;
         splr_barrier();
         float c = 0.f;

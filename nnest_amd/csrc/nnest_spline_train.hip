@@ -2039,23 +2039,21 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
         hipLaunchKernelGGL(spl_assemble_kernel, dim3(64), dim3(256), 0, st, h->w_dev, h->pi_dev, h->wmat, ts, (const int *)nullptr);
         if ((rc = spline_rows_prepare(h, ts, 128, n_valid, st, nullptr))) return rc;
     }
-    const int CHUNK = 8;
-    hipEvent_t ev[2];
-    SHIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    SHIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-    int chunks = 0;
-    bool stopped_seen = false;
+    // How far the host may queue without looking: the books of an epoch stop the run when `counter` (epochs since the last improvement,
+    // this one included) exceeds `patience`, so from a state read after epoch e0 with counter c0 the earliest epoch that can stop is
+    // e0 + patience + 1 - c0.  Up to there the launches are queued blind (the validation pass of an epoch riding with the next epoch's
+    // first gradient launch); THAT epoch ends with its own validation launch and its books, the stream is drained and the state read:
+    // stopped, or a later check epoch.  (Was: a snapshot every 8 epochs, looked at one chunk later -- up to 16 epochs of launches
+    // queued past the stop, each a no-op but a launch: 1.4 ms of a 40 ms call.)
+    int check_epoch = patience;   // e0 = -1, c0 = 0
+    bool stopped_seen = false, pending_validation = false;
     const int vtiles = (n_valid + rows_per_tile(h->s) - 1) / rows_per_tile(h->s);
-    // the state after epoch `done` epochs: snapshot every CHUNK epochs, looked at one chunk later
-    auto snapshot = [&](int done) -> int {
-        if (done % CHUNK != 0 || done >= max_epochs) return NNEST_OK;
-        SHIP_TRY(hipMemcpyAsync(&snap[chunks & 1], ctl, sizeof(SplTrainCtl), hipMemcpyDeviceToHost, st));
-        SHIP_TRY(hipEventRecord(ev[chunks & 1], st));
-        if (chunks > 0) {
-            SHIP_TRY(hipEventSynchronize(ev[(chunks - 1) & 1]));
-            stopped_seen = snap[(chunks - 1) & 1].stopped != 0;
-        }
-        chunks += 1;
+    auto read_state = [&](int epoch) -> int {   // after the books of `epoch` have been queued
+        SHIP_TRY(hipMemcpyAsync(&snap[0], ctl, sizeof(SplTrainCtl), hipMemcpyDeviceToHost, st));
+        SHIP_TRY(hipStreamSynchronize(st));
+        stopped_seen = snap[0].stopped != 0;
+        check_epoch = epoch + patience + 1 - snap[0].counter;
+        if (check_epoch <= epoch) check_epoch = epoch + 1;
         return NNEST_OK;
     };
     auto valid_args = [&]() {
@@ -2080,7 +2078,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             h->adam_step += 1;
             const double bc1 = 1.0 - pow(0.9, (double)h->adam_step), bc2 = 1.0 - pow(0.999, (double)h->adam_step);
             if (rows) {
-                const bool ride = mb == 0 && epoch > 0;  // the validation pass of the epoch before: forward-only rows behind the minibatch's
+                const bool ride = mb == 0 && pending_validation;  // the validation pass of the epoch before: forward-only rows behind the minibatch's
                 SplRowsBatch bt;
                 memset(&bt, 0, sizeof(bt));
                 bt.x = a.x; bt.perm = a.perm; bt.M = M; bt.mtot = M; bt.noise = a.noise; bt.seed = seed; bt.noise_row0 = a.noise_row0; bt.epoch = epoch;
@@ -2090,7 +2088,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
                 if (ride) {
                     hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch - 1, patience,
                                        h->epoch_losses_dev, spline_rows_rowlp(h) + M + 3, 1, n_valid, h->w_dev, h->best_w, np);
-                    if ((rc = snapshot(epoch))) return rc;
+                    pending_validation = false;
                 }
                 SplRowsStep u;
                 memset(&u, 0, sizeof(u));
@@ -2099,13 +2097,13 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
                 SHIP_TRY(spline_rows_update(h, ts, u, st));
             } else if (fused) {
                 if (mb == 0 && epoch == 0 && (rc = build_timage(h, ts, st, stop))) return rc;
-                const bool ride = mb == 0 && epoch > 0;  // the validation pass of the epoch before
+                const bool ride = mb == 0 && pending_validation;  // the validation pass of the epoch before
                 if (ride) { a.val_tiles = vtiles; a.xv = xvalid_dev; a.Mv = n_valid; }
                 SHIP_TRY(launch_grad(a, st));
                 if (ride) {
                     hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch - 1, patience,
                                        h->epoch_losses_dev, h->partial + (size_t)tiles * ts.gw_floats, ts.gw_floats, vtiles, h->w_dev, h->best_w, np);
-                    if ((rc = snapshot(epoch))) return rc;
+                    pending_validation = false;
                 }
                 SplUpdateArgs u;
                 memset(&u, 0, sizeof(u));
@@ -2131,7 +2129,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             }
         }
         SHIP_TRY(hipGetLastError());
-        if ((fused || rows) && epoch + 1 < max_epochs) continue;  // this epoch's validation rides with the next epoch's first gradient pass
+        if ((fused || rows) && epoch + 1 < max_epochs && epoch < check_epoch) { pending_validation = true; continue; }  // rides with the next epoch's first gradient pass
         // Trainer._validate (trainer.py:405-418): one full batch; mean, then / len(dataset)
         if (rows) {
             SplRowsBatch bt;
@@ -2141,7 +2139,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch, patience,
                                h->epoch_losses_dev, spline_rows_rowlp(h) + 3, 1, n_valid, h->w_dev, h->best_w, np);
             SHIP_TRY(hipGetLastError());
-            if ((rc = snapshot(epoch + 1))) return rc;
+            if (epoch + 1 < max_epochs && epoch >= check_epoch && (rc = read_state(epoch))) return rc;
             continue;
         }
         if (!fused && (rc = build_timage(h, ts, st, stop))) return rc;
@@ -2152,12 +2150,11 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
         hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch, patience,
                            h->epoch_losses_dev, h->partial, ts.gw_floats, vtiles, h->w_dev, h->best_w, np);
         SHIP_TRY(hipGetLastError());
-        if ((rc = snapshot(epoch + 1))) return rc;
+        if (epoch + 1 < max_epochs && epoch >= check_epoch && (rc = read_state(epoch))) return rc;
     }
     SHIP_TRY(hipMemcpyAsync(h->w_dev, h->best_w, nb, hipMemcpyDeviceToDevice, st));  // netG.load_state_dict(best_model)  trainer.py:241
     SHIP_TRY(hipMemcpyAsync(&snap[0], ctl, sizeof(SplTrainCtl), hipMemcpyDeviceToHost, st));
     SHIP_TRY(hipStreamSynchronize(st));
-    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
     const SplTrainCtl fin = snap[0];
     if (losses_host && fin.epochs_run > 0)
         SHIP_TRY(hipMemcpy(losses_host, h->epoch_losses_dev, 2 * (size_t)fin.epochs_run * sizeof(float), hipMemcpyDeviceToHost));
