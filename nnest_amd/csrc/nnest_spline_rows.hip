@@ -296,6 +296,30 @@ struct SplrLastW {    // the last layer, tile st of this wave = output rows 16 (
         }
     }
 };
+// The last layer forward on v_mfma_f32_4x4x1 (sixteen independent 4x4 outer products an instruction, 8 cycles): block b = lane >> 2,
+// row i = lane & 3 of the block -- lane L supplies output row 64 g + L of group g, the vector element of step k is the B operand of
+// every lane, and register i of the block's lanes is output row 64 g + 4 b + i.  64 output rows per 16 instructions of 8 cycles against
+// 16 rows per 4 instructions of 32 cycles for the 16x16x4 shape (whose sixteen columns all carry the same vector): four times the
+// rows per matrix-core cycle.  A lane's operands are its whole weight row: 64 contiguous bytes.
+template <int NW>
+struct SplrLastF {
+    enum { NG = 3 };   // groups of 64 rows per wave: 23 * 32 rows are 12 groups, NW <= 4 waves take three each (8 n_out <= 64 NW lanes)
+    f32x4 w[NG][4];
+    float e0, e1, e2;   // the three biases of the outputs this lane reads back as (item, bin), added there
+    __device__ __forceinline__ void load(const float *pn, int nin, int nout, int wv, int lane, int item, int k) {
+        const float *W3 = pn + 16 * nin + 16 + 2 * (256 + 16), *pb3 = W3 + (size_t)SPL_P * nout * 16;
+#pragma unroll
+        for (int sg = 0; sg < NG; ++sg) {
+            const float *row = W3 + (size_t)(64 * (wv + NW * sg) + lane) * 16;   // (rows past the outputs: finite -- w_dev's slack -- and not stored)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[sg][q] = splr_ld4(row + 4 * q);
+        }
+        const int jb = SPL_P * (item < nout ? item : 0);
+        e0 = pb3[jb + k]; e1 = pb3[jb + 8 + k]; e2 = pb3[jb + 16 + (k < 7 ? k : 6)];
+    }
+};
+__device__ __forceinline__ f32x4 mfma1(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
 template <int NC>
 struct SplrTrunkB {   // the trunk's transposed layers: A[i = c16][k = 4 lk + s] = W[4 lk + s][i]
     float c2[4], c1[4], c0[NC][4];
@@ -373,7 +397,8 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     };
     float wcol[PM], an_s, an_t;
     SplrTrunkF<NC> tw;
-    SplrLastW<NW, NS> lw;
+    SplrLastF<NW> lf;      // forward
+    SplrLastW<NW, NS> lw;  // the way back
     SplrTrunkB<NC> bw;
     const int lk = lane >> 4;
     load_col(a.wmat, wcol);
@@ -381,7 +406,7 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     float ldc_sum = 0.f;
     for (int b = 0; b < B; ++b) ldc_sum += a.ldc[b];
     tw.load(a.w + ts.p_f[0], nl, o16, lk);
-    lw.load(a.w + ts.p_f[0], nl, nu, wv, o16, lk, item, k, true);
+    lf.load(a.w + ts.p_f[0], nl, nu, wv, lane, item, k);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
     if (stop_flag) return;   // (uniform over the workgroup, in front of its first barrier)
     splr_barrier();
@@ -436,7 +461,6 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
         for (int c = 0; c < 2; ++c) {
             const int ci = 2 * b + c;
             const int nin = c ? nu : nl, nout = c ? nl : nu, idoff = c ? nl : 0, troff = c ? 0 : nl;
-            const int nrows = SPL_P * nout;
             // trunk (networks.py:393-409): Linear LReLU x3 on the matrix cores, every wave the same
             f32x4 ub[NC];
 #pragma unroll
@@ -466,17 +490,32 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
                 Tr[96 + lane] = uL;
             }
             R_STAMP(2)
-            // last layer: tile st of this wave, sixteen output rows a product
+            // last layer: group sg of this wave, 64 output rows per sixteen 4x4x1 products (SplrLastF); the vector's sixteen elements first,
+            // each in every lane
+            float hb[16];
 #pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                // (no branch around a tile: the products of the wave's tiles are independent and should interleave; tiles past the
-                // outputs multiply clamped rows and are not stored)
-                const int o = 16 * (wv + NW * st);
-                const f32x4 r = splr_mv16(lw.l3[st], h2, (f32x4){0.f, 0.f, 0.f, 0.f});
-                if (o16 == 0 && o < nrows) *reinterpret_cast<f32x4 *>(rawbuf + o + 4 * lk) = r;
+            for (int q = 0; q < 4; ++q) {
+                hb[4 * q + 0] = splr_rl(h2.x, 16 * q); hb[4 * q + 1] = splr_rl(h2.y, 16 * q);
+                hb[4 * q + 2] = splr_rl(h2.z, 16 * q); hb[4 * q + 3] = splr_rl(h2.w, 16 * q);
             }
-            const float e0 = lw.e0, e1 = lw.e1, e2 = lw.e2;
-            if (ci + 1 < 2 * B) lw.load(net_of(ci + 1), c ? nl : nu, c ? nu : nl, wv, o16, lk, item, k, true);   // (the last coupling's stay: the way back starts there)
+            f32x4 rl3[SplrLastF<NW>::NG];
+#pragma unroll
+            for (int sg = 0; sg < SplrLastF<NW>::NG; ++sg) rl3[sg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int sg = 0; sg < SplrLastF<NW>::NG; ++sg) rl3[sg] = mfma1(splr_comp(lf.w[sg][q], e), hb[4 * q + e], rl3[sg]);
+            if ((lane & 3) == 0) {
+#pragma unroll
+                for (int sg = 0; sg < SplrLastF<NW>::NG; ++sg) {
+                    const int o = 64 * (wv + NW * sg) + lane;   // rows o .. o + 3 of the row: register i is row 4 b + i of the group
+                    if (o + 3 < a.lay.grow) *reinterpret_cast<f32x4 *>(rawbuf + o) = rl3[sg];
+                }
+            }
+            const float e0 = lf.e0, e1 = lf.e1, e2 = lf.e2;
+            if (ci + 1 < 2 * B) lf.load(net_of(ci + 1), c ? nl : nu, c ? nu : nl, wv, lane, item, k);
             splr_barrier();
             R_STAMP(3)
             // the spline, eight lanes per item (networks.py:583-587, :425-556)
@@ -504,6 +543,7 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
             load_col(a.wmatT + (size_t)(B - 1) * D * D, wcol);
             an_s = a.w[(size_t)(B - 1) * s.blk_params + ts.p_s + jl];
             bw.load(net_of(2 * B - 1), nu, o16, lk);
+            lw.load(net_of(2 * B - 1), nu, nl, wv, o16, lk, item, k, false);
         }
         // one reduction: the lanes' log-derivatives, minus (wave 0) the base density's terms; the blocks' log-det constants were
         // requested in the prologue (written by the update kernel a launch ago: a cold load here was 1 us of the row's chain)
