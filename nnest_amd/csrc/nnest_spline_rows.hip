@@ -630,9 +630,11 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
 #pragma unroll
                 for (int t = 0; t < NC; ++t) du[t] = splr_mv16((f32x4){bw.c0[t][0], bw.c0[t][1], bw.c0[t][2], bw.c0[t][3]}, d0, z4);   // inputs 16 t + 4 lk + r
                 if (ci > 0) bw.load(net_of(ci - 1), c ? nl : nu, o16, lk);
-                if (wv == 0 && o16 == 0) {
+                if (wv == NW - 1 && o16 == 0) {   // (the staging stores on another wave than the gradient row's update: both tails are on the way to the barrier)
                     float *Tr = T0 + ((size_t)ci * rc + row) * SPLR_TROW;
                     *reinterpret_cast<f32x4 *>(Tr + 48 + 4 * lk) = d0; *reinterpret_cast<f32x4 *>(Tr + 64 + 4 * lk) = d1; *reinterpret_cast<f32x4 *>(Tr + 80 + 4 * lk) = d2;
+                }
+                if (wv == 0 && o16 == 0) {
                     // (all reads of the update first: as four guarded read-modify-writes per tile they were eight dependent LDS round
                     // trips on the one wave the other three wait for)
                     float gv[NC][4];
