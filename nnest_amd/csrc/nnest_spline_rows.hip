@@ -360,6 +360,9 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     const bool vrow = (int)blockIdx.x >= a.M;
     const int row = vrow ? (int)blockIdx.x - a.M : (int)blockIdx.x;
     const int jl = lane < D ? lane : D - 1;
+    // the row vector and its gradient in LDS: the lower half (the first coupling's conditioning dims) at 0, the upper half at 32 -- both
+    // halves start on 16 bytes whatever x_dim (the trunk reads its input as whole 16-byte quarters); the slots past a half stay 0
+    const int xo = jl < nl ? jl : 32 + jl - nl;
     long src = row;
     if (!vrow && a.perm) src = a.perm[row];
     // the weights were written by the update kernel, i.e. into other XCDs' L2s: one dword per 128-byte line, all in flight at once,
@@ -387,7 +390,9 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
             }
             xv += nz * a.jitter;
         }
-        if (lane < D) xrow[lane] = xv;
+        xrow[lane] = 0.f; grow[lane] = 0.f;   // (64 slots; lane < 64 = this wave)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < D) xrow[xo] = xv;
     }
     // the first block's conv column, ActNorm vectors and the first coupling's weights ride behind the warm-up
     const int ci0 = wv * PM;
@@ -444,11 +449,11 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     for (int b = 0; b < B; ++b) {
         // ActNorm (networks.py:672-677) and the 1x1 conv z = x W (:649)
         {
-            const float xd = xrow[jl];
+            const float xd = xrow[xo];
             const float av = lane < D ? xd * spl_exp(an_s) + an_t : 0.f;
             if (wv == 0 && !vrow && lane < D) V0[((size_t)(3 * b + 0) * rc + row) * SPLR_VROW + lane] = av;
             const float c = matvec(wcol, av);
-            if (wv == 0 && lane < D) xrow[lane] = c;
+            if (wv == 0 && lane < D) xrow[xo] = c;
             if (b + 1 < B) {   // the next block's: two couplings to arrive
                 const float *pbn = a.w + (size_t)(b + 1) * s.blk_params;
                 load_col(a.wmat + (size_t)(b + 1) * D * D, wcol);
@@ -460,14 +465,13 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
 #pragma unroll 1
         for (int c = 0; c < 2; ++c) {
             const int ci = 2 * b + c;
-            const int nin = c ? nu : nl, nout = c ? nl : nu, idoff = c ? nl : 0, troff = c ? 0 : nl;
+            const int nin = c ? nu : nl, nout = c ? nl : nu, idoff = c ? 32 : 0, troff = c ? 0 : 32;
             // trunk (networks.py:393-409): Linear LReLU x3 on the matrix cores, every wave the same
             f32x4 ub[NC];
 #pragma unroll
             for (int t = 0; t < NC; ++t) {
                 const int i = 16 * t + 4 * lk;
-                ub[t] = (f32x4){i + 0 < nin ? xrow[idoff + i + 0] : 0.f, i + 1 < nin ? xrow[idoff + i + 1] : 0.f,
-                                i + 2 < nin ? xrow[idoff + i + 2] : 0.f, i + 3 < nin ? xrow[idoff + i + 3] : 0.f};
+                ub[t] = *reinterpret_cast<const f32x4 *>(xrow + idoff + i);   // (one 16-byte read; 0 past the half's dims)
             }
             const float uL = lane < nin ? xrow[idoff + lane] : 0.f;   // (for the staging only)
             R_STAMP(1)
@@ -547,7 +551,7 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
         }
         // one reduction: the lanes' log-derivatives, minus (wave 0) the base density's terms; the blocks' log-det constants were
         // requested in the prologue (written by the update kernel a launch ago: a cold load here was 1 us of the row's chain)
-        float t = ld - ((wv == 0 && lane < D) ? base_E(xrow[jl], s.base_beta) : 0.f);
+        float t = ld - ((wv == 0 && lane < D) ? base_E(xrow[xo], s.base_beta) : 0.f);
         t += splr_dpp<0x128>(t); t += splr_dpp<0x124>(t); t += splr_dpp<0x122>(t); t += splr_dpp<0x121>(t);   // the four rows of the wave
         t = (splr_rl(t, 0) + splr_rl(t, 16)) + (splr_rl(t, 32) + splr_rl(t, 48));
         if (lane == 0) red[wv] = t;
@@ -563,13 +567,13 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
 
     // ---- backward: loss = -mean(log_probs) (trainer.py:394) ------------------------------------------------------------------
     const float invM = 1.0f / (float)a.mtot, gld = -invM;
-    if (wv == 0 && lane < D) grow[lane] = base_dE(xrow[lane], s.base_beta) * invM;
+    if (wv == 0 && lane < D) grow[xo] = base_dE(xrow[xo], s.base_beta) * invM;
     splr_barrier();
     for (int b = B - 1; b >= 0; --b) {
 #pragma unroll 1
         for (int c = 1; c >= 0; --c) {
             const int ci = 2 * b + c;
-            const int nin = c ? nu : nl, nout = c ? nl : nu, idoff = c ? nl : 0, troff = c ? 0 : nl;
+            const int nout = c ? nl : nu, idoff = c ? 32 : 0, troff = c ? 0 : 32;
             const int nrows = SPL_P * nout;
             // evaluation, reverse
             {
@@ -637,17 +641,14 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
                 if (wv == 0 && o16 == 0) {
                     // (all reads of the update first: as four guarded read-modify-writes per tile they were eight dependent LDS round
                     // trips on the one wave the other three wait for)
-                    float gv[NC][4];
+                    f32x4 gv[NC];
 #pragma unroll
-                    for (int t = 0; t < NC; ++t)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { const int i = 16 * t + 4 * lk + e; gv[t][e] = grow[idoff + (i < nin ? i : 0)]; }
+                    for (int t = 0; t < NC; ++t) gv[t] = *reinterpret_cast<const f32x4 *>(grow + idoff + 16 * t + 4 * lk);
 #pragma unroll
                     for (int t = 0; t < NC; ++t) {
                         const int i = 16 * t + 4 * lk;
-                        const float dv[4] = {du[t].x, du[t].y, du[t].z, du[t].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (i + e < nin) grow[idoff + i + e] = gv[t][e] + dv[e];
+                        // (slots past the half's dims take the products of the next rows' weights: finite, never read)
+                        if (i < 32) *reinterpret_cast<f32x4 *>(grow + idoff + i) = gv[t] + du[t];
                     }
                 }
             }
@@ -656,11 +657,11 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
         }
         // 1x1 conv c = a W: g_a = g_c W^T (dLoss/dW = sum_rows a^T g_c: the update kernel's contraction); ActNorm a = x e^s + t
         {
-            const float gc = lane < D ? grow[jl] : 0.f;
+            const float gc = lane < D ? grow[xo] : 0.f;
             if (wv == 0 && lane < D) V0[((size_t)(3 * b + 1) * rc + row) * SPLR_VROW + lane] = gc;
             const float es = spl_exp(an_s);
             const float ga = matvec(wcol, gc);
-            if (wv == 0 && lane < D) grow[lane] = ga * es;   // (ActNorm's own gradients: from dLoss/dW in the update kernel)
+            if (wv == 0 && lane < D) grow[xo] = ga * es;   // (ActNorm's own gradients: from dLoss/dW in the update kernel)
             if (b > 0) {
                 load_col(a.wmatT + (size_t)(b - 1) * D * D, wcol);
                 an_s = a.w[(size_t)(b - 1) * s.blk_params + ts.p_s + jl];
