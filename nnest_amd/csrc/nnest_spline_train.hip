@@ -1620,6 +1620,17 @@ __global__ void __launch_bounds__(1024) spl_epoch_end_kernel(SplTrainCtl *__rest
                                                              const float *__restrict__ vpartial, int gw, int vtiles,
                                                              const float *__restrict__ w, float *__restrict__ best_w, int np) {
     __shared__ int flag[2];
+    __shared__ float vsum;
+    // (the validation rows' sum by the first wave, its loads in flight together: as a loop of thread 0 over up to 128 per-row values it
+    // was 2 us of every epoch; the order of the additions is fixed: lane, then the shuffle tree)
+    if (threadIdx.x < 64 && vpartial) {
+        float acc = 0.f;
+        for (int t = threadIdx.x; t < vtiles; t += 64) acc += vpartial[(size_t)t * gw + gw - 4];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+        if (threadIdx.x == 0) vsum = acc;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         flag[0] = c->stopped;
         flag[1] = 0;
@@ -1628,11 +1639,7 @@ __global__ void __launch_bounds__(1024) spl_epoch_end_kernel(SplTrainCtl *__rest
             for (int mb = 0; mb < n_mb; ++mb) tl += losses[mb];
             const float train_loss = tl / (float)n_train;            // trainer.py:403
             float vmean = losses[n_mb];
-            if (vpartial) {
-                float acc = 0.f;
-                for (int t = 0; t < vtiles; ++t) acc += vpartial[(size_t)t * gw + gw - 4];
-                vmean = acc * (-1.0f / (float)n_valid);
-            }
+            if (vpartial) vmean = vsum * (-1.0f / (float)n_valid);
             const float valid_loss = vmean / (float)n_valid;         // trainer.py:418
             epoch_losses[2 * epoch] = train_loss;
             epoch_losses[2 * epoch + 1] = valid_loss;
