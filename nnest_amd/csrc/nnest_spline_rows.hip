@@ -112,7 +112,7 @@ struct SplrKeep {
     float a_w, p_w, a_h, p_h;      // the two softmax stages of the width / height logits (spl_knots)
     float dd, left, width, chl;    // d(right knot derivative)/d(logit); this bin's left edge, width, bottom edge
     float ht, d0, d1, x;           // height, knot derivatives, the input
-    float cnt, use, pad0, pad1;    // selected bin (as a float), 1 if this lane IS the selected bin of an input inside the interval
+    float cnt, use, ribw, theta;   // selected bin (as a float), 1 if this lane IS the selected bin of an input inside the interval; 1 / width, (x - left) / width
 };
 
 // forward evaluation, lane k of an item: logits rw, rh (bins) and rd (right knot of bin k; unused for k = 7).  Returns y (all 8
@@ -171,7 +171,7 @@ __device__ __forceinline__ float splr_eval(float rw, float rh, float rd, float x
     kp.a_w = a_w; kp.p_w = p_w; kp.a_h = a_h; kp.p_h = p_h;
     kp.dd = dd; kp.left = left; kp.width = width; kp.chl = chl;
     kp.ht = ht; kp.d0 = d0; kp.d1 = d1; kp.x = x;
-    kp.cnt = cnt; kp.use = use ? 1.f : 0.f; kp.pad0 = 0.f; kp.pad1 = 0.f;
+    kp.cnt = cnt; kp.use = use ? 1.f : 0.f; kp.ribw = ribw; kp.theta = theta;
     return y;
 }
 
@@ -182,9 +182,8 @@ __device__ __forceinline__ float splr_eval_bwd(const SplrKeep &kp, float tail, i
     const bool inside = kp.x >= -tail && kp.x <= tail;
     const bool use = kp.use != 0.f;
     const float ih = kp.ht, d0 = kp.d0, d1 = kp.d1;
-    const float ribw = spl_rcp(kp.width);
+    const float ribw = kp.ribw, theta = kp.theta;
     const float delta = ih * ribw;
-    const float theta = (kp.x - kp.left) * ribw;
     const float tomt = theta * (1.f - theta);
     const float sdd = d0 + d1 - 2.f * delta;
     const float Nn = ih * (delta * theta * theta + d0 * tomt);
@@ -365,19 +364,8 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     const int xo = jl < nl ? jl : 32 + jl - nl;
     long src = row;
     if (!vrow && a.perm) src = a.perm[row];
-    // the weights were written by the update kernel, i.e. into other XCDs' L2s: one dword per 128-byte line, all in flight at once,
-    // brings what the pass reads into this XCD's L2 (spl_grad_kernel has the measurement)
-    float sink = 0.f;
-    {
-        const size_t nb_w = (size_t)s.num_params * sizeof(float), nb_m = (size_t)B * D * D * sizeof(float);
-        const int l_w = (int)((nb_w + 127) >> 7), l_m = (int)((nb_m + 127) >> 7);
-        for (int i = tid; i < l_w + 2 * l_m; i += NT) {
-            const char *p = i < l_w ? reinterpret_cast<const char *>(a.w) + ((size_t)i << 7)
-                                    : (i < l_w + l_m ? reinterpret_cast<const char *>(a.wmat) + ((size_t)(i - l_w) << 7)
-                                                     : reinterpret_cast<const char *>(a.wmatT) + ((size_t)(i - l_w - l_m) << 7));
-            asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
-        }
-    }
+    // (No warm-up of this XCD's L2 as the tile form has one: every weight is read once per workgroup, a coupling ahead of its use, and
+    // touching all 380 KB up front made the first barrier wait for all of it: 0.498 -> 0.483 ms per epoch without.)
     // data = X[perm] + jitter * randn (trainer.py:392); the noise of dim d is component d & 3 of quad d >> 2 (spl_grad_kernel's numbering)
     if (wv == 0) {
         float xv = (vrow ? a.xv : a.x)[(size_t)src * D + jl];
@@ -394,7 +382,7 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
         __builtin_amdgcn_wave_barrier();
         if (lane < D) xrow[xo] = xv;
     }
-    // the first block's conv column, ActNorm vectors and the first coupling's weights ride behind the warm-up
+    // the first block's conv column, ActNorm vectors and the first coupling's weights: requested here, used behind the first barrier
     const int ci0 = wv * PM;
     auto load_col = [&](const float *Mt, float (&wcol)[PM]) {
 #pragma unroll
@@ -412,7 +400,6 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
     for (int b = 0; b < B; ++b) ldc_sum += a.ldc[b];
     tw.load(a.w + ts.p_f[0], nl, o16, lk);
     lf.load(a.w + ts.p_f[0], nl, nu, wv, lane, item, k);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
     if (stop_flag) return;   // (uniform over the workgroup, in front of its first barrier)
     splr_barrier();
     float *const T0 = a.stg + a.lay.off_T, *const G0 = a.stg + a.lay.off_G, *const V0 = a.stg + a.lay.off_V;
@@ -533,7 +520,7 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
                 if (!vrow) {
                     f32x4 *kq = keep + ((size_t)ci * NT + tid) * 4;
                     kq[0] = (f32x4){kp.a_w, kp.p_w, kp.a_h, kp.p_h}; kq[1] = (f32x4){kp.dd, kp.left, kp.width, kp.chl};
-                    kq[2] = (f32x4){kp.ht, kp.d0, kp.d1, kp.x}; kq[3] = (f32x4){kp.cnt, kp.use, 0.f, 0.f};
+                    kq[2] = (f32x4){kp.ht, kp.d0, kp.d1, kp.x}; kq[3] = (f32x4){kp.cnt, kp.use, kp.ribw, kp.theta};
                 }
                 if (active && k == 0) xrow[troff + item] = y;
             }
@@ -582,7 +569,7 @@ __global__ void __launch_bounds__(64 * NW) splr_grad_kernel(SplRowsArgs a) {
                 const f32x4 k0 = kq[0], k1 = kq[1], k2 = kq[2], k3 = kq[3];
                 SplrKeep kp;
                 kp.a_w = k0.x; kp.p_w = k0.y; kp.a_h = k0.z; kp.p_h = k0.w; kp.dd = k1.x; kp.left = k1.y; kp.width = k1.z; kp.chl = k1.w;
-                kp.ht = k2.x; kp.d0 = k2.y; kp.d1 = k2.z; kp.x = k2.w; kp.cnt = k3.x; kp.use = k3.y; kp.pad0 = 0.f; kp.pad1 = 0.f;
+                kp.ht = k2.x; kp.d0 = k2.y; kp.d1 = k2.z; kp.x = k2.w; kp.cnt = k3.x; kp.use = k3.y; kp.ribw = k3.z; kp.theta = k3.w;
                 const float gy = grow[troff + (active ? item : 0)];
                 float g_rw, g_rh, g_rd;
                 const float gx = splr_eval_bwd(kp, s.tail, k, gy, gld, g_rw, g_rh, g_rd);
@@ -1142,6 +1129,7 @@ hipError_t spline_rows_grad(nnest_spline *h, const SplTrainShape &ts, const SplR
     a.w = h->w_dev; a.wmat = h->wmat; a.wmatT = r->wmatT; a.ldc = r->ldc; a.ts = ts;
     a.x = bt.x; a.perm = bt.perm; a.M = bt.M; a.mtot = bt.mtot; a.noise = bt.noise; a.seed = bt.seed; a.noise_row0 = bt.noise_row0;
     a.epoch = bt.epoch; a.jitter = bt.jitter; a.xv = bt.xv; a.Mv = bt.Mv; a.rowlp = r->rowlp; a.stg = r->stg; a.lay = r->lay; a.stop = bt.stop;
+
     const size_t ldsb = rows_grad_lds(h->s, r->lay);
     const int NW = rows_waves(h->s), grid = bt.M + bt.Mv;
     hipError_t e = hipSuccess;
