@@ -1,4 +1,5 @@
 // probe: per-launch cost of dependent small kernels in one stream, plain launches against a captured graph
+// build: hipcc --offload-arch=gfx950 -O2 -o tools/probe/launch_gap tools/probe/launch_gap.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <chrono>
