@@ -1615,6 +1615,7 @@ struct SplTrainCtl {
 // One workgroup: thread 0 keeps the books, then all threads copy the weights if the epoch improved the validation loss
 // (best_model = deepcopy(netG), trainer.py:205-209).  `vpartial` != NULL: the validation loss comes straight from the `vtiles`
 // per-tile sums of the forward-only tiles (their slots of the gradient workspace, stride `gw` floats) instead of losses[n_mb].
+enum { SPL_EPOCH_END_THREADS = 512 };
 __global__ void __launch_bounds__(1024) spl_epoch_end_kernel(SplTrainCtl *__restrict__ c, const float *__restrict__ losses, int n_mb, int n_train,
                                                              int n_valid, int epoch, int patience, float *__restrict__ epoch_losses,
                                                              const float *__restrict__ vpartial, int gw, int vtiles,
@@ -2093,7 +2094,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
                 if (ride) { bt.xv = xvalid_dev; bt.Mv = n_valid; }
                 SHIP_TRY(spline_rows_grad(h, ts, bt, st));
                 if (ride) {
-                    hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch - 1, patience,
+                    hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(SPL_EPOCH_END_THREADS), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch - 1, patience,
                                        h->epoch_losses_dev, spline_rows_rowlp(h) + M + 3, 1, n_valid, h->w_dev, h->best_w, np);
                     pending_validation = false;
                 }
@@ -2108,7 +2109,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
                 if (ride) { a.val_tiles = vtiles; a.xv = xvalid_dev; a.Mv = n_valid; }
                 SHIP_TRY(launch_grad(a, st));
                 if (ride) {
-                    hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch - 1, patience,
+                    hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(SPL_EPOCH_END_THREADS), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch - 1, patience,
                                        h->epoch_losses_dev, h->partial + (size_t)tiles * ts.gw_floats, ts.gw_floats, vtiles, h->w_dev, h->best_w, np);
                     pending_validation = false;
                 }
@@ -2143,7 +2144,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             memset(&bt, 0, sizeof(bt));
             bt.xv = xvalid_dev; bt.Mv = n_valid; bt.stop = stop;
             SHIP_TRY(spline_rows_grad(h, ts, bt, st));
-            hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch, patience,
+            hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(SPL_EPOCH_END_THREADS), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch, patience,
                                h->epoch_losses_dev, spline_rows_rowlp(h) + 3, 1, n_valid, h->w_dev, h->best_w, np);
             SHIP_TRY(hipGetLastError());
             if (epoch + 1 < max_epochs && epoch >= check_epoch && (rc = read_state(epoch))) return rc;
@@ -2154,7 +2155,7 @@ int nnest_spline_train(nnest_spline_t *h, const float *xtrain_dev, int n_train, 
             const SplGradArgs a = valid_args();
             SHIP_TRY(launch_grad(a, st));
         }
-        hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(1024), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch, patience,
+        hipLaunchKernelGGL(spl_epoch_end_kernel, dim3(1), dim3(SPL_EPOCH_END_THREADS), 0, st, ctl, h->losses_dev, n_mb, n_train, n_valid, epoch, patience,
                            h->epoch_losses_dev, h->partial, ts.gw_floats, vtiles, h->w_dev, h->best_w, np);
         SHIP_TRY(hipGetLastError());
         if (epoch + 1 < max_epochs && epoch >= check_epoch && (rc = read_state(epoch))) return rc;
