@@ -15,7 +15,7 @@ for tag in ('sq', 'sq2'):
         for r in csv.DictReader(open(f)):
             agg[r['Kernel_Name'][:48]][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, d in agg.items():
-            if 'spline_mh' in k or 'spl_grad' in k:
+            if 'spline_mh' in k or 'spl_grad' in k or 'splr_' in k or 'spl_update' in k:
                 print(tag, k, {c: round(sum(v) / len(v)) for c, v in d.items()}, 'n', len(next(iter(d.values()))))
 PY
 tail -3 "$OUT/sq2.log"
